@@ -1,0 +1,174 @@
+/*
+ * ldso_hip.h — C-ABI of libldso_hip.so: the MI355X (gfx950) implementation of LDSO's windowed
+ * photometric bundle-adjustment hot path and CoarseTracker image alignment.
+ *
+ * The reference has no FFI layer; its boundary is two C++ member functions:
+ *     float FullSystem::optimize(int mnumOptIts)                       src/frontend/FullSystem.cc:725
+ *     bool  CoarseTracker::trackNewestCoarse(fh, SE3&, AffLight&, int, Vec5)   src/frontend/CoarseTracker.cc:61
+ * Each entry point below names the reference function it replaces.  All functions are extern "C",
+ * take plain pointers and sizes (layouts: ldso_window.h), return 0 on success or a negative
+ * ldso_status code, never throw, and never free caller memory.  Handles are not thread-safe; distinct
+ * handles are independent (one BA handle on the mapping thread, tracker handles on the tracking
+ * thread, as FullSystem uses them).  Non-finite results are reported as LDSO_E_NONFINITE, the
+ * analogue of the reference's isLost path (FullSystem.cc:845-849).
+ */
+#ifndef LDSO_HIP_H_
+#define LDSO_HIP_H_
+
+#include "ldso_window.h"
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum ldso_status {
+    LDSO_OK = 0,
+    LDSO_E_INVALID = -1,      /* bad argument / window exceeds the handle's capacity            */
+    LDSO_E_HIP = -2,          /* a HIP runtime call failed (see ldso_last_error)                */
+    LDSO_E_NONFINITE = -3,    /* NaN/Inf in energies or the solve (reference: isLost = true)    */
+    LDSO_E_UNSUPPORTED = -4,  /* a setting_* mode this implementation does not provide          */
+    LDSO_E_NODEVICE = -5      /* no HIP device visible                                          */
+};
+
+int ldso_version(void);
+const char *ldso_last_error(void);
+int ldso_device_count(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Host-side helpers mirroring small reference functions that stay on the CPU.
+ * ---------------------------------------------------------------------------------------------- */
+/* FrameHessian::setEvalPT (FrameHessian.h:104-109) + setStateZero (FrameHessian.cc:12-42): fills
+ * worldToCam_evalPT, state, state_zero and the numeric nullspaces of *f. */
+int ldso_frame_set_evalPT(ldso_frame_t *f, const double worldToCam[12], const double state[10]);
+/* FrameHessian::getPrior (FrameHessian.h:129-154): writes f->prior from f->frameID and the settings. */
+int ldso_frame_set_prior(ldso_frame_t *f, const ldso_settings_t *s);
+/* Defaults of src/Setting.cc for every field of ldso_settings_t. */
+int ldso_settings_default(ldso_settings_t *s);
+/* setGlobalCalib's pyramid rule (GlobalCalib.cc:20-29). */
+int ldso_pyr_levels_used(int w, int h);
+
+/* ------------------------------------------------------------------------------------------------
+ * Windowed bundle adjustment (EnergyFunctional + the optimisation slice of FullSystem).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ldso_ba ldso_ba_t;
+
+/* Allocate device state for windows up to max_frames x max_points on HIP device `device`. */
+int ldso_ba_create(int device, int w, int h, int max_frames, int max_points, ldso_ba_t **out);
+int ldso_ba_destroy(ldso_ba_t *h);
+/* Run all launches on the caller's hipStream_t (e.g. torch's current stream); NULL = internal stream. */
+int ldso_ba_set_stream(ldso_ba_t *h, void *hip_stream);
+int ldso_ba_set_settings(ldso_ba_t *h, const ldso_settings_t *s);
+
+/* Upload FrameHessian::dIp[0] (w*h Vec3f AoS: I,dx,dy; FrameHessian.h:169-175) into image slot
+ * `slot` (0..max_frames-1).  Done once per new keyframe; slots are recycled on marginalisation. */
+int ldso_ba_set_image(ldso_ba_t *h, int slot, const float *dI_level0_host);
+/* Same, the pyramid level already being device-resident (zero-copy hand-over, not retained after the
+ * next ldso_ba_set_image* on that slot). */
+int ldso_ba_set_image_device(ldso_ba_t *h, int slot, const void *dI_level0_dev);
+
+/* Describe the window: EnergyFunctional::frames / allPoints / p->residuals after makeIDX
+ * (EnergyFunctional.cc:380-401).  image_slot[f] = slot holding frame f's image.  linJ / lin_res_toZeroF
+ * (R entries, may be NULL) are read where residuals[i].is_linearized != 0. */
+int ldso_ba_set_window(ldso_ba_t *h, int F, const int32_t *image_slot, int P, const ldso_point_t *points,
+                       int R, const ldso_residual_t *residuals, const ldso_rawjac_t *linJ, const float *lin_res_toZeroF);
+/* Frame / calibration state (FrameHessian::setState..., CalibHessian::setValue) and the
+ * marginalisation prior HM,bM ((8F+4)^2 row-major, (8F+4); NULL = zero).  Also performs
+ * EnergyFunctional::setAdjointsF (EnergyFunctional.cc:431-489) and FullSystem::setPrecalcValues
+ * (FullSystem.cc:1423-1431) on the device. */
+int ldso_ba_set_frames(ldso_ba_t *h, const ldso_frame_t *frames, const ldso_calib_t *calib);
+int ldso_ba_set_prior(ldso_ba_t *h, const double *HM, const double *bM);
+
+/* Multi-GPU: this rank owns points [begin,end) of the window (whole points only).
+ * reduce_buf_dev is a caller-allocated device buffer of ldso_ba_reduce_doubles() doubles that the
+ * caller all-reduces (sum) between ldso_ba_reduce_local() and ldso_ba_solve_reduced(). */
+int ldso_ba_set_shard(ldso_ba_t *h, int point_begin, int point_end);
+size_t ldso_ba_reduce_doubles(ldso_ba_t *h);
+
+/* --- the optimisation slice, one entry per reference function ------------------------------------ */
+/* FullSystem::optimize preamble (FullSystem.cc:735-755): activeResiduals = !isLinearized, resetOOB. */
+int ldso_ba_collect_active(ldso_ba_t *h);
+/* FullSystem::linearizeAll(fix) (FullSystem.cc:1442-1492) = PointFrameResidual::linearize on every
+ * active residual (Residuals.cc:13-214) + setNewFrameEnergyTH (:1762-1793); with fix != 0 also
+ * applyRes, maxRelBaseline/numGoodResiduals and removal flags.  energy_out = Vec3[0]. */
+int ldso_ba_linearize_all(ldso_ba_t *h, int fixLinearization, double *energy_out);
+/* FullSystem::applyRes_Reductor(true) (FullSystem.cc:1706-1709) -> PointFrameResidual::applyRes. */
+int ldso_ba_apply_res(ldso_ba_t *h);
+/* FullSystem::backupState (FullSystem.cc:1625-1673, non-momentum branch). */
+int ldso_ba_backup_state(ldso_ba_t *h);
+/* FullSystem::solveSystem (FullSystem.cc:1433-1440) -> EnergyFunctional::solveSystemF
+ * (EnergyFunctional.cc:240-351): accumulate A/L/SC, stitch, solve, orthogonalise, resubstitute. */
+int ldso_ba_solve_system(ldso_ba_t *h, int iteration, double lambda);
+/* FullSystem::doStepFromBackup(1,1,1,1,1) (FullSystem.cc:1546-1623) incl. setPrecalcValues. */
+int ldso_ba_do_step(ldso_ba_t *h, int *canbreak_out);
+/* FullSystem::loadSateBackup (FullSystem.cc:1675-1692). */
+int ldso_ba_load_state_backup(ldso_ba_t *h);
+/* FullSystem::optimize(mnumOptIts) (FullSystem.cc:725-864) with everything on the device and no host
+ * synchronisation inside the loop.  force_all_iterations != 0 ignores `canbreak` (BASELINE config C3).
+ * rmse_out = the function's return value; iterations_out = GN iterations executed. */
+int ldso_ba_optimize(ldso_ba_t *h, int mnumOptIts, int force_all_iterations, float *rmse_out, int *iterations_out);
+/* Asynchronous variant used by bench.py: enqueue `iters` Gauss-Newton iterations (solveSystem +
+ * doStepFromBackup + linearizeAll + applyRes) on the handle's stream and return immediately. */
+int ldso_ba_enqueue_gn(ldso_ba_t *h, int first_iteration, int iters);
+int ldso_ba_sync(ldso_ba_t *h);
+
+/* multi-GPU split of solveSystemF: local accumulate+stitch into the reduce buffer, then (after the
+ * caller's all-reduce) the replicated solve + step + precalc. */
+int ldso_ba_reduce_local(ldso_ba_t *h, void *reduce_buf_dev);
+int ldso_ba_solve_reduced(ldso_ba_t *h, const void *reduce_buf_dev, int iteration, double lambda, int do_step);
+
+/* --- results --------------------------------------------------------------------------------------- */
+/* Per-residual outputs in the caller's flat residual order (any pointer may be NULL). */
+int ldso_ba_get_residuals(ldso_ba_t *h, ldso_res_out_t *out, int32_t *state_state, int32_t *is_active, int32_t *to_remove);
+int ldso_ba_get_points(ldso_ba_t *h, ldso_point_out_t *out);
+int ldso_ba_get_frames(ldso_ba_t *h, ldso_frame_t *frames, double *step /*F*10*/, double *calib_value, double *calib_step,
+                       double *pre_worldToCam /*F*12*/);
+/* Stitched systems of the last solve, (8F+4)^2 / (8F+4) doubles, reference ordering [calib | frames]. */
+int ldso_ba_get_system(ldso_ba_t *h, double *HA, double *bA, double *HL, double *bL, double *Hsc, double *bsc,
+                       double *HFinal, double *bFinal, double *x);
+/* RawResidualJacobian of selected residuals (for fixLinearizationF callers): recomputed on demand at the
+ * current state, or - with ldso_ba_set_debug_dump(h,1) - the copy written by the last linearize pass. */
+int ldso_ba_set_debug_dump(ldso_ba_t *h, int enable);
+int ldso_ba_get_jacobians(ldso_ba_t *h, const int32_t *res_ids, int n, ldso_rawjac_t *out);
+/* Pair precalc [h*F+t][27] as FrameFramePrecalc: KRKi 9, Kt 3, R0 9, t0 3, aff 2, b0 1. */
+int ldso_ba_get_precalc(ldso_ba_t *h, float *out);
+int ldso_ba_get_counts(ldso_ba_t *h, int *resInA, int *resInL);
+/* energies of the linearizeAll calls inside the last ldso_ba_optimize (<= cap values), returns count */
+int ldso_ba_get_energy_log(ldso_ba_t *h, double *out, int cap);
+/* average device time (ms) per launch of kernel `which` since the last reset (HIP events on the
+ * handle's stream); which: 0 = linearize, 1 = reduce, 2 = solve, 3 = point step. */
+int ldso_ba_kernel_time_ms(ldso_ba_t *h, int which, double *avg_ms, int *launches);
+int ldso_ba_profile(ldso_ba_t *h, int enable);
+
+/* ------------------------------------------------------------------------------------------------
+ * CoarseTracker (src/frontend/CoarseTracker.cc).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ldso_tracker ldso_tracker_t;
+
+int ldso_tr_create(int device, int w, int h, int levels, ldso_tracker_t **out);
+int ldso_tr_destroy(ldso_tracker_t *t);
+int ldso_tr_set_stream(ldso_tracker_t *t, void *hip_stream);
+int ldso_tr_set_settings(ldso_tracker_t *t, const ldso_settings_t *s);
+/* CoarseTracker::makeK (CoarseTracker.cc:219-246). */
+int ldso_tr_make_k(ldso_tracker_t *t, const ldso_calib_t *calib);
+/* CoarseTracker::setCoarseTrackingRef (CoarseTracker.cc:248-256) + makeCoarseDepthL0 (:258-438).
+ * ref_dIp: `levels` host pointers to the reference keyframe pyramid; pts = n x (Ku,Kv,new_idepth,HdiF)
+ * of the active points whose lastResiduals[0] is IN, in the reference's iteration order. */
+int ldso_tr_set_ref(ldso_tracker_t *t, const float *const *ref_dIp, float ref_aff_a, float ref_aff_b, float ref_exposure,
+                    const float *pts, int n);
+/* the frame to be tracked (FrameHessian::dIp[0..levels-1]) */
+int ldso_tr_set_new_frame(ldso_tracker_t *t, const float *const *new_dIp, float exposure);
+/* CoarseTracker::calcRes (CoarseTracker.cc:440-572). rs_out = Vec6; returns buf_warped_n via n_warped. */
+int ldso_tr_calc_res(ldso_tracker_t *t, int lvl, const double T_ref2new[12], float aff_a, float aff_b, float cutoffTH,
+                     double rs_out[6], int *n_warped);
+/* CoarseTracker::calcGSSSE (CoarseTracker.cc:574-632) for the buffers of the last calcRes. */
+int ldso_tr_calc_gs(ldso_tracker_t *t, int lvl, const double T_ref2new[12], float aff_a, float aff_b, double H_out[64], double b_out[8]);
+/* CoarseTracker::trackNewestCoarse (CoarseTracker.cc:61-217): whole LM pyramid loop on the device. */
+int ldso_tr_track(ldso_tracker_t *t, double T_ref2new_inout[12], float aff_inout[2], int coarsestLvl, const double minResForAbort[5],
+                  double lastResiduals_out[5], double lastFlowIndicators_out[3], int *ok_out, int *iterations_out);
+int ldso_tr_get_pc(ldso_tracker_t *t, int lvl, float *u, float *v, float *idepth, float *color, int *n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LDSO_HIP_H_ */

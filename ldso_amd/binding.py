@@ -1,0 +1,235 @@
+"""ctypes binding of libldso_hip.so — the product path.  Every call goes through the C-ABI declared in
+include/ldso_hip.h; there is NO CPU fallback: if the HIP library is missing or no GPU is visible the
+constructors raise."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import synth
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class LdsoError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"ldso_hip error {code}: {msg}")
+        self.code = code
+
+
+def lib_path() -> str:
+    return os.path.join(_HERE, "libldso_hip.so")
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        p = lib_path()
+        if not os.path.exists(p):
+            raise RuntimeError(f"{p} is missing: build it with `python -m ldso_amd.build` (hipcc, gfx950). There is no CPU fallback.")
+        L = C.CDLL(p)
+        L.ldso_last_error.restype = C.c_char_p
+        L.ldso_ba_reduce_doubles.restype = C.c_size_t
+        _LIB = L
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _chk(code):
+    if code != 0:
+        raise LdsoError(code, lib().ldso_last_error().decode())
+
+
+def default_settings() -> np.ndarray:
+    s = np.zeros((), synth.SETTINGS_DTYPE)
+    _chk(lib().ldso_settings_default(_p(s)))
+    return s
+
+
+class BA:
+    """Windowed bundle adjustment handle (EnergyFunctional + FullSystem::optimize slice) on one GPU."""
+
+    def __init__(self, w, h, max_frames, max_points, device=0, stream=None):
+        self.L = lib()
+        self.h = C.c_void_p()
+        _chk(self.L.ldso_ba_create(C.c_int(device), C.c_int(w), C.c_int(h), C.c_int(max_frames), C.c_int(max_points), C.byref(self.h)))
+        self.w, self.hh = w, h
+        self.F = self.P = self.R = 0
+        if stream is not None:
+            self.set_stream(stream)
+
+    @classmethod
+    def from_window(cls, win: synth.Window, device=0, stream=None, max_frames=None, max_points=None):
+        ba = cls(win.w, win.h, max_frames or max(win.F, 2), max_points or win.P, device=device, stream=stream)
+        ba.load_window(win)
+        return ba
+
+    def close(self):
+        if self.h:
+            self.L.ldso_ba_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_ptr: int):
+        _chk(self.L.ldso_ba_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    def set_settings(self, s):
+        s = np.ascontiguousarray(s)
+        _chk(self.L.ldso_ba_set_settings(self.h, _p(s)))
+
+    def set_image(self, slot, dI0):
+        a = np.ascontiguousarray(dI0, np.float32)
+        _chk(self.L.ldso_ba_set_image(self.h, C.c_int(slot), _p(a)))
+
+    def set_window(self, image_slots, points, residuals, lin_J=None, lin_rtz=None):
+        sl = np.ascontiguousarray(image_slots, np.int32)
+        pts = np.ascontiguousarray(points)
+        res = np.ascontiguousarray(residuals)
+        J = np.ascontiguousarray(lin_J) if lin_J is not None else None
+        rt = np.ascontiguousarray(lin_rtz, np.float32) if lin_rtz is not None else None
+        self.F, self.P, self.R = len(sl), len(pts), len(res)
+        _chk(self.L.ldso_ba_set_window(self.h, C.c_int(self.F), _p(sl), C.c_int(self.P), _p(pts), C.c_int(self.R), _p(res), _p(J), _p(rt)))
+
+    def set_frames(self, frames, calib):
+        fr = np.ascontiguousarray(frames)
+        c = np.ascontiguousarray(calib)
+        _chk(self.L.ldso_ba_set_frames(self.h, _p(fr), _p(c)))
+
+    def set_prior(self, HM, bM):
+        HM = np.ascontiguousarray(HM, np.float64) if HM is not None else None
+        bM = np.ascontiguousarray(bM, np.float64) if bM is not None else None
+        _chk(self.L.ldso_ba_set_prior(self.h, _p(HM), _p(bM)))
+
+    def load_window(self, win: synth.Window):
+        self.set_settings(win.settings)
+        for f in range(win.F):
+            self.set_image(f, win.images[f][0])
+        self.set_window(np.arange(win.F), win.points, win.residuals, win.lin_J, win.lin_res_toZeroF)
+        self.set_frames(win.frames, win.calib)
+        if np.any(win.HM) or np.any(win.bM):
+            self.set_prior(win.HM, win.bM)
+
+    def set_shard(self, begin, end):
+        _chk(self.L.ldso_ba_set_shard(self.h, C.c_int(begin), C.c_int(end)))
+
+    def reduce_doubles(self) -> int:
+        return int(self.L.ldso_ba_reduce_doubles(self.h))
+
+    # --- optimisation slice --------------------------------------------------------------------------
+    def collect_active(self):
+        _chk(self.L.ldso_ba_collect_active(self.h))
+
+    def linearize_all(self, fix=False) -> float:
+        e = C.c_double()
+        _chk(self.L.ldso_ba_linearize_all(self.h, C.c_int(1 if fix else 0), C.byref(e)))
+        return e.value
+
+    def apply_res(self):
+        _chk(self.L.ldso_ba_apply_res(self.h))
+
+    def backup_state(self):
+        _chk(self.L.ldso_ba_backup_state(self.h))
+
+    def solve_system(self, iteration, lam=1e-1):
+        _chk(self.L.ldso_ba_solve_system(self.h, C.c_int(iteration), C.c_double(lam)))
+
+    def do_step(self) -> bool:
+        cb = C.c_int()
+        _chk(self.L.ldso_ba_do_step(self.h, C.byref(cb)))
+        return bool(cb.value)
+
+    def load_state_backup(self):
+        _chk(self.L.ldso_ba_load_state_backup(self.h))
+
+    def optimize(self, niters, force_all=False):
+        rm = C.c_float()
+        it = C.c_int()
+        _chk(self.L.ldso_ba_optimize(self.h, C.c_int(niters), C.c_int(1 if force_all else 0), C.byref(rm), C.byref(it)))
+        return rm.value, it.value
+
+    def enqueue_gn(self, first_iteration, iters):
+        _chk(self.L.ldso_ba_enqueue_gn(self.h, C.c_int(first_iteration), C.c_int(iters)))
+
+    def sync(self):
+        _chk(self.L.ldso_ba_sync(self.h))
+
+    def reduce_local(self, buf_ptr: int):
+        _chk(self.L.ldso_ba_reduce_local(self.h, C.c_void_p(buf_ptr)))
+
+    def solve_reduced(self, buf_ptr: int, iteration, lam=1e-1, do_step=True):
+        _chk(self.L.ldso_ba_solve_reduced(self.h, C.c_void_p(buf_ptr), C.c_int(iteration), C.c_double(lam), C.c_int(1 if do_step else 0)))
+
+    # --- results ----------------------------------------------------------------------------------------
+    def get_residuals(self):
+        out = np.zeros(self.R, synth.RES_OUT_DTYPE)
+        st = np.zeros(self.R, np.int32)
+        act = np.zeros(self.R, np.int32)
+        rem = np.zeros(self.R, np.int32)
+        _chk(self.L.ldso_ba_get_residuals(self.h, _p(out), _p(st), _p(act), _p(rem)))
+        return dict(out=out, state_state=st, is_active=act, to_remove=rem)
+
+    def get_points(self):
+        out = np.zeros(self.P, synth.POINT_OUT_DTYPE)
+        _chk(self.L.ldso_ba_get_points(self.h, _p(out)))
+        return out
+
+    def get_frames(self):
+        fr = np.zeros(self.F, synth.FRAME_DTYPE)
+        step = np.zeros((self.F, 10))
+        cv, cs = np.zeros(4), np.zeros(4)
+        pre = np.zeros((self.F, 12))
+        _chk(self.L.ldso_ba_get_frames(self.h, _p(fr), _p(step), _p(cv), _p(cs), _p(pre)))
+        return dict(frames=fr, step=step, calib_value=cv, calib_step=cs, pre_worldToCam=pre)
+
+    def get_system(self):
+        n = 8 * self.F + 4
+        d = {k: np.zeros((n, n)) for k in ("HA", "HL", "Hsc", "HFinal")}
+        d.update({k: np.zeros(n) for k in ("bA", "bL", "bsc", "bFinal", "x")})
+        _chk(self.L.ldso_ba_get_system(self.h, _p(d["HA"]), _p(d["bA"]), _p(d["HL"]), _p(d["bL"]), _p(d["Hsc"]), _p(d["bsc"]),
+                                       _p(d["HFinal"]), _p(d["bFinal"]), _p(d["x"])))
+        return d
+
+    def get_jacobians(self, ids=None):
+        ids = np.arange(self.R, dtype=np.int32) if ids is None else np.ascontiguousarray(ids, np.int32)
+        out = np.zeros(len(ids), synth.RAWJAC_DTYPE)
+        _chk(self.L.ldso_ba_get_jacobians(self.h, _p(ids), C.c_int(len(ids)), _p(out)))
+        return out
+
+    def set_debug_dump(self, enable=True):
+        _chk(self.L.ldso_ba_set_debug_dump(self.h, C.c_int(1 if enable else 0)))
+
+    def get_precalc(self):
+        out = np.zeros((self.F, self.F, 27), np.float32)
+        _chk(self.L.ldso_ba_get_precalc(self.h, _p(out)))
+        return out
+
+    def get_counts(self):
+        a, l = C.c_int(), C.c_int()
+        _chk(self.L.ldso_ba_get_counts(self.h, C.byref(a), C.byref(l)))
+        return a.value, l.value
+
+    def get_energy_log(self):
+        buf = np.zeros(64)
+        n = self.L.ldso_ba_get_energy_log(self.h, _p(buf), C.c_int(64))
+        self._dbg = buf[40:56].copy()
+        return buf[:n].copy()
+
+    def profile(self, enable=True):
+        _chk(self.L.ldso_ba_profile(self.h, C.c_int(1 if enable else 0)))
+
+    def kernel_time_ms(self, which):
+        ms = C.c_double()
+        n = C.c_int()
+        _chk(self.L.ldso_ba_kernel_time_ms(self.h, C.c_int(which), C.byref(ms), C.byref(n)))
+        return ms.value, n.value

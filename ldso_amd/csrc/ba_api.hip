@@ -1,0 +1,782 @@
+// ba_api.hip — C-ABI (include/ldso_hip.h) of the windowed bundle adjustment: device memory, the
+// flattening of the window into slot tables / chunks, kernel sequencing, fetchers.
+#include <hip/hip_runtime.h>
+#include <vector>
+#include <string>
+#include <cstring>
+#include <cstdio>
+#include <cmath>
+#include <algorithm>
+#include "../../include/ldso_hip.h"
+#include "ba_dev.h"
+#include "ba_solve.h"
+#include "lie_dev.h"
+
+hipError_t ba_launch_linearize(const BaPtrs &B, const BaDims &D, const ResSet &cur, const ResSet &nxt, const ldso_settings_t &S, bool hasL, bool fix, hipStream_t st);
+hipError_t ba_launch_reduce(const BaPtrs &B, const BaDims &D, const ResSet &S, const int32_t *chunkStart, bool hasL, int GSP, hipStream_t st);
+hipError_t ba_launch_gather(const BaPtrs &B, const BaDims &D, const ResSet &S, bool hasL, bool hasPrior, int GSP, double lambda,
+                            const ldso_settings_t &St, int mode, double *rbuf, hipStream_t st);
+hipError_t ba_launch_solve(const BaPtrs &B, const BaDims &D, const ResSet &S, const ldso_settings_t &St, const SolveArgs &A, hipStream_t st);
+hipError_t ba_launch_point_step(const BaPtrs &B, const BaDims &D, const ResSet &S, int mode, hipStream_t st);
+
+static thread_local std::string g_err;
+void ldso_set_error(const std::string &s) { g_err = s; }
+
+#define CHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { ldso_set_error(std::string(#call) + ": " + hipGetErrorString(e_)); return LDSO_E_HIP; } } while (0)
+#define REQ(cond, msg) do { if (!(cond)) { ldso_set_error(msg); return LDSO_E_INVALID; } } while (0)
+
+struct Timer { hipEvent_t a, b; int which; };
+
+struct ldso_ba {
+    int device = 0, w = 0, h = 0, maxF = 0, maxP = 0, FSmax = 0, maxChunks = 0;
+    hipStream_t stream = nullptr;
+    bool ownStream = false;
+    ldso_settings_t settings;
+    BaDims D;
+    BaPtrs B;
+    ResSet sets[2];
+    int cur = 0;
+    bool pendingApply = false;
+    bool hasL = false;
+    bool hasPrior = false;
+    int GSP = 0;
+    int R = 0;
+    float *imgSlots[LD_MAXF] = {nullptr};
+    bool imgOwned[LD_MAXF] = {false};
+    int32_t *d_chunkStart = nullptr;
+    ldso_rawjac_t *d_dumpJ = nullptr;
+    std::vector<int32_t> flat2slot;
+    std::vector<int32_t> imageSlot;
+    std::vector<void *> allocs;
+    // host staging of the window (for shard rebuilds)
+    std::vector<int32_t> h_phost;
+    // profiling
+    bool profile = false;
+    std::vector<Timer> timers;
+    double tsum[4] = {0, 0, 0, 0};
+    int tcnt[4] = {0, 0, 0, 0};
+    int lastIterations = 0;
+};
+
+extern "C" {
+
+int ldso_version(void) { return 100; }
+const char *ldso_last_error(void) { return g_err.c_str(); }
+int ldso_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+
+int ldso_settings_default(ldso_settings_t *s) {
+    if (!s) return LDSO_E_INVALID;
+    memset(s, 0, sizeof(*s));
+    s->huberTH = 9; s->outlierTHSumComponent = 50 * 50; s->affineOptModeA = 1e12f; s->affineOptModeB = 1e8f;
+    s->frameEnergyTHN = 0.7f; s->frameEnergyTHFacMedian = 1.5f; s->frameEnergyTHConstWeight = 0.5f; s->overallEnergyTHWeight = 1;
+    s->initialCalibHessian = 5e9f; s->margWeightFac = 0.5f * 0.5f; s->idepthFixPriorMargFac = 600 * 600; s->thOptIterations = 1.2f;
+    s->coarseCutoffTH = 20; s->minOptIterations = 1; s->solverMode = LDSO_SOLVER_FIX_LAMBDA | LDSO_SOLVER_ORTHOGONALIZE_X_LATER;
+    s->forceAcceptStep = 1; s->solverModeDelta = 0.00001;
+    return LDSO_OK;
+}
+
+int ldso_pyr_levels_used(int w, int h) {
+    int wl = w, hl = h, lv = 1;
+    while (wl % 2 == 0 && hl % 2 == 0 && wl * hl > 5000 && lv < LDSO_PYR_LEVELS) { wl /= 2; hl /= 2; lv++; }
+    return lv;
+}
+
+int ldso_frame_set_evalPT(ldso_frame_t *f, const double worldToCam[12], const double state[10]) {
+    if (!f || !worldToCam || !state) return LDSO_E_INVALID;
+    memcpy(f->worldToCam_evalPT, worldToCam, 12 * sizeof(double));
+    memcpy(f->state, state, 10 * sizeof(double));
+    memcpy(f->state_zero, state, 10 * sizeof(double));
+    ld::frame_nullspaces(f->worldToCam_evalPT, f->state_zero[6], f->ab_exposure, f->nullspaces_pose, f->nullspaces_scale, f->nullspaces_affine);
+    return LDSO_OK;
+}
+
+int ldso_frame_set_prior(ldso_frame_t *f, const ldso_settings_t *s) {
+    if (!f || !s) return LDSO_E_INVALID;
+    for (int i = 0; i < 8; i++) f->prior[i] = 0;
+    const double initialRotPrior = 1e11, initialTransPrior = 1e10, initialAffBPrior = 1e14, initialAffAPrior = 1e14;   // Setting.cc:18-21
+    if (f->frameID == 0) {
+        for (int i = 0; i < 3; i++) { f->prior[i] = initialTransPrior; f->prior[3 + i] = initialRotPrior; }
+        if (s->solverMode & LDSO_SOLVER_REMOVE_POSEPRIOR) for (int i = 0; i < 6; i++) f->prior[i] = 0;
+        f->prior[6] = initialAffAPrior; f->prior[7] = initialAffBPrior;
+    } else {
+        f->prior[6] = (s->affineOptModeA < 0) ? initialAffAPrior : (double) s->affineOptModeA;
+        f->prior[7] = (s->affineOptModeB < 0) ? initialAffBPrior : (double) s->affineOptModeB;
+    }
+    return LDSO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+}  // extern "C"
+template <class T> static int dalloc(ldso_ba *H, T **p, size_t n) {
+    void *q = nullptr;
+    CHK(hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T)));
+    CHK(hipMemset(q, 0, std::max<size_t>(n, 1) * sizeof(T)));
+    H->allocs.push_back(q);
+    *p = (T *) q;
+    return LDSO_OK;
+}
+#define DA(ptr, n) do { int r_ = dalloc(H, &(ptr), (n)); if (r_ != LDSO_OK) return r_; } while (0)
+template <class T> static int h2d(ldso_ba *H, T *dst, const std::vector<T> &src) {
+    if (src.empty()) return LDSO_OK;
+    CHK(hipMemcpyAsync(dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, H->stream));
+    return LDSO_OK;
+}
+template <class T> static int d2h(ldso_ba *H, std::vector<T> &dst, const T *src, size_t n) {
+    dst.resize(n);
+    if (n == 0) return LDSO_OK;
+    CHK(hipMemcpyAsync(dst.data(), src, n * sizeof(T), hipMemcpyDeviceToHost, H->stream));
+    return LDSO_OK;
+}
+extern "C" {
+
+static int alloc_set(ldso_ba *H, ResSet &S) {
+    const size_t P = H->maxP, FS = H->FSmax, PS = P * FS, C = H->maxChunks;
+    DA(S.state, PS); DA(S.active, PS); DA(S.energy, PS); DA(S.JpJdF, PS * 8); DA(S.newEnergyWO, PS); DA(S.center, PS * 3); DA(S.toRemove, PS);
+    DA(S.HdiF, P); DA(S.bdSumF, P); DA(S.idH, P); DA(S.HddA, P); DA(S.bdA, P); DA(S.HcdA, P * 4); DA(S.HddL, P); DA(S.bdL, P); DA(S.HcdL, P * 4);
+    DA(S.maxRelBS, P); DA(S.numGood, P); DA(S.nActive, P); DA(S.candE, P);
+    DA(S.G, P * (8 * FS + LD_GEXTRA)); DA(S.topA, C * FS * LD_TOPN); DA(S.topL, C * FS * LD_TOPN);
+    DA(S.chunkEnergy, C); DA(S.chunkCnt, C * 2); DA(S.chunkNID, C * 2);
+    return LDSO_OK;
+}
+
+int ldso_ba_create(int device, int w, int h, int max_frames, int max_points, ldso_ba_t **out) {
+    REQ(out && w > 8 && h > 8 && max_frames >= 2 && max_frames <= LD_MAXF && max_points > 0, "ldso_ba_create: bad arguments");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { ldso_set_error("no HIP device visible"); return LDSO_E_NODEVICE; }
+    REQ(device >= 0 && device < ndev, "ldso_ba_create: device index out of range");
+    CHK(hipSetDevice(device));
+    ldso_ba *H = new ldso_ba();
+    H->device = device; H->w = w; H->h = h; H->maxF = max_frames; H->maxP = max_points;
+    H->FSmax = (max_frames + 7) / 8 * 8;
+    H->maxChunks = max_points / 4 + max_frames + 4;
+    ldso_settings_default(&H->settings);
+    CHK(hipStreamCreateWithFlags(&H->stream, hipStreamNonBlocking));
+    H->ownStream = true;
+    memset(&H->B, 0, sizeof(H->B));
+    memset(&H->D, 0, sizeof(H->D));
+    BaPtrs &B = H->B;
+    const size_t F = max_frames, P = max_points, FS = H->FSmax, nmax = 8 * F + 4;
+    DA(B.frames, F); DA(B.calib, 1); DA(B.pairs, F * F);
+    DA(B.adHost, F * F * 64); DA(B.adTarget, F * F * 64); DA(B.adHostF, F * F * 64); DA(B.adTargetF, F * F * 64);
+    DA(B.nsProj, nmax * 7); DA(B.HM, nmax * nmax); DA(B.bM, nmax);
+    DA(B.pu, P); DA(B.pv, P); DA(B.pidepth, P); DA(B.pidepth_zero, P); DA(B.pidepth_backup, P); DA(B.pstep, P); DA(B.ppriorF, P);
+    DA(B.pcolor, P * 8); DA(B.pweights, P * 8); DA(B.phost, P);
+    DA(B.rflat, P * FS); DA(B.rlin, P * FS); DA(B.rnew, P * FS); DA(B.rlidx, P * FS);
+    DA(B.Jlin, P * FS); DA(B.rtz, P * FS * 8);
+    DA(B.chunk_p0, H->maxChunks); DA(B.chunk_n, H->maxChunks); DA(B.chunk_host, H->maxChunks);
+    DA(H->d_chunkStart, F + 2);
+    DA(B.pairC, 2 * F * F * LD_PAIRC);
+    const size_t GSPmax = (8 * FS + LD_GEXTRA + 15) / 16 * 16;
+    DA(B.scPart, (size_t) LD_SC_SPLITS * GSPmax * GSPmax);
+    DA(B.sys, 4 * (nmax * nmax + nmax));
+    DA(B.x, nmax); DA(B.xAd, F * F * 8); DA(B.xc, 4); DA(B.scalars, 16); DA(B.energyLog, 64);
+    DA(H->d_dumpJ, P * FS);
+    B.dumpJ = nullptr;
+    int r;
+    if ((r = alloc_set(H, H->sets[0])) != LDSO_OK) return r;
+    if ((r = alloc_set(H, H->sets[1])) != LDSO_OK) return r;
+    *out = H;
+    return LDSO_OK;
+}
+
+int ldso_ba_destroy(ldso_ba_t *H) {
+    if (!H) return LDSO_OK;
+    hipSetDevice(H->device);
+    hipDeviceSynchronize();
+    for (void *p : H->allocs) hipFree(p);
+    for (int i = 0; i < LD_MAXF; i++) if (H->imgOwned[i] && H->imgSlots[i]) hipFree(H->imgSlots[i]);
+    for (auto &t : H->timers) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
+    if (H->ownStream && H->stream) hipStreamDestroy(H->stream);
+    delete H;
+    return LDSO_OK;
+}
+
+int ldso_ba_set_stream(ldso_ba_t *H, void *s) {
+    REQ(H, "null handle");
+    CHK(hipSetDevice(H->device));
+    if (H->ownStream && H->stream) { hipStreamSynchronize(H->stream); if (s) { hipStreamDestroy(H->stream); H->ownStream = false; } }
+    if (s) { H->stream = (hipStream_t) s; H->ownStream = false; }
+    else if (!H->ownStream) { CHK(hipStreamCreateWithFlags(&H->stream, hipStreamNonBlocking)); H->ownStream = true; }
+    return LDSO_OK;
+}
+
+int ldso_ba_set_settings(ldso_ba_t *H, const ldso_settings_t *s) {
+    REQ(H && s, "null argument");
+    if (s->solverMode & (LDSO_SOLVER_SVD | LDSO_SOLVER_ORTHOGONALIZE_SYSTEM | LDSO_SOLVER_ORTHOGONALIZE_POINTMARG | LDSO_SOLVER_ORTHOGONALIZE_FULL |
+                         LDSO_SOLVER_MOMENTUM | LDSO_SOLVER_STEPMOMENTUM)) {
+        ldso_set_error("solverMode bits SVD/ORTHOGONALIZE_SYSTEM/_POINTMARG/_FULL/MOMENTUM/STEPMOMENTUM are not provided by the device path");
+        return LDSO_E_UNSUPPORTED;
+    }
+    H->settings = *s;
+    return LDSO_OK;
+}
+
+int ldso_ba_set_image(ldso_ba_t *H, int slot, const float *src) {
+    REQ(H && src && slot >= 0 && slot < H->maxF, "ldso_ba_set_image: bad arguments");
+    CHK(hipSetDevice(H->device));
+    size_t bytes = (size_t) H->w * H->h * 3 * sizeof(float);
+    if (!H->imgOwned[slot]) { void *p; CHK(hipMalloc(&p, bytes)); H->imgSlots[slot] = (float *) p; H->imgOwned[slot] = true; }
+    CHK(hipMemcpyAsync(H->imgSlots[slot], src, bytes, hipMemcpyHostToDevice, H->stream));
+    CHK(hipStreamSynchronize(H->stream));
+    return LDSO_OK;
+}
+
+int ldso_ba_set_image_device(ldso_ba_t *H, int slot, const void *dev) {
+    REQ(H && dev && slot >= 0 && slot < H->maxF, "ldso_ba_set_image_device: bad arguments");
+    if (H->imgOwned[slot] && H->imgSlots[slot]) { hipFree(H->imgSlots[slot]); H->imgOwned[slot] = false; }
+    H->imgSlots[slot] = (float *) dev;
+    return LDSO_OK;
+}
+
+#define H2D(dst, vec) do { int r_ = h2d(H, (dst), (vec)); if (r_ != LDSO_OK) return r_; } while (0)
+
+static int build_chunks(ldso_ba *H) {
+    // host-major chunks over the local shard [pBegin,pEnd)
+    BaDims &D = H->D;
+    const int Pn = D.pEnd - D.pBegin;
+    int CH = std::max(4, (Pn + 511) / 512);
+    CH = (CH + 3) / 4 * 4;
+    std::vector<int32_t> p0, cn, ch, cs(D.F + 1, 0);
+    int p = D.pBegin;
+    for (int hst = 0; hst < D.F; hst++) {
+        cs[hst] = (int) p0.size();
+        while (p < D.pEnd && H->h_phost[p] == hst) {
+            int e = p;
+            while (e < D.pEnd && H->h_phost[e] == hst && e - p < CH) e++;
+            p0.push_back(p); cn.push_back(e - p); ch.push_back(hst);
+            p = e;
+        }
+    }
+    cs[D.F] = (int) p0.size();
+    REQ(p == D.pEnd, "ldso_ba_set_window: points must be ordered by host frame (EnergyFunctional::allPoints order)");
+    REQ((int) p0.size() <= H->maxChunks, "too many chunks");
+    D.nChunks = (int) p0.size();
+    H2D(H->B.chunk_p0, p0); H2D(H->B.chunk_n, cn); H2D(H->B.chunk_host, ch); H2D(H->d_chunkStart, cs);
+    CHK(hipStreamSynchronize(H->stream));
+    return LDSO_OK;
+}
+
+int ldso_ba_set_window(ldso_ba_t *H, int F, const int32_t *image_slot, int P, const ldso_point_t *pts, int R, const ldso_residual_t *res,
+                       const ldso_rawjac_t *linJ, const float *lin_rtz) {
+    REQ(H && image_slot && pts && res, "ldso_ba_set_window: null argument");
+    REQ(F >= 2 && F <= H->maxF && P >= 1 && P <= H->maxP && R >= 0, "ldso_ba_set_window: window exceeds the handle's capacity");
+    CHK(hipSetDevice(H->device));
+    BaDims &D = H->D;
+    BaPtrs &B = H->B;
+    D.F = F; D.FS = (F + 7) / 8 * 8; D.P = P; D.R = R; D.n = 8 * F + 4; D.GS = 8 * D.FS + LD_GEXTRA; D.w = H->w; D.h = H->h; D.nsg = D.FS / 8;
+    D.pBegin = 0; D.pEnd = P; D.wM3G = (float) (H->w - 3); D.hM3G = (float) (H->h - 3);
+    H->GSP = (D.GS + 15) / 16 * 16;
+    H->R = R;
+    H->imageSlot.assign(image_slot, image_slot + F);
+    for (int f = 0; f < F; f++) {
+        REQ(image_slot[f] >= 0 && image_slot[f] < H->maxF && H->imgSlots[image_slot[f]] != nullptr, "ldso_ba_set_window: image slot not set");
+        B.img[f] = H->imgSlots[image_slot[f]];
+    }
+    const int FS = D.FS;
+    std::vector<float> pu(P), pv(P), pid(P), pidz(P), ppr(P), pcol((size_t) P * 8), pwt((size_t) P * 8);
+    H->h_phost.resize(P);
+    for (int i = 0; i < P; i++) {
+        pu[i] = pts[i].u; pv[i] = pts[i].v; pid[i] = pts[i].idepth; pidz[i] = pts[i].idepth_zero; ppr[i] = pts[i].priorF;
+        REQ(pts[i].host >= 0 && pts[i].host < F, "ldso_ba_set_window: point host out of range");
+        H->h_phost[i] = pts[i].host;
+        memcpy(&pcol[(size_t) i * 8], pts[i].color, 32); memcpy(&pwt[(size_t) i * 8], pts[i].weights, 32);
+    }
+    const size_t PS = (size_t) P * FS;
+    std::vector<int32_t> rflat(PS, -1), rlin(PS, 0), rnew(PS, 0), rlidx(PS, -1), st(PS, LDSO_RES_OOB), act(PS, 0);
+    std::vector<float> en(PS, 0.f), jp(PS * 8, 0.f);
+    std::vector<ldso_rawjac_t> Jl;
+    std::vector<float> rtz;
+    H->flat2slot.assign(R, -1);
+    for (int i = 0; i < R; i++) {
+        const ldso_residual_t &r = res[i];
+        REQ(r.point >= 0 && r.point < P && r.target >= 0 && r.target < F && r.host == pts[r.point].host && r.target != r.host, "ldso_ba_set_window: bad residual indices");
+        size_t slot = (size_t) r.point * FS + r.target;
+        REQ(rflat[slot] < 0, "ldso_ba_set_window: two residuals of one point target the same frame");
+        rflat[slot] = i; rlin[slot] = r.is_linearized ? 1 : 0; rnew[slot] = r.is_new ? 1 : 0;
+        st[slot] = r.state_state; act[slot] = r.is_active ? 1 : 0; en[slot] = r.state_energy;
+        H->flat2slot[i] = (int32_t) slot;
+        if (r.is_linearized) {
+            REQ(linJ && lin_rtz, "ldso_ba_set_window: linearised residual without linJ / lin_res_toZeroF");
+            rlidx[slot] = (int32_t) Jl.size();
+            Jl.push_back(linJ[i]);
+            for (int k = 0; k < 8; k++) rtz.push_back(lin_rtz[(size_t) i * 8 + k]);
+            // takeData (Residuals.h:123-128)
+            const ldso_rawjac_t &J = linJ[i];
+            float v0 = J.JIdx2[0] * J.Jpdd[0] + J.JIdx2[1] * J.Jpdd[1], v1 = J.JIdx2[2] * J.Jpdd[0] + J.JIdx2[3] * J.Jpdd[1];
+            for (int k = 0; k < 6; k++) jp[slot * 8 + k] = J.Jpdxi[0][k] * v0 + J.Jpdxi[1][k] * v1;
+            jp[slot * 8 + 6] = J.JabJIdx[0] * J.Jpdd[0] + J.JabJIdx[1] * J.Jpdd[1];
+            jp[slot * 8 + 7] = J.JabJIdx[2] * J.Jpdd[0] + J.JabJIdx[3] * J.Jpdd[1];
+        }
+    }
+    D.nL = (int) Jl.size();
+    H->hasL = D.nL > 0;
+    H2D(B.pu, pu); H2D(B.pv, pv); H2D(B.pidepth, pid); H2D(B.pidepth_zero, pidz); H2D(B.pidepth_backup, pid); H2D(B.ppriorF, ppr);
+    H2D(B.pcolor, pcol); H2D(B.pweights, pwt); H2D(B.phost, H->h_phost);
+    H2D(B.rflat, rflat); H2D(B.rlin, rlin); H2D(B.rnew, rnew); H2D(B.rlidx, rlidx);
+    H2D(B.Jlin, Jl); H2D(B.rtz, rtz);
+    H->cur = 0; H->pendingApply = false;
+    for (int s = 0; s < 2; s++) {
+        ResSet &S = H->sets[s];
+        H2D(S.state, st); H2D(S.active, act); H2D(S.energy, en); H2D(S.JpJdF, jp);
+        CHK(hipMemsetAsync(S.newEnergyWO, 0, PS * 4, H->stream));
+        CHK(hipMemsetAsync(S.center, 0, PS * 12, H->stream));
+        CHK(hipMemsetAsync(S.toRemove, 0, PS * 4, H->stream));
+        CHK(hipMemsetAsync(S.maxRelBS, 0, (size_t) P * 4, H->stream));
+        CHK(hipMemsetAsync(S.numGood, 0, (size_t) P * 4, H->stream));
+        CHK(hipMemsetAsync(S.nActive, 0, (size_t) P * 4, H->stream));
+        CHK(hipMemsetAsync(S.G, 0, (size_t) P * D.GS * 4, H->stream));
+    }
+    CHK(hipMemsetAsync(B.pstep, 0, (size_t) P * 4, H->stream));
+    CHK(hipMemsetAsync(B.scalars, 0, 16 * 8, H->stream));
+    CHK(hipMemsetAsync(B.scPart, 0, (size_t) LD_SC_SPLITS * H->GSP * H->GSP * 4, H->stream));
+    CHK(hipStreamSynchronize(H->stream));
+    return build_chunks(H);
+}
+
+int ldso_ba_set_shard(ldso_ba_t *H, int pb, int pe) {
+    REQ(H && pb >= 0 && pe >= pb && pe <= H->D.P, "ldso_ba_set_shard: bad range");
+    H->D.pBegin = pb; H->D.pEnd = pe;
+    return build_chunks(H);
+}
+
+size_t ldso_ba_reduce_doubles(ldso_ba_t *H) {
+    if (!H) return 0;
+    size_t n = H->D.n;
+    return 3 * (n * n + n) + 8 + (size_t) H->D.P;
+}
+
+static int launch_solve(ldso_ba *H, const ResSet &S, unsigned flags, int iteration = 0, double lambda = 0, int logIdx = -1, double *rout = nullptr, const double *rin = nullptr);
+
+int ldso_ba_set_frames(ldso_ba_t *H, const ldso_frame_t *fr, const ldso_calib_t *calib) {
+    REQ(H && fr && calib && H->D.F > 0, "ldso_ba_set_frames: set the window first");
+    CHK(hipSetDevice(H->device));
+    const int F = H->D.F;
+    std::vector<DevFrame> df(F);
+    for (int f = 0; f < F; f++) {
+        DevFrame &d = df[f];
+        memset(&d, 0, sizeof(d));
+        memcpy(d.evalPT, fr[f].worldToCam_evalPT, sizeof(d.evalPT));
+        memcpy(d.state, fr[f].state, sizeof(d.state)); memcpy(d.state_zero, fr[f].state_zero, sizeof(d.state_zero));
+        memcpy(d.state_backup, fr[f].state, sizeof(d.state));
+        memcpy(d.prior, fr[f].prior, sizeof(d.prior));
+        memcpy(d.ns_pose, fr[f].nullspaces_pose, sizeof(d.ns_pose)); memcpy(d.ns_scale, fr[f].nullspaces_scale, sizeof(d.ns_scale));
+        memcpy(d.ns_affine, fr[f].nullspaces_affine, sizeof(d.ns_affine));
+        d.ab_exposure = fr[f].ab_exposure; d.frameEnergyTH = fr[f].frameEnergyTH; d.frameID = fr[f].frameID; d.imgSlot = H->imageSlot[f];
+    }
+    DevCalib dc;
+    memset(&dc, 0, sizeof(dc));
+    for (int i = 0; i < 4; i++) { dc.value[i] = calib->value[i]; dc.value_zero[i] = calib->value_zero[i]; dc.value_backup[i] = calib->value[i]; }
+    CHK(hipMemcpyAsync(H->B.frames, df.data(), F * sizeof(DevFrame), hipMemcpyHostToDevice, H->stream));
+    CHK(hipMemcpyAsync(H->B.calib, &dc, sizeof(dc), hipMemcpyHostToDevice, H->stream));
+    size_t n = H->D.n;
+    CHK(hipMemsetAsync(H->B.HM, 0, n * n * 8, H->stream));
+    CHK(hipMemsetAsync(H->B.bM, 0, n * 8, H->stream));
+    H->hasPrior = false;
+    CHK(hipStreamSynchronize(H->stream));
+    // first precalc needs valid calib floats for the adjoint-independent parts; adjoints, then precalc
+    return launch_solve(H, H->sets[H->cur], SK_ADJ | SK_PRECALC);
+}
+
+int ldso_ba_set_prior(ldso_ba_t *H, const double *HM, const double *bM) {
+    REQ(H && H->D.n > 0, "ldso_ba_set_prior: set the window first");
+    CHK(hipSetDevice(H->device));
+    size_t n = H->D.n;
+    H->hasPrior = (HM != nullptr) || (bM != nullptr);
+    if (HM) CHK(hipMemcpyAsync(H->B.HM, HM, n * n * 8, hipMemcpyHostToDevice, H->stream)); else CHK(hipMemsetAsync(H->B.HM, 0, n * n * 8, H->stream));
+    if (bM) CHK(hipMemcpyAsync(H->B.bM, bM, n * 8, hipMemcpyHostToDevice, H->stream)); else CHK(hipMemsetAsync(H->B.bM, 0, n * 8, H->stream));
+    CHK(hipStreamSynchronize(H->stream));
+    return LDSO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// launch helpers with optional HIP-event timing
+// ---------------------------------------------------------------------------------------------------------
+static void t_begin(ldso_ba *H, int which) {
+    if (!H->profile) return;
+    Timer t; t.which = which;
+    hipEventCreate(&t.a); hipEventCreate(&t.b);
+    hipEventRecord(t.a, H->stream);
+    H->timers.push_back(t);
+}
+static void t_end(ldso_ba *H) { if (H->profile) hipEventRecord(H->timers.back().b, H->stream); }
+
+static int launch_solve(ldso_ba *H, const ResSet &S, unsigned flags, int iteration, double lambda, int logIdx, double *rout, const double *rin) {
+    SolveArgs A;
+    A.flags = flags; A.iteration = iteration; A.lambda = lambda; A.hasL = H->hasL ? 1 : 0; A.hasPrior = H->hasPrior ? 1 : 0; A.GSP = H->GSP; A.logIdx = logIdx; A.reduceOut = rout; A.reduceIn = rin;
+    t_begin(H, 2);
+    CHK(ba_launch_solve(H->B, H->D, S, H->settings, A, H->stream));
+    t_end(H);
+    return LDSO_OK;
+}
+static int launch_linearize(ldso_ba *H, bool fix) {
+    t_begin(H, 0);
+    CHK(ba_launch_linearize(H->B, H->D, H->sets[H->cur], H->sets[H->cur ^ 1], H->settings, H->hasL, fix, H->stream));
+    t_end(H);
+    return LDSO_OK;
+}
+static int launch_reduce(ldso_ba *H, const ResSet &S) {
+    t_begin(H, 1);
+    CHK(ba_launch_reduce(H->B, H->D, S, H->d_chunkStart, H->hasL, H->GSP, H->stream));
+    t_end(H);
+    return LDSO_OK;
+}
+static int launch_gather(ldso_ba *H, const ResSet &S, double lambda, int mode, double *rbuf) {
+    t_begin(H, 1);
+    CHK(ba_launch_gather(H->B, H->D, S, H->hasL, H->hasPrior, H->GSP, lambda, H->settings, mode, rbuf, H->stream));
+    t_end(H);
+    return LDSO_OK;
+}
+static int launch_pstep(ldso_ba *H, const ResSet &S, int mode) {
+    t_begin(H, 3);
+    CHK(ba_launch_point_step(H->B, H->D, S, mode, H->stream));
+    t_end(H);
+    return LDSO_OK;
+}
+#define RUN(x) do { int r_ = (x); if (r_ != LDSO_OK) return r_; } while (0)
+
+static int read_scalars(ldso_ba *H, double *sc) {
+    CHK(hipMemcpyAsync(sc, H->B.scalars, 16 * sizeof(double), hipMemcpyDeviceToHost, H->stream));
+    CHK(hipStreamSynchronize(H->stream));
+    return LDSO_OK;
+}
+
+int ldso_ba_profile(ldso_ba_t *H, int enable) {
+    REQ(H, "null handle");
+    H->profile = enable != 0;
+    for (auto &t : H->timers) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
+    H->timers.clear();
+    for (int i = 0; i < 4; i++) { H->tsum[i] = 0; H->tcnt[i] = 0; }
+    return LDSO_OK;
+}
+
+int ldso_ba_kernel_time_ms(ldso_ba_t *H, int which, double *avg_ms, int *launches) {
+    REQ(H && which >= 0 && which < 4, "bad arguments");
+    CHK(hipStreamSynchronize(H->stream));
+    for (auto &t : H->timers) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) { H->tsum[t.which] += ms; H->tcnt[t.which]++; }
+        hipEventDestroy(t.a); hipEventDestroy(t.b);
+    }
+    H->timers.clear();
+    if (avg_ms) *avg_ms = H->tcnt[which] ? H->tsum[which] / H->tcnt[which] : 0.0;
+    if (launches) *launches = H->tcnt[which];
+    return LDSO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// the optimisation slice
+// ---------------------------------------------------------------------------------------------------------
+int ldso_ba_collect_active(ldso_ba_t *H) {
+    REQ(H && H->D.P > 0, "no window");
+    CHK(hipSetDevice(H->device));
+    H->pendingApply = false;
+    return launch_solve(H, H->sets[H->cur], SK_COLLECT);
+}
+
+int ldso_ba_linearize_all(ldso_ba_t *H, int fix, double *energy_out) {
+    REQ(H && H->D.P > 0, "no window");
+    CHK(hipSetDevice(H->device));
+    RUN(launch_linearize(H, fix != 0));
+    RUN(launch_solve(H, H->sets[H->cur ^ 1], SK_POST | SK_THRESH));
+    H->pendingApply = true;
+    if (fix) { H->cur ^= 1; H->pendingApply = false; }     // applyRes happens inside the reductor when fixing
+    double sc[16];
+    RUN(read_scalars(H, sc));
+    if (energy_out) *energy_out = sc[0];
+    if (!std::isfinite(sc[0])) return LDSO_E_NONFINITE;
+    return LDSO_OK;
+}
+
+int ldso_ba_apply_res(ldso_ba_t *H) {
+    REQ(H, "null handle");
+    if (H->pendingApply) { H->cur ^= 1; H->pendingApply = false; }
+    return LDSO_OK;
+}
+
+int ldso_ba_backup_state(ldso_ba_t *H) {
+    REQ(H && H->D.P > 0, "no window");
+    CHK(hipSetDevice(H->device));
+    RUN(launch_solve(H, H->sets[H->cur], SK_BACKUP));
+    RUN(launch_pstep(H, H->sets[H->cur], PS_BACKUP));
+    return LDSO_OK;
+}
+
+int ldso_ba_solve_system(ldso_ba_t *H, int iteration, double lambda) {
+    REQ(H && H->D.P > 0, "no window");
+    CHK(hipSetDevice(H->device));
+    const ResSet &S = H->sets[H->cur];
+    RUN(launch_reduce(H, S));
+    RUN(launch_gather(H, S, lambda, 0, nullptr));
+    RUN(launch_solve(H, S, SK_SOLVE, iteration, lambda));
+    RUN(launch_pstep(H, S, PS_RESUB));
+    double sc[16];
+    RUN(read_scalars(H, sc));
+    if (sc[4] != 0.0) return LDSO_E_NONFINITE;
+    return LDSO_OK;
+}
+
+int ldso_ba_do_step(ldso_ba_t *H, int *canbreak) {
+    REQ(H && H->D.P > 0, "no window");
+    CHK(hipSetDevice(H->device));
+    RUN(launch_solve(H, H->sets[H->cur], SK_STEP | SK_PRECALC));
+    RUN(launch_pstep(H, H->sets[H->cur], PS_STEP));
+    double sc[16];
+    RUN(read_scalars(H, sc));
+    if (canbreak) *canbreak = sc[3] != 0.0;
+    return LDSO_OK;
+}
+
+int ldso_ba_load_state_backup(ldso_ba_t *H) {
+    REQ(H && H->D.P > 0, "no window");
+    CHK(hipSetDevice(H->device));
+    RUN(launch_solve(H, H->sets[H->cur], SK_LOADBK | SK_PRECALC));
+    RUN(launch_pstep(H, H->sets[H->cur], PS_LOAD));
+    H->pendingApply = false;
+    return LDSO_OK;
+}
+
+// one GN iteration = solveSystem + doStepFromBackup + linearizeAll(false) + applyRes, 4 launches, no host sync
+static int enqueue_iteration(ldso_ba *H, int iteration, double lambda, int logIdx, bool postOfPrev) {
+    const ResSet &S = H->sets[H->cur];
+    RUN(launch_reduce(H, S));
+    RUN(launch_gather(H, S, lambda, 0, nullptr));
+    unsigned fl = SK_SOLVE | SK_BACKUP | SK_STEP | SK_PRECALC;
+    if (postOfPrev) fl |= SK_POST | SK_THRESH | SK_LOG;
+    RUN(launch_solve(H, S, fl, iteration, lambda, logIdx));
+    RUN(launch_pstep(H, S, PS_RESUB | PS_BACKUP | PS_STEP));
+    RUN(launch_linearize(H, false));
+    H->cur ^= 1;      // forceAcceptStep: applyRes
+    return LDSO_OK;
+}
+
+int ldso_ba_enqueue_gn(ldso_ba_t *H, int first_iteration, int iters) {
+    REQ(H && H->D.P > 0 && iters >= 0, "bad arguments");
+    CHK(hipSetDevice(H->device));
+    for (int i = 0; i < iters; i++) RUN(enqueue_iteration(H, first_iteration + i, 1e-1, -1, true));
+    return LDSO_OK;
+}
+
+int ldso_ba_sync(ldso_ba_t *H) {
+    REQ(H, "null handle");
+    CHK(hipStreamSynchronize(H->stream));
+    return LDSO_OK;
+}
+
+int ldso_ba_optimize(ldso_ba_t *H, int mnumOptIts, int force_all, float *rmse_out, int *iters_out) {
+    REQ(H && H->D.P > 0, "no window");
+    CHK(hipSetDevice(H->device));
+    if (!H->settings.forceAcceptStep) { ldso_set_error("ldso_ba_optimize runs the forceAcceptStep=true schedule; drive LM rejection through the step-wise calls"); return LDSO_E_UNSUPPORTED; }
+    const int F = H->D.F;
+    if (F < 2) { if (rmse_out) *rmse_out = 0; return LDSO_OK; }
+    if (!force_all) { if (F < 3) mnumOptIts = 20; if (F < 4) mnumOptIts = 15; }
+    REQ(mnumOptIts + 2 < 64, "too many iterations");
+    CHK(hipMemsetAsync(H->B.energyLog, 0, 64 * 8, H->stream));
+    RUN(launch_solve(H, H->sets[H->cur], SK_COLLECT));
+    H->pendingApply = false;
+    RUN(launch_linearize(H, false));
+    H->cur ^= 1;                                   // applyRes
+    int done = 0;
+    double lambda = 1e-1;
+    for (int it = 0; it < mnumOptIts; it++) {
+        RUN(enqueue_iteration(H, it, lambda, it, true));    // POST/THRESH/LOG of the previous linearize ride along
+        lambda *= 0.25;
+        done++;
+        if (!force_all) {
+            double sc[16];
+            RUN(read_scalars(H, sc));
+            if (sc[3] != 0.0 && it >= H->settings.minOptIterations) break;
+        }
+    }
+    // tail: statistics of the last linearize, re-anchor the newest frame, adjoints, precalc, linearizeAll(true)
+    RUN(launch_solve(H, H->sets[H->cur], SK_POST | SK_THRESH | SK_LOG | SK_REANCHOR | SK_ADJ | SK_PRECALC, 0, 0, done));
+    RUN(launch_linearize(H, true));
+    H->cur ^= 1;
+    RUN(launch_solve(H, H->sets[H->cur], SK_POST | SK_THRESH | SK_LOG, 0, 0, done + 1));
+    double sc[16];
+    RUN(read_scalars(H, sc));
+    H->lastIterations = done;
+    if (iters_out) *iters_out = done;
+    if (rmse_out) *rmse_out = sqrtf((float) (sc[0] / (8 * sc[9])));
+    if (!std::isfinite(sc[0]) || sc[4] != 0.0) return LDSO_E_NONFINITE;
+    return LDSO_OK;
+}
+
+int ldso_ba_reduce_local(ldso_ba_t *H, void *buf) {
+    REQ(H && buf && H->D.P > 0, "bad arguments");
+    CHK(hipSetDevice(H->device));
+    const ResSet &S = H->sets[H->cur];
+    RUN(launch_reduce(H, S));
+    RUN(launch_solve(H, S, SK_POST | SK_EXPORT, 0, 0, -1, (double *) buf, nullptr));
+    RUN(launch_gather(H, S, 0.0, 1, (double *) buf));
+    return LDSO_OK;
+}
+
+int ldso_ba_solve_reduced(ldso_ba_t *H, const void *buf, int iteration, double lambda, int do_step) {
+    REQ(H && buf && H->D.P > 0, "bad arguments");
+    CHK(hipSetDevice(H->device));
+    const ResSet &S = H->sets[H->cur];
+    unsigned fl = SK_FROMREDUCED | SK_THRESH | SK_SOLVE;
+    if (do_step) fl |= SK_BACKUP | SK_STEP | SK_PRECALC;
+    RUN(launch_gather(H, S, lambda, 2, (double *) buf));
+    RUN(launch_solve(H, S, fl, iteration, lambda, -1, nullptr, (const double *) buf));
+    RUN(launch_pstep(H, S, do_step ? (PS_RESUB | PS_BACKUP | PS_STEP) : PS_RESUB));
+    if (do_step) { RUN(launch_linearize(H, false)); H->cur ^= 1; }
+    return LDSO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// fetchers
+// ---------------------------------------------------------------------------------------------------------
+#define D2H(vec, src, n) do { int r_ = d2h(H, (vec), (src), (n)); if (r_ != LDSO_OK) return r_; } while (0)
+
+int ldso_ba_get_residuals(ldso_ba_t *H, ldso_res_out_t *out, int32_t *state_state, int32_t *is_active, int32_t *to_remove) {
+    REQ(H && H->D.P > 0, "no window");
+    CHK(hipSetDevice(H->device));
+    const size_t PS = (size_t) H->D.P * H->D.FS;
+    // "new" values come from the set written by the last linearize, applied values from the current set
+    const ResSet &Sn = H->pendingApply ? H->sets[H->cur ^ 1] : H->sets[H->cur];
+    const ResSet &Sc = H->sets[H->cur];
+    std::vector<int32_t> nst, cst, cact, trm;
+    std::vector<float> nen, nwo, cen, jp;
+    D2H(nst, Sn.state, PS); D2H(nen, Sn.energy, PS); D2H(nwo, Sn.newEnergyWO, PS); D2H(cen, Sn.center, PS * 3); D2H(jp, Sn.JpJdF, PS * 8);
+    D2H(cst, Sc.state, PS); D2H(cact, Sc.active, PS); D2H(trm, Sn.toRemove, PS);
+    CHK(hipStreamSynchronize(H->stream));
+    for (int i = 0; i < H->R; i++) {
+        size_t s = H->flat2slot[i];
+        if (out) {
+            ldso_res_out_t &o = out[i];
+            o.state_NewEnergy = nen[s]; o.state_NewEnergyWithOutlier = nwo[s]; o.state_NewState = nst[s];
+            for (int k = 0; k < 3; k++) o.centerProjectedTo[k] = cen[s * 3 + k];
+            for (int k = 0; k < 8; k++) o.JpJdF[k] = jp[s * 8 + k];
+        }
+        if (state_state) state_state[i] = cst[s];
+        if (is_active) is_active[i] = cact[s];
+        if (to_remove) to_remove[i] = trm[s];
+    }
+    return LDSO_OK;
+}
+
+int ldso_ba_get_points(ldso_ba_t *H, ldso_point_out_t *out) {
+    REQ(H && out && H->D.P > 0, "bad arguments");
+    CHK(hipSetDevice(H->device));
+    const size_t P = H->D.P;
+    const ResSet &S = H->sets[H->cur];
+    std::vector<float> step, HdiF, bd, idH, HddA, bdA, HcdA, HddL, bdL, HcdL, idp, mrb;
+    std::vector<int32_t> ng;
+    D2H(step, H->B.pstep, P); D2H(HdiF, S.HdiF, P); D2H(bd, S.bdSumF, P); D2H(idH, S.idH, P); D2H(HddA, S.HddA, P); D2H(bdA, S.bdA, P);
+    D2H(HcdA, S.HcdA, P * 4); D2H(HddL, S.HddL, P); D2H(bdL, S.bdL, P); D2H(HcdL, S.HcdL, P * 4); D2H(idp, H->B.pidepth, P);
+    D2H(mrb, S.maxRelBS, P); D2H(ng, S.numGood, P);
+    CHK(hipStreamSynchronize(H->stream));
+    for (size_t i = 0; i < P; i++) {
+        ldso_point_out_t &o = out[i];
+        o.step = step[i]; o.HdiF = HdiF[i]; o.bdSumF = bd[i]; o.idepth_hessian = idH[i]; o.Hdd_accAF = HddA[i]; o.bd_accAF = bdA[i];
+        o.Hdd_accLF = HddL[i]; o.bd_accLF = bdL[i];
+        for (int k = 0; k < 4; k++) { o.Hcd_accAF[k] = HcdA[i * 4 + k]; o.Hcd_accLF[k] = HcdL[i * 4 + k]; }
+        o.idepth = idp[i]; o.maxRelBaseline = mrb[i]; o.numGoodResiduals = ng[i];
+    }
+    return LDSO_OK;
+}
+
+int ldso_ba_get_frames(ldso_ba_t *H, ldso_frame_t *fr, double *step, double *cv, double *cs, double *pre) {
+    REQ(H && H->D.F > 0, "no window");
+    CHK(hipSetDevice(H->device));
+    const int F = H->D.F;
+    std::vector<DevFrame> df;
+    D2H(df, H->B.frames, (size_t) F);
+    DevCalib dc;
+    CHK(hipMemcpyAsync(&dc, H->B.calib, sizeof(dc), hipMemcpyDeviceToHost, H->stream));
+    CHK(hipStreamSynchronize(H->stream));
+    for (int f = 0; f < F; f++) {
+        if (fr) {
+            ldso_frame_t &o = fr[f];
+            memcpy(o.worldToCam_evalPT, df[f].evalPT, sizeof(o.worldToCam_evalPT));
+            memcpy(o.state, df[f].state, sizeof(o.state)); memcpy(o.state_zero, df[f].state_zero, sizeof(o.state_zero));
+            memcpy(o.prior, df[f].prior, sizeof(o.prior));
+            memcpy(o.nullspaces_pose, df[f].ns_pose, sizeof(o.nullspaces_pose)); memcpy(o.nullspaces_scale, df[f].ns_scale, sizeof(o.nullspaces_scale));
+            memcpy(o.nullspaces_affine, df[f].ns_affine, sizeof(o.nullspaces_affine));
+            o.ab_exposure = df[f].ab_exposure; o.frameEnergyTH = df[f].frameEnergyTH; o.frameID = df[f].frameID; o.pad_ = 0;
+        }
+        if (step) memcpy(step + f * 10, df[f].step, 10 * sizeof(double));
+        if (pre) memcpy(pre + f * 12, df[f].PRE_w2c, 12 * sizeof(double));
+    }
+    if (cv) memcpy(cv, dc.value, 4 * sizeof(double));
+    if (cs) memcpy(cs, dc.step, 4 * sizeof(double));
+    return LDSO_OK;
+}
+
+int ldso_ba_get_system(ldso_ba_t *H, double *HA, double *bA, double *HL, double *bL, double *Hsc, double *bsc, double *HF, double *bF, double *x) {
+    REQ(H && H->D.n > 0, "no window");
+    CHK(hipSetDevice(H->device));
+    const size_t n = H->D.n, blk = n * n + n;
+    std::vector<double> sys, xx;
+    D2H(sys, H->B.sys, 4 * blk); D2H(xx, H->B.x, n);
+    CHK(hipStreamSynchronize(H->stream));
+    double *Hs[4] = {HA, HL, Hsc, HF}, *bs[4] = {bA, bL, bsc, bF};
+    for (int m = 0; m < 4; m++) {
+        if (Hs[m]) memcpy(Hs[m], sys.data() + m * blk, n * n * 8);
+        if (bs[m]) memcpy(bs[m], sys.data() + m * blk + n * n, n * 8);
+    }
+    if (x) memcpy(x, xx.data(), n * 8);
+    return LDSO_OK;
+}
+
+int ldso_ba_set_debug_dump(ldso_ba_t *H, int enable) {
+    REQ(H, "null handle");
+    H->B.dumpJ = enable ? H->d_dumpJ : nullptr;
+    return LDSO_OK;
+}
+
+int ldso_ba_get_jacobians(ldso_ba_t *H, const int32_t *ids, int n, ldso_rawjac_t *out) {
+    REQ(H && ids && out && n >= 0 && H->D.P > 0, "bad arguments");
+    CHK(hipSetDevice(H->device));
+    std::vector<ldso_rawjac_t> all;
+    if (H->B.dumpJ == nullptr) {
+        // recompute on demand: run the linearize kernel at the current state with the J dump enabled, into the
+        // spare set; neither the applied set nor the frame-energy thresholds are touched.
+        REQ(!H->pendingApply, "ldso_ba_get_jacobians: a linearisation is pending (call ldso_ba_apply_res first, or enable ldso_ba_set_debug_dump)");
+        BaPtrs Bd = H->B;
+        Bd.dumpJ = H->d_dumpJ;
+        CHK(ba_launch_linearize(Bd, H->D, H->sets[H->cur], H->sets[H->cur ^ 1], H->settings, H->hasL, false, H->stream));
+    }
+    D2H(all, H->d_dumpJ, (size_t) H->R);
+    CHK(hipStreamSynchronize(H->stream));
+    for (int i = 0; i < n; i++) { REQ(ids[i] >= 0 && ids[i] < H->R, "residual id out of range"); out[i] = all[ids[i]]; }
+    return LDSO_OK;
+}
+
+int ldso_ba_get_precalc(ldso_ba_t *H, float *out) {
+    REQ(H && out && H->D.F > 0, "bad arguments");
+    CHK(hipSetDevice(H->device));
+    const int F = H->D.F;
+    std::vector<DevPair> dp;
+    D2H(dp, H->B.pairs, (size_t) F * F);
+    CHK(hipStreamSynchronize(H->stream));
+    for (int i = 0; i < F * F; i++) {
+        float *o = out + i * 27;
+        memcpy(o, dp[i].KRKi, 36); memcpy(o + 9, dp[i].Kt, 12); memcpy(o + 12, dp[i].R0, 36); memcpy(o + 21, dp[i].t0, 12);
+        o[24] = dp[i].aff[0]; o[25] = dp[i].aff[1]; o[26] = dp[i].b0;
+    }
+    return LDSO_OK;
+}
+
+int ldso_ba_get_counts(ldso_ba_t *H, int *a, int *l) {
+    REQ(H, "null handle");
+    double sc[16];
+    RUN(read_scalars(H, sc));
+    if (a) *a = (int) sc[9];
+    if (l) *l = (int) sc[10];
+    return LDSO_OK;
+}
+
+int ldso_ba_get_energy_log(ldso_ba_t *H, double *out, int cap) {
+    REQ(H && out, "bad arguments");
+    std::vector<double> e;
+    D2H(e, H->B.energyLog, (size_t) 64);
+    CHK(hipStreamSynchronize(H->stream));
+    int n = H->lastIterations + 2;
+    if (cap >= 64) { for (int i = 0; i < 64; i++) out[i] = e[i]; return n; }
+    for (int i = 0; i < std::min(n, cap); i++) out[i] = e[i];
+    return n;
+}
+
+}  // extern "C"

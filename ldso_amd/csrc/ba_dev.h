@@ -1,0 +1,111 @@
+// ba_dev.h — device-side data layout of one bundle-adjustment handle (gfx950).
+//
+// HBM layout (sizes at the BASELINE C3 window: F=7, P=2000, 640x480):
+//   img[f]      level-0 image of frame f exactly as FrameHessian::dIp[0]: 12-byte AoS (I,dx,dy), w*h px   (3.7 MB each)
+//   frames[F]   DevFrame: eval point, state, backup, step, priors (double)                                  (<1 KB each)
+//   pairs[F*F]  DevPair at [host*F + target]: FrameFramePrecalc floats + adHTdeltaF + max frameEnergyTH    (144 B each)
+//   ad*[F*F]    adjoints at [host + target*F] (reference slot order), double and float copies
+//   points      SoA arrays of P entries
+//   residuals   dense slot table [P][FS], slot index == target frame idx, FS = F rounded up to 8
+//   ResSet x2   ping-pong "applied" residual state + accumulator partials (linearize writes the other
+//               set; applyRes is a pointer swap, so a rejected LM step costs nothing)
+#pragma once
+#include <stdint.h>
+#include "../../include/ldso_window.h"
+
+#define LD_MAXF LDSO_MAX_FRAMES
+#define LD_TOPN 91            // unique entries of the 13x13 symmetric relative Hessian block
+#define LD_WAVES 4            // waves per linearize block
+#define LD_GEXTRA 8           // per-point extras appended to a G row: Hcd[4], bdSum, HdiF, pad, pad
+
+struct DevPair {
+    float KRKi[9];
+    float Kt[3];
+    float R0[9];
+    float t0[3];
+    float aff[2];
+    float b0;
+    float thMax;     // max(host.frameEnergyTH, target.frameEnergyTH)
+    float dp[8];     // adHTdeltaF[host + target*F]
+};
+
+struct DevFrame {
+    double evalPT[12];
+    double state[10], state_zero[10], state_backup[10], step[10];
+    double prior[8], delta[8], delta_prior[8];
+    double PRE_w2c[12], PRE_c2w[12];
+    double ns_pose[36], ns_scale[6], ns_affine[8];
+    float ab_exposure, frameEnergyTH;
+    int32_t frameID, imgSlot;
+};
+
+struct DevCalib {
+    double value[4], value_zero[4], value_backup[4], step[4];
+    float sf[4];        // value_scaledf: fx fy cx cy
+    float si[4];        // value_scaledi: 1/fx 1/fy -cx/fx -cy/fy
+    float cDeltaF[4];
+    float pad_[4];
+};
+
+// One of the two ping-pong sets (see header comment).
+struct ResSet {
+    int32_t *state;        // [P*FS] ResState
+    int32_t *active;       // [P*FS] isActiveAndIsGoodNEW
+    float *energy;         // [P*FS] state_energy
+    float *JpJdF;          // [P*FS*8]
+    float *newEnergyWO;    // [P*FS] state_NewEnergyWithOutlier of the linearize that produced this set (-1: none)
+    float *center;         // [P*FS*3] centerProjectedTo
+    int32_t *toRemove;     // [P*FS] (fix mode) residual became inactive -> host drops it
+    // per point
+    float *HdiF, *bdSumF, *idH, *HddA, *bdA, *HcdA, *HddL, *bdL, *HcdL, *maxRelBS;
+    int32_t *numGood, *nActive;
+    float *candE;          // [P] newest-frame candidate energy for setNewFrameEnergyTH (-1: none)
+    // accumulator outputs of the fused linearize
+    float *G;              // [P][GS]  lifted Schur rows  g_p (8*FS frame entries + LD_GEXTRA)
+    float *topA;           // [nChunks][FS][91]
+    float *topL;           // [nChunks][FS][91]
+    double *chunkEnergy;   // [nChunks]
+    int32_t *chunkCnt;     // [nChunks*2]  nres A, nres L
+    float *chunkNID;       // [nChunks*2]  sum |idepth|, count   (doStepFromBackup statistics)
+};
+
+struct BaDims {
+    int32_t F, FS, P, R, n, GS, w, h, nChunks, nL, nsg;
+    int32_t pBegin, pEnd;      // shard of points owned by this rank
+    float wM3G, hM3G;
+};
+
+struct BaPtrs {
+    const float *img[LD_MAXF];
+    DevFrame *frames;
+    DevCalib *calib;
+    DevPair *pairs;
+    double *adHost, *adTarget;
+    float *adHostF, *adTargetF;
+    double *nsProj;                  // n*n projector onto the gauge nullspaces (reference ordering)
+    double *HM, *bM;
+    // points
+    float *pu, *pv, *pidepth, *pidepth_zero, *pidepth_backup, *pstep, *ppriorF, *pcolor, *pweights;
+    int32_t *phost;
+    // residual slots
+    int32_t *rflat, *rlin, *rnew, *rlidx;
+    // linearised store
+    ldso_rawjac_t *Jlin;
+    float *rtz;
+    // chunks
+    int32_t *chunk_p0, *chunk_n, *chunk_host;
+    // solve-side buffers
+    double *pairC;      // [F*F][PAIRC] lifted top contributions (A then L)
+    float *scPart;      // [SC_SPLITS][n*(n+1)] Schur partials
+    double *sys;        // HA,bA,HL,bL,Hsc,bsc,HFinal,bFinal,x  (debug/fetch)
+    double *x;          // n
+    float *xAd;         // [F*F*8] at [h*F+t]
+    float *xc;          // 4 (calib step as float, = x[0:4])
+    double *scalars;    // misc: [0] energy, [1] resInA, [2] resInL, [3] canbreak, [4] nonfinite flag, [5] sumNID mean
+    double *energyLog;  // [64]
+    ldso_rawjac_t *dumpJ;   // optional [R]
+};
+
+#define LD_PAIRC 296        // doubles per pair contribution: hh 64, tt 64, ht 64, hc 32, tc 32, cc 16, bh 8, bt 8, bc 4 (=292, padded)
+#define LD_SC_SPLITS 16
+#define LD_SYS_MATS 4       // HA, HL, Hsc, HFinal

@@ -1,0 +1,501 @@
+// ba_linearize.hip — fused per-point kernel of the windowed photometric BA (gfx950, wave64).
+//
+// Replaces, for every active point of the window, the reference's
+//   PointFrameResidual::linearize        src/internal/Residuals.cc:13-214
+//   PointFrameResidual::applyRes/takeData include/internal/Residuals.h:70-87,123-128
+//   AccumulatedTopHessianSSE::addPoint<0|1>  src/internal/OptimizationBackend/AccumulatedTopHessian.cc:8-118
+//   AccumulatedSCHessianSSE::addPoint (per-point part)  .../AccumulatedSCHessian.cc:9-31
+// Mapping: one wavefront per point; lane = slot*8 + k where slot = target frame (8 per pass) and
+// k = pattern pixel.  All residuals of a point share its host, and points arrive host-major
+// (EnergyFunctional::allPoints order), so a block's register accumulators belong to fixed
+// (host, target=slot) pairs: the 13x13 relative Hessian block of a pair is accumulated as the outer
+// product of each pixel row, in registers, with no atomics; a block writes ONE partial per slot.
+// The Schur complement is kept in lifted form: per point the row g_p = [Ad^T JpJdF | Hcd] is stored
+// (G matrix) and reduced later as G diag(HdiF) G^T by ba_reduce.hip.
+//
+// Roofline: HBM/gather bound — per residual 8 px x 4 taps x 12 B of the target image.
+// Arithmetic is IEEE (compile with -ffp-contract=off): every elementwise expression below follows
+// the reference's operation order so that energies and residual states are bit-identical to the
+// CPU path; fused multiply-adds are used only (explicitly) in the accumulators.
+#include <hip/hip_runtime.h>
+#include "ba_dev.h"
+
+#define RES_IN 0
+#define RES_OOB 1
+#define RES_OUTLIER 2
+
+// value of lane (i-1) within the 16-lane row; callers zero it for k==0
+__device__ __forceinline__ float dpp_row_shr1(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x111, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dpp_quad_xor1(float x) {   // quad_perm [1,0,3,2]
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dpp_quad_xor2(float x) {   // quad_perm [2,3,0,1]
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dpp_half_mirror(float x) {   // lane i <-> 7-i within each 8-lane half row
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, true));
+}
+// sum over the 8 lanes of a slot group, result in all 8 lanes (tree order)
+__device__ __forceinline__ float sum8(float x) {
+    x += dpp_quad_xor1(x);
+    x += dpp_quad_xor2(x);
+    x += dpp_half_mirror(x);
+    return x;
+}
+// sum over the 8 lanes in the reference's sequential order ((((x0+x1)+x2)+...)+x7), result in all 8 lanes
+__device__ __forceinline__ float seq8(float x, int k, int lane) {
+    float t = x;
+#pragma unroll
+    for (int j = 0; j < 7; j++) {
+        float sh = dpp_row_shr1(t);
+        sh = (k == 0) ? 0.0f : sh;
+        t = sh + x;
+    }
+    return __shfl(t, lane | 7, 64);
+}
+
+// flat index of entry (r,c), r<=c, in the packed upper triangle of a 13x13 matrix
+__host__ __device__ constexpr int tri13(int r, int c) { return r * 13 - (r * (r - 1)) / 2 + (c - r); }
+
+struct PointIO {
+    float u, v, idepth, idepth_zero, priorF;
+};
+
+template <int NSG, bool HAS_L, bool FIX>
+__global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D, ResSet cur, ResSet nxt, ldso_settings_t S) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int FS = D.FS, F = D.F;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, s = lane >> 3, k = lane & 7;
+    const int chunk = blockIdx.x;
+    const int p0 = B.chunk_p0[chunk], np = B.chunk_n[chunk], h = B.chunk_host[chunk];
+
+    // ---- LDS carve: pair structs of this host, float adjoints of this host, reduction scratch --------
+    DevPair *sPair = (DevPair *) smem;                                  // [FS]
+    float *sAdH = smem + FS * (sizeof(DevPair) / 4);                    // [FS][64]
+    float *sAdT = sAdH + FS * 64;                                       // [FS][64]
+    float *sRed = sAdT + FS * 64;                                       // [LD_WAVES][FS][91] (+ topL [FS][91] when HAS_L)
+    float *sTopL = sRed + LD_WAVES * FS * LD_TOPN;
+
+    for (int i = tid; i < FS * (int) (sizeof(DevPair) / 4); i += blockDim.x) {
+        int t = i / (int) (sizeof(DevPair) / 4), o = i % (int) (sizeof(DevPair) / 4);
+        ((float *) sPair)[i] = (t < F) ? ((const float *) &B.pairs[h * F + t])[o] : 0.0f;
+    }
+    for (int i = tid; i < FS * 64; i += blockDim.x) {
+        int t = i >> 6, o = i & 63;
+        sAdH[i] = (t < F) ? B.adHostF[(h + t * F) * 64 + o] : 0.0f;
+        sAdT[i] = (t < F) ? B.adTargetF[(h + t * F) * 64 + o] : 0.0f;
+    }
+    if (HAS_L) for (int i = tid; i < FS * LD_TOPN; i += blockDim.x) sTopL[i] = 0.0f;
+    __syncthreads();
+
+    const float fx = B.calib->sf[0], fy = B.calib->sf[1], cx = B.calib->sf[2], cy = B.calib->sf[3];
+    const float fxi = B.calib->si[0], fyi = B.calib->si[1];
+    const float cD0 = B.calib->cDeltaF[0], cD1 = B.calib->cDeltaF[1], cD2 = B.calib->cDeltaF[2], cD3 = B.calib->cDeltaF[3];
+    const int ox = (k == 1 || k == 6) ? -1 : (k == 2) ? 1 : (k == 3) ? -2 : (k == 5) ? 2 : 0;     // staticPattern[8], Setting.cc:221
+    const int oy = (k == 0) ? -2 : (k == 1 || k == 2) ? -1 : (k == 6) ? 1 : (k == 7) ? 2 : 0;
+    const int W = D.w;
+
+    float accA[NSG][LD_TOPN];
+#pragma unroll
+    for (int g = 0; g < NSG; g++)
+#pragma unroll
+        for (int i = 0; i < LD_TOPN; i++) accA[g][i] = 0.0f;
+    double energySum = 0.0;     // sum of linearize() return values (slot leaders only)
+    int nresA = 0, nresL = 0;
+    float nidSum = 0.0f;
+    int nidCnt = 0;
+
+    for (int pi = wave; pi < np; pi += LD_WAVES) {
+        const int p = p0 + pi;
+        const float pu = B.pu[p], pv = B.pv[p], idp = B.pidepth[p], idz = B.pidepth_zero[p], priorF = B.ppriorF[p];
+        const float color = B.pcolor[p * 8 + k], wgt = B.pweights[p * 8 + k];
+        const float deltaF = idp - idz;
+        float HddA = 0, bdA = 0, HcdA0 = 0, HcdA1 = 0, HcdA2 = 0, HcdA3 = 0;
+        float HddL = 0, bdL = 0, HcdL0 = 0, HcdL1 = 0, HcdL2 = 0, HcdL3 = 0;
+        float hostPart = 0.0f;       // this lane's partial of the host block of g_p (component k)
+        float maxRelBS = cur.maxRelBS[p];
+        int numGood = cur.numGood[p];
+        int nActive = 0;
+        float gT[NSG];
+
+#pragma unroll
+        for (int g = 0; g < NSG; g++) {
+            const int t = g * 8 + s;
+            const int slot = p * FS + t;
+            const bool exists = (t < F) && (B.rflat[slot] >= 0);
+            const bool isLin = exists && (B.rlin[slot] != 0);
+            const int st = exists ? cur.state[slot] : RES_OOB;
+            const DevPair &pr = sPair[t];
+
+            int newState = st;
+            float newEnergy = exists ? cur.energy[slot] : 0.0f;
+            float newEnergyWO = -1.0f;
+            int activeNew = exists ? cur.active[slot] : 0;
+            float jp = exists ? cur.JpJdF[slot * 8 + k] : 0.0f;     // this lane's component k of JpJdF
+            float c0 = 0, c1 = 0, c2 = 0;
+            int toRemove = 0;
+            double ret = 0.0;                                      // linearize() return value
+            const bool doLin = exists && !isLin;
+
+            // ================= active-set residual: PointFrameResidual::linearize ==================
+            if (doLin && st == RES_OOB) { newState = RES_OOB; ret = (double) newEnergy; if (FIX) toRemove = 1; }
+            // (wave-uniform structure below is predicated per 8-lane group)
+            bool compute = doLin && st != RES_OOB;
+            // ---- centre projection at the linearisation point (ResidualProjections.h:57-84) --------
+            float KliP0 = (pu + 0 - cx) * fxi, KliP1 = (pv + 0 - cy) * fyi;
+            float ptp0 = ((pr.R0[0] * KliP0 + pr.R0[1] * KliP1) + pr.R0[2] * 1.0f) + pr.t0[0] * idz;
+            float ptp1 = ((pr.R0[3] * KliP0 + pr.R0[4] * KliP1) + pr.R0[5] * 1.0f) + pr.t0[1] * idz;
+            float ptp2 = ((pr.R0[6] * KliP0 + pr.R0[7] * KliP1) + pr.R0[8] * 1.0f) + pr.t0[2] * idz;
+            float drescale = 1.0f / ptp2;
+            float new_idepth = idz * drescale;
+            float uu = ptp0 * drescale, vv = ptp1 * drescale;
+            float cKu = uu * fx + cx, cKv = vv * fy + cy;
+            bool centerOK = (drescale > 0) && cKu > 1.1f && cKv > 1.1f && cKu < D.wM3G && cKv < D.hM3G;
+            // ---- pattern pixel projection at the current state (ResidualProjections.h:24-33) ---------
+            float px_ = pu + (float) ox, py_ = pv + (float) oy;
+            float q0 = ((pr.KRKi[0] * px_ + pr.KRKi[1] * py_) + pr.KRKi[2] * 1.0f) + pr.Kt[0] * idp;
+            float q1 = ((pr.KRKi[3] * px_ + pr.KRKi[4] * py_) + pr.KRKi[5] * 1.0f) + pr.Kt[1] * idp;
+            float q2 = ((pr.KRKi[6] * px_ + pr.KRKi[7] * py_) + pr.KRKi[8] * 1.0f) + pr.Kt[2] * idp;
+            float Ku = q0 / q2, Kv = q1 / q2;
+            bool pixOK = Ku > 1.1f && Kv > 1.1f && Ku < D.wM3G && Kv < D.hM3G;
+            // ---- bilinear Vec3f sample of the target image (GlobalFuncs.h:89-103) ---------------------
+            float hit0 = 0, hit1 = 0, hit2 = 0;
+            if (compute && centerOK && pixOK) {
+                int ix = (int) Ku, iy = (int) Kv;
+                float dx = Ku - ix, dy = Kv - iy, dxdy = dx * dy;
+                const float *bp = B.img[t] + 3 * (ix + iy * W);
+                float a0 = bp[0], a1 = bp[1], a2 = bp[2], b0_ = bp[3], b1 = bp[4], b2 = bp[5];
+                const float *bq = bp + 3 * W;
+                float c0_ = bq[0], c1_ = bq[1], c2_ = bq[2], d0 = bq[3], d1 = bq[4], d2 = bq[5];
+                float w11 = dxdy, w01 = dy - dxdy, w10 = dx - dxdy, w00 = 1 - dx - dy + dxdy;
+                hit0 = ((w11 * d0 + w01 * c0_) + w10 * b0_) + w00 * a0;
+                hit1 = ((w11 * d1 + w01 * c1_) + w10 * b1) + w00 * a1;
+                hit2 = ((w11 * d2 + w01 * c2_) + w10 * b2) + w00 * a2;
+            }
+            bool laneBad = compute && (!centerOK || !pixOK || !isfinite(hit0));
+            unsigned long long badMask = __ballot(laneBad);
+            bool anyBad = ((badMask >> (s * 8)) & 0xFFull) != 0;
+            if (compute && anyBad) { newState = RES_OOB; ret = (double) newEnergy; compute = false; }
+
+            // ---- photometric terms (Residuals.cc:126-188) ---------------------------------------------
+            float residual = hit0 - (float) (pr.aff[0] * color + pr.aff[1]);
+            float drdA = (color - pr.b0);
+            float w_ = sqrtf(S.outlierTHSumComponent / (S.outlierTHSumComponent + (hit1 * hit1 + hit2 * hit2)));
+            w_ = 0.5f * (w_ + wgt);
+            float hw = fabsf(residual) < S.huberTH ? 1 : S.huberTH / fabsf(residual);
+            float eTerm = w_ * w_ * hw * residual * residual * (2 - hw);
+            if (hw < 1) hw = sqrtf(hw);
+            hw = hw * w_;
+            float gx = hit1 * hw, gy = hit2 * hw;
+            float resF = residual * hw;
+            float jab0 = drdA * hw, jab1 = hw;
+            if (!compute) { eTerm = 0; gx = 0; gy = 0; resF = 0; jab0 = 0; jab1 = 0; }
+
+            float energyLeft = seq8(eTerm, k, lane);
+            float wJI2_sum = seq8(hw * hw * (gx * gx + gy * gy), k, lane);
+            float JI00 = sum8(gx * gx), JI11 = sum8(gy * gy), JI10 = sum8(gx * gy);
+            float JabJI00 = sum8(drdA * hw * gx), JabJI01 = sum8(drdA * hw * gy), JabJI10 = sum8(hw * gx), JabJI11 = sum8(hw * gy);
+            float Jab00 = sum8(drdA * drdA * hw * hw), Jab01 = sum8(drdA * hw * hw), Jab11 = sum8(hw * hw);
+            if (S.affineOptModeA < 0) jab0 = 0;     // J->JabF zeroed AFTER the 2x2 sums (Residuals.cc:184-185)
+            if (S.affineOptModeB < 0) jab1 = 0;
+
+            // ---- geometric Jacobians at the linearisation point (Residuals.cc:67-104) ----------------
+            float Jpdd0 = drescale * (pr.t0[0] - pr.t0[2] * uu) * 1.0f * fx;
+            float Jpdd1 = drescale * (pr.t0[1] - pr.t0[2] * vv) * 1.0f * fy;
+            float dCx2 = drescale * (pr.R0[6] * uu - pr.R0[0]);
+            float dCx3 = fx * drescale * (pr.R0[7] * uu - pr.R0[1]) * fyi;
+            float dCx0 = KliP0 * dCx2, dCx1 = KliP1 * dCx3;
+            float dCy2 = fy * drescale * (pr.R0[6] * vv - pr.R0[3]) * fxi;
+            float dCy3 = drescale * (pr.R0[7] * vv - pr.R0[4]);
+            float dCy0 = KliP0 * dCy2, dCy1 = KliP1 * dCy3;
+            float x[10], y[10];
+            x[0] = (dCx0 + uu) * 50.0f; x[1] = dCx1 * 50.0f; x[2] = (dCx2 + 1) * 50.0f; x[3] = dCx3 * 50.0f;
+            y[0] = dCy0 * 50.0f; y[1] = (dCy1 + vv) * 50.0f; y[2] = dCy2 * 50.0f; y[3] = (dCy3 + 1) * 50.0f;
+            x[4] = new_idepth * fx; x[5] = 0; x[6] = -new_idepth * uu * fx; x[7] = -uu * vv * fx; x[8] = (1 + uu * uu) * fx; x[9] = -vv * fx;
+            y[4] = 0; y[5] = new_idepth * fy; y[6] = -new_idepth * vv * fy; y[7] = -(1 + vv * vv) * fy; y[8] = uu * vv * fy; y[9] = uu * fy;
+
+            if (compute) {
+                newEnergyWO = energyLeft;
+                float th = pr.thMax;
+                if (energyLeft > th || wJI2_sum < 2) { energyLeft = th; newState = RES_OUTLIER; }
+                else newState = RES_IN;
+                newEnergy = energyLeft;
+                ret = (double) energyLeft;
+                c0 = cKu; c1 = cKv; c2 = new_idepth;
+            }
+
+            // ================= applyRes(true) (Residuals.h:70-87) ======================================
+            if (doLin && st != RES_OOB) {
+                if (newState == RES_IN) {
+                    activeNew = 1;
+                    // takeData (Residuals.h:123-128)
+                    float v0 = JI00 * Jpdd0 + JI10 * Jpdd1, v1 = JI10 * Jpdd0 + JI11 * Jpdd1;
+                    float jx = (k == 0) ? x[4] : (k == 1) ? x[5] : (k == 2) ? x[6] : (k == 3) ? x[7] : (k == 4) ? x[8] : x[9];
+                    float jy = (k == 0) ? y[4] : (k == 1) ? y[5] : (k == 2) ? y[6] : (k == 3) ? y[7] : (k == 4) ? y[8] : y[9];
+                    float j6 = JabJI00 * Jpdd0 + JabJI01 * Jpdd1, j7 = JabJI10 * Jpdd0 + JabJI11 * Jpdd1;
+                    jp = (k < 6) ? (jx * v0 + jy * v1) : (k == 6 ? j6 : j7);
+                } else {
+                    activeNew = 0;
+                }
+                if (FIX) {
+                    if (activeNew) {
+                        if (B.rnew[slot]) {
+                            // FullSystem.cc:1518-1534: relative baseline of new residuals
+                            float inf0 = (pr.KRKi[0] * pu + pr.KRKi[1] * pv) + pr.KRKi[2] * 1.0f;
+                            float inf1 = (pr.KRKi[3] * pu + pr.KRKi[4] * pv) + pr.KRKi[5] * 1.0f;
+                            float inf2 = (pr.KRKi[6] * pu + pr.KRKi[7] * pv) + pr.KRKi[8] * 1.0f;
+                            float r0 = inf0 + pr.Kt[0] * idp, r1 = inf1 + pr.Kt[1] * idp, r2 = inf2 + pr.Kt[2] * idp;
+                            float ax = inf0 / inf2 - r0 / r2, ay = inf1 / inf2 - r1 / r2;
+                            float relBS = (float) (0.01 * (double) sqrtf(ax * ax + ay * ay));
+                            if (relBS > maxRelBS) maxRelBS = relBS;     // merged across slots after the loop
+                        }
+                    } else toRemove = 1;
+                }
+            }
+            unsigned long long newGoodMask = 0;
+            if (FIX) newGoodMask = __ballot(doLin && st != RES_OOB && activeNew && B.rnew[exists ? slot : 0] && k == 0);
+
+            // ================= accumulate: active residual, mode 0 (AccumulatedTopHessian.cc) ==========
+            const bool accHere = doLin && activeNew && compute;
+            if (accHere) {
+                float v[13];
+#pragma unroll
+                for (int i = 0; i < 10; i++) v[i] = __builtin_fmaf(gx, x[i], gy * y[i]);
+                v[10] = drdA * hw; v[11] = hw; v[12] = resF;
+                // Jab_r uses the (possibly zeroed) JabF, Jab2/JabJIdx the un-zeroed sums
+                const float z10 = (S.affineOptModeA < 0) ? 0.0f : 1.0f, z11 = (S.affineOptModeB < 0) ? 0.0f : 1.0f;
+#pragma unroll
+                for (int r = 0; r < 13; r++)
+#pragma unroll
+                    for (int c = r; c < 13; c++) {
+                        float a = v[r], b = v[c];
+                        if (r == 10 && c == 12) a *= z10;
+                        if (r == 11 && c == 12) a *= z11;
+                        accA[g][tri13(r, c)] = __builtin_fmaf(a, b, accA[g][tri13(r, c)]);
+                    }
+            }
+            // per-slot contributions to the point sums (same value in all 8 lanes of the slot)
+            float JI_r0 = sum8(resF * gx), JI_r1 = sum8(resF * gy);
+            float Ji2_0 = JI00 * Jpdd0 + JI10 * Jpdd1, Ji2_1 = JI10 * Jpdd0 + JI11 * Jpdd1;
+            float sbd = accHere ? (JI_r0 * Jpdd0 + JI_r1 * Jpdd1) : 0.0f;
+            float sHdd = accHere ? (Ji2_0 * Jpdd0 + Ji2_1 * Jpdd1) : 0.0f;
+            float sHc0 = accHere ? (x[0] * Ji2_0 + y[0] * Ji2_1) : 0.0f, sHc1 = accHere ? (x[1] * Ji2_0 + y[1] * Ji2_1) : 0.0f;
+            float sHc2 = accHere ? (x[2] * Ji2_0 + y[2] * Ji2_1) : 0.0f, sHc3 = accHere ? (x[3] * Ji2_0 + y[3] * Ji2_1) : 0.0f;
+            // sequential sum over the 8 slots of this pass, ascending target (reference: p->residuals order)
+#pragma unroll
+            for (int ss = 0; ss < 8; ss++) {
+                bdA += __shfl(sbd, ss * 8, 64); HddA += __shfl(sHdd, ss * 8, 64);
+                HcdA0 += __shfl(sHc0, ss * 8, 64); HcdA1 += __shfl(sHc1, ss * 8, 64);
+                HcdA2 += __shfl(sHc2, ss * 8, 64); HcdA3 += __shfl(sHc3, ss * 8, 64);
+            }
+            if (accHere && k == 0) nresA++;
+
+            // ================= linearised residual, mode 1 (AccumulatedTopHessian.cc:29-31,44-63) =======
+            if (HAS_L) {
+                const bool accL = isLin && activeNew;
+                float lsbd = 0, lsHdd = 0, lH0 = 0, lH1 = 0, lH2 = 0, lH3 = 0;
+                if (accL) {
+                    const ldso_rawjac_t &J = B.Jlin[B.rlidx[slot]];
+                    const float *rtz = B.rtz + B.rlidx[slot] * 8;
+                    float dpx = 0, dpy = 0;
+#pragma unroll
+                    for (int i = 0; i < 6; i++) { dpx += J.Jpdxi[0][i] * pr.dp[i]; dpy += J.Jpdxi[1][i] * pr.dp[i]; }
+                    float dcx = ((J.Jpdc[0][0] * cD0 + J.Jpdc[0][1] * cD1) + J.Jpdc[0][2] * cD2) + J.Jpdc[0][3] * cD3;
+                    float dcy = ((J.Jpdc[1][0] * cD0 + J.Jpdc[1][1] * cD1) + J.Jpdc[1][2] * cD2) + J.Jpdc[1][3] * cD3;
+                    float Jp_delta_x = dpx + dcx + J.Jpdd[0] * deltaF;
+                    float Jp_delta_y = dpy + dcy + J.Jpdd[1] * deltaF;
+                    float lgx = J.JIdx[0][k], lgy = J.JIdx[1][k], la0 = J.JabF[0][k], la1 = J.JabF[1][k];
+                    float ra = rtz[k];
+                    ra = ra + lgx * Jp_delta_x; ra = ra + lgy * Jp_delta_y; ra = ra + la0 * pr.dp[6]; ra = ra + la1 * pr.dp[7];
+                    float lJI_r0 = seq8(ra * lgx, k, lane), lJI_r1 = seq8(ra * lgy, k, lane);
+                    float lJab_r0 = seq8(ra * la0, k, lane), lJab_r1 = seq8(ra * la1, k, lane), lrr = seq8(ra * ra, k, lane);
+                    float a = J.JIdx2[0], b = J.JIdx2[1], c = J.JIdx2[3];
+                    float lx[10], ly[10];
+#pragma unroll
+                    for (int i = 0; i < 4; i++) { lx[i] = J.Jpdc[0][i]; ly[i] = J.Jpdc[1][i]; }
+#pragma unroll
+                    for (int i = 0; i < 6; i++) { lx[4 + i] = J.Jpdxi[0][i]; ly[4 + i] = J.Jpdxi[1][i]; }
+                    if (k == 0) {
+                        float *dst = sTopL + t * LD_TOPN;
+#pragma unroll
+                        for (int r = 0; r < 10; r++)
+#pragma unroll
+                            for (int cc = r; cc < 10; cc++)
+                                atomicAdd(&dst[tri13(r, cc)], a * lx[cc] * lx[r] + c * ly[cc] * ly[r] + b * (lx[cc] * ly[r] + ly[cc] * lx[r]));
+#pragma unroll
+                        for (int r = 0; r < 10; r++) {
+                            atomicAdd(&dst[tri13(r, 10)], lx[r] * J.JabJIdx[0] + ly[r] * J.JabJIdx[1]);
+                            atomicAdd(&dst[tri13(r, 11)], lx[r] * J.JabJIdx[2] + ly[r] * J.JabJIdx[3]);
+                            atomicAdd(&dst[tri13(r, 12)], lx[r] * lJI_r0 + ly[r] * lJI_r1);
+                        }
+                        atomicAdd(&dst[tri13(10, 10)], J.Jab2[0]); atomicAdd(&dst[tri13(10, 11)], J.Jab2[1]); atomicAdd(&dst[tri13(10, 12)], lJab_r0);
+                        atomicAdd(&dst[tri13(11, 11)], J.Jab2[3]); atomicAdd(&dst[tri13(11, 12)], lJab_r1); atomicAdd(&dst[tri13(12, 12)], lrr);
+                        nresL++;
+                    }
+                    float lJi0 = a * J.Jpdd[0] + b * J.Jpdd[1], lJi1 = b * J.Jpdd[0] + c * J.Jpdd[1];
+                    lsbd = lJI_r0 * J.Jpdd[0] + lJI_r1 * J.Jpdd[1];
+                    lsHdd = lJi0 * J.Jpdd[0] + lJi1 * J.Jpdd[1];
+                    lH0 = lx[0] * lJi0 + ly[0] * lJi1; lH1 = lx[1] * lJi0 + ly[1] * lJi1; lH2 = lx[2] * lJi0 + ly[2] * lJi1; lH3 = lx[3] * lJi0 + ly[3] * lJi1;
+                }
+#pragma unroll
+                for (int ss = 0; ss < 8; ss++) {
+                    bdL += __shfl(lsbd, ss * 8, 64); HddL += __shfl(lsHdd, ss * 8, 64);
+                    HcdL0 += __shfl(lH0, ss * 8, 64); HcdL1 += __shfl(lH1, ss * 8, 64);
+                    HcdL2 += __shfl(lH2, ss * 8, 64); HcdL3 += __shfl(lH3, ss * 8, 64);
+                }
+            }
+
+            // ================= lifted Schur row: target block and this slot's share of the host block ==
+            float tgt = 0.0f, hpart = 0.0f;
+            {
+                // all 8 components of JpJdF of this slot, gathered from the 8 lanes
+                float vj[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) vj[j] = __shfl(jp, (lane & ~7) | j, 64);
+                if (exists && activeNew) {
+                    const float *aT = sAdT + t * 64 + k * 8, *aH = sAdH + t * 64 + k * 8;
+#pragma unroll
+                    for (int j = 0; j < 8; j++) { tgt = __builtin_fmaf(aT[j], vj[j], tgt); hpart = __builtin_fmaf(aH[j], vj[j], hpart); }
+                }
+            }
+#pragma unroll
+            for (int ss = 0; ss < 8; ss++) hostPart += __shfl(hpart, ss * 8 + k, 64);
+            gT[g] = tgt;
+            nActive += __popcll(__ballot(exists && activeNew && k == 0));
+            if (FIX) numGood += __popcll(newGoodMask);
+            if (FIX) { float m = maxRelBS; m = fmaxf(m, __shfl_xor(m, 8, 64)); m = fmaxf(m, __shfl_xor(m, 16, 64)); m = fmaxf(m, __shfl_xor(m, 32, 64)); maxRelBS = m; }
+
+            // ---- per-slot outputs (slot leader) ----------------------------------------------------------
+            if (t < F) {
+                nxt.JpJdF[slot * 8 + k] = jp;
+                if (k == 0) {
+                    nxt.state[slot] = newState;
+                    nxt.active[slot] = activeNew;
+                    nxt.energy[slot] = newEnergy;
+                    nxt.newEnergyWO[slot] = doLin ? newEnergyWO : -1.0f;
+                    if (t == F - 1) nxt.candE[p] = doLin ? newEnergyWO : -1.0f;
+                    nxt.toRemove[slot] = toRemove;
+                    if (doLin) energySum += ret;
+                }
+                if (k < 3) nxt.center[slot * 3 + k] = compute ? (k == 0 ? c0 : k == 1 ? c1 : c2) : cur.center[slot * 3 + k];
+            }
+            if (B.dumpJ != nullptr && compute) {
+                ldso_rawjac_t &o = B.dumpJ[B.rflat[slot]];
+                o.resF[k] = resF; o.JIdx[0][k] = gx; o.JIdx[1][k] = gy; o.JabF[0][k] = jab0; o.JabF[1][k] = jab1;
+                if (k == 0) {
+                    for (int i = 0; i < 6; i++) { o.Jpdxi[0][i] = x[4 + i]; o.Jpdxi[1][i] = y[4 + i]; }
+                    for (int i = 0; i < 4; i++) { o.Jpdc[0][i] = x[i]; o.Jpdc[1][i] = y[i]; }
+                    o.Jpdd[0] = Jpdd0; o.Jpdd[1] = Jpdd1;
+                    o.JIdx2[0] = JI00; o.JIdx2[1] = JI10; o.JIdx2[2] = JI10; o.JIdx2[3] = JI11;
+                    o.JabJIdx[0] = JabJI00; o.JabJIdx[1] = JabJI01; o.JabJIdx[2] = JabJI10; o.JabJIdx[3] = JabJI11;
+                    o.Jab2[0] = Jab00; o.Jab2[1] = Jab01; o.Jab2[2] = Jab01; o.Jab2[3] = Jab11;
+                }
+            }
+        }   // slot groups
+
+        // ================= per-point Schur quantities (AccumulatedSCHessian.cc:9-31) =====================
+        float HdiF = 0, bdSumF = 0, idH = 0;
+        float Hc0 = HcdA0 + HcdL0, Hc1 = HcdA1 + HcdL1, Hc2 = HcdA2 + HcdL2, Hc3 = HcdA3 + HcdL3;
+        if (nActive > 0) {
+            float H = HddA + HddL + priorF;
+            if (H < 1e-10) H = 1e-10;
+            idH = H;
+            HdiF = (float) (1.0 / (double) H);
+            bdSumF = bdA + bdL;
+            bdSumF += priorF * deltaF;       // shiftPriorToZero = true in accumulateSCF_MT
+        } else {
+            maxRelBS = 0;
+        }
+        // ---- store G row: [8*FS frame entries | Hcd 4, bdSum, HdiF, 0, 0] --------------------------------
+        float *Grow = nxt.G + (size_t) p * D.GS;
+#pragma unroll
+        for (int g = 0; g < NSG; g++) {
+            const int t = g * 8 + s;
+            float val = (t == h) ? hostPart : gT[g];
+            if (nActive == 0) val = 0.0f;
+            Grow[8 * t + k] = val;
+        }
+        if (lane < LD_GEXTRA) {
+            float e = (lane == 0) ? Hc0 : (lane == 1) ? Hc1 : (lane == 2) ? Hc2 : (lane == 3) ? Hc3 : (lane == 4) ? bdSumF : (lane == 5) ? HdiF : 0.0f;
+            if (nActive == 0 && lane < 4) e = 0.0f;
+            Grow[8 * FS + lane] = e;
+        }
+        if (lane == 0) {
+            nxt.HdiF[p] = HdiF; nxt.bdSumF[p] = bdSumF; nxt.idH[p] = idH;
+            nxt.HddA[p] = HddA; nxt.bdA[p] = bdA; nxt.HddL[p] = HddL; nxt.bdL[p] = bdL;
+            nxt.HcdA[p * 4 + 0] = HcdA0; nxt.HcdA[p * 4 + 1] = HcdA1; nxt.HcdA[p * 4 + 2] = HcdA2; nxt.HcdA[p * 4 + 3] = HcdA3;
+            nxt.HcdL[p * 4 + 0] = HcdL0; nxt.HcdL[p * 4 + 1] = HcdL1; nxt.HcdL[p * 4 + 2] = HcdL2; nxt.HcdL[p * 4 + 3] = HcdL3;
+            nxt.maxRelBS[p] = maxRelBS; nxt.numGood[p] = numGood; nxt.nActive[p] = nActive;
+            nidSum += fabsf(idp); nidCnt++;
+        }
+    }   // points of this wave
+
+    // ================= block reduction of the top accumulators =============================================
+    // (1) over the 8 pattern lanes, (2) over the waves of the block through LDS, fixed order
+#pragma unroll
+    for (int g = 0; g < NSG; g++)
+#pragma unroll
+        for (int i = 0; i < LD_TOPN; i++) {
+            float a = sum8(accA[g][i]);
+            if (k == 0) sRed[(wave * FS + g * 8 + s) * LD_TOPN + i] = a;
+        }
+    __syncthreads();
+    for (int i = tid; i < FS * LD_TOPN; i += blockDim.x) {
+        float a = 0;
+#pragma unroll
+        for (int wv = 0; wv < LD_WAVES; wv++) a += sRed[wv * FS * LD_TOPN + i];
+        nxt.topA[(size_t) chunk * FS * LD_TOPN + i] = a;
+        if (HAS_L) nxt.topL[(size_t) chunk * FS * LD_TOPN + i] = sTopL[i];
+    }
+    // energy / counters: wave reduce then LDS
+    __syncthreads();
+    double *sE = (double *) sRed;
+    int *sC = (int *) (sE + LD_WAVES);
+    float *sN = (float *) (sC + 4 * LD_WAVES);
+    {
+        double e = energySum;
+        for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o, 64);
+        int na = nresA, nl = nresL;
+        for (int o = 32; o > 0; o >>= 1) { na += __shfl_xor(na, o, 64); nl += __shfl_xor(nl, o, 64); }
+        if (lane == 0) { sE[wave] = e; sC[wave * 4 + 0] = na; sC[wave * 4 + 1] = nl; sC[wave * 4 + 2] = nidCnt; sN[wave] = nidSum; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double e = 0; int na = 0, nl = 0, nc = 0; float ns = 0;
+        for (int wv = 0; wv < LD_WAVES; wv++) { e += sE[wv]; na += sC[wv * 4 + 0]; nl += sC[wv * 4 + 1]; nc += sC[wv * 4 + 2]; ns += sN[wv]; }
+        nxt.chunkEnergy[chunk] = e;
+        nxt.chunkCnt[chunk * 2 + 0] = na; nxt.chunkCnt[chunk * 2 + 1] = nl;
+        nxt.chunkNID[chunk * 2 + 0] = ns; nxt.chunkNID[chunk * 2 + 1] = (float) nc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// launcher
+// ---------------------------------------------------------------------------------------------------------
+size_t ba_linearize_lds_bytes(int FS, bool hasL) {
+    size_t fl = (size_t) FS * (sizeof(DevPair) / 4) + 2 * (size_t) FS * 64 + (size_t) LD_WAVES * FS * LD_TOPN + (hasL ? (size_t) FS * LD_TOPN : 0);
+    return fl * sizeof(float) + 256;
+}
+
+template <int NSG, bool HAS_L, bool FIX>
+static hipError_t launch_one(const BaPtrs &B, const BaDims &D, const ResSet &cur, const ResSet &nxt, const ldso_settings_t &S, hipStream_t st) {
+    size_t lds = ba_linearize_lds_bytes(D.FS, HAS_L);
+    auto kfn = k_linearize<NSG, HAS_L, FIX>;
+    if (lds > 48 * 1024) hipFuncSetAttribute((const void *) kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+    hipLaunchKernelGGL(kfn, dim3(D.nChunks), dim3(64 * LD_WAVES), lds, st, B, D, cur, nxt, S);
+    return hipGetLastError();
+}
+
+hipError_t ba_launch_linearize(const BaPtrs &B, const BaDims &D, const ResSet &cur, const ResSet &nxt, const ldso_settings_t &S,
+                               bool hasL, bool fix, hipStream_t st) {
+    if (D.nChunks == 0) return hipSuccess;
+    if (D.nsg == 1) {
+        if (hasL) return fix ? launch_one<1, true, true>(B, D, cur, nxt, S, st) : launch_one<1, true, false>(B, D, cur, nxt, S, st);
+        return fix ? launch_one<1, false, true>(B, D, cur, nxt, S, st) : launch_one<1, false, false>(B, D, cur, nxt, S, st);
+    } else {
+        if (hasL) return fix ? launch_one<2, true, true>(B, D, cur, nxt, S, st) : launch_one<2, true, false>(B, D, cur, nxt, S, st);
+        return fix ? launch_one<2, false, true>(B, D, cur, nxt, S, st) : launch_one<2, false, false>(B, D, cur, nxt, S, st);
+    }
+}

@@ -1,0 +1,257 @@
+// ba_reduce.hip — second stage of the Hessian accumulation (gfx950).
+//
+// Part A (one block per (host,target) pair; reference AccumulatedTopHessianSSE::stitchDoubleInternal,
+//   src/internal/OptimizationBackend/AccumulatedTopHessian.cc:193-255): sum the per-block 91-entry
+//   partials of the pair in double, rebuild the 13x13 block and lift it through the adjoints:
+//   Ad_h A88 Ad_h^T, Ad_t A88 Ad_t^T, Ad_h A88 Ad_t^T, Ad_h A8c, Ad_t A8c, Acc and the b parts.
+// Part B (Schur complement; reference AccumulatedSCHessianSSE::addPoint + stitchDoubleInternal,
+//   .../AccumulatedSCHessian.cc:9-119): with the lifted rows g_p produced by the linearize kernel the
+//   whole F^3-block stitch collapses into one symmetric rank-P update  M = sum_p HdiF_p g_p g_p^T,
+//   computed here with exact-fp32 matrix cores (v_mfma_f32_16x16x4_f32), split over LD_SC_SPLITS
+//   K-ranges.  This is the only MFMA use on the path ("the final small dense Hessian accumulate").
+#include <hip/hip_runtime.h>
+#include "ba_dev.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define SC_SLAB 64
+#define SC_MAXT 12      // tiles per wave: GSP=144 (FS=16) -> 45 upper tiles / 4 waves
+
+__host__ __device__ constexpr int tri13r(int r, int c) { return r * 13 - (r * (r - 1)) / 2 + (c - r); }
+
+// chunkStart[h]..chunkStart[h+1]: chunks of host h (chunks are host-major)
+__global__ __launch_bounds__(256) void k_reduce(BaPtrs B, BaDims D, ResSet S, const int32_t *__restrict__ chunkStart, int hasL, int GSP) {
+    const int F = D.F, FS = D.FS;
+    const int nPairBlocks = F * F * (hasL ? 2 : 1);
+    const int tid = threadIdx.x;
+    __shared__ double sA[13 * 13];
+    __shared__ double sT[2][64];
+
+    if ((int) blockIdx.x < nPairBlocks) {
+        // ------------------------------- Part A ---------------------------------------------------------
+        const int which = blockIdx.x / (F * F);     // 0 = A, 1 = L
+        const int pair = blockIdx.x % (F * F);
+        const int h = pair / F, t = pair % F;        // pairC index [h*F + t]
+        const float *part = which ? S.topL : S.topA;
+        const int c0 = chunkStart[h], c1 = chunkStart[h + 1];
+        if (tid < LD_TOPN) {
+            double a = 0;
+            for (int c = c0; c < c1; c++) a += (double) part[((size_t) c * FS + t) * LD_TOPN + tid];
+            // unpack to symmetric 13x13
+            int r = 0, rem = tid;
+            while (rem >= 13 - r) { rem -= 13 - r; r++; }
+            int cidx = r + rem;
+            sA[r * 13 + cidx] = a;
+            sA[cidx * 13 + r] = a;
+        }
+        __syncthreads();
+        double *out = B.pairC + ((size_t) which * F * F + pair) * LD_PAIRC;
+        const double *AH = B.adHost + (size_t) (h + t * F) * 64, *AT = B.adTarget + (size_t) (h + t * F) * 64;
+        if (tid < 64) {
+            int i = tid >> 3, j = tid & 7;
+            double th = 0, tt = 0;
+            for (int m = 0; m < 8; m++) { th += AH[i * 8 + m] * sA[(4 + m) * 13 + 4 + j]; tt += AT[i * 8 + m] * sA[(4 + m) * 13 + 4 + j]; }
+            sT[0][tid] = th; sT[1][tid] = tt;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            int i = tid >> 3, j = tid & 7;
+            double hh = 0, tt = 0, ht = 0;
+            for (int m = 0; m < 8; m++) { hh += sT[0][i * 8 + m] * AH[j * 8 + m]; tt += sT[1][i * 8 + m] * AT[j * 8 + m]; ht += sT[0][i * 8 + m] * AT[j * 8 + m]; }
+            out[tid] = hh; out[64 + tid] = tt; out[128 + tid] = ht;
+        } else if (tid < 64 + 32) {
+            int e = tid - 64, i = e >> 2, c = e & 3;
+            double hc = 0, tc = 0;
+            for (int m = 0; m < 8; m++) { hc += AH[i * 8 + m] * sA[(4 + m) * 13 + c]; tc += AT[i * 8 + m] * sA[(4 + m) * 13 + c]; }
+            out[192 + e] = hc; out[224 + e] = tc;
+        } else if (tid < 96 + 16) {
+            int e = tid - 96;
+            out[256 + e] = sA[(e >> 2) * 13 + (e & 3)];
+        } else if (tid < 112 + 8) {
+            int i = tid - 112;
+            double bh = 0, bt = 0;
+            for (int m = 0; m < 8; m++) { bh += AH[i * 8 + m] * sA[(4 + m) * 13 + 12]; bt += AT[i * 8 + m] * sA[(4 + m) * 13 + 12]; }
+            out[272 + i] = bh; out[280 + i] = bt;
+        } else if (tid < 120 + 4) {
+            int i = tid - 120;
+            out[288 + i] = sA[i * 13 + 12];
+        }
+        return;
+    }
+
+    // ----------------------------------- Part B -----------------------------------------------------------
+    // M[sp] = sum over this split's points of  w_p * r_p r_p^T  with r_p = G row (GS entries, zero padded
+    // to GSP = multiple of 16) and w_p = HdiF_p = r_p[8*FS+5].  Upper-triangular 16x16 tiles only.
+    // G rows are staged through LDS in slabs of SC_SLAB points (coalesced row copies), then consumed by
+    // v_mfma_f32_16x16x4_f32: A[i][k] = w_k r_k[ti*16+i], B[k][j] = r_k[tj*16+j].
+    extern __shared__ __attribute__((aligned(16))) float sG[];      // [SC_SLAB][GSP] + [SC_SLAB] weights
+    const int sp = blockIdx.x - nPairBlocks;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int nT = GSP / 16;
+    const int P0 = D.pBegin, Pn = D.pEnd - D.pBegin;
+    const int per = (Pn + LD_SC_SPLITS - 1) / LD_SC_SPLITS;
+    const int pa = P0 + sp * per, pb = min(P0 + Pn, pa + per);
+    const int GS = D.GS;
+    const int li = lane & 15, lk = lane >> 4;
+    float *sWt = sG + SC_SLAB * GSP;
+    float *Mout = B.scPart + (size_t) sp * GSP * GSP;
+    // this wave's tiles (upper triangle, round-robin), at most SC_MAXT per wave
+    int myTi[SC_MAXT], myTj[SC_MAXT], nMine = 0;
+    {
+        int tileIdx = 0;
+        for (int ti = 0; ti < nT; ti++)
+            for (int tj = ti; tj < nT; tj++, tileIdx++)
+                if ((tileIdx & 3) == wave && nMine < SC_MAXT) { myTi[nMine] = ti; myTj[nMine] = tj; nMine++; }
+    }
+    f32x4 acc[SC_MAXT];
+#pragma unroll
+    for (int q = 0; q < SC_MAXT; q++) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int base = pa; base < pb; base += SC_SLAB) {
+        const int cnt = min(SC_SLAB, pb - base);
+        __syncthreads();
+        for (int e = tid; e < SC_SLAB * GSP; e += 256) {
+            int r = e / GSP, c = e % GSP;
+            sG[e] = (r < cnt && c < GS) ? S.G[(size_t) (base + r) * GS + c] : 0.f;
+        }
+        __syncthreads();
+        if (tid < SC_SLAB) sWt[tid] = sG[tid * GSP + 8 * FS + 5];
+        __syncthreads();
+        for (int k0 = 0; k0 < SC_SLAB; k0 += 4) {
+            if (k0 >= cnt) break;
+            const float *row = sG + (k0 + lk) * GSP;
+            const float w = sWt[k0 + lk];
+#pragma unroll
+            for (int q = 0; q < SC_MAXT; q++) {
+                if (q < nMine) {
+                    float a = row[myTi[q] * 16 + li] * w;
+                    float b = row[myTj[q] * 16 + li];
+                    acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[q], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // C/D layout: col = lane&15, row = (lane>>4)*4 + r
+#pragma unroll
+    for (int q = 0; q < SC_MAXT; q++)
+        if (q < nMine)
+#pragma unroll
+            for (int r = 0; r < 4; r++) Mout[(size_t) (myTi[q] * 16 + lk * 4 + r) * GSP + myTj[q] * 16 + li] = acc[q][r];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_gather — one thread per entry of the stitched systems (n*n + n entries): sums the pair contributions
+// (fixed order) and the Schur K-split partials, adds priors, and assembles HFinal / bFinal of
+// EnergyFunctional::solveSystemF (EnergyFunctional.cc:257-291, default solver mode):
+//   HFinal = (H_L + H_M + H_A) with diag*(1+lambda) - H_sc/(1+lambda);  bFinal = b_L + (b_M + H_M delta) + b_A - b_sc.
+// Reference: AccumulatedTopHessian.h:64-105 (symmetrisation), AccumulatedSCHessian.h:64-98.
+// mode 0: single GPU;  mode 1: export rank-local sums into the all-reduce buffer (no HFinal);
+// mode 2: import all-reduced sums, then assemble HFinal/bFinal.
+// sys layout: HA n*n | bA n | HL | bL | Hsc | bsc | HFinal | bFinal.
+// ---------------------------------------------------------------------------------------------------------
+static __device__ __forceinline__ int g_col(int i, int FS) { return (i < 4) ? (8 * FS + i) : (i - 4); }
+
+static __device__ __forceinline__ double top_entry(const double *PC, int F, int i, int j) {
+    // i, j in reference ordering [calib 4 | frames 8F]; j == -1 -> b entry
+    double v = 0;
+    if (j < 0) {
+        if (i < 4) { for (int pq = 0; pq < F * F; pq++) v += PC[(size_t) pq * LD_PAIRC + 288 + i]; }
+        else {
+            int f = (i - 4) >> 3, a = (i - 4) & 7;
+            for (int t = 0; t < F; t++) v += PC[(size_t) (f * F + t) * LD_PAIRC + 272 + a];
+            for (int h = 0; h < F; h++) v += PC[(size_t) (h * F + f) * LD_PAIRC + 280 + a];
+        }
+        return v;
+    }
+    if (i < 4 && j < 4) { for (int pq = 0; pq < F * F; pq++) v += PC[(size_t) pq * LD_PAIRC + 256 + i * 4 + j]; return v; }
+    if (i < 4 || j < 4) {
+        int fi = (i < 4) ? j : i, c = (i < 4) ? i : j;
+        int f = (fi - 4) >> 3, a = (fi - 4) & 7;
+        for (int t = 0; t < F; t++) v += PC[(size_t) (f * F + t) * LD_PAIRC + 192 + a * 4 + c];
+        for (int h = 0; h < F; h++) v += PC[(size_t) (h * F + f) * LD_PAIRC + 224 + a * 4 + c];
+        return v;
+    }
+    int f = (i - 4) >> 3, a = (i - 4) & 7, g = (j - 4) >> 3, c = (j - 4) & 7;
+    if (f == g) {
+        for (int t = 0; t < F; t++) v += PC[(size_t) (f * F + t) * LD_PAIRC + a * 8 + c];
+        for (int h = 0; h < F; h++) v += PC[(size_t) (h * F + f) * LD_PAIRC + 64 + a * 8 + c];
+        return v;
+    }
+    if (f < g) return PC[(size_t) (f * F + g) * LD_PAIRC + 128 + a * 8 + c] + PC[(size_t) (g * F + f) * LD_PAIRC + 128 + c * 8 + a];
+    return PC[(size_t) (g * F + f) * LD_PAIRC + 128 + c * 8 + a] + PC[(size_t) (f * F + g) * LD_PAIRC + 128 + a * 8 + c];
+}
+
+__global__ __launch_bounds__(256) void k_gather(BaPtrs B, BaDims D, ResSet S, int hasL, int hasPrior, int GSP, double lambdaIn, int solverMode,
+                                                float calibPrior, int mode, double *rbuf) {
+    const int F = D.F, n = D.n, FS = D.FS;
+    const int N = n * n + n;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    double lambda = lambdaIn;
+    if (solverMode & LDSO_SOLVER_USE_GN) lambda = 0;
+    if (solverMode & LDSO_SOLVER_FIX_LAMBDA) lambda = 1e-5;
+    const size_t blk = (size_t) n * n + n;
+    double *HA = B.sys, *bA = HA + n * n, *HL = bA + n, *bL = HL + n * n, *Hsc = bL + n, *bsc = Hsc + n * n, *HF = bsc + n, *bF = HF + n * n;
+    if (mode == 1 && e >= N && e < N + D.P) {
+        // newest-frame energy candidates of the local points: value+1, zero elsewhere (see post_thresh)
+        int i = e - N;
+        double v = 0.0;
+        if (i >= D.pBegin && i < D.pEnd) { float c = S.candE[i]; if (c >= 0.0f) v = (double) c + 1.0; }
+        rbuf[3 * blk + 8 + i] = v;
+    }
+    if (e >= N) return;
+    const int i = (e < n * n) ? e / n : (e - n * n), j = (e < n * n) ? e % n : -1;
+    double prH = 0, prb = 0;      // prior contributions (L pass only, AccumulatedTopHessian.cc:246-254)
+    if (j < 0) prb = (i < 4) ? (double) calibPrior * (double) B.calib->cDeltaF[i] : B.frames[(i - 4) >> 3].prior[(i - 4) & 7] * B.frames[(i - 4) >> 3].delta_prior[(i - 4) & 7];
+    else if (i == j) prH = (i < 4) ? (double) calibPrior : B.frames[(i - 4) >> 3].prior[(i - 4) & 7];
+
+    double vA, vL, vS;
+    if (mode == 2) {
+        vA = rbuf[e]; vL = rbuf[blk + e]; vS = rbuf[2 * blk + e];
+    } else {
+        vA = top_entry(B.pairC, F, i, j);
+        vL = hasL ? top_entry(B.pairC + (size_t) F * F * LD_PAIRC, F, i, j) : 0.0;
+        // Schur: only upper-triangular 16x16 tiles are stored; a diagonal tile holds both triangles
+        int ci = g_col(i, FS), cj = (j >= 0) ? g_col(j, FS) : (8 * FS + 4);
+        int r = min(ci, cj), c = max(ci, cj);
+        size_t off = (r / 16 == c / 16) ? ((size_t) ci * GSP + cj) : ((size_t) r * GSP + c);
+        float q[LD_SC_SPLITS];
+#pragma unroll
+        for (int sp = 0; sp < LD_SC_SPLITS; sp++) q[sp] = B.scPart[(size_t) sp * GSP * GSP + off];
+        vS = 0;
+#pragma unroll
+        for (int sp = 0; sp < LD_SC_SPLITS; sp++) vS += (double) q[sp];
+    }
+    if (mode == 1) { rbuf[e] = vA; rbuf[blk + e] = vL; rbuf[2 * blk + e] = vS; return; }
+    if (j >= 0) { HA[e] = vA; HL[e] = vL + prH; Hsc[e] = vS; }
+    else { bA[i] = vA; bL[i] = vL + prb; bsc[i] = vS; }
+    // HFinal / bFinal
+    if (j >= 0) {
+        double v = (vL + prH) + (hasPrior ? B.HM[e] : 0.0) + vA;
+        if (i == j) v *= (1 + lambda);
+        v -= vS * (double) (1.0f / (1 + lambda));
+        HF[e] = v;
+    } else {
+        double s = 0;
+        if (hasPrior) {
+            s = B.bM[i];
+            for (int jj = 0; jj < n; jj++) {
+                double dj = (jj < 4) ? (double) B.calib->cDeltaF[jj] : B.frames[(jj - 4) >> 3].delta[(jj - 4) & 7];
+                s += B.HM[(size_t) i * n + jj] * dj;
+            }
+        }
+        bF[i] = (vL + prb) + s + vA - vS;
+    }
+}
+
+hipError_t ba_launch_gather(const BaPtrs &B, const BaDims &D, const ResSet &S, bool hasL, bool hasPrior, int GSP, double lambda,
+                            const ldso_settings_t &St, int mode, double *rbuf, hipStream_t st) {
+    int N = D.n * D.n + D.n + (mode == 1 ? D.P : 0);
+    hipLaunchKernelGGL(k_gather, dim3((N + 255) / 256), dim3(256), 0, st, B, D, S, hasL ? 1 : 0, hasPrior ? 1 : 0, GSP, lambda, St.solverMode,
+                       St.initialCalibHessian, mode, rbuf);
+    return hipGetLastError();
+}
+
+hipError_t ba_launch_reduce(const BaPtrs &B, const BaDims &D, const ResSet &S, const int32_t *chunkStart, bool hasL, int GSP, hipStream_t st) {
+    int nb = D.F * D.F * (hasL ? 2 : 1) + LD_SC_SPLITS;
+    size_t lds = (size_t) (SC_SLAB * GSP + SC_SLAB) * sizeof(float);
+    hipLaunchKernelGGL(k_reduce, dim3(nb), dim3(256), lds, st, B, D, S, chunkStart, hasL ? 1 : 0, GSP);
+    return hipGetLastError();
+}

@@ -1,0 +1,592 @@
+// ba_solve.hip — the single-workgroup "control" kernel of a Gauss-Newton iteration (gfx950).
+//
+// Everything the reference does sequentially on the host between two residual passes runs here in one
+// launch of one 256-thread block, selected by flag bits, so that a GN iteration needs no host sync:
+//   SK_POST     FullSystem::linearizeAll tail: energy sum + setNewFrameEnergyTH (FullSystem.cc:1762-1793)
+//   SK_ADJ      EnergyFunctional::setAdjointsF (EnergyFunctional.cc:431-489) + gauge nullspace basis
+//               for orthogonalize (EnergyFunctional.cc:685-717, FullSystem.cc:1711-1760)
+//   SK_GATHER   sum pair contributions / Schur partials into H_A,b_A,H_L,b_L,H_sc,b_sc
+//               (AccumulatedTopHessian.h:64-105, AccumulatedSCHessian.h:64-98)
+//   SK_SOLVE    EnergyFunctional::solveSystemF (EnergyFunctional.cc:240-351, default solver mode) and the
+//               frame part of resubstituteF_MT (:491-516)
+//   SK_BACKUP   FullSystem::backupState (FullSystem.cc:1625-1673)
+//   SK_STEP     FullSystem::doStepFromBackup frame/calib part + canbreak (FullSystem.cc:1546-1623)
+//   SK_LOADBK   FullSystem::loadSateBackup frame/calib part (FullSystem.cc:1675-1692)
+//   SK_PRECALC  FullSystem::setPrecalcValues: FrameFramePrecalc::Set for F^2 pairs + setDeltaF
+//               (FullSystem.cc:1423-1431, FrameFramePrecalc.cc:6-35, EnergyFunctional.cc:403-429)
+//   SK_REANCHOR end of optimize(): newest frame setEvalPT(PRE_worldToCam, newStateZero) (FullSystem.cc:833-841)
+// All dense math is fp64 like the reference.  The factorisation is Eigen's LDLT (diagonal pivoting).
+#include <hip/hip_runtime.h>
+#include "ba_dev.h"
+#include "lie_dev.h"
+#include "ba_solve.h"
+
+#define NT 256
+#define TH_CAP 8192      // candidate energies staged in LDS up to this many points
+
+static __device__ __forceinline__ double wave_sum(double v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// setNewFrameEnergyTH: k-th smallest of the newest frame's residual energies by a 4-pass radix select
+// ---------------------------------------------------------------------------------------------------------
+static __device__ void post_sums(const BaPtrs &B, const BaDims &D, const ResSet &S, double *sD /*8 doubles*/) {
+    const int tid = threadIdx.x;
+    // ---- energy sum + counters over the chunks, fixed order -----------------------------------------------
+    {
+        double e = 0; double na = 0, nl = 0, ns = 0, nc = 0;
+        for (int c = tid; c < D.nChunks; c += NT) {
+            e += S.chunkEnergy[c]; na += S.chunkCnt[c * 2]; nl += S.chunkCnt[c * 2 + 1];
+            ns += (double) S.chunkNID[c * 2]; nc += (double) S.chunkNID[c * 2 + 1];
+        }
+        e = wave_sum(e); na = wave_sum(na); nl = wave_sum(nl); ns = wave_sum(ns); nc = wave_sum(nc);
+        if ((tid & 63) == 0) { sD[(tid >> 6)] = e; sD[4 + (tid >> 6)] = na; }
+        __syncthreads();
+        if (tid == 0) { B.scalars[0] = sD[0] + sD[1] + sD[2] + sD[3]; B.scalars[1] = sD[4] + sD[5] + sD[6] + sD[7]; }
+        __syncthreads();
+        if ((tid & 63) == 0) { sD[(tid >> 6)] = nl; sD[4 + (tid >> 6)] = ns; }
+        __syncthreads();
+        if (tid == 0) { B.scalars[2] = sD[0] + sD[1] + sD[2] + sD[3]; B.scalars[6] = sD[4] + sD[5] + sD[6] + sD[7]; }
+        __syncthreads();
+        if ((tid & 63) == 0) sD[(tid >> 6)] = nc;
+        __syncthreads();
+        if (tid == 0) B.scalars[7] = sD[0] + sD[1] + sD[2] + sD[3];
+        __syncthreads();
+    }
+}
+
+// candidates: active-set residuals targeting the newest frame with state_NewEnergyWithOutlier >= 0,
+// written compactly by the linearize kernel (S.candE[p], -1 = no candidate).
+// extE (multi-GPU): all-reduced array of P doubles holding value+1 for candidates and 0 otherwise.
+static __device__ void post_thresh(const BaPtrs &B, const BaDims &D, const ResSet &S, const ldso_settings_t &St,
+                                   const double *extE, float *sVal /*LDS, TH_CAP floats*/, int *sHist /*256 ints*/, int *sI /*8 ints*/) {
+    const int tid = threadIdx.x;
+    const int F = D.F;
+    const int tN = F - 1;
+    const int nItems = D.P;
+    const bool inLds = nItems <= TH_CAP;
+    // stage the candidate values (negative = not a candidate)
+    for (int i0 = tid; i0 < nItems; i0 += NT * 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            int i = i0 + u * NT;
+            v[u] = -1.0f;
+            if (i < nItems) {
+                if (extE != nullptr) { double d = extE[i]; v[u] = (d > 0.0) ? (float) (d - 1.0) : -1.0f; }
+                else if (i >= D.pBegin && i < D.pEnd) v[u] = S.candE[i];
+            }
+        }
+        if (inLds) {
+#pragma unroll
+            for (int u = 0; u < 8; u++) { int i = i0 + u * NT; if (i < nItems) sVal[i] = v[u]; }
+        }
+    }
+    __syncthreads();
+    auto value = [&](int i) -> float {
+        if (inLds) return sVal[i];
+        if (extE != nullptr) { double d = extE[i]; return (d > 0.0) ? (float) (d - 1.0) : -1.0f; }
+        return (i >= D.pBegin && i < D.pEnd) ? S.candE[i] : -1.0f;
+    };
+    int cnt = 0;
+    for (int i = tid; i < nItems; i += NT) if (value(i) >= 0.0f) cnt++;
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    if ((tid & 63) == 0) sI[tid >> 6] = cnt;
+    __syncthreads();
+    const int total = sI[0] + sI[1] + sI[2] + sI[3];
+    __syncthreads();
+    DevFrame &nf = B.frames[tN];
+    if (total == 0) {
+        if (tid == 0) nf.frameEnergyTH = 12 * 12 * 8;
+        __syncthreads();
+    } else {
+        int kth = (int) (St.frameEnergyTHN * (float) total);
+        unsigned prefix = 0, mask = 0;
+        for (int pass = 3; pass >= 0; pass--) {
+            sHist[tid] = 0;
+            __syncthreads();
+            const int shift = pass * 8;
+            for (int i = tid; i < nItems; i += NT) {
+                float v = value(i);
+                if (v >= 0.0f) {
+                    unsigned u = __float_as_uint(v);
+                    if ((u & mask) == prefix) atomicAdd(&sHist[(u >> shift) & 0xFF], 1);
+                }
+            }
+            __syncthreads();
+            {
+                const int c = sHist[tid];
+                int inc = c;
+                for (int o = 1; o < 64; o <<= 1) { int v = __shfl_up(inc, o, 64); if ((tid & 63) >= o) inc += v; }
+                if ((tid & 63) == 63) sI[tid >> 6] = inc;
+                __syncthreads();
+                int base = 0;
+                for (int wv = 0; wv < (tid >> 6); wv++) base += sI[wv];
+                inc += base;
+                const int exc = inc - c;
+                __syncthreads();
+                if (c > 0 && exc <= kth && kth < inc) { sI[4] = tid; sI[5] = kth - exc; }
+            }
+            __syncthreads();
+            prefix |= ((unsigned) sI[4]) << shift;
+            mask |= 0xFFu << shift;
+            kth = sI[5];
+            __syncthreads();
+        }
+        if (tid == 0) {
+            float nthElement = sqrtf(__uint_as_float(prefix));
+            float th = nthElement * St.frameEnergyTHFacMedian;
+            th = 26.0f * St.frameEnergyTHConstWeight + th * (1 - St.frameEnergyTHConstWeight);
+            th = th * th;
+            th *= St.overallEnergyTHWeight * St.overallEnergyTHWeight;
+            nf.frameEnergyTH = th;
+        }
+        __syncthreads();
+    }
+    // refresh thMax of the pairs (the next linearize reads it)
+    for (int i = tid; i < F * F; i += NT) {
+        int h = i / F, t = i % F;
+        B.pairs[i].thMax = fmaxf(B.frames[h].frameEnergyTH, B.frames[t].frameEnergyTH);
+    }
+    __syncthreads();
+}
+
+static __device__ void frame_nullspaces(DevFrame &f) { ld::frame_nullspaces(f.evalPT, f.state_zero[6], f.ab_exposure, f.ns_pose, f.ns_scale, f.ns_affine); }
+
+static __device__ __forceinline__ void aff_from_to(float expF, float expT, float aF, float bF, float aT, float bT, float &a, float &b) {
+    if (expF == 0 || expT == 0) { expT = expF = 1; }
+    a = expf(aT - aF) * expT / expF;
+    b = bT - a * bF;
+}
+
+// setAdjointsF + nullspace basis U (n x 7, columns with dropped singular values zeroed)
+static __device__ void set_adjoints(const BaPtrs &B, const BaDims &D, const ldso_settings_t &St, double *sW /*LDS scratch >= 7*n + 64 doubles*/) {
+    const int tid = threadIdx.x, F = D.F, n = D.n;
+    for (int i = tid; i < F * F; i += NT) {
+        int h = i % F, t = i / F;      // slot h + t*F
+        const DevFrame &fh = B.frames[h], &ft = B.frames[t];
+        double Ti[12], T[12], Adj[36];
+        ld::se3_inv(fh.evalPT, Ti);
+        ld::se3_mul(ft.evalPT, Ti, T);
+        ld::se3_adj(T, Adj);
+        double AH[64], AT[64];
+        for (int r = 0; r < 8; r++) for (int c = 0; c < 8; c++) { AH[r * 8 + c] = (r == c) ? 1.0 : 0.0; AT[r * 8 + c] = (r == c) ? 1.0 : 0.0; }
+        for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) AH[r * 8 + c] = -Adj[c * 6 + r];
+        float a, b;
+        aff_from_to(fh.ab_exposure, ft.ab_exposure, (float) (fh.state_zero[6] * 10.0), (float) (fh.state_zero[7] * 1000.0),
+                    (float) (ft.state_zero[6] * 10.0), (float) (ft.state_zero[7] * 1000.0), a, b);
+        AT[6 * 8 + 6] = -(double) a; AH[6 * 8 + 6] = (double) a; AT[7 * 8 + 7] = -1; AH[7 * 8 + 7] = (double) a;
+        const double rs[8] = {0.5, 0.5, 0.5, 1.0, 1.0, 1.0, 10.0, 1000.0};
+        for (int r = 0; r < 8; r++) for (int c = 0; c < 8; c++) { AH[r * 8 + c] *= rs[r]; AT[r * 8 + c] *= rs[r]; }
+        for (int e = 0; e < 64; e++) {
+            B.adHost[(size_t) i * 64 + e] = AH[e]; B.adTarget[(size_t) i * 64 + e] = AT[e];
+            B.adHostF[(size_t) i * 64 + e] = (float) AH[e]; B.adTargetF[(size_t) i * 64 + e] = (float) AT[e];
+        }
+    }
+    // ---- N = [6 pose | 1 scale] nullspaces, columns normalised (FullSystem.cc:1711-1760, EF.cc:691-694) -----
+    double *N = sW;               // column-major n x 7
+    for (int i = tid; i < n * 7; i += NT) {
+        int c = i / n, r = i % n;
+        double v = 0;
+        if (r >= 4) {
+            int f = (r - 4) / 8, o = (r - 4) % 8;
+            if (o < 6) {
+                v = (c < 6) ? B.frames[f].ns_pose[o * 6 + c] : B.frames[f].ns_scale[o];
+                v *= (o < 3) ? (double) (1.0f / 0.5f) : (double) (1.0f / 1.0f);
+            }
+        }
+        N[c * n + r] = v;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        // one wave: normalise, then one-sided Jacobi (Hestenes) on the 7 columns
+        const int lane = tid;
+        for (int c = 0; c < 7; c++) {
+            double s = 0;
+            for (int r = lane; r < n; r += 64) s += N[c * n + r] * N[c * n + r];
+            s = sqrt(wave_sum(s));
+            for (int r = lane; r < n; r += 64) N[c * n + r] /= s;
+        }
+        for (int sweep = 0; sweep < 30; sweep++) {
+            double off = 0;
+            for (int p = 0; p < 6; p++)
+                for (int q = p + 1; q < 7; q++) {
+                    double al = 0, be = 0, ga = 0;
+                    for (int r = lane; r < n; r += 64) { double a = N[p * n + r], b = N[q * n + r]; al += a * a; be += b * b; ga += a * b; }
+                    al = wave_sum(al); be = wave_sum(be); ga = wave_sum(ga);
+                    if (ga == 0) continue;
+                    off = fmax(off, fabs(ga) / sqrt(al * be + 1e-300));
+                    double zeta = (be - al) / (2 * ga);
+                    double tt = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1 + zeta * zeta));
+                    double cs = 1 / sqrt(1 + tt * tt), sn = cs * tt;
+                    for (int r = lane; r < n; r += 64) { double a = N[p * n + r], b = N[q * n + r]; N[p * n + r] = cs * a - sn * b; N[q * n + r] = sn * a + cs * b; }
+                }
+            if (off < 1e-15) break;
+        }
+        double sv[7], maxSv = 0;
+        for (int c = 0; c < 7; c++) {
+            double s = 0;
+            for (int r = lane; r < n; r += 64) s += N[c * n + r] * N[c * n + r];
+            sv[c] = sqrt(wave_sum(s));
+            maxSv = fmax(maxSv, sv[c]);
+        }
+        for (int c = 0; c < 7; c++) {
+            bool keep = sv[c] > St.solverModeDelta * maxSv;
+            for (int r = lane; r < n; r += 64) B.nsProj[c * n + r] = keep ? N[c * n + r] / sv[c] : 0.0;
+        }
+    }
+    __syncthreads();
+}
+
+// setPrecalcValues: frames' PRE poses, pair precalc, deltas
+static __device__ void set_precalc(const BaPtrs &B, const BaDims &D) {
+    const int tid = threadIdx.x, F = D.F;
+    DevCalib &C = *B.calib;
+    if (tid < F) {
+        DevFrame &f = B.frames[tid];
+        double ss[6] = {0.5 * f.state[0], 0.5 * f.state[1], 0.5 * f.state[2], 1.0 * f.state[3], 1.0 * f.state[4], 1.0 * f.state[5]};
+        double E[12];
+        ld::se3_exp(ss, E);
+        ld::se3_mul(E, f.evalPT, f.PRE_w2c);
+        ld::se3_inv(f.PRE_w2c, f.PRE_c2w);
+        for (int i = 0; i < 8; i++) { f.delta[i] = f.state[i] - f.state_zero[i]; f.delta_prior[i] = f.state[i]; }
+    }
+    if (tid == 0) {
+        // CalibHessian::setValue derived floats (CalibHessian.h:71-85)
+        double vs[4] = {50.0 * C.value[0], 50.0 * C.value[1], 50.0 * C.value[2], 50.0 * C.value[3]};
+        for (int i = 0; i < 4; i++) C.sf[i] = (float) vs[i];
+        C.si[0] = 1.0f / C.sf[0]; C.si[1] = 1.0f / C.sf[1]; C.si[2] = -C.sf[2] / C.sf[0]; C.si[3] = -C.sf[3] / C.sf[1];
+        for (int i = 0; i < 4; i++) C.cDeltaF[i] = (float) (C.value[i] - C.value_zero[i]);
+    }
+    __syncthreads();
+    for (int i = tid; i < F * F; i += NT) {
+        const int h = i / F, t = i % F;
+        const DevFrame &fh = B.frames[h], &ft = B.frames[t];
+        DevPair pr;
+        double Ti[12], T0[12], T[12];
+        ld::se3_inv(fh.evalPT, Ti);
+        ld::se3_mul(ft.evalPT, Ti, T0);
+        ld::se3_mul(ft.PRE_w2c, fh.PRE_c2w, T);
+        float R[9], tt[3];
+        for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) { pr.R0[r * 3 + c] = (float) T0[r * 4 + c]; R[r * 3 + c] = (float) T[r * 4 + c]; } pr.t0[r] = (float) T0[r * 4 + 3]; tt[r] = (float) T[r * 4 + 3]; }
+        const float fx = C.sf[0], fy = C.sf[1], cx = C.sf[2], cy = C.sf[3];
+        // K^-1 by Eigen's 3x3 cofactor inverse (float)
+        float K[9] = {fx, 0, cx, 0, fy, cy, 0, 0, 1};
+        float Ki[9];
+        {
+            auto cof = [&](int a, int b) { int a1 = (a + 1) % 3, a2 = (a + 2) % 3, b1 = (b + 1) % 3, b2 = (b + 2) % 3; return K[a1 * 3 + b1] * K[a2 * 3 + b2] - K[a1 * 3 + b2] * K[a2 * 3 + b1]; };
+            float k0 = cof(0, 0), k1 = cof(1, 0), k2 = cof(2, 0);
+            float det = (k0 * K[0] + k1 * K[3]) + k2 * K[6];
+            float invdet = 1.0f / det;
+            Ki[0] = k0 * invdet; Ki[1] = k1 * invdet; Ki[2] = k2 * invdet;
+            Ki[3] = cof(0, 1) * invdet; Ki[4] = cof(1, 1) * invdet; Ki[5] = cof(2, 1) * invdet;
+            Ki[6] = cof(0, 2) * invdet; Ki[7] = cof(1, 2) * invdet; Ki[8] = cof(2, 2) * invdet;
+        }
+        float KR[9];
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) KR[r * 3 + c] = (K[r * 3 + 0] * R[0 * 3 + c] + K[r * 3 + 1] * R[1 * 3 + c]) + K[r * 3 + 2] * R[2 * 3 + c];
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) pr.KRKi[r * 3 + c] = (KR[r * 3 + 0] * Ki[0 * 3 + c] + KR[r * 3 + 1] * Ki[1 * 3 + c]) + KR[r * 3 + 2] * Ki[2 * 3 + c];
+        for (int r = 0; r < 3; r++) pr.Kt[r] = (K[r * 3 + 0] * tt[0] + K[r * 3 + 1] * tt[1]) + K[r * 3 + 2] * tt[2];
+        aff_from_to(fh.ab_exposure, ft.ab_exposure, (float) (10.0f * fh.state[6]), (float) (1000.0f * fh.state[7]),
+                    (float) (10.0f * ft.state[6]), (float) (1000.0f * ft.state[7]), pr.aff[0], pr.aff[1]);
+        pr.b0 = (float) (fh.state_zero[7] * 1000.0);
+        pr.thMax = fmaxf(fh.frameEnergyTH, ft.frameEnergyTH);
+        // adHTdeltaF[h + t*F] = delta_h^T adHostF + delta_t^T adTargetF  (EnergyFunctional.cc:403-414)
+        const float *AH = B.adHostF + (size_t) (h + t * F) * 64, *AT = B.adTargetF + (size_t) (h + t * F) * 64;
+        for (int c = 0; c < 8; c++) {
+            float s1 = 0, s2 = 0;
+            for (int k = 0; k < 8; k++) s1 += (float) (fh.state[k] - fh.state_zero[k]) * AH[k * 8 + c];
+            for (int k = 0; k < 8; k++) s2 += (float) (ft.state[k] - ft.state_zero[k]) * AT[k * 8 + c];
+            pr.dp[c] = s1 + s2;
+        }
+        B.pairs[i] = pr;
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// LDL^T of the scaled system in LDS.  The matrix is symmetric positive (semi-)definite after the
+// (diag+10)^-1/2 scaling, so the factorisation runs WITHOUT pivoting (Eigen's LDLT pivots on the
+// diagonal; for SPD input both give the same solution up to rounding).  The right-hand side rides along as
+// row n of the lower triangle, so the forward substitution is part of the factorisation.  One barrier
+// per column: the scaled column L[:,k] is written to the (otherwise unused) upper triangle A[k][i].
+// Zero pivots (all-zero row/column of a PSD matrix) are skipped, like Eigen's D^+ pseudo-inverse.
+// ---------------------------------------------------------------------------------------------------------
+// The LDS matrix is padded to M = 16*NB rows/cols (M >= n+1): rows/cols [0,n) system, row n = rhs, the rest
+// padding (zeros).  The loops below are branch-free per thread: fixed NB x NB register tiles, masked stores.
+template <int NB>
+static __device__ void ldlt_factor_aug_t(double *A, int lda, int n) {
+    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    for (int k = 0; k < n; k++) {
+        const double d = A[k * lda + k];
+        const double invd = (fabs(d) > 2.2250738585072014e-308) ? 1.0 / d : 0.0;
+        const int a0 = (k + 1) >> 4;                 // first 16-row band that still has rows > k
+        double lik[NB], ljk[NB], v[NB][NB];
+#pragma unroll
+        for (int a = 0; a < NB; a++) { lik[a] = A[(ty + 16 * a) * lda + k]; ljk[a] = A[(tx + 16 * a) * lda + k]; }
+#pragma unroll
+        for (int a = 0; a < NB; a++)
+#pragma unroll
+            for (int b = 0; b <= a; b++) v[a][b] = (a >= a0) ? A[(ty + 16 * a) * lda + tx + 16 * b] : 0.0;
+#pragma unroll
+        for (int a = 0; a < NB; a++) {
+            const int i = ty + 16 * a;
+            const double f = lik[a] * invd;
+#pragma unroll
+            for (int b = 0; b <= a; b++) {
+                const int j = tx + 16 * b;
+                const bool m = (a >= a0) && (b >= a0) && (i > k) && (j > k) && (j <= i) && (j < n) && (i <= n);
+                if (a >= a0 && b >= a0) A[i * lda + j] = m ? (v[a][b] - f * ljk[b]) : v[a][b];
+            }
+            if (tx == 0 && i > k && i < n) A[k * lda + i] = f;            // L[i][k] -> upper triangle (row k is finished)
+        }
+        __syncthreads();
+    }
+}
+
+static __device__ void ldlt_factor_aug(double *A, int lda, int n) {
+    if (n + 1 <= 64) ldlt_factor_aug_t<4>(A, lda, n);
+    else if (n + 1 <= 112) ldlt_factor_aug_t<7>(A, lda, n);
+    else ldlt_factor_aug_t<9>(A, lda, n);
+}
+
+static __device__ __forceinline__ double readlane_f64(double v, int lane) {
+    unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    unsigned lo = (unsigned) __builtin_amdgcn_readlane((int) (u & 0xFFFFFFFFu), lane);
+    unsigned hi = (unsigned) __builtin_amdgcn_readlane((int) (u >> 32), lane);
+    return __builtin_bit_cast(double, ((unsigned long long) hi << 32) | lo);
+}
+
+// back substitution by wave 0: x = L^-T D^+ z, z = rhs row n, L[k][i] = A[i][k] (upper triangle, k > i)
+static __device__ void ldlt_back_wave(const double *A, int lda, int n, double *x) {
+    const int lane = threadIdx.x;
+    if (n < 64) {
+        // lane i owns x_i and row i of L^T in registers; x_k is broadcast with v_readlane (padded matrix: no guards)
+        double row[64];
+#pragma unroll
+        for (int k = 0; k < 64; k++) { double a = A[lane * lda + k]; row[k] = (k > lane && k < n) ? a : 0.0; }
+        const double d = A[lane * lda + lane];
+        const double z = A[n * lda + lane];
+        double xi = (lane < n && fabs(d) > 2.2250738585072014e-308) ? z / d : 0.0;
+#pragma unroll
+        for (int k = 63; k >= 1; k--) { double xk = readlane_f64(xi, k); xi -= row[k] * xk; }
+        if (lane < n) x[lane] = xi;
+        return;
+    }
+    for (int i = lane; i < n; i += 64) { double d = A[i * lda + i]; x[i] = (fabs(d) > 2.2250738585072014e-308) ? A[n * lda + i] / d : 0.0; }
+    __builtin_amdgcn_wave_barrier();
+    for (int k = n - 1; k > 0; k--) {           // column oriented: x_i -= L[k][i] x_k for i < k
+        const double xk = x[k];
+        for (int i = lane; i < k; i += 64) x[i] -= A[i * lda + k] * xk;
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void k_solve(BaPtrs B, BaDims D, ResSet S, ldso_settings_t St, SolveArgs A) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int tid = threadIdx.x, F = D.F, n = D.n;
+    const int Mp = (n + 1 <= 64) ? 64 : (n + 1 <= 112) ? 112 : 144;      // padded dimension, see ldlt_factor_aug_t
+    const int lda = Mp + 1;
+    double *sA = sm;                         // (n+1)*(n+1): system + rhs row
+    double *sx = sA + (size_t) Mp * lda;      // n
+    double *sW = sx + n;                     // scratch: 7n + 64
+    int *sTr = (int *) (sW + 7 * n + 64);    // n
+    int *sHist = sTr + n + (n & 1);          // 256
+    int *sI = sHist + 256;                   // 8
+    const unsigned fl = A.flags;
+    long long t0_ = clock64();
+#define STAMP(i) do { __syncthreads(); if (tid == 0) B.energyLog[40 + (i)] = (double) (clock64() - t0_); } while (0)
+
+    if (fl & SK_COLLECT) {
+        // FullSystem::optimize preamble: resetOOB on every non-linearised residual (FullSystem.cc:744-748)
+        for (int i = tid; i < D.P * D.FS; i += NT)
+            if (B.rflat[i] >= 0 && !B.rlin[i]) { S.state[i] = 0; S.energy[i] = 0.0f; }
+        __syncthreads();
+    }
+    if (fl & SK_POST) post_sums(B, D, S, sW);
+    STAMP(0);
+
+    if (fl & SK_REANCHOR) {
+        if (tid == 0) {
+            DevFrame &f = B.frames[F - 1];
+            for (int i = 0; i < 12; i++) f.evalPT[i] = f.PRE_w2c[i];
+            double a = f.state[6], b = f.state[7];
+            for (int i = 0; i < 10; i++) { f.state[i] = 0; f.state_zero[i] = 0; }
+            f.state[6] = a; f.state[7] = b; f.state_zero[6] = a; f.state_zero[7] = b;
+            frame_nullspaces(f);
+        }
+        __syncthreads();
+    }
+    if (fl & SK_ADJ) set_adjoints(B, D, St, sW);
+
+    double *HF = B.sys + 3 * (n * n + n), *bF = HF + n * n;
+    if (fl & SK_EXPORT) {
+        // multi-GPU: rank-local scalar sums ride in the all-reduce buffer
+        double na = 0, nl = 0;
+        for (int c = tid; c < D.nChunks; c += NT) { na += S.chunkCnt[c * 2]; nl += S.chunkCnt[c * 2 + 1]; }
+        na = wave_sum(na); nl = wave_sum(nl);
+        if ((tid & 63) == 0) { sW[tid >> 6] = na; sW[4 + (tid >> 6)] = nl; }
+        __syncthreads();
+        if (tid == 0) { double *sc = A.reduceOut + 3 * (n * n + n); sc[0] = B.scalars[0]; sc[1] = B.scalars[1]; sc[2] = B.scalars[2]; sc[3] = B.scalars[6]; sc[4] = B.scalars[7];
+                        sc[5] = sW[0] + sW[1] + sW[2] + sW[3]; sc[6] = sW[4] + sW[5] + sW[6] + sW[7]; sc[7] = 0; }
+        __syncthreads();
+    }
+    if (fl & SK_FROMREDUCED) {
+        const double *sc = A.reduceIn + 3 * (n * n + n);
+        if (tid == 0) { B.scalars[0] = sc[0]; B.scalars[1] = sc[1]; B.scalars[2] = sc[2]; B.scalars[6] = sc[3]; B.scalars[7] = sc[4]; B.scalars[9] = sc[5]; B.scalars[10] = sc[6]; }
+        __syncthreads();
+    }
+    if (fl & SK_THRESH) post_thresh(B, D, S, St, (fl & SK_FROMREDUCED) ? (A.reduceIn + 3 * (n * n + n) + 8) : nullptr, (float *) (sI + 8), sHist, sI);
+    STAMP(3);
+    if (fl & SK_LOG) { if (tid == 0 && A.logIdx >= 0 && A.logIdx < 64) B.energyLog[A.logIdx] = B.scalars[0]; __syncthreads(); }
+
+    if (fl & SK_SOLVE) {
+        // HFinal / bFinal were assembled by k_gather (ba_reduce.hip)
+        if (!(fl & SK_FROMREDUCED)) {   // resInA / resInL of this accumulate (EnergyFunctional.cc:558,573)
+            double na = 0, nl = 0;
+            for (int c = tid; c < D.nChunks; c += NT) { na += S.chunkCnt[c * 2]; nl += S.chunkCnt[c * 2 + 1]; }
+            na = wave_sum(na); nl = wave_sum(nl);
+            if ((tid & 63) == 0) { sW[tid >> 6] = na; sW[4 + (tid >> 6)] = nl; }
+            __syncthreads();
+            if (tid == 0) { B.scalars[9] = sW[0] + sW[1] + sW[2] + sW[3]; B.scalars[10] = sW[4] + sW[5] + sW[6] + sW[7]; }
+            __syncthreads();
+        }
+        // scaled system into LDS (lower triangle is what the factorisation reads)
+        for (int i = tid; i < n; i += NT) sW[i] = 1.0 / sqrt(HF[(size_t) i * n + i] + 10.0);
+        __syncthreads();
+        for (int e = tid; e < Mp * lda; e += NT) sA[e] = 0.0;
+        __syncthreads();
+        for (int e0 = tid; e0 < n * n; e0 += 8 * NT) {
+            double q[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { int e = e0 + u * NT; q[u] = (e < n * n) ? HF[e] : 0.0; }
+#pragma unroll
+            for (int u = 0; u < 8; u++) { int e = e0 + u * NT; if (e < n * n) { int i = e / n, j = e % n; sA[i * lda + j] = sW[i] * q[u] * sW[j]; } }
+        }
+        for (int i = tid; i < n; i += NT) sx[i] = sW[i] * bF[i];
+        __syncthreads();
+        for (int i = tid; i < n; i += NT) sA[n * lda + i] = sx[i];
+        __syncthreads();
+        STAMP(4);
+        ldlt_factor_aug(sA, lda, n);
+        STAMP(5);
+        if (tid < 64) ldlt_back_wave(sA, lda, n, sx);
+        __syncthreads();
+        STAMP(6);
+        for (int i = tid; i < n; i += NT) sx[i] *= sW[i];
+        __syncthreads();
+        // orthogonalize x against the gauge nullspaces (x -= U U^T x)
+        if ((St.solverMode & LDSO_SOLVER_ORTHOGONALIZE_X) || (A.iteration >= 2 && (St.solverMode & LDSO_SOLVER_ORTHOGONALIZE_X_LATER))) {
+            if (tid < 64) {
+                double c[7];
+                for (int k = 0; k < 7; k++) { double s = 0; for (int r = tid; r < n; r += 64) s += B.nsProj[k * n + r] * sx[r]; c[k] = wave_sum(s); }
+                for (int r = tid; r < n; r += 64) { double s = 0; for (int k = 0; k < 7; k++) s += B.nsProj[k * n + r] * c[k]; sx[r] -= s; }
+            }
+            __syncthreads();
+        }
+        // outputs: x, steps, xAd
+        bool bad = false;
+        for (int i = tid; i < n; i += NT) { B.x[i] = sx[i]; if (!isfinite(sx[i])) bad = true; }
+        if (bad) B.scalars[4] = 1.0;
+        if (tid < 4) { B.calib->step[tid] = -sx[tid]; B.xc[tid] = (float) sx[tid]; }
+        for (int i = tid; i < F * 10; i += NT) { int f = i / 10, a = i % 10; B.frames[f].step[a] = (a < 8) ? -sx[4 + 8 * f + a] : 0.0; }
+        for (int i = tid; i < F * F * 8; i += NT) {
+            int c = i & 7, pr = i >> 3, h = pr / F, t = pr % F;
+            const float *AH = B.adHostF + (size_t) (h + F * t) * 64, *AT = B.adTargetF + (size_t) (h + F * t) * 64;
+            float s1 = 0, s2 = 0;
+            for (int k = 0; k < 8; k++) s1 += (float) sx[4 + 8 * h + k] * AH[k * 8 + c];
+            for (int k = 0; k < 8; k++) s2 += (float) sx[4 + 8 * t + k] * AT[k * 8 + c];
+            B.xAd[i] = s1 + s2;
+        }
+        __syncthreads();
+    }
+
+    STAMP(7);
+    if (fl & SK_BACKUP) {
+        if (tid < F) for (int i = 0; i < 10; i++) B.frames[tid].state_backup[i] = B.frames[tid].state[i];
+        if (tid == 0) for (int i = 0; i < 4; i++) B.calib->value_backup[i] = B.calib->value[i];
+        __syncthreads();
+    }
+    if (fl & SK_STEP) {
+        if (tid < F) for (int i = 0; i < 10; i++) B.frames[tid].state[i] = B.frames[tid].state_backup[i] + B.frames[tid].step[i];
+        if (tid == 0) {
+            for (int i = 0; i < 4; i++) B.calib->value[i] = B.calib->value_backup[i] + B.calib->step[i] * (double) 1.0f;
+            float sumA = 0, sumB = 0, sumT = 0, sumR = 0;
+            for (int f = 0; f < F; f++) {
+                const double *s = B.frames[f].step;
+                sumA += s[6] * s[6]; sumB += s[7] * s[7];
+                sumT += s[0] * s[0] + s[1] * s[1] + s[2] * s[2];
+                sumR += s[3] * s[3] + s[4] * s[4] + s[5] * s[5];
+            }
+            sumA /= F; sumB /= F; sumR /= F; sumT /= F;
+            float sumNID = (float) B.scalars[6] / (float) B.scalars[7];
+            bool cb = sqrtf(sumA) < 0.0005 * St.thOptIterations && sqrtf(sumB) < 0.00005 * St.thOptIterations &&
+                      sqrtf(sumR) < 0.00005 * St.thOptIterations && sqrtf(sumT) * sumNID < 0.00005 * St.thOptIterations;
+            B.scalars[3] = cb ? 1.0 : 0.0;
+        }
+        __syncthreads();
+    }
+    if (fl & SK_LOADBK) {
+        if (tid < F) for (int i = 0; i < 10; i++) B.frames[tid].state[i] = B.frames[tid].state_backup[i];
+        if (tid == 0) for (int i = 0; i < 4; i++) B.calib->value[i] = B.calib->value_backup[i];
+        __syncthreads();
+    }
+    STAMP(8);
+    if (fl & SK_PRECALC) set_precalc(B, D);
+    STAMP(9);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// point part of resubstituteFPt + doStepFromBackup / backupState / loadSateBackup
+//   (EnergyFunctional.cc:518-547, FullSystem.cc:1585-1602)
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_point_step(BaPtrs B, BaDims D, ResSet S, int mode) {
+    const int p = D.pBegin + blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= D.pEnd) return;
+    if (mode & PS_LOAD) { float b = B.pidepth_backup[p]; B.pidepth[p] = b; B.pidepth_zero[p] = b; return; }   // loadSateBackup
+    const int F = D.F, FS = D.FS, h = B.phost[p];
+    float step = B.pstep[p];
+    if ((mode & PS_RESUB) && S.nActive[p] <= 0) step = 0.0f;
+    if ((mode & PS_RESUB) && S.nActive[p] > 0) {
+        float b = S.bdSumF[p];
+        float dot = 0;
+        for (int i = 0; i < 4; i++) dot += B.xc[i] * (S.HcdA[p * 4 + i] + S.HcdL[p * 4 + i]);
+        b -= dot;
+        bool finite = true;
+        for (int t = 0; t < F; t++) {
+            int slot = p * FS + t;
+            if (B.rflat[slot] < 0 || !S.active[slot]) continue;
+            const float *xa = B.xAd + (size_t) (h * F + t) * 8, *jp = S.JpJdF + (size_t) slot * 8;
+            float s = 0;
+            for (int i = 0; i < 8; i++) s += xa[i] * jp[i];
+            b -= s;
+        }
+        if (!isfinite(b)) finite = false;
+        if (finite) step = -b * S.HdiF[p]; else { step = B.pstep[p]; B.scalars[4] = 1.0; }
+    }
+    B.pstep[p] = step;
+    if (mode & PS_BACKUP) B.pidepth_backup[p] = B.pidepth[p];
+    if (mode & PS_STEP) {     // doStepFromBackup (stepfacD = 1)
+        float ni = B.pidepth_backup[p] + 1.0f * step;
+        B.pidepth[p] = ni;
+        B.pidepth_zero[p] = ni;
+    }
+}
+
+hipError_t ba_launch_solve(const BaPtrs &B, const BaDims &D, const ResSet &S, const ldso_settings_t &St, const SolveArgs &A, hipStream_t st) {
+    size_t n = D.n;
+    size_t Mp = (n + 1 <= 64) ? 64 : (n + 1 <= 112) ? 112 : 144;
+    size_t lds = (Mp * (Mp + 1) + n + 7 * n + 64) * sizeof(double) + (n + 2 + 256 + 8) * sizeof(int) + 64 + TH_CAP * sizeof(float);
+    if (lds > 48 * 1024) hipFuncSetAttribute((const void *) k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+    hipLaunchKernelGGL(k_solve, dim3(1), dim3(NT), lds, st, B, D, S, St, A);
+    return hipGetLastError();
+}
+
+hipError_t ba_launch_point_step(const BaPtrs &B, const BaDims &D, const ResSet &S, int mode, hipStream_t st) {
+    int np = D.pEnd - D.pBegin;
+    if (np <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_point_step, dim3((np + 255) / 256), dim3(256), 0, st, B, D, S, mode);
+    return hipGetLastError();
+}
