@@ -166,6 +166,10 @@ int ldso_tr_calc_gs(ldso_tracker_t *t, int lvl, const double T_ref2new[12], floa
 /* CoarseTracker::trackNewestCoarse (CoarseTracker.cc:61-217): whole LM pyramid loop on the device. */
 int ldso_tr_track(ldso_tracker_t *t, double T_ref2new_inout[12], float aff_inout[2], int coarsestLvl, const double minResForAbort[5],
                   double lastResiduals_out[5], double lastFlowIndicators_out[3], int *ok_out, int *iterations_out);
+/* evaluate nhyp motion hypotheses of FullSystem::trackNewCoarse (FullSystem.cc:213-357)
+ * concurrently, one workgroup each (nhyp <= 128).  Arrays are nhyp-major. */
+int ldso_tr_track_batch(ldso_tracker_t *t, int nhyp, double *T_ref2new_inout, float *aff_inout, int coarsestLvl, const double minResForAbort[5],
+                        double *lastResiduals_out, double *lastFlowIndicators_out, int *ok_out, int *iterations_out);
 int ldso_tr_get_pc(ldso_tracker_t *t, int lvl, float *u, float *v, float *idepth, float *color, int *n);
 
 #ifdef __cplusplus

@@ -30,6 +30,13 @@ def lib():
         p = lib_path()
         if not os.path.exists(p):
             raise RuntimeError(f"{p} is missing: build it with `python -m ldso_amd.build` (hipcc, gfx950). There is no CPU fallback.")
+        # PyTorch-ROCm wheels bundle their own libamdhip64/libhsa-runtime64 (same SONAMEs as /opt/rocm).  Two HIP
+        # runtimes in one process cannot both own the GPU, so when torch is part of the process (streams, RCCL) it
+        # must be loaded first; libldso_hip.so then binds to the runtime that is already resident.
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
         L = C.CDLL(p)
         L.ldso_last_error.restype = C.c_char_p
         L.ldso_ba_reduce_doubles.restype = C.c_size_t
@@ -233,3 +240,79 @@ class BA:
         n = C.c_int()
         _chk(self.L.ldso_ba_kernel_time_ms(self.h, C.c_int(which), C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+
+class Tracker:
+    """CoarseTracker handle (src/frontend/CoarseTracker.cc) on one GPU."""
+
+    def __init__(self, w, h, levels, settings, calib, device=0):
+        self.L = lib()
+        self.h = C.c_void_p()
+        _chk(self.L.ldso_tr_create(C.c_int(device), C.c_int(w), C.c_int(h), C.c_int(levels), C.byref(self.h)))
+        self.w, self.hh, self.levels = w, h, levels
+        s = np.ascontiguousarray(settings)
+        _chk(self.L.ldso_tr_set_settings(self.h, _p(s)))
+        c = np.ascontiguousarray(calib)
+        _chk(self.L.ldso_tr_make_k(self.h, _p(c)))
+
+    def close(self):
+        if self.h:
+            self.L.ldso_tr_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _pyr(self, pyr):
+        keep = [np.ascontiguousarray(pyr[l], np.float32) for l in range(self.levels)]
+        arr = (C.c_void_p * self.levels)(*[a.ctypes.data for a in keep])
+        return arr, keep
+
+    def set_ref(self, pyr, a, b, exposure, pts):
+        arr, keep = self._pyr(pyr)
+        pts = np.ascontiguousarray(pts, np.float32)
+        _chk(self.L.ldso_tr_set_ref(self.h, arr, C.c_float(a), C.c_float(b), C.c_float(exposure), _p(pts), C.c_int(len(pts))))
+
+    def set_new_frame(self, pyr, exposure=1.0):
+        arr, keep = self._pyr(pyr)
+        _chk(self.L.ldso_tr_set_new_frame(self.h, arr, C.c_float(exposure)))
+
+    def pc(self, lvl):
+        n = C.c_int()
+        _chk(self.L.ldso_tr_get_pc(self.h, C.c_int(lvl), None, None, None, None, C.byref(n)))
+        u, v, d, c = (np.zeros(n.value, np.float32) for _ in range(4))
+        _chk(self.L.ldso_tr_get_pc(self.h, C.c_int(lvl), _p(u), _p(v), _p(d), _p(c), C.byref(n)))
+        return u, v, d, c
+
+    def calc_res(self, lvl, T, a, b, cutoff):
+        T = np.ascontiguousarray(T[:3, :4], np.float64)
+        rs = np.zeros(6)
+        n = C.c_int()
+        _chk(self.L.ldso_tr_calc_res(self.h, C.c_int(lvl), _p(T), C.c_float(a), C.c_float(b), C.c_float(cutoff), _p(rs), C.byref(n)))
+        return rs, n.value
+
+    def calc_gs(self, lvl, T, a, b):
+        T = np.ascontiguousarray(T[:3, :4], np.float64)
+        H = np.zeros((8, 8))
+        bb = np.zeros(8)
+        _chk(self.L.ldso_tr_calc_gs(self.h, C.c_int(lvl), _p(T), C.c_float(a), C.c_float(b), _p(H), _p(bb)))
+        return H, bb
+
+    def track(self, T, a, b, coarsest, min_res=None):
+        r = self.track_batch([T], [(a, b)], coarsest, min_res)
+        return {k: (v[0] if isinstance(v, (list, np.ndarray)) else v) for k, v in r.items()}
+
+    def track_batch(self, Ts, affs, coarsest, min_res=None):
+        n = len(Ts)
+        T = np.ascontiguousarray(np.stack([np.asarray(t)[:3, :4] for t in Ts]), np.float64).copy()
+        ab = np.ascontiguousarray(np.asarray(affs, np.float32).reshape(n, 2)).copy()
+        mr = np.full(5, np.nan) if min_res is None else np.asarray(min_res, np.float64)
+        lr = np.zeros((n, 5))
+        fl = np.zeros((n, 3))
+        ok = np.zeros(n, np.int32)
+        it = np.zeros(n, np.int32)
+        _chk(self.L.ldso_tr_track_batch(self.h, C.c_int(n), _p(T), _p(ab), C.c_int(coarsest), _p(mr), _p(lr), _p(fl), _p(ok), _p(it)))
+        return dict(ok=ok.astype(bool), T=T, a=ab[:, 0].copy(), b=ab[:, 1].copy(), lastResiduals=lr, flow=fl, iterations=it)

@@ -337,7 +337,8 @@ static __device__ void ldlt_factor_aug_t(double *A, int lda, int n) {
             for (int b = 0; b <= a; b++) {
                 const int j = tx + 16 * b;
                 const bool m = (a >= a0) && (b >= a0) && (i > k) && (j > k) && (j <= i) && (j < n) && (i <= n);
-                if (a >= a0 && b >= a0) A[i * lda + j] = m ? (v[a][b] - f * ljk[b]) : v[a][b];
+                if (m) A[i * lda + j] = v[a][b] - f * ljk[b];     // masked-out entries are never written (the upper part of a
+                                                                  // diagonal tile holds L values written by the tx==0 lanes)
             }
             if (tx == 0 && i > k && i < n) A[k * lda + i] = f;            // L[i][k] -> upper triangle (row k is finished)
         }

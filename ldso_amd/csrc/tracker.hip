@@ -1,0 +1,707 @@
+// tracker.hip — CoarseTracker direct image alignment on gfx950 (reference src/frontend/CoarseTracker.cc).
+//
+//   makeK                 CoarseTracker.cc:219-246   (host, float arithmetic as the reference)
+//   makeCoarseDepthL0     CoarseTracker.cc:258-438   k_tr_scatter / k_tr_pool / k_tr_dilate / k_tr_count+scan+write
+//   calcRes + calcGSSSE   CoarseTracker.cc:440-632   tr_eval(): ONE fused pass — projection, bilinear Vec3f gather,
+//                                                    Huber, energy, flow indicators and the 9x9 weighted outer
+//                                                    product; the warped buffers are never materialised
+//   trackNewestCoarse     CoarseTracker.cc:61-217    k_tr_track: the whole coarse-to-fine LM loop runs inside one
+//                                                    persistent workgroup per motion hypothesis (no host sync, no
+//                                                    launch per iteration); the 8x8 LDLT, SE3::exp and the
+//                                                    accept/reject logic run on the device in fp64.
+// The per-level point clouds are tiny (10^3..10^4 points): the path is latency bound, so the design minimises
+// dependent launches, and batches hypotheses across workgroups (FullSystem::trackNewCoarse tries up to 83).
+#include <hip/hip_runtime.h>
+#include <vector>
+#include <string>
+#include <cstring>
+#include <cmath>
+#include "../../include/ldso_hip.h"
+#include "lie_dev.h"
+
+void ldso_set_error(const std::string &s);
+#define CHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { ldso_set_error(std::string(#call) + ": " + hipGetErrorString(e_)); return LDSO_E_HIP; } } while (0)
+#define REQ(cond, msg) do { if (!(cond)) { ldso_set_error(msg); return LDSO_E_INVALID; } } while (0)
+
+#define TR_NT 1024
+#define TR_MAXL LDSO_PYR_LEVELS
+
+struct TrLevel {
+    int w, h, n;
+    float fx, fy, cx, cy;
+    float Ki[9];
+    const float *newImg;      // Vec3f AoS of the frame being tracked
+    const float *refImg;      // Vec3f AoS of the reference keyframe
+    float *pc_u, *pc_v, *pc_idepth, *pc_color;
+    float *idepth, *wsum, *wsum_bak;
+    int *blockCnt;            // compaction scratch
+};
+
+struct TrParams {
+    TrLevel lv[TR_MAXL];
+    int levels;
+    float ref_a, ref_b, ref_exposure, new_exposure;
+    float huberTH, coarseCutoffTH, affineOptModeA, affineOptModeB;
+};
+
+struct TrHyp {                 // one motion hypothesis in / result out
+    double T[12];
+    float a, b;
+    int coarsestLvl;
+    double minRes[5];
+    double lastResiduals[5];
+    double flow[3];
+    int ok, iterations;
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// makeCoarseDepthL0
+// ---------------------------------------------------------------------------------------------------------
+__global__ void k_tr_scatter(const float *pts, int n, float *idepth, float *wsum, int w) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int u = (int) (pts[4 * i + 0] + 0.5f), v = (int) (pts[4 * i + 1] + 0.5f);
+    float new_idepth = pts[4 * i + 2];
+    float weight = sqrtf((float) (1e-3 / ((double) pts[4 * i + 3] + 1e-12)));
+    atomicAdd(&idepth[u + w * v], new_idepth * weight);
+    atomicAdd(&wsum[u + w * v], weight);
+}
+
+__global__ void k_tr_pool(const float *id_lm, const float *ws_lm, float *id_l, float *ws_l, int wl, int hl, int wlm1) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= wl * hl) return;
+    int x = i % wl, y = i / wl;
+    int bidx = 2 * x + 2 * y * wlm1;
+    id_l[i] = id_lm[bidx] + id_lm[bidx + 1] + id_lm[bidx + wlm1] + id_lm[bidx + wlm1 + 1];
+    ws_l[i] = ws_lm[bidx] + ws_lm[bidx + 1] + ws_lm[bidx + wlm1] + ws_lm[bidx + wlm1 + 1];
+}
+
+// in-place dilation exactly as the reference: reads the weight backup and idepth of pixels with weight > 0,
+// writes only pixels with weight <= 0, so a parallel sweep equals the sequential one.
+__global__ void k_tr_dilate(float *idepth, float *wsum, const float *bak, int wl, int hl, int diagonal) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x + wl;
+    int wh = wl * hl - wl;
+    if (i >= wh) return;
+    if (bak[i] <= 0) {
+        float sum = 0, num = 0, numn = 0;
+        int o0 = diagonal ? 1 + wl : 1, o1 = diagonal ? -1 - wl : -1, o2 = diagonal ? wl - 1 : wl, o3 = diagonal ? -wl + 1 : -wl;
+        if (bak[i + o0] > 0) { sum += idepth[i + o0]; num += bak[i + o0]; numn++; }
+        if (bak[i + o1] > 0) { sum += idepth[i + o1]; num += bak[i + o1]; numn++; }
+        if (bak[i + o2] > 0) { sum += idepth[i + o2]; num += bak[i + o2]; numn++; }
+        if (bak[i + o3] > 0) { sum += idepth[i + o3]; num += bak[i + o3]; numn++; }
+        if (numn > 0) { idepth[i] = sum / numn; wsum[i] = num / numn; }
+    }
+}
+
+// order-preserving compaction over the interior (2 <= x < w-2, 2 <= y < h-2), row-major like the reference
+__device__ __forceinline__ bool tr_keep(const float *idepth, const float *wsum, const float *ref, int i, float &id, float &col) {
+    float ws = wsum[i];
+    if (!(ws > 0)) return false;
+    id = idepth[i] / ws;
+    col = ref[3 * i];
+    return isfinite(col) && (id > 0);
+}
+
+__global__ void k_tr_count(TrLevel L) {
+    __shared__ int sc[256 / 64];
+    int wi = L.w - 4, hi = L.h - 4;
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    bool keep = false;
+    if (e < wi * hi) { int x = 2 + e % wi, y = 2 + e / wi; float id, col; keep = tr_keep(L.idepth, L.wsum, L.refImg, x + y * L.w, id, col); }
+    int c = __popcll(__ballot(keep));
+    if ((threadIdx.x & 63) == 0) sc[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) L.blockCnt[blockIdx.x] = sc[0] + sc[1] + sc[2] + sc[3];
+}
+
+__global__ void k_tr_scan(int *cnt, int nb, int *total) {     // single block exclusive scan
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nb; base += blockDim.x) {
+        int i = base + threadIdx.x;
+        int v = (i < nb) ? cnt[i] : 0;
+        int inc = v;
+        for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(inc, o, 64); if ((threadIdx.x & 63) >= o) inc += t; }
+        __shared__ int ws[16];
+        if ((threadIdx.x & 63) == 63) ws[threadIdx.x >> 6] = inc;
+        __syncthreads();
+        int off = carry;
+        for (int wv = 0; wv < (int) (threadIdx.x >> 6); wv++) off += ws[wv];
+        if (i < nb) cnt[i] = off + inc - v;
+        __syncthreads();
+        if (threadIdx.x == blockDim.x - 1) carry = off + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+
+__global__ void k_tr_write(TrLevel L) {
+    __shared__ int sc[256 / 64];
+    int wi = L.w - 4, hi = L.h - 4;
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    bool keep = false;
+    float id = 0, col = 0;
+    int x = 0, y = 0;
+    if (e < wi * hi) { x = 2 + e % wi; y = 2 + e / wi; keep = tr_keep(L.idepth, L.wsum, L.refImg, x + y * L.w, id, col); }
+    unsigned long long m = __ballot(keep);
+    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) sc[wv] = __popcll(m);
+    __syncthreads();
+    int off = L.blockCnt[blockIdx.x];
+    for (int q = 0; q < wv; q++) off += sc[q];
+    off += __popcll(m & ((1ull << lane) - 1ull));
+    if (keep) { L.pc_u[off] = (float) x; L.pc_v[off] = (float) y; L.pc_idepth[off] = id; L.pc_color[off] = col; }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// fused calcRes + calcGSSSE over one level by one workgroup; results in LDS `out` (doubles):
+//   [0] E  [1] numTermsInE  [2] sumSquaredShiftT  [3] sumSquaredShiftRT  [4] sumSquaredShiftNum  [5] numSaturated
+//   [6] numTermsInWarped   [7..51] 45 upper-triangular entries of sum w J J^T (9x9)
+// ---------------------------------------------------------------------------------------------------------
+#define TR_NACC 52
+
+__device__ __forceinline__ void aff_from_to_f(float expF, float expT, float aF, float bF, float aT, float bT, float &a, float &b) {
+    if (expF == 0 || expT == 0) { expT = expF = 1; }
+    a = expf(aT - aF) * expT / expF;
+    b = bT - a * bF;
+}
+
+__device__ void tr_eval(const TrParams &P, int lvl, const double *T, float aff_a, float aff_b, float cutoffTH, double *out /*LDS TR_NACC*/,
+                        double *red /*LDS [nWaves][TR_NACC]*/, int i0, int istride) {
+    const TrLevel &L = P.lv[lvl];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nW = blockDim.x >> 6;
+    const int wl = L.w, hl = L.h;
+    const float fxl = L.fx, fyl = L.fy, cxl = L.cx, cyl = L.cy;
+    // RKi = R.cast<float>() * Ki ; t.cast<float>()
+    float R[9], RKi[9], t[3];
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) R[r * 3 + c] = (float) T[r * 4 + c]; t[r] = (float) T[r * 4 + 3]; }
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) RKi[r * 3 + c] = (R[r * 3 + 0] * L.Ki[0 * 3 + c] + R[r * 3 + 1] * L.Ki[1 * 3 + c]) + R[r * 3 + 2] * L.Ki[2 * 3 + c];
+    float affA, affB;
+    aff_from_to_f(P.ref_exposure, P.new_exposure, P.ref_a, P.ref_b, aff_a, aff_b, affA, affB);
+    const float maxEnergy = 2 * P.huberTH * cutoffTH - P.huberTH * P.huberTH;
+    const float b0 = P.ref_b;
+
+    float acc[TR_NACC];
+#pragma unroll
+    for (int q = 0; q < TR_NACC; q++) acc[q] = 0.f;
+
+    for (int i = i0 + tid; i < L.n; i += istride) {
+        float id = L.pc_idepth[i], x = L.pc_u[i], y = L.pc_v[i];
+        float p0 = ((RKi[0] * x + RKi[1] * y) + RKi[2] * 1.0f) + t[0] * id;
+        float p1 = ((RKi[3] * x + RKi[4] * y) + RKi[5] * 1.0f) + t[1] * id;
+        float p2 = ((RKi[6] * x + RKi[7] * y) + RKi[8] * 1.0f) + t[2] * id;
+        float u = p0 / p2, v = p1 / p2;
+        float Ku = fxl * u + cxl, Kv = fyl * v + cyl;
+        float new_idepth = id / p2;
+        if (lvl == 0 && i % 32 == 0) {
+            const float *Ki = L.Ki;
+            float k0 = (Ki[0] * x + Ki[1] * y) + Ki[2] * 1.0f, k1 = (Ki[3] * x + Ki[4] * y) + Ki[5] * 1.0f, k2 = (Ki[6] * x + Ki[7] * y) + Ki[8] * 1.0f;
+            float a0 = k0 + t[0] * id, a1 = k1 + t[1] * id, a2 = k2 + t[2] * id;
+            float KuT = fxl * (a0 / a2) + cxl, KvT = fyl * (a1 / a2) + cyl;
+            float c0 = k0 - t[0] * id, c1 = k1 - t[1] * id, c2 = k2 - t[2] * id;
+            float KuT2 = fxl * (c0 / c2) + cxl, KvT2 = fyl * (c1 / c2) + cyl;
+            float r0 = (((RKi[0] * x + RKi[1] * y) + RKi[2] * 1.0f)) - t[0] * id, r1 = (((RKi[3] * x + RKi[4] * y) + RKi[5] * 1.0f)) - t[1] * id,
+                  r2 = (((RKi[6] * x + RKi[7] * y) + RKi[8] * 1.0f)) - t[2] * id;
+            float Ku3 = fxl * (r0 / r2) + cxl, Kv3 = fyl * (r1 / r2) + cyl;
+            acc[2] += (KuT - x) * (KuT - x) + (KvT - y) * (KvT - y);
+            acc[2] += (KuT2 - x) * (KuT2 - x) + (KvT2 - y) * (KvT2 - y);
+            acc[3] += (Ku - x) * (Ku - x) + (Kv - y) * (Kv - y);
+            acc[3] += (Ku3 - x) * (Ku3 - x) + (Kv3 - y) * (Kv3 - y);
+            acc[4] += 2;
+        }
+        if (!(Ku > 2 && Kv > 2 && Ku < wl - 3 && Kv < hl - 3 && new_idepth > 0)) continue;
+        float refColor = L.pc_color[i];
+        int ix = (int) Ku, iy = (int) Kv;
+        float dx = Ku - ix, dy = Kv - iy, dxdy = dx * dy;
+        const float *bp = L.newImg + 3 * (ix + iy * wl);
+        const float *bq = bp + 3 * wl;
+        float w11 = dxdy, w01 = dy - dxdy, w10 = dx - dxdy, w00 = 1 - dx - dy + dxdy;
+        float h0 = ((w11 * bq[3] + w01 * bq[0]) + w10 * bp[3]) + w00 * bp[0];
+        float h1 = ((w11 * bq[4] + w01 * bq[1]) + w10 * bp[4]) + w00 * bp[1];
+        float h2 = ((w11 * bq[5] + w01 * bq[2]) + w10 * bp[5]) + w00 * bp[2];
+        if (!isfinite(h0)) continue;
+        float residual = h0 - (float) (affA * refColor + affB);
+        float hw = fabsf(residual) < P.huberTH ? 1 : P.huberTH / fabsf(residual);
+        if (fabsf(residual) > cutoffTH) {
+            acc[0] += maxEnergy; acc[1] += 1; acc[5] += 1;
+        } else {
+            acc[0] += hw * residual * residual * (2 - hw); acc[1] += 1; acc[6] += 1;
+            // calcGSSSE row (CoarseTracker.cc:592-615)
+            float ddx = h1 * fxl, ddy = h2 * fyl;
+            float J[9];
+            J[0] = new_idepth * ddx;
+            J[1] = new_idepth * ddy;
+            J[2] = 0 - new_idepth * (u * ddx + v * ddy);
+            J[3] = 0 - ((u * v) * ddx + ddy * (1 + v * v));
+            J[4] = (u * v) * ddy + ddx * (1 + u * u);
+            J[5] = u * ddy - v * ddx;
+            J[6] = affA * (b0 - refColor);
+            J[7] = -1;
+            J[8] = residual;
+            int q = 7;
+#pragma unroll
+            for (int r = 0; r < 9; r++) {
+                float jw = J[r] * hw;
+#pragma unroll
+                for (int c = r; c < 9; c++) { acc[q] = __builtin_fmaf(jw, J[c], acc[q]); q++; }
+            }
+        }
+    }
+    // block reduction in double, fixed order
+#pragma unroll
+    for (int q = 0; q < TR_NACC; q++) {
+        double v = (double) acc[q];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) red[wave * TR_NACC + q] = v;
+    }
+    __syncthreads();
+    if (tid < TR_NACC) { double s = 0; for (int wv = 0; wv < nW; wv++) s += red[wv * TR_NACC + tid]; out[tid] = s; }
+    __syncthreads();
+}
+
+// H (8x8), b (8) from the accumulated sums: divide by the padded n, apply the reference's scale swap
+__device__ void tr_hb(const double *acc, double *H, double *b) {
+    int nw = (int) acc[6];
+    int npad = (nw + 3) / 4 * 4;
+    double inv = (double) (1.0f / (float) npad);
+    const double cs[8] = {1.0, 1.0, 1.0, 0.5, 0.5, 0.5, 10.0, 1000.0};     // cols 0-2 x SCALE_XI_ROT, 3-5 x SCALE_XI_TRANS (sic)
+    int q = 7;
+    double M[81];
+    for (int r = 0; r < 9; r++) for (int c = r; c < 9; c++) { double v = (double) (float) acc[q++]; M[r * 9 + c] = v; M[c * 9 + r] = v; }
+    for (int r = 0; r < 8; r++) { for (int c = 0; c < 8; c++) H[r * 8 + c] = M[r * 9 + c] * inv * cs[r] * cs[c]; b[r] = M[r * 9 + 8] * inv * cs[r]; }
+}
+
+// Eigen-style pivoted LDLT solve of an n x n (n <= 8) system, single thread
+__device__ void small_ldlt_solve(const double *Ain, const double *rhs, double *x, int n) {
+    double A[64];
+    int tr[8];
+    for (int i = 0; i < n * n; i++) A[i] = Ain[i];
+    for (int k = 0; k < n; k++) {
+        int idx = k; double best = fabs(A[k * n + k]);
+        for (int i = k + 1; i < n; i++) if (fabs(A[i * n + i]) > best) { best = fabs(A[i * n + i]); idx = i; }
+        tr[k] = idx;
+        if (idx != k) {
+            for (int j = 0; j < k; j++) { double a = A[k * n + j]; A[k * n + j] = A[idx * n + j]; A[idx * n + j] = a; }
+            for (int j = idx + 1; j < n; j++) { double a = A[j * n + k]; A[j * n + k] = A[j * n + idx]; A[j * n + idx] = a; }
+            { double a = A[k * n + k]; A[k * n + k] = A[idx * n + idx]; A[idx * n + idx] = a; }
+            for (int j = k + 1; j < idx; j++) { double a = A[j * n + k]; A[j * n + k] = A[idx * n + j]; A[idx * n + j] = a; }
+        }
+        double temp[8];
+        for (int j = 0; j < k; j++) temp[j] = A[j * n + j] * A[k * n + j];
+        double s = 0;
+        for (int j = 0; j < k; j++) s += A[k * n + j] * temp[j];
+        A[k * n + k] -= s;
+        for (int i = k + 1; i < n; i++) { double tt = 0; for (int j = 0; j < k; j++) tt += A[i * n + j] * temp[j]; A[i * n + k] -= tt; }
+        double akk = A[k * n + k];
+        if (fabs(akk) > 0.0) for (int i = k + 1; i < n; i++) A[i * n + k] /= akk;
+    }
+    for (int i = 0; i < n; i++) x[i] = rhs[i];
+    for (int k = 0; k < n; k++) if (tr[k] != k) { double a = x[k]; x[k] = x[tr[k]]; x[tr[k]] = a; }
+    for (int i = 0; i < n; i++) { double s = x[i]; for (int j = 0; j < i; j++) s -= A[i * n + j] * x[j]; x[i] = s; }
+    for (int i = 0; i < n; i++) x[i] = (fabs(A[i * n + i]) > 2.2250738585072014e-308) ? x[i] / A[i * n + i] : 0.0;
+    for (int i = n - 1; i >= 0; i--) { double s = x[i]; for (int j = i + 1; j < n; j++) s -= A[j * n + i] * x[j]; x[i] = s; }
+    for (int k = n - 1; k >= 0; k--) if (tr[k] != k) { double a = x[k]; x[k] = x[tr[k]]; x[tr[k]] = a; }
+}
+
+__device__ void tr_vec6(const double *acc, double *rs) {
+    rs[0] = (double) (float) acc[0];
+    rs[1] = (double) (int) acc[1];
+    rs[2] = (double) ((float) acc[2] / ((float) acc[4] + 0.1f));
+    rs[3] = 0;
+    rs[4] = (double) ((float) acc[3] / ((float) acc[4] + 0.1f));
+    rs[5] = (double) ((float) (int) acc[5] / (float) (int) acc[1]);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// trackNewestCoarse: one workgroup per hypothesis
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TR_NT) void k_tr_track(TrParams P, TrHyp *hyps) {
+    __shared__ double sAcc[TR_NACC];
+    __shared__ double sRed[(TR_NT / 64) * TR_NACC];
+    __shared__ double sT[12], sTnew[12];
+    __shared__ float sAff[2], sAffNew[2];
+    __shared__ double sH[64], sB[8], sResOld[6], sResNew[6];
+    __shared__ int sCtl[4];          // 0: continue LM loop, 1: accept, 2: abort (return false), 3: iterations
+    __shared__ float sLambda, sCutRep;
+    TrHyp &hy = hyps[blockIdx.x];
+    const int tid = threadIdx.x;
+    if (tid < 12) sT[tid] = hy.T[tid];
+    if (tid == 0) { sAff[0] = hy.a; sAff[1] = hy.b; sCtl[3] = 0; sCtl[2] = 0; for (int i = 0; i < 5; i++) hy.lastResiduals[i] = NAN; for (int i = 0; i < 3; i++) hy.flow[i] = 1000; }
+    __syncthreads();
+    const int maxIterations[5] = {10, 20, 50, 50, 50};
+    const float lambdaExtrapolationLimit = 0.001f;
+    bool haveRepeated = false;
+
+    for (int lvl = hy.coarsestLvl; lvl >= 0; lvl--) {
+        float levelCutoffRepeat = 1;
+        tr_eval(P, lvl, sT, sAff[0], sAff[1], P.coarseCutoffTH * levelCutoffRepeat, sAcc, sRed, 0, TR_NT);
+        if (tid == 0) tr_vec6(sAcc, sResOld);
+        __syncthreads();
+        while (sResOld[5] > 0.6 && levelCutoffRepeat < 50) {
+            levelCutoffRepeat *= 2;
+            tr_eval(P, lvl, sT, sAff[0], sAff[1], P.coarseCutoffTH * levelCutoffRepeat, sAcc, sRed, 0, TR_NT);
+            if (tid == 0) tr_vec6(sAcc, sResOld);
+            __syncthreads();
+        }
+        if (tid == 0) { tr_hb(sAcc, sH, sB); sLambda = 0.01f; }
+        __syncthreads();
+
+        for (int iteration = 0; iteration < maxIterations[lvl]; iteration++) {
+            if (tid == 0) {
+                sCtl[3]++;
+                const float lambda = sLambda;
+                double Hl[64], nb[8], inc[8];
+                for (int i = 0; i < 64; i++) Hl[i] = sH[i];
+                for (int i = 0; i < 8; i++) { Hl[i * 8 + i] *= (1 + lambda); nb[i] = -sB[i]; }
+                small_ldlt_solve(Hl, nb, inc, 8);
+                const bool fixA = P.affineOptModeA < 0, fixB = P.affineOptModeB < 0;
+                if (fixA && fixB) {
+                    double H6[36], x6[6];
+                    for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) H6[i * 6 + j] = Hl[i * 8 + j];
+                    small_ldlt_solve(H6, nb, x6, 6);
+                    for (int i = 0; i < 6; i++) inc[i] = x6[i];
+                    inc[6] = 0; inc[7] = 0;
+                }
+                if (!fixA && fixB) {
+                    double H7[49], x7[7];
+                    for (int i = 0; i < 7; i++) for (int j = 0; j < 7; j++) H7[i * 7 + j] = Hl[i * 8 + j];
+                    small_ldlt_solve(H7, nb, x7, 7);
+                    for (int i = 0; i < 7; i++) inc[i] = x7[i];
+                    inc[7] = 0;
+                }
+                if (fixA && !fixB) {
+                    double Hs[64], bs[8], H7[49], x7[7], nb7[7];
+                    for (int i = 0; i < 64; i++) Hs[i] = Hl[i];
+                    for (int i = 0; i < 8; i++) bs[i] = sB[i];
+                    for (int i = 0; i < 8; i++) Hs[i * 8 + 6] = Hs[i * 8 + 7];
+                    for (int j = 0; j < 8; j++) Hs[6 * 8 + j] = Hs[7 * 8 + j];
+                    bs[6] = bs[7];
+                    for (int i = 0; i < 7; i++) { nb7[i] = -bs[i]; for (int j = 0; j < 7; j++) H7[i * 7 + j] = Hs[i * 8 + j]; }
+                    small_ldlt_solve(H7, nb7, x7, 7);
+                    for (int i = 0; i < 8; i++) inc[i] = 0;
+                    for (int i = 0; i < 6; i++) inc[i] = x7[i];
+                    inc[7] = x7[6];
+                }
+                float extrapFac = 1;
+                if (lambda < lambdaExtrapolationLimit) extrapFac = sqrtf((float) sqrt((double) (lambdaExtrapolationLimit / lambda)));
+                double incScaled[8], nrm = 0, sum = 0;
+                const double sc[8] = {1.0, 1.0, 1.0, 0.5, 0.5, 0.5, 10.0, 1000.0};
+                for (int i = 0; i < 8; i++) { inc[i] *= extrapFac; nrm += inc[i] * inc[i]; incScaled[i] = inc[i] * sc[i]; sum += incScaled[i]; }
+                if (!isfinite(sum)) for (int i = 0; i < 8; i++) incScaled[i] = 0;
+                double E[12];
+                ld::se3_exp(incScaled, E);
+                ld::se3_mul(E, sT, sTnew);
+                sAffNew[0] = sAff[0]; sAffNew[1] = sAff[1];
+                sAffNew[0] += incScaled[6]; sAffNew[1] += incScaled[7];
+                sCtl[0] = (sqrt(nrm) > 1e-3) ? 1 : 0;          // continue after this iteration?
+            }
+            __syncthreads();
+            tr_eval(P, lvl, sTnew, sAffNew[0], sAffNew[1], P.coarseCutoffTH * levelCutoffRepeat, sAcc, sRed, 0, TR_NT);
+            if (tid == 0) {
+                tr_vec6(sAcc, sResNew);
+                bool accept = (sResNew[0] / sResNew[1]) < (sResOld[0] / sResOld[1]);
+                if (accept) {
+                    tr_hb(sAcc, sH, sB);
+                    for (int i = 0; i < 6; i++) sResOld[i] = sResNew[i];
+                    sAff[0] = sAffNew[0]; sAff[1] = sAffNew[1];
+                    for (int i = 0; i < 12; i++) sT[i] = sTnew[i];
+                    sLambda *= 0.5f;
+                } else {
+                    sLambda *= 4;
+                    if (sLambda < lambdaExtrapolationLimit) sLambda = lambdaExtrapolationLimit;
+                }
+            }
+            __syncthreads();
+            if (!sCtl[0]) break;
+        }
+        if (tid == 0) {
+            float lr = sqrtf((float) (sResOld[0] / sResOld[1]));
+            hy.lastResiduals[lvl] = lr;
+            for (int i = 0; i < 3; i++) hy.flow[i] = sResOld[2 + i];
+            if (lr > 1.5 * hy.minRes[lvl]) sCtl[2] = 1;
+        }
+        __syncthreads();
+        if (sCtl[2]) break;
+        if (levelCutoffRepeat > 1 && !haveRepeated) { lvl++; haveRepeated = true; }
+    }
+    if (tid == 0) {
+        hy.iterations = sCtl[3];
+        if (sCtl[2]) { hy.ok = 0; }
+        else {
+            for (int i = 0; i < 12; i++) hy.T[i] = sT[i];
+            float a = sAff[0], b = sAff[1];
+            bool ok = true;
+            if ((P.affineOptModeA != 0 && (fabsf(a) > 1.2)) || (P.affineOptModeB != 0 && (fabsf(b) > 200))) ok = false;
+            float ra, rb;
+            aff_from_to_f(P.ref_exposure, P.new_exposure, P.ref_a, P.ref_b, a, b, ra, rb);
+            if ((P.affineOptModeA == 0 && (fabsf(logf(ra)) > 1.5)) || (P.affineOptModeB == 0 && (fabsf(rb) > 200))) ok = false;
+            if (ok) { if (P.affineOptModeA < 0) a = 0; if (P.affineOptModeB < 0) b = 0; }
+            hy.a = a; hy.b = b;
+            hy.ok = ok ? 1 : 0;
+        }
+    }
+}
+
+// stand-alone calcRes / calcGSSSE for the step-wise API (one workgroup)
+__global__ __launch_bounds__(TR_NT) void k_tr_calc(TrParams P, int lvl, const double *Tdev, float a, float b, float cutoffTH, double *outAcc) {
+    __shared__ double sAcc[TR_NACC];
+    __shared__ double sRed[(TR_NT / 64) * TR_NACC];
+    __shared__ double sT[12];
+    if (threadIdx.x < 12) sT[threadIdx.x] = Tdev[threadIdx.x];
+    __syncthreads();
+    tr_eval(P, lvl, sT, a, b, cutoffTH, sAcc, sRed, 0, TR_NT);
+    if (threadIdx.x < TR_NACC) outAcc[threadIdx.x] = sAcc[threadIdx.x];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------
+struct ldso_tracker {
+    int device = 0, w = 0, h = 0, levels = 0;
+    hipStream_t stream = nullptr;
+    bool ownStream = false;
+    ldso_settings_t settings;
+    TrParams P;
+    std::vector<void *> allocs;
+    float *d_newImg[TR_MAXL] = {nullptr}, *d_refImg[TR_MAXL] = {nullptr};
+    float *d_pts = nullptr;
+    int ptsCap = 0;
+    int *d_total = nullptr;
+    double *d_T = nullptr, *d_acc = nullptr;
+    TrHyp *d_hyp = nullptr;
+    double lastAcc[TR_NACC];
+    bool haveAcc = false;
+};
+
+template <class T> static int tr_alloc(ldso_tracker *H, T **p, size_t n) {
+    void *q = nullptr;
+    CHK(hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T)));
+    CHK(hipMemset(q, 0, std::max<size_t>(n, 1) * sizeof(T)));
+    H->allocs.push_back(q);
+    *p = (T *) q;
+    return LDSO_OK;
+}
+#define TA(ptr, n) do { int r_ = tr_alloc(H, &(ptr), (n)); if (r_ != LDSO_OK) return r_; } while (0)
+
+extern "C" {
+
+int ldso_tr_create(int device, int w, int h, int levels, ldso_tracker_t **out) {
+    REQ(out && w > 16 && h > 16 && levels >= 1 && levels <= TR_MAXL && (w >> (levels - 1)) >= 8, "ldso_tr_create: bad arguments");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { ldso_set_error("no HIP device visible"); return LDSO_E_NODEVICE; }
+    REQ(device >= 0 && device < ndev, "ldso_tr_create: device index out of range");
+    CHK(hipSetDevice(device));
+    ldso_tracker *H = new ldso_tracker();
+    H->device = device; H->w = w; H->h = h; H->levels = levels;
+    ldso_settings_default(&H->settings);
+    CHK(hipStreamCreateWithFlags(&H->stream, hipStreamNonBlocking));
+    H->ownStream = true;
+    memset(&H->P, 0, sizeof(H->P));
+    H->P.levels = levels;
+    for (int l = 0; l < levels; l++) {
+        TrLevel &L = H->P.lv[l];
+        L.w = w >> l; L.h = h >> l; L.n = 0;
+        size_t n = (size_t) L.w * L.h;
+        TA(H->d_newImg[l], n * 3); TA(H->d_refImg[l], n * 3);
+        L.newImg = H->d_newImg[l]; L.refImg = H->d_refImg[l];
+        TA(L.pc_u, n); TA(L.pc_v, n); TA(L.pc_idepth, n); TA(L.pc_color, n);
+        // 64 floats of zeroed padding on both sides: the reference's dilation reads one element before / after
+        // the image (CoarseTracker.cc:331-345, index i-1-w at i==w) out of its over-allocated buffers
+        TA(L.idepth, n + 128); TA(L.wsum, n + 128); TA(L.wsum_bak, n + 128);
+        L.idepth += 64; L.wsum += 64; L.wsum_bak += 64;
+        TA(L.blockCnt, n / 256 + 2);
+    }
+    TA(H->d_total, 1); TA(H->d_T, 12); TA(H->d_acc, TR_NACC); TA(H->d_hyp, 128);
+    *out = H;
+    return LDSO_OK;
+}
+
+int ldso_tr_destroy(ldso_tracker_t *H) {
+    if (!H) return LDSO_OK;
+    hipSetDevice(H->device);
+    hipDeviceSynchronize();
+    for (void *p : H->allocs) hipFree(p);
+    if (H->d_pts) hipFree(H->d_pts);
+    if (H->ownStream && H->stream) hipStreamDestroy(H->stream);
+    delete H;
+    return LDSO_OK;
+}
+
+int ldso_tr_set_stream(ldso_tracker_t *H, void *s) {
+    REQ(H, "null handle");
+    if (H->ownStream && H->stream) { hipStreamSynchronize(H->stream); if (s) { hipStreamDestroy(H->stream); H->ownStream = false; } }
+    if (s) { H->stream = (hipStream_t) s; H->ownStream = false; }
+    else if (!H->ownStream) { CHK(hipStreamCreateWithFlags(&H->stream, hipStreamNonBlocking)); H->ownStream = true; }
+    return LDSO_OK;
+}
+
+int ldso_tr_set_settings(ldso_tracker_t *H, const ldso_settings_t *s) {
+    REQ(H && s, "null argument");
+    H->settings = *s;
+    H->P.huberTH = s->huberTH; H->P.coarseCutoffTH = s->coarseCutoffTH; H->P.affineOptModeA = s->affineOptModeA; H->P.affineOptModeB = s->affineOptModeB;
+    return LDSO_OK;
+}
+
+// CoarseTracker::makeK, float arithmetic as the reference (CoarseTracker.cc:219-246)
+int ldso_tr_make_k(ldso_tracker_t *H, const ldso_calib_t *calib) {
+    REQ(H && calib, "null argument");
+    ldso_tr_set_settings(H, &H->settings);
+    float fx[TR_MAXL], fy[TR_MAXL], cx[TR_MAXL], cy[TR_MAXL];
+    fx[0] = (float) (50.0 * calib->value[0]); fy[0] = (float) (50.0 * calib->value[1]); cx[0] = (float) (50.0 * calib->value[2]); cy[0] = (float) (50.0 * calib->value[3]);
+    for (int l = 1; l < H->levels; l++) {
+        fx[l] = (float) (fx[l - 1] * 0.5); fy[l] = (float) (fy[l - 1] * 0.5);
+        cx[l] = (float) ((cx[0] + 0.5) / ((int) 1 << l) - 0.5); cy[l] = (float) ((cy[0] + 0.5) / ((int) 1 << l) - 0.5);
+    }
+    for (int l = 0; l < H->levels; l++) {
+        TrLevel &L = H->P.lv[l];
+        L.fx = fx[l]; L.fy = fy[l]; L.cx = cx[l]; L.cy = cy[l];
+        float K[9] = {fx[l], 0, cx[l], 0, fy[l], cy[l], 0, 0, 1};
+        auto cof = [&](int a, int b) { int a1 = (a + 1) % 3, a2 = (a + 2) % 3, b1 = (b + 1) % 3, b2 = (b + 2) % 3; return K[a1 * 3 + b1] * K[a2 * 3 + b2] - K[a1 * 3 + b2] * K[a2 * 3 + b1]; };
+        float k0 = cof(0, 0), k1 = cof(1, 0), k2 = cof(2, 0);
+        float det = (k0 * K[0] + k1 * K[3]) + k2 * K[6];
+        float invdet = 1.0f / det;
+        L.Ki[0] = k0 * invdet; L.Ki[1] = k1 * invdet; L.Ki[2] = k2 * invdet;
+        L.Ki[3] = cof(0, 1) * invdet; L.Ki[4] = cof(1, 1) * invdet; L.Ki[5] = cof(2, 1) * invdet;
+        L.Ki[6] = cof(0, 2) * invdet; L.Ki[7] = cof(1, 2) * invdet; L.Ki[8] = cof(2, 2) * invdet;
+    }
+    return LDSO_OK;
+}
+
+int ldso_tr_set_ref(ldso_tracker_t *H, const float *const *ref_dIp, float ref_a, float ref_b, float ref_exposure, const float *pts, int n) {
+    REQ(H && ref_dIp && (pts || n == 0) && n >= 0, "ldso_tr_set_ref: bad arguments");
+    CHK(hipSetDevice(H->device));
+    for (int l = 0; l < H->levels; l++) {
+        REQ(ref_dIp[l], "ldso_tr_set_ref: missing pyramid level");
+        size_t bytes = (size_t) H->P.lv[l].w * H->P.lv[l].h * 3 * sizeof(float);
+        CHK(hipMemcpyAsync(H->d_refImg[l], ref_dIp[l], bytes, hipMemcpyHostToDevice, H->stream));
+    }
+    H->P.ref_a = ref_a; H->P.ref_b = ref_b; H->P.ref_exposure = ref_exposure;
+    if (n > H->ptsCap) { if (H->d_pts) hipFree(H->d_pts); void *q; CHK(hipMalloc(&q, (size_t) n * 16)); H->d_pts = (float *) q; H->ptsCap = n; }
+    if (n) CHK(hipMemcpyAsync(H->d_pts, pts, (size_t) n * 16, hipMemcpyHostToDevice, H->stream));
+    // makeCoarseDepthL0
+    TrLevel *lv = H->P.lv;
+    CHK(hipMemsetAsync(lv[0].idepth, 0, (size_t) lv[0].w * lv[0].h * 4, H->stream));
+    CHK(hipMemsetAsync(lv[0].wsum, 0, (size_t) lv[0].w * lv[0].h * 4, H->stream));
+    if (n) hipLaunchKernelGGL(k_tr_scatter, dim3((n + 255) / 256), dim3(256), 0, H->stream, H->d_pts, n, lv[0].idepth, lv[0].wsum, lv[0].w);
+    for (int l = 1; l < H->levels; l++) {
+        int npx = lv[l].w * lv[l].h;
+        hipLaunchKernelGGL(k_tr_pool, dim3((npx + 255) / 256), dim3(256), 0, H->stream, lv[l - 1].idepth, lv[l - 1].wsum, lv[l].idepth, lv[l].wsum, lv[l].w, lv[l].h, lv[l - 1].w);
+    }
+    for (int l = 0; l < H->levels; l++) {
+        int npx = lv[l].w * lv[l].h;
+        CHK(hipMemcpyAsync(lv[l].wsum_bak, lv[l].wsum, (size_t) npx * 4, hipMemcpyDeviceToDevice, H->stream));
+        hipLaunchKernelGGL(k_tr_dilate, dim3((npx + 255) / 256), dim3(256), 0, H->stream, lv[l].idepth, lv[l].wsum, lv[l].wsum_bak, lv[l].w, lv[l].h, l < 2 ? 1 : 0);
+    }
+    for (int l = 0; l < H->levels; l++) {
+        int ni = (lv[l].w - 4) * (lv[l].h - 4);
+        int nb = (ni + 255) / 256;
+        hipLaunchKernelGGL(k_tr_count, dim3(nb), dim3(256), 0, H->stream, lv[l]);
+        hipLaunchKernelGGL(k_tr_scan, dim3(1), dim3(1024), 0, H->stream, lv[l].blockCnt, nb, H->d_total);
+        hipLaunchKernelGGL(k_tr_write, dim3(nb), dim3(256), 0, H->stream, lv[l]);
+        int tot = 0;
+        CHK(hipMemcpyAsync(&tot, H->d_total, 4, hipMemcpyDeviceToHost, H->stream));
+        CHK(hipStreamSynchronize(H->stream));
+        lv[l].n = tot;
+    }
+    CHK(hipGetLastError());
+    return LDSO_OK;
+}
+
+int ldso_tr_set_new_frame(ldso_tracker_t *H, const float *const *new_dIp, float exposure) {
+    REQ(H && new_dIp, "ldso_tr_set_new_frame: bad arguments");
+    CHK(hipSetDevice(H->device));
+    for (int l = 0; l < H->levels; l++) {
+        REQ(new_dIp[l], "ldso_tr_set_new_frame: missing pyramid level");
+        size_t bytes = (size_t) H->P.lv[l].w * H->P.lv[l].h * 3 * sizeof(float);
+        CHK(hipMemcpyAsync(H->d_newImg[l], new_dIp[l], bytes, hipMemcpyHostToDevice, H->stream));
+    }
+    H->P.new_exposure = exposure;
+    CHK(hipStreamSynchronize(H->stream));
+    return LDSO_OK;
+}
+
+static int tr_calc(ldso_tracker *H, int lvl, const double *T, float a, float b, float cutoff) {
+    CHK(hipMemcpyAsync(H->d_T, T, 12 * 8, hipMemcpyHostToDevice, H->stream));
+    hipLaunchKernelGGL(k_tr_calc, dim3(1), dim3(TR_NT), 0, H->stream, H->P, lvl, H->d_T, a, b, cutoff, H->d_acc);
+    CHK(hipGetLastError());
+    CHK(hipMemcpyAsync(H->lastAcc, H->d_acc, TR_NACC * 8, hipMemcpyDeviceToHost, H->stream));
+    CHK(hipStreamSynchronize(H->stream));
+    H->haveAcc = true;
+    return LDSO_OK;
+}
+
+int ldso_tr_calc_res(ldso_tracker_t *H, int lvl, const double T[12], float a, float b, float cutoffTH, double rs[6], int *n_warped) {
+    REQ(H && T && rs && lvl >= 0 && lvl < H->levels, "ldso_tr_calc_res: bad arguments");
+    CHK(hipSetDevice(H->device));
+    int r = tr_calc(H, lvl, T, a, b, cutoffTH);
+    if (r != LDSO_OK) return r;
+    const double *acc = H->lastAcc;
+    rs[0] = (double) (float) acc[0]; rs[1] = (double) (int) acc[1];
+    rs[2] = (double) ((float) acc[2] / ((float) acc[4] + 0.1f)); rs[3] = 0; rs[4] = (double) ((float) acc[3] / ((float) acc[4] + 0.1f));
+    rs[5] = (double) ((float) (int) acc[5] / (float) (int) acc[1]);
+    if (n_warped) *n_warped = ((int) acc[6] + 3) / 4 * 4;
+    return LDSO_OK;
+}
+
+int ldso_tr_calc_gs(ldso_tracker_t *H, int lvl, const double T[12], float a, float b, double Hout[64], double bout[8]) {
+    REQ(H && T && Hout && bout && lvl >= 0 && lvl < H->levels, "ldso_tr_calc_gs: bad arguments");
+    REQ(H->haveAcc, "ldso_tr_calc_gs: call ldso_tr_calc_res first (the reference reuses the warped buffers of the last calcRes)");
+    const double *acc = H->lastAcc;
+    int nw = (int) acc[6];
+    int npad = (nw + 3) / 4 * 4;
+    double inv = (double) (1.0f / (float) npad);
+    const double cs[8] = {1.0, 1.0, 1.0, 0.5, 0.5, 0.5, 10.0, 1000.0};
+    double M[81];
+    int q = 7;
+    for (int r = 0; r < 9; r++) for (int c = r; c < 9; c++) { double v = (double) (float) acc[q++]; M[r * 9 + c] = v; M[c * 9 + r] = v; }
+    for (int r = 0; r < 8; r++) { for (int c = 0; c < 8; c++) Hout[r * 8 + c] = M[r * 9 + c] * inv * cs[r] * cs[c]; bout[r] = M[r * 9 + 8] * inv * cs[r]; }
+    return LDSO_OK;
+}
+
+int ldso_tr_track_batch(ldso_tracker_t *H, int nhyp, double *T_inout /*nhyp*12*/, float *aff_inout /*nhyp*2*/, int coarsestLvl, const double minRes[5],
+                        double *lastResiduals /*nhyp*5*/, double *flow /*nhyp*3*/, int *ok /*nhyp*/, int *iterations /*nhyp*/) {
+    REQ(H && nhyp >= 1 && nhyp <= 128 && T_inout && aff_inout && coarsestLvl >= 0 && coarsestLvl < 5 && coarsestLvl < H->levels, "ldso_tr_track: bad arguments");
+    CHK(hipSetDevice(H->device));
+    std::vector<TrHyp> hy(nhyp);
+    for (int i = 0; i < nhyp; i++) {
+        memset(&hy[i], 0, sizeof(TrHyp));
+        memcpy(hy[i].T, T_inout + i * 12, 96);
+        hy[i].a = aff_inout[2 * i]; hy[i].b = aff_inout[2 * i + 1]; hy[i].coarsestLvl = coarsestLvl;
+        for (int k = 0; k < 5; k++) hy[i].minRes[k] = minRes ? minRes[k] : NAN;
+    }
+    CHK(hipMemcpyAsync(H->d_hyp, hy.data(), nhyp * sizeof(TrHyp), hipMemcpyHostToDevice, H->stream));
+    hipLaunchKernelGGL(k_tr_track, dim3(nhyp), dim3(TR_NT), 0, H->stream, H->P, H->d_hyp);
+    CHK(hipGetLastError());
+    CHK(hipMemcpyAsync(hy.data(), H->d_hyp, nhyp * sizeof(TrHyp), hipMemcpyDeviceToHost, H->stream));
+    CHK(hipStreamSynchronize(H->stream));
+    for (int i = 0; i < nhyp; i++) {
+        memcpy(T_inout + i * 12, hy[i].T, 96);
+        aff_inout[2 * i] = hy[i].a; aff_inout[2 * i + 1] = hy[i].b;
+        if (lastResiduals) memcpy(lastResiduals + i * 5, hy[i].lastResiduals, 40);
+        if (flow) memcpy(flow + i * 3, hy[i].flow, 24);
+        if (ok) ok[i] = hy[i].ok;
+        if (iterations) iterations[i] = hy[i].iterations;
+    }
+    return LDSO_OK;
+}
+
+int ldso_tr_track(ldso_tracker_t *H, double T[12], float aff[2], int coarsestLvl, const double minRes[5], double lastResiduals[5], double flow[3], int *ok, int *iterations) {
+    return ldso_tr_track_batch(H, 1, T, aff, coarsestLvl, minRes, lastResiduals, flow, ok, iterations);
+}
+
+int ldso_tr_get_pc(ldso_tracker_t *H, int lvl, float *u, float *v, float *idepth, float *color, int *n) {
+    REQ(H && lvl >= 0 && lvl < H->levels, "ldso_tr_get_pc: bad arguments");
+    CHK(hipSetDevice(H->device));
+    const TrLevel &L = H->P.lv[lvl];
+    if (n) *n = L.n;
+    size_t bytes = (size_t) L.n * 4;
+    if (u) CHK(hipMemcpyAsync(u, L.pc_u, bytes, hipMemcpyDeviceToHost, H->stream));
+    if (v) CHK(hipMemcpyAsync(v, L.pc_v, bytes, hipMemcpyDeviceToHost, H->stream));
+    if (idepth) CHK(hipMemcpyAsync(idepth, L.pc_idepth, bytes, hipMemcpyDeviceToHost, H->stream));
+    if (color) CHK(hipMemcpyAsync(color, L.pc_color, bytes, hipMemcpyDeviceToHost, H->stream));
+    CHK(hipStreamSynchronize(H->stream));
+    return LDSO_OK;
+}
+
+}  // extern "C"

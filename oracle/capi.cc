@@ -290,6 +290,12 @@ void orc_get_system(void *h, double *HA, double *bA, double *HL, double *bL, dou
 
 void orc_get_prior(void *h, double *HM, double *bM) { EnergyFunctional *ef = ((OrcWindow *) h)->fs.ef; copyM(ef->HM, HM); copyV(ef->bM, bM); }
 
+// fixLinearizationF on selected residuals (flat ids), used to build the "mixed" windows that exercise mode 1
+void orc_fix_linearization(void *h, const int32_t *ids, int n) {
+    OrcWindow *W = (OrcWindow *) h;
+    for (int i = 0; i < n; i++) { PointFrameResidual *r = W->resByFlat[ids[i]]; if (r->isActive()) r->fixLinearizationF(W->fs.ef); }
+}
+
 // --- marginalisation (config C5) -------------------------------------------------------------------
 void orc_flag_frame(void *h, int frame_idx) { ((OrcWindow *) h)->fs.frames[frame_idx]->flaggedForMarginalization = true; }
 void orc_flag_points_for_removal(void *h) { ((OrcWindow *) h)->fs.flagPointsForRemoval(); }

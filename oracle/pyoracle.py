@@ -204,6 +204,10 @@ class OracleWindow:
         self.L.orc_get_prior(self.h, _p(HM), _p(bM))
         return HM, bM
 
+    def fix_linearization(self, ids):
+        ids = np.ascontiguousarray(ids, np.int32)
+        self.L.orc_fix_linearization(self.h, _p(ids), C.c_int(len(ids)))
+
     # --- marginalisation ---------------------------------------------------------------------------
     def flag_frame(self, idx):
         self.L.orc_flag_frame(self.h, C.c_int(idx))
@@ -232,6 +236,35 @@ class OracleWindow:
         P, R = P.value, R.value
         return dict(F=F.value, points=pts[:P].copy(), residuals=res[:R].copy(), lin_J=J[:R].copy(), lin_res_toZeroF=rtz[:R].copy(),
                     orig_point=op[:P].copy(), orig_res=orr[:R].copy())
+
+
+def make_mixed_window(win: synth.Window, oldest=2, perturb_seed=7) -> synth.Window:
+    """SURVEY.md §8(d) "mixed" variant: residuals whose target is among the `oldest` frames are pre-linearised
+    (isLinearized, res_toZeroF, J from a prior linearize), then the frame states / idepths are perturbed so that
+    the delta terms of mode 1 are non-zero."""
+    import copy
+    o = OracleWindow(win)
+    o.collect_active()
+    o.linearize_all(False)
+    o.apply_res()
+    ids = np.nonzero(win.residuals["target"] < oldest)[0]
+    o.fix_linearization(ids)
+    ex = o.export_window()
+    w2 = copy.deepcopy(win)
+    assert len(ex["points"]) == win.P and len(ex["residuals"]) == win.R
+    w2.residuals = ex["residuals"]
+    w2.lin_J = ex["lin_J"]
+    w2.lin_res_toZeroF = ex["lin_res_toZeroF"]
+    rng = np.random.default_rng(perturb_seed)
+    for k in range(1, win.F):
+        w2.frames["state"][k][0:3] += rng.normal(0, 5e-4, 3)
+        w2.frames["state"][k][3:6] += rng.normal(0, 5e-5, 3)
+        w2.frames["state"][k][6] += rng.normal(0, 1e-4)
+        w2.frames["state"][k][7] += rng.normal(0, 5e-5)
+    w2.points["idepth"] = (w2.points["idepth"] * (1 + rng.normal(0, 2e-3, win.P))).astype(np.float32)
+    w2.calib["value"] = w2.calib["value"] * (1 + rng.normal(0, 1e-6, 4))
+    o.close()
+    return w2
 
 
 class OracleTracker:

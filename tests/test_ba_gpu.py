@@ -1,0 +1,204 @@
+"""GPU parity tests of the windowed BA hot path: libldso_hip.so (through the C-ABI) against the oracle on the
+same seeded windows.  Tolerances (north_star): 1e-4 relative on energies and Hessian entries (entry tolerance
+relative to the 4x4 block maximum), bit-exact on residual states / indices."""
+import copy
+
+import numpy as np
+import pytest
+
+from conftest import rel, blockrel, get_window
+from ldso_amd import synth, binding
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+def stage_compare(win, check_J=True):
+    o = po.OracleWindow(win)
+    g = binding.BA.from_window(win)
+    # setPrecalcValues
+    assert rel(g.get_precalc(), o.get_precalc()) < 1e-6
+    o.collect_active(); g.collect_active()
+    g.set_debug_dump(True)
+    Eo, Eg = o.linearize_all(False), g.linearize_all(False)
+    assert abs(Eo - Eg) <= TOL * abs(Eo)
+    ro, rg = o.get_residuals(), g.get_residuals()
+    assert np.array_equal(ro["out"]["state_NewState"], rg["out"]["state_NewState"])            # bit-exact states
+    lin = win.residuals["is_linearized"].astype(bool)
+    assert rel(rg["out"]["state_NewEnergy"][~lin], ro["out"]["state_NewEnergy"][~lin]) < 1e-6
+    assert rel(g.get_frames()["frames"]["frameEnergyTH"], o.get_frames()["frames"]["frameEnergyTH"]) < 1e-6
+    if check_J:
+        Jg = g.get_jacobians()
+        ok = (ro["out"]["state_NewState"] != 1) & ~lin
+        for k in ("resF", "Jpdxi", "Jpdc", "Jpdd", "JIdx", "JabF", "JIdx2", "JabJIdx", "Jab2"):
+            assert rel(Jg[k][ok], ro["J"][k][ok]) < 1e-5, k
+    g.set_debug_dump(False)
+    o.apply_res(); g.apply_res()
+    ro, rg = o.get_residuals(), g.get_residuals()
+    assert np.array_equal(ro["is_active"], rg["is_active"]) and np.array_equal(ro["state_state"], rg["state_state"])
+    act = ro["is_active"].astype(bool)
+    assert rel(rg["out"]["JpJdF"][act], ro["out"]["JpJdF"][act]) < 1e-5
+    assert rel(rg["out"]["centerProjectedTo"][act & ~lin], ro["out"]["centerProjectedTo"][act & ~lin]) < 1e-6
+    # solveSystem
+    o.backup_state(); g.backup_state()
+    o.solve_system(0); g.solve_system(0)
+    so, sg = o.get_system(), g.get_system()
+    for k in ("HA", "HL", "Hsc", "HFinal"):
+        assert rel(sg[k], so[k]) < TOL, k
+        assert blockrel(sg[k], so[k], 4) < TOL, k
+        assert np.abs(sg[k] - sg[k].T).max() <= 1e-7 * np.abs(sg[k]).max(), k
+    for k in ("bA", "bL", "bsc", "bFinal"):
+        assert rel(sg[k], so[k]) < TOL, k
+    assert np.linalg.norm(sg["HFinal"] @ sg["x"] - sg["bFinal"]) / np.linalg.norm(sg["bFinal"]) < 1e-8     # backward error
+    assert rel(sg["x"], so["x"]) < 5e-2                                                                       # gauge-limited
+    assert o.counts()[:2] == g.get_counts()
+    pto, _ = o.get_points(); ptg = g.get_points()
+    for k in ("HdiF", "bdSumF", "idepth_hessian", "Hdd_accAF", "bd_accAF", "Hcd_accAF", "Hdd_accLF", "bd_accLF", "Hcd_accLF"):
+        assert rel(ptg[k], pto[k]) < 1e-5, k
+    # doStepFromBackup + relinearise
+    cbo, cbg = o.do_step(), g.do_step()
+    assert cbo == cbg
+    fo, fg = o.get_frames(), g.get_frames()
+    assert rel(fg["step"], fo["step"]) < 5e-2
+    Eo, Eg = o.linearize_all(False), g.linearize_all(False)
+    assert abs(Eo - Eg) <= 5 * TOL * abs(Eo)
+    return o, g
+
+
+def test_stagewise_tiny(tiny):
+    stage_compare(tiny)
+
+
+def test_stagewise_small(small):
+    stage_compare(small)
+
+
+def test_stagewise_mixed_linearized(small):
+    """20..50 % of the residuals pre-linearised: exercises addPoint<1> (res_toZeroF + J*delta) and H_L."""
+    w2 = po.make_mixed_window(small)
+    assert 0 < w2.residuals["is_linearized"].sum() < w2.R
+    o, g = stage_compare(w2, check_J=False)
+    a, l = g.get_counts()
+    assert a > 0 and l > 0
+
+
+def test_optimize_small(small):
+    o = po.OracleWindow(small); o.set_force_all_iterations(True)
+    g = binding.BA.from_window(small)
+    rmo = o.optimize(6)
+    rmg, its = g.optimize(6, force_all=True)
+    assert its == 6 and abs(rmo - rmg) <= TOL * rmo
+    eo, eg = o.energy_log(), g.get_energy_log()
+    assert len(eo) == len(eg) == 8 and rel(eg, eo) < 5 * TOL
+    ro, rg = o.get_residuals(), g.get_residuals()
+    assert np.array_equal(ro["state_state"], rg["state_state"]) and np.array_equal(ro["is_active"], rg["is_active"])
+    assert np.array_equal(rg["to_remove"].astype(bool), ro["alive"] == 0)
+    pto, _ = o.get_points(); ptg = g.get_points()
+    assert np.array_equal(pto["numGoodResiduals"], ptg["numGoodResiduals"])
+    assert rel(ptg["idepth"], pto["idepth"]) < 5e-3 and rel(ptg["maxRelBaseline"], pto["maxRelBaseline"]) < 1e-3
+    fo, fg = o.get_frames(), g.get_frames()
+    assert rel(fg["frames"]["worldToCam_evalPT"], fo["frames"]["worldToCam_evalPT"]) < 1e-3     # re-anchored newest frame
+    assert np.array_equal(fg["frames"]["state_zero"][-1][:6], np.zeros(6))
+    assert rel(fg["frames"]["nullspaces_pose"][-1], fo["frames"]["nullspaces_pose"][-1]) < 1e-3
+
+
+def test_optimize_canbreak_path(small):
+    """un-forced optimize: the host reads `canbreak` every iteration like the reference loop (FullSystem.cc:829)."""
+    o = po.OracleWindow(small)
+    g = binding.BA.from_window(small)
+    rmo = o.optimize(6)
+    rmg, its = g.optimize(6, force_all=False)
+    assert its == len(o.energy_log()) - 2
+    assert abs(rmo - rmg) <= 5 * TOL * rmo
+
+
+@pytest.mark.parametrize("name", ["C3", "C4"])
+def test_full_size_parity_and_properties(name):
+    """BASELINE configs at full size: one stage-wise pass against the oracle plus size-independent properties."""
+    win = get_window(name)
+    o = po.OracleWindow(win); g = binding.BA.from_window(win)
+    o.collect_active(); g.collect_active()
+    Eo, Eg = o.linearize_all(False), g.linearize_all(False)
+    assert abs(Eo - Eg) <= TOL * Eo
+    assert np.array_equal(o.get_residuals(False)["out"]["state_NewState"], g.get_residuals()["out"]["state_NewState"])
+    o.apply_res(); g.apply_res(); o.backup_state(); g.backup_state(); o.solve_system(0); g.solve_system(0)
+    so, sg = o.get_system(), g.get_system()
+    for k in ("HA", "Hsc"):
+        assert blockrel(sg[k], so[k], 4) < TOL, k
+        # symmetry + positive semi-definiteness of the accumulated blocks
+        assert np.abs(sg[k] - sg[k].T).max() <= 1e-7 * np.abs(sg[k]).max()
+        assert np.linalg.eigvalsh(0.5 * (sg[k] + sg[k].T)).min() > -1e-6 * np.abs(sg[k]).max()
+    # H_A - H_sc (the reduced camera system) must be PSD as a Schur complement
+    red = sg["HA"] - sg["Hsc"]
+    assert np.linalg.eigvalsh(0.5 * (red + red.T)).min() > -1e-6 * np.abs(red).max()
+
+
+def test_shard_and_sum_invariance(small):
+    """points sharded over two 'ranks' on one GPU: the summed reduce buffers equal the unsharded one (the
+    multi-GPU all-reduce is a plain sum of these buffers)."""
+    import torch
+    g = binding.BA.from_window(small)
+    g.collect_active(); g.linearize_all(False); g.apply_res()
+    nd = g.reduce_doubles()
+    full = torch.zeros(nd, dtype=torch.float64, device="cuda")
+    g.set_stream(torch.cuda.current_stream().cuda_stream)
+    g.reduce_local(full.data_ptr()); torch.cuda.synchronize()
+    parts = []
+    half = small.P // 2
+    for (a, b) in ((0, half), (half, small.P)):
+        gi = binding.BA.from_window(small)
+        gi.set_stream(torch.cuda.current_stream().cuda_stream)
+        gi.set_shard(a, b)
+        gi.collect_active(); gi.linearize_all(False); gi.apply_res()
+        buf = torch.zeros(nd, dtype=torch.float64, device="cuda")
+        gi.reduce_local(buf.data_ptr()); torch.cuda.synchronize()
+        parts.append(buf)
+    s = (parts[0] + parts[1]).cpu().numpy()
+    f = full.cpu().numpy()
+    n = 8 * small.F + 4
+    blk = n * n + n
+    assert blockrel(s[:n * n].reshape(n, n), f[:n * n].reshape(n, n), 4) < 1e-5          # H_A
+    assert blockrel(s[2 * blk:2 * blk + n * n].reshape(n, n), f[2 * blk:2 * blk + n * n].reshape(n, n), 4) < 1e-5   # H_sc
+    assert rel(s[3 * blk:3 * blk + 3], f[3 * blk:3 * blk + 3]) < 1e-9                     # energy, counters
+    assert np.array_equal(s[3 * blk + 8:], f[3 * blk + 8:])                               # energy candidates: exact
+
+
+def test_edge_points_without_residuals_and_oob(tiny):
+    """points with no residuals, OOB residuals (point projected outside the image) and an all-OUTLIER point."""
+    w2 = copy.deepcopy(tiny)
+    # point 0: move to the image corner so its residuals go OOB; point 1: absurd idepth -> OOB/outliers
+    w2.points["u"][0] = 3.0; w2.points["v"][0] = 3.0
+    w2.points["idepth"][1] = 50.0; w2.points["idepth_zero"][1] = 50.0
+    # point 2: corrupt colours -> OUTLIER
+    w2.points["color"][2] += 100.0
+    o = po.OracleWindow(w2); g = binding.BA.from_window(w2)
+    o.collect_active(); g.collect_active()
+    Eo, Eg = o.linearize_all(False), g.linearize_all(False)
+    ro, rg = o.get_residuals(False), g.get_residuals()
+    assert np.array_equal(ro["out"]["state_NewState"], rg["out"]["state_NewState"])
+    assert (rg["out"]["state_NewState"] == 1).sum() > 0 and (rg["out"]["state_NewState"] == 2).sum() > 0
+    assert abs(Eo - Eg) <= TOL * Eo
+    o.apply_res(); g.apply_res(); o.backup_state(); g.backup_state(); o.solve_system(0); g.solve_system(0)
+    pto, _ = o.get_points(); ptg = g.get_points()
+    assert rel(ptg["HdiF"], pto["HdiF"]) < 1e-5 and rel(ptg["step"], pto["step"]) < 5e-2
+    assert ptg["HdiF"][0] == 0 and ptg["step"][0] == 0          # no good residual -> zeroed (AccumulatedSCHessian.cc:16-22)
+
+
+def test_invalid_arguments_fail_loudly(tiny):
+    with pytest.raises(binding.LdsoError):
+        binding.BA(64, 64, 32, 10)                              # more frames than LDSO_MAX_FRAMES
+    g = binding.BA(tiny.w, tiny.h, tiny.F, tiny.P)
+    with pytest.raises(binding.LdsoError):
+        g.linearize_all(False)                                  # no window yet
+    g.set_settings(tiny.settings)
+    for f in range(tiny.F):
+        g.set_image(f, tiny.images[f][0])
+    bad = tiny.residuals.copy(); bad["target"][0] = bad["host"][0]
+    with pytest.raises(binding.LdsoError):
+        g.set_window(np.arange(tiny.F), tiny.points, bad)
+    s = tiny.settings.copy(); s["solverMode"] = 1
+    with pytest.raises(binding.LdsoError) as e:
+        g.set_settings(s)
+    assert e.value.code == -4

@@ -1,0 +1,89 @@
+"""GPU parity of CoarseTracker (C-ABI ldso_tr_*) against the oracle: makeCoarseDepthL0 point clouds exact,
+calcRes / calcGSSSE within 1e-4, trackNewestCoarse end result within the LM convergence tolerance."""
+import numpy as np
+import pytest
+
+from conftest import rel
+from tracker_common import tracker_scenario
+from ldso_amd import synth, binding
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+
+
+def make_pair(sc):
+    win = sc["win"]
+    o = po.OracleTracker(win.w, win.h, sc["levels"], win.settings, win.calib)
+    g = binding.Tracker(win.w, win.h, sc["levels"], win.settings, win.calib)
+    for t in (o, g):
+        t.set_ref(sc["ref_pyr"], sc["ref_aff"][0], sc["ref_aff"][1], 1.0, sc["pts"])
+        t.set_new_frame(sc["new_pyr"], 1.0)
+    return o, g
+
+
+@pytest.mark.parametrize("name,levels", [("small", None), ("C3", None), ("C3", 5)])
+def test_point_cloud_exact(name, levels):
+    sc = tracker_scenario(name, levels=levels)
+    o, g = make_pair(sc)
+    for l in range(sc["levels"]):
+        a, b = o.pc(l), g.pc(l)
+        assert len(a[0]) == len(b[0]) > 0
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])             # indices bit-exact
+        assert rel(b[2], a[2]) < 1e-6 and np.array_equal(a[3], b[3])
+
+
+@pytest.mark.parametrize("name", ["small", "C3"])
+def test_calc_res_and_gs(name):
+    sc = tracker_scenario(name)
+    o, g = make_pair(sc)
+    a, b = sc["new_aff"]
+    for T in (np.eye(4), sc["T_true"]):
+        for lvl in range(sc["levels"]):
+            for cutoff in (20.0, 1e9):
+                ro, no = o.calc_res(lvl, T, a, b, cutoff)
+                rg, ng = g.calc_res(lvl, T, a, b, cutoff)
+                assert no == ng and ro[1] == rg[1]                                   # counts bit-exact
+                assert abs(ro[0] - rg[0]) <= 1e-4 * abs(ro[0])
+                assert rel(rg[2:], ro[2:], 1e-6) < 1e-4
+                Ho, bo = o.calc_gs(lvl, T, a, b)
+                Hg, bg = g.calc_gs(lvl, T, a, b)
+                assert rel(Hg, Ho) < 1e-4 and rel(bg, bo) < 1e-4
+
+
+@pytest.mark.parametrize("name,levels", [("small", None), ("C3", None), ("C3", 5)])
+def test_track_matches_oracle(name, levels):
+    sc = tracker_scenario(name, levels=levels)
+    o, g = make_pair(sc)
+    a, b = sc["new_aff"]
+    ro = o.track(np.eye(4), a, b, sc["levels"] - 1)
+    rg = g.track(np.eye(4), a, b, sc["levels"] - 1)
+    assert ro["ok"] and rg["ok"]
+    To, Tg = np.eye(4), np.eye(4)
+    To[:3, :4] = ro["T"]; Tg[:3, :4] = rg["T"]
+    d = np.linalg.norm(synth.se3_log(Tg @ np.linalg.inv(To)))
+    m = np.linalg.norm(synth.se3_log(To))
+    assert d < 2e-2 * m + 1e-5                                       # LM stops at |inc| <= 1e-3
+    assert rel(rg["lastResiduals"][:sc["levels"]], ro["lastResiduals"][:sc["levels"]]) < 1e-2
+    err = np.linalg.norm(synth.se3_log(Tg @ np.linalg.inv(sc["T_true"])))
+    assert err < 0.25 * np.linalg.norm(synth.se3_log(sc["T_true"]))
+
+
+def test_track_batch_equals_single():
+    sc = tracker_scenario("small")
+    o, g = make_pair(sc)
+    a, b = sc["new_aff"]
+    guesses = [np.eye(4), sc["T_true"], synth.se3_exp([0.01, 0, 0, 0, 0.002, 0])]
+    singles = [g.track(T, a, b, sc["levels"] - 1) for T in guesses]
+    batch = g.track_batch(guesses, [(a, b)] * 3, sc["levels"] - 1)
+    for i in range(3):
+        assert np.array_equal(singles[i]["T"], batch["T"][i]) and singles[i]["iterations"] == batch["iterations"][i]
+
+
+def test_abort_on_min_res():
+    sc = tracker_scenario("small")
+    o, g = make_pair(sc)
+    a, b = sc["new_aff"]
+    mr = np.full(5, 1e-3)
+    ro = o.track(np.eye(4), a, b, sc["levels"] - 1, mr)
+    rg = g.track(np.eye(4), a, b, sc["levels"] - 1, mr)
+    assert not ro["ok"] and not rg["ok"]
