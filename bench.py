@@ -1,0 +1,173 @@
+#!/usr/bin/env python
+"""bench.py — Gauss-Newton iterations/s (and Mresiduals/s) of the windowed photometric BA hot path on MI355X.
+
+Workload (BASELINE.json configs[2], "C3"): 7 keyframes x 2000 points x 8-pixel pattern, 640x480, R = 12000
+residuals, synthetic window (seed 20260925), forced iterations (canbreak ignored).  One *step* = one GN iteration
+= solveSystem (accumulate A/L/SC, stitch, solve, back-substitute) + doStepFromBackup + linearizeAll + applyRes
+(reference FullSystem.cc:777-831), with the window resident in HBM.  N > 1: points are sharded across the ranks,
+one RCCL all-reduce of the stitched system per iteration, replicated solve (strong scaling).
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (k_linearize): algorithmic bytes per launch
+(436 B per residual + 112 B per point) / average launch duration measured with HIP events on the
+launch stream in a separate profiled pass of the same process.  `cpu_baseline` times the oracle (CPU restatement
+of the reference, "port") on this box's host cores with the reference's 6-worker IndexThreadReduce schedule.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--config", default="C3")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    from ldso_amd import synth, binding, dist as ldist
+
+    win = synth.make_config(args.config)
+    F, P, R = win.F, win.P, win.R
+    stream = torch.cuda.current_stream().cuda_stream
+    ba = binding.BA.from_window(win, device=local_rank, stream=stream)
+    pb, pe = ldist.shard_range(P, rank, world)
+    if world > 1:
+        ba.set_shard(pb, pe)
+    ba.collect_active()
+    ba.linearize_all(False)
+    ba.apply_res()
+    rbuf = torch.zeros(ba.reduce_doubles(), dtype=torch.float64, device="cuda") if world > 1 else None
+
+    def run(k, it0):
+        if world == 1:
+            ba.enqueue_gn(it0, k)
+        else:
+            for i in range(k):
+                ba.reduce_local(rbuf.data_ptr())
+                dist.all_reduce(rbuf)
+                ba.solve_reduced(rbuf.data_ptr(), it0 + i, 1e-1, True)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    run(args.warmup, 0)
+    fence()
+    t0 = time.perf_counter()
+    run(args.steps, 2)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- roofline of the dominant kernel: separate profiled pass (HIP events around every launch) -------------
+    ba.profile(True)
+    run(min(50, args.steps), 2)
+    fence()
+    names = ["k_linearize", "k_reduce+k_gather", "k_solve", "k_point_step"]
+    ktimes = {}
+    for i, nm in enumerate(names):
+        ms, n = ba.kernel_time_ms(i)
+        ktimes[nm] = {"avg_us": round(ms * 1e3, 3), "launches": n}
+    ev_ms, _ = ba.kernel_time_ms(4)          # empty event pair = overhead of the measurement itself
+    ba.profile(False)
+    Rloc = int(((win.residuals["point"] >= pb) & (win.residuals["point"] < pe)).sum())
+    alg_bytes = 436 * Rloc + 112 * (pe - pb)
+    lin_us = max(ktimes["k_linearize"]["avg_us"] - ev_ms * 1e3, 1e-3)
+    lin_s = lin_us * 1e-6
+    achieved = alg_bytes / lin_s / 1e9 if lin_s > 0 else 0.0
+
+    # sanity: the state after the run is finite
+    fr = ba.get_frames()
+    ok = bool(np.all(np.isfinite(fr["frames"]["state"])))
+
+    if rank == 0:
+        out = {
+            "metric": "GN iters/sec + Mresiduals/sec, 7-KF/2000-pt window",
+            "value": round(args.steps / dt, 2),
+            "unit": "GN iters/s",
+            "mresiduals_per_s": round(args.steps * R / dt / 1e6, 3),
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 5),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32 residual/Jacobian/accumulate, f64 stitch+solve",
+            "data": "synthetic",
+            "config": {"workload": f"{args.config}: {F} KF x {P} pt x 8 px, {win.w}x{win.h}, R={R}, forced GN iterations",
+                       "parallelism": "1 GPU" if world == 1 else f"points sharded over {world} GPUs, RCCL all-reduce of the stitched system per iteration"},
+            "roofline": {"bound": "hbm", "kernel": "k_linearize", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
+                         "frac": round(achieved / 8000.0, 5), "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": round(lin_us, 3), "event_pair_overhead_us": round(ev_ms * 1e3, 3)},
+            "kernels": ktimes,
+            "state_finite": ok,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(win)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(win):
+    """Oracle (CPU restatement of the reference) timed on the host cores: GN iterations/s on the same window.
+    Per-iteration time by differencing optimize(12) - optimize(2) (removes window set-up and the final fix pass)."""
+    from oracle import pyoracle as po
+    fast = True
+    try:
+        po.build(fast=True)
+    except Exception:
+        fast = False
+
+    def t_opt(n, mt):
+        o = po.OracleWindow(win, multithreading=mt, fast=fast)
+        o.set_force_all_iterations(True)
+        t = o.time_optimize(n)
+        o.close()
+        return t
+
+    res = {}
+    for mt, key in ((True, "mt6"), (False, "st1")):
+        d = []
+        t_end = time.perf_counter() + 8.0
+        while time.perf_counter() < t_end or len(d) < 3:
+            d.append((t_opt(12, mt) - t_opt(2, mt)) / 10.0)
+        res[key] = float(np.median(d))
+    ncpu = os.cpu_count()
+    return {"value": round(1.0 / res["mt6"], 2), "unit": "GN iters/s", "cores": 6, "kind": "port",
+            "sample": f"median per-iteration time of optimize(12)-optimize(2) over ~8 s, same {win.F} KF x {win.P} pt window, 6 worker threads "
+                      f"(reference NUM_THREADS) on a {ncpu}-vCPU host; -O3 -march=native" if fast else "portable build",
+            "single_thread_value": round(1.0 / res["st1"], 2), "host_vcpus": ncpu}
+
+
+if __name__ == "__main__":
+    main()

@@ -136,7 +136,8 @@ int ldso_ba_get_counts(ldso_ba_t *h, int *resInA, int *resInL);
 /* energies of the linearizeAll calls inside the last ldso_ba_optimize (<= cap values), returns count */
 int ldso_ba_get_energy_log(ldso_ba_t *h, double *out, int cap);
 /* average device time (ms) per launch of kernel `which` since the last reset (HIP events on the
- * handle's stream); which: 0 = linearize, 1 = reduce, 2 = solve, 3 = point step. */
+ * handle's stream); which: 0 = linearize, 1 = reduce+gather, 2 = solve, 3 = point step, 4 = an empty event pair
+ * recorded right after every linearize launch (the event overhead to subtract). */
 int ldso_ba_kernel_time_ms(ldso_ba_t *h, int which, double *avg_ms, int *launches);
 int ldso_ba_profile(ldso_ba_t *h, int enable);
 
