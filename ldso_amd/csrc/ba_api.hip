@@ -12,12 +12,13 @@
 #include "ba_solve.h"
 #include "lie_dev.h"
 
-hipError_t ba_launch_linearize(const BaPtrs &B, const BaDims &D, const ResSet &cur, const ResSet &nxt, const ldso_settings_t &S, bool hasL, bool fix, hipStream_t st);
+hipError_t ba_launch_linearize(const BaPtrs &B, const BaDims &D, const ResSet &cur, const ResSet &nxt, const ldso_settings_t &S, bool hasL, bool fix, int stepMode, hipStream_t st);
 hipError_t ba_launch_reduce(const BaPtrs &B, const BaDims &D, const ResSet &S, const int32_t *chunkStart, bool hasL, int GSP, hipStream_t st);
 hipError_t ba_launch_gather(const BaPtrs &B, const BaDims &D, const ResSet &S, bool hasL, bool hasPrior, int GSP, double lambda,
                             const ldso_settings_t &St, int mode, double *rbuf, hipStream_t st);
 hipError_t ba_launch_solve(const BaPtrs &B, const BaDims &D, const ResSet &S, const ldso_settings_t &St, const SolveArgs &A, hipStream_t st);
 hipError_t ba_launch_point_step(const BaPtrs &B, const BaDims &D, const ResSet &S, int mode, hipStream_t st);
+hipError_t ba_launch_gn_solve(const BaPtrs &B, const BaDims &D, const ResSet &S, const ldso_settings_t &St, const SolveArgs &A, hipStream_t st);
 
 static thread_local std::string g_err;
 void ldso_set_error(const std::string &s) { g_err = s; }
@@ -28,7 +29,7 @@ void ldso_set_error(const std::string &s) { g_err = s; }
 struct Timer { hipEvent_t a, b; int which; };
 
 struct ldso_ba {
-    int device = 0, w = 0, h = 0, maxF = 0, maxP = 0, FSmax = 0, maxChunks = 0;
+    int device = 0, w = 0, h = 0, maxF = 0, maxP = 0, FSmax = 0, maxChunks = 0, numCU = 256;
     hipStream_t stream = nullptr;
     bool ownStream = false;
     ldso_settings_t settings;
@@ -149,6 +150,7 @@ int ldso_ba_create(int device, int w, int h, int max_frames, int max_points, lds
     H->device = device; H->w = w; H->h = h; H->maxF = max_frames; H->maxP = max_points;
     H->FSmax = (max_frames + 7) / 8 * 8;
     H->maxChunks = max_points / 4 + max_frames + 4;
+    { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) H->numCU = pr.multiProcessorCount; }
     ldso_settings_default(&H->settings);
     CHK(hipStreamCreateWithFlags(&H->stream, hipStreamNonBlocking));
     H->ownStream = true;
@@ -234,8 +236,14 @@ static int build_chunks(ldso_ba *H) {
     // host-major chunks over the local shard [pBegin,pEnd)
     BaDims &D = H->D;
     const int Pn = D.pEnd - D.pBegin;
-    int CH = std::max(4, (Pn + 511) / 512);
-    CH = (CH + 3) / 4 * 4;
+    // smallest multiple of 4 points per chunk that keeps the grid within one wave of workgroups (one per CU)
+    int CH = 4;
+    for (;; CH += 4) {
+        int cnt = 0, run = 0, prev = -1;
+        for (int q = D.pBegin; q < D.pEnd; q++) { int hq = H->h_phost[q]; if (hq != prev) { cnt += (run + CH - 1) / CH; run = 0; prev = hq; } run++; }
+        cnt += (run + CH - 1) / CH;
+        if (cnt <= H->numCU || CH >= 1024) break;
+    }
     std::vector<int32_t> p0, cn, ch, cs(D.F + 1, 0);
     int p = D.pBegin;
     for (int hst = 0; hst < D.F; hst++) {
@@ -408,9 +416,9 @@ static int launch_solve(ldso_ba *H, const ResSet &S, unsigned flags, int iterati
     t_end(H);
     return LDSO_OK;
 }
-static int launch_linearize(ldso_ba *H, bool fix) {
+static int launch_linearize(ldso_ba *H, bool fix, int stepMode = 0) {
     t_begin(H, 0);
-    CHK(ba_launch_linearize(H->B, H->D, H->sets[H->cur], H->sets[H->cur ^ 1], H->settings, H->hasL, fix, H->stream));
+    CHK(ba_launch_linearize(H->B, H->D, H->sets[H->cur], H->sets[H->cur ^ 1], H->settings, H->hasL, fix, stepMode, H->stream));
     t_end(H);
     if (H->profile) { t_begin(H, 4); t_end(H); }      // empty event pair: calibrates the event overhead (which = 4)
     return LDSO_OK;
@@ -536,16 +544,22 @@ int ldso_ba_load_state_backup(ldso_ba_t *H) {
     return LDSO_OK;
 }
 
-// one GN iteration = solveSystem + doStepFromBackup + linearizeAll(false) + applyRes, 4 launches, no host sync
+// one GN iteration = solveSystem + doStepFromBackup + linearizeAll(false) + applyRes: 4 launches (k_reduce, k_gather,
+// k_gn_solve, k_linearize with the point step fused in), no host sync
 static int enqueue_iteration(ldso_ba *H, int iteration, double lambda, int logIdx, bool postOfPrev) {
     const ResSet &S = H->sets[H->cur];
     RUN(launch_reduce(H, S));
     RUN(launch_gather(H, S, lambda, 0, nullptr));
-    unsigned fl = SK_SOLVE | SK_BACKUP | SK_STEP | SK_PRECALC;
-    if (postOfPrev) fl |= SK_POST | SK_THRESH | SK_LOG;
-    RUN(launch_solve(H, S, fl, iteration, lambda, logIdx));
-    RUN(launch_pstep(H, S, PS_RESUB | PS_BACKUP | PS_STEP));
-    RUN(launch_linearize(H, false));
+    (void) postOfPrev;
+    {
+        SolveArgs A;
+        A.flags = 0; A.iteration = iteration; A.lambda = lambda; A.hasL = H->hasL ? 1 : 0; A.hasPrior = H->hasPrior ? 1 : 0; A.GSP = H->GSP; A.logIdx = logIdx;
+        A.reduceOut = nullptr; A.reduceIn = nullptr;
+        t_begin(H, 2);
+        CHK(ba_launch_gn_solve(H->B, H->D, S, H->settings, A, H->stream));
+        t_end(H);
+    }
+    RUN(launch_linearize(H, false, 1));
     H->cur ^= 1;      // forceAcceptStep: applyRes
     return LDSO_OK;
 }
@@ -737,7 +751,7 @@ int ldso_ba_get_jacobians(ldso_ba_t *H, const int32_t *ids, int n, ldso_rawjac_t
         REQ(!H->pendingApply, "ldso_ba_get_jacobians: a linearisation is pending (call ldso_ba_apply_res first, or enable ldso_ba_set_debug_dump)");
         BaPtrs Bd = H->B;
         Bd.dumpJ = H->d_dumpJ;
-        CHK(ba_launch_linearize(Bd, H->D, H->sets[H->cur], H->sets[H->cur ^ 1], H->settings, H->hasL, false, H->stream));
+        CHK(ba_launch_linearize(Bd, H->D, H->sets[H->cur], H->sets[H->cur ^ 1], H->settings, H->hasL, false, 0, H->stream));
     }
     D2H(all, H->d_dumpJ, (size_t) H->R);
     CHK(hipStreamSynchronize(H->stream));

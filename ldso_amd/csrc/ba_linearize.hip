@@ -59,12 +59,44 @@ __device__ __forceinline__ float seq8(float x, int k, int lane) {
 // flat index of entry (r,c), r<=c, in the packed upper triangle of a 13x13 matrix
 __host__ __device__ constexpr int tri13(int r, int c) { return r * 13 - (r * (r - 1)) / 2 + (c - r); }
 
-struct PointIO {
-    float u, v, idepth, idepth_zero, priorF;
+// Everything a wave reads from HBM for one point besides the image taps.  Loaded one point ahead (software
+// pipeline): the loads of point i+1 are in flight while point i is computed, and the first point's loads overlap
+// the LDS staging of the block, so a wave sees two dependent memory levels (this record, then the taps).
+template <int NSG>
+struct PtIn {
+    float pu, pv, idp, idz, priorF, color, wgt, maxRelBS;
+    int numGood;
+    int rflat[NSG], rlin[NSG], rnew[NSG], rlidx[NSG], state[NSG], active[NSG];
+    float energy[NSG], jp[NSG], cen[NSG];
+    // inputs of the fused point step (resubstituteFPt)
+    float pstep, bdSumF, HdiF, hcd[4];
+    int nAct;
 };
 
 template <int NSG, bool HAS_L, bool FIX>
-__global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D, ResSet cur, ResSet nxt, ldso_settings_t S) {
+static __device__ __forceinline__ void load_point(PtIn<NSG> &q, const BaPtrs &B, const ResSet &cur, int FS, int p, int s, int k, int stepMode) {
+    q.pu = B.pu[p]; q.pv = B.pv[p]; q.idp = B.pidepth[p]; q.idz = B.pidepth_zero[p]; q.priorF = B.ppriorF[p];
+    q.color = B.pcolor[p * 8 + k]; q.wgt = B.pweights[p * 8 + k];
+    q.maxRelBS = cur.maxRelBS[p]; q.numGood = cur.numGood[p];
+#pragma unroll
+    for (int g = 0; g < NSG; g++) {
+        const int slot = p * FS + g * 8 + s;       // slot tables are dense [P][FS]: every index is readable
+        q.rflat[g] = B.rflat[slot]; q.rlin[g] = B.rlin[slot]; q.rnew[g] = FIX ? B.rnew[slot] : 0; q.rlidx[g] = HAS_L ? B.rlidx[slot] : 0;
+        q.state[g] = cur.state[slot]; q.active[g] = cur.active[slot]; q.energy[g] = cur.energy[slot];
+        q.jp[g] = cur.JpJdF[slot * 8 + k]; q.cen[g] = cur.center[slot * 3 + (k < 3 ? k : 2)];
+    }
+    if (stepMode) {
+        q.pstep = B.pstep[p]; q.bdSumF = cur.bdSumF[p]; q.HdiF = cur.HdiF[p]; q.nAct = cur.nActive[p];
+#pragma unroll
+        for (int i = 0; i < 4; i++) q.hcd[i] = cur.HcdA[p * 4 + i] + cur.HcdL[p * 4 + i];
+    }
+}
+
+// stepMode != 0 fuses the point part of resubstituteF_MT + backupState + doStepFromBackup (EnergyFunctional.cc:518-547,
+// FullSystem.cc:1585-1602, 1625-1673) in front of the linearisation of each point (what k_point_step does with
+// PS_RESUB|PS_BACKUP|PS_STEP), so a forced-accept GN iteration needs no separate point pass.
+template <int NSG, bool HAS_L, bool FIX>
+__global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D, ResSet cur, ResSet nxt, ldso_settings_t S, int stepMode) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int FS = D.FS, F = D.F;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, s = lane >> 3, k = lane & 7;
@@ -76,12 +108,28 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D,
     float *sAdH = smem + FS * (sizeof(DevPair) / 4);                    // [FS][64]
     float *sAdT = sAdH + FS * 64;                                       // [FS][64]
     float *sRed = sAdT + FS * 64;                                       // [LD_WAVES][FS][91] (+ topL [FS][91] when HAS_L)
-    float *sTopL = sRed + LD_WAVES * FS * LD_TOPN;
+    float *sTopL = sRed + LD_WAVES * FS * LD_TOPN;                        // [FS][91] when HAS_L
+    float *sXa = sTopL + (HAS_L ? FS * LD_TOPN : 0);                      // [FS][8] xAd of this host (stepMode)
 
+    const float fx = B.calib->sf[0], fy = B.calib->sf[1], cx = B.calib->sf[2], cy = B.calib->sf[3];
+    const float fxi = B.calib->si[0], fyi = B.calib->si[1];
+    const float cD0 = B.calib->cDeltaF[0], cD1 = B.calib->cDeltaF[1], cD2 = B.calib->cDeltaF[2], cD3 = B.calib->cDeltaF[3];
+    float xc0 = 0, xc1 = 0, xc2 = 0, xc3 = 0;
+    if (stepMode) { xc0 = B.xc[0]; xc1 = B.xc[1]; xc2 = B.xc[2]; xc3 = B.xc[3]; }
+
+    PtIn<NSG> nx;
+    int pi = wave;
+    if (pi < np) load_point<NSG, HAS_L, FIX>(nx, B, cur, FS, p0 + pi, s, k, stepMode);
+
+    const float thHost = B.frames[h].frameEnergyTH;
     for (int i = tid; i < FS * (int) (sizeof(DevPair) / 4); i += blockDim.x) {
         int t = i / (int) (sizeof(DevPair) / 4), o = i % (int) (sizeof(DevPair) / 4);
-        ((float *) sPair)[i] = (t < F) ? ((const float *) &B.pairs[h * F + t])[o] : 0.0f;
+        float v = (t < F) ? ((const float *) &B.pairs[h * F + t])[o] : 0.0f;
+        // the energy threshold of a pair is max(host, target) of the frames' CURRENT thresholds (Residuals.cc:191)
+        if (o == (int) (offsetof(DevPair, thMax) / 4) && t < F) v = fmaxf(thHost, B.frames[t].frameEnergyTH);
+        ((float *) sPair)[i] = v;
     }
+    if (stepMode) for (int i = tid; i < FS * 8; i += blockDim.x) sXa[i] = ((i >> 3) < F) ? B.xAd[(size_t) (h * F + (i >> 3)) * 8 + (i & 7)] : 0.0f;
     for (int i = tid; i < FS * 64; i += blockDim.x) {
         int t = i >> 6, o = i & 63;
         sAdH[i] = (t < F) ? B.adHostF[(h + t * F) * 64 + o] : 0.0f;
@@ -90,9 +138,6 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D,
     if (HAS_L) for (int i = tid; i < FS * LD_TOPN; i += blockDim.x) sTopL[i] = 0.0f;
     __syncthreads();
 
-    const float fx = B.calib->sf[0], fy = B.calib->sf[1], cx = B.calib->sf[2], cy = B.calib->sf[3];
-    const float fxi = B.calib->si[0], fyi = B.calib->si[1];
-    const float cD0 = B.calib->cDeltaF[0], cD1 = B.calib->cDeltaF[1], cD2 = B.calib->cDeltaF[2], cD3 = B.calib->cDeltaF[3];
     const int ox = (k == 1 || k == 6) ? -1 : (k == 2) ? 1 : (k == 3) ? -2 : (k == 5) ? 2 : 0;     // staticPattern[8], Setting.cc:221
     const int oy = (k == 0) ? -2 : (k == 1 || k == 2) ? -1 : (k == 6) ? 1 : (k == 7) ? 2 : 0;
     const int W = D.w;
@@ -107,16 +152,42 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D,
     float nidSum = 0.0f;
     int nidCnt = 0;
 
-    for (int pi = wave; pi < np; pi += LD_WAVES) {
+    for (; pi < np; pi += LD_WAVES) {
         const int p = p0 + pi;
-        const float pu = B.pu[p], pv = B.pv[p], idp = B.pidepth[p], idz = B.pidepth_zero[p], priorF = B.ppriorF[p];
-        const float color = B.pcolor[p * 8 + k], wgt = B.pweights[p * 8 + k];
+        const PtIn<NSG> q = nx;
+        if (pi + LD_WAVES < np) load_point<NSG, HAS_L, FIX>(nx, B, cur, FS, p + LD_WAVES, s, k, stepMode);
+        const float pu = q.pu, pv = q.pv, priorF = q.priorF;
+        const float color = q.color, wgt = q.wgt;
+        float idp = q.idp, idz = q.idz;
+        if (stepMode) {
+            // ---- resubstituteFPt for this point, then backupState + doStepFromBackup (stepfacD = 1) ------------
+            float step = 0.0f;
+            if (q.nAct > 0) {
+                float b = q.bdSumF;
+                float dot = 0;
+                dot += xc0 * q.hcd[0]; dot += xc1 * q.hcd[1]; dot += xc2 * q.hcd[2]; dot += xc3 * q.hcd[3];
+                b -= dot;
+#pragma unroll
+                for (int g = 0; g < NSG; g++) {
+                    const int t = g * 8 + s;
+                    const bool act = (t < F) && (q.rflat[g] >= 0) && (q.active[g] != 0);
+                    float sres = seq8(sXa[t * 8 + k] * q.jp[g], k, lane);
+                    sres = act ? sres : 0.0f;
+#pragma unroll
+                    for (int ss = 0; ss < 8; ss++) b -= __shfl(sres, ss * 8, 64);
+                }
+                if (isfinite(b)) step = -b * q.HdiF; else { step = q.pstep; if (lane == 0) B.scalars[4] = 1.0; }
+            }
+            const float ni = idp + 1.0f * step;
+            if (lane == 0) { B.pstep[p] = step; B.pidepth_backup[p] = idp; B.pidepth[p] = ni; B.pidepth_zero[p] = ni; }
+            idp = ni; idz = ni;
+        }
         const float deltaF = idp - idz;
         float HddA = 0, bdA = 0, HcdA0 = 0, HcdA1 = 0, HcdA2 = 0, HcdA3 = 0;
         float HddL = 0, bdL = 0, HcdL0 = 0, HcdL1 = 0, HcdL2 = 0, HcdL3 = 0;
         float hostPart = 0.0f;       // this lane's partial of the host block of g_p (component k)
-        float maxRelBS = cur.maxRelBS[p];
-        int numGood = cur.numGood[p];
+        float maxRelBS = q.maxRelBS;
+        int numGood = q.numGood;
         int nActive = 0;
         float gT[NSG];
 
@@ -124,16 +195,16 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D,
         for (int g = 0; g < NSG; g++) {
             const int t = g * 8 + s;
             const int slot = p * FS + t;
-            const bool exists = (t < F) && (B.rflat[slot] >= 0);
-            const bool isLin = exists && (B.rlin[slot] != 0);
-            const int st = exists ? cur.state[slot] : RES_OOB;
+            const bool exists = (t < F) && (q.rflat[g] >= 0);
+            const bool isLin = exists && (q.rlin[g] != 0);
+            const int st = exists ? q.state[g] : RES_OOB;
             const DevPair &pr = sPair[t];
 
             int newState = st;
-            float newEnergy = exists ? cur.energy[slot] : 0.0f;
+            float newEnergy = exists ? q.energy[g] : 0.0f;
             float newEnergyWO = -1.0f;
-            int activeNew = exists ? cur.active[slot] : 0;
-            float jp = exists ? cur.JpJdF[slot * 8 + k] : 0.0f;     // this lane's component k of JpJdF
+            int activeNew = exists ? q.active[g] : 0;
+            float jp = exists ? q.jp[g] : 0.0f;     // this lane's component k of JpJdF
             float c0 = 0, c1 = 0, c2 = 0;
             int toRemove = 0;
             double ret = 0.0;                                      // linearize() return value
@@ -241,7 +312,7 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D,
                 }
                 if (FIX) {
                     if (activeNew) {
-                        if (B.rnew[slot]) {
+                        if (q.rnew[g]) {
                             // FullSystem.cc:1518-1534: relative baseline of new residuals
                             float inf0 = (pr.KRKi[0] * pu + pr.KRKi[1] * pv) + pr.KRKi[2] * 1.0f;
                             float inf1 = (pr.KRKi[3] * pu + pr.KRKi[4] * pv) + pr.KRKi[5] * 1.0f;
@@ -255,7 +326,7 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D,
                 }
             }
             unsigned long long newGoodMask = 0;
-            if (FIX) newGoodMask = __ballot(doLin && st != RES_OOB && activeNew && B.rnew[exists ? slot : 0] && k == 0);
+            if (FIX) newGoodMask = __ballot(doLin && st != RES_OOB && activeNew && q.rnew[g] && k == 0);
 
             // ================= accumulate: active residual, mode 0 (AccumulatedTopHessian.cc) ==========
             const bool accHere = doLin && activeNew && compute;
@@ -297,8 +368,8 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D,
                 const bool accL = isLin && activeNew;
                 float lsbd = 0, lsHdd = 0, lH0 = 0, lH1 = 0, lH2 = 0, lH3 = 0;
                 if (accL) {
-                    const ldso_rawjac_t &J = B.Jlin[B.rlidx[slot]];
-                    const float *rtz = B.rtz + B.rlidx[slot] * 8;
+                    const ldso_rawjac_t &J = B.Jlin[q.rlidx[g]];
+                    const float *rtz = B.rtz + q.rlidx[g] * 8;
                     float dpx = 0, dpy = 0;
 #pragma unroll
                     for (int i = 0; i < 6; i++) { dpx += J.Jpdxi[0][i] * pr.dp[i]; dpy += J.Jpdxi[1][i] * pr.dp[i]; }
@@ -379,10 +450,10 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D,
                     nxt.toRemove[slot] = toRemove;
                     if (doLin) energySum += ret;
                 }
-                if (k < 3) nxt.center[slot * 3 + k] = compute ? (k == 0 ? c0 : k == 1 ? c1 : c2) : cur.center[slot * 3 + k];
+                if (k < 3) nxt.center[slot * 3 + k] = compute ? (k == 0 ? c0 : k == 1 ? c1 : c2) : q.cen[g];
             }
             if (B.dumpJ != nullptr && compute) {
-                ldso_rawjac_t &o = B.dumpJ[B.rflat[slot]];
+                ldso_rawjac_t &o = B.dumpJ[q.rflat[g]];
                 o.resF[k] = resF; o.JIdx[0][k] = gx; o.JIdx[1][k] = gy; o.JabF[0][k] = jab0; o.JabF[1][k] = jab1;
                 if (k == 0) {
                     for (int i = 0; i < 6; i++) { o.Jpdxi[0][i] = x[4 + i]; o.Jpdxi[1][i] = y[4 + i]; }
@@ -475,27 +546,27 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D,
 // launcher
 // ---------------------------------------------------------------------------------------------------------
 size_t ba_linearize_lds_bytes(int FS, bool hasL) {
-    size_t fl = (size_t) FS * (sizeof(DevPair) / 4) + 2 * (size_t) FS * 64 + (size_t) LD_WAVES * FS * LD_TOPN + (hasL ? (size_t) FS * LD_TOPN : 0);
+    size_t fl = (size_t) FS * (sizeof(DevPair) / 4) + 2 * (size_t) FS * 64 + (size_t) LD_WAVES * FS * LD_TOPN + (hasL ? (size_t) FS * LD_TOPN : 0) + (size_t) FS * 8;
     return fl * sizeof(float) + 256;
 }
 
 template <int NSG, bool HAS_L, bool FIX>
-static hipError_t launch_one(const BaPtrs &B, const BaDims &D, const ResSet &cur, const ResSet &nxt, const ldso_settings_t &S, hipStream_t st) {
+static hipError_t launch_one(const BaPtrs &B, const BaDims &D, const ResSet &cur, const ResSet &nxt, const ldso_settings_t &S, int stepMode, hipStream_t st) {
     size_t lds = ba_linearize_lds_bytes(D.FS, HAS_L);
     auto kfn = k_linearize<NSG, HAS_L, FIX>;
     if (lds > 48 * 1024) hipFuncSetAttribute((const void *) kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-    hipLaunchKernelGGL(kfn, dim3(D.nChunks), dim3(64 * LD_WAVES), lds, st, B, D, cur, nxt, S);
+    hipLaunchKernelGGL(kfn, dim3(D.nChunks), dim3(64 * LD_WAVES), lds, st, B, D, cur, nxt, S, stepMode);
     return hipGetLastError();
 }
 
 hipError_t ba_launch_linearize(const BaPtrs &B, const BaDims &D, const ResSet &cur, const ResSet &nxt, const ldso_settings_t &S,
-                               bool hasL, bool fix, hipStream_t st) {
+                               bool hasL, bool fix, int stepMode, hipStream_t st) {
     if (D.nChunks == 0) return hipSuccess;
     if (D.nsg == 1) {
-        if (hasL) return fix ? launch_one<1, true, true>(B, D, cur, nxt, S, st) : launch_one<1, true, false>(B, D, cur, nxt, S, st);
-        return fix ? launch_one<1, false, true>(B, D, cur, nxt, S, st) : launch_one<1, false, false>(B, D, cur, nxt, S, st);
+        if (hasL) return fix ? launch_one<1, true, true>(B, D, cur, nxt, S, stepMode, st) : launch_one<1, true, false>(B, D, cur, nxt, S, stepMode, st);
+        return fix ? launch_one<1, false, true>(B, D, cur, nxt, S, stepMode, st) : launch_one<1, false, false>(B, D, cur, nxt, S, stepMode, st);
     } else {
-        if (hasL) return fix ? launch_one<2, true, true>(B, D, cur, nxt, S, st) : launch_one<2, true, false>(B, D, cur, nxt, S, st);
-        return fix ? launch_one<2, false, true>(B, D, cur, nxt, S, st) : launch_one<2, false, false>(B, D, cur, nxt, S, st);
+        if (hasL) return fix ? launch_one<2, true, true>(B, D, cur, nxt, S, stepMode, st) : launch_one<2, true, false>(B, D, cur, nxt, S, stepMode, st);
+        return fix ? launch_one<2, false, true>(B, D, cur, nxt, S, stepMode, st) : launch_one<2, false, false>(B, D, cur, nxt, S, stepMode, st);
     }
 }

@@ -57,6 +57,18 @@ static __device__ void post_sums(const BaPtrs &B, const BaDims &D, const ResSet 
     }
 }
 
+// resInA / resInL of the accumulate that produced this set (EnergyFunctional.cc:558,573)
+static __device__ void res_counts(const BaPtrs &B, const BaDims &D, const ResSet &S, double *sD /*8 doubles*/) {
+    const int tid = threadIdx.x;
+    double na = 0, nl = 0;
+    for (int c = tid; c < D.nChunks; c += NT) { na += S.chunkCnt[c * 2]; nl += S.chunkCnt[c * 2 + 1]; }
+    na = wave_sum(na); nl = wave_sum(nl);
+    if ((tid & 63) == 0) { sD[tid >> 6] = na; sD[4 + (tid >> 6)] = nl; }
+    __syncthreads();
+    if (tid == 0) { B.scalars[9] = sD[0] + sD[1] + sD[2] + sD[3]; B.scalars[10] = sD[4] + sD[5] + sD[6] + sD[7]; }
+    __syncthreads();
+}
+
 // candidates: active-set residuals targeting the newest frame with state_NewEnergyWithOutlier >= 0,
 // written compactly by the linearize kernel (S.candE[p], -1 = no candidate).
 // extE (multi-GPU): all-reduced array of P doubles holding value+1 for candidates and 0 otherwise.
@@ -241,11 +253,12 @@ static __device__ void set_adjoints(const BaPtrs &B, const BaDims &D, const ldso
 }
 
 // setPrecalcValues: frames' PRE poses, pair precalc, deltas
-static __device__ void set_precalc(const BaPtrs &B, const BaDims &D) {
+// fr / cal: working copies of the frames and the calibration (global memory, or the LDS mirror of k_gn_solve)
+static __device__ void set_precalc(const BaPtrs &B, const BaDims &D, DevFrame *fr, DevCalib *cal) {
     const int tid = threadIdx.x, F = D.F;
-    DevCalib &C = *B.calib;
+    DevCalib &C = *cal;
     if (tid < F) {
-        DevFrame &f = B.frames[tid];
+        DevFrame &f = fr[tid];
         double ss[6] = {0.5 * f.state[0], 0.5 * f.state[1], 0.5 * f.state[2], 1.0 * f.state[3], 1.0 * f.state[4], 1.0 * f.state[5]};
         double E[12];
         ld::se3_exp(ss, E);
@@ -263,7 +276,7 @@ static __device__ void set_precalc(const BaPtrs &B, const BaDims &D) {
     __syncthreads();
     for (int i = tid; i < F * F; i += NT) {
         const int h = i / F, t = i % F;
-        const DevFrame &fh = B.frames[h], &ft = B.frames[t];
+        const DevFrame &fh = fr[h], &ft = fr[t];
         DevPair pr;
         double Ti[12], T0[12], T[12];
         ld::se3_inv(fh.evalPT, Ti);
@@ -306,15 +319,25 @@ static __device__ void set_precalc(const BaPtrs &B, const BaDims &D) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// LDL^T of the scaled system in LDS.  The matrix is symmetric positive (semi-)definite after the
-// (diag+10)^-1/2 scaling, so the factorisation runs WITHOUT pivoting (Eigen's LDLT pivots on the
-// diagonal; for SPD input both give the same solution up to rounding).  The right-hand side rides along as
-// row n of the lower triangle, so the forward substitution is part of the factorisation.  One barrier
-// per column: the scaled column L[:,k] is written to the (otherwise unused) upper triangle A[k][i].
-// Zero pivots (all-zero row/column of a PSD matrix) are skipped, like Eigen's D^+ pseudo-inverse.
+// solve_core — EnergyFunctional::solveSystemF after the assembly (EnergyFunctional.cc:293-351): scale by
+// (diag+10)^-1/2, LDL^T, back substitution, unscale, orthogonalise against the gauge nullspaces, then the frame /
+// calibration part of resubstituteF_MT (:491-516).
+//
+// The matrix is symmetric positive (semi-)definite after the scaling, so the factorisation runs WITHOUT pivoting
+// (Eigen's LDLT pivots on the diagonal; for SPD input both give the same solution up to rounding).  Zero pivots
+// (all-zero row/column of a PSD matrix) are skipped, like Eigen's D^+ pseudo-inverse.
+//
+// Layout: the (n+1)x(n+1) augmented system (row n = right-hand side, so the forward substitution is part of the
+// factorisation) is padded to M = 16*NB and its lower triangle lives in REGISTERS: thread (ty,tx) of the 16x16
+// block owns element (ty+16a, tx+16b) of every tile a >= b.  FOUR columns are eliminated per round:
+//   phase 1: one thread per row replays the four scalar elimination steps on its 4 panel entries (private copy of
+//            the 4x4 pivot block) -> multipliers F[i][q] = L[i][k+q] and pivot-row values G[j][q] into LDS;
+//   phase 2: every thread applies the rank-4 update v -= sum_q F[i][q] G[j][q] to its register tiles and the
+//            owners of the next four columns publish them as the next panel.
+// Two barriers per round, no global or matrix LDS traffic inside the loop.  Every global read of the solve is
+// issued in the prologue (one latency level).
 // ---------------------------------------------------------------------------------------------------------
-// reciprocal with two Newton steps on the hardware estimate (v_rcp_f64): full double accuracy, a ~10x shorter
-// dependency chain than the IEEE division sequence — the factorisation is a chain of n dependent pivots.
+// reciprocal with two Newton steps on the hardware estimate (v_rcp_f64)
 static __device__ __forceinline__ double fast_rcp(double d) {
     double r = __builtin_amdgcn_rcp(d);
     r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
@@ -322,18 +345,74 @@ static __device__ __forceinline__ double fast_rcp(double d) {
     return r;
 }
 
-// The LDS matrix is padded to M = 16*NB rows/cols (M >= n+1): rows/cols [0,n) system, row n = rhs, the rest
-// padding (zeros).  FOUR columns are eliminated per round, two barriers per round:
-//   phase 1: one thread per row replays the four scalar elimination steps on its 4 panel entries (with a private
-//            copy of the 4x4 pivot block) -> scaled multipliers F[i][q] and unscaled pivots-row values G[j][q];
-//   phase 2: all threads apply the rank-4 update A[i][j] -= sum_q F[i][q] G[j][q] to the trailing lower triangle.
-// Arithmetic and order are those of the column-by-column LDL^T.  Outputs for the back substitution: D on the
-// diagonal, L[i][c] in the upper triangle A[c][i], y in row n.
+static __device__ __forceinline__ double readlane_f64(double v, int lane) {
+    unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    unsigned lo = (unsigned) __builtin_amdgcn_readlane((int) (u & 0xFFFFFFFFu), lane);
+    unsigned hi = (unsigned) __builtin_amdgcn_readlane((int) (u >> 32), lane);
+    return __builtin_bit_cast(double, ((unsigned long long) hi << 32) | lo);
+}
+
+// packed storage of L (column c holds rows c..M-1)
+#define LPK(i, c) ((c) * M - (((c) * ((c) -1)) >> 1) + ((i) - (c)))
+
+static __host__ __device__ inline size_t solve_core_lds_doubles(int NB, int n) {
+    size_t M = 16 * NB;
+    return M * (M + 1) / 2 + 2 * M /*D,Y*/ + 12 * M /*F,G,panel*/ + 2 * M /*scale,x*/ + 7 * (size_t) n + 16;
+}
+
 template <int NB>
-static __device__ void ldlt_factor_aug_t(double *A, int lda, int n, double *Fp, double *Gp) {
-    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+static __device__ void solve_core(const BaPtrs &B, const BaDims &D, const ldso_settings_t &St, int iteration, double *sm, DevFrame *fr, DevCalib *cal) {
+    constexpr int M = 16 * NB;
+    constexpr int NTILE = NB * (NB + 1) / 2;
     const double TINY = 2.2250738585072014e-308;
-    const int M = 16 * NB;
+    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15, F = D.F, n = D.n;
+    double *sL = sm;                       // packed L
+    double *sD = sL + M * (M + 1) / 2;     // [M]
+    double *sY = sD + M;                   // [M]
+    double *sFp = sY + M;                  // [M][4]
+    double *sGp = sFp + 4 * M;             // [M][4]
+    double *sPn = sGp + 4 * M;             // [M][4]
+    double *sSc = sPn + 4 * M;             // [M]
+    double *sx = sSc + M;                  // [M]
+    double *sNs = sx + M;                  // [7][n]
+    const double *HF = B.sys + 3 * (n * n + n), *bF = HF + n * n;
+    const bool ortho = (St.solverMode & LDSO_SOLVER_ORTHOGONALIZE_X) || (iteration >= 2 && (St.solverMode & LDSO_SOLVER_ORTHOGONALIZE_X_LATER));
+
+    // ---------------- prologue: all loads ----------------
+    double v[NTILE], dI[NB], dJ[NB];
+#pragma unroll
+    for (int a = 0; a < NB; a++) {
+        const int i = ty + 16 * a, j = tx + 16 * a;
+        dI[a] = (i < n) ? HF[(size_t) i * n + i] : 0.0;
+        dJ[a] = (j < n) ? HF[(size_t) j * n + j] : 0.0;
+    }
+#pragma unroll
+    for (int a = 0; a < NB; a++)
+#pragma unroll
+        for (int b = 0; b <= a; b++) {
+            const int i = ty + 16 * a, j = tx + 16 * b;
+            double q = 0.0;
+            if (j < n) { if (i < n) q = HF[(size_t) i * n + j]; else if (i == n) q = bF[j]; }
+            v[a * (a + 1) / 2 + b] = q;
+        }
+    const double dS = (tid < n) ? HF[(size_t) tid * n + tid] : 0.0;
+    if (ortho) for (int i = tid; i < 7 * n; i += NT) sNs[i] = B.nsProj[i];
+    if (tid < M) sSc[tid] = 1.0 / sqrt(dS + 10.0);
+#pragma unroll
+    for (int a = 0; a < NB; a++)
+#pragma unroll
+        for (int b = 0; b <= a; b++) {
+            const int i = ty + 16 * a;
+            const double si = (i == n) ? 1.0 : 1.0 / sqrt(dI[a] + 10.0), sj = 1.0 / sqrt(dJ[b] + 10.0);
+            v[a * (a + 1) / 2 + b] = si * v[a * (a + 1) / 2 + b] * sj;
+        }
+    // first panel (columns 0..3)
+    if (tx < 4) {
+#pragma unroll
+        for (int a = 0; a < NB; a++) sPn[(ty + 16 * a) * 4 + tx] = v[a * (a + 1) / 2];
+    }
+    __syncthreads();
+
     for (int k = 0; k < n; k += 4) {
         // ---------------- phase 1 ----------------
         if (tid < M) {
@@ -342,10 +421,10 @@ static __device__ void ldlt_factor_aug_t(double *A, int lda, int n, double *Fp, 
 #pragma unroll
             for (int r = 0; r < 4; r++)
 #pragma unroll
-                for (int c = 0; c <= r; c++) { double v = A[(k + r) * lda + k + c]; P[r][c] = v; P[c][r] = v; }
+                for (int c = 0; c <= r; c++) { double w = sPn[(k + r) * 4 + c]; P[r][c] = w; P[c][r] = w; }
             double a4[4];
 #pragma unroll
-            for (int q = 0; q < 4; q++) a4[q] = A[i * lda + k + q];
+            for (int q = 0; q < 4; q++) a4[q] = sPn[i * 4 + q];
             if (i >= k && i < k + 4) {
 #pragma unroll
                 for (int q = 0; q < 4; q++) a4[q] = (i == k) ? P[0][q] : (i == k + 1) ? P[1][q] : (i == k + 2) ? P[2][q] : P[3][q];
@@ -360,105 +439,146 @@ static __device__ void ldlt_factor_aug_t(double *A, int lda, int n, double *Fp, 
                 const double f = on ? a4[q] * invd : 0.0;
                 f4[q] = f;
 #pragma unroll
-                for (int r = q + 1; r < 4; r++) a4[r] -= f * P[q][r];
-                if (i == k + q) A[i * lda + i] = d;                       // D
+                for (int r = q + 1; r < 4; r++) a4[r] = __builtin_fma(-f, P[q][r], a4[r]);
+                if (i == k + q) sD[i] = d;
 #pragma unroll
                 for (int r = q + 1; r < 4; r++) {
-                    const double fr = P[r][q] * invd;
+                    const double fr_ = P[r][q] * invd;
 #pragma unroll
-                    for (int c = q + 1; c < 4; c++) P[r][c] -= fr * P[q][c];
+                    for (int c = q + 1; c < 4; c++) P[r][c] = __builtin_fma(-fr_, P[q][c], P[r][c]);
                 }
             }
             const bool colRole = (i >= k + 4) && (i < n);
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                Fp[i * 4 + q] = f4[q];
-                Gp[i * 4 + q] = colRole ? g4[q] : 0.0;
-                if (i > k + q && i < n) A[(k + q) * lda + i] = f4[q];     // L[i][k+q] -> upper triangle
-                if (i == n) A[n * lda + k + q] = g4[q];                   // y_{k+q}
+                sFp[i * 4 + q] = f4[q];
+                sGp[i * 4 + q] = colRole ? g4[q] : 0.0;
+                if (i > k + q && i < n) sL[LPK(i, k + q)] = f4[q];
+                if (i == n) sY[k + q] = g4[q];
             }
         }
         __syncthreads();
         // ---------------- phase 2 ----------------
-        const int a0 = (k + 4) >> 4;
+        const int a0 = (k + 4) >> 4, c0 = (k + 4) & 15;
         double fi[NB][4], gj[NB][4];
 #pragma unroll
         for (int a = 0; a < NB; a++)
 #pragma unroll
-            for (int q = 0; q < 4; q++) { fi[a][q] = Fp[(ty + 16 * a) * 4 + q]; gj[a][q] = Gp[(tx + 16 * a) * 4 + q]; }
+            for (int q = 0; q < 4; q++) { fi[a][q] = sFp[(ty + 16 * a) * 4 + q]; gj[a][q] = sGp[(tx + 16 * a) * 4 + q]; }
 #pragma unroll
-        for (int a = 0; a < NB; a++) {
-            if (a < a0) continue;
+        for (int b = 0; b < NB; b++) {
+            if (b < a0) continue;
 #pragma unroll
-            for (int b = 0; b <= a; b++) {
-                if (b < a0) continue;
-                const int i = ty + 16 * a, j = tx + 16 * b;
-                if (i >= k + 4 && j >= k + 4 && j <= i && j < n && i <= n) {
-                    double v = A[i * lda + j];
+            for (int a = b; a < NB; a++) {
+                double w = v[a * (a + 1) / 2 + b];
 #pragma unroll
-                    for (int q = 0; q < 4; q++) v -= fi[a][q] * gj[b][q];
-                    A[i * lda + j] = v;
-                }
+                for (int q = 0; q < 4; q++) w = __builtin_fma(-fi[a][q], gj[b][q], w);
+                v[a * (a + 1) / 2 + b] = w;
+            }
+            if (b == a0 && tx >= c0 && tx < c0 + 4) {
+#pragma unroll
+                for (int a = b; a < NB; a++) sPn[(ty + 16 * a) * 4 + (tx - c0)] = v[a * (a + 1) / 2 + b];
             }
         }
         __syncthreads();
     }
-}
 
-static __device__ void ldlt_factor_aug(double *A, int lda, int n, double *Fp, double *Gp) {
-    if (n + 1 <= 64) ldlt_factor_aug_t<4>(A, lda, n, Fp, Gp);
-    else if (n + 1 <= 112) ldlt_factor_aug_t<7>(A, lda, n, Fp, Gp);
-    else ldlt_factor_aug_t<9>(A, lda, n, Fp, Gp);
-}
-
-static __device__ __forceinline__ double readlane_f64(double v, int lane) {
-    unsigned long long u = __builtin_bit_cast(unsigned long long, v);
-    unsigned lo = (unsigned) __builtin_amdgcn_readlane((int) (u & 0xFFFFFFFFu), lane);
-    unsigned hi = (unsigned) __builtin_amdgcn_readlane((int) (u >> 32), lane);
-    return __builtin_bit_cast(double, ((unsigned long long) hi << 32) | lo);
-}
-
-// back substitution by wave 0: x = L^-T D^+ z, z = rhs row n, L[k][i] = A[i][k] (upper triangle, k > i)
-static __device__ void ldlt_back_wave(const double *A, int lda, int n, double *x) {
-    const int lane = threadIdx.x;
-    if (n < 64) {
-        // lane i owns x_i and row i of L^T in registers; x_k is broadcast with v_readlane (padded matrix: no guards)
-        double row[64];
+    // ---------------- back substitution by wave 0: x = L^-T D^+ y ----------------
+    if (tid < 64) {
+        const int lane = tid;
+        if (NB == 4 && n < 64) {
+            // lane i owns x_i and column i of L in registers; x_k is broadcast with v_readlane
+            double row[64];
 #pragma unroll
-        for (int k = 0; k < 64; k++) { double a = A[lane * lda + k]; row[k] = (k > lane && k < n) ? a : 0.0; }
-        const double d = A[lane * lda + lane];
-        const double z = A[n * lda + lane];
-        double xi = (lane < n && fabs(d) > 2.2250738585072014e-308) ? z / d : 0.0;
+            for (int kk = 0; kk < 64; kk++) { const bool in = (kk > lane && kk < n); double a = sL[in ? LPK(kk, lane) : 0]; row[kk] = in ? a : 0.0; }
+            const double d = sD[lane], z = sY[lane];
+            double xi = (lane < n && fabs(d) > TINY) ? z / d : 0.0;
 #pragma unroll
-        for (int k = 63; k >= 1; k--) { double xk = readlane_f64(xi, k); xi -= row[k] * xk; }
-        if (lane < n) x[lane] = xi;
-        return;
+            for (int kk = 63; kk >= 1; kk--) { double xk = readlane_f64(xi, kk); xi = __builtin_fma(-row[kk], xk, xi); }
+            if (lane < n) sx[lane] = xi * sSc[lane];
+        } else {
+            for (int i = lane; i < n; i += 64) { double d = sD[i]; sx[i] = (fabs(d) > TINY) ? sY[i] / d : 0.0; }
+            __builtin_amdgcn_wave_barrier();
+            for (int kk = n - 1; kk > 0; kk--) {           // column oriented: x_i -= L[k][i] x_k for i < k
+                const double xk = sx[kk];
+                for (int i = lane; i < kk; i += 64) sx[i] -= sL[LPK(kk, i)] * xk;
+                __builtin_amdgcn_wave_barrier();
+            }
+            for (int i = lane; i < n; i += 64) sx[i] *= sSc[i];
+        }
+        // orthogonalize x against the gauge nullspaces (x -= U U^T x)
+        if (ortho) {
+            __builtin_amdgcn_wave_barrier();
+            double c[7];
+            for (int kk = 0; kk < 7; kk++) { double s = 0; for (int r = lane; r < n; r += 64) s += sNs[kk * n + r] * sx[r]; c[kk] = wave_sum(s); }
+            for (int r = lane; r < n; r += 64) { double s = 0; for (int kk = 0; kk < 7; kk++) s += sNs[kk * n + r] * c[kk]; sx[r] -= s; }
+        }
     }
-    for (int i = lane; i < n; i += 64) { double d = A[i * lda + i]; x[i] = (fabs(d) > 2.2250738585072014e-308) ? A[n * lda + i] / d : 0.0; }
-    __builtin_amdgcn_wave_barrier();
-    for (int k = n - 1; k > 0; k--) {           // column oriented: x_i -= L[k][i] x_k for i < k
-        const double xk = x[k];
-        for (int i = lane; i < k; i += 64) x[i] -= A[i * lda + k] * xk;
-        __builtin_amdgcn_wave_barrier();
+    __syncthreads();
+    // ---------------- outputs: x, steps, xAd ----------------
+    bool bad = false;
+    for (int i = tid; i < n; i += NT) { B.x[i] = sx[i]; if (!isfinite(sx[i])) bad = true; }
+    if (bad) B.scalars[4] = 1.0;
+    if (tid < 4) { cal->step[tid] = -sx[tid]; B.xc[tid] = (float) sx[tid]; }
+    for (int i = tid; i < F * 10; i += NT) { int f = i / 10, a = i % 10; fr[f].step[a] = (a < 8) ? -sx[4 + 8 * f + a] : 0.0; }
+    for (int i = tid; i < F * F * 8; i += NT) {
+        int c = i & 7, pr = i >> 3, h = pr / F, t = pr % F;
+        const float *AH = B.adHostF + (size_t) (h + F * t) * 64, *AT = B.adTargetF + (size_t) (h + F * t) * 64;
+        float ah[8], at[8];
+#pragma unroll
+        for (int kk = 0; kk < 8; kk++) { ah[kk] = AH[kk * 8 + c]; at[kk] = AT[kk * 8 + c]; }
+        float s1 = 0, s2 = 0;
+#pragma unroll
+        for (int kk = 0; kk < 8; kk++) s1 += (float) sx[4 + 8 * h + kk] * ah[kk];
+#pragma unroll
+        for (int kk = 0; kk < 8; kk++) s2 += (float) sx[4 + 8 * t + kk] * at[kk];
+        B.xAd[i] = s1 + s2;
     }
+    __syncthreads();
+}
+
+static __device__ void solve_core_dispatch(const BaPtrs &B, const BaDims &D, const ldso_settings_t &St, int iteration, double *sm, DevFrame *fr, DevCalib *cal) {
+    if (D.n + 1 <= 64) solve_core<4>(B, D, St, iteration, sm, fr, cal);
+    else if (D.n + 1 <= 112) solve_core<7>(B, D, St, iteration, sm, fr, cal);
+    else solve_core<9>(B, D, St, iteration, sm, fr, cal);
+}
+
+// frame / calibration part of backupState, doStepFromBackup (+ canbreak), loadSateBackup on the working copies
+static __device__ void frames_backup(DevFrame *fr, DevCalib *cal, int F) {
+    const int tid = threadIdx.x;
+    if (tid < F) for (int i = 0; i < 10; i++) fr[tid].state_backup[i] = fr[tid].state[i];
+    if (tid == 0) for (int i = 0; i < 4; i++) cal->value_backup[i] = cal->value[i];
+    __syncthreads();
+}
+static __device__ void frames_step(const BaPtrs &B, const ldso_settings_t &St, DevFrame *fr, DevCalib *cal, int F, float sumNID) {
+    const int tid = threadIdx.x;
+    if (tid < F) for (int i = 0; i < 10; i++) fr[tid].state[i] = fr[tid].state_backup[i] + fr[tid].step[i];
+    if (tid == 0) {
+        for (int i = 0; i < 4; i++) cal->value[i] = cal->value_backup[i] + cal->step[i] * (double) 1.0f;
+        float sumA = 0, sumB = 0, sumT = 0, sumR = 0;
+        for (int f = 0; f < F; f++) {
+            const double *s = fr[f].step;
+            sumA += s[6] * s[6]; sumB += s[7] * s[7];
+            sumT += s[0] * s[0] + s[1] * s[1] + s[2] * s[2];
+            sumR += s[3] * s[3] + s[4] * s[4] + s[5] * s[5];
+        }
+        sumA /= F; sumB /= F; sumR /= F; sumT /= F;
+        bool cb = sqrtf(sumA) < 0.0005 * St.thOptIterations && sqrtf(sumB) < 0.00005 * St.thOptIterations &&
+                  sqrtf(sumR) < 0.00005 * St.thOptIterations && sqrtf(sumT) * sumNID < 0.00005 * St.thOptIterations;
+        B.scalars[3] = cb ? 1.0 : 0.0;
+    }
+    __syncthreads();
 }
 
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(NT) void k_solve(BaPtrs B, BaDims D, ResSet S, ldso_settings_t St, SolveArgs A) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int tid = threadIdx.x, F = D.F, n = D.n;
-    const int Mp = (n + 1 <= 64) ? 64 : (n + 1 <= 112) ? 112 : 144;      // padded dimension, see ldlt_factor_aug_t
-    const int lda = Mp + 1;
-    double *sA = sm;                         // (n+1)*(n+1): system + rhs row
-    double *sx = sA + (size_t) Mp * lda;      // n
-    double *sFG = sx + n;                    // 2 x [Mp][4] panel buffers of the factorisation
-    double *sW = sFG + 8 * Mp;               // scratch: 7n + 64
-    int *sTr = (int *) (sW + 7 * n + 64);    // n
-    int *sHist = sTr + n + (n & 1);          // 256
-    int *sI = sHist + 256;                   // 8
+    const int NBsel = (n + 1 <= 64) ? 4 : (n + 1 <= 112) ? 7 : 9;
+    double *sW = sm + solve_core_lds_doubles(NBsel, n);      // scratch: 7n + 64
+    int *sHist = (int *) (sW + 7 * n + 64);  // 256
+    int *sI = sHist + 256;                   // 8 (+ TH_CAP floats of candidate staging behind it)
     const unsigned fl = A.flags;
-    long long t0_ = clock64();
-#define STAMP(i) do { __syncthreads(); if (tid == 0) B.energyLog[40 + (i)] = (double) (clock64() - t0_); } while (0)
 
     if (fl & SK_COLLECT) {
         // FullSystem::optimize preamble: resetOOB on every non-linearised residual (FullSystem.cc:744-748)
@@ -467,7 +587,6 @@ __global__ __launch_bounds__(NT) void k_solve(BaPtrs B, BaDims D, ResSet S, ldso
         __syncthreads();
     }
     if (fl & SK_POST) post_sums(B, D, S, sW);
-    STAMP(0);
 
     if (fl & SK_REANCHOR) {
         if (tid == 0) {
@@ -482,7 +601,6 @@ __global__ __launch_bounds__(NT) void k_solve(BaPtrs B, BaDims D, ResSet S, ldso
     }
     if (fl & SK_ADJ) set_adjoints(B, D, St, sW);
 
-    double *HF = B.sys + 3 * (n * n + n), *bF = HF + n * n;
     if (fl & SK_EXPORT) {
         // multi-GPU: rank-local scalar sums ride in the all-reduce buffer
         double na = 0, nl = 0;
@@ -500,103 +618,76 @@ __global__ __launch_bounds__(NT) void k_solve(BaPtrs B, BaDims D, ResSet S, ldso
         __syncthreads();
     }
     if (fl & SK_THRESH) post_thresh(B, D, S, St, (fl & SK_FROMREDUCED) ? (A.reduceIn + 3 * (n * n + n) + 8) : nullptr, (float *) (sI + 8), sHist, sI);
-    STAMP(3);
     if (fl & SK_LOG) { if (tid == 0 && A.logIdx >= 0 && A.logIdx < 64) B.energyLog[A.logIdx] = B.scalars[0]; __syncthreads(); }
 
     if (fl & SK_SOLVE) {
         // HFinal / bFinal were assembled by k_gather (ba_reduce.hip)
-        if (!(fl & SK_FROMREDUCED)) {   // resInA / resInL of this accumulate (EnergyFunctional.cc:558,573)
-            double na = 0, nl = 0;
-            for (int c = tid; c < D.nChunks; c += NT) { na += S.chunkCnt[c * 2]; nl += S.chunkCnt[c * 2 + 1]; }
-            na = wave_sum(na); nl = wave_sum(nl);
-            if ((tid & 63) == 0) { sW[tid >> 6] = na; sW[4 + (tid >> 6)] = nl; }
-            __syncthreads();
-            if (tid == 0) { B.scalars[9] = sW[0] + sW[1] + sW[2] + sW[3]; B.scalars[10] = sW[4] + sW[5] + sW[6] + sW[7]; }
-            __syncthreads();
-        }
-        // scaled system into LDS (lower triangle is what the factorisation reads)
-        for (int i = tid; i < n; i += NT) sW[i] = 1.0 / sqrt(HF[(size_t) i * n + i] + 10.0);
-        __syncthreads();
-        for (int e = tid; e < Mp * lda; e += NT) sA[e] = 0.0;
-        __syncthreads();
-        for (int e0 = tid; e0 < n * n; e0 += 8 * NT) {
-            double q[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) { int e = e0 + u * NT; q[u] = (e < n * n) ? HF[e] : 0.0; }
-#pragma unroll
-            for (int u = 0; u < 8; u++) { int e = e0 + u * NT; if (e < n * n) { int i = e / n, j = e % n; sA[i * lda + j] = sW[i] * q[u] * sW[j]; } }
-        }
-        for (int i = tid; i < n; i += NT) sx[i] = sW[i] * bF[i];
-        __syncthreads();
-        for (int i = tid; i < n; i += NT) sA[n * lda + i] = sx[i];
-        __syncthreads();
-        STAMP(4);
-        ldlt_factor_aug(sA, lda, n, sFG, sFG + 4 * Mp);
-        STAMP(5);
-        if (tid < 64) ldlt_back_wave(sA, lda, n, sx);
-        __syncthreads();
-        STAMP(6);
-        for (int i = tid; i < n; i += NT) sx[i] *= sW[i];
-        __syncthreads();
-        // orthogonalize x against the gauge nullspaces (x -= U U^T x)
-        if ((St.solverMode & LDSO_SOLVER_ORTHOGONALIZE_X) || (A.iteration >= 2 && (St.solverMode & LDSO_SOLVER_ORTHOGONALIZE_X_LATER))) {
-            if (tid < 64) {
-                double c[7];
-                for (int k = 0; k < 7; k++) { double s = 0; for (int r = tid; r < n; r += 64) s += B.nsProj[k * n + r] * sx[r]; c[k] = wave_sum(s); }
-                for (int r = tid; r < n; r += 64) { double s = 0; for (int k = 0; k < 7; k++) s += B.nsProj[k * n + r] * c[k]; sx[r] -= s; }
-            }
-            __syncthreads();
-        }
-        // outputs: x, steps, xAd
-        bool bad = false;
-        for (int i = tid; i < n; i += NT) { B.x[i] = sx[i]; if (!isfinite(sx[i])) bad = true; }
-        if (bad) B.scalars[4] = 1.0;
-        if (tid < 4) { B.calib->step[tid] = -sx[tid]; B.xc[tid] = (float) sx[tid]; }
-        for (int i = tid; i < F * 10; i += NT) { int f = i / 10, a = i % 10; B.frames[f].step[a] = (a < 8) ? -sx[4 + 8 * f + a] : 0.0; }
-        for (int i = tid; i < F * F * 8; i += NT) {
-            int c = i & 7, pr = i >> 3, h = pr / F, t = pr % F;
-            const float *AH = B.adHostF + (size_t) (h + F * t) * 64, *AT = B.adTargetF + (size_t) (h + F * t) * 64;
-            float s1 = 0, s2 = 0;
-            for (int k = 0; k < 8; k++) s1 += (float) sx[4 + 8 * h + k] * AH[k * 8 + c];
-            for (int k = 0; k < 8; k++) s2 += (float) sx[4 + 8 * t + k] * AT[k * 8 + c];
-            B.xAd[i] = s1 + s2;
-        }
-        __syncthreads();
+        if (!(fl & SK_FROMREDUCED)) res_counts(B, D, S, sW);
+        solve_core_dispatch(B, D, St, A.iteration, sm, B.frames, B.calib);
     }
-
-    STAMP(7);
-    if (fl & SK_BACKUP) {
-        if (tid < F) for (int i = 0; i < 10; i++) B.frames[tid].state_backup[i] = B.frames[tid].state[i];
-        if (tid == 0) for (int i = 0; i < 4; i++) B.calib->value_backup[i] = B.calib->value[i];
-        __syncthreads();
-    }
-    if (fl & SK_STEP) {
-        if (tid < F) for (int i = 0; i < 10; i++) B.frames[tid].state[i] = B.frames[tid].state_backup[i] + B.frames[tid].step[i];
-        if (tid == 0) {
-            for (int i = 0; i < 4; i++) B.calib->value[i] = B.calib->value_backup[i] + B.calib->step[i] * (double) 1.0f;
-            float sumA = 0, sumB = 0, sumT = 0, sumR = 0;
-            for (int f = 0; f < F; f++) {
-                const double *s = B.frames[f].step;
-                sumA += s[6] * s[6]; sumB += s[7] * s[7];
-                sumT += s[0] * s[0] + s[1] * s[1] + s[2] * s[2];
-                sumR += s[3] * s[3] + s[4] * s[4] + s[5] * s[5];
-            }
-            sumA /= F; sumB /= F; sumR /= F; sumT /= F;
-            float sumNID = (float) B.scalars[6] / (float) B.scalars[7];
-            bool cb = sqrtf(sumA) < 0.0005 * St.thOptIterations && sqrtf(sumB) < 0.00005 * St.thOptIterations &&
-                      sqrtf(sumR) < 0.00005 * St.thOptIterations && sqrtf(sumT) * sumNID < 0.00005 * St.thOptIterations;
-            B.scalars[3] = cb ? 1.0 : 0.0;
-        }
-        __syncthreads();
-    }
+    if (fl & SK_BACKUP) frames_backup(B.frames, B.calib, F);
+    if (fl & SK_STEP) frames_step(B, St, B.frames, B.calib, F, (float) B.scalars[6] / (float) B.scalars[7]);
     if (fl & SK_LOADBK) {
         if (tid < F) for (int i = 0; i < 10; i++) B.frames[tid].state[i] = B.frames[tid].state_backup[i];
         if (tid == 0) for (int i = 0; i < 4; i++) B.calib->value[i] = B.calib->value_backup[i];
         __syncthreads();
     }
-    STAMP(8);
-    if (fl & SK_PRECALC) set_precalc(B, D);
-    STAMP(9);
+    if (fl & SK_PRECALC) set_precalc(B, D, B.frames, B.calib);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_gn_solve — the control step of ONE forced-accept Gauss-Newton iteration, two concurrent workgroups:
+//   block 0 (critical path): solve_core + backupState + doStepFromBackup + setPrecalcValues, working on an LDS
+//            mirror of the frames / calibration that is written back once at the end;
+//   block 1 (statistics of the previous linearizeAll): energy sums, setNewFrameEnergyTH, energy log.
+// The two blocks touch disjoint data: block 0 never reads frameEnergyTH (the linearize kernel takes the pair
+// maximum itself) and skips that word in its write-back; canbreak's sumNID is recomputed from the chunk sums.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void k_gn_solve(BaPtrs B, BaDims D, ResSet S, ldso_settings_t St, SolveArgs A) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int tid = threadIdx.x, F = D.F, n = D.n;
+    const int NBsel = (n + 1 <= 64) ? 4 : (n + 1 <= 112) ? 7 : 9;
+    double *sW = sm + solve_core_lds_doubles(NBsel, n);      // 64 doubles of scratch
+    if (blockIdx.x == 1) {
+        int *sHist = (int *) (sW + 64);
+        int *sI = sHist + 256;
+        post_sums(B, D, S, sW);
+        res_counts(B, D, S, sW);
+        post_thresh(B, D, S, St, nullptr, (float *) (sI + 8), sHist, sI);
+        if (tid == 0 && A.logIdx >= 0 && A.logIdx < 64) B.energyLog[A.logIdx] = B.scalars[0];
+        return;
+    }
+    DevFrame *sFr = (DevFrame *) (sW + 64);
+    DevCalib *sCal = (DevCalib *) (sFr + F);
+    // mirror of frames / calibration (32-bit words)
+    {
+        const unsigned *gF = (const unsigned *) B.frames; unsigned *lF = (unsigned *) sFr;
+        for (int i = tid; i < F * (int) (sizeof(DevFrame) / 4); i += NT) lF[i] = gF[i];
+        const unsigned *gC = (const unsigned *) B.calib; unsigned *lC = (unsigned *) sCal;
+        for (int i = tid; i < (int) (sizeof(DevCalib) / 4); i += NT) lC[i] = gC[i];
+    }
+    // sumNID of doStepFromBackup, same summation order as post_sums
+    float sumNID;
+    {
+        double ns = 0, nc = 0;
+        for (int c = tid; c < D.nChunks; c += NT) { ns += (double) S.chunkNID[c * 2]; nc += (double) S.chunkNID[c * 2 + 1]; }
+        ns = wave_sum(ns); nc = wave_sum(nc);
+        if ((tid & 63) == 0) { sW[tid >> 6] = ns; sW[4 + (tid >> 6)] = nc; }
+        __syncthreads();
+        sumNID = (float) (sW[0] + sW[1] + sW[2] + sW[3]) / (float) (sW[4] + sW[5] + sW[6] + sW[7]);
+    }
+    solve_core_dispatch(B, D, St, A.iteration, sm, sFr, sCal);
+    frames_backup(sFr, sCal, F);
+    frames_step(B, St, sFr, sCal, F, sumNID);
+    set_precalc(B, D, sFr, sCal);
+    // write the mirrors back (all but frameEnergyTH, which block 1 owns)
+    {
+        unsigned *gF = (unsigned *) B.frames; const unsigned *lF = (const unsigned *) sFr;
+        const int W = (int) (sizeof(DevFrame) / 4), skip = (int) (offsetof(DevFrame, frameEnergyTH) / 4);
+        for (int i = tid; i < F * W; i += NT) if (i % W != skip) gF[i] = lF[i];
+        unsigned *gC = (unsigned *) B.calib; const unsigned *lC = (const unsigned *) sCal;
+        for (int i = tid; i < (int) (sizeof(DevCalib) / 4); i += NT) gC[i] = lC[i];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -636,12 +727,23 @@ __global__ __launch_bounds__(256) void k_point_step(BaPtrs B, BaDims D, ResSet S
     }
 }
 
+static size_t solve_lds_common(const BaDims &D) {
+    const int n = D.n, NBsel = (n + 1 <= 64) ? 4 : (n + 1 <= 112) ? 7 : 9;
+    return solve_core_lds_doubles(NBsel, n) * sizeof(double);
+}
+
 hipError_t ba_launch_solve(const BaPtrs &B, const BaDims &D, const ResSet &S, const ldso_settings_t &St, const SolveArgs &A, hipStream_t st) {
-    size_t n = D.n;
-    size_t Mp = (n + 1 <= 64) ? 64 : (n + 1 <= 112) ? 112 : 144;
-    size_t lds = (Mp * (Mp + 1) + n + 8 * Mp + 7 * n + 64) * sizeof(double) + (n + 2 + 256 + 8) * sizeof(int) + 64 + TH_CAP * sizeof(float);
+    size_t lds = solve_lds_common(D) + (7 * (size_t) D.n + 64) * sizeof(double) + (256 + 8) * sizeof(int) + TH_CAP * sizeof(float) + 64;
     if (lds > 48 * 1024) hipFuncSetAttribute((const void *) k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
     hipLaunchKernelGGL(k_solve, dim3(1), dim3(NT), lds, st, B, D, S, St, A);
+    return hipGetLastError();
+}
+
+hipError_t ba_launch_gn_solve(const BaPtrs &B, const BaDims &D, const ResSet &S, const ldso_settings_t &St, const SolveArgs &A, hipStream_t st) {
+    size_t mirror = (size_t) D.F * sizeof(DevFrame) + sizeof(DevCalib), stats = (256 + 8) * sizeof(int) + TH_CAP * sizeof(float);
+    size_t lds = solve_lds_common(D) + 64 * sizeof(double) + (mirror > stats ? mirror : stats) + 64;
+    if (lds > 48 * 1024) hipFuncSetAttribute((const void *) k_gn_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+    hipLaunchKernelGGL(k_gn_solve, dim3(2), dim3(NT), lds, st, B, D, S, St, A);
     return hipGetLastError();
 }
 
