@@ -13,7 +13,9 @@
 #include "ba_dev.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-#define SC_SLAB 64
+#define SC_SLAB 128     // points staged per LDS slab (one slab per split at the C3 window: a single load level)
+#define PA_SLICES 2     // Part A: interleaved slices of a pair's chunk range (2 x 91 threads)
+#define PA_UNROLL 16    // Part A: partial loads in flight per thread
 #define SC_MAXT 12      // tiles per wave: GSP=144 (FS=16) -> 45 upper tiles / 4 waves
 
 __host__ __device__ constexpr int tri13r(int r, int c) { return r * 13 - (r * (r - 1)) / 2 + (c - r); }
@@ -33,9 +35,29 @@ __global__ __launch_bounds__(256) void k_reduce(BaPtrs B, BaDims D, ResSet S, co
         const int h = pair / F, t = pair % F;        // pairC index [h*F + t]
         const float *part = which ? S.topL : S.topA;
         const int c0 = chunkStart[h], c1 = chunkStart[h + 1];
-        if (tid < LD_TOPN) {
+        // adjoints of this pair -> LDS (issued together with the partial loads: one latency level)
+        __shared__ double sAH[64], sAT[64];
+        __shared__ double sPart[PA_SLICES][LD_TOPN];
+        if (tid >= 128 && tid < 192) { sAH[tid - 128] = B.adHost[(size_t) (h + t * F) * 64 + (tid - 128)]; }
+        if (tid >= 192) { sAT[tid - 192] = B.adTarget[(size_t) (h + t * F) * 64 + (tid - 192)]; }
+        // the per-chunk partials of this pair: PA_SLICES interleaved slices of the chunk range, PA_UNROLL loads in flight
+        const int slice = tid / LD_TOPN, ent = tid % LD_TOPN;
+        if (slice < PA_SLICES) {
             double a = 0;
-            for (int c = c0; c < c1; c++) a += (double) part[((size_t) c * FS + t) * LD_TOPN + tid];
+            for (int cb = c0 + slice; cb < c1; cb += PA_SLICES * PA_UNROLL) {
+                float q[PA_UNROLL];
+#pragma unroll
+                for (int u = 0; u < PA_UNROLL; u++) { int c = cb + u * PA_SLICES; q[u] = (c < c1) ? part[((size_t) c * FS + t) * LD_TOPN + ent] : 0.0f; }
+#pragma unroll
+                for (int u = 0; u < PA_UNROLL; u++) a += (double) q[u];
+            }
+            sPart[slice][ent] = a;
+        }
+        __syncthreads();
+        if (tid < LD_TOPN) {
+            double a = sPart[0][tid];
+#pragma unroll
+            for (int sl = 1; sl < PA_SLICES; sl++) a += sPart[sl][tid];
             // unpack to symmetric 13x13
             int r = 0, rem = tid;
             while (rem >= 13 - r) { rem -= 13 - r; r++; }
@@ -45,7 +67,7 @@ __global__ __launch_bounds__(256) void k_reduce(BaPtrs B, BaDims D, ResSet S, co
         }
         __syncthreads();
         double *out = B.pairC + ((size_t) which * F * F + pair) * LD_PAIRC;
-        const double *AH = B.adHost + (size_t) (h + t * F) * 64, *AT = B.adTarget + (size_t) (h + t * F) * 64;
+        const double *AH = sAH, *AT = sAT;
         if (tid < 64) {
             int i = tid >> 3, j = tid & 7;
             double th = 0, tt = 0;
@@ -108,17 +130,27 @@ __global__ __launch_bounds__(256) void k_reduce(BaPtrs B, BaDims D, ResSet S, co
     for (int base = pa; base < pb; base += SC_SLAB) {
         const int cnt = min(SC_SLAB, pb - base);
         __syncthreads();
-        for (int e = tid; e < SC_SLAB * GSP; e += 256) {
-            int r = e / GSP, c = e % GSP;
-            sG[e] = (r < cnt && c < GS) ? S.G[(size_t) (base + r) * GS + c] : 0.f;
+        {
+            // coalesced 16-byte row copies (GS is a multiple of 8 floats); the pad columns GS..GSP-1 and the unused rows are zeroed
+            const int g4 = GS >> 2, p4 = GSP >> 2;
+            const int rows = (cnt + 3) & ~3;          // the MFMA loop consumes rows in groups of 4
+            for (int e0 = tid; e0 < rows * p4; e0 += 256 * 8) {
+                float4 q[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int e = e0 + u * 256, r = e / p4, c = e % p4;
+                    q[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (e < rows * p4 && r < cnt && c < g4) q[u] = ((const float4 *) (S.G + (size_t) (base + r) * GS))[c];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) { const int e = e0 + u * 256; if (e < rows * p4) ((float4 *) sG)[e] = q[u]; }
+            }
         }
-        __syncthreads();
-        if (tid < SC_SLAB) sWt[tid] = sG[tid * GSP + 8 * FS + 5];
         __syncthreads();
         for (int k0 = 0; k0 < SC_SLAB; k0 += 4) {
             if (k0 >= cnt) break;
             const float *row = sG + (k0 + lk) * GSP;
-            const float w = sWt[k0 + lk];
+            const float w = row[8 * FS + 5];
 #pragma unroll
             for (int q = 0; q < SC_MAXT; q++) {
                 if (q < nMine) {
@@ -149,31 +181,48 @@ __global__ __launch_bounds__(256) void k_reduce(BaPtrs B, BaDims D, ResSet S, co
 // ---------------------------------------------------------------------------------------------------------
 static __device__ __forceinline__ int g_col(int i, int FS) { return (i < 4) ? (8 * FS + i) : (i - 4); }
 
+// sum over x = 0..F-1 of PC[(base + x*stride) * LD_PAIRC + off], fixed order, all loads issued before the adds
+static __device__ __forceinline__ double sum_f(const double *PC, int F, int base, int stride, int off, double init = 0.0) {
+    double q[LD_MAXF];
+#pragma unroll
+    for (int x = 0; x < LD_MAXF; x++) q[x] = (x < F) ? PC[(size_t) (base + x * stride) * LD_PAIRC + off] : 0.0;
+    double v = init;
+#pragma unroll
+    for (int x = 0; x < LD_MAXF; x++) if (x < F) v += q[x];
+    return v;
+}
+// sum over all F*F pairs, 16 loads in flight
+static __device__ __forceinline__ double sum_pairs(const double *PC, int F, int off) {
+    double v = 0;
+    for (int p0 = 0; p0 < F * F; p0 += 16) {
+        double q[16];
+#pragma unroll
+        for (int x = 0; x < 16; x++) q[x] = (p0 + x < F * F) ? PC[(size_t) (p0 + x) * LD_PAIRC + off] : 0.0;
+#pragma unroll
+        for (int x = 0; x < 16; x++) if (p0 + x < F * F) v += q[x];
+    }
+    return v;
+}
+
 static __device__ __forceinline__ double top_entry(const double *PC, int F, int i, int j) {
     // i, j in reference ordering [calib 4 | frames 8F]; j == -1 -> b entry
-    double v = 0;
     if (j < 0) {
-        if (i < 4) { for (int pq = 0; pq < F * F; pq++) v += PC[(size_t) pq * LD_PAIRC + 288 + i]; }
-        else {
-            int f = (i - 4) >> 3, a = (i - 4) & 7;
-            for (int t = 0; t < F; t++) v += PC[(size_t) (f * F + t) * LD_PAIRC + 272 + a];
-            for (int h = 0; h < F; h++) v += PC[(size_t) (h * F + f) * LD_PAIRC + 280 + a];
-        }
-        return v;
+        if (i < 4) return sum_pairs(PC, F, 288 + i);
+        int f = (i - 4) >> 3, a = (i - 4) & 7;
+        double v = sum_f(PC, F, f * F, 1, 272 + a);
+        return sum_f(PC, F, f, F, 280 + a, v);          // host part first, then target part
     }
-    if (i < 4 && j < 4) { for (int pq = 0; pq < F * F; pq++) v += PC[(size_t) pq * LD_PAIRC + 256 + i * 4 + j]; return v; }
+    if (i < 4 && j < 4) return sum_pairs(PC, F, 256 + i * 4 + j);
     if (i < 4 || j < 4) {
         int fi = (i < 4) ? j : i, c = (i < 4) ? i : j;
         int f = (fi - 4) >> 3, a = (fi - 4) & 7;
-        for (int t = 0; t < F; t++) v += PC[(size_t) (f * F + t) * LD_PAIRC + 192 + a * 4 + c];
-        for (int h = 0; h < F; h++) v += PC[(size_t) (h * F + f) * LD_PAIRC + 224 + a * 4 + c];
-        return v;
+        double v = sum_f(PC, F, f * F, 1, 192 + a * 4 + c);
+        return sum_f(PC, F, f, F, 224 + a * 4 + c, v);
     }
     int f = (i - 4) >> 3, a = (i - 4) & 7, g = (j - 4) >> 3, c = (j - 4) & 7;
     if (f == g) {
-        for (int t = 0; t < F; t++) v += PC[(size_t) (f * F + t) * LD_PAIRC + a * 8 + c];
-        for (int h = 0; h < F; h++) v += PC[(size_t) (h * F + f) * LD_PAIRC + 64 + a * 8 + c];
-        return v;
+        double v = sum_f(PC, F, f * F, 1, a * 8 + c);
+        return sum_f(PC, F, f, F, 64 + a * 8 + c, v);
     }
     if (f < g) return PC[(size_t) (f * F + g) * LD_PAIRC + 128 + a * 8 + c] + PC[(size_t) (g * F + f) * LD_PAIRC + 128 + c * 8 + a];
     return PC[(size_t) (g * F + f) * LD_PAIRC + 128 + c * 8 + a] + PC[(size_t) (f * F + g) * LD_PAIRC + 128 + a * 8 + c];

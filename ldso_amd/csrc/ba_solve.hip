@@ -254,7 +254,7 @@ static __device__ void set_adjoints(const BaPtrs &B, const BaDims &D, const ldso
 
 // setPrecalcValues: frames' PRE poses, pair precalc, deltas
 // fr / cal: working copies of the frames and the calibration (global memory, or the LDS mirror of k_gn_solve)
-static __device__ void set_precalc(const BaPtrs &B, const BaDims &D, DevFrame *fr, DevCalib *cal) {
+static __device__ void set_precalc(const BaPtrs &B, const BaDims &D, DevFrame *fr, DevCalib *cal, const float *adH, const float *adT) {
     const int tid = threadIdx.x, F = D.F;
     DevCalib &C = *cal;
     if (tid < F) {
@@ -306,7 +306,7 @@ static __device__ void set_precalc(const BaPtrs &B, const BaDims &D, DevFrame *f
         pr.b0 = (float) (fh.state_zero[7] * 1000.0);
         pr.thMax = fmaxf(fh.frameEnergyTH, ft.frameEnergyTH);
         // adHTdeltaF[h + t*F] = delta_h^T adHostF + delta_t^T adTargetF  (EnergyFunctional.cc:403-414)
-        const float *AH = B.adHostF + (size_t) (h + t * F) * 64, *AT = B.adTargetF + (size_t) (h + t * F) * 64;
+        const float *AH = adH + (size_t) (h + t * F) * 64, *AT = adT + (size_t) (h + t * F) * 64;
         for (int c = 0; c < 8; c++) {
             float s1 = 0, s2 = 0;
             for (int k = 0; k < 8; k++) s1 += (float) (fh.state[k] - fh.state_zero[k]) * AH[k * 8 + c];
@@ -360,8 +360,19 @@ static __host__ __device__ inline size_t solve_core_lds_doubles(int NB, int n) {
     return M * (M + 1) / 2 + 2 * M /*D,Y*/ + 12 * M /*F,G,panel*/ + 2 * M /*scale,x*/ + 7 * (size_t) n + 16;
 }
 
-template <int NB>
-static __device__ void solve_core(const BaPtrs &B, const BaDims &D, const ldso_settings_t &St, int iteration, double *sm, DevFrame *fr, DevCalib *cal) {
+// GN = true (k_gn_solve): the prologue also mirrors the frames / calibration (and, when they fit, the float
+// adjoints) into LDS and reduces sumNID, so that the whole control step has ONE global-load latency level.
+struct SolveIO {
+    DevFrame *fr;          // working copy of the frames (global, or the LDS mirror)
+    DevCalib *cal;
+    const float *adH, *adT;  // float adjoints [F*F][64] (global, or LDS)
+    float *ldsAd;          // LDS room for both adjoint tables (GN, may be null)
+    double *sRed;          // 16 doubles of LDS scratch
+    float sumNID;          // out (GN)
+};
+
+template <int NB, bool GN>
+static __device__ void solve_core(const BaPtrs &B, const BaDims &D, const ResSet &S, const ldso_settings_t &St, int iteration, double *sm, SolveIO &io) {
     constexpr int M = 16 * NB;
     constexpr int NTILE = NB * (NB + 1) / 2;
     const double TINY = 2.2250738585072014e-308;
@@ -396,6 +407,23 @@ static __device__ void solve_core(const BaPtrs &B, const BaDims &D, const ldso_s
             v[a * (a + 1) / 2 + b] = q;
         }
     const double dS = (tid < n) ? HF[(size_t) tid * n + tid] : 0.0;
+    if (GN) {
+        double ns = 0, nc = 0;      // sumNID of doStepFromBackup, same summation order as post_sums
+        for (int c = tid; c < D.nChunks; c += NT) { ns += (double) S.chunkNID[c * 2]; nc += (double) S.chunkNID[c * 2 + 1]; }
+        const unsigned *gF = (const unsigned *) B.frames; unsigned *lF = (unsigned *) io.fr;
+        for (int i = tid; i < F * (int) (sizeof(DevFrame) / 4); i += NT) lF[i] = gF[i];
+        const unsigned *gC = (const unsigned *) B.calib; unsigned *lC = (unsigned *) io.cal;
+        for (int i = tid; i < (int) (sizeof(DevCalib) / 4); i += NT) lC[i] = gC[i];
+        if (io.ldsAd != nullptr) {
+            const float4 *gh = (const float4 *) B.adHostF, *gt = (const float4 *) B.adTargetF;
+            float4 *lh = (float4 *) io.ldsAd, *lt = (float4 *) (io.ldsAd + F * F * 64);
+            for (int i = tid; i < F * F * 16; i += NT) { lh[i] = gh[i]; lt[i] = gt[i]; }
+            io.adH = io.ldsAd; io.adT = io.ldsAd + F * F * 64;
+        }
+        // two interleaved butterfly reductions
+        for (int o = 32; o > 0; o >>= 1) { double a_ = __shfl_xor(ns, o, 64), b_ = __shfl_xor(nc, o, 64); ns += a_; nc += b_; }
+        if ((tid & 63) == 0) { io.sRed[tid >> 6] = ns; io.sRed[4 + (tid >> 6)] = nc; }
+    }
     if (ortho) for (int i = tid; i < 7 * n; i += NT) sNs[i] = B.nsProj[i];
     if (tid < M) sSc[tid] = 1.0 / sqrt(dS + 10.0);
 #pragma unroll
@@ -412,6 +440,8 @@ static __device__ void solve_core(const BaPtrs &B, const BaDims &D, const ldso_s
         for (int a = 0; a < NB; a++) sPn[(ty + 16 * a) * 4 + tx] = v[a * (a + 1) / 2];
     }
     __syncthreads();
+    if (GN && tid == 0) B.energyLog[41] = (double) wall_clock64();
+    if (GN) io.sumNID = (float) (io.sRed[0] + io.sRed[1] + io.sRed[2] + io.sRed[3]) / (float) (io.sRed[4] + io.sRed[5] + io.sRed[6] + io.sRed[7]);
 
     for (int k = 0; k < n; k += 4) {
         // ---------------- phase 1 ----------------
@@ -419,16 +449,20 @@ static __device__ void solve_core(const BaPtrs &B, const BaDims &D, const ldso_s
             const int i = tid;
             double P[4][4];
 #pragma unroll
-            for (int r = 0; r < 4; r++)
+            for (int r = 0; r < 4; r++) {
+                const double2 lo = *(const double2 *) &sPn[(k + r) * 4], hi = *(const double2 *) &sPn[(k + r) * 4 + 2];
+                const double w[4] = {lo.x, lo.y, hi.x, hi.y};
 #pragma unroll
-                for (int c = 0; c <= r; c++) { double w = sPn[(k + r) * 4 + c]; P[r][c] = w; P[c][r] = w; }
-            double a4[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++) a4[q] = sPn[i * 4 + q];
-            if (i >= k && i < k + 4) {
-#pragma unroll
-                for (int q = 0; q < 4; q++) a4[q] = (i == k) ? P[0][q] : (i == k + 1) ? P[1][q] : (i == k + 2) ? P[2][q] : P[3][q];
+                for (int c = 0; c <= r; c++) { P[r][c] = w[c]; P[c][r] = w[c]; }
             }
+            double a4[4];
+            {
+                const double2 lo = *(const double2 *) &sPn[i * 4], hi = *(const double2 *) &sPn[i * 4 + 2];
+                a4[0] = lo.x; a4[1] = lo.y; a4[2] = hi.x; a4[3] = hi.y;
+            }
+            const int ri = i - k;
+#pragma unroll
+            for (int q = 0; q < 4; q++) a4[q] = (ri == 0) ? P[0][q] : (ri == 1) ? P[1][q] : (ri == 2) ? P[2][q] : (ri == 3) ? P[3][q] : a4[q];
             double f4[4], g4[4];
 #pragma unroll
             for (int q = 0; q < 4; q++) {
@@ -449,48 +483,58 @@ static __device__ void solve_core(const BaPtrs &B, const BaDims &D, const ldso_s
                 }
             }
             const bool colRole = (i >= k + 4) && (i < n);
+            *(double2 *) &sFp[i * 4] = make_double2(f4[0], f4[1]);
+            *(double2 *) &sFp[i * 4 + 2] = make_double2(f4[2], f4[3]);
+            *(double2 *) &sGp[i * 4] = colRole ? make_double2(g4[0], g4[1]) : make_double2(0.0, 0.0);
+            *(double2 *) &sGp[i * 4 + 2] = colRole ? make_double2(g4[2], g4[3]) : make_double2(0.0, 0.0);
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                sFp[i * 4 + q] = f4[q];
-                sGp[i * 4 + q] = colRole ? g4[q] : 0.0;
                 if (i > k + q && i < n) sL[LPK(i, k + q)] = f4[q];
                 if (i == n) sY[k + q] = g4[q];
             }
         }
         __syncthreads();
-        // ---------------- phase 2 ----------------
+        // ---------------- phase 2 (branch free: finished columns have G = 0, finished rows F = 0) ----------------
         const int a0 = (k + 4) >> 4, c0 = (k + 4) & 15;
         double fi[NB][4], gj[NB][4];
 #pragma unroll
+        for (int a = 0; a < NB; a++) {
+            const double2 f0 = *(const double2 *) &sFp[(ty + 16 * a) * 4], f1 = *(const double2 *) &sFp[(ty + 16 * a) * 4 + 2];
+            const double2 g0 = *(const double2 *) &sGp[(tx + 16 * a) * 4], g1 = *(const double2 *) &sGp[(tx + 16 * a) * 4 + 2];
+            fi[a][0] = f0.x; fi[a][1] = f0.y; fi[a][2] = f1.x; fi[a][3] = f1.y;
+            gj[a][0] = g0.x; gj[a][1] = g0.y; gj[a][2] = g1.x; gj[a][3] = g1.y;
+        }
+#pragma unroll
         for (int a = 0; a < NB; a++)
 #pragma unroll
-            for (int q = 0; q < 4; q++) { fi[a][q] = sFp[(ty + 16 * a) * 4 + q]; gj[a][q] = sGp[(tx + 16 * a) * 4 + q]; }
-#pragma unroll
-        for (int b = 0; b < NB; b++) {
-            if (b < a0) continue;
-#pragma unroll
-            for (int a = b; a < NB; a++) {
+            for (int b = 0; b <= a; b++) {
                 double w = v[a * (a + 1) / 2 + b];
 #pragma unroll
                 for (int q = 0; q < 4; q++) w = __builtin_fma(-fi[a][q], gj[b][q], w);
                 v[a * (a + 1) / 2 + b] = w;
             }
-            if (b == a0 && tx >= c0 && tx < c0 + 4) {
+        // owners of columns k+4 .. k+7 publish them as the next panel
+        const bool pub = (tx >= c0) && (tx < c0 + 4);
 #pragma unroll
-                for (int a = b; a < NB; a++) sPn[(ty + 16 * a) * 4 + (tx - c0)] = v[a * (a + 1) / 2 + b];
-            }
+        for (int a = 0; a < NB; a++) {
+            double w = v[a * (a + 1) / 2];
+#pragma unroll
+            for (int b = 1; b <= a; b++) w = (a0 == b) ? v[a * (a + 1) / 2 + b] : w;
+            if (pub && a >= a0) sPn[(ty + 16 * a) * 4 + (tx - c0)] = w;
         }
         __syncthreads();
     }
 
+    if (GN && tid == 0) B.energyLog[42] = (double) wall_clock64();
     // ---------------- back substitution by wave 0: x = L^-T D^+ y ----------------
     if (tid < 64) {
         const int lane = tid;
         if (NB == 4 && n < 64) {
             // lane i owns x_i and column i of L in registers; x_k is broadcast with v_readlane
             double row[64];
+            const int base = lane * M - ((lane * (lane - 1)) >> 1) - lane;      // LPK(kk, lane) = base + kk
 #pragma unroll
-            for (int kk = 0; kk < 64; kk++) { const bool in = (kk > lane && kk < n); double a = sL[in ? LPK(kk, lane) : 0]; row[kk] = in ? a : 0.0; }
+            for (int kk = 0; kk < 64; kk++) { const bool in = (kk > lane && kk < n); double a = sL[in ? base + kk : 0]; row[kk] = in ? a : 0.0; }
             const double d = sD[lane], z = sY[lane];
             double xi = (lane < n && fabs(d) > TINY) ? z / d : 0.0;
 #pragma unroll
@@ -506,24 +550,43 @@ static __device__ void solve_core(const BaPtrs &B, const BaDims &D, const ldso_s
             }
             for (int i = lane; i < n; i += 64) sx[i] *= sSc[i];
         }
-        // orthogonalize x against the gauge nullspaces (x -= U U^T x)
+        // orthogonalize x against the gauge nullspaces (x -= U U^T x); the 7 reductions run interleaved
         if (ortho) {
             __builtin_amdgcn_wave_barrier();
             double c[7];
-            for (int kk = 0; kk < 7; kk++) { double s = 0; for (int r = lane; r < n; r += 64) s += sNs[kk * n + r] * sx[r]; c[kk] = wave_sum(s); }
-            for (int r = lane; r < n; r += 64) { double s = 0; for (int kk = 0; kk < 7; kk++) s += sNs[kk * n + r] * c[kk]; sx[r] -= s; }
+#pragma unroll
+            for (int kk = 0; kk < 7; kk++) { double s_ = 0; for (int r = lane; r < n; r += 64) s_ += sNs[kk * n + r] * sx[r]; c[kk] = s_; }
+            for (int o = 32; o > 0; o >>= 1) {
+                double t_[7];
+#pragma unroll
+                for (int kk = 0; kk < 7; kk++) t_[kk] = __shfl_xor(c[kk], o, 64);
+#pragma unroll
+                for (int kk = 0; kk < 7; kk++) c[kk] += t_[kk];
+            }
+            for (int r = lane; r < n; r += 64) { double s_ = 0; for (int kk = 0; kk < 7; kk++) s_ += sNs[kk * n + r] * c[kk]; sx[r] -= s_; }
         }
     }
     __syncthreads();
+    if (GN && tid == 0) B.energyLog[43] = (double) wall_clock64();
     // ---------------- outputs: x, steps, xAd ----------------
+    DevFrame *fr = io.fr;
     bool bad = false;
     for (int i = tid; i < n; i += NT) { B.x[i] = sx[i]; if (!isfinite(sx[i])) bad = true; }
     if (bad) B.scalars[4] = 1.0;
-    if (tid < 4) { cal->step[tid] = -sx[tid]; B.xc[tid] = (float) sx[tid]; }
-    for (int i = tid; i < F * 10; i += NT) { int f = i / 10, a = i % 10; fr[f].step[a] = (a < 8) ? -sx[4 + 8 * f + a] : 0.0; }
+    if (tid < 4) {
+        const double st = -sx[tid];
+        io.cal->step[tid] = st; B.xc[tid] = (float) sx[tid];
+        if (GN) { const double bk = io.cal->value[tid]; io.cal->value_backup[tid] = bk; io.cal->value[tid] = bk + st * (double) 1.0f; }
+    }
+    for (int i = tid; i < F * 10; i += NT) {
+        int f = i / 10, a = i % 10;
+        const double st = (a < 8) ? -sx[4 + 8 * f + a] : 0.0;
+        fr[f].step[a] = st;
+        if (GN) { const double bk = fr[f].state[a]; fr[f].state_backup[a] = bk; fr[f].state[a] = bk + st; }     // backupState + doStepFromBackup
+    }
     for (int i = tid; i < F * F * 8; i += NT) {
         int c = i & 7, pr = i >> 3, h = pr / F, t = pr % F;
-        const float *AH = B.adHostF + (size_t) (h + F * t) * 64, *AT = B.adTargetF + (size_t) (h + F * t) * 64;
+        const float *AH = io.adH + (size_t) (h + F * t) * 64, *AT = io.adT + (size_t) (h + F * t) * 64;
         float ah[8], at[8];
 #pragma unroll
         for (int kk = 0; kk < 8; kk++) { ah[kk] = AH[kk * 8 + c]; at[kk] = AT[kk * 8 + c]; }
@@ -537,24 +600,16 @@ static __device__ void solve_core(const BaPtrs &B, const BaDims &D, const ldso_s
     __syncthreads();
 }
 
-static __device__ void solve_core_dispatch(const BaPtrs &B, const BaDims &D, const ldso_settings_t &St, int iteration, double *sm, DevFrame *fr, DevCalib *cal) {
-    if (D.n + 1 <= 64) solve_core<4>(B, D, St, iteration, sm, fr, cal);
-    else if (D.n + 1 <= 112) solve_core<7>(B, D, St, iteration, sm, fr, cal);
-    else solve_core<9>(B, D, St, iteration, sm, fr, cal);
+template <bool GN>
+static __device__ void solve_core_dispatch(const BaPtrs &B, const BaDims &D, const ResSet &S, const ldso_settings_t &St, int iteration, double *sm, SolveIO &io) {
+    if (D.n + 1 <= 64) solve_core<4, GN>(B, D, S, St, iteration, sm, io);
+    else if (D.n + 1 <= 112) solve_core<7, GN>(B, D, S, St, iteration, sm, io);
+    else solve_core<9, GN>(B, D, S, St, iteration, sm, io);
 }
 
-// frame / calibration part of backupState, doStepFromBackup (+ canbreak), loadSateBackup on the working copies
-static __device__ void frames_backup(DevFrame *fr, DevCalib *cal, int F) {
-    const int tid = threadIdx.x;
-    if (tid < F) for (int i = 0; i < 10; i++) fr[tid].state_backup[i] = fr[tid].state[i];
-    if (tid == 0) for (int i = 0; i < 4; i++) cal->value_backup[i] = cal->value[i];
-    __syncthreads();
-}
-static __device__ void frames_step(const BaPtrs &B, const ldso_settings_t &St, DevFrame *fr, DevCalib *cal, int F, float sumNID) {
-    const int tid = threadIdx.x;
-    if (tid < F) for (int i = 0; i < 10; i++) fr[tid].state[i] = fr[tid].state_backup[i] + fr[tid].step[i];
-    if (tid == 0) {
-        for (int i = 0; i < 4; i++) cal->value[i] = cal->value_backup[i] + cal->step[i] * (double) 1.0f;
+// canbreak of doStepFromBackup (FullSystem.cc:1604-1622)
+static __device__ void step_canbreak(const BaPtrs &B, const ldso_settings_t &St, const DevFrame *fr, int F, float sumNID) {
+    if (threadIdx.x == 0) {
         float sumA = 0, sumB = 0, sumT = 0, sumR = 0;
         for (int f = 0; f < F; f++) {
             const double *s = fr[f].step;
@@ -567,6 +622,20 @@ static __device__ void frames_step(const BaPtrs &B, const ldso_settings_t &St, D
                   sqrtf(sumR) < 0.00005 * St.thOptIterations && sqrtf(sumT) * sumNID < 0.00005 * St.thOptIterations;
         B.scalars[3] = cb ? 1.0 : 0.0;
     }
+}
+
+// frame / calibration part of backupState, doStepFromBackup (+ canbreak), loadSateBackup on the working copies
+static __device__ void frames_backup(DevFrame *fr, DevCalib *cal, int F) {
+    const int tid = threadIdx.x;
+    if (tid < F) for (int i = 0; i < 10; i++) fr[tid].state_backup[i] = fr[tid].state[i];
+    if (tid == 0) for (int i = 0; i < 4; i++) cal->value_backup[i] = cal->value[i];
+    __syncthreads();
+}
+static __device__ void frames_step(const BaPtrs &B, const ldso_settings_t &St, DevFrame *fr, DevCalib *cal, int F, float sumNID) {
+    const int tid = threadIdx.x;
+    if (tid < F) for (int i = 0; i < 10; i++) fr[tid].state[i] = fr[tid].state_backup[i] + fr[tid].step[i];
+    if (tid == 0) for (int i = 0; i < 4; i++) cal->value[i] = cal->value_backup[i] + cal->step[i] * (double) 1.0f;
+    step_canbreak(B, St, fr, F, sumNID);
     __syncthreads();
 }
 
@@ -623,7 +692,9 @@ __global__ __launch_bounds__(NT) void k_solve(BaPtrs B, BaDims D, ResSet S, ldso
     if (fl & SK_SOLVE) {
         // HFinal / bFinal were assembled by k_gather (ba_reduce.hip)
         if (!(fl & SK_FROMREDUCED)) res_counts(B, D, S, sW);
-        solve_core_dispatch(B, D, St, A.iteration, sm, B.frames, B.calib);
+        SolveIO io;
+        io.fr = B.frames; io.cal = B.calib; io.adH = B.adHostF; io.adT = B.adTargetF; io.ldsAd = nullptr; io.sRed = sW; io.sumNID = 0;
+        solve_core_dispatch<false>(B, D, S, St, A.iteration, sm, io);
     }
     if (fl & SK_BACKUP) frames_backup(B.frames, B.calib, F);
     if (fl & SK_STEP) frames_step(B, St, B.frames, B.calib, F, (float) B.scalars[6] / (float) B.scalars[7]);
@@ -632,7 +703,7 @@ __global__ __launch_bounds__(NT) void k_solve(BaPtrs B, BaDims D, ResSet S, ldso
         if (tid == 0) for (int i = 0; i < 4; i++) B.calib->value[i] = B.calib->value_backup[i];
         __syncthreads();
     }
-    if (fl & SK_PRECALC) set_precalc(B, D, B.frames, B.calib);
+    if (fl & SK_PRECALC) set_precalc(B, D, B.frames, B.calib, B.adHostF, B.adTargetF);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -648,38 +719,32 @@ __global__ __launch_bounds__(NT) void k_gn_solve(BaPtrs B, BaDims D, ResSet S, l
     const int tid = threadIdx.x, F = D.F, n = D.n;
     const int NBsel = (n + 1 <= 64) ? 4 : (n + 1 <= 112) ? 7 : 9;
     double *sW = sm + solve_core_lds_doubles(NBsel, n);      // 64 doubles of scratch
+    const long long t0_ = wall_clock64();
+#define GSTAMP(i) do { if (tid == 0) B.energyLog[40 + (i)] = (double) (wall_clock64() - t0_); } while (0)
     if (blockIdx.x == 1) {
         int *sHist = (int *) (sW + 64);
         int *sI = sHist + 256;
         post_sums(B, D, S, sW);
+        GSTAMP(10);
         res_counts(B, D, S, sW);
+        GSTAMP(11);
         post_thresh(B, D, S, St, nullptr, (float *) (sI + 8), sHist, sI);
+        GSTAMP(12);
         if (tid == 0 && A.logIdx >= 0 && A.logIdx < 64) B.energyLog[A.logIdx] = B.scalars[0];
         return;
     }
     DevFrame *sFr = (DevFrame *) (sW + 64);
     DevCalib *sCal = (DevCalib *) (sFr + F);
-    // mirror of frames / calibration (32-bit words)
-    {
-        const unsigned *gF = (const unsigned *) B.frames; unsigned *lF = (unsigned *) sFr;
-        for (int i = tid; i < F * (int) (sizeof(DevFrame) / 4); i += NT) lF[i] = gF[i];
-        const unsigned *gC = (const unsigned *) B.calib; unsigned *lC = (unsigned *) sCal;
-        for (int i = tid; i < (int) (sizeof(DevCalib) / 4); i += NT) lC[i] = gC[i];
-    }
-    // sumNID of doStepFromBackup, same summation order as post_sums
-    float sumNID;
-    {
-        double ns = 0, nc = 0;
-        for (int c = tid; c < D.nChunks; c += NT) { ns += (double) S.chunkNID[c * 2]; nc += (double) S.chunkNID[c * 2 + 1]; }
-        ns = wave_sum(ns); nc = wave_sum(nc);
-        if ((tid & 63) == 0) { sW[tid >> 6] = ns; sW[4 + (tid >> 6)] = nc; }
-        __syncthreads();
-        sumNID = (float) (sW[0] + sW[1] + sW[2] + sW[3]) / (float) (sW[4] + sW[5] + sW[6] + sW[7]);
-    }
-    solve_core_dispatch(B, D, St, A.iteration, sm, sFr, sCal);
-    frames_backup(sFr, sCal, F);
-    frames_step(B, St, sFr, sCal, F, sumNID);
-    set_precalc(B, D, sFr, sCal);
+    if (tid == 0) B.energyLog[39] = (double) t0_;
+    SolveIO io;
+    io.fr = sFr; io.cal = sCal; io.adH = B.adHostF; io.adT = B.adTargetF; io.sRed = sW; io.sumNID = 0;
+    io.ldsAd = (F <= 8) ? (float *) (sCal + 1) : nullptr;
+    solve_core_dispatch<true>(B, D, S, St, A.iteration, sm, io);      // + mirrors, backupState, doStepFromBackup
+    GSTAMP(4);
+    step_canbreak(B, St, sFr, F, io.sumNID);
+    GSTAMP(5);
+    set_precalc(B, D, sFr, sCal, io.adH, io.adT);
+    GSTAMP(6);
     // write the mirrors back (all but frameEnergyTH, which block 1 owns)
     {
         unsigned *gF = (unsigned *) B.frames; const unsigned *lF = (const unsigned *) sFr;
@@ -740,7 +805,7 @@ hipError_t ba_launch_solve(const BaPtrs &B, const BaDims &D, const ResSet &S, co
 }
 
 hipError_t ba_launch_gn_solve(const BaPtrs &B, const BaDims &D, const ResSet &S, const ldso_settings_t &St, const SolveArgs &A, hipStream_t st) {
-    size_t mirror = (size_t) D.F * sizeof(DevFrame) + sizeof(DevCalib), stats = (256 + 8) * sizeof(int) + TH_CAP * sizeof(float);
+    size_t mirror = (size_t) D.F * sizeof(DevFrame) + sizeof(DevCalib) + (D.F <= 8 ? (size_t) D.F * D.F * 128 * sizeof(float) : 0), stats = (256 + 8) * sizeof(int) + TH_CAP * sizeof(float);
     size_t lds = solve_lds_common(D) + 64 * sizeof(double) + (mirror > stats ? mirror : stats) + 64;
     if (lds > 48 * 1024) hipFuncSetAttribute((const void *) k_gn_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
     hipLaunchKernelGGL(k_gn_solve, dim3(2), dim3(NT), lds, st, B, D, S, St, A);
