@@ -12,8 +12,8 @@
 #include "ba_solve.h"
 #include "lie_dev.h"
 
-hipError_t ba_launch_linearize(const BaPtrs &B, const BaDims &D, const ResSet &cur, const ResSet &nxt, const ldso_settings_t &S, bool hasL, bool fix, int stepMode, hipStream_t st);
-hipError_t ba_launch_reduce(const BaPtrs &B, const BaDims &D, const ResSet &S, const int32_t *chunkStart, bool hasL, int GSP, hipStream_t st);
+hipError_t ba_launch_linearize(const BaPtrs &B, const BaDims &D, const ResSet &cur, const ResSet &nxt, const ldso_settings_t &S, bool hasL, bool fix, int stepMode, const GnInit &gi, hipStream_t st);
+hipError_t ba_launch_reduce(const BaPtrs &B, const BaDims &D, const ResSet &S, const int32_t *chunkStart, bool hasL, int GSP, bool atomicMode, bool hasPrior, float calibPrior, double l1, double il, hipStream_t st);
 hipError_t ba_launch_gather(const BaPtrs &B, const BaDims &D, const ResSet &S, bool hasL, bool hasPrior, int GSP, double lambda,
                             const ldso_settings_t &St, int mode, double *rbuf, hipStream_t st);
 hipError_t ba_launch_solve(const BaPtrs &B, const BaDims &D, const ResSet &S, const ldso_settings_t &St, const SolveArgs &A, hipStream_t st);
@@ -171,6 +171,7 @@ int ldso_ba_create(int device, int w, int h, int max_frames, int max_points, lds
     const size_t GSPmax = (8 * FS + LD_GEXTRA + 15) / 16 * 16;
     DA(B.scPart, (size_t) LD_SC_SPLITS * GSPmax * GSPmax);
     DA(B.sys, 4 * (nmax * nmax + nmax));
+    DA(B.acc, nmax * nmax + nmax);
     DA(B.x, nmax); DA(B.xAd, F * F * 8); DA(B.xc, 4); DA(B.scalars, 16); DA(B.energyLog, 64);
     DA(H->d_dumpJ, P * FS);
     B.dumpJ = nullptr;
@@ -418,14 +419,18 @@ static int launch_solve(ldso_ba *H, const ResSet &S, unsigned flags, int iterati
 }
 static int launch_linearize(ldso_ba *H, bool fix, int stepMode = 0) {
     t_begin(H, 0);
-    CHK(ba_launch_linearize(H->B, H->D, H->sets[H->cur], H->sets[H->cur ^ 1], H->settings, H->hasL, fix, stepMode, H->stream));
+    GnInit gi; gi.enable = 1; gi.hasPrior = H->hasPrior ? 1 : 0; gi.calibPrior = H->settings.initialCalibHessian;
+    CHK(ba_launch_linearize(H->B, H->D, H->sets[H->cur], H->sets[H->cur ^ 1], H->settings, H->hasL, fix, stepMode, gi, H->stream));
     t_end(H);
     if (H->profile) { t_begin(H, 4); t_end(H); }      // empty event pair: calibrates the event overhead (which = 4)
     return LDSO_OK;
 }
-static int launch_reduce(ldso_ba *H, const ResSet &S) {
+static int launch_reduce(ldso_ba *H, const ResSet &S, bool atomicMode = false, double lambda = 0.0) {
     t_begin(H, 1);
-    CHK(ba_launch_reduce(H->B, H->D, S, H->d_chunkStart, H->hasL, H->GSP, H->stream));
+    if (H->settings.solverMode & LDSO_SOLVER_USE_GN) lambda = 0;
+    if (H->settings.solverMode & LDSO_SOLVER_FIX_LAMBDA) lambda = 1e-5;
+    const double l1 = 1 + lambda, il = (double) (1.0f / (1 + lambda));
+    CHK(ba_launch_reduce(H->B, H->D, S, H->d_chunkStart, H->hasL, H->GSP, atomicMode, H->hasPrior, H->settings.initialCalibHessian, l1, il, H->stream));
     t_end(H);
     return LDSO_OK;
 }
@@ -548,8 +553,7 @@ int ldso_ba_load_state_backup(ldso_ba_t *H) {
 // k_gn_solve, k_linearize with the point step fused in), no host sync
 static int enqueue_iteration(ldso_ba *H, int iteration, double lambda, int logIdx, bool postOfPrev) {
     const ResSet &S = H->sets[H->cur];
-    RUN(launch_reduce(H, S));
-    RUN(launch_gather(H, S, lambda, 0, nullptr));
+    RUN(launch_reduce(H, S, true, lambda));      // accumulates HFinal / bFinal straight into B.acc (no k_gather on this path)
     (void) postOfPrev;
     {
         SolveArgs A;
@@ -751,7 +755,7 @@ int ldso_ba_get_jacobians(ldso_ba_t *H, const int32_t *ids, int n, ldso_rawjac_t
         REQ(!H->pendingApply, "ldso_ba_get_jacobians: a linearisation is pending (call ldso_ba_apply_res first, or enable ldso_ba_set_debug_dump)");
         BaPtrs Bd = H->B;
         Bd.dumpJ = H->d_dumpJ;
-        CHK(ba_launch_linearize(Bd, H->D, H->sets[H->cur], H->sets[H->cur ^ 1], H->settings, H->hasL, false, 0, H->stream));
+        CHK(ba_launch_linearize(Bd, H->D, H->sets[H->cur], H->sets[H->cur ^ 1], H->settings, H->hasL, false, 0, GnInit{0, 0, 0.0f}, H->stream));
     }
     D2H(all, H->d_dumpJ, (size_t) H->R);
     CHK(hipStreamSynchronize(H->stream));

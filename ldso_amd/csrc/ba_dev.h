@@ -98,12 +98,19 @@ struct BaPtrs {
     double *pairC;      // [F*F][PAIRC] lifted top contributions (A then L)
     float *scPart;      // [SC_SPLITS][n*(n+1)] Schur partials
     double *sys;        // HA,bA,HL,bL,Hsc,bsc,HFinal,bFinal,x  (debug/fetch)
+    double *acc;        // GN fast path: [n*n+n] HFinal (lower triangle) | bFinal, initialised by k_linearize, accumulated by k_reduce (atomics)
     double *x;          // n
     float *xAd;         // [F*F*8] at [h*F+t]
     float *xc;          // 4 (calib step as float, = x[0:4])
     double *scalars;    // misc: [0] energy, [1] resInA, [2] resInL, [3] canbreak, [4] nonfinite flag, [5] sumNID mean
     double *energyLog;  // [64]
     ldso_rawjac_t *dumpJ;   // optional [R]
+};
+
+// GN fast path: what k_linearize needs to initialise B.acc for the solve that follows it
+struct GnInit {
+    int enable, hasPrior;
+    float calibPrior;
 };
 
 #define LD_PAIRC 296        // doubles per pair contribution: hh 64, tt 64, ht 64, hc 32, tc 32, cc 16, bh 8, bt 8, bc 4 (=292, padded)

@@ -96,7 +96,7 @@ static __device__ __forceinline__ void load_point(PtIn<NSG> &q, const BaPtrs &B,
 // FullSystem.cc:1585-1602, 1625-1673) in front of the linearisation of each point (what k_point_step does with
 // PS_RESUB|PS_BACKUP|PS_STEP), so a forced-accept GN iteration needs no separate point pass.
 template <int NSG, bool HAS_L, bool FIX>
-__global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D, ResSet cur, ResSet nxt, ldso_settings_t S, int stepMode) {
+__global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D, ResSet cur, ResSet nxt, ldso_settings_t S, int stepMode, GnInit gi) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int FS = D.FS, F = D.F;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, s = lane >> 3, k = lane & 7;
@@ -111,6 +111,23 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D,
     float *sTopL = sRed + LD_WAVES * FS * LD_TOPN;                        // [FS][91] when HAS_L
     float *sXa = sTopL + (HAS_L ? FS * LD_TOPN : 0);                      // [FS][8] xAd of this host (stepMode)
 
+    if (gi.enable) {
+        // initialise the HFinal / bFinal accumulator of the k_reduce that follows (lower triangle) with H_M and the diagonal
+        // priors (EnergyFunctional.cc:257-291; the lambda scaling of these terms is added by k_reduce); b starts at zero.
+        const int n = D.n, N1 = n * n + n, per = (N1 + (int) gridDim.x - 1) / (int) gridDim.x;
+        const int z0 = blockIdx.x * per, z1 = min(N1, z0 + per);
+        for (int e = z0 + tid; e < z1; e += blockDim.x) {
+            double v = 0.0;
+            if (e < n * n) {
+                const int i = e / n, j = e % n;
+                if (j <= i) {
+                    if (gi.hasPrior) v = B.HM[e];
+                    if (i == j) { v += (i < 4) ? (double) gi.calibPrior : B.frames[(i - 4) >> 3].prior[(i - 4) & 7]; }
+                }
+            }
+            B.acc[e] = v;
+        }
+    }
     const float fx = B.calib->sf[0], fy = B.calib->sf[1], cx = B.calib->sf[2], cy = B.calib->sf[3];
     const float fxi = B.calib->si[0], fyi = B.calib->si[1];
     const float cD0 = B.calib->cDeltaF[0], cD1 = B.calib->cDeltaF[1], cD2 = B.calib->cDeltaF[2], cD3 = B.calib->cDeltaF[3];
@@ -551,22 +568,22 @@ size_t ba_linearize_lds_bytes(int FS, bool hasL) {
 }
 
 template <int NSG, bool HAS_L, bool FIX>
-static hipError_t launch_one(const BaPtrs &B, const BaDims &D, const ResSet &cur, const ResSet &nxt, const ldso_settings_t &S, int stepMode, hipStream_t st) {
+static hipError_t launch_one(const BaPtrs &B, const BaDims &D, const ResSet &cur, const ResSet &nxt, const ldso_settings_t &S, int stepMode, const GnInit &gi, hipStream_t st) {
     size_t lds = ba_linearize_lds_bytes(D.FS, HAS_L);
     auto kfn = k_linearize<NSG, HAS_L, FIX>;
     if (lds > 48 * 1024) hipFuncSetAttribute((const void *) kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-    hipLaunchKernelGGL(kfn, dim3(D.nChunks), dim3(64 * LD_WAVES), lds, st, B, D, cur, nxt, S, stepMode);
+    hipLaunchKernelGGL(kfn, dim3(D.nChunks), dim3(64 * LD_WAVES), lds, st, B, D, cur, nxt, S, stepMode, gi);
     return hipGetLastError();
 }
 
 hipError_t ba_launch_linearize(const BaPtrs &B, const BaDims &D, const ResSet &cur, const ResSet &nxt, const ldso_settings_t &S,
-                               bool hasL, bool fix, int stepMode, hipStream_t st) {
+                               bool hasL, bool fix, int stepMode, const GnInit &gi, hipStream_t st) {
     if (D.nChunks == 0) return hipSuccess;
     if (D.nsg == 1) {
-        if (hasL) return fix ? launch_one<1, true, true>(B, D, cur, nxt, S, stepMode, st) : launch_one<1, true, false>(B, D, cur, nxt, S, stepMode, st);
-        return fix ? launch_one<1, false, true>(B, D, cur, nxt, S, stepMode, st) : launch_one<1, false, false>(B, D, cur, nxt, S, stepMode, st);
+        if (hasL) return fix ? launch_one<1, true, true>(B, D, cur, nxt, S, stepMode, gi, st) : launch_one<1, true, false>(B, D, cur, nxt, S, stepMode, gi, st);
+        return fix ? launch_one<1, false, true>(B, D, cur, nxt, S, stepMode, gi, st) : launch_one<1, false, false>(B, D, cur, nxt, S, stepMode, gi, st);
     } else {
-        if (hasL) return fix ? launch_one<2, true, true>(B, D, cur, nxt, S, stepMode, st) : launch_one<2, true, false>(B, D, cur, nxt, S, stepMode, st);
-        return fix ? launch_one<2, false, true>(B, D, cur, nxt, S, stepMode, st) : launch_one<2, false, false>(B, D, cur, nxt, S, stepMode, st);
+        if (hasL) return fix ? launch_one<2, true, true>(B, D, cur, nxt, S, stepMode, gi, st) : launch_one<2, true, false>(B, D, cur, nxt, S, stepMode, gi, st);
+        return fix ? launch_one<2, false, true>(B, D, cur, nxt, S, stepMode, gi, st) : launch_one<2, false, false>(B, D, cur, nxt, S, stepMode, gi, st);
     }
 }

@@ -21,12 +21,23 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __host__ __device__ constexpr int tri13r(int r, int c) { return r * 13 - (r * (r - 1)) / 2 + (c - r); }
 
 // chunkStart[h]..chunkStart[h+1]: chunks of host h (chunks are host-major)
-__global__ __launch_bounds__(256) void k_reduce(BaPtrs B, BaDims D, ResSet S, const int32_t *__restrict__ chunkStart, int hasL, int GSP) {
+// atomicMode (GN fast path): instead of pairC / scPart the results are added (fp64 atomics) straight into the lower triangle of
+// HFinal / bFinal (B.acc, initialised by k_linearize with the H_M / prior terms; EnergyFunctional.cc:257-291):
+//   HFinal = (H_A + H_L + priors + H_M) with diag * (1+lambda) - H_sc / (1+lambda)   ->  top terms are scaled by l1 = 1+lambda on the
+//   diagonal, Schur terms by -il = -1/(1+lambda);  bFinal = b_A + b_L + (prior delta + b_M + H_M delta) - b_sc.
+static __device__ __forceinline__ void acc_add(double *p, double v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+template <int NT, int W> static __device__ __forceinline__ void schur_wave(const float *sG, int GSP, int cnt, int wcol, int li, int lk, f32x4 *acc);
+
+__global__ __launch_bounds__(256) void k_reduce(BaPtrs B, BaDims D, ResSet S, const int32_t *__restrict__ chunkStart, int hasL, int GSP, int atomicMode,
+                                                int hasPrior, float calibPrior, double l1, double il) {
     const int F = D.F, FS = D.FS;
     const int nPairBlocks = F * F * (hasL ? 2 : 1);
     const int tid = threadIdx.x;
     __shared__ double sA[13 * 13];
     __shared__ double sT[2][64];
+    const long long t0_ = wall_clock64();
+#define RSTAMP(i) do { if (tid == 0) B.energyLog[(i)] = (double) (wall_clock64() - t0_); } while (0)
 
     if ((int) blockIdx.x < nPairBlocks) {
         // ------------------------------- Part A ---------------------------------------------------------
@@ -54,6 +65,7 @@ __global__ __launch_bounds__(256) void k_reduce(BaPtrs B, BaDims D, ResSet S, co
             sPart[slice][ent] = a;
         }
         __syncthreads();
+        if (blockIdx.x == 0) RSTAMP(20);
         if (tid < LD_TOPN) {
             double a = sPart[0][tid];
 #pragma unroll
@@ -75,27 +87,74 @@ __global__ __launch_bounds__(256) void k_reduce(BaPtrs B, BaDims D, ResSet S, co
             sT[0][tid] = th; sT[1][tid] = tt;
         }
         __syncthreads();
+        const int n = D.n;
+        double *accT = B.acc, *accb = B.acc + (size_t) n * n;
+        const int rh = 4 + 8 * h, rt = 4 + 8 * t;      // first rows of the two frames in the reference ordering
         if (tid < 64) {
             int i = tid >> 3, j = tid & 7;
             double hh = 0, tt = 0, ht = 0;
             for (int m = 0; m < 8; m++) { hh += sT[0][i * 8 + m] * AH[j * 8 + m]; tt += sT[1][i * 8 + m] * AT[j * 8 + m]; ht += sT[0][i * 8 + m] * AT[j * 8 + m]; }
-            out[tid] = hh; out[64 + tid] = tt; out[128 + tid] = ht;
+            if (!atomicMode) { out[tid] = hh; out[64 + tid] = tt; out[128 + tid] = ht; }
+            else {
+                if (i >= j) { const double dsc = (i == j) ? l1 : 1.0; acc_add(&accT[(size_t) (rh + i) * n + rh + j], hh * dsc); acc_add(&accT[(size_t) (rt + i) * n + rt + j], tt * dsc); }
+                if (h > t) acc_add(&accT[(size_t) (rh + i) * n + rt + j], ht);
+                else if (h < t) acc_add(&accT[(size_t) (rt + j) * n + rh + i], ht);
+            }
         } else if (tid < 64 + 32) {
             int e = tid - 64, i = e >> 2, c = e & 3;
             double hc = 0, tc = 0;
             for (int m = 0; m < 8; m++) { hc += AH[i * 8 + m] * sA[(4 + m) * 13 + c]; tc += AT[i * 8 + m] * sA[(4 + m) * 13 + c]; }
-            out[192 + e] = hc; out[224 + e] = tc;
+            if (!atomicMode) { out[192 + e] = hc; out[224 + e] = tc; }
+            else { acc_add(&accT[(size_t) (rh + i) * n + c], hc); acc_add(&accT[(size_t) (rt + i) * n + c], tc); }
         } else if (tid < 96 + 16) {
             int e = tid - 96;
-            out[256 + e] = sA[(e >> 2) * 13 + (e & 3)];
+            if (!atomicMode) out[256 + e] = sA[(e >> 2) * 13 + (e & 3)];
+            else if ((e >> 2) >= (e & 3)) acc_add(&accT[(size_t) (e >> 2) * n + (e & 3)], sA[(e >> 2) * 13 + (e & 3)] * (((e >> 2) == (e & 3)) ? l1 : 1.0));
         } else if (tid < 112 + 8) {
             int i = tid - 112;
             double bh = 0, bt = 0;
             for (int m = 0; m < 8; m++) { bh += AH[i * 8 + m] * sA[(4 + m) * 13 + 12]; bt += AT[i * 8 + m] * sA[(4 + m) * 13 + 12]; }
-            out[272 + i] = bh; out[280 + i] = bt;
+            if (!atomicMode) { out[272 + i] = bh; out[280 + i] = bt; }
+            else { acc_add(&accb[rh + i], bh); acc_add(&accb[rt + i], bt); }
         } else if (tid < 120 + 4) {
             int i = tid - 120;
-            out[288 + i] = sA[i * 13 + 12];
+            if (!atomicMode) out[288 + i] = sA[i * 13 + 12];
+            else acc_add(&accb[i], sA[i * 13 + 12]);
+        }
+        if (blockIdx.x == 0) RSTAMP(21);
+        return;
+    }
+
+    const int nSplitBase = nPairBlocks;
+    if ((int) blockIdx.x == nSplitBase + LD_SC_SPLITS) {
+        // ------------------------------- extras of the GN fast path --------------------------------------------
+        // bExtra = prior * delta_prior + (bM + HM delta), priorDiag   (AccumulatedTopHessian.cc:246-254, EnergyFunctional.cc:279)
+        const int n = D.n;
+        __shared__ double sDelta[8 * LD_MAXF + 4];
+        if (tid < n) sDelta[tid] = (tid < 4) ? (double) B.calib->cDeltaF[tid] : B.frames[(tid - 4) >> 3].delta[(tid - 4) & 7];
+        double prb = 0, prH = 0, bm = 0;
+        if (tid < n) {
+            if (tid < 4) { prH = (double) calibPrior; prb = (double) calibPrior * (double) B.calib->cDeltaF[tid]; }
+            else { const DevFrame &f = B.frames[(tid - 4) >> 3]; prH = f.prior[(tid - 4) & 7]; prb = prH * f.delta_prior[(tid - 4) & 7]; }
+            if (hasPrior) bm = B.bM[tid];
+        }
+        __syncthreads();
+        if (tid < n) {
+            double s_ = 0;
+            if (hasPrior) {
+                s_ = bm;
+                for (int j0 = 0; j0 < n; j0 += 16) {
+                    double q[16];
+#pragma unroll
+                    for (int u = 0; u < 16; u++) q[u] = (j0 + u < n) ? B.HM[(size_t) tid * n + j0 + u] : 0.0;
+#pragma unroll
+                    for (int u = 0; u < 16; u++) if (j0 + u < n) s_ += q[u] * sDelta[j0 + u];
+                }
+            }
+            acc_add(&B.acc[(size_t) n * n + tid], prb + s_);
+            // lambda scaling of the diagonal terms k_linearize put there: (H_M + prior)_ii * (l1 - 1)
+            const double dterm = prH + (hasPrior ? B.HM[(size_t) tid * n + tid] : 0.0);
+            acc_add(&B.acc[(size_t) tid * n + tid], dterm * (l1 - 1.0));
         }
         return;
     }
@@ -104,9 +163,10 @@ __global__ __launch_bounds__(256) void k_reduce(BaPtrs B, BaDims D, ResSet S, co
     // M[sp] = sum over this split's points of  w_p * r_p r_p^T  with r_p = G row (GS entries, zero padded
     // to GSP = multiple of 16) and w_p = HdiF_p = r_p[8*FS+5].  Upper-triangular 16x16 tiles only.
     // G rows are staged through LDS in slabs of SC_SLAB points (coalesced row copies), then consumed by
-    // v_mfma_f32_16x16x4_f32: A[i][k] = w_k r_k[ti*16+i], B[k][j] = r_k[tj*16+j].
-    extern __shared__ __attribute__((aligned(16))) float sG[];      // [SC_SLAB][GSP] + [SC_SLAB] weights
-    const int sp = blockIdx.x - nPairBlocks;
+    // v_mfma_f32_16x16x4_f32: A[i][k] = w_k r_k[ti*16+i], B[k][j] = r_k[tj*16+j].  Tile t (row-major over the upper
+    // triangle) belongs to wave t % 4; the tile lists are compile-time (schur_wave<NT, W>).
+    extern __shared__ __attribute__((aligned(16))) float sG[];      // [SC_SLAB][GSP]
+    const int sp = blockIdx.x - nSplitBase;
     const int wave = tid >> 6, lane = tid & 63;
     const int nT = GSP / 16;
     const int P0 = D.pBegin, Pn = D.pEnd - D.pBegin;
@@ -114,16 +174,7 @@ __global__ __launch_bounds__(256) void k_reduce(BaPtrs B, BaDims D, ResSet S, co
     const int pa = P0 + sp * per, pb = min(P0 + Pn, pa + per);
     const int GS = D.GS;
     const int li = lane & 15, lk = lane >> 4;
-    float *sWt = sG + SC_SLAB * GSP;
     float *Mout = B.scPart + (size_t) sp * GSP * GSP;
-    // this wave's tiles (upper triangle, round-robin), at most SC_MAXT per wave
-    int myTi[SC_MAXT], myTj[SC_MAXT], nMine = 0;
-    {
-        int tileIdx = 0;
-        for (int ti = 0; ti < nT; ti++)
-            for (int tj = ti; tj < nT; tj++, tileIdx++)
-                if ((tileIdx & 3) == wave && nMine < SC_MAXT) { myTi[nMine] = ti; myTj[nMine] = tj; nMine++; }
-    }
     f32x4 acc[SC_MAXT];
 #pragma unroll
     for (int q = 0; q < SC_MAXT; q++) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -147,26 +198,66 @@ __global__ __launch_bounds__(256) void k_reduce(BaPtrs B, BaDims D, ResSet S, co
             }
         }
         __syncthreads();
-        for (int k0 = 0; k0 < SC_SLAB; k0 += 4) {
-            if (k0 >= cnt) break;
-            const float *row = sG + (k0 + lk) * GSP;
-            const float w = row[8 * FS + 5];
-#pragma unroll
-            for (int q = 0; q < SC_MAXT; q++) {
-                if (q < nMine) {
-                    float a = row[myTi[q] * 16 + li] * w;
-                    float b = row[myTj[q] * 16 + li];
-                    acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[q], 0, 0, 0);
-                }
-            }
+        if (sp == 0) RSTAMP(22);
+        const int wcol = 8 * FS + 5;
+        if (nT == 5) {
+            if (wave == 0) schur_wave<5, 0>(sG, GSP, cnt, wcol, li, lk, acc); else if (wave == 1) schur_wave<5, 1>(sG, GSP, cnt, wcol, li, lk, acc);
+            else if (wave == 2) schur_wave<5, 2>(sG, GSP, cnt, wcol, li, lk, acc); else schur_wave<5, 3>(sG, GSP, cnt, wcol, li, lk, acc);
+        } else {
+            if (wave == 0) schur_wave<9, 0>(sG, GSP, cnt, wcol, li, lk, acc); else if (wave == 1) schur_wave<9, 1>(sG, GSP, cnt, wcol, li, lk, acc);
+            else if (wave == 2) schur_wave<9, 2>(sG, GSP, cnt, wcol, li, lk, acc); else schur_wave<9, 3>(sG, GSP, cnt, wcol, li, lk, acc);
         }
     }
-    // C/D layout: col = lane&15, row = (lane>>4)*4 + r
+    if (sp == 0) RSTAMP(23);
+    // C/D layout: col = lane&15, row = (lane>>4)*4 + r.  Tile list again (runtime walk, once).
+    {
+        const int n = D.n, F8 = 8 * D.F, FS8 = 8 * FS;
+        double *accS = B.acc, *accSb = accS + (size_t) n * n;
+        const double *unused_ = nullptr; (void) unused_;
+        for (int pass = 0; pass < 1; pass++) {
+            int tileIdx = 0;
+            for (int ti = 0; ti < nT; ti++)
+                for (int tj = ti; tj < nT; tj++, tileIdx++) {
+                    if ((tileIdx & 3) != wave) continue;
+                    const int q = tileIdx >> 2;
+                    f32x4 a4 = acc[0];
 #pragma unroll
-    for (int q = 0; q < SC_MAXT; q++)
-        if (q < nMine)
+                    for (int u = 1; u < SC_MAXT; u++) if (u == q) a4 = acc[u];
 #pragma unroll
-            for (int r = 0; r < 4; r++) Mout[(size_t) (myTi[q] * 16 + lk * 4 + r) * GSP + myTj[q] * 16 + li] = acc[q][r];
+                    for (int r = 0; r < 4; r++) {
+                        const int rr = ti * 16 + lk * 4 + r, cc = tj * 16 + li;
+                        if (!atomicMode) { Mout[(size_t) rr * GSP + cc] = a4[r]; continue; }
+                        if (ti == tj && rr > cc) continue;
+                        // G column -> index in the reference ordering [calib 4 | frames 8F]; n = right-hand side; -1 = padding
+                        const int I = (rr < F8) ? 4 + rr : (rr >= FS8 && rr < FS8 + 4) ? rr - FS8 : (rr == FS8 + 4) ? n : -1;
+                        const int J = (cc < F8) ? 4 + cc : (cc >= FS8 && cc < FS8 + 4) ? cc - FS8 : (cc == FS8 + 4) ? n : -1;
+                        if (I < 0 || J < 0 || I == n) continue;
+                        if (J == n) acc_add(&accSb[I], -(double) a4[r]);
+                        else acc_add(&accS[(size_t) max(I, J) * n + min(I, J)], -(double) a4[r] * il);
+                    }
+                }
+        }
+    }
+    if (sp == 0) RSTAMP(24);
+}
+
+// one wave's share of the rank-cnt update: tiles t of the upper triangle with t % 4 == W accumulate into acc[t / 4]
+template <int NT, int W>
+static __device__ __forceinline__ void schur_wave(const float *sG, int GSP, int cnt, int wcol, int li, int lk, f32x4 *acc) {
+#pragma unroll 2
+    for (int k0 = 0; k0 < cnt; k0 += 4) {
+        const float *row = sG + (k0 + lk) * GSP;
+        float val[NT];
+#pragma unroll
+        for (int c = 0; c < NT; c++) val[c] = row[c * 16 + li];
+        const float w = row[wcol];
+        int idx = 0;
+#pragma unroll
+        for (int ti = 0; ti < NT; ti++)
+#pragma unroll
+            for (int tj = ti; tj < NT; tj++, idx++)
+                if ((idx & 3) == W) acc[idx >> 2] = __builtin_amdgcn_mfma_f32_16x16x4f32(val[ti] * w, val[tj], acc[idx >> 2], 0, 0, 0);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -298,9 +389,11 @@ hipError_t ba_launch_gather(const BaPtrs &B, const BaDims &D, const ResSet &S, b
     return hipGetLastError();
 }
 
-hipError_t ba_launch_reduce(const BaPtrs &B, const BaDims &D, const ResSet &S, const int32_t *chunkStart, bool hasL, int GSP, hipStream_t st) {
-    int nb = D.F * D.F * (hasL ? 2 : 1) + LD_SC_SPLITS;
-    size_t lds = (size_t) (SC_SLAB * GSP + SC_SLAB) * sizeof(float);
-    hipLaunchKernelGGL(k_reduce, dim3(nb), dim3(256), lds, st, B, D, S, chunkStart, hasL ? 1 : 0, GSP);
+hipError_t ba_launch_reduce(const BaPtrs &B, const BaDims &D, const ResSet &S, const int32_t *chunkStart, bool hasL, int GSP, bool atomicMode, bool hasPrior,
+                            float calibPrior, double l1, double il, hipStream_t st) {
+    int nb = D.F * D.F * (hasL ? 2 : 1) + LD_SC_SPLITS + (atomicMode ? 1 : 0);
+    size_t lds = (size_t) (SC_SLAB * GSP) * sizeof(float);
+    if (lds > 48 * 1024) hipFuncSetAttribute((const void *) k_reduce, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+    hipLaunchKernelGGL(k_reduce, dim3(nb), dim3(256), lds, st, B, D, S, chunkStart, hasL ? 1 : 0, GSP, atomicMode ? 1 : 0, hasPrior ? 1 : 0, calibPrior, l1, il);
     return hipGetLastError();
 }

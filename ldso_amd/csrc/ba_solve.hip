@@ -254,6 +254,9 @@ static __device__ void set_adjoints(const BaPtrs &B, const BaDims &D, const ldso
 
 // setPrecalcValues: frames' PRE poses, pair precalc, deltas
 // fr / cal: working copies of the frames and the calibration (global memory, or the LDS mirror of k_gn_solve)
+// FULL = false (inside a GN iteration): the linearisation-point part of a pair (R0, t0, b0: functions of evalPT and
+// state_zero only) is left untouched.
+template <bool FULL>
 static __device__ void set_precalc(const BaPtrs &B, const BaDims &D, DevFrame *fr, DevCalib *cal, const float *adH, const float *adT) {
     const int tid = threadIdx.x, F = D.F;
     DevCalib &C = *cal;
@@ -266,7 +269,7 @@ static __device__ void set_precalc(const BaPtrs &B, const BaDims &D, DevFrame *f
         ld::se3_inv(f.PRE_w2c, f.PRE_c2w);
         for (int i = 0; i < 8; i++) { f.delta[i] = f.state[i] - f.state_zero[i]; f.delta_prior[i] = f.state[i]; }
     }
-    if (tid == 0) {
+    if (tid == 64) {
         // CalibHessian::setValue derived floats (CalibHessian.h:71-85)
         double vs[4] = {50.0 * C.value[0], 50.0 * C.value[1], 50.0 * C.value[2], 50.0 * C.value[3]};
         for (int i = 0; i < 4; i++) C.sf[i] = (float) vs[i];
@@ -277,13 +280,19 @@ static __device__ void set_precalc(const BaPtrs &B, const BaDims &D, DevFrame *f
     for (int i = tid; i < F * F; i += NT) {
         const int h = i / F, t = i % F;
         const DevFrame &fh = fr[h], &ft = fr[t];
-        DevPair pr;
-        double Ti[12], T0[12], T[12];
-        ld::se3_inv(fh.evalPT, Ti);
-        ld::se3_mul(ft.evalPT, Ti, T0);
+        DevPair &o = B.pairs[i];
+        double T[12];
         ld::se3_mul(ft.PRE_w2c, fh.PRE_c2w, T);
         float R[9], tt[3];
-        for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) { pr.R0[r * 3 + c] = (float) T0[r * 4 + c]; R[r * 3 + c] = (float) T[r * 4 + c]; } pr.t0[r] = (float) T0[r * 4 + 3]; tt[r] = (float) T[r * 4 + 3]; }
+        for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) R[r * 3 + c] = (float) T[r * 4 + c]; tt[r] = (float) T[r * 4 + 3]; }
+        if (FULL) {
+            double Ti[12], T0[12];
+            ld::se3_inv(fh.evalPT, Ti);
+            ld::se3_mul(ft.evalPT, Ti, T0);
+            for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) o.R0[r * 3 + c] = (float) T0[r * 4 + c]; o.t0[r] = (float) T0[r * 4 + 3]; }
+            o.b0 = (float) (fh.state_zero[7] * 1000.0);
+            o.thMax = fmaxf(fh.frameEnergyTH, ft.frameEnergyTH);
+        }
         const float fx = C.sf[0], fy = C.sf[1], cx = C.sf[2], cy = C.sf[3];
         // K^-1 by Eigen's 3x3 cofactor inverse (float)
         float K[9] = {fx, 0, cx, 0, fy, cy, 0, 0, 1};
@@ -299,21 +308,24 @@ static __device__ void set_precalc(const BaPtrs &B, const BaDims &D, DevFrame *f
         }
         float KR[9];
         for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) KR[r * 3 + c] = (K[r * 3 + 0] * R[0 * 3 + c] + K[r * 3 + 1] * R[1 * 3 + c]) + K[r * 3 + 2] * R[2 * 3 + c];
-        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) pr.KRKi[r * 3 + c] = (KR[r * 3 + 0] * Ki[0 * 3 + c] + KR[r * 3 + 1] * Ki[1 * 3 + c]) + KR[r * 3 + 2] * Ki[2 * 3 + c];
-        for (int r = 0; r < 3; r++) pr.Kt[r] = (K[r * 3 + 0] * tt[0] + K[r * 3 + 1] * tt[1]) + K[r * 3 + 2] * tt[2];
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) o.KRKi[r * 3 + c] = (KR[r * 3 + 0] * Ki[0 * 3 + c] + KR[r * 3 + 1] * Ki[1 * 3 + c]) + KR[r * 3 + 2] * Ki[2 * 3 + c];
+        for (int r = 0; r < 3; r++) o.Kt[r] = (K[r * 3 + 0] * tt[0] + K[r * 3 + 1] * tt[1]) + K[r * 3 + 2] * tt[2];
+        float a0_, b0_;
         aff_from_to(fh.ab_exposure, ft.ab_exposure, (float) (10.0f * fh.state[6]), (float) (1000.0f * fh.state[7]),
-                    (float) (10.0f * ft.state[6]), (float) (1000.0f * ft.state[7]), pr.aff[0], pr.aff[1]);
-        pr.b0 = (float) (fh.state_zero[7] * 1000.0);
-        pr.thMax = fmaxf(fh.frameEnergyTH, ft.frameEnergyTH);
-        // adHTdeltaF[h + t*F] = delta_h^T adHostF + delta_t^T adTargetF  (EnergyFunctional.cc:403-414)
+                    (float) (10.0f * ft.state[6]), (float) (1000.0f * ft.state[7]), a0_, b0_);
+        o.aff[0] = a0_; o.aff[1] = b0_;
+    }
+    // adHTdeltaF[h + t*F] = delta_h^T adHostF + delta_t^T adTargetF  (EnergyFunctional.cc:403-414), one thread per component
+    for (int i = tid; i < F * F * 8; i += NT) {
+        const int c = i & 7, pr = i >> 3, h = pr / F, t = pr % F;
+        const DevFrame &fh = fr[h], &ft = fr[t];
         const float *AH = adH + (size_t) (h + t * F) * 64, *AT = adT + (size_t) (h + t * F) * 64;
-        for (int c = 0; c < 8; c++) {
-            float s1 = 0, s2 = 0;
-            for (int k = 0; k < 8; k++) s1 += (float) (fh.state[k] - fh.state_zero[k]) * AH[k * 8 + c];
-            for (int k = 0; k < 8; k++) s2 += (float) (ft.state[k] - ft.state_zero[k]) * AT[k * 8 + c];
-            pr.dp[c] = s1 + s2;
-        }
-        B.pairs[i] = pr;
+        float s1 = 0, s2 = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) s1 += (float) (fh.state[k] - fh.state_zero[k]) * AH[k * 8 + c];
+#pragma unroll
+        for (int k = 0; k < 8; k++) s2 += (float) (ft.state[k] - ft.state_zero[k]) * AT[k * 8 + c];
+        B.pairs[pr].dp[c] = s1 + s2;
     }
     __syncthreads();
 }
@@ -337,12 +349,13 @@ static __device__ void set_precalc(const BaPtrs &B, const BaDims &D, DevFrame *f
 // Two barriers per round, no global or matrix LDS traffic inside the loop.  Every global read of the solve is
 // issued in the prologue (one latency level).
 // ---------------------------------------------------------------------------------------------------------
-// reciprocal with two Newton steps on the hardware estimate (v_rcp_f64)
+// reciprocal: hardware estimate (v_rcp_f64, ~2^-24) + ONE Newton step -> relative error <= 2.2e-15 (measured on gfx950 over
+// 2^20 samples spanning 26 decades; a second step reaches 1.1e-16).  The pivot reciprocals sit on the serial critical path of the
+// factorisation (fp64 VALU results have a ~30-cycle dependent-issue latency), and a 2e-15 perturbation of a multiplier is far
+// below the conditioning of the system.
 static __device__ __forceinline__ double fast_rcp(double d) {
     double r = __builtin_amdgcn_rcp(d);
-    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
-    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
-    return r;
+    return __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
 }
 
 static __device__ __forceinline__ double readlane_f64(double v, int lane) {
@@ -352,16 +365,29 @@ static __device__ __forceinline__ double readlane_f64(double v, int lane) {
     return __builtin_bit_cast(double, ((unsigned long long) hi << 32) | lo);
 }
 
-// packed storage of L (column c holds rows c..M-1)
-#define LPK(i, c) ((c) * M - (((c) * ((c) -1)) >> 1) + ((i) - (c)))
+// reciprocal square root: hardware estimate (v_rsq_f64) + one Newton step (relative error <= 4.2e-15; only used as a scaling)
+static __device__ __forceinline__ double fast_rsqrt(double d) {
+    double r = __builtin_amdgcn_rsq(d);
+    double e = __builtin_fma(-(d * r), r, 1.0);
+    return __builtin_fma(0.5 * r, e, r);
+}
+static __device__ __forceinline__ double2 ld2(const double *p) { return *(const double2 *) p; }
+static __device__ __forceinline__ void st2(double *p, double a, double b) { *(double2 *) p = make_double2(a, b); }
+
+// Storage of L for the back substitution: L[i][c] (i > c) at sL[LIX(i, c)].
+//   NB == 4: zero-initialised square [c][i] with row pitch M+2, so that lane c reads its whole column with 16-byte loads;
+//   NB  > 4: packed columns (column c holds rows c..M-1).
+#define LIX(i, c) ((NB == 4) ? ((c) * (M + 2) + (i)) : ((c) * M - (((c) * ((c) -1)) >> 1) + ((i) - (c))))
 
 static __host__ __device__ inline size_t solve_core_lds_doubles(int NB, int n) {
     size_t M = 16 * NB;
-    return M * (M + 1) / 2 + 2 * M /*D,Y*/ + 12 * M /*F,G,panel*/ + 2 * M /*scale,x*/ + 7 * (size_t) n + 16;
+    size_t L = (NB == 4) ? M * (M + 2) : M * (M + 1) / 2;
+    return L + 2 * M /*D,Y*/ + 12 * M /*F,G,panel*/ + 2 * M /*scale,x*/ + 7 * (size_t) n + 16;
 }
 
 // GN = true (k_gn_solve): the prologue also mirrors the frames / calibration (and, when they fit, the float
-// adjoints) into LDS and reduces sumNID, so that the whole control step has ONE global-load latency level.
+// adjoints) into LDS and reduces sumNID, so that the whole control step has ONE global-load latency level; the
+// frame / calibration part of backupState + doStepFromBackup is fused into the output pass.
 struct SolveIO {
     DevFrame *fr;          // working copy of the frames (global, or the LDS mirror)
     DevCalib *cal;
@@ -369,16 +395,19 @@ struct SolveIO {
     float *ldsAd;          // LDS room for both adjoint tables (GN, may be null)
     double *sRed;          // 16 doubles of LDS scratch
     float sumNID;          // out (GN)
+    double lambda;         // GN: LM lambda as passed to solveSystem
+    int hasPrior;          // GN: HM / bM present
 };
 
 template <int NB, bool GN>
 static __device__ void solve_core(const BaPtrs &B, const BaDims &D, const ResSet &S, const ldso_settings_t &St, int iteration, double *sm, SolveIO &io) {
     constexpr int M = 16 * NB;
     constexpr int NTILE = NB * (NB + 1) / 2;
+    constexpr int LSZ = (NB == 4) ? M * (M + 2) : M * (M + 1) / 2;
     const double TINY = 2.2250738585072014e-308;
     const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15, F = D.F, n = D.n;
-    double *sL = sm;                       // packed L
-    double *sD = sL + M * (M + 1) / 2;     // [M]
+    double *sL = sm;                       // L (see LIX)
+    double *sD = sL + LSZ;                 // [M]
     double *sY = sD + M;                   // [M]
     double *sFp = sY + M;                  // [M][4]
     double *sGp = sFp + 4 * M;             // [M][4]
@@ -386,11 +415,13 @@ static __device__ void solve_core(const BaPtrs &B, const BaDims &D, const ResSet
     double *sSc = sPn + 4 * M;             // [M]
     double *sx = sSc + M;                  // [M]
     double *sNs = sx + M;                  // [7][n]
-    const double *HF = B.sys + 3 * (n * n + n), *bF = HF + n * n;
+    const double *HF = B.sys + 3 * (n * n + n), *bF = HF + n * n;      // assembled by k_gather (step-wise path)
     const bool ortho = (St.solverMode & LDSO_SOLVER_ORTHOGONALIZE_X) || (iteration >= 2 && (St.solverMode & LDSO_SOLVER_ORTHOGONALIZE_X_LATER));
 
-    // ---------------- prologue: all loads ----------------
+    // ---------------- prologue: every global load of the control step, issued back to back ----------------
+    // GN: HFinal / bFinal (lower triangle) come straight from the accumulator k_reduce added into (B.acc)
     double v[NTILE], dI[NB], dJ[NB];
+    if (GN) { HF = B.acc; bF = HF + (size_t) n * n; }
 #pragma unroll
     for (int a = 0; a < NB; a++) {
         const int i = ty + 16 * a, j = tx + 16 * a;
@@ -403,37 +434,64 @@ static __device__ void solve_core(const BaPtrs &B, const BaDims &D, const ResSet
         for (int b = 0; b <= a; b++) {
             const int i = ty + 16 * a, j = tx + 16 * b;
             double q = 0.0;
-            if (j < n) { if (i < n) q = HF[(size_t) i * n + j]; else if (i == n) q = bF[j]; }
+            if (j < n && (!GN || j <= i)) { if (i < n) q = HF[(size_t) i * n + j]; else if (i == n) q = bF[j]; }
             v[a * (a + 1) / 2 + b] = q;
         }
     const double dS = (tid < n) ? HF[(size_t) tid * n + tid] : 0.0;
+    double nsv[4];
+    if (ortho) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int i = tid + u * NT; nsv[u] = (i < 7 * n) ? B.nsProj[i] : 0.0; }      // 7n <= 924
+    }
     if (GN) {
+        constexpr int FW = (int) (sizeof(DevFrame) / 4), CW = (int) (sizeof(DevCalib) / 4), MW = (LD_MAXF * FW + NT - 1) / NT;
+        unsigned mw[MW];
+        const unsigned *gF = (const unsigned *) B.frames;
+#pragma unroll
+        for (int u = 0; u < MW; u++) { const int i = tid + u * NT; mw[u] = (i < F * FW) ? gF[i] : 0u; }
+        const unsigned cw = (tid < CW) ? ((const unsigned *) B.calib)[tid] : 0u;
+        float4 ah[4], at[4];
+        if (io.ldsAd != nullptr) {      // F <= 8: F*F*16 <= 1024 float4 per table
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int i = tid + u * NT;
+                ah[u] = (i < F * F * 16) ? ((const float4 *) B.adHostF)[i] : make_float4(0, 0, 0, 0);
+                at[u] = (i < F * F * 16) ? ((const float4 *) B.adTargetF)[i] : make_float4(0, 0, 0, 0);
+            }
+        }
         double ns = 0, nc = 0;      // sumNID of doStepFromBackup, same summation order as post_sums
         for (int c = tid; c < D.nChunks; c += NT) { ns += (double) S.chunkNID[c * 2]; nc += (double) S.chunkNID[c * 2 + 1]; }
-        const unsigned *gF = (const unsigned *) B.frames; unsigned *lF = (unsigned *) io.fr;
-        for (int i = tid; i < F * (int) (sizeof(DevFrame) / 4); i += NT) lF[i] = gF[i];
-        const unsigned *gC = (const unsigned *) B.calib; unsigned *lC = (unsigned *) io.cal;
-        for (int i = tid; i < (int) (sizeof(DevCalib) / 4); i += NT) lC[i] = gC[i];
+        // ---- consume ----
+        unsigned *lF = (unsigned *) io.fr;
+#pragma unroll
+        for (int u = 0; u < MW; u++) { const int i = tid + u * NT; if (i < F * FW) lF[i] = mw[u]; }
+        if (tid < CW) ((unsigned *) io.cal)[tid] = cw;
         if (io.ldsAd != nullptr) {
-            const float4 *gh = (const float4 *) B.adHostF, *gt = (const float4 *) B.adTargetF;
             float4 *lh = (float4 *) io.ldsAd, *lt = (float4 *) (io.ldsAd + F * F * 64);
-            for (int i = tid; i < F * F * 16; i += NT) { lh[i] = gh[i]; lt[i] = gt[i]; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int i = tid + u * NT; if (i < F * F * 16) { lh[i] = ah[u]; lt[i] = at[u]; } }
             io.adH = io.ldsAd; io.adT = io.ldsAd + F * F * 64;
         }
-        // two interleaved butterfly reductions
         for (int o = 32; o > 0; o >>= 1) { double a_ = __shfl_xor(ns, o, 64), b_ = __shfl_xor(nc, o, 64); ns += a_; nc += b_; }
         if ((tid & 63) == 0) { io.sRed[tid >> 6] = ns; io.sRed[4 + (tid >> 6)] = nc; }
     }
-    if (ortho) for (int i = tid; i < 7 * n; i += NT) sNs[i] = B.nsProj[i];
-    if (tid < M) sSc[tid] = 1.0 / sqrt(dS + 10.0);
+    if (ortho) {
 #pragma unroll
-    for (int a = 0; a < NB; a++)
+        for (int u = 0; u < 4; u++) { const int i = tid + u * NT; if (i < 7 * n) sNs[i] = nsv[u]; }
+    }
+    if (NB == 4) {      // zero the square L buffer
+        for (int i = tid; i < LSZ / 2; i += NT) st2(&sL[2 * i], 0.0, 0.0);
+    }
+    if (tid < M) sSc[tid] = fast_rsqrt(dS + 10.0);
+    {
+        double sI[NB], sJ[NB];
 #pragma unroll
-        for (int b = 0; b <= a; b++) {
-            const int i = ty + 16 * a;
-            const double si = (i == n) ? 1.0 : 1.0 / sqrt(dI[a] + 10.0), sj = 1.0 / sqrt(dJ[b] + 10.0);
-            v[a * (a + 1) / 2 + b] = si * v[a * (a + 1) / 2 + b] * sj;
-        }
+        for (int a = 0; a < NB; a++) { sI[a] = (ty + 16 * a == n) ? 1.0 : fast_rsqrt(dI[a] + 10.0); sJ[a] = fast_rsqrt(dJ[a] + 10.0); }
+#pragma unroll
+        for (int a = 0; a < NB; a++)
+#pragma unroll
+            for (int b = 0; b <= a; b++) v[a * (a + 1) / 2 + b] = sI[a] * v[a * (a + 1) / 2 + b] * sJ[b];
+    }
     // first panel (columns 0..3)
     if (tx < 4) {
 #pragma unroll
@@ -444,63 +502,61 @@ static __device__ void solve_core(const BaPtrs &B, const BaDims &D, const ResSet
     if (GN) io.sumNID = (float) (io.sRed[0] + io.sRed[1] + io.sRed[2] + io.sRed[3]) / (float) (io.sRed[4] + io.sRed[5] + io.sRed[6] + io.sRed[7]);
 
     for (int k = 0; k < n; k += 4) {
-        // ---------------- phase 1 ----------------
+        // ---------------- phase 1: LDL^T of the 4x4 pivot block (replicated) + this row's multipliers ----------------
+        if (GN && k == 8 && (tid & 63) == 0) B.energyLog[26 + (tid >> 6) * 3] = (double) clock64();
         if (tid < M) {
             const int i = tid;
-            double P[4][4];
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const double2 lo = *(const double2 *) &sPn[(k + r) * 4], hi = *(const double2 *) &sPn[(k + r) * 4 + 2];
-                const double w[4] = {lo.x, lo.y, hi.x, hi.y};
-#pragma unroll
-                for (int c = 0; c <= r; c++) { P[r][c] = w[c]; P[c][r] = w[c]; }
-            }
-            double a4[4];
-            {
-                const double2 lo = *(const double2 *) &sPn[i * 4], hi = *(const double2 *) &sPn[i * 4 + 2];
-                a4[0] = lo.x; a4[1] = lo.y; a4[2] = hi.x; a4[3] = hi.y;
-            }
-            const int ri = i - k;
-#pragma unroll
-            for (int q = 0; q < 4; q++) a4[q] = (ri == 0) ? P[0][q] : (ri == 1) ? P[1][q] : (ri == 2) ? P[2][q] : (ri == 3) ? P[3][q] : a4[q];
-            double f4[4], g4[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const double d = P[q][q];
-                const double invd = (fabs(d) > TINY) ? fast_rcp(d) : 0.0;
-                const bool on = (i > k + q) && (i <= n);
-                g4[q] = a4[q];
-                const double f = on ? a4[q] * invd : 0.0;
-                f4[q] = f;
-#pragma unroll
-                for (int r = q + 1; r < 4; r++) a4[r] = __builtin_fma(-f, P[q][r], a4[r]);
-                if (i == k + q) sD[i] = d;
-#pragma unroll
-                for (int r = q + 1; r < 4; r++) {
-                    const double fr_ = P[r][q] * invd;
-#pragma unroll
-                    for (int c = q + 1; c < 4; c++) P[r][c] = __builtin_fma(-fr_, P[q][c], P[r][c]);
-                }
-            }
-            const bool colRole = (i >= k + 4) && (i < n);
-            *(double2 *) &sFp[i * 4] = make_double2(f4[0], f4[1]);
-            *(double2 *) &sFp[i * 4 + 2] = make_double2(f4[2], f4[3]);
-            *(double2 *) &sGp[i * 4] = colRole ? make_double2(g4[0], g4[1]) : make_double2(0.0, 0.0);
-            *(double2 *) &sGp[i * 4 + 2] = colRole ? make_double2(g4[2], g4[3]) : make_double2(0.0, 0.0);
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                if (i > k + q && i < n) sL[LPK(i, k + q)] = f4[q];
-                if (i == n) sY[k + q] = g4[q];
+            const double p00 = sPn[(k + 0) * 4];
+            const double2 p1 = ld2(&sPn[(k + 1) * 4]);                                         // P10 P11
+            const double2 p2 = ld2(&sPn[(k + 2) * 4]); const double p22 = sPn[(k + 2) * 4 + 2];    // P20 P21 | P22
+            const double2 p3 = ld2(&sPn[(k + 3) * 4]), p3b = ld2(&sPn[(k + 3) * 4 + 2]);       // P30 P31 | P32 P33
+            const double2 a01 = ld2(&sPn[i * 4]), a23 = ld2(&sPn[i * 4 + 2]);
+            // LDL^T of the pivot block and of this row, arranged so that every pivot d_q is ONE fma behind the reciprocal of
+            // d_{q-1} (products of already known quantities are formed while the reciprocal is in flight):
+            //   c_rq = column q of the block after the eliminations 0..q-1 (unscaled), d_q = c_qq, l_rq = c_rq / d_q,
+            //   g_q  = A[i][k+q] after the eliminations 0..q-1,                          f_q = g_q / d_q = L[i][k+q].
+            const double a0 = a01.x;
+            const double d0 = p00, i0 = (fabs(d0) > TINY) ? fast_rcp(d0) : 0.0;
+            const double q11 = p1.x * p1.x, q21 = p2.x * p1.x, q31 = p3.x * p1.x, q22 = p2.x * p2.x, q32 = p3.x * p2.x, q33 = p3.x * p3.x;
+            const double r1 = a0 * p1.x, r2 = a0 * p2.x, r3 = a0 * p3.x;
+            const double d1 = __builtin_fma(-q11, i0, p1.y);
+            const double c21 = __builtin_fma(-q21, i0, p2.y), c31 = __builtin_fma(-q31, i0, p3.y);
+            const double t22 = __builtin_fma(-q22, i0, p22), t32 = __builtin_fma(-q32, i0, p3b.x), t33 = __builtin_fma(-q33, i0, p3b.y);
+            const double g1 = __builtin_fma(-r1, i0, a01.y), h2 = __builtin_fma(-r2, i0, a23.x), h3 = __builtin_fma(-r3, i0, a23.y);
+            const double i1 = (fabs(d1) > TINY) ? fast_rcp(d1) : 0.0;
+            const double w22 = c21 * c21, w32 = c31 * c21, w33 = c31 * c31, s2 = g1 * c21, s3 = g1 * c31;
+            const double d2 = __builtin_fma(-w22, i1, t22);
+            const double c32 = __builtin_fma(-w32, i1, t32), u33 = __builtin_fma(-w33, i1, t33);
+            const double g2 = __builtin_fma(-s2, i1, h2), h3b = __builtin_fma(-s3, i1, h3);
+            const double i2 = (fabs(d2) > TINY) ? fast_rcp(d2) : 0.0;
+            const double z33 = c32 * c32, s3b = g2 * c32;
+            const double d3 = __builtin_fma(-z33, i2, u33);
+            const double g3 = __builtin_fma(-s3b, i2, h3b);
+            const double i3 = (fabs(d3) > TINY) ? fast_rcp(d3) : 0.0;
+            const double g0 = a0, f0 = g0 * i0, f1 = g1 * i1, f2 = g2 * i2, f3 = g3 * i3;
+            const double l10 = p1.x * i0, l20 = p2.x * i0, l30 = p3.x * i0, l21 = c21 * i1, l31 = c31 * i1, l32 = c32 * i2;
+            const bool below = (i >= k + 4);
+            const bool rowOn = below && (i <= n), colOn = below && (i < n);
+            st2(&sFp[i * 4], rowOn ? f0 : 0.0, rowOn ? f1 : 0.0); st2(&sFp[i * 4 + 2], rowOn ? f2 : 0.0, rowOn ? f3 : 0.0);
+            st2(&sGp[i * 4], colOn ? g0 : 0.0, colOn ? g1 : 0.0); st2(&sGp[i * 4 + 2], colOn ? g2 : 0.0, colOn ? g3 : 0.0);
+            if (colOn) { sL[LIX(i, k)] = f0; sL[LIX(i, k + 1)] = f1; sL[LIX(i, k + 2)] = f2; sL[LIX(i, k + 3)] = f3; }
+            if (i == n) { st2(&sY[k], g0, g1); st2(&sY[k + 2], g2, g3); }          // forward-substituted rhs (k + 4 <= n + 3 < M)
+            if (i == k) {                                                          // D and L of the pivot block itself
+                st2(&sD[k], d0, d1); st2(&sD[k + 2], d2, d3);
+                if (k + 1 < n) sL[LIX(k + 1, k)] = l10;
+                if (k + 2 < n) { sL[LIX(k + 2, k)] = l20; sL[LIX(k + 2, k + 1)] = l21; }
+                if (k + 3 < n) { sL[LIX(k + 3, k)] = l30; sL[LIX(k + 3, k + 1)] = l31; sL[LIX(k + 3, k + 2)] = l32; }
             }
         }
         __syncthreads();
         // ---------------- phase 2 (branch free: finished columns have G = 0, finished rows F = 0) ----------------
+        if (GN && k == 8 && (tid & 63) == 0) B.energyLog[27 + (tid >> 6) * 3] = (double) clock64();
         const int a0 = (k + 4) >> 4, c0 = (k + 4) & 15;
         double fi[NB][4], gj[NB][4];
 #pragma unroll
         for (int a = 0; a < NB; a++) {
-            const double2 f0 = *(const double2 *) &sFp[(ty + 16 * a) * 4], f1 = *(const double2 *) &sFp[(ty + 16 * a) * 4 + 2];
-            const double2 g0 = *(const double2 *) &sGp[(tx + 16 * a) * 4], g1 = *(const double2 *) &sGp[(tx + 16 * a) * 4 + 2];
+            const double2 f0 = ld2(&sFp[(ty + 16 * a) * 4]), f1 = ld2(&sFp[(ty + 16 * a) * 4 + 2]);
+            const double2 g0 = ld2(&sGp[(tx + 16 * a) * 4]), g1 = ld2(&sGp[(tx + 16 * a) * 4 + 2]);
             fi[a][0] = f0.x; fi[a][1] = f0.y; fi[a][2] = f1.x; fi[a][3] = f1.y;
             gj[a][0] = g0.x; gj[a][1] = g0.y; gj[a][2] = g1.x; gj[a][3] = g1.y;
         }
@@ -522,21 +578,22 @@ static __device__ void solve_core(const BaPtrs &B, const BaDims &D, const ResSet
             for (int b = 1; b <= a; b++) w = (a0 == b) ? v[a * (a + 1) / 2 + b] : w;
             if (pub && a >= a0) sPn[(ty + 16 * a) * 4 + (tx - c0)] = w;
         }
+        if (GN && k == 8 && (tid & 63) == 0) B.energyLog[28 + (tid >> 6) * 3] = (double) clock64();
         __syncthreads();
     }
-
     if (GN && tid == 0) B.energyLog[42] = (double) wall_clock64();
+
     // ---------------- back substitution by wave 0: x = L^-T D^+ y ----------------
     if (tid < 64) {
         const int lane = tid;
-        if (NB == 4 && n < 64) {
-            // lane i owns x_i and column i of L in registers; x_k is broadcast with v_readlane
+        if (NB == 4) {
+            // lane i owns x_i and column i of L in registers (zero outside the strict lower triangle); x_k is broadcast
+            // with v_readlane
             double row[64];
-            const int base = lane * M - ((lane * (lane - 1)) >> 1) - lane;      // LPK(kk, lane) = base + kk
 #pragma unroll
-            for (int kk = 0; kk < 64; kk++) { const bool in = (kk > lane && kk < n); double a = sL[in ? base + kk : 0]; row[kk] = in ? a : 0.0; }
+            for (int kk = 0; kk < 64; kk += 2) { const double2 q = ld2(&sL[lane * (M + 2) + kk]); row[kk] = q.x; row[kk + 1] = q.y; }
             const double d = sD[lane], z = sY[lane];
-            double xi = (lane < n && fabs(d) > TINY) ? z / d : 0.0;
+            double xi = (lane < n && fabs(d) > TINY) ? z * fast_rcp(d) : 0.0;
 #pragma unroll
             for (int kk = 63; kk >= 1; kk--) { double xk = readlane_f64(xi, kk); xi = __builtin_fma(-row[kk], xk, xi); }
             if (lane < n) sx[lane] = xi * sSc[lane];
@@ -545,25 +602,27 @@ static __device__ void solve_core(const BaPtrs &B, const BaDims &D, const ResSet
             __builtin_amdgcn_wave_barrier();
             for (int kk = n - 1; kk > 0; kk--) {           // column oriented: x_i -= L[k][i] x_k for i < k
                 const double xk = sx[kk];
-                for (int i = lane; i < kk; i += 64) sx[i] -= sL[LPK(kk, i)] * xk;
+                for (int i = lane; i < kk; i += 64) sx[i] -= sL[LIX(kk, i)] * xk;
                 __builtin_amdgcn_wave_barrier();
             }
             for (int i = lane; i < n; i += 64) sx[i] *= sSc[i];
         }
-        // orthogonalize x against the gauge nullspaces (x -= U U^T x); the 7 reductions run interleaved
+        // orthogonalize x against the gauge nullspaces (x -= U U^T x): 8 lanes per nullspace vector
         if (ortho) {
             __builtin_amdgcn_wave_barrier();
-            double c[7];
+            const int kk = lane >> 3, j = lane & 7;
+            double c = 0;
+            if (kk < 7) for (int r = j; r < n; r += 8) c = __builtin_fma(sNs[kk * n + r], sx[r], c);
+            c += __shfl_xor(c, 1, 64); c += __shfl_xor(c, 2, 64); c += __shfl_xor(c, 4, 64);
+            double cc[7];
 #pragma unroll
-            for (int kk = 0; kk < 7; kk++) { double s_ = 0; for (int r = lane; r < n; r += 64) s_ += sNs[kk * n + r] * sx[r]; c[kk] = s_; }
-            for (int o = 32; o > 0; o >>= 1) {
-                double t_[7];
+            for (int q = 0; q < 7; q++) cc[q] = readlane_f64(c, q * 8);
+            for (int r = lane; r < n; r += 64) {
+                double s_ = 0;
 #pragma unroll
-                for (int kk = 0; kk < 7; kk++) t_[kk] = __shfl_xor(c[kk], o, 64);
-#pragma unroll
-                for (int kk = 0; kk < 7; kk++) c[kk] += t_[kk];
+                for (int q = 0; q < 7; q++) s_ = __builtin_fma(sNs[q * n + r], cc[q], s_);
+                sx[r] -= s_;
             }
-            for (int r = lane; r < n; r += 64) { double s_ = 0; for (int kk = 0; kk < 7; kk++) s_ += sNs[kk * n + r] * c[kk]; sx[r] -= s_; }
         }
     }
     __syncthreads();
@@ -607,17 +666,26 @@ static __device__ void solve_core_dispatch(const BaPtrs &B, const BaDims &D, con
     else solve_core<9, GN>(B, D, S, St, iteration, sm, io);
 }
 
-// canbreak of doStepFromBackup (FullSystem.cc:1604-1622)
-static __device__ void step_canbreak(const BaPtrs &B, const ldso_settings_t &St, const DevFrame *fr, int F, float sumNID) {
-    if (threadIdx.x == 0) {
-        float sumA = 0, sumB = 0, sumT = 0, sumR = 0;
+// canbreak of doStepFromBackup (FullSystem.cc:1604-1622); the four sums are accumulated by lane 0 of the four waves.
+// Contains a block barrier: call from uniform control flow.
+static __device__ void step_canbreak(const BaPtrs &B, const ldso_settings_t &St, const DevFrame *fr, int F, float sumNID, double *sRed /*>= 16 doubles*/) {
+    const int tid = threadIdx.x, w = tid >> 6;
+    float *sF = (float *) (sRed + 8);
+    if ((tid & 63) == 0) {
+        float acc = 0;
         for (int f = 0; f < F; f++) {
             const double *s = fr[f].step;
-            sumA += s[6] * s[6]; sumB += s[7] * s[7];
-            sumT += s[0] * s[0] + s[1] * s[1] + s[2] * s[2];
-            sumR += s[3] * s[3] + s[4] * s[4] + s[5] * s[5];
+            if (w == 0) acc += s[6] * s[6];
+            else if (w == 1) acc += s[7] * s[7];
+            else if (w == 2) acc += s[0] * s[0] + s[1] * s[1] + s[2] * s[2];
+            else acc += s[3] * s[3] + s[4] * s[4] + s[5] * s[5];
         }
-        sumA /= F; sumB /= F; sumR /= F; sumT /= F;
+        acc /= F;
+        sF[w] = acc;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const float sumA = sF[0], sumB = sF[1], sumT = sF[2], sumR = sF[3];
         bool cb = sqrtf(sumA) < 0.0005 * St.thOptIterations && sqrtf(sumB) < 0.00005 * St.thOptIterations &&
                   sqrtf(sumR) < 0.00005 * St.thOptIterations && sqrtf(sumT) * sumNID < 0.00005 * St.thOptIterations;
         B.scalars[3] = cb ? 1.0 : 0.0;
@@ -631,11 +699,11 @@ static __device__ void frames_backup(DevFrame *fr, DevCalib *cal, int F) {
     if (tid == 0) for (int i = 0; i < 4; i++) cal->value_backup[i] = cal->value[i];
     __syncthreads();
 }
-static __device__ void frames_step(const BaPtrs &B, const ldso_settings_t &St, DevFrame *fr, DevCalib *cal, int F, float sumNID) {
+static __device__ void frames_step(const BaPtrs &B, const ldso_settings_t &St, DevFrame *fr, DevCalib *cal, int F, float sumNID, double *sRed) {
     const int tid = threadIdx.x;
     if (tid < F) for (int i = 0; i < 10; i++) fr[tid].state[i] = fr[tid].state_backup[i] + fr[tid].step[i];
     if (tid == 0) for (int i = 0; i < 4; i++) cal->value[i] = cal->value_backup[i] + cal->step[i] * (double) 1.0f;
-    step_canbreak(B, St, fr, F, sumNID);
+    step_canbreak(B, St, fr, F, sumNID, sRed);
     __syncthreads();
 }
 
@@ -693,17 +761,17 @@ __global__ __launch_bounds__(NT) void k_solve(BaPtrs B, BaDims D, ResSet S, ldso
         // HFinal / bFinal were assembled by k_gather (ba_reduce.hip)
         if (!(fl & SK_FROMREDUCED)) res_counts(B, D, S, sW);
         SolveIO io;
-        io.fr = B.frames; io.cal = B.calib; io.adH = B.adHostF; io.adT = B.adTargetF; io.ldsAd = nullptr; io.sRed = sW; io.sumNID = 0;
+        io.fr = B.frames; io.cal = B.calib; io.adH = B.adHostF; io.adT = B.adTargetF; io.ldsAd = nullptr; io.sRed = sW; io.sumNID = 0; io.lambda = A.lambda; io.hasPrior = A.hasPrior;
         solve_core_dispatch<false>(B, D, S, St, A.iteration, sm, io);
     }
     if (fl & SK_BACKUP) frames_backup(B.frames, B.calib, F);
-    if (fl & SK_STEP) frames_step(B, St, B.frames, B.calib, F, (float) B.scalars[6] / (float) B.scalars[7]);
+    if (fl & SK_STEP) frames_step(B, St, B.frames, B.calib, F, (float) B.scalars[6] / (float) B.scalars[7], sW);
     if (fl & SK_LOADBK) {
         if (tid < F) for (int i = 0; i < 10; i++) B.frames[tid].state[i] = B.frames[tid].state_backup[i];
         if (tid == 0) for (int i = 0; i < 4; i++) B.calib->value[i] = B.calib->value_backup[i];
         __syncthreads();
     }
-    if (fl & SK_PRECALC) set_precalc(B, D, B.frames, B.calib, B.adHostF, B.adTargetF);
+    if (fl & SK_PRECALC) set_precalc<true>(B, D, B.frames, B.calib, B.adHostF, B.adTargetF);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -737,13 +805,13 @@ __global__ __launch_bounds__(NT) void k_gn_solve(BaPtrs B, BaDims D, ResSet S, l
     DevCalib *sCal = (DevCalib *) (sFr + F);
     if (tid == 0) B.energyLog[39] = (double) t0_;
     SolveIO io;
-    io.fr = sFr; io.cal = sCal; io.adH = B.adHostF; io.adT = B.adTargetF; io.sRed = sW; io.sumNID = 0;
+    io.fr = sFr; io.cal = sCal; io.adH = B.adHostF; io.adT = B.adTargetF; io.sRed = sW; io.sumNID = 0; io.lambda = A.lambda; io.hasPrior = A.hasPrior;
     io.ldsAd = (F <= 8) ? (float *) (sCal + 1) : nullptr;
     solve_core_dispatch<true>(B, D, S, St, A.iteration, sm, io);      // + mirrors, backupState, doStepFromBackup
     GSTAMP(4);
-    step_canbreak(B, St, sFr, F, io.sumNID);
+    step_canbreak(B, St, sFr, F, io.sumNID, sW);
     GSTAMP(5);
-    set_precalc(B, D, sFr, sCal, io.adH, io.adT);
+    set_precalc<false>(B, D, sFr, sCal, io.adH, io.adT);
     GSTAMP(6);
     // write the mirrors back (all but frameEnergyTH, which block 1 owns)
     {
