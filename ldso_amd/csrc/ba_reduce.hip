@@ -15,7 +15,9 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define SC_SLAB 128     // points staged per LDS slab (one slab per split at the C3 window: a single load level)
 #define PA_SLICES 2     // Part A: interleaved slices of a pair's chunk range (2 x 91 threads)
-#define PA_UNROLL 16    // Part A: partial loads in flight per thread
+#define PA_UNROLL 24    // Part A: partial loads in flight per thread
+#define SCT_KS 4         // atomic mode: K-splits per Schur tile
+#define SCT_SLAB 512    // atomic mode: points staged per LDS slab of a tile block
 #define SC_MAXT 12      // tiles per wave: GSP=144 (FS=16) -> 45 upper tiles / 4 waves
 
 __host__ __device__ constexpr int tri13r(int r, int c) { return r * 13 - (r * (r - 1)) / 2 + (c - r); }
@@ -126,7 +128,76 @@ __global__ __launch_bounds__(256) void k_reduce(BaPtrs B, BaDims D, ResSet S, co
     }
 
     const int nSplitBase = nPairBlocks;
-    if ((int) blockIdx.x == nSplitBase + LD_SC_SPLITS) {
+    if (atomicMode && (int) blockIdx.x < nSplitBase + SCT_KS * (GSP / 16) * (GSP / 16 + 1) / 2) {
+        // ------------------------------- Part B, atomic mode: one block per (16x16 tile, K-split) ---------------------
+        // The block stages the two 16-column blocks of its G rows (and the weights HdiF) in LDS with 16-byte loads, its four
+        // waves interleave the k-steps of v_mfma_f32_16x16x4_f32, the four partial tiles are summed through LDS and each
+        // thread adds ONE element (scaled by -1/(1+lambda)) into HFinal / bFinal: SCT_KS-way contention per address.
+        extern __shared__ __attribute__((aligned(16))) float sT_[];
+        float *sAc = sT_, *sBc = sAc + SCT_SLAB * 16, *sWc = sBc + SCT_SLAB * 16;      // [SLAB][16], [SLAB][16], [SLAB]
+        const int bb = blockIdx.x - nSplitBase, tile = bb / SCT_KS, ks = bb % SCT_KS;
+        const int nT = GSP / 16, GS = D.GS, n = D.n;
+        int ti = 0, rem = tile;
+        while (rem >= nT - ti) { rem -= nT - ti; ti++; }
+        const int tj = ti + rem;
+        const int P0 = D.pBegin, Pn = D.pEnd - D.pBegin, per = ((Pn + SCT_KS - 1) / SCT_KS + 3) & ~3;
+        const int pa = P0 + ks * per, pb = min(P0 + Pn, pa + per);
+        const int wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
+        const int wcol = 8 * FS + 5;
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int base = pa; base < pb; base += SCT_SLAB) {
+            const int cnt = min(SCT_SLAB, pb - base), rows = (cnt + 3) & ~3;
+            __syncthreads();
+            {
+                // float4 e of the slab: row r = e / 8, half = (e / 4) & 1 (A or B column block), c4 = e & 3
+                float4 q[16];
+                float wq[2];
+#pragma unroll
+                for (int u = 0; u < 16; u++) {
+                    const int e = tid + u * 256, r = e >> 3, half = (e >> 2) & 1, c4 = e & 3;
+                    q[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    const int col = (half ? tj : ti) * 16 + c4 * 4;
+                    if (r < cnt && col < GS) q[u] = *(const float4 *) (S.G + (size_t) (base + r) * GS + col);
+                }
+#pragma unroll
+                for (int u = 0; u < 2; u++) { const int r = tid + u * 256; wq[u] = (r < cnt) ? S.G[(size_t) (base + r) * GS + wcol] : 0.f; }
+#pragma unroll
+                for (int u = 0; u < 16; u++) {
+                    const int e = tid + u * 256, r = e >> 3, half = (e >> 2) & 1, c4 = e & 3;
+                    if (r < rows) *(float4 *) ((half ? sBc : sAc) + r * 16 + c4 * 4) = q[u];
+                }
+#pragma unroll
+                for (int u = 0; u < 2; u++) { const int r = tid + u * 256; if (r < rows) sWc[r] = wq[u]; }
+            }
+            __syncthreads();
+#pragma unroll 4
+            for (int k0 = wave * 4; k0 < rows; k0 += 16) {
+                const float a = sAc[(k0 + lk) * 16 + li] * sWc[k0 + lk];
+                const float b = sBc[(k0 + lk) * 16 + li];
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        float *sR = sT_;      // [4 waves][256]
+#pragma unroll
+        for (int r = 0; r < 4; r++) sR[wave * 256 + (lk * 4 + r) * 16 + li] = acc[r];
+        __syncthreads();
+        {
+            const float v = ((sR[tid] + sR[256 + tid]) + sR[512 + tid]) + sR[768 + tid];
+            const int rr = ti * 16 + (tid >> 4), cc = tj * 16 + (tid & 15);
+            const int F8 = 8 * D.F, FS8 = 8 * FS;
+            // G column -> index in the reference ordering [calib 4 | frames 8F]; n = right-hand side; -1 = padding
+            const int I = (rr < F8) ? 4 + rr : (rr >= FS8 && rr < FS8 + 4) ? rr - FS8 : (rr == FS8 + 4) ? n : -1;
+            const int J = (cc < F8) ? 4 + cc : (cc >= FS8 && cc < FS8 + 4) ? cc - FS8 : (cc == FS8 + 4) ? n : -1;
+            const bool use = !(ti == tj && rr > cc) && I >= 0 && J >= 0 && I != n;
+            if (use) {
+                if (J == n) acc_add(&B.acc[(size_t) n * n + I], -(double) v);
+                else acc_add(&B.acc[(size_t) max(I, J) * n + min(I, J)], -(double) v * il);
+            }
+        }
+        return;
+    }
+    if (atomicMode) {
         // ------------------------------- extras of the GN fast path --------------------------------------------
         // bExtra = prior * delta_prior + (bM + HM delta), priorDiag   (AccumulatedTopHessian.cc:246-254, EnergyFunctional.cc:279)
         const int n = D.n;
@@ -391,8 +462,9 @@ hipError_t ba_launch_gather(const BaPtrs &B, const BaDims &D, const ResSet &S, b
 
 hipError_t ba_launch_reduce(const BaPtrs &B, const BaDims &D, const ResSet &S, const int32_t *chunkStart, bool hasL, int GSP, bool atomicMode, bool hasPrior,
                             float calibPrior, double l1, double il, hipStream_t st) {
-    int nb = D.F * D.F * (hasL ? 2 : 1) + LD_SC_SPLITS + (atomicMode ? 1 : 0);
-    size_t lds = (size_t) (SC_SLAB * GSP) * sizeof(float);
+    const int nT = GSP / 16;
+    int nb = D.F * D.F * (hasL ? 2 : 1) + (atomicMode ? SCT_KS * nT * (nT + 1) / 2 + 1 : LD_SC_SPLITS);
+    size_t lds = atomicMode ? (size_t) (2 * SCT_SLAB * 16 + SCT_SLAB) * sizeof(float) : (size_t) (SC_SLAB * GSP) * sizeof(float);
     if (lds > 48 * 1024) hipFuncSetAttribute((const void *) k_reduce, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
     hipLaunchKernelGGL(k_reduce, dim3(nb), dim3(256), lds, st, B, D, S, chunkStart, hasL ? 1 : 0, GSP, atomicMode ? 1 : 0, hasPrior ? 1 : 0, calibPrior, l1, il);
     return hipGetLastError();
