@@ -101,6 +101,8 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D,
     const int FS = D.FS, F = D.F;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, s = lane >> 3, k = lane & 7;
     const int chunk = blockIdx.x;
+    const long long t0_ = wall_clock64();
+#define LSTAMP(i) do { if (blockIdx.x == 0 && tid == 0) B.energyLog[8 + (i)] = (double) (wall_clock64() - t0_); } while (0)
     const int p0 = B.chunk_p0[chunk], np = B.chunk_n[chunk], h = B.chunk_host[chunk];
 
     // ---- LDS carve: pair structs of this host, float adjoints of this host, reduction scratch --------
@@ -154,6 +156,7 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D,
     }
     if (HAS_L) for (int i = tid; i < FS * LD_TOPN; i += blockDim.x) sTopL[i] = 0.0f;
     __syncthreads();
+    LSTAMP(1);
 
     const int ox = (k == 1 || k == 6) ? -1 : (k == 2) ? 1 : (k == 3) ? -2 : (k == 5) ? 2 : 0;     // staticPattern[8], Setting.cc:221
     const int oy = (k == 0) ? -2 : (k == 1 || k == 2) ? -1 : (k == 6) ? 1 : (k == 7) ? 2 : 0;
@@ -170,6 +173,7 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D,
     int nidCnt = 0;
 
     for (; pi < np; pi += LD_WAVES) {
+        if (pi == wave) LSTAMP(2);
         const int p = p0 + pi;
         const PtIn<NSG> q = nx;
         if (pi + LD_WAVES < np) load_point<NSG, HAS_L, FIX>(nx, B, cur, FS, p + LD_WAVES, s, k, stepMode);
@@ -248,6 +252,7 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D,
             float q2 = ((pr.KRKi[6] * px_ + pr.KRKi[7] * py_) + pr.KRKi[8] * 1.0f) + pr.Kt[2] * idp;
             float Ku = q0 / q2, Kv = q1 / q2;
             bool pixOK = Ku > 1.1f && Kv > 1.1f && Ku < D.wM3G && Kv < D.hM3G;
+            if (pi == wave && g == 0) LSTAMP(3);
             // ---- bilinear Vec3f sample of the target image (GlobalFuncs.h:89-103) ---------------------
             float hit0 = 0, hit1 = 0, hit2 = 0;
             if (compute && centerOK && pixOK) {
@@ -483,6 +488,7 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D,
             }
         }   // slot groups
 
+        if (pi == wave) LSTAMP(5);
         // ================= per-point Schur quantities (AccumulatedSCHessian.cc:9-31) =====================
         float HdiF = 0, bdSumF = 0, idH = 0;
         float Hc0 = HcdA0 + HcdL0, Hc1 = HcdA1 + HcdL1, Hc2 = HcdA2 + HcdL2, Hc3 = HcdA3 + HcdL3;
@@ -520,6 +526,7 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D,
         }
     }   // points of this wave
 
+    LSTAMP(6);
     // ================= block reduction of the top accumulators =============================================
     // (1) over the 8 pattern lanes, (2) over the waves of the block through LDS, fixed order
 #pragma unroll
@@ -550,6 +557,7 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D,
         if (lane == 0) { sE[wave] = e; sC[wave * 4 + 0] = na; sC[wave * 4 + 1] = nl; sC[wave * 4 + 2] = nidCnt; sN[wave] = nidSum; }
     }
     __syncthreads();
+    LSTAMP(7);
     if (tid == 0) {
         double e = 0; int na = 0, nl = 0, nc = 0; float ns = 0;
         for (int wv = 0; wv < LD_WAVES; wv++) { e += sE[wv]; na += sC[wv * 4 + 0]; nl += sC[wv * 4 + 1]; nc += sC[wv * 4 + 2]; ns += sN[wv]; }

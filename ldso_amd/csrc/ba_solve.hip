@@ -371,6 +371,8 @@ static __device__ __forceinline__ double fast_rsqrt(double d) {
     double e = __builtin_fma(-(d * r), r, 1.0);
     return __builtin_fma(0.5 * r, e, r);
 }
+static __device__ __forceinline__ long long tick() { long long t; asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); return t; }
+#define PSTAMP(j) do { if (GN && k == 8 && tid == 0) B.energyLog[26 + (j)] = (double) tick(); } while (0)
 static __device__ __forceinline__ double2 ld2(const double *p) { return *(const double2 *) p; }
 static __device__ __forceinline__ void st2(double *p, double a, double b) { *(double2 *) p = make_double2(a, b); }
 
@@ -382,7 +384,7 @@ static __device__ __forceinline__ void st2(double *p, double a, double b) { *(do
 static __host__ __device__ inline size_t solve_core_lds_doubles(int NB, int n) {
     size_t M = 16 * NB;
     size_t L = (NB == 4) ? M * (M + 2) : M * (M + 1) / 2;
-    return L + 2 * M /*D,Y*/ + 12 * M /*F,G,panel*/ + 2 * M /*scale,x*/ + 7 * (size_t) n + 16;
+    return L + 2 * (M + 8) /*D,Y*/ + 30 * M /*F,G,panel (up to 8 columns, pitch 10)*/ + 2 * M /*scale,x*/ + 7 * (size_t) n + 16;
 }
 
 // GN = true (k_gn_solve): the prologue also mirrors the frames / calibration (and, when they fit, the float
@@ -399,20 +401,21 @@ struct SolveIO {
     int hasPrior;          // GN: HM / bM present
 };
 
-template <int NB, bool GN>
+template <int NB, int C, bool GN>
 static __device__ void solve_core(const BaPtrs &B, const BaDims &D, const ResSet &S, const ldso_settings_t &St, int iteration, double *sm, SolveIO &io) {
     constexpr int M = 16 * NB;
+    constexpr int CP = C + 2;      // row pitch of the panel buffers: 16-byte aligned rows, conflict-free 16-byte accesses at stride CP
     constexpr int NTILE = NB * (NB + 1) / 2;
     constexpr int LSZ = (NB == 4) ? M * (M + 2) : M * (M + 1) / 2;
     const double TINY = 2.2250738585072014e-308;
     const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15, F = D.F, n = D.n;
     double *sL = sm;                       // L (see LIX)
-    double *sD = sL + LSZ;                 // [M]
-    double *sY = sD + M;                   // [M]
-    double *sFp = sY + M;                  // [M][4]
-    double *sGp = sFp + 4 * M;             // [M][4]
-    double *sPn = sGp + 4 * M;             // [M][4]
-    double *sSc = sPn + 4 * M;             // [M]
+    double *sD = sL + LSZ;                 // [M + 8]
+    double *sY = sD + M + 8;               // [M + 8]
+    double *sFp = sY + M + 8;              // [M][CP]
+    double *sGp = sFp + CP * M;            // [M][CP]
+    double *sPn = sGp + CP * M;            // [M][CP]
+    double *sSc = sPn + CP * M;            // [M]
     double *sx = sSc + M;                  // [M]
     double *sNs = sx + M;                  // [7][n]
     const double *HF = B.sys + 3 * (n * n + n), *bF = HF + n * n;      // assembled by k_gather (step-wise path)
@@ -492,93 +495,101 @@ static __device__ void solve_core(const BaPtrs &B, const BaDims &D, const ResSet
 #pragma unroll
             for (int b = 0; b <= a; b++) v[a * (a + 1) / 2 + b] = sI[a] * v[a * (a + 1) / 2 + b] * sJ[b];
     }
-    // first panel (columns 0..3)
-    if (tx < 4) {
+    // first panel (columns 0..C-1)
+    if (tx < C) {
 #pragma unroll
-        for (int a = 0; a < NB; a++) sPn[(ty + 16 * a) * 4 + tx] = v[a * (a + 1) / 2];
+        for (int a = 0; a < NB; a++) sPn[(ty + 16 * a) * CP + tx] = v[a * (a + 1) / 2];
     }
     __syncthreads();
     if (GN && tid == 0) B.energyLog[41] = (double) wall_clock64();
     if (GN) io.sumNID = (float) (io.sRed[0] + io.sRed[1] + io.sRed[2] + io.sRed[3]) / (float) (io.sRed[4] + io.sRed[5] + io.sRed[6] + io.sRed[7]);
 
-    for (int k = 0; k < n; k += 4) {
-        // ---------------- phase 1: LDL^T of the 4x4 pivot block (replicated) + this row's multipliers ----------------
-        if (GN && k == 8 && (tid & 63) == 0) B.energyLog[26 + (tid >> 6) * 3] = (double) clock64();
+#pragma nounroll
+    for (int k = 0; k < n; k += C) {
+        // ---------------- phase 1: LDL^T of the CxC pivot block (replicated in every lane) + this row's multipliers -------
+        // c[r][q] (r >= q) = column q of the block after the eliminations 0..q-1 (unscaled), d_q = c[q][q], inv_q = 1/d_q;
+        // g_q = A[i][k+q] after the eliminations 0..q-1, f_q = g_q / d_q = L[i][k+q].  Every update is written as
+        // x -= (product of already known values) * inv_q, so that pivot d_{q+1} is ONE fma behind the reciprocal of d_q.
         if (tid < M) {
             const int i = tid;
-            const double p00 = sPn[(k + 0) * 4];
-            const double2 p1 = ld2(&sPn[(k + 1) * 4]);                                         // P10 P11
-            const double2 p2 = ld2(&sPn[(k + 2) * 4]); const double p22 = sPn[(k + 2) * 4 + 2];    // P20 P21 | P22
-            const double2 p3 = ld2(&sPn[(k + 3) * 4]), p3b = ld2(&sPn[(k + 3) * 4 + 2]);       // P30 P31 | P32 P33
-            const double2 a01 = ld2(&sPn[i * 4]), a23 = ld2(&sPn[i * 4 + 2]);
-            // LDL^T of the pivot block and of this row, arranged so that every pivot d_q is ONE fma behind the reciprocal of
-            // d_{q-1} (products of already known quantities are formed while the reciprocal is in flight):
-            //   c_rq = column q of the block after the eliminations 0..q-1 (unscaled), d_q = c_qq, l_rq = c_rq / d_q,
-            //   g_q  = A[i][k+q] after the eliminations 0..q-1,                          f_q = g_q / d_q = L[i][k+q].
-            const double a0 = a01.x;
-            const double d0 = p00, i0 = (fabs(d0) > TINY) ? fast_rcp(d0) : 0.0;
-            const double q11 = p1.x * p1.x, q21 = p2.x * p1.x, q31 = p3.x * p1.x, q22 = p2.x * p2.x, q32 = p3.x * p2.x, q33 = p3.x * p3.x;
-            const double r1 = a0 * p1.x, r2 = a0 * p2.x, r3 = a0 * p3.x;
-            const double d1 = __builtin_fma(-q11, i0, p1.y);
-            const double c21 = __builtin_fma(-q21, i0, p2.y), c31 = __builtin_fma(-q31, i0, p3.y);
-            const double t22 = __builtin_fma(-q22, i0, p22), t32 = __builtin_fma(-q32, i0, p3b.x), t33 = __builtin_fma(-q33, i0, p3b.y);
-            const double g1 = __builtin_fma(-r1, i0, a01.y), h2 = __builtin_fma(-r2, i0, a23.x), h3 = __builtin_fma(-r3, i0, a23.y);
-            const double i1 = (fabs(d1) > TINY) ? fast_rcp(d1) : 0.0;
-            const double w22 = c21 * c21, w32 = c31 * c21, w33 = c31 * c31, s2 = g1 * c21, s3 = g1 * c31;
-            const double d2 = __builtin_fma(-w22, i1, t22);
-            const double c32 = __builtin_fma(-w32, i1, t32), u33 = __builtin_fma(-w33, i1, t33);
-            const double g2 = __builtin_fma(-s2, i1, h2), h3b = __builtin_fma(-s3, i1, h3);
-            const double i2 = (fabs(d2) > TINY) ? fast_rcp(d2) : 0.0;
-            const double z33 = c32 * c32, s3b = g2 * c32;
-            const double d3 = __builtin_fma(-z33, i2, u33);
-            const double g3 = __builtin_fma(-s3b, i2, h3b);
-            const double i3 = (fabs(d3) > TINY) ? fast_rcp(d3) : 0.0;
-            const double g0 = a0, f0 = g0 * i0, f1 = g1 * i1, f2 = g2 * i2, f3 = g3 * i3;
-            const double l10 = p1.x * i0, l20 = p2.x * i0, l30 = p3.x * i0, l21 = c21 * i1, l31 = c31 * i1, l32 = c32 * i2;
-            const bool below = (i >= k + 4);
+            double c[C][C], g[C], f[C], inv[C];
+#pragma unroll
+            for (int r = 0; r < C; r++)
+#pragma unroll
+                for (int q2 = 0; q2 <= r; q2 += 2) {
+                    const double2 w = ld2(&sPn[(k + r) * CP + q2]);
+                    c[r][q2] = w.x; if (q2 + 1 < C) c[r][q2 + 1] = w.y;
+                }
+#pragma unroll
+            for (int q2 = 0; q2 < C; q2 += 2) { const double2 w = ld2(&sPn[i * CP + q2]); g[q2] = w.x; g[q2 + 1] = w.y; }
+#pragma unroll
+            for (int q = 0; q < C; q++) {
+                const double d = c[q][q];
+                double w_[C][C], wg[C];
+#pragma unroll
+                for (int r = q + 1; r < C; r++) {
+#pragma unroll
+                    for (int s_ = q + 1; s_ <= r; s_++) w_[r][s_] = c[r][q] * c[s_][q];
+                    wg[r] = g[q] * c[r][q];
+                }
+                inv[q] = (fabs(d) > TINY) ? fast_rcp(d) : 0.0;
+#pragma unroll
+                for (int r = q + 1; r < C; r++) {
+#pragma unroll
+                    for (int s_ = q + 1; s_ <= r; s_++) c[r][s_] = __builtin_fma(-w_[r][s_], inv[q], c[r][s_]);
+                    g[r] = __builtin_fma(-wg[r], inv[q], g[r]);
+                }
+                f[q] = g[q] * inv[q];
+            }
+            const bool below = (i >= k + C);
             const bool rowOn = below && (i <= n), colOn = below && (i < n);
-            st2(&sFp[i * 4], rowOn ? f0 : 0.0, rowOn ? f1 : 0.0); st2(&sFp[i * 4 + 2], rowOn ? f2 : 0.0, rowOn ? f3 : 0.0);
-            st2(&sGp[i * 4], colOn ? g0 : 0.0, colOn ? g1 : 0.0); st2(&sGp[i * 4 + 2], colOn ? g2 : 0.0, colOn ? g3 : 0.0);
-            if (colOn) { sL[LIX(i, k)] = f0; sL[LIX(i, k + 1)] = f1; sL[LIX(i, k + 2)] = f2; sL[LIX(i, k + 3)] = f3; }
-            if (i == n) { st2(&sY[k], g0, g1); st2(&sY[k + 2], g2, g3); }          // forward-substituted rhs (k + 4 <= n + 3 < M)
-            if (i == k) {                                                          // D and L of the pivot block itself
-                st2(&sD[k], d0, d1); st2(&sD[k + 2], d2, d3);
-                if (k + 1 < n) sL[LIX(k + 1, k)] = l10;
-                if (k + 2 < n) { sL[LIX(k + 2, k)] = l20; sL[LIX(k + 2, k + 1)] = l21; }
-                if (k + 3 < n) { sL[LIX(k + 3, k)] = l30; sL[LIX(k + 3, k + 1)] = l31; sL[LIX(k + 3, k + 2)] = l32; }
+#pragma unroll
+            for (int q2 = 0; q2 < C; q2 += 2) {
+                st2(&sFp[i * CP + q2], rowOn ? f[q2] : 0.0, rowOn ? f[q2 + 1] : 0.0);
+                st2(&sGp[i * CP + q2], colOn ? g[q2] : 0.0, colOn ? g[q2 + 1] : 0.0);
+            }
+            if (i > k && i < n) {                 // L[i][k+q] for the rows of the pivot block (q < i-k) and all rows below it
+#pragma unroll
+                for (int q = 0; q < C; q++) if (i > k + q) sL[LIX(i, k + q)] = f[q];
+            }
+            if (i == n) {                         // forward-substituted rhs (k + C <= n + C - 1 < M + C: sY has C spare entries)
+#pragma unroll
+                for (int q2 = 0; q2 < C; q2 += 2) st2(&sY[k + q2], g[q2], g[q2 + 1]);
+            }
+            if (i == k) {
+#pragma unroll
+                for (int q2 = 0; q2 < C; q2 += 2) st2(&sD[k + q2], c[q2][q2], c[q2 + 1][q2 + 1]);
             }
         }
         __syncthreads();
         // ---------------- phase 2 (branch free: finished columns have G = 0, finished rows F = 0) ----------------
-        if (GN && k == 8 && (tid & 63) == 0) B.energyLog[27 + (tid >> 6) * 3] = (double) clock64();
-        const int a0 = (k + 4) >> 4, c0 = (k + 4) & 15;
-        double fi[NB][4], gj[NB][4];
+        const int a0 = (k + C) >> 4, c0 = (k + C) & 15;
+        double fi[NB][C], gj[NB][C];
 #pragma unroll
-        for (int a = 0; a < NB; a++) {
-            const double2 f0 = ld2(&sFp[(ty + 16 * a) * 4]), f1 = ld2(&sFp[(ty + 16 * a) * 4 + 2]);
-            const double2 g0 = ld2(&sGp[(tx + 16 * a) * 4]), g1 = ld2(&sGp[(tx + 16 * a) * 4 + 2]);
-            fi[a][0] = f0.x; fi[a][1] = f0.y; fi[a][2] = f1.x; fi[a][3] = f1.y;
-            gj[a][0] = g0.x; gj[a][1] = g0.y; gj[a][2] = g1.x; gj[a][3] = g1.y;
-        }
+        for (int a = 0; a < NB; a++)
+#pragma unroll
+            for (int q2 = 0; q2 < C; q2 += 2) {
+                const double2 f0 = ld2(&sFp[(ty + 16 * a) * CP + q2]), g0 = ld2(&sGp[(tx + 16 * a) * CP + q2]);
+                fi[a][q2] = f0.x; fi[a][q2 + 1] = f0.y; gj[a][q2] = g0.x; gj[a][q2 + 1] = g0.y;
+            }
 #pragma unroll
         for (int a = 0; a < NB; a++)
 #pragma unroll
             for (int b = 0; b <= a; b++) {
                 double w = v[a * (a + 1) / 2 + b];
 #pragma unroll
-                for (int q = 0; q < 4; q++) w = __builtin_fma(-fi[a][q], gj[b][q], w);
+                for (int q = 0; q < C; q++) w = __builtin_fma(-fi[a][q], gj[b][q], w);
                 v[a * (a + 1) / 2 + b] = w;
             }
-        // owners of columns k+4 .. k+7 publish them as the next panel
-        const bool pub = (tx >= c0) && (tx < c0 + 4);
+        // owners of columns k+C .. k+2C-1 publish them as the next panel
+        const bool pub = (tx >= c0) && (tx < c0 + C);
 #pragma unroll
         for (int a = 0; a < NB; a++) {
             double w = v[a * (a + 1) / 2];
 #pragma unroll
             for (int b = 1; b <= a; b++) w = (a0 == b) ? v[a * (a + 1) / 2 + b] : w;
-            if (pub && a >= a0) sPn[(ty + 16 * a) * 4 + (tx - c0)] = w;
+            if (pub && a >= a0) sPn[(ty + 16 * a) * CP + (tx - c0)] = w;
         }
-        if (GN && k == 8 && (tid & 63) == 0) B.energyLog[28 + (tid >> 6) * 3] = (double) clock64();
         __syncthreads();
     }
     if (GN && tid == 0) B.energyLog[42] = (double) wall_clock64();
@@ -661,9 +672,9 @@ static __device__ void solve_core(const BaPtrs &B, const BaDims &D, const ResSet
 
 template <bool GN>
 static __device__ void solve_core_dispatch(const BaPtrs &B, const BaDims &D, const ResSet &S, const ldso_settings_t &St, int iteration, double *sm, SolveIO &io) {
-    if (D.n + 1 <= 64) solve_core<4, GN>(B, D, S, St, iteration, sm, io);
-    else if (D.n + 1 <= 112) solve_core<7, GN>(B, D, S, St, iteration, sm, io);
-    else solve_core<9, GN>(B, D, S, St, iteration, sm, io);
+    if (D.n + 1 <= 64) solve_core<4, 4, GN>(B, D, S, St, iteration, sm, io);
+    else if (D.n + 1 <= 112) solve_core<7, 4, GN>(B, D, S, St, iteration, sm, io);
+    else solve_core<9, 4, GN>(B, D, S, St, iteration, sm, io);
 }
 
 // canbreak of doStepFromBackup (FullSystem.cc:1604-1622); the four sums are accumulated by lane 0 of the four waves.

@@ -1,7 +1,7 @@
 // dependent-issue latencies on gfx950, one wave per SIMD (run on the GPU box)
 #include <hip/hip_runtime.h>
 #include <cstdio>
-__global__ void k(double *o, long long *t, double seed) {
+__global__ __launch_bounds__(256) void k(double *o, long long *t, double seed) {
     __shared__ double sh[1024];
     const int tid = threadIdx.x;
     double x = seed + tid * 1e-9, y = 1.0000001;

@@ -114,6 +114,64 @@ def test_optimize_canbreak_path(small):
     assert abs(rmo - rmg) <= 5 * TOL * rmo
 
 
+def _optimize_compare(win, its=5, tol_e=5 * TOL):
+    o = po.OracleWindow(win); o.set_force_all_iterations(True)
+    g = binding.BA.from_window(win)
+    rmo = o.optimize(its)
+    rmg, n_its = g.optimize(its, force_all=True)
+    assert n_its == its and abs(rmo - rmg) <= tol_e * rmo
+    eo, eg = o.energy_log(), g.get_energy_log()
+    assert len(eo) == len(eg) == its + 2 and rel(eg, eo) < tol_e
+    ro, rg = o.get_residuals(), g.get_residuals()
+    mism = (ro["state_state"] != rg["state_state"]).sum()
+    assert mism <= 2e-3 * len(ro["state_state"])          # a few threshold-borderline residuals may flip after several GN steps
+    fo, fg = o.get_frames(), g.get_frames()
+    assert rel(fg["frames"]["state"], fo["frames"]["state"]) < 5e-3
+    return o, g
+
+
+def test_optimize_mixed_linearized(small):
+    """GN fast path (k_reduce atomics -> k_gn_solve -> fused k_linearize) with linearised residuals (H_L, b_L)."""
+    w2 = po.make_mixed_window(small)
+    _, g = _optimize_compare(w2)
+    a, l = g.get_counts()
+    assert a > 0 and l > 0
+
+
+def test_optimize_with_marginalization_prior(small):
+    """H_M / b_M present: bFinal picks up b_M + H_M delta every iteration (EnergyFunctional.cc:279).  The prior is a
+    synthetic symmetric PSD matrix (both sides get the same one)."""
+    w1 = copy.deepcopy(small)
+    rng = np.random.default_rng(11)
+    n = w1.HM.shape[0]
+    A = rng.standard_normal((n, 6))
+    w1.HM = 2e3 * (A @ A.T)
+    w1.bM = 5.0 * rng.standard_normal(n)
+    _optimize_compare(w1)
+    g = binding.BA.from_window(w1); o = po.OracleWindow(w1)
+    o.collect_active(); g.collect_active(); o.linearize_all(False); g.linearize_all(False)
+    o.apply_res(); g.apply_res(); o.backup_state(); g.backup_state(); o.solve_system(0); g.solve_system(0)
+    so, sg = o.get_system(), g.get_system()
+    assert blockrel(sg["HFinal"], so["HFinal"], 4) < TOL and rel(sg["bFinal"], so["bFinal"]) < TOL
+
+
+def test_optimize_12_frames():
+    """F = 12 > 8: two slot groups per point (NSG = 2), FS = 16, 9x9 Schur tiles, 7x16 padded LDL^T."""
+    win = synth.make_window(F=12, P=500, w=320, h=240, fx=200.0, seed=5)
+    assert win.F == 12
+    o = po.OracleWindow(win); g = binding.BA.from_window(win)
+    o.collect_active(); g.collect_active()
+    Eo, Eg = o.linearize_all(False), g.linearize_all(False)
+    assert abs(Eo - Eg) <= TOL * Eo
+    assert np.array_equal(o.get_residuals(False)["out"]["state_NewState"], g.get_residuals()["out"]["state_NewState"])
+    o.apply_res(); g.apply_res(); o.backup_state(); g.backup_state(); o.solve_system(0); g.solve_system(0)
+    so, sg = o.get_system(), g.get_system()
+    for k in ("HA", "Hsc", "HFinal"):
+        assert blockrel(sg[k], so[k], 4) < TOL, k
+    assert np.linalg.norm(sg["HFinal"] @ sg["x"] - sg["bFinal"]) / np.linalg.norm(sg["bFinal"]) < 1e-8
+    _optimize_compare(win, its=4)
+
+
 @pytest.mark.parametrize("name", ["C3", "C4"])
 def test_full_size_parity_and_properties(name):
     """BASELINE configs at full size: one stage-wise pass against the oracle plus size-independent properties."""
