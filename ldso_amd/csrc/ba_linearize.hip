@@ -110,8 +110,8 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D,
     float *sAdH = smem + FS * (sizeof(DevPair) / 4);                    // [FS][64]
     float *sAdT = sAdH + FS * 64;                                       // [FS][64]
     float *sRed = sAdT + FS * 64;                                       // [LD_WAVES][FS][91] (+ topL [FS][91] when HAS_L)
-    float *sTopL = sRed + LD_WAVES * FS * LD_TOPN;                        // [FS][91] when HAS_L
-    float *sXa = sTopL + (HAS_L ? FS * LD_TOPN : 0);                      // [FS][8] xAd of this host (stepMode)
+    float *sTopL = sRed + LD_WAVES * FS * LD_TOPN;                        // [LD_WAVES][FS][91] when HAS_L: each (wave, slot) cell has ONE writer lane
+    float *sXa = sTopL + (HAS_L ? LD_WAVES * FS * LD_TOPN : 0);                      // [FS][8] xAd of this host (stepMode)
 
     if (gi.enable) {
         // initialise the HFinal / bFinal accumulator of the k_reduce that follows (lower triangle) with H_M and the diagonal
@@ -140,21 +140,37 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D,
     int pi = wave;
     if (pi < np) load_point<NSG, HAS_L, FIX>(nx, B, cur, FS, p0 + pi, s, k, stepMode);
 
-    const float thHost = B.frames[h].frameEnergyTH;
-    for (int i = tid; i < FS * (int) (sizeof(DevPair) / 4); i += blockDim.x) {
-        int t = i / (int) (sizeof(DevPair) / 4), o = i % (int) (sizeof(DevPair) / 4);
-        float v = (t < F) ? ((const float *) &B.pairs[h * F + t])[o] : 0.0f;
-        // the energy threshold of a pair is max(host, target) of the frames' CURRENT thresholds (Residuals.cc:191)
-        if (o == (int) (offsetof(DevPair, thMax) / 4) && t < F) v = fmaxf(thHost, B.frames[t].frameEnergyTH);
-        ((float *) sPair)[i] = v;
+    // ---- staging: all global loads first (one latency level), then the LDS stores --------------------------------
+    {
+        constexpr int PW = (int) (sizeof(DevPair) / 4), TH_OFF = (int) (offsetof(DevPair, thMax) / 4);
+        constexpr int NPB = (LD_MAXF * PW + 64 * LD_WAVES - 1) / (64 * LD_WAVES), NAB = (LD_MAXF * 64) / (64 * LD_WAVES);
+        const float thHost = B.frames[h].frameEnergyTH;
+        float pv[NPB], ahv[NAB], atv[NAB], xav = 0.0f;
+#pragma unroll
+        for (int u = 0; u < NPB; u++) {
+            const int i = tid + u * 64 * LD_WAVES, t = i / PW, o = i % PW;
+            float v = 0.0f;
+            if (i < FS * PW && t < F) {
+                // the energy threshold of a pair is max(host, target) of the frames' CURRENT thresholds (Residuals.cc:191)
+                v = (o == TH_OFF) ? fmaxf(thHost, B.frames[t].frameEnergyTH) : ((const float *) &B.pairs[h * F + t])[o];
+            }
+            pv[u] = v;
+        }
+#pragma unroll
+        for (int u = 0; u < NAB; u++) {
+            const int i = tid + u * 64 * LD_WAVES, t = i >> 6, o = i & 63;
+            const bool in = (i < FS * 64) && (t < F);
+            ahv[u] = in ? B.adHostF[(h + t * F) * 64 + o] : 0.0f;
+            atv[u] = in ? B.adTargetF[(h + t * F) * 64 + o] : 0.0f;
+        }
+        if (stepMode && tid < FS * 8) xav = ((tid >> 3) < F) ? B.xAd[(size_t) (h * F + (tid >> 3)) * 8 + (tid & 7)] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < NPB; u++) { const int i = tid + u * 64 * LD_WAVES; if (i < FS * PW) ((float *) sPair)[i] = pv[u]; }
+#pragma unroll
+        for (int u = 0; u < NAB; u++) { const int i = tid + u * 64 * LD_WAVES; if (i < FS * 64) { sAdH[i] = ahv[u]; sAdT[i] = atv[u]; } }
+        if (stepMode && tid < FS * 8) sXa[tid] = xav;
     }
-    if (stepMode) for (int i = tid; i < FS * 8; i += blockDim.x) sXa[i] = ((i >> 3) < F) ? B.xAd[(size_t) (h * F + (i >> 3)) * 8 + (i & 7)] : 0.0f;
-    for (int i = tid; i < FS * 64; i += blockDim.x) {
-        int t = i >> 6, o = i & 63;
-        sAdH[i] = (t < F) ? B.adHostF[(h + t * F) * 64 + o] : 0.0f;
-        sAdT[i] = (t < F) ? B.adTargetF[(h + t * F) * 64 + o] : 0.0f;
-    }
-    if (HAS_L) for (int i = tid; i < FS * LD_TOPN; i += blockDim.x) sTopL[i] = 0.0f;
+    if (HAS_L) for (int i = tid; i < LD_WAVES * FS * LD_TOPN; i += blockDim.x) sTopL[i] = 0.0f;
     __syncthreads();
     LSTAMP(1);
 
@@ -411,20 +427,20 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D,
 #pragma unroll
                     for (int i = 0; i < 6; i++) { lx[4 + i] = J.Jpdxi[0][i]; ly[4 + i] = J.Jpdxi[1][i]; }
                     if (k == 0) {
-                        float *dst = sTopL + t * LD_TOPN;
+                        float *dst = sTopL + (wave * FS + t) * LD_TOPN;      // plain read-modify-write: deterministic, no atomics
 #pragma unroll
                         for (int r = 0; r < 10; r++)
 #pragma unroll
                             for (int cc = r; cc < 10; cc++)
-                                atomicAdd(&dst[tri13(r, cc)], a * lx[cc] * lx[r] + c * ly[cc] * ly[r] + b * (lx[cc] * ly[r] + ly[cc] * lx[r]));
+                                dst[tri13(r, cc)] += a * lx[cc] * lx[r] + c * ly[cc] * ly[r] + b * (lx[cc] * ly[r] + ly[cc] * lx[r]);
 #pragma unroll
                         for (int r = 0; r < 10; r++) {
-                            atomicAdd(&dst[tri13(r, 10)], lx[r] * J.JabJIdx[0] + ly[r] * J.JabJIdx[1]);
-                            atomicAdd(&dst[tri13(r, 11)], lx[r] * J.JabJIdx[2] + ly[r] * J.JabJIdx[3]);
-                            atomicAdd(&dst[tri13(r, 12)], lx[r] * lJI_r0 + ly[r] * lJI_r1);
+                            dst[tri13(r, 10)] += lx[r] * J.JabJIdx[0] + ly[r] * J.JabJIdx[1];
+                            dst[tri13(r, 11)] += lx[r] * J.JabJIdx[2] + ly[r] * J.JabJIdx[3];
+                            dst[tri13(r, 12)] += lx[r] * lJI_r0 + ly[r] * lJI_r1;
                         }
-                        atomicAdd(&dst[tri13(10, 10)], J.Jab2[0]); atomicAdd(&dst[tri13(10, 11)], J.Jab2[1]); atomicAdd(&dst[tri13(10, 12)], lJab_r0);
-                        atomicAdd(&dst[tri13(11, 11)], J.Jab2[3]); atomicAdd(&dst[tri13(11, 12)], lJab_r1); atomicAdd(&dst[tri13(12, 12)], lrr);
+                        dst[tri13(10, 10)] += J.Jab2[0]; dst[tri13(10, 11)] += J.Jab2[1]; dst[tri13(10, 12)] += lJab_r0;
+                        dst[tri13(11, 11)] += J.Jab2[3]; dst[tri13(11, 12)] += lJab_r1; dst[tri13(12, 12)] += lrr;
                         nresL++;
                     }
                     float lJi0 = a * J.Jpdd[0] + b * J.Jpdd[1], lJi1 = b * J.Jpdd[0] + c * J.Jpdd[1];
@@ -542,7 +558,12 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D,
 #pragma unroll
         for (int wv = 0; wv < LD_WAVES; wv++) a += sRed[wv * FS * LD_TOPN + i];
         nxt.topA[(size_t) chunk * FS * LD_TOPN + i] = a;
-        if (HAS_L) nxt.topL[(size_t) chunk * FS * LD_TOPN + i] = sTopL[i];
+        if (HAS_L) {
+            float l = 0;
+#pragma unroll
+            for (int wv = 0; wv < LD_WAVES; wv++) l += sTopL[wv * FS * LD_TOPN + i];
+            nxt.topL[(size_t) chunk * FS * LD_TOPN + i] = l;
+        }
     }
     // energy / counters: wave reduce then LDS
     __syncthreads();
@@ -571,7 +592,7 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D,
 // launcher
 // ---------------------------------------------------------------------------------------------------------
 size_t ba_linearize_lds_bytes(int FS, bool hasL) {
-    size_t fl = (size_t) FS * (sizeof(DevPair) / 4) + 2 * (size_t) FS * 64 + (size_t) LD_WAVES * FS * LD_TOPN + (hasL ? (size_t) FS * LD_TOPN : 0) + (size_t) FS * 8;
+    size_t fl = (size_t) FS * (sizeof(DevPair) / 4) + 2 * (size_t) FS * 64 + (size_t) LD_WAVES * FS * LD_TOPN + (hasL ? (size_t) LD_WAVES * FS * LD_TOPN : 0) + (size_t) FS * 8;
     return fl * sizeof(float) + 256;
 }
 

@@ -252,14 +252,41 @@ static __device__ void set_adjoints(const BaPtrs &B, const BaDims &D, const ldso
     __syncthreads();
 }
 
+// canbreak of doStepFromBackup (FullSystem.cc:1604-1622) in two parts so that it can overlap setPrecalcValues: the four
+// sums are accumulated by lanes of waves 1..3 (wave 0 is busy with the frame exponentials), the decision is taken by one
+// thread after the next block barrier.
+static __device__ __forceinline__ void canbreak_partial(const DevFrame *fr, int F, float *sF /*4 floats of LDS*/) {
+    const int tid = threadIdx.x;
+    const int which = (tid == 64) ? 0 : (tid == 65) ? 1 : (tid == 128) ? 2 : (tid == 192) ? 3 : -1;
+    if (which < 0) return;
+    float acc = 0;
+    for (int f = 0; f < F; f++) {
+        const double *s = fr[f].step;
+        if (which == 0) acc += s[6] * s[6];
+        else if (which == 1) acc += s[7] * s[7];
+        else if (which == 2) acc += s[0] * s[0] + s[1] * s[1] + s[2] * s[2];
+        else acc += s[3] * s[3] + s[4] * s[4] + s[5] * s[5];
+    }
+    acc /= F;
+    sF[which] = acc;
+}
+static __device__ __forceinline__ void canbreak_final(const BaPtrs &B, const ldso_settings_t &St, const float *sF, float sumNID) {
+    const float sumA = sF[0], sumB = sF[1], sumT = sF[2], sumR = sF[3];
+    bool cb = sqrtf(sumA) < 0.0005 * St.thOptIterations && sqrtf(sumB) < 0.00005 * St.thOptIterations &&
+              sqrtf(sumR) < 0.00005 * St.thOptIterations && sqrtf(sumT) * sumNID < 0.00005 * St.thOptIterations;
+    B.scalars[3] = cb ? 1.0 : 0.0;
+}
+
 // setPrecalcValues: frames' PRE poses, pair precalc, deltas
 // fr / cal: working copies of the frames and the calibration (global memory, or the LDS mirror of k_gn_solve)
 // FULL = false (inside a GN iteration): the linearisation-point part of a pair (R0, t0, b0: functions of evalPT and
 // state_zero only) is left untouched.
 template <bool FULL>
-static __device__ void set_precalc(const BaPtrs &B, const BaDims &D, DevFrame *fr, DevCalib *cal, const float *adH, const float *adT) {
+static __device__ void set_precalc(const BaPtrs &B, const BaDims &D, DevFrame *fr, DevCalib *cal, const float *adH, const float *adT,
+                                   const ldso_settings_t *cbSt = nullptr, float *cbF = nullptr, float cbNID = 0.0f) {
     const int tid = threadIdx.x, F = D.F;
     DevCalib &C = *cal;
+    if (cbF != nullptr) canbreak_partial(fr, F, cbF);
     if (tid < F) {
         DevFrame &f = fr[tid];
         double ss[6] = {0.5 * f.state[0], 0.5 * f.state[1], 0.5 * f.state[2], 1.0 * f.state[3], 1.0 * f.state[4], 1.0 * f.state[5]};
@@ -277,6 +304,7 @@ static __device__ void set_precalc(const BaPtrs &B, const BaDims &D, DevFrame *f
         for (int i = 0; i < 4; i++) C.cDeltaF[i] = (float) (C.value[i] - C.value_zero[i]);
     }
     __syncthreads();
+    if (cbF != nullptr && tid == 192) canbreak_final(B, *cbSt, cbF, cbNID);
     for (int i = tid; i < F * F; i += NT) {
         const int h = i / F, t = i % F;
         const DevFrame &fh = fr[h], &ft = fr[t];
@@ -677,32 +705,6 @@ static __device__ void solve_core_dispatch(const BaPtrs &B, const BaDims &D, con
     else solve_core<9, 4, GN>(B, D, S, St, iteration, sm, io);
 }
 
-// canbreak of doStepFromBackup (FullSystem.cc:1604-1622); the four sums are accumulated by lane 0 of the four waves.
-// Contains a block barrier: call from uniform control flow.
-static __device__ void step_canbreak(const BaPtrs &B, const ldso_settings_t &St, const DevFrame *fr, int F, float sumNID, double *sRed /*>= 16 doubles*/) {
-    const int tid = threadIdx.x, w = tid >> 6;
-    float *sF = (float *) (sRed + 8);
-    if ((tid & 63) == 0) {
-        float acc = 0;
-        for (int f = 0; f < F; f++) {
-            const double *s = fr[f].step;
-            if (w == 0) acc += s[6] * s[6];
-            else if (w == 1) acc += s[7] * s[7];
-            else if (w == 2) acc += s[0] * s[0] + s[1] * s[1] + s[2] * s[2];
-            else acc += s[3] * s[3] + s[4] * s[4] + s[5] * s[5];
-        }
-        acc /= F;
-        sF[w] = acc;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        const float sumA = sF[0], sumB = sF[1], sumT = sF[2], sumR = sF[3];
-        bool cb = sqrtf(sumA) < 0.0005 * St.thOptIterations && sqrtf(sumB) < 0.00005 * St.thOptIterations &&
-                  sqrtf(sumR) < 0.00005 * St.thOptIterations && sqrtf(sumT) * sumNID < 0.00005 * St.thOptIterations;
-        B.scalars[3] = cb ? 1.0 : 0.0;
-    }
-}
-
 // frame / calibration part of backupState, doStepFromBackup (+ canbreak), loadSateBackup on the working copies
 static __device__ void frames_backup(DevFrame *fr, DevCalib *cal, int F) {
     const int tid = threadIdx.x;
@@ -714,7 +716,9 @@ static __device__ void frames_step(const BaPtrs &B, const ldso_settings_t &St, D
     const int tid = threadIdx.x;
     if (tid < F) for (int i = 0; i < 10; i++) fr[tid].state[i] = fr[tid].state_backup[i] + fr[tid].step[i];
     if (tid == 0) for (int i = 0; i < 4; i++) cal->value[i] = cal->value_backup[i] + cal->step[i] * (double) 1.0f;
-    step_canbreak(B, St, fr, F, sumNID, sRed);
+    canbreak_partial(fr, F, (float *) (sRed + 8));
+    __syncthreads();
+    if (tid == 0) canbreak_final(B, St, (const float *) (sRed + 8), sumNID);
     __syncthreads();
 }
 
@@ -820,9 +824,8 @@ __global__ __launch_bounds__(NT) void k_gn_solve(BaPtrs B, BaDims D, ResSet S, l
     io.ldsAd = (F <= 8) ? (float *) (sCal + 1) : nullptr;
     solve_core_dispatch<true>(B, D, S, St, A.iteration, sm, io);      // + mirrors, backupState, doStepFromBackup
     GSTAMP(4);
-    step_canbreak(B, St, sFr, F, io.sumNID, sW);
     GSTAMP(5);
-    set_precalc<false>(B, D, sFr, sCal, io.adH, io.adT);
+    set_precalc<false>(B, D, sFr, sCal, io.adH, io.adT, &St, (float *) (sW + 8), io.sumNID);      // + canbreak of doStepFromBackup
     GSTAMP(6);
     // write the mirrors back (all but frameEnergyTH, which block 1 owns)
     {

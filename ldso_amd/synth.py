@@ -482,6 +482,17 @@ CONFIGS = {
 }
 
 
+def add_synthetic_prior(win: Window, seed: int = 11, rank: int = 6, scale: float = 2e3, b_scale: float = 5.0) -> Window:
+    """Give the window a marginalisation prior (H_M symmetric PSD of the given rank, b_M), as every steady-state LDSO window
+    has one (EnergyFunctional::marginalizeFrame).  Synthetic: it only has to be the same on both sides of a comparison."""
+    rng = np.random.default_rng(seed)
+    n = win.HM.shape[0]
+    A = rng.standard_normal((n, rank))
+    win.HM = scale * (A @ A.T)
+    win.bM = b_scale * rng.standard_normal(n)
+    return win
+
+
 def make_config(name: str, **over) -> Window:
     kw = dict(CONFIGS[name])
     kw.update(over)
