@@ -12,6 +12,8 @@ SOURCES = ["ba_linearize.hip", "ba_reduce.hip", "ba_solve.hip", "ba_api.hip", "t
 # -ffp-contract=off: elementwise arithmetic is IEEE and follows the reference's operation order (bit-identical
 # energies / residual states); fused multiply-adds are spelled explicitly where they are wanted.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result"]
+if os.environ.get("LDSO_STAMPS"):          # device-side phase stamps for scripts/dbg_gn.py (debug builds only, see ba_dev.h)
+    FLAGS.append("-DLDSO_STAMPS")
 
 
 def needs_build() -> bool:

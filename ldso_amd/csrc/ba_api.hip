@@ -13,7 +13,7 @@
 #include "lie_dev.h"
 
 hipError_t ba_launch_linearize(const BaPtrs &B, const BaDims &D, const ResSet &cur, const ResSet &nxt, const ldso_settings_t &S, bool hasL, bool fix, int stepMode, const GnInit &gi, hipStream_t st);
-hipError_t ba_launch_reduce(const BaPtrs &B, const BaDims &D, const ResSet &S, const int32_t *chunkStart, bool hasL, int GSP, bool atomicMode, bool hasPrior, float calibPrior, double l1, double il, hipStream_t st);
+hipError_t ba_launch_reduce(const BaPtrs &B, const BaDims &D, const ResSet &S, const ChunkStarts &chunkStart, bool hasL, int GSP, bool atomicMode, bool hasPrior, float calibPrior, double l1, double il, hipStream_t st);
 hipError_t ba_launch_gather(const BaPtrs &B, const BaDims &D, const ResSet &S, bool hasL, bool hasPrior, int GSP, double lambda,
                             const ldso_settings_t &St, int mode, double *rbuf, hipStream_t st);
 hipError_t ba_launch_solve(const BaPtrs &B, const BaDims &D, const ResSet &S, const ldso_settings_t &St, const SolveArgs &A, hipStream_t st);
@@ -45,6 +45,7 @@ struct ldso_ba {
     float *imgSlots[LD_MAXF] = {nullptr};
     bool imgOwned[LD_MAXF] = {false};
     int32_t *d_chunkStart = nullptr;
+    ChunkStarts chunkStarts;
     ldso_rawjac_t *d_dumpJ = nullptr;
     std::vector<int32_t> flat2slot;
     std::vector<int32_t> imageSlot;
@@ -261,6 +262,7 @@ static int build_chunks(ldso_ba *H) {
     REQ((int) p0.size() <= H->maxChunks, "too many chunks");
     D.nChunks = (int) p0.size();
     H2D(H->B.chunk_p0, p0); H2D(H->B.chunk_n, cn); H2D(H->B.chunk_host, ch); H2D(H->d_chunkStart, cs);
+    for (int i = 0; i <= LD_MAXF; i++) H->chunkStarts.v[i] = (i <= D.F) ? cs[i] : cs[D.F];
     CHK(hipStreamSynchronize(H->stream));
     return LDSO_OK;
 }
@@ -430,7 +432,7 @@ static int launch_reduce(ldso_ba *H, const ResSet &S, bool atomicMode = false, d
     if (H->settings.solverMode & LDSO_SOLVER_USE_GN) lambda = 0;
     if (H->settings.solverMode & LDSO_SOLVER_FIX_LAMBDA) lambda = 1e-5;
     const double l1 = 1 + lambda, il = (double) (1.0f / (1 + lambda));
-    CHK(ba_launch_reduce(H->B, H->D, S, H->d_chunkStart, H->hasL, H->GSP, atomicMode, H->hasPrior, H->settings.initialCalibHessian, l1, il, H->stream));
+    CHK(ba_launch_reduce(H->B, H->D, S, H->chunkStarts, H->hasL, H->GSP, atomicMode, H->hasPrior, H->settings.initialCalibHessian, l1, il, H->stream));
     t_end(H);
     return LDSO_OK;
 }

@@ -107,11 +107,24 @@ struct BaPtrs {
     ldso_rawjac_t *dumpJ;   // optional [R]
 };
 
+// first chunk of every host frame (chunks are host-major), passed to k_reduce by value: one load level less than a device array
+struct ChunkStarts {
+    int32_t v[LD_MAXF + 1];
+};
+
 // GN fast path: what k_linearize needs to initialise B.acc for the solve that follows it
 struct GnInit {
     int enable, hasPrior;
     float calibPrior;
 };
+
+// Device-side phase stamps (scripts/dbg_gn.py): build with -DLDSO_STAMPS; they use energyLog[8..60] and therefore corrupt the
+// energy log of optimize() runs with more than 6 iterations - never enable them in a product build.
+#ifdef LDSO_STAMPS
+#define LD_STAMP_ON 1
+#else
+#define LD_STAMP_ON 0
+#endif
 
 #define LD_PAIRC 296        // doubles per pair contribution: hh 64, tt 64, ht 64, hc 32, tc 32, cc 16, bh 8, bt 8, bc 4 (=292, padded)
 #define LD_SC_SPLITS 16

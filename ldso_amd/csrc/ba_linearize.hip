@@ -102,7 +102,7 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D,
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, s = lane >> 3, k = lane & 7;
     const int chunk = blockIdx.x;
     const long long t0_ = wall_clock64();
-#define LSTAMP(i) do { if (blockIdx.x == 0 && tid == 0) B.energyLog[8 + (i)] = (double) (wall_clock64() - t0_); } while (0)
+#define LSTAMP(i) do { if (LD_STAMP_ON && blockIdx.x == 0 && tid == 0) B.energyLog[8 + (i)] = (double) (wall_clock64() - t0_); } while (0)
     const int p0 = B.chunk_p0[chunk], np = B.chunk_n[chunk], h = B.chunk_host[chunk];
 
     // ---- LDS carve: pair structs of this host, float adjoints of this host, reduction scratch --------
@@ -552,7 +552,18 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D,
             float a = sum8(accA[g][i]);
             if (k == 0) sRed[(wave * FS + g * 8 + s) * LD_TOPN + i] = a;
         }
+    // energy / counters: wave reduce, then LDS (own cells: no second barrier)
+    double *sE = (double *) (sXa + FS * 8);
+    int *sC = (int *) (sE + LD_WAVES);
+    float *sN = (float *) (sC + 4 * LD_WAVES);
+    {
+        double e = energySum;
+        int na = nresA, nl = nresL;
+        for (int o = 32; o > 0; o >>= 1) { double e2 = __shfl_xor(e, o, 64); int a2 = __shfl_xor(na, o, 64), l2 = __shfl_xor(nl, o, 64); e += e2; na += a2; nl += l2; }
+        if (lane == 0) { sE[wave] = e; sC[wave * 4 + 0] = na; sC[wave * 4 + 1] = nl; sC[wave * 4 + 2] = nidCnt; sN[wave] = nidSum; }
+    }
     __syncthreads();
+    LSTAMP(7);
     for (int i = tid; i < FS * LD_TOPN; i += blockDim.x) {
         float a = 0;
 #pragma unroll
@@ -565,20 +576,6 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D,
             nxt.topL[(size_t) chunk * FS * LD_TOPN + i] = l;
         }
     }
-    // energy / counters: wave reduce then LDS
-    __syncthreads();
-    double *sE = (double *) sRed;
-    int *sC = (int *) (sE + LD_WAVES);
-    float *sN = (float *) (sC + 4 * LD_WAVES);
-    {
-        double e = energySum;
-        for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o, 64);
-        int na = nresA, nl = nresL;
-        for (int o = 32; o > 0; o >>= 1) { na += __shfl_xor(na, o, 64); nl += __shfl_xor(nl, o, 64); }
-        if (lane == 0) { sE[wave] = e; sC[wave * 4 + 0] = na; sC[wave * 4 + 1] = nl; sC[wave * 4 + 2] = nidCnt; sN[wave] = nidSum; }
-    }
-    __syncthreads();
-    LSTAMP(7);
     if (tid == 0) {
         double e = 0; int na = 0, nl = 0, nc = 0; float ns = 0;
         for (int wv = 0; wv < LD_WAVES; wv++) { e += sE[wv]; na += sC[wv * 4 + 0]; nl += sC[wv * 4 + 1]; nc += sC[wv * 4 + 2]; ns += sN[wv]; }
@@ -592,7 +589,7 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D,
 // launcher
 // ---------------------------------------------------------------------------------------------------------
 size_t ba_linearize_lds_bytes(int FS, bool hasL) {
-    size_t fl = (size_t) FS * (sizeof(DevPair) / 4) + 2 * (size_t) FS * 64 + (size_t) LD_WAVES * FS * LD_TOPN + (hasL ? (size_t) LD_WAVES * FS * LD_TOPN : 0) + (size_t) FS * 8;
+    size_t fl = (size_t) FS * (sizeof(DevPair) / 4) + 2 * (size_t) FS * 64 + (size_t) LD_WAVES * FS * LD_TOPN + (hasL ? (size_t) LD_WAVES * FS * LD_TOPN : 0) + (size_t) FS * 8 + 64;
     return fl * sizeof(float) + 256;
 }
 

@@ -31,7 +31,7 @@ static __device__ __forceinline__ void acc_add(double *p, double v) { __hip_atom
 
 template <int NT, int W> static __device__ __forceinline__ void schur_wave(const float *sG, int GSP, int cnt, int wcol, int li, int lk, f32x4 *acc);
 
-__global__ __launch_bounds__(256) void k_reduce(BaPtrs B, BaDims D, ResSet S, const int32_t *__restrict__ chunkStart, int hasL, int GSP, int atomicMode,
+__global__ __launch_bounds__(256) void k_reduce(BaPtrs B, BaDims D, ResSet S, ChunkStarts chunkStart, int hasL, int GSP, int atomicMode,
                                                 int hasPrior, float calibPrior, double l1, double il) {
     const int F = D.F, FS = D.FS;
     const int nPairBlocks = F * F * (hasL ? 2 : 1);
@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void k_reduce(BaPtrs B, BaDims D, ResSet S, co
     __shared__ double sA[13 * 13];
     __shared__ double sT[2][64];
     const long long t0_ = wall_clock64();
-#define RSTAMP(i) do { if (tid == 0) B.energyLog[(i)] = (double) (wall_clock64() - t0_); } while (0)
+#define RSTAMP(i) do { if (LD_STAMP_ON && tid == 0) B.energyLog[(i)] = (double) (wall_clock64() - t0_); } while (0)
 
     if ((int) blockIdx.x < nPairBlocks) {
         // ------------------------------- Part A ---------------------------------------------------------
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void k_reduce(BaPtrs B, BaDims D, ResSet S, co
         const int pair = blockIdx.x % (F * F);
         const int h = pair / F, t = pair % F;        // pairC index [h*F + t]
         const float *part = which ? S.topL : S.topA;
-        const int c0 = chunkStart[h], c1 = chunkStart[h + 1];
+        const int c0 = chunkStart.v[h], c1 = chunkStart.v[h + 1];
         // adjoints of this pair -> LDS (issued together with the partial loads: one latency level)
         __shared__ double sAH[64], sAT[64];
         __shared__ double sPart[PA_SLICES][LD_TOPN];
@@ -460,7 +460,7 @@ hipError_t ba_launch_gather(const BaPtrs &B, const BaDims &D, const ResSet &S, b
     return hipGetLastError();
 }
 
-hipError_t ba_launch_reduce(const BaPtrs &B, const BaDims &D, const ResSet &S, const int32_t *chunkStart, bool hasL, int GSP, bool atomicMode, bool hasPrior,
+hipError_t ba_launch_reduce(const BaPtrs &B, const BaDims &D, const ResSet &S, const ChunkStarts &chunkStart, bool hasL, int GSP, bool atomicMode, bool hasPrior,
                             float calibPrior, double l1, double il, hipStream_t st) {
     const int nT = GSP / 16;
     int nb = D.F * D.F * (hasL ? 2 : 1) + (atomicMode ? SCT_KS * nT * (nT + 1) / 2 + 1 : LD_SC_SPLITS);

@@ -399,8 +399,6 @@ static __device__ __forceinline__ double fast_rsqrt(double d) {
     double e = __builtin_fma(-(d * r), r, 1.0);
     return __builtin_fma(0.5 * r, e, r);
 }
-static __device__ __forceinline__ long long tick() { long long t; asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); return t; }
-#define PSTAMP(j) do { if (GN && k == 8 && tid == 0) B.energyLog[26 + (j)] = (double) tick(); } while (0)
 static __device__ __forceinline__ double2 ld2(const double *p) { return *(const double2 *) p; }
 static __device__ __forceinline__ void st2(double *p, double a, double b) { *(double2 *) p = make_double2(a, b); }
 
@@ -529,7 +527,7 @@ static __device__ void solve_core(const BaPtrs &B, const BaDims &D, const ResSet
         for (int a = 0; a < NB; a++) sPn[(ty + 16 * a) * CP + tx] = v[a * (a + 1) / 2];
     }
     __syncthreads();
-    if (GN && tid == 0) B.energyLog[41] = (double) wall_clock64();
+    if (LD_STAMP_ON && GN && tid == 0) B.energyLog[41] = (double) wall_clock64();
     if (GN) io.sumNID = (float) (io.sRed[0] + io.sRed[1] + io.sRed[2] + io.sRed[3]) / (float) (io.sRed[4] + io.sRed[5] + io.sRed[6] + io.sRed[7]);
 
 #pragma nounroll
@@ -620,7 +618,7 @@ static __device__ void solve_core(const BaPtrs &B, const BaDims &D, const ResSet
         }
         __syncthreads();
     }
-    if (GN && tid == 0) B.energyLog[42] = (double) wall_clock64();
+    if (LD_STAMP_ON && GN && tid == 0) B.energyLog[42] = (double) wall_clock64();
 
     // ---------------- back substitution by wave 0: x = L^-T D^+ y ----------------
     if (tid < 64) {
@@ -665,7 +663,7 @@ static __device__ void solve_core(const BaPtrs &B, const BaDims &D, const ResSet
         }
     }
     __syncthreads();
-    if (GN && tid == 0) B.energyLog[43] = (double) wall_clock64();
+    if (LD_STAMP_ON && GN && tid == 0) B.energyLog[43] = (double) wall_clock64();
     // ---------------- outputs: x, steps, xAd ----------------
     DevFrame *fr = io.fr;
     bool bad = false;
@@ -803,7 +801,7 @@ __global__ __launch_bounds__(NT) void k_gn_solve(BaPtrs B, BaDims D, ResSet S, l
     const int NBsel = (n + 1 <= 64) ? 4 : (n + 1 <= 112) ? 7 : 9;
     double *sW = sm + solve_core_lds_doubles(NBsel, n);      // 64 doubles of scratch
     const long long t0_ = wall_clock64();
-#define GSTAMP(i) do { if (tid == 0) B.energyLog[40 + (i)] = (double) (wall_clock64() - t0_); } while (0)
+#define GSTAMP(i) do { if (LD_STAMP_ON && tid == 0) B.energyLog[40 + (i)] = (double) (wall_clock64() - t0_); } while (0)
     if (blockIdx.x == 1) {
         int *sHist = (int *) (sW + 64);
         int *sI = sHist + 256;
@@ -818,7 +816,7 @@ __global__ __launch_bounds__(NT) void k_gn_solve(BaPtrs B, BaDims D, ResSet S, l
     }
     DevFrame *sFr = (DevFrame *) (sW + 64);
     DevCalib *sCal = (DevCalib *) (sFr + F);
-    if (tid == 0) B.energyLog[39] = (double) t0_;
+    if (LD_STAMP_ON && tid == 0) B.energyLog[39] = (double) t0_;
     SolveIO io;
     io.fr = sFr; io.cal = sCal; io.adH = B.adHostF; io.adT = B.adTargetF; io.sRed = sW; io.sumNID = 0; io.lambda = A.lambda; io.hasPrior = A.hasPrior;
     io.ldsAd = (F <= 8) ? (float *) (sCal + 1) : nullptr;
