@@ -23,7 +23,7 @@ void ldso_set_error(const std::string &s);
 #define CHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { ldso_set_error(std::string(#call) + ": " + hipGetErrorString(e_)); return LDSO_E_HIP; } } while (0)
 #define REQ(cond, msg) do { if (!(cond)) { ldso_set_error(msg); return LDSO_E_INVALID; } } while (0)
 
-#define TR_NT 1024
+#define TR_NT 512          // one workgroup per hypothesis; 512 threads -> 256 VGPRs per lane (no spills in tr_eval)
 #define TR_MAXL LDSO_PYR_LEVELS
 
 struct TrLevel {
@@ -52,6 +52,7 @@ struct TrHyp {                 // one motion hypothesis in / result out
     double lastResiduals[5];
     double flow[3];
     int ok, iterations;
+    double dbg[12];             // LDSO_STAMPS builds: time in tr_eval / serial LM sections / evals count
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -159,7 +160,18 @@ __global__ void k_tr_write(TrLevel L) {
 //   [0] E  [1] numTermsInE  [2] sumSquaredShiftT  [3] sumSquaredShiftRT  [4] sumSquaredShiftNum  [5] numSaturated
 //   [6] numTermsInWarped   [7..51] 45 upper-triangular entries of sum w J J^T (9x9)
 // ---------------------------------------------------------------------------------------------------------
+#ifdef LDSO_STAMPS
+#define LD_STAMP_ON_TR 1
+#else
+#define LD_STAMP_ON_TR 0
+#endif
 #define TR_NACC 52
+#define TR_U 4            // points per thread and pass of tr_eval
+
+template <int CTRL> __device__ __forceinline__ float tr_dpp(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float tr_readlane(float x, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l)); }
 
 __device__ __forceinline__ void aff_from_to_f(float expF, float expT, float aF, float bF, float aT, float bT, float &a, float &b) {
     if (expF == 0 || expT == 0) { expT = expF = 1; }
@@ -186,90 +198,124 @@ __device__ void tr_eval(const TrParams &P, int lvl, const double *T, float aff_a
 #pragma unroll
     for (int q = 0; q < TR_NACC; q++) acc[q] = 0.f;
 
-    for (int i = i0 + tid; i < L.n; i += istride) {
-        float id = L.pc_idepth[i], x = L.pc_u[i], y = L.pc_v[i];
-        float p0 = ((RKi[0] * x + RKi[1] * y) + RKi[2] * 1.0f) + t[0] * id;
-        float p1 = ((RKi[3] * x + RKi[4] * y) + RKi[5] * 1.0f) + t[1] * id;
-        float p2 = ((RKi[6] * x + RKi[7] * y) + RKi[8] * 1.0f) + t[2] * id;
-        float u = p0 / p2, v = p1 / p2;
-        float Ku = fxl * u + cxl, Kv = fyl * v + cyl;
-        float new_idepth = id / p2;
-        if (lvl == 0 && i % 32 == 0) {
-            const float *Ki = L.Ki;
-            float k0 = (Ki[0] * x + Ki[1] * y) + Ki[2] * 1.0f, k1 = (Ki[3] * x + Ki[4] * y) + Ki[5] * 1.0f, k2 = (Ki[6] * x + Ki[7] * y) + Ki[8] * 1.0f;
-            float a0 = k0 + t[0] * id, a1 = k1 + t[1] * id, a2 = k2 + t[2] * id;
-            float KuT = fxl * (a0 / a2) + cxl, KvT = fyl * (a1 / a2) + cyl;
-            float c0 = k0 - t[0] * id, c1 = k1 - t[1] * id, c2 = k2 - t[2] * id;
-            float KuT2 = fxl * (c0 / c2) + cxl, KvT2 = fyl * (c1 / c2) + cyl;
-            float r0 = (((RKi[0] * x + RKi[1] * y) + RKi[2] * 1.0f)) - t[0] * id, r1 = (((RKi[3] * x + RKi[4] * y) + RKi[5] * 1.0f)) - t[1] * id,
-                  r2 = (((RKi[6] * x + RKi[7] * y) + RKi[8] * 1.0f)) - t[2] * id;
-            float Ku3 = fxl * (r0 / r2) + cxl, Kv3 = fyl * (r1 / r2) + cyl;
-            acc[2] += (KuT - x) * (KuT - x) + (KvT - y) * (KvT - y);
-            acc[2] += (KuT2 - x) * (KuT2 - x) + (KvT2 - y) * (KvT2 - y);
-            acc[3] += (Ku - x) * (Ku - x) + (Kv - y) * (Kv - y);
-            acc[3] += (Ku3 - x) * (Ku3 - x) + (Kv3 - y) * (Kv3 - y);
-            acc[4] += 2;
+    // TR_U points per thread and pass: all point-cloud loads of a pass are issued together, then all 12-float tap gathers,
+    // so a pass costs two memory latencies instead of 2 x TR_U (a single workgroup runs the whole level).
+    for (int ib = i0 + tid; ib < L.n; ib += istride * TR_U) {
+        float id[TR_U], x[TR_U], y[TR_U], col[TR_U];
+        bool in[TR_U];
+#pragma unroll
+        for (int u_ = 0; u_ < TR_U; u_++) {
+            const int i = ib + u_ * istride;
+            in[u_] = i < L.n;
+            const int ic = in[u_] ? i : 0;
+            id[u_] = L.pc_idepth[ic]; x[u_] = L.pc_u[ic]; y[u_] = L.pc_v[ic]; col[u_] = L.pc_color[ic];
         }
-        if (!(Ku > 2 && Kv > 2 && Ku < wl - 3 && Kv < hl - 3 && new_idepth > 0)) continue;
-        float refColor = L.pc_color[i];
-        int ix = (int) Ku, iy = (int) Kv;
-        float dx = Ku - ix, dy = Kv - iy, dxdy = dx * dy;
-        const float *bp = L.newImg + 3 * (ix + iy * wl);
-        const float *bq = bp + 3 * wl;
-        float w11 = dxdy, w01 = dy - dxdy, w10 = dx - dxdy, w00 = 1 - dx - dy + dxdy;
-        float h0 = ((w11 * bq[3] + w01 * bq[0]) + w10 * bp[3]) + w00 * bp[0];
-        float h1 = ((w11 * bq[4] + w01 * bq[1]) + w10 * bp[4]) + w00 * bp[1];
-        float h2 = ((w11 * bq[5] + w01 * bq[2]) + w10 * bp[5]) + w00 * bp[2];
-        if (!isfinite(h0)) continue;
-        float residual = h0 - (float) (affA * refColor + affB);
-        float hw = fabsf(residual) < P.huberTH ? 1 : P.huberTH / fabsf(residual);
-        if (fabsf(residual) > cutoffTH) {
-            acc[0] += maxEnergy; acc[1] += 1; acc[5] += 1;
-        } else {
-            acc[0] += hw * residual * residual * (2 - hw); acc[1] += 1; acc[6] += 1;
-            // calcGSSSE row (CoarseTracker.cc:592-615)
-            float ddx = h1 * fxl, ddy = h2 * fyl;
-            float J[9];
-            J[0] = new_idepth * ddx;
-            J[1] = new_idepth * ddy;
-            J[2] = 0 - new_idepth * (u * ddx + v * ddy);
-            J[3] = 0 - ((u * v) * ddx + ddy * (1 + v * v));
-            J[4] = (u * v) * ddy + ddx * (1 + u * u);
-            J[5] = u * ddy - v * ddx;
-            J[6] = affA * (b0 - refColor);
-            J[7] = -1;
-            J[8] = residual;
-            int q = 7;
+        float uu[TR_U], vv[TR_U], Ku[TR_U], Kv[TR_U], nid[TR_U], tap[TR_U][12];
+        bool ok[TR_U];
 #pragma unroll
-            for (int r = 0; r < 9; r++) {
-                float jw = J[r] * hw;
+        for (int u_ = 0; u_ < TR_U; u_++) {
+            float p0 = ((RKi[0] * x[u_] + RKi[1] * y[u_]) + RKi[2] * 1.0f) + t[0] * id[u_];
+            float p1 = ((RKi[3] * x[u_] + RKi[4] * y[u_]) + RKi[5] * 1.0f) + t[1] * id[u_];
+            float p2 = ((RKi[6] * x[u_] + RKi[7] * y[u_]) + RKi[8] * 1.0f) + t[2] * id[u_];
+            uu[u_] = p0 / p2; vv[u_] = p1 / p2;
+            Ku[u_] = fxl * uu[u_] + cxl; Kv[u_] = fyl * vv[u_] + cyl;
+            nid[u_] = id[u_] / p2;
+            ok[u_] = in[u_] && (Ku[u_] > 2 && Kv[u_] > 2 && Ku[u_] < wl - 3 && Kv[u_] < hl - 3 && nid[u_] > 0);
+            const int ix = ok[u_] ? (int) Ku[u_] : 0, iy = ok[u_] ? (int) Kv[u_] : 0;
+            const float *bp = L.newImg + 3 * (ix + iy * wl);
+            const float *bq = bp + 3 * wl;
 #pragma unroll
-                for (int c = r; c < 9; c++) { acc[q] = __builtin_fmaf(jw, J[c], acc[q]); q++; }
+            for (int c = 0; c < 6; c++) { tap[u_][c] = bp[c]; tap[u_][6 + c] = bq[c]; }
+        }
+#pragma unroll
+        for (int u_ = 0; u_ < TR_U; u_++) {
+            const int i = ib + u_ * istride;
+            if (in[u_] && lvl == 0 && i % 32 == 0) {
+                const float *Ki = L.Ki;
+                const float xx = x[u_], yy = y[u_], idd = id[u_];
+                float k0 = (Ki[0] * xx + Ki[1] * yy) + Ki[2] * 1.0f, k1 = (Ki[3] * xx + Ki[4] * yy) + Ki[5] * 1.0f, k2 = (Ki[6] * xx + Ki[7] * yy) + Ki[8] * 1.0f;
+                float a0 = k0 + t[0] * idd, a1 = k1 + t[1] * idd, a2 = k2 + t[2] * idd;
+                float KuT = fxl * (a0 / a2) + cxl, KvT = fyl * (a1 / a2) + cyl;
+                float c0 = k0 - t[0] * idd, c1 = k1 - t[1] * idd, c2 = k2 - t[2] * idd;
+                float KuT2 = fxl * (c0 / c2) + cxl, KvT2 = fyl * (c1 / c2) + cyl;
+                float r0 = (((RKi[0] * xx + RKi[1] * yy) + RKi[2] * 1.0f)) - t[0] * idd, r1 = (((RKi[3] * xx + RKi[4] * yy) + RKi[5] * 1.0f)) - t[1] * idd,
+                      r2 = (((RKi[6] * xx + RKi[7] * yy) + RKi[8] * 1.0f)) - t[2] * idd;
+                float Ku3 = fxl * (r0 / r2) + cxl, Kv3 = fyl * (r1 / r2) + cyl;
+                acc[2] += (KuT - xx) * (KuT - xx) + (KvT - yy) * (KvT - yy);
+                acc[2] += (KuT2 - xx) * (KuT2 - xx) + (KvT2 - yy) * (KvT2 - yy);
+                acc[3] += (Ku[u_] - xx) * (Ku[u_] - xx) + (Kv[u_] - yy) * (Kv[u_] - yy);
+                acc[3] += (Ku3 - xx) * (Ku3 - xx) + (Kv3 - yy) * (Kv3 - yy);
+                acc[4] += 2;
+            }
+            if (!ok[u_]) continue;
+            const float refColor = col[u_], u = uu[u_], v = vv[u_], new_idepth = nid[u_];
+            const int ix = (int) Ku[u_], iy = (int) Kv[u_];
+            float dx = Ku[u_] - ix, dy = Kv[u_] - iy, dxdy = dx * dy;
+            float w11 = dxdy, w01 = dy - dxdy, w10 = dx - dxdy, w00 = 1 - dx - dy + dxdy;
+            const float *tp = tap[u_];
+            float h0 = ((w11 * tp[9] + w01 * tp[6]) + w10 * tp[3]) + w00 * tp[0];
+            float h1 = ((w11 * tp[10] + w01 * tp[7]) + w10 * tp[4]) + w00 * tp[1];
+            float h2 = ((w11 * tp[11] + w01 * tp[8]) + w10 * tp[5]) + w00 * tp[2];
+            if (!isfinite(h0)) continue;
+            float residual = h0 - (float) (affA * refColor + affB);
+            float hw = fabsf(residual) < P.huberTH ? 1 : P.huberTH / fabsf(residual);
+            if (fabsf(residual) > cutoffTH) {
+                acc[0] += maxEnergy; acc[1] += 1; acc[5] += 1;
+            } else {
+                acc[0] += hw * residual * residual * (2 - hw); acc[1] += 1; acc[6] += 1;
+                // calcGSSSE row (CoarseTracker.cc:592-615)
+                float ddx = h1 * fxl, ddy = h2 * fyl;
+                float J[9];
+                J[0] = new_idepth * ddx;
+                J[1] = new_idepth * ddy;
+                J[2] = 0 - new_idepth * (u * ddx + v * ddy);
+                J[3] = 0 - ((u * v) * ddx + ddy * (1 + v * v));
+                J[4] = (u * v) * ddy + ddx * (1 + u * u);
+                J[5] = u * ddy - v * ddx;
+                J[6] = affA * (b0 - refColor);
+                J[7] = -1;
+                J[8] = residual;
+                int q = 7;
+#pragma unroll
+                for (int r = 0; r < 9; r++) {
+                    float jw = J[r] * hw;
+#pragma unroll
+                    for (int c = r; c < 9; c++) { acc[q] = __builtin_fmaf(jw, J[c], acc[q]); q++; }
+                }
             }
         }
     }
-    // block reduction in double, fixed order
+    // block reduction, fixed order: the 16 lanes of a DPP row in float (the per-lane sums are float already), then the
+    // 4 rows x nW waves in double by 52 threads
 #pragma unroll
     for (int q = 0; q < TR_NACC; q++) {
-        double v = (double) acc[q];
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-        if (lane == 0) red[wave * TR_NACC + q] = v;
+        float v = acc[q];
+        v += tr_dpp<0xB1>(v);      // quad_perm [1,0,3,2]
+        v += tr_dpp<0x4E>(v);      // quad_perm [2,3,0,1]
+        v += tr_dpp<0x141>(v);     // row_half_mirror
+        v += tr_dpp<0x140>(v);     // row_mirror          -> every lane holds the sum of its 16-lane row
+        if ((lane & 15) == 0) red[((wave << 2) + (lane >> 4)) * TR_NACC + q] = (double) v;
     }
     __syncthreads();
-    if (tid < TR_NACC) { double s = 0; for (int wv = 0; wv < nW; wv++) s += red[wv * TR_NACC + tid]; out[tid] = s; }
+    if (tid < TR_NACC) { double s = 0; for (int r = 0; r < nW * 4; r++) s += red[r * TR_NACC + tid]; out[tid] = s; }
     __syncthreads();
 }
 
-// H (8x8), b (8) from the accumulated sums: divide by the padded n, apply the reference's scale swap
+// H (8x8), b (8) from the accumulated sums: divide by the padded n, apply the reference's scale swap.
+// One thread per entry (threads 0..71 of the block): no local arrays (they would live in scratch memory).
 __device__ void tr_hb(const double *acc, double *H, double *b) {
-    int nw = (int) acc[6];
-    int npad = (nw + 3) / 4 * 4;
-    double inv = (double) (1.0f / (float) npad);
-    const double cs[8] = {1.0, 1.0, 1.0, 0.5, 0.5, 0.5, 10.0, 1000.0};     // cols 0-2 x SCALE_XI_ROT, 3-5 x SCALE_XI_TRANS (sic)
-    int q = 7;
-    double M[81];
-    for (int r = 0; r < 9; r++) for (int c = r; c < 9; c++) { double v = (double) (float) acc[q++]; M[r * 9 + c] = v; M[c * 9 + r] = v; }
-    for (int r = 0; r < 8; r++) { for (int c = 0; c < 8; c++) H[r * 8 + c] = M[r * 9 + c] * inv * cs[r] * cs[c]; b[r] = M[r * 9 + 8] * inv * cs[r]; }
+    const int tid = threadIdx.x;
+    if (tid >= 72) return;
+    const int r = (tid < 64) ? (tid >> 3) : (tid - 64), c = (tid < 64) ? (tid & 7) : 8;
+    const int nw = (int) acc[6];
+    const int npad = (nw + 3) / 4 * 4;
+    const double inv = (double) (1.0f / (float) npad);
+    // cols 0-2 x SCALE_XI_ROT, 3-5 x SCALE_XI_TRANS (sic)
+    auto cs = [](int q) -> double { return (q < 3) ? 1.0 : (q < 6) ? 0.5 : (q == 6) ? 10.0 : 1000.0; };
+    const int lo = min(r, c), hi = max(r, c);
+    const double m = (double) (float) acc[7 + lo * 9 - (lo * (lo - 1)) / 2 + (hi - lo)];
+    if (c < 8) H[r * 8 + c] = m * inv * cs(r) * cs(c);
+    else b[r] = m * inv * cs(r);
 }
 
 // Eigen-style pivoted LDLT solve of an n x n (n <= 8) system, single thread
@@ -304,6 +350,78 @@ __device__ void small_ldlt_solve(const double *Ain, const double *rhs, double *x
     for (int k = n - 1; k >= 0; k--) if (tr[k] != k) { double a = x[k]; x[k] = x[tr[k]]; x[tr[k]] = a; }
 }
 
+// 64-bit lane shuffles / broadcasts for the wave-parallel 8x8 solve
+__device__ __forceinline__ double tr_shfl64(double v, int src) {
+    unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    int lo = __builtin_amdgcn_ds_bpermute(src << 2, (int) (u & 0xFFFFFFFFu)), hi = __builtin_amdgcn_ds_bpermute(src << 2, (int) (u >> 32));
+    return __builtin_bit_cast(double, ((unsigned long long) (unsigned) hi << 32) | (unsigned) lo);
+}
+__device__ __forceinline__ double tr_bcast64(double v, int l) {
+    unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    unsigned lo = (unsigned) __builtin_amdgcn_readlane((int) (u & 0xFFFFFFFFu), l), hi = (unsigned) __builtin_amdgcn_readlane((int) (u >> 32), l);
+    return __builtin_bit_cast(double, ((unsigned long long) hi << 32) | lo);
+}
+
+// Eigen-style LDL^T (pivot = largest remaining |diagonal|, D^+ on zero pivots) of the 8x8 system by ONE wavefront:
+// lane i*8+j holds A[i][j].  Replaces the single-thread small_ldlt_solve on the LM critical path (its dynamically indexed
+// local arrays live in scratch memory: ~60 us per solve against ~2 us here).  Must be called by all 64 lanes of a wave;
+// x (8 entries) is written by lanes 0..7.
+__device__ void ldlt8_wave(const double *H /*LDS 64, row major*/, const double *rhs /*LDS 8*/, double diagScale, double *x /*LDS 8*/) {
+    const int lane = threadIdx.x & 63, i = lane >> 3, j = lane & 7;
+    double a = H[lane];
+    if (i == j) a *= diagScale;
+    int tr[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        // pivot: first largest |A[q][q]|, q >= k   (uniform)
+        int idx = k;
+        double best = fabs(tr_bcast64(a, k * 9));
+#pragma unroll
+        for (int q = k + 1; q < 8; q++) { const double d = fabs(tr_bcast64(a, q * 9)); if (d > best) { best = d; idx = q; } }
+        tr[k] = idx;
+        if (idx != k) {
+            const int si = (i == k) ? idx : (i == idx) ? k : i, sj = (j == k) ? idx : (j == idx) ? k : j;
+            a = tr_shfl64(a, si * 8 + sj);
+        }
+        const double d = tr_bcast64(a, k * 9);
+        const double ci = tr_shfl64(a, i * 8 + k), cj = tr_shfl64(a, j * 8 + k);
+        if (fabs(d) > 0.0) {
+            if (i > k && j > k) a -= ci * (cj / d);
+            else if (j == k && i > k) a = ci / d;             // L[i][k]
+            else if (i == k && j > k) a = cj / d;             // mirror (unused)
+        }
+    }
+    // solve: x = P^T L^-T D^+ L^-1 P b ; lane r (< 8) holds x_r
+    double xr = (lane < 8) ? rhs[lane] : 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int t_ = tr[k];
+        if (t_ != k) { const int src = (lane == k) ? t_ : (lane == t_) ? k : lane; xr = tr_shfl64(xr, src & 63); }
+    }
+#pragma unroll
+    for (int c = 0; c < 7; c++) {                  // forward: x_r -= L[r][c] x_c, r > c
+        const double xc = tr_bcast64(xr, c);
+        const double l = tr_shfl64(a, (lane & 7) * 8 + c);      // lane r reads L[r][c]
+        if (lane < 8 && lane > c) xr -= l * xc;
+    }
+    {
+        const double dr = tr_shfl64(a, (lane & 7) * 9);
+        xr = (fabs(dr) > 2.2250738585072014e-308) ? xr / dr : 0.0;
+    }
+#pragma unroll
+    for (int c = 7; c >= 1; c--) {                 // backward: x_r -= L[c][r] x_c, r < c
+        const double xc = tr_bcast64(xr, c);
+        const double l = tr_shfl64(a, c * 8 + (lane & 7));      // lane r reads L[c][r]
+        if (lane < c) xr -= l * xc;
+    }
+#pragma unroll
+    for (int k = 7; k >= 0; k--) {
+        const int t_ = tr[k];
+        if (t_ != k) { const int src = (lane == k) ? t_ : (lane == t_) ? k : lane; xr = tr_shfl64(xr, src & 63); }
+    }
+    if (lane < 8) x[lane] = xr;
+}
+
 __device__ void tr_vec6(const double *acc, double *rs) {
     rs[0] = (double) (float) acc[0];
     rs[1] = (double) (int) acc[1];
@@ -318,11 +436,13 @@ __device__ void tr_vec6(const double *acc, double *rs) {
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(TR_NT) void k_tr_track(TrParams P, TrHyp *hyps) {
     __shared__ double sAcc[TR_NACC];
-    __shared__ double sRed[(TR_NT / 64) * TR_NACC];
+    __shared__ double sRed[(TR_NT / 16) * TR_NACC];
     __shared__ double sT[12], sTnew[12];
     __shared__ float sAff[2], sAffNew[2];
-    __shared__ double sH[64], sB[8], sResOld[6], sResNew[6];
+    __shared__ double sH[64], sB[8], sNb[8], sInc[8], sResOld[6], sResNew[6];
     __shared__ int sCtl[4];          // 0: continue LM loop, 1: accept, 2: abort (return false), 3: iterations
+    long long tEval = 0, tTot0 = wall_clock64(), tLv[5] = {0, 0, 0, 0, 0}; int nEval = 0, nLv[5] = {0, 0, 0, 0, 0};
+#define TEV(call) do { long long t_ = wall_clock64(); call; t_ = wall_clock64() - t_; tEval += t_; nEval++; if (lvl < 5) { tLv[lvl] += t_; nLv[lvl]++; } } while (0)
     __shared__ float sLambda, sCutRep;
     TrHyp &hy = hyps[blockIdx.x];
     const int tid = threadIdx.x;
@@ -335,27 +455,32 @@ __global__ __launch_bounds__(TR_NT) void k_tr_track(TrParams P, TrHyp *hyps) {
 
     for (int lvl = hy.coarsestLvl; lvl >= 0; lvl--) {
         float levelCutoffRepeat = 1;
-        tr_eval(P, lvl, sT, sAff[0], sAff[1], P.coarseCutoffTH * levelCutoffRepeat, sAcc, sRed, 0, TR_NT);
+        TEV(tr_eval(P, lvl, sT, sAff[0], sAff[1], P.coarseCutoffTH * levelCutoffRepeat, sAcc, sRed, 0, TR_NT););
         if (tid == 0) tr_vec6(sAcc, sResOld);
         __syncthreads();
         while (sResOld[5] > 0.6 && levelCutoffRepeat < 50) {
             levelCutoffRepeat *= 2;
-            tr_eval(P, lvl, sT, sAff[0], sAff[1], P.coarseCutoffTH * levelCutoffRepeat, sAcc, sRed, 0, TR_NT);
+            TEV(tr_eval(P, lvl, sT, sAff[0], sAff[1], P.coarseCutoffTH * levelCutoffRepeat, sAcc, sRed, 0, TR_NT););
             if (tid == 0) tr_vec6(sAcc, sResOld);
             __syncthreads();
         }
-        if (tid == 0) { tr_hb(sAcc, sH, sB); sLambda = 0.01f; }
+        tr_hb(sAcc, sH, sB);
+        if (tid == 0) sLambda = 0.01f;
         __syncthreads();
 
         for (int iteration = 0; iteration < maxIterations[lvl]; iteration++) {
+            // H (1 + lambda on the diagonal) x = -b: wave 0 solves the 8x8 system lane-parallel (CoarseTracker.cc:120-128)
+            if (tid < 8) sNb[tid] = -sB[tid];
+            __syncthreads();
+            if (tid < 64) ldlt8_wave(sH, sNb, (double) (1 + sLambda), sInc);
+            __syncthreads();
             if (tid == 0) {
                 sCtl[3]++;
                 const float lambda = sLambda;
                 double Hl[64], nb[8], inc[8];
-                for (int i = 0; i < 64; i++) Hl[i] = sH[i];
-                for (int i = 0; i < 8; i++) { Hl[i * 8 + i] *= (1 + lambda); nb[i] = -sB[i]; }
-                small_ldlt_solve(Hl, nb, inc, 8);
+                for (int i = 0; i < 8; i++) { inc[i] = sInc[i]; nb[i] = sNb[i]; }
                 const bool fixA = P.affineOptModeA < 0, fixB = P.affineOptModeB < 0;
+                if (fixA || fixB) { for (int i = 0; i < 64; i++) Hl[i] = sH[i]; for (int i = 0; i < 8; i++) Hl[i * 8 + i] *= (1 + lambda); }
                 if (fixA && fixB) {
                     double H6[36], x6[6];
                     for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) H6[i * 6 + j] = Hl[i * 8 + j];
@@ -397,12 +522,16 @@ __global__ __launch_bounds__(TR_NT) void k_tr_track(TrParams P, TrHyp *hyps) {
                 sCtl[0] = (sqrt(nrm) > 1e-3) ? 1 : 0;          // continue after this iteration?
             }
             __syncthreads();
-            tr_eval(P, lvl, sTnew, sAffNew[0], sAffNew[1], P.coarseCutoffTH * levelCutoffRepeat, sAcc, sRed, 0, TR_NT);
+            TEV(tr_eval(P, lvl, sTnew, sAffNew[0], sAffNew[1], P.coarseCutoffTH * levelCutoffRepeat, sAcc, sRed, 0, TR_NT););
             if (tid == 0) {
                 tr_vec6(sAcc, sResNew);
-                bool accept = (sResNew[0] / sResNew[1]) < (sResOld[0] / sResOld[1]);
+                sCtl[1] = ((sResNew[0] / sResNew[1]) < (sResOld[0] / sResOld[1])) ? 1 : 0;
+            }
+            __syncthreads();
+            if (sCtl[1]) tr_hb(sAcc, sH, sB);
+            if (tid == 0) {
+                const bool accept = sCtl[1] != 0;
                 if (accept) {
-                    tr_hb(sAcc, sH, sB);
                     for (int i = 0; i < 6; i++) sResOld[i] = sResNew[i];
                     sAff[0] = sAffNew[0]; sAff[1] = sAffNew[1];
                     for (int i = 0; i < 12; i++) sT[i] = sTnew[i];
@@ -425,6 +554,7 @@ __global__ __launch_bounds__(TR_NT) void k_tr_track(TrParams P, TrHyp *hyps) {
         if (sCtl[2]) break;
         if (levelCutoffRepeat > 1 && !haveRepeated) { lvl++; haveRepeated = true; }
     }
+    if (LD_STAMP_ON_TR && tid == 0) { hy.dbg[0] = (double) tEval; hy.dbg[1] = (double) (wall_clock64() - tTot0); hy.dbg[2] = nEval; for (int q = 0; q < 5; q++) hy.dbg[3 + q] = nLv[q] ? (double) tLv[q] / nLv[q] : 0.0; }
     if (tid == 0) {
         hy.iterations = sCtl[3];
         if (sCtl[2]) { hy.ok = 0; }
@@ -446,7 +576,7 @@ __global__ __launch_bounds__(TR_NT) void k_tr_track(TrParams P, TrHyp *hyps) {
 // stand-alone calcRes / calcGSSSE for the step-wise API (one workgroup)
 __global__ __launch_bounds__(TR_NT) void k_tr_calc(TrParams P, int lvl, const double *Tdev, float a, float b, float cutoffTH, double *outAcc) {
     __shared__ double sAcc[TR_NACC];
-    __shared__ double sRed[(TR_NT / 64) * TR_NACC];
+    __shared__ double sRed[(TR_NT / 16) * TR_NACC];
     __shared__ double sT[12];
     if (threadIdx.x < 12) sT[threadIdx.x] = Tdev[threadIdx.x];
     __syncthreads();
@@ -682,6 +812,7 @@ int ldso_tr_track_batch(ldso_tracker_t *H, int nhyp, double *T_inout /*nhyp*12*/
         if (flow) memcpy(flow + i * 3, hy[i].flow, 24);
         if (ok) ok[i] = hy[i].ok;
         if (iterations) iterations[i] = hy[i].iterations;
+        if (LD_STAMP_ON_TR && i == 0) fprintf(stderr, "[tr stamps] evals %d: %.1f us in tr_eval of %.1f us kernel; per-eval us by level 0..4: %.1f %.1f %.1f %.1f %.1f\n", (int) hy[i].dbg[2], hy[i].dbg[0] / 100.0, hy[i].dbg[1] / 100.0, hy[i].dbg[3] / 100, hy[i].dbg[4] / 100, hy[i].dbg[5] / 100, hy[i].dbg[6] / 100, hy[i].dbg[7] / 100);
     }
     return LDSO_OK;
 }
