@@ -108,6 +108,20 @@ def main():
     lin_s = lin_us * 1e-6
     achieved = alg_bytes / lin_s / 1e9 if lin_s > 0 else 0.0
 
+    # HBM traffic of the dominant kernel per launch: rocprofv3 PMC counters cannot be read from inside this process; the
+    # value is the committed measurement of the same command (profiles/rNN_pmc_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE)
+    traffic, traffic_src = None, None
+    try:
+        import glob
+        cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+        if cand and world == 1 and args.config == "C3" and not args.no_prior:
+            pj = json.load(open(cand[-1]))
+            for kname, kv in pj["kernels"].items():
+                if kname.startswith("k_linearize"):
+                    traffic, traffic_src = kv["hbm_bytes_per_launch_corrected"], os.path.relpath(cand[-1], ROOT)
+    except Exception:
+        traffic = None
+
     # sanity: the state after the run is finite
     fr = ba.get_frames()
     ok = bool(np.all(np.isfinite(fr["frames"]["state"])))
@@ -131,16 +145,57 @@ def main():
                                    + ("no prior" if args.no_prior else "synthetic rank-6 marginalisation prior H_M/b_M"),
                        "parallelism": "1 GPU" if world == 1 else f"points sharded over {world} GPUs, RCCL all-reduce of the stitched system per iteration"},
             "roofline": {"bound": "hbm", "kernel": "k_linearize", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
-                         "frac": round(achieved / 8000.0, 5), "traffic": None,
+                         "frac": round(achieved / 8000.0, 5), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": round(lin_us, 3), "event_pair_overhead_us": round(ev_ms * 1e3, 3)},
             "kernels": ktimes,
             "state_finite": ok,
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(win)
+            try:
+                out["tracker"] = tracker_line()
+            except Exception as e:          # the tracker line is informational (BASELINE configs[1]); never fail the BA metric on it
+                out["tracker"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def tracker_line():
+    """BASELINE configs[1] (informational): CoarseTracker::trackNewestCoarse on a 640x480 pair, 5 pyramid levels — one
+    ldso_tr_track call (images resident, host round trip included) and a 20-hypothesis batch, next to the oracle on one core."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from tracker_common import tracker_scenario
+    from ldso_amd import synth, binding
+    from oracle import pyoracle as po
+    sc = tracker_scenario("C3", levels=5)
+    win = sc["win"]
+    a, b = sc["new_aff"]
+    g = binding.Tracker(win.w, win.h, sc["levels"], win.settings, win.calib)
+    o = po.OracleTracker(win.w, win.h, sc["levels"], win.settings, win.calib, fast=True)
+    for t in (g, o):
+        t.set_ref(sc["ref_pyr"], sc["ref_aff"][0], sc["ref_aff"][1], 1.0, sc["pts"])
+        t.set_new_frame(sc["new_pyr"], 1.0)
+
+    def timeit(t, n):
+        r = None
+        t0 = time.perf_counter()
+        for _ in range(n):
+            r = t.track(np.eye(4), a, b, sc["levels"] - 1)
+        return (time.perf_counter() - t0) / n, r
+
+    timeit(g, 3)
+    tg, rg = timeit(g, 50)
+    to, ro = timeit(o, 5)
+    guesses = [synth.se3_exp([0.002 * i, 0, 0, 0, 0.0005 * i, 0]) for i in range(20)]
+    g.track_batch(guesses, [(a, b)] * 20, sc["levels"] - 1)
+    t0 = time.perf_counter()
+    for _ in range(10):
+        g.track_batch(guesses, [(a, b)] * 20, sc["levels"] - 1)
+    tb = (time.perf_counter() - t0) / 10
+    return {"workload": f"C2: {win.w}x{win.h} pair, {sc['levels']} levels, {len(sc['pts'])} reference points",
+            "gpu_track_ms": round(tg * 1e3, 4), "lm_iterations": int(rg["iterations"]), "gpu_track_batch20_ms": round(tb * 1e3, 4),
+            "cpu_oracle_track_ms": round(to * 1e3, 4), "cpu_cores": 1}
 
 
 def cpu_baseline(win):
