@@ -107,6 +107,17 @@ int ldso_ba_load_state_backup(ldso_ba_t *h);
  * synchronisation inside the loop.  force_all_iterations != 0 ignores `canbreak` (BASELINE config C3).
  * rmse_out = the function's return value; iterations_out = GN iterations executed. */
 int ldso_ba_optimize(ldso_ba_t *h, int mnumOptIts, int force_all_iterations, float *rmse_out, int *iterations_out);
+/* EnergyFunctional::marginalizePointsF (EnergyFunctional.cc:165-222) for the points with flags[p] != 0 (the caller's
+ * PS_MARGINALIZED decision, FullSystem.cc:1208-1270), fused with the reset + re-linearise + fixLinearizationF pass that
+ * FullSystem::flagPointsForRemoval runs on exactly these points (FullSystem.cc:1241-1250, Residuals.cc:216-242):
+ * HM += margWeightFac (M - Msc), bM += margWeightFac (Mb - Mbsc) on the device (and copied to HM_out / bM_out when
+ * non-NULL, (8F+4)^2 row-major and 8F+4 doubles).  The window's applied state is unchanged; the caller removes the
+ * points (next ldso_ba_set_window) and calls EnergyFunctional::marginalizeFrame on the returned prior as before. */
+int ldso_ba_marginalize_points(ldso_ba_t *h, const int32_t *flags, double *HM_out, double *bM_out);
+/* EnergyFunctional::marginalizeFrame (EnergyFunctional.cc:72-151) on the device prior H_M / b_M (as set by
+ * ldso_ba_set_prior or left by ldso_ba_marginalize_points) with the frame's prior / delta_prior: out = prior of the window
+ * without frame `frame_idx`, (8(F-1)+4)^2 row-major and 8(F-1)+4 doubles. */
+int ldso_ba_marginalize_frame(ldso_ba_t *h, int frame_idx, double *HM_out, double *bM_out);
 /* Asynchronous variant used by bench.py: enqueue `iters` Gauss-Newton iterations (solveSystem +
  * doStepFromBackup + linearizeAll + applyRes) on the handle's stream and return immediately. */
 int ldso_ba_enqueue_gn(ldso_ba_t *h, int first_iteration, int iters);

@@ -165,6 +165,22 @@ class BA:
         _chk(self.L.ldso_ba_optimize(self.h, C.c_int(niters), C.c_int(1 if force_all else 0), C.byref(rm), C.byref(it)))
         return rm.value, it.value
 
+    def marginalize_points(self, flags):
+        """EnergyFunctional::marginalizePointsF for the flagged points -> (HM, bM)"""
+        flags = np.ascontiguousarray(flags, np.int32)
+        assert len(flags) == self.P
+        n = 8 * self.F + 4
+        HM = np.zeros((n, n)); bM = np.zeros(n)
+        _chk(self.L.ldso_ba_marginalize_points(self.h, _p(flags), _p(HM), _p(bM)))
+        return HM, bM
+
+    def marginalize_frame(self, idx):
+        """EnergyFunctional::marginalizeFrame on the device prior -> (HM, bM) of the window without frame idx"""
+        n = 8 * (self.F - 1) + 4
+        HM = np.zeros((n, n)); bM = np.zeros(n)
+        _chk(self.L.ldso_ba_marginalize_frame(self.h, C.c_int(idx), _p(HM), _p(bM)))
+        return HM, bM
+
     def enqueue_gn(self, first_iteration, iters):
         _chk(self.L.ldso_ba_enqueue_gn(self.h, C.c_int(first_iteration), C.c_int(iters)))
 

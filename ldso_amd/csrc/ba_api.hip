@@ -18,6 +18,9 @@ hipError_t ba_launch_gather(const BaPtrs &B, const BaDims &D, const ResSet &S, b
                             const ldso_settings_t &St, int mode, double *rbuf, hipStream_t st);
 hipError_t ba_launch_solve(const BaPtrs &B, const BaDims &D, const ResSet &S, const ldso_settings_t &St, const SolveArgs &A, hipStream_t st);
 hipError_t ba_launch_point_step(const BaPtrs &B, const BaDims &D, const ResSet &S, int mode, hipStream_t st);
+hipError_t ba_launch_linearize_marg(const BaPtrs &B, const BaDims &D, const ResSet &cur, const ResSet &nxt, const ldso_settings_t &S, const int32_t *margFlags, hipStream_t st);
+hipError_t ba_launch_marg_frame(const BaPtrs &B, const BaDims &D, int idx, double *work, double *outH, double *outb, hipStream_t st);
+hipError_t ba_launch_marg_update(const BaPtrs &B, const BaDims &D, double w, hipStream_t st);
 hipError_t ba_launch_gn_solve(const BaPtrs &B, const BaDims &D, const ResSet &S, const ldso_settings_t &St, const SolveArgs &A, hipStream_t st);
 
 static thread_local std::string g_err;
@@ -45,6 +48,7 @@ struct ldso_ba {
     float *imgSlots[LD_MAXF] = {nullptr};
     bool imgOwned[LD_MAXF] = {false};
     int32_t *d_chunkStart = nullptr;
+    int32_t *d_margFlags = nullptr;
     ChunkStarts chunkStarts;
     ldso_rawjac_t *d_dumpJ = nullptr;
     std::vector<int32_t> flat2slot;
@@ -168,6 +172,7 @@ int ldso_ba_create(int device, int w, int h, int max_frames, int max_points, lds
     DA(B.Jlin, P * FS); DA(B.rtz, P * FS * 8);
     DA(B.chunk_p0, H->maxChunks); DA(B.chunk_n, H->maxChunks); DA(B.chunk_host, H->maxChunks);
     DA(H->d_chunkStart, F + 2);
+    DA(H->d_margFlags, P);
     DA(B.pairC, 2 * F * F * LD_PAIRC);
     const size_t GSPmax = (8 * FS + LD_GEXTRA + 15) / 16 * 16;
     DA(B.scPart, (size_t) LD_SC_SPLITS * GSPmax * GSPmax);
@@ -619,6 +624,46 @@ int ldso_ba_optimize(ldso_ba_t *H, int mnumOptIts, int force_all, float *rmse_ou
     if (iters_out) *iters_out = done;
     if (rmse_out) *rmse_out = sqrtf((float) (sc[0] / (8 * sc[9])));
     if (!std::isfinite(sc[0]) || sc[4] != 0.0) return LDSO_E_NONFINITE;
+    return LDSO_OK;
+}
+
+// EnergyFunctional::marginalizePointsF (EnergyFunctional.cc:165-222) for the points with flags[p] != 0, including the
+// re-linearise + fixLinearizationF pass FullSystem::flagPointsForRemoval ran on them (FullSystem.cc:1241-1250).
+// The applied state of the window is not changed; the caller removes the points (next ldso_ba_set_window).
+int ldso_ba_marginalize_points(ldso_ba_t *H, const int32_t *flags, double *HM_out, double *bM_out) {
+    REQ(H && flags && H->D.P > 0, "ldso_ba_marginalize_points: bad arguments");
+    CHK(hipSetDevice(H->device));
+    REQ(!H->pendingApply, "ldso_ba_marginalize_points: a linearizeAll result is pending (apply or discard it first)");
+    REQ(H->D.pBegin == 0 && H->D.pEnd == H->D.P, "ldso_ba_marginalize_points: not available on a sharded handle");
+    const size_t n = H->D.n;
+    if (!H->hasPrior) { CHK(hipMemsetAsync(H->B.HM, 0, n * n * 8, H->stream)); CHK(hipMemsetAsync(H->B.bM, 0, n * 8, H->stream)); }
+    CHK(hipMemcpyAsync(H->d_margFlags, flags, (size_t) H->D.P * 4, hipMemcpyHostToDevice, H->stream));
+    const ResSet &scratch = H->sets[H->cur ^ 1];
+    CHK(ba_launch_linearize_marg(H->B, H->D, H->sets[H->cur], scratch, H->settings, H->d_margFlags, H->stream));
+    CHK(ba_launch_reduce(H->B, H->D, scratch, H->chunkStarts, /*hasL*/ false, H->GSP, false, false, 0.0f, 1.0, 1.0, H->stream));
+    CHK(ba_launch_gather(H->B, H->D, scratch, /*hasL*/ false, /*hasPrior*/ false, H->GSP, 0.0, H->settings, 0, nullptr, H->stream));
+    CHK(ba_launch_marg_update(H->B, H->D, (double) H->settings.margWeightFac, H->stream));
+    H->hasPrior = true;
+    if (HM_out) CHK(hipMemcpyAsync(HM_out, H->B.HM, n * n * 8, hipMemcpyDeviceToHost, H->stream));
+    if (bM_out) CHK(hipMemcpyAsync(bM_out, H->B.bM, n * 8, hipMemcpyDeviceToHost, H->stream));
+    CHK(hipStreamSynchronize(H->stream));
+    return LDSO_OK;
+}
+
+// EnergyFunctional::marginalizeFrame (EnergyFunctional.cc:72-151) applied to the device prior: returns the prior of the
+// window without frame `frame_idx` ((8(F-1)+4)^2 row-major, 8(F-1)+4).  The handle keeps its window; the caller rebuilds
+// it without the frame (ldso_ba_set_window / ldso_ba_set_prior with the returned matrices).
+int ldso_ba_marginalize_frame(ldso_ba_t *H, int frame_idx, double *HM_out, double *bM_out) {
+    REQ(H && HM_out && bM_out && H->D.F >= 2 && frame_idx >= 0 && frame_idx < H->D.F, "ldso_ba_marginalize_frame: bad arguments");
+    CHK(hipSetDevice(H->device));
+    const size_t n = H->D.n, nd = n - 8;
+    if (!H->hasPrior) { CHK(hipMemsetAsync(H->B.HM, 0, n * n * 8, H->stream)); CHK(hipMemsetAsync(H->B.bM, 0, n * 8, H->stream)); }
+    // scratch: B.sys holds 4 (n^2 + n) doubles: work = first n^2 + n, output after it
+    double *work = H->B.sys, *oH = work + n * n + n, *ob = oH + nd * nd;
+    CHK(ba_launch_marg_frame(H->B, H->D, frame_idx, work, oH, ob, H->stream));
+    CHK(hipMemcpyAsync(HM_out, oH, nd * nd * 8, hipMemcpyDeviceToHost, H->stream));
+    CHK(hipMemcpyAsync(bM_out, ob, nd * 8, hipMemcpyDeviceToHost, H->stream));
+    CHK(hipStreamSynchronize(H->stream));
     return LDSO_OK;
 }
 

@@ -95,8 +95,15 @@ static __device__ __forceinline__ void load_point(PtIn<NSG> &q, const BaPtrs &B,
 // stepMode != 0 fuses the point part of resubstituteF_MT + backupState + doStepFromBackup (EnergyFunctional.cc:518-547,
 // FullSystem.cc:1585-1602, 1625-1673) in front of the linearisation of each point (what k_point_step does with
 // PS_RESUB|PS_BACKUP|PS_STEP), so a forced-accept GN iteration needs no separate point pass.
-template <int NSG, bool HAS_L, bool FIX>
-__global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D, ResSet cur, ResSet nxt, ldso_settings_t S, int stepMode, GnInit gi) {
+// MARG = true: the accumulate of EnergyFunctional::marginalizePointsF (EnergyFunctional.cc:165-222) for the points flagged in
+// margFlags, fused with what FullSystem::flagPointsForRemoval did to them just before (FullSystem.cc:1241-1250): every residual
+// of a flagged point is reset (resetOOB), re-linearised at the current state, applied, and - if active - fixed
+// (fixLinearizationF, Residuals.cc:216-242: res_toZeroF = resF - [JIdx (Jp delta) + JabF delta_ab]); the top / Schur accumulators
+// then take addPoint<2> (resApprox = res_toZeroF) with priorF * idepthFixPriorMargFac and no prior shift.  Unflagged points
+// contribute nothing.  The output set is scratch (never applied).
+template <int NSG, bool HAS_L, bool FIX, bool MARG>
+__global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D, ResSet cur, ResSet nxt, ldso_settings_t S, int stepMode, GnInit gi,
+                                                             const int32_t *__restrict__ margFlags) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int FS = D.FS, F = D.F;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, s = lane >> 3, k = lane & 7;
@@ -193,7 +200,8 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D,
         const int p = p0 + pi;
         const PtIn<NSG> q = nx;
         if (pi + LD_WAVES < np) load_point<NSG, HAS_L, FIX>(nx, B, cur, FS, p + LD_WAVES, s, k, stepMode);
-        const float pu = q.pu, pv = q.pv, priorF = q.priorF;
+        const float pu = q.pu, pv = q.pv, priorF = MARG ? q.priorF * S.idepthFixPriorMargFac : q.priorF;
+        const bool flagged = MARG ? (margFlags[p] != 0) : true;
         const float color = q.color, wgt = q.wgt;
         float idp = q.idp, idz = q.idz;
         if (stepMode) {
@@ -232,13 +240,13 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D,
         for (int g = 0; g < NSG; g++) {
             const int t = g * 8 + s;
             const int slot = p * FS + t;
-            const bool exists = (t < F) && (q.rflat[g] >= 0);
-            const bool isLin = exists && (q.rlin[g] != 0);
-            const int st = exists ? q.state[g] : RES_OOB;
+            const bool exists = (t < F) && (q.rflat[g] >= 0) && flagged;
+            const bool isLin = MARG ? false : (exists && (q.rlin[g] != 0));
+            const int st = exists ? (MARG ? RES_IN : q.state[g]) : RES_OOB;          // MARG: resetOOB()
             const DevPair &pr = sPair[t];
 
             int newState = st;
-            float newEnergy = exists ? q.energy[g] : 0.0f;
+            float newEnergy = (exists && !MARG) ? q.energy[g] : 0.0f;
             float newEnergyWO = -1.0f;
             int activeNew = exists ? q.active[g] : 0;
             float jp = exists ? q.jp[g] : 0.0f;     // this lane's component k of JpJdF
@@ -325,6 +333,18 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D,
             x[4] = new_idepth * fx; x[5] = 0; x[6] = -new_idepth * uu * fx; x[7] = -uu * vv * fx; x[8] = (1 + uu * uu) * fx; x[9] = -vv * fx;
             y[4] = 0; y[5] = new_idepth * fy; y[6] = -new_idepth * vv * fy; y[7] = -(1 + vv * vv) * fy; y[8] = uu * vv * fy; y[9] = uu * fy;
 
+            float resAcc = resF;          // the residual column of the accumulators: resF (mode 0) or res_toZeroF (MARG, mode 2)
+            if (MARG) {
+                float dpx = 0, dpy = 0;
+#pragma unroll
+                for (int i = 0; i < 6; i++) { dpx += x[4 + i] * pr.dp[i]; dpy += y[4 + i] * pr.dp[i]; }
+                const float dcx = ((x[0] * cD0 + x[1] * cD1) + x[2] * cD2) + x[3] * cD3;
+                const float dcy = ((y[0] * cD0 + y[1] * cD1) + y[2] * cD2) + y[3] * cD3;
+                const float Jp_delta_x = dpx + dcx + Jpdd0 * deltaF, Jp_delta_y = dpy + dcy + Jpdd1 * deltaF;
+                float rtz = resF;
+                rtz = rtz - gx * Jp_delta_x; rtz = rtz - gy * Jp_delta_y; rtz = rtz - jab0 * pr.dp[6]; rtz = rtz - jab1 * pr.dp[7];
+                resAcc = compute ? rtz : 0.0f;
+            }
             if (compute) {
                 newEnergyWO = energyLeft;
                 float th = pr.thMax;
@@ -372,7 +392,7 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D,
                 float v[13];
 #pragma unroll
                 for (int i = 0; i < 10; i++) v[i] = __builtin_fmaf(gx, x[i], gy * y[i]);
-                v[10] = drdA * hw; v[11] = hw; v[12] = resF;
+                v[10] = drdA * hw; v[11] = hw; v[12] = resAcc;
                 // Jab_r uses the (possibly zeroed) JabF, Jab2/JabJIdx the un-zeroed sums
                 const float z10 = (S.affineOptModeA < 0) ? 0.0f : 1.0f, z11 = (S.affineOptModeB < 0) ? 0.0f : 1.0f;
 #pragma unroll
@@ -386,7 +406,7 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D,
                     }
             }
             // per-slot contributions to the point sums (same value in all 8 lanes of the slot)
-            float JI_r0 = sum8(resF * gx), JI_r1 = sum8(resF * gy);
+            float JI_r0 = sum8(resAcc * gx), JI_r1 = sum8(resAcc * gy);
             float Ji2_0 = JI00 * Jpdd0 + JI10 * Jpdd1, Ji2_1 = JI10 * Jpdd0 + JI11 * Jpdd1;
             float sbd = accHere ? (JI_r0 * Jpdd0 + JI_r1 * Jpdd1) : 0.0f;
             float sHdd = accHere ? (Ji2_0 * Jpdd0 + Ji2_1 * Jpdd1) : 0.0f;
@@ -514,7 +534,7 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D,
             idH = H;
             HdiF = (float) (1.0 / (double) H);
             bdSumF = bdA + bdL;
-            bdSumF += priorF * deltaF;       // shiftPriorToZero = true in accumulateSCF_MT
+            if (!MARG) bdSumF += priorF * deltaF;       // shiftPriorToZero = true in accumulateSCF_MT, false in marginalizePointsF
         } else {
             maxRelBS = 0;
         }
@@ -593,12 +613,13 @@ size_t ba_linearize_lds_bytes(int FS, bool hasL) {
     return fl * sizeof(float) + 256;
 }
 
-template <int NSG, bool HAS_L, bool FIX>
-static hipError_t launch_one(const BaPtrs &B, const BaDims &D, const ResSet &cur, const ResSet &nxt, const ldso_settings_t &S, int stepMode, const GnInit &gi, hipStream_t st) {
+template <int NSG, bool HAS_L, bool FIX, bool MARG = false>
+static hipError_t launch_one(const BaPtrs &B, const BaDims &D, const ResSet &cur, const ResSet &nxt, const ldso_settings_t &S, int stepMode, const GnInit &gi, hipStream_t st,
+                            const int32_t *margFlags = nullptr) {
     size_t lds = ba_linearize_lds_bytes(D.FS, HAS_L);
-    auto kfn = k_linearize<NSG, HAS_L, FIX>;
+    auto kfn = k_linearize<NSG, HAS_L, FIX, MARG>;
     if (lds > 48 * 1024) hipFuncSetAttribute((const void *) kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-    hipLaunchKernelGGL(kfn, dim3(D.nChunks), dim3(64 * LD_WAVES), lds, st, B, D, cur, nxt, S, stepMode, gi);
+    hipLaunchKernelGGL(kfn, dim3(D.nChunks), dim3(64 * LD_WAVES), lds, st, B, D, cur, nxt, S, stepMode, gi, margFlags);
     return hipGetLastError();
 }
 
@@ -612,4 +633,13 @@ hipError_t ba_launch_linearize(const BaPtrs &B, const BaDims &D, const ResSet &c
         if (hasL) return fix ? launch_one<2, true, true>(B, D, cur, nxt, S, stepMode, gi, st) : launch_one<2, true, false>(B, D, cur, nxt, S, stepMode, gi, st);
         return fix ? launch_one<2, false, true>(B, D, cur, nxt, S, stepMode, gi, st) : launch_one<2, false, false>(B, D, cur, nxt, S, stepMode, gi, st);
     }
+}
+
+// marginalizePointsF accumulate for the flagged points (see the MARG note at k_linearize); `nxt` is scratch
+hipError_t ba_launch_linearize_marg(const BaPtrs &B, const BaDims &D, const ResSet &cur, const ResSet &nxt, const ldso_settings_t &S, const int32_t *margFlags,
+                                    hipStream_t st) {
+    if (D.nChunks == 0) return hipSuccess;
+    const GnInit gi{0, 0, 0.0f};
+    if (D.nsg == 1) return launch_one<1, false, false, true>(B, D, cur, nxt, S, 0, gi, st, margFlags);
+    return launch_one<2, false, false, true>(B, D, cur, nxt, S, 0, gi, st, margFlags);
 }

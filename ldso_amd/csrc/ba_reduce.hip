@@ -469,3 +469,99 @@ hipError_t ba_launch_reduce(const BaPtrs &B, const BaDims &D, const ResSet &S, c
     hipLaunchKernelGGL(k_reduce, dim3(nb), dim3(256), lds, st, B, D, S, chunkStart, hasL ? 1 : 0, GSP, atomicMode ? 1 : 0, hasPrior ? 1 : 0, calibPrior, l1, il);
     return hipGetLastError();
 }
+
+// EnergyFunctional::marginalizePointsF tail (EnergyFunctional.cc:203-216): HM += margWeightFac (M - Msc), bM += margWeightFac (Mb - Mbsc),
+// with M / Msc the top / Schur systems of the marginalised points assembled by k_gather (mode 0) in B.sys
+__global__ __launch_bounds__(256) void k_marg_update(BaPtrs B, BaDims D, double w) {
+    const int n = D.n, e = blockIdx.x * blockDim.x + threadIdx.x;
+    const double *HA = B.sys, *bA = HA + n * n, *Hsc = bA + n + (size_t) n * n + n, *bsc = Hsc + n * n;
+    if (e < n * n) B.HM[e] += (HA[e] - Hsc[e]) * w;
+    else if (e < n * n + n) B.bM[e - n * n] += (bA[e - n * n] - bsc[e - n * n]) * w;
+}
+
+hipError_t ba_launch_marg_update(const BaPtrs &B, const BaDims &D, double w, hipStream_t st) {
+    const int N = D.n * D.n + D.n;
+    hipLaunchKernelGGL(k_marg_update, dim3((N + 255) / 256), dim3(256), 0, st, B, D, w);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// EnergyFunctional::marginalizeFrame (EnergyFunctional.cc:72-151) on the device prior H_M / b_M: move the frame's 8 rows /
+// columns to the end, add its prior, scale by (|diag|+10)^-1/2, eliminate the 8x8 block (inverse by partial-pivot LU like Eigen's
+// fixed-size inverse()), unscale, symmetrise.  One workgroup; the matrices live in global memory (n <= 132), W = n*n + n doubles
+// of scratch.  Output: (n-8)^2 row-major + (n-8).  Per key frame, not per iteration: written for clarity, not speed.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_marg_frame(BaPtrs B, BaDims D, int idx, double *W, double *outH, double *outb) {
+    const int tid = threadIdx.x, n = D.n, nd = n - 8;
+    double *Hs = W, *bs = W + (size_t) n * n;
+    __shared__ double sSV[8 * LD_MAXF + 4], sHpi[64], sLU[64], sBli[8];
+    __shared__ int sPiv[8];
+    auto perm = [&](int i) { const int io = 4 + 8 * idx; return (i < io) ? i : (i < nd) ? i + 8 : io + (i - nd); };
+    // permuted copy + the frame's prior on its (now trailing) diagonal block
+    const DevFrame &fh = B.frames[idx];
+    for (int e = tid; e < n * n; e += 256) {
+        const int i = e / n, j = e % n;
+        double v = B.HM[(size_t) perm(i) * n + perm(j)];
+        if (i == j && i >= nd) v += fh.prior[i - nd];
+        Hs[e] = v;
+    }
+    for (int i = tid; i < n; i += 256) bs[i] = B.bM[perm(i)] + ((i >= nd) ? fh.prior[i - nd] * fh.delta_prior[i - nd] : 0.0);
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) sSV[i] = sqrt(fabs(Hs[(size_t) i * n + i]) + 10.0);
+    __syncthreads();
+    for (int e = tid; e < n * n; e += 256) { const int i = e / n, j = e % n; Hs[e] = (1.0 / sSV[i]) * Hs[e] * (1.0 / sSV[j]); }
+    for (int i = tid; i < n; i += 256) bs[i] = (1.0 / sSV[i]) * bs[i];
+    __syncthreads();
+    // hpi = inverse(0.5 (hpi + hpi^T)) by LU with partial pivoting (thread 0, LDS), then symmetrised again
+    if (tid < 64) { const int r = tid >> 3, c = tid & 7; sLU[tid] = 0.5 * (Hs[(size_t) (nd + r) * n + nd + c] + Hs[(size_t) (nd + c) * n + nd + r]); }
+    __syncthreads();
+    if (tid == 0) {
+        for (int k = 0; k < 8; k++) {
+            int p = k; double best = fabs(sLU[k * 8 + k]);
+            for (int i = k + 1; i < 8; i++) if (fabs(sLU[i * 8 + k]) > best) { best = fabs(sLU[i * 8 + k]); p = i; }
+            sPiv[k] = p;
+            if (p != k) for (int j = 0; j < 8; j++) { double t = sLU[k * 8 + j]; sLU[k * 8 + j] = sLU[p * 8 + j]; sLU[p * 8 + j] = t; }
+            for (int i = k + 1; i < 8; i++) {
+                sLU[i * 8 + k] /= sLU[k * 8 + k];
+                for (int j = k + 1; j < 8; j++) sLU[i * 8 + j] -= sLU[i * 8 + k] * sLU[k * 8 + j];
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < 8) {      // column tid of the inverse: solve LU x = P e_tid
+        double x[8];
+        for (int i = 0; i < 8; i++) x[i] = (i == tid) ? 1.0 : 0.0;
+        for (int k = 0; k < 8; k++) { const int p = sPiv[k]; if (p != k) { double t = x[k]; x[k] = x[p]; x[p] = t; } }
+        for (int i = 0; i < 8; i++) for (int j = 0; j < i; j++) x[i] -= sLU[i * 8 + j] * x[j];
+        for (int i = 7; i >= 0; i--) { for (int j = i + 1; j < 8; j++) x[i] -= sLU[i * 8 + j] * x[j]; x[i] /= sLU[i * 8 + i]; }
+        for (int i = 0; i < 8; i++) sHpi[i * 8 + tid] = x[i];
+    }
+    __syncthreads();
+    double hsym = 0.0;
+    if (tid < 64) { const int r = tid >> 3, c = tid & 7; hsym = 0.5 * (sHpi[r * 8 + c] + sHpi[c * 8 + r]); }
+    __syncthreads();
+    if (tid < 64) sHpi[tid] = hsym;
+    __syncthreads();
+    // Schur complement of the trailing block: row i of the result needs bli[i][:] = sum_k Hs[nd+k][i] hpi[k][:]
+    for (int i = 0; i < nd; i++) {
+        if (tid < 8) { double s_ = 0; for (int k = 0; k < 8; k++) s_ += Hs[(size_t) (nd + k) * n + i] * sHpi[k * 8 + tid]; sBli[tid] = s_; }
+        __syncthreads();
+        for (int j = tid; j <= nd; j += 256) {
+            double s_ = 0;
+            if (j < nd) { for (int k = 0; k < 8; k++) s_ += sBli[k] * Hs[(size_t) (nd + k) * n + j]; Hs[(size_t) i * n + j] -= s_; }
+            else { for (int k = 0; k < 8; k++) s_ += sBli[k] * bs[nd + k]; bs[i] -= s_; }
+        }
+        __syncthreads();
+    }
+    // unscale and symmetrise
+    for (int e = tid; e < nd * nd; e += 256) {
+        const int i = e / nd, j = e % nd;
+        outH[e] = 0.5 * (sSV[i] * Hs[(size_t) i * n + j] * sSV[j] + sSV[j] * Hs[(size_t) j * n + i] * sSV[i]);
+    }
+    for (int i = tid; i < nd; i += 256) outb[i] = sSV[i] * bs[i];
+}
+
+hipError_t ba_launch_marg_frame(const BaPtrs &B, const BaDims &D, int idx, double *work, double *outH, double *outb, hipStream_t st) {
+    hipLaunchKernelGGL(k_marg_frame, dim3(1), dim3(256), 0, st, B, D, idx, work, outH, outb);
+    return hipGetLastError();
+}

@@ -171,6 +171,46 @@ def test_optimize_12_frames():
     _optimize_compare(win, its=4)
 
 
+@pytest.mark.parametrize("with_prior", [False, True])
+def test_marginalize_points(small, with_prior):
+    """a11: marginalizePointsF on the device (mode-2 accumulate of the flagged points incl. the re-linearise + fixLinearizationF
+    pass of flagPointsForRemoval) against the oracle's flagPointsForRemoval + marginalizePointsF: the new H_M / b_M."""
+    win = synth.add_synthetic_prior(copy.deepcopy(small)) if with_prior else small
+    o = po.OracleWindow(win); o.set_force_all_iterations(True)
+    o.optimize(3)
+    # the device handle starts from the oracle's post-optimize state (identical applied state on both sides)
+    ex, fo = o.export_window(), o.get_frames()
+    assert ex["F"] == win.F and len(ex["points"]) == win.P and np.array_equal(ex["orig_point"], np.arange(win.P))
+    w2 = copy.deepcopy(win)
+    w2.points, w2.residuals, w2.lin_J, w2.lin_res_toZeroF = ex["points"], ex["residuals"], ex["lin_J"], ex["lin_res_toZeroF"]
+    w2.frames = fo["frames"]
+    w2.calib = w2.calib.copy(); w2.calib["value"] = fo["calib_value"]
+    g = binding.BA.from_window(w2)
+    o.flag_frame(0)
+    o.flag_points_for_removal()
+    _, status = o.get_points()
+    flags = (status == 3).astype(np.int32)                  # PS_MARGINALIZED
+    assert 0 < flags.sum() < win.P
+    o.drop_points()
+    o.marginalize_points()
+    HMo, bMo = o.get_prior()
+    HMg, bMg = g.marginalize_points(flags)
+    assert np.abs(HMo).max() > 0
+    assert blockrel(HMg, HMo, 4) < TOL and rel(HMg, HMo) < TOL
+    assert rel(bMg, bMo) < TOL
+    assert np.abs(HMg - HMg.T).max() <= 1e-6 * np.abs(HMg).max()
+    # the applied window state is untouched by the call
+    rg = g.get_residuals()
+    assert np.array_equal(rg["state_state"], ex["residuals"]["state_state"])
+    # marginalizeFrame on the resulting prior (frame 0 = the flagged one)
+    o.marginalize_frame(0)
+    HM2o, bM2o = o.get_prior()
+    HM2g, bM2g = g.marginalize_frame(0)
+    assert HM2g.shape == HM2o.shape == (8 * (win.F - 1) + 4,) * 2
+    assert blockrel(HM2g, HM2o, 4) < 5 * TOL and rel(HM2g, HM2o) < 5 * TOL and rel(bM2g, bM2o) < 5 * TOL
+    assert np.abs(HM2g - HM2g.T).max() <= 1e-9 * np.abs(HM2g).max()
+
+
 @pytest.mark.parametrize("name", ["C3", "C4"])
 def test_full_size_parity_and_properties(name):
     """BASELINE configs at full size: one stage-wise pass against the oracle plus size-independent properties."""
