@@ -55,7 +55,10 @@ def main():
     if not args.no_prior:
         synth.add_synthetic_prior(win)          # steady-state windows always carry H_M / b_M (EnergyFunctional::marginalizeFrame)
     F, P, R = win.F, win.P, win.R
-    stream = torch.cuda.current_stream().cuda_stream
+    # everything (our kernels, torch ops, the RCCL all-reduce) is ordered on ONE non-default torch stream
+    tstream = torch.cuda.Stream()
+    torch.cuda.set_stream(tstream)
+    stream = tstream.cuda_stream
     ba = binding.BA.from_window(win, device=local_rank, stream=stream)
     pb, pe = ldist.shard_range(P, rank, world)
     if world > 1:
@@ -63,16 +66,17 @@ def main():
     ba.collect_active()
     ba.linearize_all(False)
     ba.apply_res()
-    rbuf = torch.zeros(ba.reduce_doubles(), dtype=torch.float64, device="cuda") if world > 1 else None
+    rbuf = torch.zeros(ba.gn_reduce_doubles(), dtype=torch.float64, device="cuda") if world > 1 else None
 
     def run(k, it0):
         if world == 1:
             ba.enqueue_gn(it0, k)
         else:
+            # the all-reduce buffer is the HFinal / bFinal accumulator of the 3-launch iteration (+ scalars, energy candidates)
             for i in range(k):
-                ba.reduce_local(rbuf.data_ptr())
+                ba.gn_reduce_local(rbuf.data_ptr(), 1e-1)
                 dist.all_reduce(rbuf)
-                ba.solve_reduced(rbuf.data_ptr(), it0 + i, 1e-1, True)
+                ba.gn_solve_reduced(rbuf.data_ptr(), it0 + i, 1e-1)
 
     def fence():
         torch.cuda.synchronize()

@@ -125,6 +125,14 @@ int ldso_ba_sync(ldso_ba_t *h);
 
 /* multi-GPU split of solveSystemF: local accumulate+stitch into the reduce buffer, then (after the
  * caller's all-reduce) the replicated solve + step + precalc. */
+/* Multi-GPU fast path (what bench.py --gpus N runs): the all-reduce buffer IS the HFinal / bFinal accumulator of the
+ * 3-launch iteration.  Layout, ldso_ba_gn_reduce_doubles() doubles: [HFinal lower triangle (8F+4)^2 | bFinal 8F+4 |
+ * 8 scalar sums | P newest-frame energy candidates (value+1)].  Per iteration: ldso_ba_gn_reduce_local (rank-local
+ * accumulate; the H_M / prior / lambda terms are added by the rank that owns point 0) -> all-reduce(sum) by the caller
+ * -> ldso_ba_gn_solve_reduced (replicated solve + step + linearizeAll of the shard + applyRes).  lambda as solveSystemF. */
+size_t ldso_ba_gn_reduce_doubles(ldso_ba_t *h);
+int ldso_ba_gn_reduce_local(ldso_ba_t *h, void *reduce_buf_dev, double lambda);
+int ldso_ba_gn_solve_reduced(ldso_ba_t *h, const void *reduce_buf_dev, int iteration, double lambda);
 int ldso_ba_reduce_local(ldso_ba_t *h, void *reduce_buf_dev);
 int ldso_ba_solve_reduced(ldso_ba_t *h, const void *reduce_buf_dev, int iteration, double lambda, int do_step);
 

@@ -40,6 +40,7 @@ def lib():
         L = C.CDLL(p)
         L.ldso_last_error.restype = C.c_char_p
         L.ldso_ba_reduce_doubles.restype = C.c_size_t
+        L.ldso_ba_gn_reduce_doubles.restype = C.c_size_t
         _LIB = L
     return _LIB
 
@@ -89,6 +90,11 @@ class BA:
             pass
 
     def set_stream(self, stream_ptr: int):
+        """Run the handle on a caller's HIP stream.  The legacy default stream (handle 0, what torch.cuda.current_stream() is
+        unless a torch.cuda.Stream was made current) cannot be passed through the C-ABI (NULL = "own stream") and would not
+        order against the handle's own non-blocking stream: refuse it instead of racing silently."""
+        if not stream_ptr:
+            raise ValueError("pass a non-default HIP stream (e.g. s = torch.cuda.Stream(); torch.cuda.set_stream(s); s.cuda_stream)")
         _chk(self.L.ldso_ba_set_stream(self.h, C.c_void_p(stream_ptr)))
 
     def set_settings(self, s):
@@ -186,6 +192,15 @@ class BA:
 
     def sync(self):
         _chk(self.L.ldso_ba_sync(self.h))
+
+    def gn_reduce_doubles(self):
+        return int(self.L.ldso_ba_gn_reduce_doubles(self.h))
+
+    def gn_reduce_local(self, buf_ptr: int, lam=1e-1):
+        _chk(self.L.ldso_ba_gn_reduce_local(self.h, C.c_void_p(buf_ptr), C.c_double(lam)))
+
+    def gn_solve_reduced(self, buf_ptr: int, iteration, lam=1e-1):
+        _chk(self.L.ldso_ba_gn_solve_reduced(self.h, C.c_void_p(buf_ptr), C.c_int(iteration), C.c_double(lam)))
 
     def reduce_local(self, buf_ptr: int):
         _chk(self.L.ldso_ba_reduce_local(self.h, C.c_void_p(buf_ptr)))

@@ -13,13 +13,15 @@
 #include "lie_dev.h"
 
 hipError_t ba_launch_linearize(const BaPtrs &B, const BaDims &D, const ResSet &cur, const ResSet &nxt, const ldso_settings_t &S, bool hasL, bool fix, int stepMode, const GnInit &gi, hipStream_t st);
-hipError_t ba_launch_reduce(const BaPtrs &B, const BaDims &D, const ResSet &S, const ChunkStarts &chunkStart, bool hasL, int GSP, bool atomicMode, bool hasPrior, float calibPrior, double l1, double il, hipStream_t st);
+hipError_t ba_launch_reduce(const BaPtrs &B, const BaDims &D, const ResSet &S, const ChunkStarts &chunkStart, bool hasL, int GSP, int atomicMode, bool hasPrior, float calibPrior, double l1, double il, hipStream_t st);
 hipError_t ba_launch_gather(const BaPtrs &B, const BaDims &D, const ResSet &S, bool hasL, bool hasPrior, int GSP, double lambda,
                             const ldso_settings_t &St, int mode, double *rbuf, hipStream_t st);
 hipError_t ba_launch_solve(const BaPtrs &B, const BaDims &D, const ResSet &S, const ldso_settings_t &St, const SolveArgs &A, hipStream_t st);
 hipError_t ba_launch_point_step(const BaPtrs &B, const BaDims &D, const ResSet &S, int mode, hipStream_t st);
 hipError_t ba_launch_linearize_marg(const BaPtrs &B, const BaDims &D, const ResSet &cur, const ResSet &nxt, const ldso_settings_t &S, const int32_t *margFlags, hipStream_t st);
 hipError_t ba_launch_marg_frame(const BaPtrs &B, const BaDims &D, int idx, double *work, double *outH, double *outb, hipStream_t st);
+hipError_t ba_launch_acc_init(const BaPtrs &B, const BaDims &D, const GnInit &gi, hipStream_t st);
+hipError_t ba_launch_gn_export(const BaPtrs &B, const BaDims &D, const ResSet &S, double *tail, hipStream_t st);
 hipError_t ba_launch_marg_update(const BaPtrs &B, const BaDims &D, double w, hipStream_t st);
 hipError_t ba_launch_gn_solve(const BaPtrs &B, const BaDims &D, const ResSet &S, const ldso_settings_t &St, const SolveArgs &A, hipStream_t st);
 
@@ -49,6 +51,7 @@ struct ldso_ba {
     bool imgOwned[LD_MAXF] = {false};
     int32_t *d_chunkStart = nullptr;
     int32_t *d_margFlags = nullptr;
+    double *ownAcc = nullptr;          // the handle's own HFinal/bFinal accumulator (B.acc may point at a caller's all-reduce buffer)
     ChunkStarts chunkStarts;
     ldso_rawjac_t *d_dumpJ = nullptr;
     std::vector<int32_t> flat2slot;
@@ -177,7 +180,7 @@ int ldso_ba_create(int device, int w, int h, int max_frames, int max_points, lds
     const size_t GSPmax = (8 * FS + LD_GEXTRA + 15) / 16 * 16;
     DA(B.scPart, (size_t) LD_SC_SPLITS * GSPmax * GSPmax);
     DA(B.sys, 4 * (nmax * nmax + nmax));
-    DA(B.acc, nmax * nmax + nmax);
+    DA(B.acc, nmax * nmax + nmax); H->ownAcc = B.acc;
     DA(B.x, nmax); DA(B.xAd, F * F * 8); DA(B.xc, 4); DA(B.scalars, 16); DA(B.energyLog, 64);
     DA(H->d_dumpJ, P * FS);
     B.dumpJ = nullptr;
@@ -426,7 +429,7 @@ static int launch_solve(ldso_ba *H, const ResSet &S, unsigned flags, int iterati
 }
 static int launch_linearize(ldso_ba *H, bool fix, int stepMode = 0) {
     t_begin(H, 0);
-    GnInit gi; gi.enable = 1; gi.hasPrior = H->hasPrior ? 1 : 0; gi.calibPrior = H->settings.initialCalibHessian;
+    GnInit gi; gi.enable = (H->D.pBegin > 0) ? 2 : 1; gi.hasPrior = H->hasPrior ? 1 : 0; gi.calibPrior = H->settings.initialCalibHessian;
     CHK(ba_launch_linearize(H->B, H->D, H->sets[H->cur], H->sets[H->cur ^ 1], H->settings, H->hasL, fix, stepMode, gi, H->stream));
     t_end(H);
     if (H->profile) { t_begin(H, 4); t_end(H); }      // empty event pair: calibrates the event overhead (which = 4)
@@ -437,7 +440,7 @@ static int launch_reduce(ldso_ba *H, const ResSet &S, bool atomicMode = false, d
     if (H->settings.solverMode & LDSO_SOLVER_USE_GN) lambda = 0;
     if (H->settings.solverMode & LDSO_SOLVER_FIX_LAMBDA) lambda = 1e-5;
     const double l1 = 1 + lambda, il = (double) (1.0f / (1 + lambda));
-    CHK(ba_launch_reduce(H->B, H->D, S, H->chunkStarts, H->hasL, H->GSP, atomicMode, H->hasPrior, H->settings.initialCalibHessian, l1, il, H->stream));
+    CHK(ba_launch_reduce(H->B, H->D, S, H->chunkStarts, H->hasL, H->GSP, atomicMode ? ((H->D.pBegin > 0) ? 2 : 1) : 0, H->hasPrior, H->settings.initialCalibHessian, l1, il, H->stream));
     t_end(H);
     return LDSO_OK;
 }
@@ -560,6 +563,11 @@ int ldso_ba_load_state_backup(ldso_ba_t *H) {
 // k_gn_solve, k_linearize with the point step fused in), no host sync
 static int enqueue_iteration(ldso_ba *H, int iteration, double lambda, int logIdx, bool postOfPrev) {
     const ResSet &S = H->sets[H->cur];
+    if (H->B.acc != H->ownAcc) {      // the accumulator was lent to an all-reduce buffer: take it back (and re-initialise)
+        H->B.acc = H->ownAcc;
+        GnInit gi; gi.enable = 1; gi.hasPrior = H->hasPrior ? 1 : 0; gi.calibPrior = H->settings.initialCalibHessian;
+        CHK(ba_launch_acc_init(H->B, H->D, gi, H->stream));
+    }
     RUN(launch_reduce(H, S, true, lambda));      // accumulates HFinal / bFinal straight into B.acc (no k_gather on this path)
     (void) postOfPrev;
     {
@@ -640,7 +648,7 @@ int ldso_ba_marginalize_points(ldso_ba_t *H, const int32_t *flags, double *HM_ou
     CHK(hipMemcpyAsync(H->d_margFlags, flags, (size_t) H->D.P * 4, hipMemcpyHostToDevice, H->stream));
     const ResSet &scratch = H->sets[H->cur ^ 1];
     CHK(ba_launch_linearize_marg(H->B, H->D, H->sets[H->cur], scratch, H->settings, H->d_margFlags, H->stream));
-    CHK(ba_launch_reduce(H->B, H->D, scratch, H->chunkStarts, /*hasL*/ false, H->GSP, false, false, 0.0f, 1.0, 1.0, H->stream));
+    CHK(ba_launch_reduce(H->B, H->D, scratch, H->chunkStarts, /*hasL*/ false, H->GSP, 0, false, 0.0f, 1.0, 1.0, H->stream));
     CHK(ba_launch_gather(H->B, H->D, scratch, /*hasL*/ false, /*hasPrior*/ false, H->GSP, 0.0, H->settings, 0, nullptr, H->stream));
     CHK(ba_launch_marg_update(H->B, H->D, (double) H->settings.margWeightFac, H->stream));
     H->hasPrior = true;
@@ -664,6 +672,46 @@ int ldso_ba_marginalize_frame(ldso_ba_t *H, int frame_idx, double *HM_out, doubl
     CHK(hipMemcpyAsync(HM_out, oH, nd * nd * 8, hipMemcpyDeviceToHost, H->stream));
     CHK(hipMemcpyAsync(bM_out, ob, nd * 8, hipMemcpyDeviceToHost, H->stream));
     CHK(hipStreamSynchronize(H->stream));
+    return LDSO_OK;
+}
+
+// ---- multi-GPU fast path: the all-reduce buffer IS the HFinal / bFinal accumulator -----------------------------------
+//   layout: [HFinal lower triangle (n*n) | bFinal (n) | 8 scalars | P energy candidates], n = 8F+4
+size_t ldso_ba_gn_reduce_doubles(ldso_ba_t *H) {
+    if (!H) return 0;
+    size_t n = H->D.n;
+    return n * n + n + 8 + (size_t) H->D.P;
+}
+
+int ldso_ba_gn_reduce_local(ldso_ba_t *H, void *buf, double lambda) {
+    REQ(H && buf && H->D.P > 0, "bad arguments");
+    CHK(hipSetDevice(H->device));
+    const ResSet &S = H->sets[H->cur];
+    if (H->B.acc != (double *) buf) {
+        // first use of this buffer: re-point the accumulator at it and give it what the last k_linearize put into the old one
+        H->B.acc = (double *) buf;
+        GnInit gi; gi.enable = (H->D.pBegin > 0) ? 2 : 1; gi.hasPrior = H->hasPrior ? 1 : 0; gi.calibPrior = H->settings.initialCalibHessian;
+        CHK(ba_launch_acc_init(H->B, H->D, gi, H->stream));
+    }
+    RUN(launch_reduce(H, S, true, lambda));
+    const size_t n = H->D.n;
+    CHK(ba_launch_gn_export(H->B, H->D, S, (double *) buf + n * n + n, H->stream));
+    return LDSO_OK;
+}
+
+int ldso_ba_gn_solve_reduced(ldso_ba_t *H, const void *buf, int iteration, double lambda) {
+    REQ(H && buf && H->D.P > 0 && H->B.acc == (const double *) buf, "ldso_ba_gn_solve_reduced: pass the buffer of ldso_ba_gn_reduce_local");
+    CHK(hipSetDevice(H->device));
+    const ResSet &S = H->sets[H->cur];
+    const size_t n = H->D.n;
+    SolveArgs A;
+    A.flags = 0; A.iteration = iteration; A.lambda = lambda; A.hasL = H->hasL ? 1 : 0; A.hasPrior = H->hasPrior ? 1 : 0; A.GSP = H->GSP; A.logIdx = -1;
+    A.reduceOut = nullptr; A.reduceIn = (const double *) buf + n * n + n;
+    t_begin(H, 2);
+    CHK(ba_launch_gn_solve(H->B, H->D, S, H->settings, A, H->stream));
+    t_end(H);
+    RUN(launch_linearize(H, false, 1));
+    H->cur ^= 1;
     return LDSO_OK;
 }
 

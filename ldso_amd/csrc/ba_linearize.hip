@@ -129,7 +129,7 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D,
             double v = 0.0;
             if (e < n * n) {
                 const int i = e / n, j = e % n;
-                if (j <= i) {
+                if (j <= i && gi.enable == 1) {      // enable == 2 (ranks > 0 of a sharded window): zeros only
                     if (gi.hasPrior) v = B.HM[e];
                     if (i == j) { v += (i < 4) ? (double) gi.calibPrior : B.frames[(i - 4) >> 3].prior[(i - 4) & 7]; }
                 }

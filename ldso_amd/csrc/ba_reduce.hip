@@ -197,6 +197,7 @@ __global__ __launch_bounds__(256) void k_reduce(BaPtrs B, BaDims D, ResSet S, Ch
         }
         return;
     }
+    if (atomicMode == 2) return;      // ranks > 0 of a sharded window: the prior / lambda terms are added once, by rank 0
     if (atomicMode) {
         // ------------------------------- extras of the GN fast path --------------------------------------------
         // bExtra = prior * delta_prior + (bM + HM delta), priorDiag   (AccumulatedTopHessian.cc:246-254, EnergyFunctional.cc:279)
@@ -460,13 +461,13 @@ hipError_t ba_launch_gather(const BaPtrs &B, const BaDims &D, const ResSet &S, b
     return hipGetLastError();
 }
 
-hipError_t ba_launch_reduce(const BaPtrs &B, const BaDims &D, const ResSet &S, const ChunkStarts &chunkStart, bool hasL, int GSP, bool atomicMode, bool hasPrior,
+hipError_t ba_launch_reduce(const BaPtrs &B, const BaDims &D, const ResSet &S, const ChunkStarts &chunkStart, bool hasL, int GSP, int atomicMode, bool hasPrior,
                             float calibPrior, double l1, double il, hipStream_t st) {
     const int nT = GSP / 16;
     int nb = D.F * D.F * (hasL ? 2 : 1) + (atomicMode ? SCT_KS * nT * (nT + 1) / 2 + 1 : LD_SC_SPLITS);
     size_t lds = atomicMode ? (size_t) (2 * SCT_SLAB * 16 + SCT_SLAB) * sizeof(float) : (size_t) (SC_SLAB * GSP) * sizeof(float);
     if (lds > 48 * 1024) hipFuncSetAttribute((const void *) k_reduce, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-    hipLaunchKernelGGL(k_reduce, dim3(nb), dim3(256), lds, st, B, D, S, chunkStart, hasL ? 1 : 0, GSP, atomicMode ? 1 : 0, hasPrior ? 1 : 0, calibPrior, l1, il);
+    hipLaunchKernelGGL(k_reduce, dim3(nb), dim3(256), lds, st, B, D, S, chunkStart, hasL ? 1 : 0, GSP, atomicMode, hasPrior ? 1 : 0, calibPrior, l1, il);
     return hipGetLastError();
 }
 
@@ -563,5 +564,27 @@ __global__ __launch_bounds__(256) void k_marg_frame(BaPtrs B, BaDims D, int idx,
 
 hipError_t ba_launch_marg_frame(const BaPtrs &B, const BaDims &D, int idx, double *work, double *outH, double *outb, hipStream_t st) {
     hipLaunchKernelGGL(k_marg_frame, dim3(1), dim3(256), 0, st, B, D, idx, work, outH, outb);
+    return hipGetLastError();
+}
+
+// initialisation of the HFinal / bFinal accumulator outside k_linearize (used when the accumulator is re-pointed at a
+// caller's all-reduce buffer): mode 1 = H_M + diagonal priors (lower triangle), mode 2 = zeros
+__global__ __launch_bounds__(256) void k_acc_init(BaPtrs B, BaDims D, GnInit gi) {
+    const int n = D.n, e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n * n + n) return;
+    double v = 0.0;
+    if (e < n * n && gi.enable == 1) {
+        const int i = e / n, j = e % n;
+        if (j <= i) {
+            if (gi.hasPrior) v = B.HM[e];
+            if (i == j) v += (i < 4) ? (double) gi.calibPrior : B.frames[(i - 4) >> 3].prior[(i - 4) & 7];
+        }
+    }
+    B.acc[e] = v;
+}
+
+hipError_t ba_launch_acc_init(const BaPtrs &B, const BaDims &D, const GnInit &gi, hipStream_t st) {
+    const int N = D.n * D.n + D.n;
+    hipLaunchKernelGGL(k_acc_init, dim3((N + 255) / 256), dim3(256), 0, st, B, D, gi);
     return hipGetLastError();
 }

@@ -425,6 +425,7 @@ struct SolveIO {
     float sumNID;          // out (GN)
     double lambda;         // GN: LM lambda as passed to solveSystem
     int hasPrior;          // GN: HM / bM present
+    const double *redScalars;  // GN, multi-GPU: all-reduced scalar sums (see k_gn_export), nullptr on one GPU
 };
 
 template <int NB, int C, bool GN>
@@ -528,7 +529,8 @@ static __device__ void solve_core(const BaPtrs &B, const BaDims &D, const ResSet
     }
     __syncthreads();
     if (LD_STAMP_ON && GN && tid == 0) B.energyLog[41] = (double) wall_clock64();
-    if (GN) io.sumNID = (float) (io.sRed[0] + io.sRed[1] + io.sRed[2] + io.sRed[3]) / (float) (io.sRed[4] + io.sRed[5] + io.sRed[6] + io.sRed[7]);
+    if (GN) io.sumNID = (io.redScalars != nullptr) ? (float) io.redScalars[3] / (float) io.redScalars[4]
+                                                   : (float) (io.sRed[0] + io.sRed[1] + io.sRed[2] + io.sRed[3]) / (float) (io.sRed[4] + io.sRed[5] + io.sRed[6] + io.sRed[7]);
 
 #pragma nounroll
     for (int k = 0; k < n; k += C) {
@@ -774,7 +776,7 @@ __global__ __launch_bounds__(NT) void k_solve(BaPtrs B, BaDims D, ResSet S, ldso
         // HFinal / bFinal were assembled by k_gather (ba_reduce.hip)
         if (!(fl & SK_FROMREDUCED)) res_counts(B, D, S, sW);
         SolveIO io;
-        io.fr = B.frames; io.cal = B.calib; io.adH = B.adHostF; io.adT = B.adTargetF; io.ldsAd = nullptr; io.sRed = sW; io.sumNID = 0; io.lambda = A.lambda; io.hasPrior = A.hasPrior;
+        io.fr = B.frames; io.cal = B.calib; io.adH = B.adHostF; io.adT = B.adTargetF; io.ldsAd = nullptr; io.sRed = sW; io.sumNID = 0; io.lambda = A.lambda; io.hasPrior = A.hasPrior; io.redScalars = nullptr;
         solve_core_dispatch<false>(B, D, S, St, A.iteration, sm, io);
     }
     if (fl & SK_BACKUP) frames_backup(B.frames, B.calib, F);
@@ -805,12 +807,20 @@ __global__ __launch_bounds__(NT) void k_gn_solve(BaPtrs B, BaDims D, ResSet S, l
     if (blockIdx.x == 1) {
         int *sHist = (int *) (sW + 64);
         int *sI = sHist + 256;
-        post_sums(B, D, S, sW);
-        GSTAMP(10);
-        res_counts(B, D, S, sW);
-        GSTAMP(11);
-        post_thresh(B, D, S, St, nullptr, (float *) (sI + 8), sHist, sI);
-        GSTAMP(12);
+        if (A.reduceIn != nullptr) {
+            // multi-GPU: the sums over all ranks arrive in the all-reduce buffer (k_gn_export layout), the candidates behind them
+            const double *sc = A.reduceIn;
+            if (tid == 0) { B.scalars[0] = sc[0]; B.scalars[1] = sc[1]; B.scalars[2] = sc[2]; B.scalars[6] = sc[3]; B.scalars[7] = sc[4]; B.scalars[9] = sc[5]; B.scalars[10] = sc[6]; }
+            __syncthreads();
+            post_thresh(B, D, S, St, A.reduceIn + 8, (float *) (sI + 8), sHist, sI);
+        } else {
+            post_sums(B, D, S, sW);
+            GSTAMP(10);
+            res_counts(B, D, S, sW);
+            GSTAMP(11);
+            post_thresh(B, D, S, St, nullptr, (float *) (sI + 8), sHist, sI);
+            GSTAMP(12);
+        }
         if (tid == 0 && A.logIdx >= 0 && A.logIdx < 64) B.energyLog[A.logIdx] = B.scalars[0];
         return;
     }
@@ -818,7 +828,7 @@ __global__ __launch_bounds__(NT) void k_gn_solve(BaPtrs B, BaDims D, ResSet S, l
     DevCalib *sCal = (DevCalib *) (sFr + F);
     if (LD_STAMP_ON && tid == 0) B.energyLog[39] = (double) t0_;
     SolveIO io;
-    io.fr = sFr; io.cal = sCal; io.adH = B.adHostF; io.adT = B.adTargetF; io.sRed = sW; io.sumNID = 0; io.lambda = A.lambda; io.hasPrior = A.hasPrior;
+    io.fr = sFr; io.cal = sCal; io.adH = B.adHostF; io.adT = B.adTargetF; io.sRed = sW; io.sumNID = 0; io.lambda = A.lambda; io.hasPrior = A.hasPrior; io.redScalars = A.reduceIn;
     io.ldsAd = (F <= 8) ? (float *) (sCal + 1) : nullptr;
     solve_core_dispatch<true>(B, D, S, St, A.iteration, sm, io);      // + mirrors, backupState, doStepFromBackup
     GSTAMP(4);
@@ -833,6 +843,33 @@ __global__ __launch_bounds__(NT) void k_gn_solve(BaPtrs B, BaDims D, ResSet S, l
         unsigned *gC = (unsigned *) B.calib; const unsigned *lC = (const unsigned *) sCal;
         for (int i = tid; i < (int) (sizeof(DevCalib) / 4); i += NT) gC[i] = lC[i];
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_gn_export (multi-GPU fast path): rank-local scalar sums and newest-frame energy candidates into the tail of the all-reduce
+// buffer  [HFinal lower | bFinal | 8 scalars | P candidates (value+1, 0 = none)]  whose head k_reduce accumulated (B.acc).
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void k_gn_export(BaPtrs B, BaDims D, ResSet S, double *tail) {
+    __shared__ double sW[16];
+    const int tid = threadIdx.x;
+    if (blockIdx.x == 0) {
+        post_sums(B, D, S, sW);
+        res_counts(B, D, S, sW);
+        if (tid == 0) { tail[0] = B.scalars[0]; tail[1] = B.scalars[1]; tail[2] = B.scalars[2]; tail[3] = B.scalars[6]; tail[4] = B.scalars[7];
+                        tail[5] = B.scalars[9]; tail[6] = B.scalars[10]; tail[7] = 0; }
+        return;
+    }
+    const int i = (blockIdx.x - 1) * NT + tid;
+    if (i < D.P) {
+        double v = 0.0;
+        if (i >= D.pBegin && i < D.pEnd) { const float c = S.candE[i]; if (c >= 0.0f) v = (double) c + 1.0; }
+        tail[8 + i] = v;
+    }
+}
+
+hipError_t ba_launch_gn_export(const BaPtrs &B, const BaDims &D, const ResSet &S, double *tail, hipStream_t st) {
+    hipLaunchKernelGGL(k_gn_export, dim3(1 + (D.P + NT - 1) / NT), dim3(NT), 0, st, B, D, S, tail);
+    return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -23,6 +23,13 @@ def reduce_layout(F: int, P: int):
                 bsc=(2 * blk + n * n, 3 * blk), scalars=(3 * blk, 3 * blk + 8), cand=(3 * blk + 8, 3 * blk + 8 + P), size=3 * blk + 8 + P)
 
 
+def gn_reduce_layout(F: int, P: int):
+    """Fast path (ldso_ba_gn_reduce_local): the all-reduce buffer is the HFinal / bFinal accumulator itself."""
+    n = 8 * F + 4
+    blk = n * n + n
+    return dict(n=n, HFinal_lower=(0, n * n), bFinal=(n * n, blk), scalars=(blk, blk + 8), cand=(blk + 8, blk + 8 + P), size=blk + 8 + P)
+
+
 def unpack(buf: np.ndarray, F: int, P: int):
     L = reduce_layout(F, P)
     n = L["n"]

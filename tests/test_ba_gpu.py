@@ -236,6 +236,7 @@ def test_shard_and_sum_invariance(small):
     """points sharded over two 'ranks' on one GPU: the summed reduce buffers equal the unsharded one (the
     multi-GPU all-reduce is a plain sum of these buffers)."""
     import torch
+    ts = torch.cuda.Stream(); torch.cuda.set_stream(ts)          # one non-default stream for torch and the handles
     g = binding.BA.from_window(small)
     g.collect_active(); g.linearize_all(False); g.apply_res()
     nd = g.reduce_doubles()
@@ -260,6 +261,56 @@ def test_shard_and_sum_invariance(small):
     assert blockrel(s[2 * blk:2 * blk + n * n].reshape(n, n), f[2 * blk:2 * blk + n * n].reshape(n, n), 4) < 1e-5   # H_sc
     assert rel(s[3 * blk:3 * blk + 3], f[3 * blk:3 * blk + 3]) < 1e-9                     # energy, counters
     assert np.array_equal(s[3 * blk + 8:], f[3 * blk + 8:])                               # energy candidates: exact
+
+
+@pytest.mark.parametrize("with_prior", [False, True])
+def test_two_rank_fast_path_equals_single_gpu(small, with_prior):
+    """Multi-GPU fast path on one GPU: two handles own the two halves of the points; per iteration their accumulator buffers are
+    summed (what the RCCL all-reduce does) and both run the replicated solve.  After 4 iterations every 'rank' holds the state of
+    the unsharded 3-launch path."""
+    import torch
+    win = synth.add_synthetic_prior(copy.deepcopy(small)) if with_prior else small
+    ts = torch.cuda.Stream(); torch.cuda.set_stream(ts)          # one non-default stream for torch and the handles
+    st = ts.cuda_stream
+    ref = binding.BA.from_window(win, stream=st)
+    ref.collect_active(); ref.linearize_all(False); ref.apply_res()
+    ref.enqueue_gn(0, 4); ref.sync()
+    half = win.P // 2
+    ranks, bufs = [], []
+    for (a, b) in ((0, half), (half, win.P)):
+        g = binding.BA.from_window(win, stream=st)
+        g.set_shard(a, b)
+        g.collect_active(); g.linearize_all(False); g.apply_res()
+        ranks.append(g); bufs.append(torch.zeros(g.gn_reduce_doubles(), dtype=torch.float64, device="cuda"))
+    for it in range(4):
+        for g, b in zip(ranks, bufs):
+            g.gn_reduce_local(b.data_ptr(), 1e-1)
+        tot = bufs[0] + bufs[1]
+        for g, b in zip(ranks, bufs):
+            b.copy_(tot)
+            g.gn_solve_reduced(b.data_ptr(), it, 1e-1)
+    torch.cuda.synchronize()
+    # Tolerances: the fp32 partial sums (chunk / K-split boundaries differ between the sharded and the unsharded run) perturb the
+    # reduced system at 1e-7, the gauge-ill-conditioned solve amplifies that to ~2e-3 in the state (same band as GPU vs oracle);
+    # the energy of the next linearizeAll is insensitive to it.
+    fr = ref.get_frames()
+    for g in ranks:
+        fg = g.get_frames()
+        assert rel(fg["frames"]["state"], fr["frames"]["state"]) < 5e-3
+        assert rel(fg["frames"]["frameEnergyTH"], fr["frames"]["frameEnergyTH"]) < 1e-3
+    idr = ref.get_points()["idepth"]
+    assert rel(ranks[0].get_points()["idepth"][:half], idr[:half]) < 5e-3 and rel(ranks[1].get_points()["idepth"][half:], idr[half:]) < 5e-3
+    rb = torch.zeros(ref.gn_reduce_doubles(), dtype=torch.float64, device="cuda")
+    ref.gn_reduce_local(rb.data_ptr(), 1e-1)
+    for g, b in zip(ranks, bufs):
+        g.gn_reduce_local(b.data_ptr(), 1e-1)
+    torch.cuda.synchronize()
+    n = 8 * win.F + 4
+    blk = n * n + n
+    tot, r = (bufs[0] + bufs[1]).cpu().numpy(), rb.cpu().numpy()
+    assert abs(tot[blk] - r[blk]) <= 1e-4 * r[blk]                                   # energy after 4 iterations
+    assert (tot[blk + 8:] > 0).sum() == (r[blk + 8:] > 0).sum()                      # same set size of newest-frame candidates
+    assert blockrel(np.tril(tot[:n * n].reshape(n, n)), np.tril(r[:n * n].reshape(n, n)), 4) < 5e-3
 
 
 def test_edge_points_without_residuals_and_oob(tiny):
