@@ -154,6 +154,9 @@ int ldso_ba_get_precalc(ldso_ba_t *h, float *out);
 int ldso_ba_get_counts(ldso_ba_t *h, int *resInA, int *resInL);
 /* energies of the linearizeAll calls inside the last ldso_ba_optimize (<= cap values), returns count */
 int ldso_ba_get_energy_log(ldso_ba_t *h, double *out, int cap);
+/* bench.py roofline: average duration (us) of `reps` back-to-back launches of the dominant kernel (k_linearize, applied state
+ * -> scratch set, nothing applied) between one pair of HIP events on the handle's stream. */
+int ldso_ba_time_linearize(ldso_ba_t *h, int reps, double *avg_us);
 /* average device time (ms) per launch of kernel `which` since the last reset (HIP events on the
  * handle's stream); which: 0 = linearize, 1 = reduce+gather, 2 = solve, 3 = point step, 4 = an empty event pair
  * recorded right after every linearize launch (the event overhead to subtract). */

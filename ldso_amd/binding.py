@@ -187,6 +187,11 @@ class BA:
         _chk(self.L.ldso_ba_marginalize_frame(self.h, C.c_int(idx), _p(HM), _p(bM)))
         return HM, bM
 
+    def time_linearize(self, reps=50):
+        us = C.c_double()
+        _chk(self.L.ldso_ba_time_linearize(self.h, C.c_int(reps), C.byref(us)))
+        return us.value
+
     def enqueue_gn(self, first_iteration, iters):
         _chk(self.L.ldso_ba_enqueue_gn(self.h, C.c_int(first_iteration), C.c_int(iters)))
 

@@ -490,6 +490,30 @@ int ldso_ba_kernel_time_ms(ldso_ba_t *H, int which, double *avg_ms, int *launche
 // ---------------------------------------------------------------------------------------------------------
 // the optimisation slice
 // ---------------------------------------------------------------------------------------------------------
+// Average duration of the dominant kernel for bench.py's roofline: `reps` back-to-back launches of k_linearize on the applied
+// state (read set -> scratch set, no point step, nothing applied: idempotent) between ONE pair of HIP events on the handle's
+// stream, so the event overhead is amortised over the launches; includes the ~1.5 us dependent-launch boundary per launch.
+int ldso_ba_time_linearize(ldso_ba_t *H, int reps, double *avg_us) {
+    REQ(H && H->D.P > 0 && reps > 0 && avg_us, "bad arguments");
+    CHK(hipSetDevice(H->device));
+    REQ(!H->pendingApply, "ldso_ba_time_linearize: a linearizeAll result is pending");
+    const bool prof = H->profile;
+    H->profile = false;
+    hipEvent_t a, b;
+    CHK(hipEventCreate(&a)); CHK(hipEventCreate(&b));
+    RUN(launch_linearize(H, false, 0));          // warm
+    CHK(hipEventRecord(a, H->stream));
+    for (int i = 0; i < reps; i++) RUN(launch_linearize(H, false, 0));
+    CHK(hipEventRecord(b, H->stream));
+    CHK(hipEventSynchronize(b));
+    float ms = 0;
+    CHK(hipEventElapsedTime(&ms, a, b));
+    hipEventDestroy(a); hipEventDestroy(b);
+    H->profile = prof;
+    *avg_us = (double) ms * 1e3 / reps;
+    return LDSO_OK;
+}
+
 int ldso_ba_collect_active(ldso_ba_t *H) {
     REQ(H && H->D.P > 0, "no window");
     CHK(hipSetDevice(H->device));
