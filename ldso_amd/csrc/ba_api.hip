@@ -1,5 +1,11 @@
 // ba_api.hip — C-ABI (include/ldso_hip.h) of the windowed bundle adjustment: device memory, the
 // flattening of the window into slot tables / chunks, kernel sequencing, fetchers.
+//
+// Kernel sequences:
+//   fast path (ldso_ba_optimize, ldso_ba_enqueue_gn):  k_reduce(atomic) -> k_gn_solve -> k_linearize(point step fused)   per iteration
+//   multi-GPU fast path:  k_reduce(atomic into the caller's all-reduce buffer) -> k_gn_export -> [all-reduce] -> k_gn_solve -> k_linearize
+//   step-wise entry points (solve_system, do_step, ...):  k_reduce -> k_gather -> k_solve(flags) -> k_point_step -> k_linearize
+//   marginalisation:  k_linearize<MARG> -> k_reduce -> k_gather -> k_marg_update;  k_marg_frame
 #include <hip/hip_runtime.h>
 #include <vector>
 #include <string>

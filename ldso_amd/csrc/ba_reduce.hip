@@ -7,8 +7,11 @@
 // Part B (Schur complement; reference AccumulatedSCHessianSSE::addPoint + stitchDoubleInternal,
 //   .../AccumulatedSCHessian.cc:9-119): with the lifted rows g_p produced by the linearize kernel the
 //   whole F^3-block stitch collapses into one symmetric rank-P update  M = sum_p HdiF_p g_p g_p^T,
-//   computed here with exact-fp32 matrix cores (v_mfma_f32_16x16x4_f32), split over LD_SC_SPLITS
-//   K-ranges.  This is the only MFMA use on the path ("the final small dense Hessian accumulate").
+//   computed here with exact-fp32 matrix cores (v_mfma_f32_16x16x4_f32).  This is the only MFMA use on the path ("the final
+//   small dense Hessian accumulate").  Fast path: one block per (16x16 tile, K-split), results added with fp64 atomics straight
+//   into HFinal / bFinal (B.acc); step-wise path: LD_SC_SPLITS K-range blocks write partial matrices for k_gather.
+// Also here: k_gather (assembly of H_A,b_A,H_L,b_L,H_sc,b_sc,HFinal,bFinal for the step-wise path and the old all-reduce layout),
+// k_marg_update / k_marg_frame (EnergyFunctional::marginalizePointsF tail, marginalizeFrame), k_acc_init.
 #include <hip/hip_runtime.h>
 #include "ba_dev.h"
 

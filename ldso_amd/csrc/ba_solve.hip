@@ -1,21 +1,25 @@
-// ba_solve.hip — the single-workgroup "control" kernel of a Gauss-Newton iteration (gfx950).
+// ba_solve.hip — the "control" side of a Gauss-Newton iteration (gfx950): everything the reference does sequentially on
+// the host between two residual passes, so that an iteration needs no host synchronisation.
 //
-// Everything the reference does sequentially on the host between two residual passes runs here in one
-// launch of one 256-thread block, selected by flag bits, so that a GN iteration needs no host sync:
-//   SK_POST     FullSystem::linearizeAll tail: energy sum + setNewFrameEnergyTH (FullSystem.cc:1762-1793)
-//   SK_ADJ      EnergyFunctional::setAdjointsF (EnergyFunctional.cc:431-489) + gauge nullspace basis
-//               for orthogonalize (EnergyFunctional.cc:685-717, FullSystem.cc:1711-1760)
-//   SK_GATHER   sum pair contributions / Schur partials into H_A,b_A,H_L,b_L,H_sc,b_sc
-//               (AccumulatedTopHessian.h:64-105, AccumulatedSCHessian.h:64-98)
-//   SK_SOLVE    EnergyFunctional::solveSystemF (EnergyFunctional.cc:240-351, default solver mode) and the
-//               frame part of resubstituteF_MT (:491-516)
-//   SK_BACKUP   FullSystem::backupState (FullSystem.cc:1625-1673)
-//   SK_STEP     FullSystem::doStepFromBackup frame/calib part + canbreak (FullSystem.cc:1546-1623)
-//   SK_LOADBK   FullSystem::loadSateBackup frame/calib part (FullSystem.cc:1675-1692)
-//   SK_PRECALC  FullSystem::setPrecalcValues: FrameFramePrecalc::Set for F^2 pairs + setDeltaF
-//               (FullSystem.cc:1423-1431, FrameFramePrecalc.cc:6-35, EnergyFunctional.cc:403-429)
-//   SK_REANCHOR end of optimize(): newest frame setEvalPT(PRE_worldToCam, newStateZero) (FullSystem.cc:833-841)
-// All dense math is fp64 like the reference.  The factorisation is Eigen's LDLT (diagonal pivoting).
+// Two kernels share the device functions below:
+//   k_gn_solve  the forced-accept fast path (ldso_ba_optimize / ldso_ba_enqueue_gn / ldso_ba_gn_solve_reduced): two concurrent
+//               workgroups - block 0: solve_core (+ backupState, doStepFromBackup, canbreak, setPrecalcValues) on an LDS mirror of
+//               the frames; block 1: statistics of the previous linearizeAll (energy sums, setNewFrameEnergyTH, energy log).
+//   k_solve     one workgroup, flag-selected pieces for the step-wise C entry points (LM rejection, debugging, old multi-GPU path):
+//     SK_POST     FullSystem::linearizeAll tail: energy sum (FullSystem.cc:1762-1793);  SK_THRESH: setNewFrameEnergyTH
+//     SK_ADJ      EnergyFunctional::setAdjointsF (EnergyFunctional.cc:431-489) + gauge nullspace basis
+//                 for orthogonalize (EnergyFunctional.cc:685-717, FullSystem.cc:1711-1760)
+//     SK_SOLVE    EnergyFunctional::solveSystemF after the assembly (EnergyFunctional.cc:293-351, default solver mode) and the
+//                 frame part of resubstituteF_MT (:491-516); HFinal / bFinal come from k_gather (ba_reduce.hip)
+//     SK_BACKUP   FullSystem::backupState (FullSystem.cc:1625-1673)
+//     SK_STEP     FullSystem::doStepFromBackup frame/calib part + canbreak (FullSystem.cc:1546-1623)
+//     SK_LOADBK   FullSystem::loadSateBackup frame/calib part (FullSystem.cc:1675-1692)
+//     SK_PRECALC  FullSystem::setPrecalcValues: FrameFramePrecalc::Set for F^2 pairs + setDeltaF
+//                 (FullSystem.cc:1423-1431, FrameFramePrecalc.cc:6-35, EnergyFunctional.cc:403-429)
+//     SK_REANCHOR end of optimize(): newest frame setEvalPT(PRE_worldToCam, newStateZero) (FullSystem.cc:833-841)
+//     SK_COLLECT / SK_LOG / SK_EXPORT / SK_FROMREDUCED: optimize() preamble, energy log, multi-GPU scalar exchange
+// All dense math is fp64 like the reference.  The factorisation is an unpivoted LDL^T of the (diag+10)^-1/2-scaled system (SPD
+// after the scaling; Eigen's LDLT pivots on the diagonal and gives the same solution up to rounding), see solve_core.
 #include <hip/hip_runtime.h>
 #include "ba_dev.h"
 #include "lie_dev.h"
@@ -369,7 +373,7 @@ static __device__ void set_precalc(const BaPtrs &B, const BaDims &D, DevFrame *f
 //
 // Layout: the (n+1)x(n+1) augmented system (row n = right-hand side, so the forward substitution is part of the
 // factorisation) is padded to M = 16*NB and its lower triangle lives in REGISTERS: thread (ty,tx) of the 16x16
-// block owns element (ty+16a, tx+16b) of every tile a >= b.  FOUR columns are eliminated per round:
+// block owns element (ty+16a, tx+16b) of every tile a >= b.  C (= 4) columns are eliminated per round:
 //   phase 1: one thread per row replays the four scalar elimination steps on its 4 panel entries (private copy of
 //            the 4x4 pivot block) -> multipliers F[i][q] = L[i][k+q] and pivot-row values G[j][q] into LDS;
 //   phase 2: every thread applies the rank-4 update v -= sum_q F[i][q] G[j][q] to its register tiles and the
