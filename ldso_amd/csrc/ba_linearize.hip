@@ -44,15 +44,23 @@ __device__ __forceinline__ float sum8(float x) {
     x += dpp_half_mirror(x);
     return x;
 }
-// sum over the 8 lanes in the reference's sequential order ((((x0+x1)+x2)+...)+x7), result in all 8 lanes
+// lane i receives lane i-J of its 16-lane row (0 when that leaves the row)
+template <int J> __device__ __forceinline__ float dpp_row_shr(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x110 + J, 0xF, 0xF, true));
+}
+// sum over the 8 lanes in the reference's sequential order ((((x0+x1)+x2)+...)+x7), result in all 8 lanes.
+// The running sum lives in lane 7 of each group (lanes 7 and 15 of a row): step j adds x_j fetched with row_shr:(7-j) - one
+// v_add_f32_dpp per step whose DPP operand (x) is old, so no hazard padding; other lanes compute values nobody reads.
 __device__ __forceinline__ float seq8(float x, int k, int lane) {
-    float t = x;
-#pragma unroll
-    for (int j = 0; j < 7; j++) {
-        float sh = dpp_row_shr1(t);
-        sh = (k == 0) ? 0.0f : sh;
-        t = sh + x;
-    }
+    (void) k;
+    float t = dpp_row_shr<7>(x);
+    t = t + dpp_row_shr<6>(x);
+    t = t + dpp_row_shr<5>(x);
+    t = t + dpp_row_shr<4>(x);
+    t = t + dpp_row_shr<3>(x);
+    t = t + dpp_row_shr<2>(x);
+    t = t + dpp_row_shr<1>(x);
+    t = t + x;
     return __shfl(t, lane | 7, 64);
 }
 
