@@ -32,6 +32,78 @@ def test_reduce_layout():
     assert np.array_equal(ldist.decode_candidates(c), np.array([2.5, 0.0], np.float32))
 
 
+def _fast_worker(rank, world, port, q):
+    """Fast layout (ldso_ba_gn_reduce_local): every rank contributes its share of the lower triangle of HFinal and of bFinal;
+    the rank that owns point 0 also adds the prior / lambda terms (EnergyFunctional.cc:257-291)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import pyoracle as po, spec_np as sp
+    win = synth.add_synthetic_prior(synth.make_config("tiny"))
+    o = po.OracleWindow(win)
+    o.collect_active(); o.linearize_all(False); o.apply_res()
+    r = o.get_residuals()
+    adH, adT = sp.adjoints_np(win.frames)
+    pb, pe = ldist.shard_range(win.P, rank, world)
+    mine = (win.residuals["point"] >= pb) & (win.residuals["point"] < pe)
+    ex = sp.explicit_system(win, r["J"], r["is_active"].astype(bool) & mine, adH, adT)
+    Hpp = np.maximum(ex["Hpp"], 1e-10)
+    own = np.zeros(win.P, bool); own[pb:pe] = True
+    G = ex["Hcp"][:, own]
+    Hsc = (G / Hpp[own][None, :]) @ G.T
+    bsc = (G / Hpp[own][None, :]) @ ex["bp"][own]
+    L = ldist.gn_reduce_layout(win.F, win.P)
+    n = L["n"]
+    lam = 1e-5                                   # FIX_LAMBDA
+    l1, il = 1 + lam, float(np.float32(1.0) / np.float32(1 + lam))
+    H = ex["Hcc"].copy()
+    H[np.diag_indices(n)] *= l1
+    H -= Hsc * il
+    b = ex["bc"] - bsc
+    if pb == 0:                                  # prior terms once
+        fr = o.get_frames()
+        prior = np.concatenate([np.full(4, float(win.settings["initialCalibHessian"])), fr["frames"]["prior"].ravel()])
+        delta = np.concatenate([fr["calib_value"] - win.calib["value_zero"], (fr["frames"]["state"][:, :8] - fr["frames"]["state_zero"][:, :8]).ravel()])
+        delta_prior = np.concatenate([fr["calib_value"] - win.calib["value_zero"], fr["frames"]["state"][:, :8].ravel()])
+        Hp = win.HM + np.diag(prior)
+        Hp[np.diag_indices(n)] *= l1
+        H += Hp
+        b += prior * delta_prior + win.bM + win.HM @ delta
+    buf = np.zeros(L["size"])
+    buf[L["HFinal_lower"][0]:L["HFinal_lower"][1]] = np.tril(H).ravel()
+    buf[L["bFinal"][0]:L["bFinal"][1]] = b
+    t = torch.from_numpy(buf)
+    dist.all_reduce(t)
+    if rank == 0:
+        q.put(t.numpy().copy())
+    dist.destroy_process_group()
+
+
+def test_two_rank_fast_layout_sums_to_hfinal():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_fast_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    summed = q.get(timeout=120)
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    from oracle import pyoracle as po
+    win = synth.add_synthetic_prior(synth.make_config("tiny"))
+    o = po.OracleWindow(win)
+    o.collect_active(); o.linearize_all(False); o.apply_res(); o.backup_state(); o.solve_system(0)
+    sref = o.get_system()
+    L = ldist.gn_reduce_layout(win.F, win.P)
+    n = L["n"]
+    Hl = summed[L["HFinal_lower"][0]:L["HFinal_lower"][1]].reshape(n, n)
+    ref = np.tril(sref["HFinal"])
+    assert np.abs(Hl - ref).max() <= 1e-6 * np.abs(ref).max()
+    bf = summed[L["bFinal"][0]:L["bFinal"][1]]
+    assert np.abs(bf - sref["bFinal"]).max() <= 1e-6 * np.abs(sref["bFinal"]).max()
+
+
 def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
