@@ -19,7 +19,7 @@
 #include "lie_dev.h"
 
 hipError_t ba_launch_linearize(const BaPtrs &B, const BaDims &D, const ResSet &cur, const ResSet &nxt, const ldso_settings_t &S, bool hasL, bool fix, int stepMode, const GnInit &gi, hipStream_t st);
-hipError_t ba_launch_reduce(const BaPtrs &B, const BaDims &D, const ResSet &S, const ChunkStarts &chunkStart, bool hasL, int GSP, int atomicMode, bool hasPrior, float calibPrior, double l1, double il, hipStream_t st);
+hipError_t ba_launch_reduce(const BaPtrs &B, const BaDims &D, const ResSet &S, const ChunkStarts &chunkStart, bool hasL, int GSP, int atomicMode, bool hasPrior, float calibPrior, double l1, double il, int itCheck, hipStream_t st);
 hipError_t ba_launch_gather(const BaPtrs &B, const BaDims &D, const ResSet &S, bool hasL, bool hasPrior, int GSP, double lambda,
                             const ldso_settings_t &St, int mode, double *rbuf, hipStream_t st);
 hipError_t ba_launch_solve(const BaPtrs &B, const BaDims &D, const ResSet &S, const ldso_settings_t &St, const SolveArgs &A, hipStream_t st);
@@ -427,26 +427,26 @@ static void t_end(ldso_ba *H) { if (H->profile) hipEventRecord(H->timers.back().
 
 static int launch_solve(ldso_ba *H, const ResSet &S, unsigned flags, int iteration, double lambda, int logIdx, double *rout, const double *rin) {
     SolveArgs A;
-    A.flags = flags; A.iteration = iteration; A.lambda = lambda; A.hasL = H->hasL ? 1 : 0; A.hasPrior = H->hasPrior ? 1 : 0; A.GSP = H->GSP; A.logIdx = logIdx; A.reduceOut = rout; A.reduceIn = rin;
+    A.flags = flags; A.iteration = iteration; A.lambda = lambda; A.hasL = H->hasL ? 1 : 0; A.hasPrior = H->hasPrior ? 1 : 0; A.GSP = H->GSP; A.logIdx = logIdx; A.reduceOut = rout; A.reduceIn = rin; A.itCheck = -1;
     t_begin(H, 2);
     CHK(ba_launch_solve(H->B, H->D, S, H->settings, A, H->stream));
     t_end(H);
     return LDSO_OK;
 }
-static int launch_linearize(ldso_ba *H, bool fix, int stepMode = 0) {
+static int launch_linearize(ldso_ba *H, bool fix, int stepMode = 0, int itCheck = -1) {
     t_begin(H, 0);
-    GnInit gi; gi.enable = (H->D.pBegin > 0) ? 2 : 1; gi.hasPrior = H->hasPrior ? 1 : 0; gi.calibPrior = H->settings.initialCalibHessian;
+    GnInit gi; gi.enable = (H->D.pBegin > 0) ? 2 : 1; gi.hasPrior = H->hasPrior ? 1 : 0; gi.calibPrior = H->settings.initialCalibHessian; gi.itCheck = itCheck;
     CHK(ba_launch_linearize(H->B, H->D, H->sets[H->cur], H->sets[H->cur ^ 1], H->settings, H->hasL, fix, stepMode, gi, H->stream));
     t_end(H);
     if (H->profile) { t_begin(H, 4); t_end(H); }      // empty event pair: calibrates the event overhead (which = 4)
     return LDSO_OK;
 }
-static int launch_reduce(ldso_ba *H, const ResSet &S, bool atomicMode = false, double lambda = 0.0) {
+static int launch_reduce(ldso_ba *H, const ResSet &S, bool atomicMode = false, double lambda = 0.0, int itCheck = -1) {
     t_begin(H, 1);
     if (H->settings.solverMode & LDSO_SOLVER_USE_GN) lambda = 0;
     if (H->settings.solverMode & LDSO_SOLVER_FIX_LAMBDA) lambda = 1e-5;
     const double l1 = 1 + lambda, il = (double) (1.0f / (1 + lambda));
-    CHK(ba_launch_reduce(H->B, H->D, S, H->chunkStarts, H->hasL, H->GSP, atomicMode ? ((H->D.pBegin > 0) ? 2 : 1) : 0, H->hasPrior, H->settings.initialCalibHessian, l1, il, H->stream));
+    CHK(ba_launch_reduce(H->B, H->D, S, H->chunkStarts, H->hasL, H->GSP, atomicMode ? ((H->D.pBegin > 0) ? 2 : 1) : 0, H->hasPrior, H->settings.initialCalibHessian, l1, il, itCheck, H->stream));
     t_end(H);
     return LDSO_OK;
 }
@@ -591,24 +591,24 @@ int ldso_ba_load_state_backup(ldso_ba_t *H) {
 
 // one GN iteration = solveSystem + doStepFromBackup + linearizeAll(false) + applyRes: 4 launches (k_reduce, k_gather,
 // k_gn_solve, k_linearize with the point step fused in), no host sync
-static int enqueue_iteration(ldso_ba *H, int iteration, double lambda, int logIdx, bool postOfPrev) {
+static int enqueue_iteration(ldso_ba *H, int iteration, double lambda, int logIdx, bool postOfPrev, int itCheck = -1) {
     const ResSet &S = H->sets[H->cur];
     if (H->B.acc != H->ownAcc) {      // the accumulator was lent to an all-reduce buffer: take it back (and re-initialise)
         H->B.acc = H->ownAcc;
-        GnInit gi; gi.enable = 1; gi.hasPrior = H->hasPrior ? 1 : 0; gi.calibPrior = H->settings.initialCalibHessian;
+        GnInit gi; gi.enable = 1; gi.hasPrior = H->hasPrior ? 1 : 0; gi.calibPrior = H->settings.initialCalibHessian; gi.itCheck = -1;
         CHK(ba_launch_acc_init(H->B, H->D, gi, H->stream));
     }
-    RUN(launch_reduce(H, S, true, lambda));      // accumulates HFinal / bFinal straight into B.acc (no k_gather on this path)
+    RUN(launch_reduce(H, S, true, lambda, itCheck));      // accumulates HFinal / bFinal straight into B.acc (no k_gather on this path)
     (void) postOfPrev;
     {
         SolveArgs A;
         A.flags = 0; A.iteration = iteration; A.lambda = lambda; A.hasL = H->hasL ? 1 : 0; A.hasPrior = H->hasPrior ? 1 : 0; A.GSP = H->GSP; A.logIdx = logIdx;
-        A.reduceOut = nullptr; A.reduceIn = nullptr;
+        A.reduceOut = nullptr; A.reduceIn = nullptr; A.itCheck = itCheck;
         t_begin(H, 2);
         CHK(ba_launch_gn_solve(H->B, H->D, S, H->settings, A, H->stream));
         t_end(H);
     }
-    RUN(launch_linearize(H, false, 1));
+    RUN(launch_linearize(H, false, 1, itCheck));
     H->cur ^= 1;      // forceAcceptStep: applyRes
     return LDSO_OK;
 }
@@ -635,24 +635,29 @@ int ldso_ba_optimize(ldso_ba_t *H, int mnumOptIts, int force_all, float *rmse_ou
     if (!force_all) { if (F < 3) mnumOptIts = 20; if (F < 4) mnumOptIts = 15; }
     REQ(mnumOptIts + 2 < 64, "too many iterations");
     CHK(hipMemsetAsync(H->B.energyLog, 0, 64 * 8, H->stream));
-    RUN(launch_solve(H, H->sets[H->cur], SK_COLLECT));
     H->pendingApply = false;
-    RUN(launch_linearize(H, false));
+    RUN(launch_linearize(H, false, 2));            // stepMode bit 1: resetOOB of the optimize() preamble fused into the first linearizeAll
     H->cur ^= 1;                                   // applyRes
     int done = 0;
     double lambda = 1e-1;
+    {   // no iteration has asked to stop yet
+        const double never = 1e300;
+        CHK(hipMemcpyAsync(H->B.scalars + LD_SC_STOP, &never, sizeof(double), hipMemcpyHostToDevice, H->stream));
+    }
     for (int it = 0; it < mnumOptIts; it++) {
-        RUN(enqueue_iteration(H, it, lambda, it, true));    // POST/THRESH/LOG of the previous linearize ride along
+        // un-forced: the device decides (canbreak && it >= minOptIterations, FullSystem.cc:829); later iterations become no-ops
+        RUN(enqueue_iteration(H, it, lambda, it, true, force_all ? -1 : it));    // POST/THRESH/LOG of the previous linearize ride along
         lambda *= 0.25;
-        done++;
-        if (!force_all) {
-            double sc[16];
-            RUN(read_scalars(H, sc));
-            if (sc[3] != 0.0 && it >= H->settings.minOptIterations) break;
-        }
+    }
+    done = mnumOptIts;
+    if (!force_all) {
+        double sc[16];
+        RUN(read_scalars(H, sc));                   // ONE host round trip for the whole loop
+        if (sc[LD_SC_STOP] < (double) mnumOptIts) done = (int) sc[LD_SC_STOP] + 1;
+        if ((mnumOptIts - done) & 1) H->cur ^= 1;   // the skipped iterations never wrote / applied a residual set
     }
     // tail: statistics of the last linearize, re-anchor the newest frame, adjoints, precalc, linearizeAll(true)
-    RUN(launch_solve(H, H->sets[H->cur], SK_POST | SK_THRESH | SK_LOG | SK_REANCHOR | SK_ADJ | SK_PRECALC, 0, 0, done));
+    RUN(launch_solve(H, H->sets[H->cur], SK_POST | SK_THRESH | SK_LOG | SK_REANCHOR | SK_ADJ | SK_NONULLSPACE | SK_PRECALC, 0, 0, done));
     RUN(launch_linearize(H, true));
     H->cur ^= 1;
     RUN(launch_solve(H, H->sets[H->cur], SK_POST | SK_THRESH | SK_LOG, 0, 0, done + 1));
@@ -678,7 +683,7 @@ int ldso_ba_marginalize_points(ldso_ba_t *H, const int32_t *flags, double *HM_ou
     CHK(hipMemcpyAsync(H->d_margFlags, flags, (size_t) H->D.P * 4, hipMemcpyHostToDevice, H->stream));
     const ResSet &scratch = H->sets[H->cur ^ 1];
     CHK(ba_launch_linearize_marg(H->B, H->D, H->sets[H->cur], scratch, H->settings, H->d_margFlags, H->stream));
-    CHK(ba_launch_reduce(H->B, H->D, scratch, H->chunkStarts, /*hasL*/ false, H->GSP, 0, false, 0.0f, 1.0, 1.0, H->stream));
+    CHK(ba_launch_reduce(H->B, H->D, scratch, H->chunkStarts, /*hasL*/ false, H->GSP, 0, false, 0.0f, 1.0, 1.0, -1, H->stream));
     CHK(ba_launch_gather(H->B, H->D, scratch, /*hasL*/ false, /*hasPrior*/ false, H->GSP, 0.0, H->settings, 0, nullptr, H->stream));
     CHK(ba_launch_marg_update(H->B, H->D, (double) H->settings.margWeightFac, H->stream));
     H->hasPrior = true;
@@ -720,7 +725,7 @@ int ldso_ba_gn_reduce_local(ldso_ba_t *H, void *buf, double lambda) {
     if (H->B.acc != (double *) buf) {
         // first use of this buffer: re-point the accumulator at it and give it what the last k_linearize put into the old one
         H->B.acc = (double *) buf;
-        GnInit gi; gi.enable = (H->D.pBegin > 0) ? 2 : 1; gi.hasPrior = H->hasPrior ? 1 : 0; gi.calibPrior = H->settings.initialCalibHessian;
+        GnInit gi; gi.enable = (H->D.pBegin > 0) ? 2 : 1; gi.hasPrior = H->hasPrior ? 1 : 0; gi.calibPrior = H->settings.initialCalibHessian; gi.itCheck = -1;
         CHK(ba_launch_acc_init(H->B, H->D, gi, H->stream));
     }
     RUN(launch_reduce(H, S, true, lambda));
@@ -736,7 +741,7 @@ int ldso_ba_gn_solve_reduced(ldso_ba_t *H, const void *buf, int iteration, doubl
     const size_t n = H->D.n;
     SolveArgs A;
     A.flags = 0; A.iteration = iteration; A.lambda = lambda; A.hasL = H->hasL ? 1 : 0; A.hasPrior = H->hasPrior ? 1 : 0; A.GSP = H->GSP; A.logIdx = -1;
-    A.reduceOut = nullptr; A.reduceIn = (const double *) buf + n * n + n;
+    A.reduceOut = nullptr; A.reduceIn = (const double *) buf + n * n + n; A.itCheck = -1;
     t_begin(H, 2);
     CHK(ba_launch_gn_solve(H->B, H->D, S, H->settings, A, H->stream));
     t_end(H);
@@ -880,7 +885,7 @@ int ldso_ba_get_jacobians(ldso_ba_t *H, const int32_t *ids, int n, ldso_rawjac_t
         REQ(!H->pendingApply, "ldso_ba_get_jacobians: a linearisation is pending (call ldso_ba_apply_res first, or enable ldso_ba_set_debug_dump)");
         BaPtrs Bd = H->B;
         Bd.dumpJ = H->d_dumpJ;
-        CHK(ba_launch_linearize(Bd, H->D, H->sets[H->cur], H->sets[H->cur ^ 1], H->settings, H->hasL, false, 0, GnInit{0, 0, 0.0f}, H->stream));
+        CHK(ba_launch_linearize(Bd, H->D, H->sets[H->cur], H->sets[H->cur ^ 1], H->settings, H->hasL, false, 0, GnInit{0, 0, 0.0f, -1}, H->stream));
     }
     D2H(all, H->d_dumpJ, (size_t) H->R);
     CHK(hipStreamSynchronize(H->stream));

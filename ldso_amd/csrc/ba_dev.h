@@ -116,7 +116,14 @@ struct ChunkStarts {
 struct GnInit {
     int enable, hasPrior;
     float calibPrior;
+    int itCheck;        // >= 0: un-forced optimize(), iteration index (see LD_SC_STOP); -1 otherwise
 };
+
+// Un-forced optimize() (FullSystem.cc:829: `if (canbreak && iteration >= setting_minOptIterations) break;`) without a host round trip
+// per iteration: k_gn_solve of iteration i stores i in scalars[LD_SC_STOP] when the loop has to end after that iteration, and the
+// kernels of every later iteration return at once (itCheck > scalars[LD_SC_STOP]).  itCheck < 0: forced iterations, no check.
+#define LD_SC_STOP 11
+#define LD_ITER_SKIPPED(B, itCheck) ((itCheck) >= 0 && (double) (itCheck) > (B).scalars[LD_SC_STOP])
 
 // Device-side phase stamps (scripts/dbg_gn.py): build with -DLDSO_STAMPS; they use energyLog[8..60] and therefore corrupt the
 // energy log of optimize() runs with more than 6 iterations - never enable them in a product build.

@@ -93,7 +93,7 @@ static __device__ __forceinline__ void load_point(PtIn<NSG> &q, const BaPtrs &B,
         q.state[g] = cur.state[slot]; q.active[g] = cur.active[slot]; q.energy[g] = cur.energy[slot];
         q.jp[g] = cur.JpJdF[slot * 8 + k]; q.cen[g] = cur.center[slot * 3 + (k < 3 ? k : 2)];
     }
-    if (stepMode) {
+    if (stepMode & 1) {
         q.pstep = B.pstep[p]; q.bdSumF = cur.bdSumF[p]; q.HdiF = cur.HdiF[p]; q.nAct = cur.nActive[p];
 #pragma unroll
         for (int i = 0; i < 4; i++) q.hcd[i] = cur.HcdA[p * 4 + i] + cur.HcdL[p * 4 + i];
@@ -112,6 +112,7 @@ static __device__ __forceinline__ void load_point(PtIn<NSG> &q, const BaPtrs &B,
 template <int NSG, bool HAS_L, bool FIX, bool MARG>
 __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D, ResSet cur, ResSet nxt, ldso_settings_t S, int stepMode, GnInit gi,
                                                              const int32_t *__restrict__ margFlags) {
+    if (LD_ITER_SKIPPED(B, gi.itCheck)) return;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int FS = D.FS, F = D.F;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, s = lane >> 3, k = lane & 7;
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D,
     const float fxi = B.calib->si[0], fyi = B.calib->si[1];
     const float cD0 = B.calib->cDeltaF[0], cD1 = B.calib->cDeltaF[1], cD2 = B.calib->cDeltaF[2], cD3 = B.calib->cDeltaF[3];
     float xc0 = 0, xc1 = 0, xc2 = 0, xc3 = 0;
-    if (stepMode) { xc0 = B.xc[0]; xc1 = B.xc[1]; xc2 = B.xc[2]; xc3 = B.xc[3]; }
+    if (stepMode & 1) { xc0 = B.xc[0]; xc1 = B.xc[1]; xc2 = B.xc[2]; xc3 = B.xc[3]; }
 
     PtIn<NSG> nx;
     int pi = wave;
@@ -178,12 +179,12 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D,
             ahv[u] = in ? B.adHostF[(h + t * F) * 64 + o] : 0.0f;
             atv[u] = in ? B.adTargetF[(h + t * F) * 64 + o] : 0.0f;
         }
-        if (stepMode && tid < FS * 8) xav = ((tid >> 3) < F) ? B.xAd[(size_t) (h * F + (tid >> 3)) * 8 + (tid & 7)] : 0.0f;
+        if ((stepMode & 1) && tid < FS * 8) xav = ((tid >> 3) < F) ? B.xAd[(size_t) (h * F + (tid >> 3)) * 8 + (tid & 7)] : 0.0f;
 #pragma unroll
         for (int u = 0; u < NPB; u++) { const int i = tid + u * 64 * LD_WAVES; if (i < FS * PW) ((float *) sPair)[i] = pv[u]; }
 #pragma unroll
         for (int u = 0; u < NAB; u++) { const int i = tid + u * 64 * LD_WAVES; if (i < FS * 64) { sAdH[i] = ahv[u]; sAdT[i] = atv[u]; } }
-        if (stepMode && tid < FS * 8) sXa[tid] = xav;
+        if ((stepMode & 1) && tid < FS * 8) sXa[tid] = xav;
     }
     if (HAS_L) for (int i = tid; i < LD_WAVES * FS * LD_TOPN; i += blockDim.x) sTopL[i] = 0.0f;
     __syncthreads();
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D,
         const bool flagged = MARG ? (margFlags[p] != 0) : true;
         const float color = q.color, wgt = q.wgt;
         float idp = q.idp, idz = q.idz;
-        if (stepMode) {
+        if (stepMode & 1) {
             // ---- resubstituteFPt for this point, then backupState + doStepFromBackup (stepfacD = 1) ------------
             float step = 0.0f;
             if (q.nAct > 0) {
@@ -250,11 +251,13 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D,
             const int slot = p * FS + t;
             const bool exists = (t < F) && (q.rflat[g] >= 0) && flagged;
             const bool isLin = MARG ? false : (exists && (q.rlin[g] != 0));
-            const int st = exists ? (MARG ? RES_IN : q.state[g]) : RES_OOB;          // MARG: resetOOB()
+            // resetOOB (Residuals.h): MARG always; stepMode bit 1 = the optimize() preamble on every non-linearised residual (FullSystem.cc:744-748)
+            const bool reset = MARG || ((stepMode & 2) && !isLin);
+            const int st = exists ? (reset ? RES_IN : q.state[g]) : RES_OOB;
             const DevPair &pr = sPair[t];
 
             int newState = st;
-            float newEnergy = (exists && !MARG) ? q.energy[g] : 0.0f;
+            float newEnergy = (exists && !reset) ? q.energy[g] : 0.0f;
             float newEnergyWO = -1.0f;
             int activeNew = exists ? q.active[g] : 0;
             float jp = exists ? q.jp[g] : 0.0f;     // this lane's component k of JpJdF

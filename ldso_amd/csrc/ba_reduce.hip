@@ -35,7 +35,8 @@ static __device__ __forceinline__ void acc_add(double *p, double v) { __hip_atom
 template <int NT, int W> static __device__ __forceinline__ void schur_wave(const float *sG, int GSP, int cnt, int wcol, int li, int lk, f32x4 *acc);
 
 __global__ __launch_bounds__(256) void k_reduce(BaPtrs B, BaDims D, ResSet S, ChunkStarts chunkStart, int hasL, int GSP, int atomicMode,
-                                                int hasPrior, float calibPrior, double l1, double il) {
+                                                int hasPrior, float calibPrior, double l1, double il, int itCheck) {
+    if (LD_ITER_SKIPPED(B, itCheck)) return;
     const int F = D.F, FS = D.FS;
     const int nPairBlocks = F * F * (hasL ? 2 : 1);
     const int tid = threadIdx.x;
@@ -465,12 +466,12 @@ hipError_t ba_launch_gather(const BaPtrs &B, const BaDims &D, const ResSet &S, b
 }
 
 hipError_t ba_launch_reduce(const BaPtrs &B, const BaDims &D, const ResSet &S, const ChunkStarts &chunkStart, bool hasL, int GSP, int atomicMode, bool hasPrior,
-                            float calibPrior, double l1, double il, hipStream_t st) {
+                            float calibPrior, double l1, double il, int itCheck, hipStream_t st) {
     const int nT = GSP / 16;
     int nb = D.F * D.F * (hasL ? 2 : 1) + (atomicMode ? SCT_KS * nT * (nT + 1) / 2 + 1 : LD_SC_SPLITS);
     size_t lds = atomicMode ? (size_t) (2 * SCT_SLAB * 16 + SCT_SLAB) * sizeof(float) : (size_t) (SC_SLAB * GSP) * sizeof(float);
     if (lds > 48 * 1024) hipFuncSetAttribute((const void *) k_reduce, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-    hipLaunchKernelGGL(k_reduce, dim3(nb), dim3(256), lds, st, B, D, S, chunkStart, hasL ? 1 : 0, GSP, atomicMode, hasPrior ? 1 : 0, calibPrior, l1, il);
+    hipLaunchKernelGGL(k_reduce, dim3(nb), dim3(256), lds, st, B, D, S, chunkStart, hasL ? 1 : 0, GSP, atomicMode, hasPrior ? 1 : 0, calibPrior, l1, il, itCheck);
     return hipGetLastError();
 }
 

@@ -178,7 +178,7 @@ static __device__ __forceinline__ void aff_from_to(float expF, float expT, float
 }
 
 // setAdjointsF + nullspace basis U (n x 7, columns with dropped singular values zeroed)
-static __device__ void set_adjoints(const BaPtrs &B, const BaDims &D, const ldso_settings_t &St, double *sW /*LDS scratch >= 7*n + 64 doubles*/) {
+static __device__ void set_adjoints(const BaPtrs &B, const BaDims &D, const ldso_settings_t &St, double *sW /*LDS scratch >= 7*n + 64 doubles*/, bool withNullspace) {
     const int tid = threadIdx.x, F = D.F, n = D.n;
     for (int i = tid; i < F * F; i += NT) {
         int h = i % F, t = i / F;      // slot h + t*F
@@ -201,6 +201,7 @@ static __device__ void set_adjoints(const BaPtrs &B, const BaDims &D, const ldso
             B.adHostF[(size_t) i * 64 + e] = (float) AH[e]; B.adTargetF[(size_t) i * 64 + e] = (float) AT[e];
         }
     }
+    if (!withNullspace) { __syncthreads(); return; }
     // ---- N = [6 pose | 1 scale] nullspaces, columns normalised (FullSystem.cc:1711-1760, EF.cc:691-694) -----
     double *N = sW;               // column-major n x 7
     for (int i = tid; i < n * 7; i += NT) {
@@ -287,7 +288,7 @@ static __device__ __forceinline__ void canbreak_final(const BaPtrs &B, const lds
 // state_zero only) is left untouched.
 template <bool FULL>
 static __device__ void set_precalc(const BaPtrs &B, const BaDims &D, DevFrame *fr, DevCalib *cal, const float *adH, const float *adT,
-                                   const ldso_settings_t *cbSt = nullptr, float *cbF = nullptr, float cbNID = 0.0f) {
+                                   const ldso_settings_t *cbSt = nullptr, float *cbF = nullptr, float cbNID = 0.0f, int cbIter = -1) {
     const int tid = threadIdx.x, F = D.F;
     DevCalib &C = *cal;
     if (cbF != nullptr) canbreak_partial(fr, F, cbF);
@@ -308,7 +309,11 @@ static __device__ void set_precalc(const BaPtrs &B, const BaDims &D, DevFrame *f
         for (int i = 0; i < 4; i++) C.cDeltaF[i] = (float) (C.value[i] - C.value_zero[i]);
     }
     __syncthreads();
-    if (cbF != nullptr && tid == 192) canbreak_final(B, *cbSt, cbF, cbNID);
+    if (cbF != nullptr && tid == 192) {
+        canbreak_final(B, *cbSt, cbF, cbNID);
+        // un-forced optimize(): end the loop after this iteration (FullSystem.cc:829)
+        if (cbIter >= 0 && B.scalars[3] != 0.0 && cbIter >= cbSt->minOptIterations && (double) cbIter < B.scalars[LD_SC_STOP]) B.scalars[LD_SC_STOP] = (double) cbIter;
+    }
     for (int i = tid; i < F * F; i += NT) {
         const int h = i / F, t = i % F;
         const DevFrame &fh = fr[h], &ft = fr[t];
@@ -755,7 +760,7 @@ __global__ __launch_bounds__(NT) void k_solve(BaPtrs B, BaDims D, ResSet S, ldso
         }
         __syncthreads();
     }
-    if (fl & SK_ADJ) set_adjoints(B, D, St, sW);
+    if (fl & SK_ADJ) set_adjoints(B, D, St, sW, !(fl & SK_NONULLSPACE));
 
     if (fl & SK_EXPORT) {
         // multi-GPU: rank-local scalar sums ride in the all-reduce buffer
@@ -806,6 +811,7 @@ __global__ __launch_bounds__(NT) void k_gn_solve(BaPtrs B, BaDims D, ResSet S, l
     const int tid = threadIdx.x, F = D.F, n = D.n;
     const int NBsel = (n + 1 <= 64) ? 4 : (n + 1 <= 112) ? 7 : 9;
     double *sW = sm + solve_core_lds_doubles(NBsel, n);      // 64 doubles of scratch
+    if (LD_ITER_SKIPPED(B, A.itCheck)) return;
     const long long t0_ = wall_clock64();
 #define GSTAMP(i) do { if (LD_STAMP_ON && tid == 0) B.energyLog[40 + (i)] = (double) (wall_clock64() - t0_); } while (0)
     if (blockIdx.x == 1) {
@@ -837,7 +843,7 @@ __global__ __launch_bounds__(NT) void k_gn_solve(BaPtrs B, BaDims D, ResSet S, l
     solve_core_dispatch<true>(B, D, S, St, A.iteration, sm, io);      // + mirrors, backupState, doStepFromBackup
     GSTAMP(4);
     GSTAMP(5);
-    set_precalc<false>(B, D, sFr, sCal, io.adH, io.adT, &St, (float *) (sW + 8), io.sumNID);      // + canbreak of doStepFromBackup
+    set_precalc<false>(B, D, sFr, sCal, io.adH, io.adT, &St, (float *) (sW + 8), io.sumNID, A.itCheck);      // + canbreak of doStepFromBackup
     GSTAMP(6);
     // write the mirrors back (all but frameEnergyTH, which block 1 owns)
     {
