@@ -737,7 +737,8 @@ __global__ __launch_bounds__(NT) void k_solve(BaPtrs B, BaDims D, ResSet S, ldso
     const int tid = threadIdx.x, F = D.F, n = D.n;
     const int NBsel = (n + 1 <= 64) ? 4 : (n + 1 <= 112) ? 7 : 9;
     double *sW = sm + solve_core_lds_doubles(NBsel, n);      // scratch: 7n + 64
-    int *sHist = (int *) (sW + 7 * n + 64);  // 256
+    // the threshold pass (histogram + staged candidates) runs before the solve and is over when solve_core starts: it aliases its LDS
+    int *sHist = (int *) sm;                 // 256
     int *sI = sHist + 256;                   // 8 (+ TH_CAP floats of candidate staging behind it)
     const unsigned fl = A.flags;
 
@@ -815,7 +816,8 @@ __global__ __launch_bounds__(NT) void k_gn_solve(BaPtrs B, BaDims D, ResSet S, l
     const long long t0_ = wall_clock64();
 #define GSTAMP(i) do { if (LD_STAMP_ON && tid == 0) B.energyLog[40 + (i)] = (double) (wall_clock64() - t0_); } while (0)
     if (blockIdx.x == 1) {
-        int *sHist = (int *) (sW + 64);
+        double *sW1 = sm;                        // block 1 never runs solve_core: its scratch starts at the base
+        int *sHist = (int *) (sW1 + 64);
         int *sI = sHist + 256;
         if (A.reduceIn != nullptr) {
             // multi-GPU: the sums over all ranks arrive in the all-reduce buffer (k_gn_export layout), the candidates behind them
@@ -824,9 +826,9 @@ __global__ __launch_bounds__(NT) void k_gn_solve(BaPtrs B, BaDims D, ResSet S, l
             __syncthreads();
             post_thresh(B, D, S, St, A.reduceIn + 8, (float *) (sI + 8), sHist, sI);
         } else {
-            post_sums(B, D, S, sW);
+            post_sums(B, D, S, sW1);
             GSTAMP(10);
-            res_counts(B, D, S, sW);
+            res_counts(B, D, S, sW1);
             GSTAMP(11);
             post_thresh(B, D, S, St, nullptr, (float *) (sI + 8), sHist, sI);
             GSTAMP(12);
@@ -925,15 +927,17 @@ static size_t solve_lds_common(const BaDims &D) {
 }
 
 hipError_t ba_launch_solve(const BaPtrs &B, const BaDims &D, const ResSet &S, const ldso_settings_t &St, const SolveArgs &A, hipStream_t st) {
-    size_t lds = solve_lds_common(D) + (7 * (size_t) D.n + 64) * sizeof(double) + (256 + 8) * sizeof(int) + TH_CAP * sizeof(float) + 64;
+    size_t stats = (256 + 8) * sizeof(int) + TH_CAP * sizeof(float), core = solve_lds_common(D);
+    size_t lds = (core > stats ? core : stats) + (7 * (size_t) D.n + 64) * sizeof(double) + 64;
     if (lds > 48 * 1024) hipFuncSetAttribute((const void *) k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
     hipLaunchKernelGGL(k_solve, dim3(1), dim3(NT), lds, st, B, D, S, St, A);
     return hipGetLastError();
 }
 
 hipError_t ba_launch_gn_solve(const BaPtrs &B, const BaDims &D, const ResSet &S, const ldso_settings_t &St, const SolveArgs &A, hipStream_t st) {
-    size_t mirror = (size_t) D.F * sizeof(DevFrame) + sizeof(DevCalib) + (D.F <= 8 ? (size_t) D.F * D.F * 128 * sizeof(float) : 0), stats = (256 + 8) * sizeof(int) + TH_CAP * sizeof(float);
-    size_t lds = solve_lds_common(D) + 64 * sizeof(double) + (mirror > stats ? mirror : stats) + 64;
+    size_t mirror = (size_t) D.F * sizeof(DevFrame) + sizeof(DevCalib) + (D.F <= 8 ? (size_t) D.F * D.F * 128 * sizeof(float) : 0), stats = 64 * sizeof(double) + (256 + 8) * sizeof(int) + TH_CAP * sizeof(float);
+    size_t lds0 = solve_lds_common(D) + 64 * sizeof(double) + mirror + 64;      // block 0
+    size_t lds = lds0 > stats + 64 ? lds0 : stats + 64;                         // block 1 aliases the base
     if (lds > 48 * 1024) hipFuncSetAttribute((const void *) k_gn_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
     hipLaunchKernelGGL(k_gn_solve, dim3(2), dim3(NT), lds, st, B, D, S, St, A);
     return hipGetLastError();
