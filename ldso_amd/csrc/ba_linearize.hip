@@ -194,11 +194,14 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D,
     const int oy = (k == 0) ? -2 : (k == 1 || k == 2) ? -1 : (k == 6) ? 1 : (k == 7) ? 2 : 0;
     const int W = D.w;
 
-    float accA[NSG][LD_TOPN];
+    // top accumulators: slot group 0 in registers; a second group (F > 8) in per-lane LDS cells [91][256] - 182 register
+    // accumulators per lane would spill to scratch memory
+    float accA[LD_TOPN];
+    float *sAcc1 = sXa + FS * 8 + 64;           // [LD_TOPN][64 * LD_WAVES], NSG == 2 only
 #pragma unroll
     for (int g = 0; g < NSG; g++)
 #pragma unroll
-        for (int i = 0; i < LD_TOPN; i++) accA[g][i] = 0.0f;
+        for (int i = 0; i < LD_TOPN; i++) { if (g == 0) accA[i] = 0.0f; else sAcc1[i * 64 * LD_WAVES + tid] = 0.0f; }
     double energySum = 0.0;     // sum of linearize() return values (slot leaders only)
     int nresA = 0, nresL = 0;
     float nidSum = 0.0f;
@@ -413,7 +416,8 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D,
                         float a = v[r], b = v[c];
                         if (r == 10 && c == 12) a *= z10;
                         if (r == 11 && c == 12) a *= z11;
-                        accA[g][tri13(r, c)] = __builtin_fmaf(a, b, accA[g][tri13(r, c)]);
+                        if (g == 0) accA[tri13(r, c)] = __builtin_fmaf(a, b, accA[tri13(r, c)]);
+                        else sAcc1[tri13(r, c) * 64 * LD_WAVES + tid] = __builtin_fmaf(a, b, sAcc1[tri13(r, c) * 64 * LD_WAVES + tid]);
                     }
             }
             // per-slot contributions to the point sums (same value in all 8 lanes of the slot)
@@ -580,7 +584,7 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D,
     for (int g = 0; g < NSG; g++)
 #pragma unroll
         for (int i = 0; i < LD_TOPN; i++) {
-            float a = sum8(accA[g][i]);
+            float a = sum8(g == 0 ? accA[i] : sAcc1[i * 64 * LD_WAVES + tid]);
             if (k == 0) sRed[(wave * FS + g * 8 + s) * LD_TOPN + i] = a;
         }
     // energy / counters: wave reduce, then LDS (own cells: no second barrier)
@@ -620,7 +624,8 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D,
 // launcher
 // ---------------------------------------------------------------------------------------------------------
 size_t ba_linearize_lds_bytes(int FS, bool hasL) {
-    size_t fl = (size_t) FS * (sizeof(DevPair) / 4) + 2 * (size_t) FS * 64 + (size_t) LD_WAVES * FS * LD_TOPN + (hasL ? (size_t) LD_WAVES * FS * LD_TOPN : 0) + (size_t) FS * 8 + 64;
+    size_t fl = (size_t) FS * (sizeof(DevPair) / 4) + 2 * (size_t) FS * 64 + (size_t) LD_WAVES * FS * LD_TOPN + (hasL ? (size_t) LD_WAVES * FS * LD_TOPN : 0) + (size_t) FS * 8 + 64 +
+                (FS > 8 ? (size_t) LD_TOPN * 64 * LD_WAVES : 0);
     return fl * sizeof(float) + 256;
 }
 
