@@ -66,6 +66,10 @@ int ldso_ba_set_image(ldso_ba_t *h, int slot, const float *dI_level0_host);
 /* Same, the pyramid level already being device-resident (zero-copy hand-over, not retained after the
  * next ldso_ba_set_image* on that slot). */
 int ldso_ba_set_image_device(ldso_ba_t *h, int slot, const void *dI_level0_dev);
+/* The same slot from the RAW level-0 irradiance (w*h floats): FrameHessian::makeImages level 0 (FrameHessian.cc:44-113: copy +
+ * central-difference gradients) runs on the device, 4 instead of 12 bytes per pixel cross PCIe.  ldso_ba_get_image: test fetch. */
+int ldso_ba_set_image_raw(ldso_ba_t *h, int slot, const float *irradiance);
+int ldso_ba_get_image(ldso_ba_t *h, int slot, float *out_w_h_3);
 
 /* Describe the window: EnergyFunctional::frames / allPoints / p->residuals after makeIDX
  * (EnergyFunctional.cc:380-401).  image_slot[f] = slot holding frame f's image.  linJ / lin_res_toZeroF
@@ -181,6 +185,10 @@ int ldso_tr_set_ref(ldso_tracker_t *t, const float *const *ref_dIp, float ref_af
                     const float *pts, int n);
 /* the frame to be tracked (FrameHessian::dIp[0..levels-1]) */
 int ldso_tr_set_new_frame(ldso_tracker_t *t, const float *const *new_dIp, float exposure);
+/* The new frame from its RAW level-0 irradiance (w*h floats): the whole FrameHessian::makeImages pyramid (2x2 mean pooling +
+ * gradients per level, FrameHessian.cc:44-113) is built on the device.  ldso_tr_get_new_frame_level: test fetch of one level. */
+int ldso_tr_set_new_frame_image(ldso_tracker_t *t, const float *irradiance, float exposure);
+int ldso_tr_get_new_frame_level(ldso_tracker_t *t, int lvl, float *out);
 /* CoarseTracker::calcRes (CoarseTracker.cc:440-572). rs_out = Vec6; returns buf_warped_n via n_warped. */
 int ldso_tr_calc_res(ldso_tracker_t *t, int lvl, const double T_ref2new[12], float aff_a, float aff_b, float cutoffTH,
                      double rs_out[6], int *n_warped);

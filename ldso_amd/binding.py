@@ -105,6 +105,15 @@ class BA:
         a = np.ascontiguousarray(dI0, np.float32)
         _chk(self.L.ldso_ba_set_image(self.h, C.c_int(slot), _p(a)))
 
+    def set_image_raw(self, slot, irradiance):
+        a = np.ascontiguousarray(irradiance, np.float32)
+        _chk(self.L.ldso_ba_set_image_raw(self.h, C.c_int(slot), _p(a)))
+
+    def get_image(self, slot):
+        out = np.zeros((self.hh, self.w, 3), np.float32)
+        _chk(self.L.ldso_ba_get_image(self.h, C.c_int(slot), _p(out)))
+        return out
+
     def set_window(self, image_slots, points, residuals, lin_J=None, lin_rtz=None):
         sl = np.ascontiguousarray(image_slots, np.int32)
         pts = np.ascontiguousarray(points)
@@ -315,6 +324,15 @@ class Tracker:
     def set_new_frame(self, pyr, exposure=1.0):
         arr, keep = self._pyr(pyr)
         _chk(self.L.ldso_tr_set_new_frame(self.h, arr, C.c_float(exposure)))
+
+    def set_new_frame_image(self, irradiance, exposure=1.0):
+        a = np.ascontiguousarray(irradiance, np.float32)
+        _chk(self.L.ldso_tr_set_new_frame_image(self.h, _p(a), C.c_float(exposure)))
+
+    def get_new_frame_level(self, lvl):
+        out = np.zeros((self.hh >> lvl, self.w >> lvl, 3), np.float32)
+        _chk(self.L.ldso_tr_get_new_frame_level(self.h, C.c_int(lvl), _p(out)))
+        return out
 
     def pc(self, lvl):
         n = C.c_int()

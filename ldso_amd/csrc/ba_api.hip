@@ -57,6 +57,7 @@ struct ldso_ba {
     bool imgOwned[LD_MAXF] = {false};
     int32_t *d_chunkStart = nullptr;
     int32_t *d_margFlags = nullptr;
+    float *d_color = nullptr;          // irradiance staging of ldso_ba_set_image_raw
     double *ownAcc = nullptr;          // the handle's own HFinal/bFinal accumulator (B.acc may point at a caller's all-reduce buffer)
     ChunkStarts chunkStarts;
     ldso_rawjac_t *d_dumpJ = nullptr;
@@ -203,6 +204,7 @@ int ldso_ba_destroy(ldso_ba_t *H) {
     hipDeviceSynchronize();
     for (void *p : H->allocs) hipFree(p);
     for (int i = 0; i < LD_MAXF; i++) if (H->imgOwned[i] && H->imgSlots[i]) hipFree(H->imgSlots[i]);
+    if (H->d_color) hipFree(H->d_color);
     for (auto &t : H->timers) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
     if (H->ownStream && H->stream) hipStreamDestroy(H->stream);
     delete H;
@@ -235,6 +237,31 @@ int ldso_ba_set_image(ldso_ba_t *H, int slot, const float *src) {
     size_t bytes = (size_t) H->w * H->h * 3 * sizeof(float);
     if (!H->imgOwned[slot]) { void *p; CHK(hipMalloc(&p, bytes)); H->imgSlots[slot] = (float *) p; H->imgOwned[slot] = true; }
     CHK(hipMemcpyAsync(H->imgSlots[slot], src, bytes, hipMemcpyHostToDevice, H->stream));
+    CHK(hipStreamSynchronize(H->stream));
+    return LDSO_OK;
+}
+
+hipError_t img_launch_make_images(const float *d_color, int w, int h, int levels, float *const *d_levels, hipStream_t st);
+
+// level-0 image of a key frame from its raw irradiance: FrameHessian::makeImages level 0 (FrameHessian.cc:44-113) on the device
+int ldso_ba_set_image_raw(ldso_ba_t *H, int slot, const float *irradiance) {
+    REQ(H && irradiance && slot >= 0 && slot < H->maxF, "ldso_ba_set_image_raw: bad arguments");
+    CHK(hipSetDevice(H->device));
+    const size_t n = (size_t) H->w * H->h;
+    if (!H->imgOwned[slot]) { void *q; CHK(hipMalloc(&q, n * 12)); H->imgSlots[slot] = (float *) q; H->imgOwned[slot] = true; }
+    if (!H->d_color) CHK(hipMalloc(&H->d_color, n * sizeof(float)));
+    CHK(hipMemcpyAsync(H->d_color, irradiance, n * sizeof(float), hipMemcpyHostToDevice, H->stream));
+    float *lv[1] = {H->imgSlots[slot]};
+    CHK(img_launch_make_images(H->d_color, H->w, H->h, 1, lv, H->stream));
+    CHK(hipStreamSynchronize(H->stream));
+    return LDSO_OK;
+}
+
+// debug / test fetch of a key-frame image slot (w*h*3 floats)
+int ldso_ba_get_image(ldso_ba_t *H, int slot, float *out) {
+    REQ(H && out && slot >= 0 && slot < H->maxF && H->imgSlots[slot], "ldso_ba_get_image: bad arguments");
+    CHK(hipSetDevice(H->device));
+    CHK(hipMemcpyAsync(out, H->imgSlots[slot], (size_t) H->w * H->h * 12, hipMemcpyDeviceToHost, H->stream));
     CHK(hipStreamSynchronize(H->stream));
     return LDSO_OK;
 }

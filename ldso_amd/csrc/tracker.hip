@@ -596,6 +596,7 @@ struct ldso_tracker {
     std::vector<void *> allocs;
     float *d_newImg[TR_MAXL] = {nullptr}, *d_refImg[TR_MAXL] = {nullptr};
     float *d_pts = nullptr;
+    float *d_color = nullptr;          // level-0 irradiance staging of ldso_tr_set_new_frame_image
     int ptsCap = 0;
     int *d_total = nullptr;
     double *d_T = nullptr, *d_acc = nullptr;
@@ -653,6 +654,7 @@ int ldso_tr_destroy(ldso_tracker_t *H) {
     hipDeviceSynchronize();
     for (void *p : H->allocs) hipFree(p);
     if (H->d_pts) hipFree(H->d_pts);
+    if (H->d_color) hipFree(H->d_color);
     if (H->ownStream && H->stream) hipStreamDestroy(H->stream);
     delete H;
     return LDSO_OK;
@@ -747,6 +749,31 @@ int ldso_tr_set_new_frame(ldso_tracker_t *H, const float *const *new_dIp, float 
         CHK(hipMemcpyAsync(H->d_newImg[l], new_dIp[l], bytes, hipMemcpyHostToDevice, H->stream));
     }
     H->P.new_exposure = exposure;
+    CHK(hipStreamSynchronize(H->stream));
+    return LDSO_OK;
+}
+
+hipError_t img_launch_make_images(const float *d_color, int w, int h, int levels, float *const *d_levels, hipStream_t st);
+
+// CoarseTracker's new frame from the raw level-0 irradiance: FrameHessian::makeImages runs on the device (images.hip), one
+// w*h float upload instead of the 12-byte AoS pyramid
+int ldso_tr_set_new_frame_image(ldso_tracker_t *H, const float *irradiance, float exposure) {
+    REQ(H && irradiance, "ldso_tr_set_new_frame_image: bad arguments");
+    CHK(hipSetDevice(H->device));
+    const size_t n = (size_t) H->w * H->h;
+    if (!H->d_color) CHK(hipMalloc(&H->d_color, n * sizeof(float)));
+    CHK(hipMemcpyAsync(H->d_color, irradiance, n * sizeof(float), hipMemcpyHostToDevice, H->stream));
+    CHK(img_launch_make_images(H->d_color, H->w, H->h, H->levels, H->d_newImg, H->stream));
+    H->P.new_exposure = exposure;
+    CHK(hipStreamSynchronize(H->stream));
+    return LDSO_OK;
+}
+
+// debug / test fetch of a level of the new frame's pyramid ((w>>lvl)*(h>>lvl)*3 floats)
+int ldso_tr_get_new_frame_level(ldso_tracker_t *H, int lvl, float *out) {
+    REQ(H && out && lvl >= 0 && lvl < H->levels, "ldso_tr_get_new_frame_level: bad arguments");
+    CHK(hipSetDevice(H->device));
+    CHK(hipMemcpyAsync(out, H->d_newImg[lvl], (size_t) H->P.lv[lvl].w * H->P.lv[lvl].h * 3 * sizeof(float), hipMemcpyDeviceToHost, H->stream));
     CHK(hipStreamSynchronize(H->stream));
     return LDSO_OK;
 }

@@ -87,3 +87,26 @@ def test_abort_on_min_res():
     ro = o.track(np.eye(4), a, b, sc["levels"] - 1, mr)
     rg = g.track(np.eye(4), a, b, sc["levels"] - 1, mr)
     assert not ro["ok"] and not rg["ok"]
+
+
+def test_make_images_on_device_bit_exact():
+    """a16 FrameHessian::makeImages on the device (images.hip) against the oracle restatement: every level of the pyramid of the
+    tracker's new frame, and level 0 of a bundle-adjustment image slot, bit for bit (rows 0 / h-1 keep zero gradients)."""
+    sc = tracker_scenario("small")
+    win = sc["win"]
+    color = np.ascontiguousarray(sc["new_pyr"][0][:, :, 0])
+    ref = po.make_images(color, sc["levels"])
+    g = binding.Tracker(win.w, win.h, sc["levels"], win.settings, win.calib)
+    g.set_new_frame_image(color, 1.0)
+    for l in range(sc["levels"]):
+        assert np.array_equal(g.get_new_frame_level(l), ref[l]), l
+        assert np.array_equal(ref[l], sc["new_pyr"][l])          # and it is what the synthetic generator stored
+    ba = binding.BA(win.w, win.h, 2, 4)
+    ba.set_image_raw(1, color)
+    assert np.array_equal(ba.get_image(1), ref[0])
+    # tracking from the device-built pyramid gives the same result as from the uploaded one
+    o, g2 = make_pair(sc)
+    g.set_ref(sc["ref_pyr"], sc["ref_aff"][0], sc["ref_aff"][1], 1.0, sc["pts"])
+    a, b = sc["new_aff"]
+    r1 = g.track(np.eye(4), a, b, sc["levels"] - 1); r2 = g2.track(np.eye(4), a, b, sc["levels"] - 1)
+    assert np.array_equal(r1["T"], r2["T"]) and r1["iterations"] == r2["iterations"]
