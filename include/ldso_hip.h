@@ -201,6 +201,12 @@ int ldso_tr_track(ldso_tracker_t *t, double T_ref2new_inout[12], float aff_inout
  * concurrently, one workgroup each (nhyp <= 128).  Arrays are nhyp-major. */
 int ldso_tr_track_batch(ldso_tracker_t *t, int nhyp, double *T_ref2new_inout, float *aff_inout, int coarsestLvl, const double minResForAbort[5],
                         double *lastResiduals_out, double *lastFlowIndicators_out, int *ok_out, int *iterations_out);
+/* The hypothesis loop of FullSystem::trackNewCoarse (FullSystem.cc:319-356) replayed on the results of one
+ * ldso_tr_track_batch call that ran every try with minRes = NaN: reproduces the sequential accept / abort / early-exit decisions
+ * (a try counts as aborted at the level where its residual exceeds 1.5 x the `achievedRes` of the tries before it).  Host only.
+ * best_out = index of the winning try or -1; tries_consumed_out = how many tries the sequential loop would have run. */
+int ldso_tr_select_hypothesis(int nhyp, int coarsestLvl, const double *lastResiduals /*nhyp*5*/, const int *ok /*nhyp*/, double lastCoarseRMSE0,
+                              double reTrackThreshold, int *best_out, int *tries_consumed_out, double achievedRes_out[5]);
 int ldso_tr_get_pc(ldso_tracker_t *t, int lvl, float *u, float *v, float *idepth, float *color, int *n);
 
 #ifdef __cplusplus

@@ -334,6 +334,15 @@ class Tracker:
         _chk(self.L.ldso_tr_get_new_frame_level(self.h, C.c_int(lvl), _p(out)))
         return out
 
+    def select_hypothesis(self, batch, coarsest, last_coarse_rmse0=float("nan"), retrack_threshold=1.5):
+        lr = np.ascontiguousarray(batch["lastResiduals"], np.float64)
+        ok = np.ascontiguousarray(batch["ok"], np.int32)
+        best, tries = C.c_int(), C.c_int()
+        ach = np.zeros(5)
+        _chk(self.L.ldso_tr_select_hypothesis(C.c_int(len(ok)), C.c_int(coarsest), _p(lr), _p(ok), C.c_double(last_coarse_rmse0), C.c_double(retrack_threshold),
+                                              C.byref(best), C.byref(tries), _p(ach)))
+        return best.value, tries.value, ach
+
     def pc(self, lvl):
         n = C.c_int()
         _chk(self.L.ldso_tr_get_pc(self.h, C.c_int(lvl), None, None, None, None, C.byref(n)))

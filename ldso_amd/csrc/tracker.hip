@@ -844,6 +844,37 @@ int ldso_tr_track_batch(ldso_tracker_t *H, int nhyp, double *T_inout /*nhyp*12*/
     return LDSO_OK;
 }
 
+// The hypothesis loop of FullSystem::trackNewCoarse (FullSystem.cc:319-356) replayed on the results of ONE
+// ldso_tr_track_batch call that ran every try to the end (minRes = NaN): try i is accepted / aborted exactly as the
+// sequential loop would have done with the `achievedRes` of the tries before it - a try whose residual on some level exceeds
+// 1.5 x achievedRes there counts as aborted at that level (finer levels NaN, trackingIsGood = false), `achievedRes` is taken
+// over "always" once one try was good, and the loop stops at the first try with achievedRes[0] < lastCoarseRMSE0 *
+// reTrackThreshold.  Pure host function (no device work).  best = -1: tracking failed entirely.
+int ldso_tr_select_hypothesis(int nhyp, int coarsestLvl, const double *lastResiduals /*nhyp*5*/, const int *ok /*nhyp*/, double lastCoarseRMSE0,
+                              double reTrackThreshold, int *best, int *tries_consumed, double achievedRes_out[5]) {
+    if (nhyp < 0 || coarsestLvl < 0 || coarsestLvl > 4 || (nhyp > 0 && (!lastResiduals || !ok)) || !best) { ldso_set_error("ldso_tr_select_hypothesis: bad arguments"); return LDSO_E_INVALID; }
+    double achieved[5] = {NAN, NAN, NAN, NAN, NAN};
+    bool haveOneGood = false;
+    int tries = 0, win = -1;
+    for (int i = 0; i < nhyp; i++) {
+        double lr[5] = {NAN, NAN, NAN, NAN, NAN};
+        bool good = ok[i] != 0;
+        for (int lvl = coarsestLvl; lvl >= 0; lvl--) {
+            lr[lvl] = lastResiduals[i * 5 + lvl];
+            if (lr[lvl] > 1.5 * achieved[lvl]) { good = false; break; }          // CoarseTracker.cc:193-200 (false with a NaN threshold)
+        }
+        tries++;
+        if (good && std::isfinite((float) lr[0]) && !(lr[0] >= achieved[0])) { win = i; haveOneGood = true; }
+        if (haveOneGood)
+            for (int l = 0; l < 5; l++) if (!std::isfinite((float) achieved[l]) || achieved[l] > lr[l]) achieved[l] = lr[l];
+        if (haveOneGood && achieved[0] < lastCoarseRMSE0 * reTrackThreshold) break;
+    }
+    *best = win;
+    if (tries_consumed) *tries_consumed = tries;
+    if (achievedRes_out) for (int l = 0; l < 5; l++) achievedRes_out[l] = achieved[l];
+    return LDSO_OK;
+}
+
 int ldso_tr_track(ldso_tracker_t *H, double T[12], float aff[2], int coarsestLvl, const double minRes[5], double lastResiduals[5], double flow[3], int *ok, int *iterations) {
     return ldso_tr_track_batch(H, 1, T, aff, coarsestLvl, minRes, lastResiduals, flow, ok, iterations);
 }

@@ -110,3 +110,39 @@ def test_make_images_on_device_bit_exact():
     a, b = sc["new_aff"]
     r1 = g.track(np.eye(4), a, b, sc["levels"] - 1); r2 = g2.track(np.eye(4), a, b, sc["levels"] - 1)
     assert np.array_equal(r1["T"], r2["T"]) and r1["iterations"] == r2["iterations"]
+
+
+def test_batched_hypotheses_reproduce_sequential_loop():
+    """SURVEY §8(f)-1: the try loop of FullSystem::trackNewCoarse (FullSystem.cc:319-356) run sequentially with the growing
+    `achievedRes` abort thresholds, against ONE batched launch + ldso_tr_select_hypothesis: same winner, same number of tries,
+    same achievedRes - for an early-exit threshold that stops the loop and for one that never does."""
+    sc = tracker_scenario("small")
+    o, g = make_pair(sc)
+    a, b = sc["new_aff"]
+    coarsest = sc["levels"] - 1
+    rng = np.random.default_rng(3)
+    # a bad first guess, some mediocre ones, the truth, more mediocre ones
+    guesses = [synth.se3_exp([0.05, -0.03, 0.02, 0.01, -0.012, 0.008])]
+    guesses += [synth.se3_exp(rng.normal(0, 1, 6) * [0.01, 0.01, 0.01, 0.003, 0.003, 0.003]) for _ in range(4)]
+    guesses += [sc["T_true"]]
+    guesses += [synth.se3_exp(rng.normal(0, 1, 6) * [0.02, 0.02, 0.02, 0.005, 0.005, 0.005]) for _ in range(4)]
+    batch = g.track_batch(guesses, [(a, b)] * len(guesses), coarsest)
+    for last_rmse0, thr in ((float("nan"), 1.5), (1e9, 1.5)):
+        # sequential reference loop on the same device tracker
+        achieved = np.full(5, np.nan); have, win, tries = False, -1, 0
+        for i, T in enumerate(guesses):
+            r = g.track(T, a, b, coarsest, achieved.copy())
+            tries += 1
+            lr = np.asarray(r["lastResiduals"], np.float64)
+            if r["ok"] and np.isfinite(np.float32(lr[0])) and not (lr[0] >= achieved[0]):
+                win, have = i, True
+            if have:
+                for l in range(5):
+                    if not np.isfinite(np.float32(achieved[l])) or achieved[l] > lr[l]:
+                        achieved[l] = lr[l]
+            if have and achieved[0] < last_rmse0 * thr:
+                break
+        best, used, ach = g.select_hypothesis(batch, coarsest, last_rmse0, thr)
+        assert best == win and used == tries
+        assert np.array_equal(np.isnan(ach), np.isnan(achieved)) and np.allclose(ach[~np.isnan(ach)], achieved[~np.isnan(achieved)], rtol=0, atol=0)
+    assert win >= 0
