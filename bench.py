@@ -176,6 +176,10 @@ def main():
                 out["tracker"] = tracker_line()
             except Exception as e:          # the tracker line is informational (BASELINE configs[1]); never fail the BA metric on it
                 out["tracker"] = {"error": repr(e)}
+            try:
+                out["tracer"] = tracer_line()
+            except Exception as e:
+                out["tracer"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -216,6 +220,27 @@ def tracker_line():
     return {"workload": f"C2: {win.w}x{win.h} pair, {sc['levels']} levels, {len(sc['pts'])} reference points",
             "gpu_track_ms": round(tg * 1e3, 4), "lm_iterations": int(rg["iterations"]), "gpu_track_batch20_ms": round(tb * 1e3, 4),
             "cpu_oracle_track_ms": round(to * 1e3, 4), "cpu_cores": 1}
+
+
+def tracer_line():
+    """Informational (SURVEY §8f rank 3): FullSystem::traceNewCoarse on 7000 fresh immature points, 640x480 - one ldso_trace_on call
+    (points resident, pose upload + launch + count read-back) next to the oracle on one core."""
+    from ldso_amd import synth, binding
+    from oracle import pyoracle as po
+    win = synth.make_config("C3", extra_frames=1)
+    pts, _ = synth.make_immature_points(win, 1000)
+    KRKi, Kt, aff = synth.trace_poses(win, win.F)
+    img = win.images[win.F][0]
+    g = binding.Tracer(win.w, win.h, len(pts))
+    g.set_frame(img)
+    tg = []
+    for _ in range(10):
+        g.set_points(pts)
+        t0 = time.perf_counter(); c = g.trace_on(KRKi, Kt, aff); tg.append(time.perf_counter() - t0)
+    ref = pts.copy()
+    t0 = time.perf_counter(); po.trace_on(ref, img, KRKi, Kt, aff); to = time.perf_counter() - t0
+    return {"workload": f"{len(pts)} fresh immature points on {win.F} key frames, {win.w}x{win.h}", "gpu_trace_on_ms": round(float(np.median(tg[2:])) * 1e3, 4),
+            "cpu_oracle_ms": round(to * 1e3, 3), "cpu_cores": 1, "status_counts_good_oob_outlier": [int(c[0]), int(c[1]), int(c[2])]}
 
 
 def cpu_baseline(win):

@@ -209,6 +209,25 @@ int ldso_tr_select_hypothesis(int nhyp, int coarsestLvl, const double *lastResid
                               double reTrackThreshold, int *best_out, int *tries_consumed_out, double achievedRes_out[5]);
 int ldso_tr_get_pc(ldso_tracker_t *t, int lvl, float *u, float *v, float *idepth, float *color, int *n);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Immature-point tracing: FullSystem::traceNewCoarse (FullSystem.cc:1012-1050) = ImmaturePoint::traceOn
+ * (src/internal/ImmaturePoint.cc:47-310) for every immature point of the window against a new frame, one launch.
+ * The points stay resident on the device between frames (set once per key frame, traced on every frame).
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct ldso_tracer ldso_tracer_t;
+int ldso_trace_settings_default(ldso_trace_settings_t *s);
+int ldso_trace_create(int device, int w, int h, int max_points, ldso_tracer_t **out);
+int ldso_trace_destroy(ldso_tracer_t *t);
+int ldso_trace_set_settings(ldso_tracer_t *t, const ldso_trace_settings_t *s);
+int ldso_trace_set_points(ldso_tracer_t *t, int n, const ldso_immature_t *points);
+int ldso_trace_get_points(ldso_tracer_t *t, ldso_immature_t *points_out);
+/* the new frame: level-0 image as FrameHessian::dIp[0] (w*h*3 floats), or the raw irradiance (makeImages on the device) */
+int ldso_trace_set_frame(ldso_tracer_t *t, const float *dI_level0);
+int ldso_trace_set_frame_raw(ldso_tracer_t *t, const float *irradiance);
+/* per host key frame h < n_hosts (FullSystem.cc:1025-1032): KRKi[h] = K R K^-1 (row-major 3x3), Kt[h] = K t,
+ * aff[h] = AffLight::fromToVecExposure(host, new).  counts_out[6] (optional): points per resulting LDSO_IPS_* status. */
+int ldso_trace_on(ldso_tracer_t *t, int n_hosts, const float *KRKi, const float *Kt, const float *aff, int *counts_out);
+
 #ifdef __cplusplus
 }
 #endif

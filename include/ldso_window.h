@@ -141,6 +141,40 @@ typedef struct ldso_point_out {
     int32_t numGoodResiduals;
 } ldso_point_out_t;
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Immature points (first half): ImmaturePoint::traceOn / FullSystem::traceNewCoarse.
+ * One record = the members of ldso::internal::ImmaturePoint that traceOn reads and writes
+ * (include/internal/ImmaturePoint.h:60-125); `host` = index of the host key frame in the per-host pose arrays.
+ * ------------------------------------------------------------------------------------------------------------ */
+enum { LDSO_IPS_GOOD = 0, LDSO_IPS_OOB = 1, LDSO_IPS_OUTLIER = 2, LDSO_IPS_SKIPPED = 3, LDSO_IPS_BADCONDITION = 4, LDSO_IPS_UNINITIALIZED = 5 };
+
+typedef struct ldso_immature {
+    float u, v;                       /* feature->uv */
+    float color[8], weights[8];       /* ImmaturePoint ctor (ImmaturePoint.cc:21-36) */
+    float gradH[4];                   /* sum over the pattern of grad grad^T, row-major 2x2 */
+    float energyTH;                   /* patternNum * setting_outlierTH * overallEnergyTHWeight^2 */
+    float idepth_min, idepth_max;     /* in / out; idepth_max = NaN: unbounded */
+    float quality;                    /* in / out (second-best / best energy of the discrete search) */
+    int32_t lastTraceStatus;          /* in / out, LDSO_IPS_* */
+    float lastTraceUV[2];             /* out */
+    float lastTracePixelInterval;     /* out */
+    int32_t host;
+    int32_t pad_;
+} ldso_immature_t;                    /* 128 bytes */
+
+typedef struct ldso_trace_settings {
+    float maxPixSearch;               /* 0.027   Setting.cc:28 */
+    float trace_stepsize;             /* 1.0     Setting.cc:89 */
+    float trace_GNThreshold;          /* 0.1     Setting.cc:91 */
+    float trace_extraSlackOnTH;       /* 1.2     Setting.cc:92 */
+    float trace_slackInterval;        /* 1.5     Setting.cc:93 */
+    float trace_minImprovementFactor; /* 2       Setting.cc:94 */
+    float huberTH;                    /* 9       Setting.cc:76 */
+    int32_t trace_GNIterations;       /* 3       Setting.cc:90 */
+    int32_t minTraceTestRadius;       /* 2       Setting.cc:52 */
+    int32_t pad_;
+} ldso_trace_settings_t;              /* 40 bytes */
+
 #ifdef __cplusplus
 }
 #endif

@@ -379,3 +379,52 @@ class Tracker:
         it = np.zeros(n, np.int32)
         _chk(self.L.ldso_tr_track_batch(self.h, C.c_int(n), _p(T), _p(ab), C.c_int(coarsest), _p(mr), _p(lr), _p(fl), _p(ok), _p(it)))
         return dict(ok=ok.astype(bool), T=T, a=ab[:, 0].copy(), b=ab[:, 1].copy(), lastResiduals=lr, flow=fl, iterations=it)
+
+
+class Tracer:
+    """Immature-point tracing handle: FullSystem::traceNewCoarse / ImmaturePoint::traceOn on one GPU."""
+
+    def __init__(self, w, h, max_points, settings=None, device=0):
+        self.L = lib()
+        self.h = C.c_void_p()
+        _chk(self.L.ldso_trace_create(C.c_int(device), C.c_int(w), C.c_int(h), C.c_int(max_points), C.byref(self.h)))
+        self.w, self.hh, self.n = w, h, 0
+        if settings is not None:
+            s = np.ascontiguousarray(settings)
+            _chk(self.L.ldso_trace_set_settings(self.h, _p(s)))
+
+    def close(self):
+        if self.h:
+            self.L.ldso_trace_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_points(self, pts):
+        a = np.ascontiguousarray(pts)
+        assert a.dtype == synth.IMMATURE_DTYPE
+        _chk(self.L.ldso_trace_set_points(self.h, C.c_int(len(a)), _p(a)))
+        self.n = len(a)
+
+    def get_points(self):
+        out = np.zeros(self.n, synth.IMMATURE_DTYPE)
+        _chk(self.L.ldso_trace_get_points(self.h, _p(out)))
+        return out
+
+    def set_frame(self, dI_level0):
+        a = np.ascontiguousarray(dI_level0, np.float32)
+        _chk(self.L.ldso_trace_set_frame(self.h, _p(a)))
+
+    def set_frame_raw(self, irradiance):
+        a = np.ascontiguousarray(irradiance, np.float32)
+        _chk(self.L.ldso_trace_set_frame_raw(self.h, _p(a)))
+
+    def trace_on(self, KRKi, Kt, aff):
+        K1 = np.ascontiguousarray(KRKi, np.float32); K2 = np.ascontiguousarray(Kt, np.float32); A = np.ascontiguousarray(aff, np.float32)
+        counts = np.zeros(6, np.int32)
+        _chk(self.L.ldso_trace_on(self.h, C.c_int(len(K1)), _p(K1), _p(K2), _p(A), _p(counts)))
+        return counts

@@ -482,6 +482,88 @@ CONFIGS = {
 }
 
 
+# ----------------------------------------------------------------------------------------------
+# immature points (ImmaturePoint::traceOn)
+# ----------------------------------------------------------------------------------------------
+IMMATURE_DTYPE = np.dtype([
+    ("u", "f4"), ("v", "f4"), ("color", "f4", (8,)), ("weights", "f4", (8,)), ("gradH", "f4", (4,)), ("energyTH", "f4"),
+    ("idepth_min", "f4"), ("idepth_max", "f4"), ("quality", "f4"), ("lastTraceStatus", "i4"), ("lastTraceUV", "f4", (2,)),
+    ("lastTracePixelInterval", "f4"), ("host", "i4"), ("pad_", "i4"),
+], align=True)
+assert IMMATURE_DTYPE.itemsize == 128
+
+TRACE_SETTINGS_DTYPE = np.dtype([
+    ("maxPixSearch", "f4"), ("trace_stepsize", "f4"), ("trace_GNThreshold", "f4"), ("trace_extraSlackOnTH", "f4"),
+    ("trace_slackInterval", "f4"), ("trace_minImprovementFactor", "f4"), ("huberTH", "f4"), ("trace_GNIterations", "i4"),
+    ("minTraceTestRadius", "i4"), ("pad_", "i4"),
+], align=True)
+assert TRACE_SETTINGS_DTYPE.itemsize == 40
+
+
+def default_trace_settings():
+    s = np.zeros((), TRACE_SETTINGS_DTYPE)
+    s["maxPixSearch"] = 0.027; s["trace_stepsize"] = 1.0; s["trace_GNThreshold"] = 0.1; s["trace_extraSlackOnTH"] = 1.2
+    s["trace_slackInterval"] = 1.5; s["trace_minImprovementFactor"] = 2; s["huberTH"] = 9; s["trace_GNIterations"] = 3
+    s["minTraceTestRadius"] = 2
+    return s
+
+
+def make_immature_points(win: "Window", per_frame: int, seed: int = 7):
+    """Fresh immature points on the key frames of a window, as the ImmaturePoint constructor makes them
+    (ImmaturePoint.cc:14-38): pattern colours / weights / gradH at gradient-rich pixels; idepth interval [0, NaN)."""
+    rng = np.random.default_rng(seed)
+    F = win.F
+    out = np.zeros(F * per_frame, IMMATURE_DTYPE)
+    true_id = np.zeros(F * per_frame, np.float32)
+    n = 0
+    for k in range(F):
+        dI = win.images[k][0]
+        us, vs = [], []
+        while len(us) < per_frame:
+            cu = rng.integers(16, win.w - 16, per_frame * 2 + 16)
+            cv = rng.integers(16, win.h - 16, per_frame * 2 + 16)
+            g2 = dI[cv, cu, 1] ** 2 + dI[cv, cu, 2] ** 2
+            ok = np.nonzero(g2 >= 50)[0]
+            us += list(cu[ok]); vs += list(cv[ok])
+        us = np.asarray(us[:per_frame], np.float32); vs = np.asarray(vs[:per_frame], np.float32)
+        sl = slice(n, n + per_frame)
+        out["u"][sl] = us; out["v"][sl] = vs; out["host"][sl] = k
+        gh = np.zeros((per_frame, 4), np.float32)
+        for j in range(8):
+            c, gx, gy = interp_bilin33(dI, us + PATTERN[j, 0], vs + PATTERN[j, 1])
+            out["color"][sl, j] = c
+            out["weights"][sl, j] = np.sqrt(np.float32(2500.0) / (np.float32(2500.0) + (gx * gx + gy * gy))).astype(np.float32)
+            gh[:, 0] += gx * gx; gh[:, 1] += gx * gy; gh[:, 2] += gx * gy; gh[:, 3] += gy * gy
+        out["gradH"][sl] = gh
+        if win.truth is not None and win.truth.get("depths") is not None:
+            true_id[sl] = 1.0 / win.truth["depths"][k][vs.astype(int), us.astype(int)]
+        n += per_frame
+    out["energyTH"] = 8 * 12 * 12
+    out["idepth_min"] = 0.0
+    out["idepth_max"] = np.nan
+    out["quality"] = 10000.0
+    out["lastTraceStatus"] = 5          # IPS_UNINITIALIZED
+    out["lastTraceUV"] = -1.0
+    return out, true_id
+
+
+def trace_poses(win: "Window", new_index: int):
+    """Per host key frame of the window: K R K^-1, K t and the affine brightness pair towards frame `new_index`
+    (FullSystem::traceNewCoarse, FullSystem.cc:1018-1032), from the ground-truth poses of the synthetic scene."""
+    K = win.K.astype(np.float32)
+    Ki = np.linalg.inv(K.astype(np.float64)).astype(np.float32)
+    F = win.F
+    KRKi = np.zeros((F, 9), np.float32); Kt = np.zeros((F, 3), np.float32); aff = np.zeros((F, 2), np.float32)
+    Tn = win.truth["w2c"][new_index]
+    for k in range(F):
+        T = Tn @ np.linalg.inv(win.truth["w2c"][k])
+        R = T[:3, :3].astype(np.float32); t = T[:3, 3].astype(np.float32)
+        KRKi[k] = (K @ R @ Ki).ravel(); Kt[k] = K @ t
+        a = np.float32(np.exp(np.float32(win.truth["aff_a"][new_index] - win.truth["aff_a"][k])))
+        aff[k] = (a, np.float32(win.truth["aff_b"][new_index]) - a * np.float32(win.truth["aff_b"][k]))
+    return KRKi, Kt, aff
+
+
 def add_synthetic_prior(win: Window, seed: int = 11, rank: int = 6, scale: float = 2e3, b_scale: float = 5.0) -> Window:
     """Give the window a marginalisation prior (H_M symmetric PSD of the given rank, b_M), as every steady-state LDSO window
     has one (EnergyFunctional::marginalizeFrame).  Synthetic: it only has to be the same on both sides of a comparison."""

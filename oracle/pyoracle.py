@@ -341,6 +341,19 @@ class OracleTracker:
         return float(self.L.orc_tr_time_track(self.h, _p(T), _p(ab), C.c_int(coarsest), C.c_int(reps)))
 
 
+def trace_on(points, dI_level0, KRKi, Kt, aff, settings=None):
+    """FullSystem::traceNewCoarse over immature-point records (ldso_amd.synth.IMMATURE_DTYPE, modified in place) -> counts[6]"""
+    L = lib()
+    s = np.ascontiguousarray(synth.default_trace_settings() if settings is None else settings)
+    img = np.ascontiguousarray(dI_level0, np.float32)
+    h, w = img.shape[:2]
+    K1 = np.ascontiguousarray(KRKi, np.float32); K2 = np.ascontiguousarray(Kt, np.float32); A = np.ascontiguousarray(aff, np.float32)
+    counts = np.zeros(6, np.int32)
+    assert points.flags["C_CONTIGUOUS"] and points.dtype == synth.IMMATURE_DTYPE
+    L.orc_trace_on(C.c_int(len(points)), _p(points), _p(img), C.c_int(w), C.c_int(h), C.c_int(len(K1)), _p(K1), _p(K2), _p(A), _p(s), _p(counts))
+    return counts
+
+
 def make_images(color, levels):
     L = lib()
     h, w = color.shape
