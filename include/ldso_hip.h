@@ -122,6 +122,14 @@ int ldso_ba_marginalize_points(ldso_ba_t *h, const int32_t *flags, double *HM_ou
  * ldso_ba_set_prior or left by ldso_ba_marginalize_points) with the frame's prior / delta_prior: out = prior of the window
  * without frame `frame_idx`, (8(F-1)+4)^2 row-major and 8(F-1)+4 doubles. */
 int ldso_ba_marginalize_frame(ldso_ba_t *h, int frame_idx, double *HM_out, double *bM_out);
+/* Point activation: FullSystem::optimizeImmaturePoint (FullSystem.cc:892-1010; ImmaturePoint::linearizeResidual,
+ * ImmaturePoint.cc:312-381) for n immature points against the key frames of the resident window (its images, calibration and
+ * CURRENT poses, i.e. after ldso_ba_set_frames): up to gn_iterations LM steps on the inverse depth from the middle of
+ * [idepth_min, idepth_max]; min_obs = 1, min_idepth_hessian = setting_minIdepthH_act (100), gn_iterations =
+ * setting_GNItsOnPointActivation (3) in the reference (FullSystem.cc:1204).  out[i].ok says whether the point is created;
+ * out[i].res_state[t] == 0 lists the target frames that get a PointFrameResidual. */
+int ldso_ba_activate_points(ldso_ba_t *h, int n, const ldso_immature_t *points, int min_obs, float min_idepth_hessian, int gn_iterations,
+                            ldso_activation_t *out);
 /* Asynchronous variant used by bench.py: enqueue `iters` Gauss-Newton iterations (solveSystem +
  * doStepFromBackup + linearizeAll + applyRes) on the handle's stream and return immediately. */
 int ldso_ba_enqueue_gn(ldso_ba_t *h, int first_iteration, int iters);
@@ -155,6 +163,8 @@ int ldso_ba_set_debug_dump(ldso_ba_t *h, int enable);
 int ldso_ba_get_jacobians(ldso_ba_t *h, const int32_t *res_ids, int n, ldso_rawjac_t *out);
 /* Pair precalc [h*F+t][27] as FrameFramePrecalc: KRKi 9, Kt 3, R0 9, t0 3, aff 2, b0 1. */
 int ldso_ba_get_precalc(ldso_ba_t *h, float *out);
+/* Pair transforms of the CURRENT state [h*F+t][14]: PRE_RTll 9, PRE_tTll 3, PRE_aff_mode 2 (what point activation reads). */
+int ldso_ba_get_pair_rt(ldso_ba_t *h, float *out);
 int ldso_ba_get_counts(ldso_ba_t *h, int *resInA, int *resInL);
 /* energies of the linearizeAll calls inside the last ldso_ba_optimize (<= cap values), returns count */
 int ldso_ba_get_energy_log(ldso_ba_t *h, double *out, int cap);

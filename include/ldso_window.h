@@ -175,6 +175,18 @@ typedef struct ldso_trace_settings {
     int32_t pad_;
 } ldso_trace_settings_t;              /* 40 bytes */
 
+/* Result of FullSystem::optimizeImmaturePoint for one immature point (FullSystem.cc:892-1010). */
+typedef struct ldso_activation {
+    float idepth;                     /* currentIdepth after the LM iterations (setIdepth / setIdepthZero of the new point) */
+    int32_t ok;                       /* 1: a PointHessian is created; 0: rejected (returns nullptr / 0 in the reference) */
+    int32_t numGoodRes;               /* residuals with state IN */
+    int32_t iterations;               /* LM iterations executed */
+    float energy;                     /* lastEnergy */
+    float Hdd, bd;                    /* lastHdd, lastbd */
+    int32_t pad_;
+    int32_t res_state[LDSO_MAX_FRAMES];   /* per target frame idx: final state_state (0 IN, 1 OOB, 2 OUTLIER), -1 for the host */
+} ldso_activation_t;                  /* 96 bytes */
+
 #ifdef __cplusplus
 }
 #endif

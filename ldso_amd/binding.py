@@ -201,6 +201,19 @@ class BA:
         _chk(self.L.ldso_ba_time_linearize(self.h, C.c_int(reps), C.byref(us)))
         return us.value
 
+    def get_pair_rt(self):
+        out = np.zeros((self.F * self.F, 14), np.float32)
+        _chk(self.L.ldso_ba_get_pair_rt(self.h, _p(out)))
+        return out
+
+    def activate_points(self, pts, min_obs=1, min_idepth_hessian=100.0, gn_iterations=3):
+        """FullSystem::optimizeImmaturePoint for a batch of immature points against the resident window"""
+        a = np.ascontiguousarray(pts)
+        assert a.dtype == synth.IMMATURE_DTYPE
+        out = np.zeros(len(a), synth.ACTIVATION_DTYPE)
+        _chk(self.L.ldso_ba_activate_points(self.h, C.c_int(len(a)), _p(a), C.c_int(min_obs), C.c_float(min_idepth_hessian), C.c_int(gn_iterations), _p(out)))
+        return out
+
     def enqueue_gn(self, first_iteration, iters):
         _chk(self.L.ldso_ba_enqueue_gn(self.h, C.c_int(first_iteration), C.c_int(iters)))
 

@@ -28,6 +28,8 @@ hipError_t ba_launch_linearize_marg(const BaPtrs &B, const BaDims &D, const ResS
 hipError_t ba_launch_marg_frame(const BaPtrs &B, const BaDims &D, int idx, double *work, double *outH, double *outb, hipStream_t st);
 hipError_t ba_launch_acc_init(const BaPtrs &B, const BaDims &D, const GnInit &gi, hipStream_t st);
 hipError_t ba_launch_gn_export(const BaPtrs &B, const BaDims &D, const ResSet &S, double *tail, hipStream_t st);
+hipError_t ba_launch_activate(const BaPtrs &B, const BaDims &D, const ldso_settings_t &S, const ldso_immature_t *d_pts, ldso_activation_t *d_out, int n, int minObs,
+                              float minIdepthH_act, int GNIts, hipStream_t st);
 hipError_t ba_launch_marg_update(const BaPtrs &B, const BaDims &D, double w, hipStream_t st);
 hipError_t ba_launch_gn_solve(const BaPtrs &B, const BaDims &D, const ResSet &S, const ldso_settings_t &St, const SolveArgs &A, hipStream_t st);
 
@@ -58,6 +60,8 @@ struct ldso_ba {
     int32_t *d_chunkStart = nullptr;
     int32_t *d_margFlags = nullptr;
     float *d_color = nullptr;          // irradiance staging of ldso_ba_set_image_raw
+    void *d_act = nullptr;             // staging of ldso_ba_activate_points: n immature records + n results
+    int actCap = 0;
     double *ownAcc = nullptr;          // the handle's own HFinal/bFinal accumulator (B.acc may point at a caller's all-reduce buffer)
     ChunkStarts chunkStarts;
     ldso_rawjac_t *d_dumpJ = nullptr;
@@ -173,7 +177,7 @@ int ldso_ba_create(int device, int w, int h, int max_frames, int max_points, lds
     memset(&H->D, 0, sizeof(H->D));
     BaPtrs &B = H->B;
     const size_t F = max_frames, P = max_points, FS = H->FSmax, nmax = 8 * F + 4;
-    DA(B.frames, F); DA(B.calib, 1); DA(B.pairs, F * F);
+    DA(B.frames, F); DA(B.calib, 1); DA(B.pairs, F * F); DA(B.pairRt, F * F * 12);
     DA(B.adHost, F * F * 64); DA(B.adTarget, F * F * 64); DA(B.adHostF, F * F * 64); DA(B.adTargetF, F * F * 64);
     DA(B.nsProj, nmax * 7); DA(B.HM, nmax * nmax); DA(B.bM, nmax);
     DA(B.pu, P); DA(B.pv, P); DA(B.pidepth, P); DA(B.pidepth_zero, P); DA(B.pidepth_backup, P); DA(B.pstep, P); DA(B.ppriorF, P);
@@ -205,6 +209,7 @@ int ldso_ba_destroy(ldso_ba_t *H) {
     for (void *p : H->allocs) hipFree(p);
     for (int i = 0; i < LD_MAXF; i++) if (H->imgOwned[i] && H->imgSlots[i]) hipFree(H->imgSlots[i]);
     if (H->d_color) hipFree(H->d_color);
+    if (H->d_act) hipFree(H->d_act);
     for (auto &t : H->timers) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
     if (H->ownStream && H->stream) hipStreamDestroy(H->stream);
     delete H;
@@ -777,6 +782,29 @@ int ldso_ba_gn_solve_reduced(ldso_ba_t *H, const void *buf, int iteration, doubl
     return LDSO_OK;
 }
 
+// FullSystem::optimizeImmaturePoint (FullSystem.cc:892-1010) for n immature points against the key frames of the window that is
+// resident in the handle (ldso_ba_set_image*, ldso_ba_set_window, ldso_ba_set_frames: images, calibration, current poses).
+int ldso_ba_activate_points(ldso_ba_t *H, int n, const ldso_immature_t *pts, int min_obs, float min_idepth_hessian, int gn_iterations, ldso_activation_t *out) {
+    REQ(H && n >= 0 && (n == 0 || (pts && out)) && gn_iterations >= 0, "ldso_ba_activate_points: bad arguments");
+    REQ(H->D.F >= 2, "ldso_ba_activate_points: set the window and the frames first");
+    if (n == 0) return LDSO_OK;
+    CHK(hipSetDevice(H->device));
+    for (int f = 0; f < H->D.F; f++) REQ(H->B.img[f] != nullptr, "ldso_ba_activate_points: a key-frame image is missing");
+    if (n > H->actCap) {
+        if (H->d_act) hipFree(H->d_act);
+        H->d_act = nullptr; H->actCap = 0;
+        CHK(hipMalloc(&H->d_act, (size_t) n * (sizeof(ldso_immature_t) + sizeof(ldso_activation_t))));
+        H->actCap = n;
+    }
+    ldso_immature_t *dp = (ldso_immature_t *) H->d_act;
+    ldso_activation_t *dout = (ldso_activation_t *) ((char *) H->d_act + (size_t) H->actCap * sizeof(ldso_immature_t));
+    CHK(hipMemcpyAsync(dp, pts, (size_t) n * sizeof(ldso_immature_t), hipMemcpyHostToDevice, H->stream));
+    CHK(ba_launch_activate(H->B, H->D, H->settings, dp, dout, n, min_obs, min_idepth_hessian, gn_iterations, H->stream));
+    CHK(hipMemcpyAsync(out, dout, (size_t) n * sizeof(ldso_activation_t), hipMemcpyDeviceToHost, H->stream));
+    CHK(hipStreamSynchronize(H->stream));
+    return LDSO_OK;
+}
+
 int ldso_ba_reduce_local(ldso_ba_t *H, void *buf) {
     REQ(H && buf && H->D.P > 0, "bad arguments");
     CHK(hipSetDevice(H->device));
@@ -932,6 +960,20 @@ int ldso_ba_get_precalc(ldso_ba_t *H, float *out) {
         memcpy(o, dp[i].KRKi, 36); memcpy(o + 9, dp[i].Kt, 12); memcpy(o + 12, dp[i].R0, 36); memcpy(o + 21, dp[i].t0, 12);
         o[24] = dp[i].aff[0]; o[25] = dp[i].aff[1]; o[26] = dp[i].b0;
     }
+    return LDSO_OK;
+}
+
+// [h*F+t][14]: PRE_RTll 9, PRE_tTll 3 (current state), PRE_aff_mode 2 - what point activation reads (debug / test fetch)
+int ldso_ba_get_pair_rt(ldso_ba_t *H, float *out) {
+    REQ(H && out && H->D.F > 0, "bad arguments");
+    CHK(hipSetDevice(H->device));
+    const int F = H->D.F;
+    std::vector<DevPair> dp;
+    std::vector<float> rt;
+    D2H(dp, H->B.pairs, (size_t) F * F);
+    D2H(rt, H->B.pairRt, (size_t) F * F * 12);
+    CHK(hipStreamSynchronize(H->stream));
+    for (int i = 0; i < F * F; i++) { memcpy(out + i * 14, rt.data() + i * 12, 48); out[i * 14 + 12] = dp[i].aff[0]; out[i * 14 + 13] = dp[i].aff[1]; }
     return LDSO_OK;
 }
 

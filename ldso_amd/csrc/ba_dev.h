@@ -80,6 +80,7 @@ struct BaPtrs {
     DevFrame *frames;
     DevCalib *calib;
     DevPair *pairs;
+    float *pairRt;                   // [F*F][12] at [host*F + target]: PRE_RTll (9) and PRE_tTll (3) of the CURRENT state (point activation)
     double *adHost, *adTarget;
     float *adHostF, *adTargetF;
     double *nsProj;                  // n*n projector onto the gauge nullspaces (reference ordering)

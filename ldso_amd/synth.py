@@ -499,6 +499,12 @@ TRACE_SETTINGS_DTYPE = np.dtype([
 ], align=True)
 assert TRACE_SETTINGS_DTYPE.itemsize == 40
 
+ACTIVATION_DTYPE = np.dtype([
+    ("idepth", "f4"), ("ok", "i4"), ("numGoodRes", "i4"), ("iterations", "i4"), ("energy", "f4"), ("Hdd", "f4"), ("bd", "f4"), ("pad_", "i4"),
+    ("res_state", "i4", (16,)),
+], align=True)
+assert ACTIVATION_DTYPE.itemsize == 96
+
 
 def default_trace_settings():
     s = np.zeros((), TRACE_SETTINGS_DTYPE)

@@ -354,6 +354,21 @@ def trace_on(points, dI_level0, KRKi, Kt, aff, settings=None):
     return counts
 
 
+def activate_points(points, images_level0, K4, pairs, w, h, huberTH=9.0, min_idepth_hessian=100.0, gn_iterations=3, min_obs=1):
+    """FullSystem::optimizeImmaturePoint over immature-point records.  images_level0: list of F arrays [h,w,3]; K4 = (fx,fy,cx,cy);
+    pairs [F*F,14] = R (9), t (3), aff (2) of the current state at [host*F + target]."""
+    L = lib()
+    pts = np.ascontiguousarray(points)
+    F = len(images_level0)
+    imgs = [np.ascontiguousarray(im, np.float32) for im in images_level0]
+    arr = (C.c_void_p * F)(*[im.ctypes.data for im in imgs])
+    K = np.ascontiguousarray(K4, np.float32); pr = np.ascontiguousarray(pairs, np.float32)
+    out = np.zeros(len(pts), synth.ACTIVATION_DTYPE)
+    L.orc_activate_points(C.c_int(len(pts)), _p(pts), C.c_int(F), arr, C.c_int(w), C.c_int(h), _p(K), _p(pr), C.c_float(huberTH),
+                          C.c_float(min_idepth_hessian), C.c_int(gn_iterations), C.c_int(min_obs), _p(out))
+    return out
+
+
 def make_images(color, levels):
     L = lib()
     h, w = color.shape

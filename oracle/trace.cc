@@ -180,3 +180,97 @@ void orc_trace_on(int n, ldso_immature_t *pts, const float *dI, int w, int h, in
 
 }  // extern "C"
 static_assert(sizeof(ldso_immature_t) == 128 && sizeof(ldso_trace_settings_t) == 40, "layout");
+
+// =====================================================================================================================
+// FullSystem::optimizeImmaturePoint (src/frontend/FullSystem.cc:892-1010) with ImmaturePoint::linearizeResidual
+// (src/internal/ImmaturePoint.cc:312-381), projectPoint (include/internal/ResidualProjections.h:57-84) and derive_idepth
+// (:12-18) on plain arrays.  pairs[host*F + target] = {R 9 (PRE_RTll), t 3 (PRE_tTll), aff 2 (PRE_aff_mode)}.
+// =====================================================================================================================
+namespace {
+
+struct TmpRes { int state_state; double state_energy; int state_NewState; double state_NewEnergy; int target; };
+enum { RS_IN = 0, RS_OOB = 1, RS_OUTLIER = 2 };
+
+double linearize_residual(const ldso_immature_t &p, const float *const *dI, int w, int h, const float *K4 /*fx fy cx cy*/, const float *pair,
+                          float huberTH, float outlierTHSlack, TmpRes &tr, float &Hdd, float &bd, float idepth) {
+    if (tr.state_state == RS_OOB) { tr.state_NewState = RS_OOB; return tr.state_energy; }                      // :317-320
+    const float *R = pair, *t = pair + 9, *aff = pair + 12;
+    const float fx = K4[0], fy = K4[1], cx = K4[2], cy = K4[3], fxi = 1.0f / fx, fyi = 1.0f / fy;
+    const float *img = dI[tr.target];
+    float energyLeft = 0;
+    for (int k = 0; k < 8; k++) {
+        const int dx = kPat[k][0], dy = kPat[k][1];
+        // projectPoint (ResidualProjections.h:57-84)
+        const float Kl0 = (p.u + dx - cx) * fxi, Kl1 = (p.v + dy - cy) * fyi;
+        const float q0 = (R[0] * Kl0 + R[1] * Kl1) + R[2] * 1.0f + t[0] * idepth, q1 = (R[3] * Kl0 + R[4] * Kl1) + R[5] * 1.0f + t[1] * idepth,
+                    q2 = (R[6] * Kl0 + R[7] * Kl1) + R[8] * 1.0f + t[2] * idepth;
+        const float drescale = 1.0f / q2;
+        bool ok = drescale > 0;
+        float u = 0, v = 0, Ku = 0, Kv = 0;
+        if (ok) { u = q0 * drescale; v = q1 * drescale; Ku = u * fx + cx; Kv = v * fy + cy; ok = Ku > 1.1f && Kv > 1.1f && Ku < w - 3 && Kv < h - 3; }
+        if (!ok) { tr.state_NewState = RS_OOB; return tr.state_energy; }
+        float hit[3];
+        interp33(img, Ku, Kv, w, hit);
+        if (!std::isfinite(hit[0])) { tr.state_NewState = RS_OOB; return tr.state_energy; }
+        const float residual = hit[0] - (aff[0] * p.color[k] + aff[1]);
+        float hw = fabsf(residual) < huberTH ? 1 : huberTH / fabsf(residual);
+        energyLeft += p.weights[k] * p.weights[k] * hw * residual * residual * (2 - hw);
+        const float dxInterp = hit[1] * fx, dyInterp = hit[2] * fy;
+        const float d_idepth = (dxInterp * drescale * (t[0] - t[2] * u) + dyInterp * drescale * (t[1] - t[2] * v)) * 1.0f;      // SCALE_IDEPTH = 1
+        hw *= p.weights[k] * p.weights[k];
+        Hdd += (hw * d_idepth) * d_idepth;
+        bd += (hw * residual) * d_idepth;
+    }
+    if (energyLeft > p.energyTH * outlierTHSlack) { energyLeft = p.energyTH * outlierTHSlack; tr.state_NewState = RS_OUTLIER; }
+    else tr.state_NewState = RS_IN;
+    tr.state_NewEnergy = energyLeft;
+    return energyLeft;
+}
+
+}  // namespace
+
+extern "C" void orc_activate_points(int n, const ldso_immature_t *pts, int F, const float *const *dI, int w, int h, const float *K4, const float *pairs,
+                                    float huberTH, float minIdepthH_act, int GNIts, int minObs, ldso_activation_t *out) {
+    for (int i = 0; i < n; i++) {
+        const ldso_immature_t &p = pts[i];
+        ldso_activation_t &o = out[i];
+        memset(&o, 0, sizeof(o));
+        for (int f = 0; f < LDSO_MAX_FRAMES; f++) o.res_state[f] = -1;
+        TmpRes tr[LDSO_MAX_FRAMES];
+        int nres = 0;
+        for (int f = 0; f < F; f++) if (f != p.host) { tr[nres].state_NewEnergy = tr[nres].state_energy = 0; tr[nres].state_NewState = RS_OUTLIER; tr[nres].state_state = RS_IN; tr[nres].target = f; nres++; }
+        float lastEnergy = 0, lastHdd = 0, lastbd = 0;
+        float currentIdepth = (p.idepth_max + p.idepth_min) * 0.5f;
+        for (int r = 0; r < nres; r++) {
+            lastEnergy += linearize_residual(p, dI, w, h, K4, pairs + (size_t) (p.host * F + tr[r].target) * 14, huberTH, 1000, tr[r], lastHdd, lastbd, currentIdepth);
+            tr[r].state_state = tr[r].state_NewState; tr[r].state_energy = tr[r].state_NewEnergy;
+        }
+        bool failed = !std::isfinite(lastEnergy) || lastHdd < minIdepthH_act;                                       // return 0 (:924-926)
+        float lambda = 0.1f;
+        int its = 0;
+        for (int iteration = 0; !failed && iteration < GNIts; iteration++) {
+            its++;
+            float H = lastHdd;
+            H *= 1 + lambda;
+            float step = (1.0 / H) * lastbd;
+            float newIdepth = currentIdepth - step;
+            float newHdd = 0, newbd = 0, newEnergy = 0;
+            for (int r = 0; r < nres; r++)
+                newEnergy += linearize_residual(p, dI, w, h, K4, pairs + (size_t) (p.host * F + tr[r].target) * 14, huberTH, 1, tr[r], newHdd, newbd, newIdepth);
+            if (!std::isfinite(lastEnergy) || newHdd < minIdepthH_act) { failed = true; break; }                       // :945-947
+            if (newEnergy < lastEnergy) {
+                currentIdepth = newIdepth; lastHdd = newHdd; lastbd = newbd; lastEnergy = newEnergy;
+                for (int r = 0; r < nres; r++) { tr[r].state_state = tr[r].state_NewState; tr[r].state_energy = tr[r].state_NewEnergy; }
+                lambda *= 0.5f;
+            } else lambda *= 5;
+            if (fabsf(step) < 0.0001 * currentIdepth) break;
+        }
+        // outputs: the loop state at exit, whatever the verdict
+        o.idepth = currentIdepth; o.energy = lastEnergy; o.Hdd = lastHdd; o.bd = lastbd; o.iterations = its;
+        int good = 0;
+        for (int r = 0; r < nres; r++) { o.res_state[tr[r].target] = tr[r].state_state; if (tr[r].state_state == RS_IN) good++; }
+        o.numGoodRes = good;
+        o.ok = (!failed && std::isfinite(currentIdepth) && good >= minObs) ? 1 : 0;                                     // :968-980
+    }
+}
+static_assert(sizeof(ldso_activation_t) == 96, "layout");
