@@ -322,7 +322,8 @@ static __device__ void set_precalc(const BaPtrs &B, const BaDims &D, DevFrame *f
         ld::se3_mul(ft.PRE_w2c, fh.PRE_c2w, T);
         float R[9], tt[3];
         for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) R[r * 3 + c] = (float) T[r * 4 + c]; tt[r] = (float) T[r * 4 + 3]; }
-        { float *rt = B.pairRt + (size_t) i * 12; for (int q = 0; q < 9; q++) rt[q] = R[q]; for (int q = 0; q < 3; q++) rt[9 + q] = tt[q]; }
+        // PRE_RTll / PRE_tTll for point activation: only where the host can call it (after set_frames / optimize), not inside GN iterations
+        if (FULL) { float *rt = B.pairRt + (size_t) i * 12; for (int q = 0; q < 9; q++) rt[q] = R[q]; for (int q = 0; q < 3; q++) rt[9 + q] = tt[q]; }
         if (FULL) {
             double Ti[12], T0[12];
             ld::se3_inv(fh.evalPT, Ti);
