@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--config", default="C3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prior", action="store_true", help="window without the (synthetic) marginalisation prior H_M / b_M")
+    ap.add_argument("--force-dist-path", action="store_true", help="1 GPU only: run the multi-GPU step (reduce_local / solve_reduced) with a no-op all-reduce")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -66,11 +67,16 @@ def main():
     ba.collect_active()
     ba.linearize_all(False)
     ba.apply_res()
-    rbuf = torch.zeros(ba.gn_reduce_doubles(), dtype=torch.float64, device="cuda") if world > 1 else None
+    dist_path = world > 1 or args.force_dist_path
+    rbuf = torch.zeros(ba.gn_reduce_doubles(), dtype=torch.float64, device="cuda") if dist_path else None
 
     def run(k, it0):
-        if world == 1:
+        if not dist_path:
             ba.enqueue_gn(it0, k)
+        elif world == 1:
+            for i in range(k):                      # the multi-GPU step without the collective (one rank owns everything)
+                ba.gn_reduce_local(rbuf.data_ptr(), 1e-1)
+                ba.gn_solve_reduced(rbuf.data_ptr(), it0 + i, 1e-1)
         else:
             # the all-reduce buffer is the HFinal / bFinal accumulator of the 3-launch iteration (+ scalars, energy candidates)
             for i in range(k):
