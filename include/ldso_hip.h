@@ -238,6 +238,35 @@ int ldso_trace_set_frame_raw(ldso_tracer_t *t, const float *irradiance);
  * aff[h] = AffLight::fromToVecExposure(host, new).  counts_out[6] (optional): points per resulting LDSO_IPS_* status. */
 int ldso_trace_on(ldso_tracer_t *t, int n_hosts, const float *KRKi, const float *Kt, const float *aff, int *counts_out);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Monocular initialiser: CoarseInitializer (src/frontend/CoarseInitializer.cc, include/frontend/CoarseInitializer.h).
+ * Replaces setFirst (:547-619, minus the pixel selection and the kd-tree of makeNN, whose results arrive as the point records),
+ * trackFrame (:40-178) and what it calls: calcResAndGS (:181-405), calcEC (:412-428), optReg (:430-459), propagateUp/Down
+ * (:462-522), resetPoints (:621-643), doStep (:645-671), applyStep (:673-687), makeK (:689-715).
+ * The whole Levenberg-Marquardt loop of one trackFrame runs on the device without a host round trip.
+ * ------------------------------------------------------------------------------------------------------------ */
+typedef struct ldso_initializer ldso_initializer_t;
+int ldso_init_create(int device, int w, int h, int pyr_levels, ldso_initializer_t **out);
+int ldso_init_destroy(ldso_initializer_t *t);
+int ldso_init_set_stream(ldso_initializer_t *t, void *hip_stream);
+/* makeK + setFirst: calib = CalibHessian fxl,fyl,cxl,cyl of level 0; the first frame as raw irradiance (w*h floats, makeImages on
+ * the device) with its exposure; points[lvl] / n_points[lvl]: the selected pixels of every level with neighbours and parents. */
+int ldso_init_set_first(ldso_initializer_t *t, const float calib[4], const float *irradiance, float ab_exposure,
+                        const ldso_init_point_t *const *points, const int *n_points, float huberTH, int fixAffine);
+/* trackFrame(newFrame): returns the state after the call in state_out (optional) */
+int ldso_init_track_frame(ldso_initializer_t *t, const float *irradiance, float ab_exposure, ldso_init_state_t *state_out);
+int ldso_init_get_state(ldso_initializer_t *t, ldso_init_state_t *state_out);
+int ldso_init_set_state(ldso_initializer_t *t, const ldso_init_state_t *state);
+int ldso_init_get_points(ldso_initializer_t *t, int lvl, ldso_init_point_t *points_out);
+int ldso_init_set_points(ldso_initializer_t *t, int lvl, const ldso_init_point_t *points);
+/* stage entry for parity tests: one calcResAndGS(lvl, refToNew, aff) on the current new frame; idepth_new of the points is used
+ * as it stands.  H,Hsc 8x8 row-major, b,bsc 8, res = (E.A, alphaEnergy, E.num), ec = calcEC(lvl). */
+int ldso_init_calc_res_and_gs(ldso_initializer_t *t, int lvl, const double refToNew[12], double aff_a, double aff_b,
+                              float *H, float *b, float *Hsc, float *bsc, float *res, float *ec);
+int ldso_init_set_new_frame(ldso_initializer_t *t, const float *irradiance, float ab_exposure);
+/* debug builds (LDSO_STAMPS=1): accumulated device-side counters, zeros otherwise */
+int ldso_init_debug_counters(ldso_initializer_t *t, long long out[4]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -187,6 +187,38 @@ typedef struct ldso_activation {
     int32_t res_state[LDSO_MAX_FRAMES];   /* per target frame idx: final state_state (0 IN, 1 OOB, 2 OUTLIER), -1 for the host */
 } ldso_activation_t;                  /* 96 bytes */
 
+/* One candidate of the monocular initialiser: struct Pnt (include/frontend/CoarseInitializer.h:19-57), bools widened to int32. */
+typedef struct ldso_init_point {
+    float u, v;                       /* pixel position on its pyramid level (x + 0.1, y + 0.1; CoarseInitializer.cc:578-579) */
+    float idepth;
+    int32_t isGood;
+    float energy[2];                  /* (photometric, regulariser) */
+    int32_t isGood_new;
+    float idepth_new;
+    float energy_new[2];
+    float iR;                         /* regularised inverse depth */
+    float iRSumNum;
+    float lastHessian, lastHessian_new;
+    float maxstep;
+    int32_t parent;                   /* index on level + 1, -1 on the coarsest level */
+    float parentDist;
+    int32_t neighbours[10];           /* 10 nearest points of the same level (makeNN, CoarseInitializer.cc:717-783), -1: none */
+    float neighboursDist[10];
+    float my_type;
+    float outlierTH;                  /* patternNum * setting_outlierTH (CoarseInitializer.cc:597) */
+    float pad_;
+} ldso_init_point_t;                  /* 160 bytes */
+
+/* State of a CoarseInitializer between two trackFrame calls (CoarseInitializer.h:66-74,91-92). */
+typedef struct ldso_init_state {
+    double thisToNext[12];            /* row-major [R|t] */
+    double aff_a, aff_b;              /* thisToNext_aff */
+    int32_t snapped, snappedAt, frameID;
+    int32_t ready;                    /* return value of the last trackFrame: snapped && frameID > snappedAt + 5 */
+    int32_t evals;                    /* calcResAndGS evaluations of the last trackFrame */
+    int32_t pad_;
+} ldso_init_state_t;                  /* 136 bytes */
+
 #ifdef __cplusplus
 }
 #endif

@@ -441,3 +441,84 @@ class Tracer:
         counts = np.zeros(6, np.int32)
         _chk(self.L.ldso_trace_on(self.h, C.c_int(len(K1)), _p(K1), _p(K2), _p(A), _p(counts)))
         return counts
+
+
+class Initializer:
+    """Monocular initialiser handle: CoarseInitializer::setFirst / trackFrame on one GPU (include/ldso_hip.h)."""
+
+    def __init__(self, w, h, levels, device=0, stream=None):
+        self.L = lib()
+        self.h = C.c_void_p()
+        _chk(self.L.ldso_init_create(C.c_int(device), C.c_int(w), C.c_int(h), C.c_int(levels), C.byref(self.h)))
+        self.w, self.hh, self.levels = w, h, levels
+        self.n = [0] * levels
+        if stream is not None:
+            self.set_stream(stream)
+
+    def close(self):
+        if self.h:
+            self.L.ldso_init_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_handle):
+        if not stream_handle:
+            raise ValueError("pass a non-default HIP stream handle (0 is the legacy default stream)")
+        _chk(self.L.ldso_init_set_stream(self.h, C.c_void_p(stream_handle)))
+
+    def set_first(self, K4, irradiance, points, exposure=1.0, huberTH=9.0, fixAffine=True):
+        """K4 = (fxl, fyl, cxl, cyl) of level 0; irradiance float32 [h,w]; points: one INIT_POINT_DTYPE array per level."""
+        k = np.ascontiguousarray(K4, np.float32)
+        img = np.ascontiguousarray(irradiance, np.float32)
+        assert img.shape == (self.hh, self.w) and len(points) == self.levels
+        pts = [np.ascontiguousarray(p, dtype=synth.INIT_POINT_DTYPE) for p in points]
+        pp = (C.c_void_p * self.levels)(*[p.ctypes.data for p in pts])
+        n = np.array([len(p) for p in pts], dtype=np.int32)
+        _chk(self.L.ldso_init_set_first(self.h, _p(k), _p(img), C.c_float(exposure), pp, _p(n), C.c_float(huberTH), C.c_int(1 if fixAffine else 0)))
+        self.n = [int(x) for x in n]
+
+    def set_new_frame(self, irradiance, exposure=1.0):
+        img = np.ascontiguousarray(irradiance, np.float32)
+        assert img.shape == (self.hh, self.w)
+        _chk(self.L.ldso_init_set_new_frame(self.h, _p(img), C.c_float(exposure)))
+
+    def track_frame(self, irradiance=None, exposure=1.0):
+        """trackFrame; irradiance None: the frame given to set_new_frame.  Returns the INIT_STATE_DTYPE record."""
+        st = np.zeros((), synth.INIT_STATE_DTYPE)
+        img = None
+        if irradiance is not None:
+            img = np.ascontiguousarray(irradiance, np.float32)
+            assert img.shape == (self.hh, self.w)
+        _chk(self.L.ldso_init_track_frame(self.h, _p(img), C.c_float(exposure), _p(st)))
+        return st
+
+    def state(self):
+        st = np.zeros((), synth.INIT_STATE_DTYPE)
+        _chk(self.L.ldso_init_get_state(self.h, _p(st)))
+        return st
+
+    def set_state(self, st):
+        st = np.ascontiguousarray(st, dtype=synth.INIT_STATE_DTYPE)
+        _chk(self.L.ldso_init_set_state(self.h, _p(st)))
+
+    def points(self, lvl):
+        out = np.zeros(self.n[lvl], synth.INIT_POINT_DTYPE)
+        _chk(self.L.ldso_init_get_points(self.h, C.c_int(lvl), _p(out)))
+        return out
+
+    def set_points(self, lvl, pts):
+        pts = np.ascontiguousarray(pts, dtype=synth.INIT_POINT_DTYPE)
+        assert len(pts) == self.n[lvl]
+        _chk(self.L.ldso_init_set_points(self.h, C.c_int(lvl), _p(pts)))
+
+    def calc_res_and_gs(self, lvl, T, a, b):
+        T = np.ascontiguousarray(np.asarray(T, dtype=np.float64)[:3, :4])
+        H = np.zeros((8, 8), np.float32); bo = np.zeros(8, np.float32); Hsc = np.zeros((8, 8), np.float32); bsc = np.zeros(8, np.float32)
+        res = np.zeros(3, np.float32); ec = np.zeros(3, np.float32)
+        _chk(self.L.ldso_init_calc_res_and_gs(self.h, C.c_int(lvl), _p(T), C.c_double(a), C.c_double(b), _p(H), _p(bo), _p(Hsc), _p(bsc), _p(res), _p(ec)))
+        return H, bo, Hsc, bsc, res, ec

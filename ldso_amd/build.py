@@ -8,7 +8,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libldso_hip.so")
-SOURCES = ["ba_linearize.hip", "ba_reduce.hip", "ba_solve.hip", "ba_api.hip", "tracker.hip", "images.hip", "trace.hip", "ba_activate.hip"]
+SOURCES = ["ba_linearize.hip", "ba_reduce.hip", "ba_solve.hip", "ba_api.hip", "tracker.hip", "images.hip", "trace.hip", "ba_activate.hip", "initializer.hip"]
 # -ffp-contract=off: elementwise arithmetic is IEEE and follows the reference's operation order (bit-identical
 # energies / residual states); fused multiply-adds are spelled explicitly where they are wanted.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result"]

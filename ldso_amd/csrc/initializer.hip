@@ -1,0 +1,1070 @@
+// initializer.hip — the monocular initialiser CoarseInitializer (reference src/frontend/CoarseInitializer.cc) for gfx950.
+//
+// One trackFrame (:40-178) is a Levenberg-Marquardt loop per pyramid level over (pose, affine, one inverse depth per point)
+// with the depths eliminated point-wise (JbBuffer, :287-297,:363-386).  Device design:
+//   k_ini_eval   grid kernel, 8 lanes per point (one lane per pattern pixel, as the BA linearise kernel): the lazily applied
+//                applyStep (:673-687) of the previously accepted step, resetPoints' per-point part (:625-626) on the first
+//                evaluation of a level, doStep (:645-671), then calcResAndGS (:181-405) and the calcEC sums (:412-428).
+//                Per-lane fp32 accumulators (45 entries of the 9x9 Hessian, 8x9+1 of the Schur block), one partial row per block.
+//   k_ini_ctl    ONE workgroup: sums the partial rows in double, takes the accept/reject decision of :120-146, keeps the LM
+//                state (lambda, fails, iteration, level) in device memory, solves the damped 6x6 / 8x8 system with a
+//                lane-parallel pivoted LDL^T, and runs everything that is sequential in the reference: optReg (:430-459),
+//                propagateDown/Up (:462-522) and the neighbour average of resetPoints (:629-641).
+// The host enqueues BEGIN + the maximal number of (eval, ctl) pairs once; finished levels / a finished frame make the
+// remaining launches return at once (device-side `done`), so there is no host round trip inside trackFrame.
+//
+// optReg and the resetPoints average update points IN PLACE in index order, reading neighbours that may already have been
+// updated.  That order is kept exactly: the host builds, per level, a schedule of passes of <= 64 points such that every
+// neighbour with a lower index sits in an earlier pass and every reader with a lower index in an earlier-or-equal pass; one
+// wavefront executes the passes with the working values in LDS (reads before writes within a pass by lock-step execution).
+#include <hip/hip_runtime.h>
+#include <vector>
+#include <string>
+#include <cstring>
+#include <cmath>
+#include <algorithm>
+#include "../../include/ldso_hip.h"
+#include "lie_dev.h"
+
+void ldso_set_error(const std::string &s);
+extern "C" hipError_t img_launch_make_images(const float *d_color, int w, int h, int levels, float *const *d_levels, hipStream_t st);
+#define CHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { ldso_set_error(std::string(#call) + ": " + hipGetErrorString(e_)); return LDSO_E_HIP; } } while (0)
+#define REQ(cond, msg) do { if (!(cond)) { ldso_set_error(msg); return LDSO_E_INVALID; } } while (0)
+
+#define INI_MAXL 5            // maxIterations[] has five entries (CoarseInitializer.cc:43)
+#define INI_NT 256            // threads of an eval block: 32 points x 8 pattern pixels
+#define INI_MAXBLK 256        // eval blocks (= partial rows) per launch
+#define INI_NPART 128         // floats per partial row
+#define INI_CT 1024           // threads of the control block (its per-point passes are latency bound: many loads in flight)
+#define INI_NB 12             // neighbour row pitch (10 used)
+// partial row layout
+#define PR_SC 45              // 8 x 9 Schur block
+#define PR_SC88 117
+#define PR_E 118
+#define PR_ECO 119
+#define PR_ECN 120
+#define PR_ECC 121
+#define PR_N 122
+
+struct IniLevel {
+    int n, w, h, nPass;
+    float fx, fy, cx, cy;
+    double Ki[9];
+    const float *first, *cur;           // dIp[lvl] of the first and of the new frame
+    float *u, *v, *idepth, *idepth_new, *iR, *iRSumNum, *lastHessian, *lastHessian_new, *maxstep, *energy0, *energy1, *energy_new0, *energy_new1, *outlierTH;
+    int *isGood, *isGood_new, *parent, *nb;
+    float *jb[2];                       // [n][10]
+    const int *sched;                   // [nPass][64] point index or -1
+    const int *schedNb;                 // [nPass][64][INI_NB] neighbour rows in schedule order
+    float *schedIdv;                    // [nPass][64] idepth of the scheduled points (gathered before an optReg sweep)
+    const int *childOff, *childIdx;     // children (points of level - 1) of every point of this level, ascending
+};
+
+struct IniCtl {
+    double Tcur[12], Tnew[12];
+    float aCur, bCur, aNew, bNew;
+    float inc[8];
+    float lambda;
+    float H[64], b[8], Hsc[64], bsc[8], resOld[3];
+    float Hn[64], bn[8], Hscn[64], bscn[8], resNew[3], ec[3];
+    int lvl, mode, iteration, fails, done, snapped, snappedAt, frameID, jbSel, applyPending, evals, ready;
+    long long dbgSweepTicks, dbgSweepPasses, dbgCtlTicks, dbgSweeps;     // LDSO_STAMPS builds only (100 MHz wall clock)
+};
+
+struct IniParams {
+    IniLevel L[INI_MAXL];
+    int levels, fixAffine;
+    float huberTH, firstExposure, newExposure;
+    IniCtl *ctl;
+    float *part;                        // [INI_MAXBLK][INI_NPART]
+};
+
+__device__ __forceinline__ float ini_dpp_xor1(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true)); }
+__device__ __forceinline__ float ini_dpp_xor2(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true)); }
+__device__ __forceinline__ float ini_dpp_hmir(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, true)); }
+__device__ __forceinline__ float ini_dpp_rmir(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xF, 0xF, true)); }
+__device__ __forceinline__ float ini_dpp_ror8(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128, 0xF, 0xF, true)); }
+__device__ __forceinline__ float ini_sum8(float x) { x += ini_dpp_xor1(x); x += ini_dpp_xor2(x); x += ini_dpp_hmir(x); return x; }
+__device__ __forceinline__ float ini_min8(float x) { x = fminf(x, ini_dpp_xor1(x)); x = fminf(x, ini_dpp_xor2(x)); x = fminf(x, ini_dpp_hmir(x)); return x; }
+__device__ __forceinline__ float ini_sum16(float x) { x = ini_sum8(x); x += ini_dpp_rmir(x); return x; }
+
+__device__ __forceinline__ int ini_nblocks(int n, int gridCap) { const int nb = (n + 31) / 32; return nb < gridCap ? (nb < 1 ? 1 : nb) : gridCap; }
+
+// ---------------------------------------------------------------------------------------------------------
+// eval: (lazy applyStep) + (resetPoints | doStep) + calcResAndGS + calcEC sums
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(INI_NT) void k_ini_eval(IniParams P, int stage) {
+    const IniCtl *ctl = P.ctl;
+    if (!stage && ctl->done) return;
+    const int lvl = ctl->lvl;
+    const IniLevel &L = P.L[lvl];
+    const int n = L.n;
+    const int nblk = ini_nblocks(n, INI_MAXBLK);
+    if ((int) blockIdx.x >= nblk) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, k = tid & 7;
+    __shared__ float sRow[16][52];
+    __shared__ float sSC[16][8][10];
+
+    // ---- uniform prologue ----
+    const int mode = stage ? 2 : ctl->mode, pend = stage ? 0 : ctl->applyPending, jbSel = ctl->jbSel, snapped = ctl->snapped;
+    const float lambda = ctl->lambda;
+    float inc[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) inc[i] = ctl->inc[i];
+    double T[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) T[i] = ctl->Tnew[i];
+    float RKi[9], t[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) RKi[r * 3 + c] = (float) (T[r * 4 + 0] * L.Ki[0 * 3 + c] + T[r * 4 + 1] * L.Ki[1 * 3 + c] + T[r * 4 + 2] * L.Ki[2 * 3 + c]);
+        t[r] = (float) T[r * 4 + 3];
+    }
+    const float affA = expf(ctl->aNew), affB = ctl->bNew;
+    const float fxl = L.fx, fyl = L.fy, cxl = L.cx, cyl = L.cy;
+    const int wl = L.w, hl = L.h;
+    const float alphaK = 2.5f * 2.5f, alphaW = 150.0f * 150.0f, couplingWeight = 1.0f;
+    float alphaOpt;
+    {
+        const double tsq = T[3] * T[3] + T[7] * T[7] + T[11] * T[11];
+        const float alphaEnergy = (float) ((double) alphaW * (0.0 + tsq * (double) n));
+        alphaOpt = (alphaEnergy > alphaK * (float) n) ? 0.0f : alphaW;
+    }
+    const float huberTH = P.huberTH;
+    const int pdx = (k == 0) ? 0 : (k == 1) ? -1 : (k == 2) ? 1 : (k == 3) ? -2 : (k == 4) ? 0 : (k == 5) ? 2 : (k == 6) ? -1 : 0;
+    const int pdy = (k == 0) ? -2 : (k == 1) ? -1 : (k == 2) ? -1 : (k == 3) ? 0 : (k == 4) ? 0 : (k == 5) ? 0 : (k == 6) ? 1 : 2;
+    const float *jbOld = L.jb[jbSel];
+    float *jbNew = L.jb[jbSel ^ 1];
+
+    float acc[45];
+#pragma unroll
+    for (int i = 0; i < 45; i++) acc[i] = 0.0f;
+    float accSC[10];
+#pragma unroll
+    for (int i = 0; i < 10; i++) accSC[i] = 0.0f;
+    float accE = 0.0f, accEO = 0.0f, accEN = 0.0f, accEC = 0.0f;
+
+    for (int i = blockIdx.x * 32 + (tid >> 3); i < ((n + 31) & ~31); i += nblk * 32) {
+        const bool valid = i < n;
+        const int ii = valid ? i : n - 1;
+        float pu = L.u[ii], pv = L.v[ii], idp = L.idepth[ii], idn = L.idepth_new[ii], iR = L.iR[ii];
+        int good = L.isGood[ii];
+        float e0 = L.energy0[ii], e1 = L.energy1[ii];
+        const float oTH = L.outlierTH[ii];
+        if (mode != 2) {
+            if (pend) {                                   // applyStep of the accepted evaluation (:673-687), this point's share
+                if (!good) { idp = iR; idn = iR; if (valid && k == 0) L.idepth[ii] = idp; }
+                else {
+                    e0 = L.energy_new0[ii]; e1 = L.energy_new1[ii]; good = L.isGood_new[ii]; idp = idn;
+                    if (valid && k == 0) {
+                        L.energy0[ii] = e0; L.energy1[ii] = e1; L.isGood[ii] = good; L.idepth[ii] = idp;
+                        L.lastHessian[ii] = L.lastHessian_new[ii];
+                    }
+                }
+            }
+            if (mode == 0) { e0 = 0.0f; e1 = 0.0f; idn = idp; if (valid && k == 0) { L.energy0[ii] = 0.0f; L.energy1[ii] = 0.0f; } }   // resetPoints :625-626
+            else if (good) {                              // doStep (:645-671)
+                const float *J = jbOld + (size_t) ii * 10;
+                float p4[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) p4[q] = J[q] * inc[q] + J[q + 4] * inc[q + 4];
+                const float b = J[8] + ((p4[0] + p4[2]) + (p4[1] + p4[3]));
+                float step = -b * J[9] / (1 + lambda);
+                float maxstep = 0.25f * L.maxstep[ii];
+                if (maxstep > 1e10f) maxstep = 1e10f;
+                if (step > maxstep) step = maxstep;
+                if (step < -maxstep) step = -maxstep;
+                float newIdepth = idp + step;
+                if (newIdepth < 1e-3f) newIdepth = 1e-3f;
+                if (newIdepth > 50.0f) newIdepth = 50.0f;
+                idn = newIdepth;
+            }
+        }
+        // ---- calcResAndGS for this point (:206-334) ----
+        bool bad = true;
+        float dp[9], dd = 0.0f, e = 0.0f, ms = 1e10f;
+#pragma unroll
+        for (int q = 0; q < 9; q++) dp[q] = 0.0f;
+        if (valid && good) {
+            const float px = pu + (float) pdx, py = pv + (float) pdy;
+            const float pt0 = ((RKi[0] * px + RKi[1] * py) + RKi[2] * 1.0f) + t[0] * idn;
+            const float pt1 = ((RKi[3] * px + RKi[4] * py) + RKi[5] * 1.0f) + t[1] * idn;
+            const float pt2 = ((RKi[6] * px + RKi[7] * py) + RKi[8] * 1.0f) + t[2] * idn;
+            const float uu = pt0 / pt2, vv = pt1 / pt2;
+            const float Ku = fxl * uu + cxl, Kv = fyl * vv + cyl;
+            const float new_idepth = idn / pt2;
+            if (Ku > 1 && Kv > 1 && Ku < wl - 2 && Kv < hl - 2 && new_idepth > 0) {
+                float hit[3], rlR;
+                {
+                    const int ix = (int) Ku, iy = (int) Kv;
+                    const float dx = Ku - ix, dy = Kv - iy, dxdy = dx * dy;
+                    const float *bp = L.cur + 3 * ((size_t) ix + (size_t) iy * wl);
+#pragma unroll
+                    for (int c = 0; c < 3; c++)
+                        hit[c] = dxdy * bp[3 + 3 * wl + c] + (dy - dxdy) * bp[3 * wl + c] + (dx - dxdy) * bp[3 + c] + (1 - dx - dy + dxdy) * bp[c];
+                }
+                {
+                    const int ix = (int) px, iy = (int) py;
+                    const float dx = px - ix, dy = py - iy, dxdy = dx * dy;
+                    const float *bp = L.first + 3 * ((size_t) ix + (size_t) iy * wl);
+                    rlR = dxdy * bp[3 + 3 * wl] + (dy - dxdy) * bp[3 * wl] + (dx - dxdy) * bp[3] + (1 - dx - dy + dxdy) * bp[0];
+                }
+                if (isfinite(rlR) && isfinite(hit[0])) {
+                    bad = false;
+                    const float residual = hit[0] - affA * rlR - affB;
+                    float hw = fabsf(residual) < huberTH ? 1 : huberTH / fabsf(residual);
+                    e = hw * residual * residual * (2 - hw);
+                    const float dxdd = (t[0] - t[2] * uu) / pt2;
+                    const float dydd = (t[1] - t[2] * vv) / pt2;
+                    if (hw < 1) hw = sqrtf(hw);
+                    const float dxI = hw * hit[1] * fxl, dyI = hw * hit[2] * fyl;
+                    dp[0] = new_idepth * dxI;
+                    dp[1] = new_idepth * dyI;
+                    dp[2] = -new_idepth * (uu * dxI + vv * dyI);
+                    dp[3] = -uu * vv * dxI - (1 + vv * vv) * dyI;
+                    dp[4] = (1 + uu * uu) * dxI + uu * vv * dyI;
+                    dp[5] = -vv * dxI + uu * dyI;
+                    dp[6] = -hw * affA * rlR;
+                    dp[7] = -hw * 1;
+                    dd = dxI * dxdd + dyI * dydd;
+                    dp[8] = hw * residual;
+                    const float nx = dxdd * fxl, ny = dydd * fyl;
+                    ms = 1.0f / sqrtf(nx * nx + ny * ny);
+                }
+            }
+        }
+        // first bad pattern pixel of the 8-lane group: the reference breaks there (:245-259), pixels before it have updated maxstep
+        const unsigned long long bm = __ballot(bad);
+        const unsigned grp = (unsigned) (bm >> (lane & ~7)) & 0xFFu;
+        const int firstBad = grp ? (__ffs(grp) - 1) : 8;
+        const float maxstepNew = ini_min8((k < firstBad) ? ms : 1e10f);
+        const float energy = ini_sum8(e);
+        const bool goodNew = valid && good && firstBad == 8 && !(energy > oTH * 20);
+        float Jb[10];
+#pragma unroll
+        for (int q = 0; q < 9; q++) Jb[q] = ini_sum8(dp[q] * dd);
+        Jb[9] = ini_sum8(dd * dd);
+        float en0, en1;
+        if (goodNew) {
+#pragma unroll
+            for (int r = 0; r < 9; r++)
+#pragma unroll
+                for (int c = r; c < 9; c++) acc[r * 9 - (r * (r - 1)) / 2 + (c - r)] += dp[r] * dp[c];
+            en0 = energy;
+            en1 = (idn - 1) * (idn - 1);
+            const float lastHn = Jb[9];
+            Jb[8] += alphaOpt * (idn - 1);
+            Jb[9] += alphaOpt;
+            if (alphaOpt == 0) { Jb[8] += couplingWeight * (idn - iR); Jb[9] += couplingWeight; }
+            Jb[9] = 1 / (1 + Jb[9]);
+            const float w = Jb[9];
+            // Schur block row k (updateSingleWeighted, MatrixAccumulators.h:1489-1614): diagonal J_r*J_r*w, off-diagonal J_c*(J_r*w)
+            const float rv = (k == 0) ? Jb[0] : (k == 1) ? Jb[1] : (k == 2) ? Jb[2] : (k == 3) ? Jb[3] : (k == 4) ? Jb[4] : (k == 5) ? Jb[5] : (k == 6) ? Jb[6] : Jb[7];
+            const float rw = rv * w;
+#pragma unroll
+            for (int q = 0; q < 9; q++) accSC[q] += (q == k) ? (rv * rv * w) : (Jb[q] * rw);
+            if (k == 0) {
+                accSC[9] += Jb[8] * Jb[8] * w;
+                accE += energy;
+                if (snapped) { const float ro = idp - iR, rn = idn - iR; accEO += ro * ro; accEN += rn * rn; accEC += 1.0f; }
+                L.lastHessian_new[ii] = lastHn;
+            }
+            float *Jo = jbNew + (size_t) ii * 10;
+            Jo[k] = rv;
+            if (k < 2) Jo[8 + k] = (k == 0) ? Jb[8] : Jb[9];
+        } else {
+            en0 = e0; en1 = e1;                            // energy_new = energy (:213, :303)
+            if (valid && k == 0) accE += e0;
+        }
+        if (valid && k == 0) {
+            L.idepth_new[ii] = idn;
+            L.isGood_new[ii] = goodNew ? 1 : 0;
+            L.energy_new0[ii] = en0; L.energy_new1[ii] = en1;
+            L.maxstep[ii] = maxstepNew;
+        }
+    }
+
+    // ---- block reduction -> one partial row ----
+#pragma unroll
+    for (int i = 0; i < 45; i++) acc[i] = ini_sum16(acc[i]);
+    accE = ini_sum16(accE); accEO = ini_sum16(accEO); accEN = ini_sum16(accEN); accEC = ini_sum16(accEC);
+#pragma unroll
+    for (int q = 0; q < 10; q++) accSC[q] += ini_dpp_ror8(accSC[q]);
+    const int row = wave * 4 + (lane >> 4);
+    if ((lane & 15) == 0) {
+#pragma unroll
+        for (int i = 0; i < 45; i++) sRow[row][i] = acc[i];
+        sRow[row][45] = accE; sRow[row][46] = accEO; sRow[row][47] = accEN; sRow[row][48] = accEC;
+    }
+    if ((lane & 15) < 8) {
+#pragma unroll
+        for (int q = 0; q < 10; q++) sSC[row][lane & 7][q] = accSC[q];
+    }
+    __syncthreads();
+    float *out = P.part + (size_t) blockIdx.x * INI_NPART;
+    if (tid < 49) {
+        float s = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) s += sRow[r][tid];
+        out[tid < 45 ? tid : (PR_E + tid - 45)] = s;
+    } else if (tid >= 64 && tid < 64 + 80) {
+        const int kk = (tid - 64) / 10, q = (tid - 64) % 10;
+        float s = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) s += sSC[r][kk][q];
+        if (q < 9) out[PR_SC + kk * 9 + q] = s;
+        else if (kk == 0) out[PR_SC88] = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// control block
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float ini_shfl(float v, int src) { return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src << 2, __builtin_bit_cast(int, v))); }
+__device__ __forceinline__ float ini_bcast(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
+
+// Eigen-style pivoted LDL^T solve (float) of the leading nn x nn block by one wavefront, lane i*8+j holds A[i][j]; x by lanes 0..7
+__device__ void ini_ldlt_wave(float a, float rhsLane, int nn, float *x /*LDS 8*/) {
+    const int lane = threadIdx.x & 63, i = lane >> 3, j = lane & 7;
+    if (i >= nn || j >= nn) a = 0.0f;
+    int tr[8];
+#pragma unroll
+    for (int kk = 0; kk < 8; kk++) {
+        tr[kk] = kk;
+        if (kk < nn) {
+            int idx = kk;
+            float best = fabsf(ini_bcast(a, kk * 9));
+#pragma unroll
+            for (int q = kk + 1; q < 8; q++) { const float d = fabsf(ini_bcast(a, q * 9)); if (q < nn && d > best) { best = d; idx = q; } }
+            tr[kk] = idx;
+            if (idx != kk) {
+                const int si = (i == kk) ? idx : (i == idx) ? kk : i, sj = (j == kk) ? idx : (j == idx) ? kk : j;
+                a = ini_shfl(a, si * 8 + sj);
+            }
+            const float d = ini_bcast(a, kk * 9);
+            const float ci = ini_shfl(a, i * 8 + kk), cj = ini_shfl(a, j * 8 + kk);
+            if (fabsf(d) > 0.0f) {
+                if (i > kk && j > kk) a -= ci * (cj / d);
+                else if (j == kk && i > kk) a = ci / d;
+                else if (i == kk && j > kk) a = cj / d;
+            }
+        }
+    }
+    float xr = (lane < nn) ? rhsLane : 0.0f;
+#pragma unroll
+    for (int kk = 0; kk < 8; kk++) { const int t_ = tr[kk]; if (t_ != kk) { const int src = (lane == kk) ? t_ : (lane == t_) ? kk : lane; xr = ini_shfl(xr, src & 63); } }
+#pragma unroll
+    for (int c = 0; c < 7; c++) { const float xc = ini_bcast(xr, c); const float l = ini_shfl(a, (lane & 7) * 8 + c); if (lane < 8 && lane > c) xr -= l * xc; }
+    { const float dr = ini_shfl(a, (lane & 7) * 9); xr = (fabsf(dr) > 1.17549435e-38f) ? xr / dr : 0.0f; }
+#pragma unroll
+    for (int c = 7; c >= 1; c--) { const float xc = ini_bcast(xr, c); const float l = ini_shfl(a, c * 8 + (lane & 7)); if (lane < c) xr -= l * xc; }
+#pragma unroll
+    for (int kk = 7; kk >= 0; kk--) { const int t_ = tr[kk]; if (t_ != kk) { const int src = (lane == kk) ? t_ : (lane == t_) ? kk : lane; xr = ini_shfl(xr, src & 63); } }
+    if (lane < 8) x[lane] = (lane < nn) ? xr : 0.0f;
+}
+
+#define CE(a, b) do { const float lo_ = fminf(a, b), hi_ = fmaxf(a, b); a = lo_; b = hi_; } while (0)
+
+// The in-place sequential sweeps (see file header).  sIR[j] = key of iR of point j if it is good, INI_NOKEY otherwise; filled by the caller.
+// op 0: optReg (:439-457); op 1: neighbour average of resetPoints (:629-641).
+struct SwIn { int i; int4 a, b, c; float id; };
+// unconditional: the schedule arrays carry INI_SWPAD passes of padding (index -1) behind the last pass
+#define INI_SWPAD 8
+__device__ __forceinline__ SwIn ini_sw_load(const IniLevel &L, int p, int lane) {
+    SwIn r;
+    const size_t q = (size_t) p * 64 + lane;
+    r.i = L.sched[q];
+    const int4 *row = (const int4 *) (L.schedNb + q * INI_NB);
+    r.a = row[0]; r.b = row[1]; r.c = row[2];
+    r.id = L.schedIdv[q];
+    return r;
+}
+// Order-preserving integer key of a (non-NaN) float: integer min/max need no NaN canonicalisation.  INI_NOKEY = point not good.
+#define INI_NOKEY 0x7fffffff
+__device__ __forceinline__ int ini_key(float f) { const int b = __builtin_bit_cast(int, f); return b ^ ((b >> 31) & 0x7fffffff); }
+__device__ __forceinline__ float ini_unkey(int k) { return __builtin_bit_cast(float, k ^ ((k >> 31) & 0x7fffffff)); }
+#define CEI(a, b) do { const int lo_ = min(a, b), hi_ = max(a, b); a = lo_; b = hi_; } while (0)
+
+__device__ __forceinline__ void ini_sw_point(const SwIn &r, int *sK, int op) {
+    const float regWeight = 0.8f;
+    const int ci = r.i;
+    int v[10];
+    // branch-free gathers: clamp the index, select afterwards
+#define GK(dst, idx) do { const int k_ = sK[max(idx, 0)]; dst = ((idx) >= 0) ? k_ : INI_NOKEY; } while (0)
+    GK(v[0], r.a.x); GK(v[1], r.a.y); GK(v[2], r.a.z); GK(v[3], r.a.w);
+    GK(v[4], r.b.x); GK(v[5], r.b.y); GK(v[6], r.b.z); GK(v[7], r.b.w);
+    GK(v[8], r.c.x); GK(v[9], r.c.y);
+    int self;
+    GK(self, ci);
+#undef GK
+    if (op == 0) {
+        int nnn = 0;
+#pragma unroll
+        for (int q = 0; q < 10; q++) nnn += (v[q] != INI_NOKEY) ? 1 : 0;
+        // 29-comparator sorting network for 10 keys; std::nth_element's result at position nnn/2 is the (nnn/2)-th smallest
+        CEI(v[0], v[5]); CEI(v[1], v[6]); CEI(v[2], v[7]); CEI(v[3], v[8]); CEI(v[4], v[9]);
+        CEI(v[0], v[3]); CEI(v[1], v[4]); CEI(v[5], v[8]); CEI(v[6], v[9]);
+        CEI(v[0], v[2]); CEI(v[3], v[6]); CEI(v[7], v[9]);
+        CEI(v[0], v[1]); CEI(v[2], v[4]); CEI(v[5], v[7]); CEI(v[8], v[9]);
+        CEI(v[1], v[2]); CEI(v[3], v[5]); CEI(v[4], v[6]); CEI(v[7], v[8]);
+        CEI(v[1], v[3]); CEI(v[2], v[5]); CEI(v[4], v[7]); CEI(v[6], v[8]);
+        CEI(v[2], v[3]); CEI(v[4], v[5]); CEI(v[6], v[7]);
+        CEI(v[3], v[4]); CEI(v[5], v[6]);
+        const int m = nnn >> 1;
+        const int mk = (m == 0) ? v[0] : (m == 1) ? v[1] : (m == 2) ? v[2] : (m == 3) ? v[3] : (m == 4) ? v[4] : v[5];
+        if (self != INI_NOKEY && nnn > 2) sK[ci] = ini_key((1 - regWeight) * r.id + regWeight * ini_unkey(mk));
+    } else {
+        float snd = 0, sn = 0;
+#pragma unroll
+        for (int q = 0; q < 10; q++) if (v[q] != INI_NOKEY) { snd += ini_unkey(v[q]); sn += 1; }
+        if (ci >= 0 && self == INI_NOKEY && sn > 0) sK[ci] = ini_key(snd / sn);
+    }
+}
+// Executed by wave 0.  The pass inputs (point index, neighbour row, idepth) are stored in schedule order, so every pass needs one
+// level of coalesced global loads, issued four passes ahead; the dependent chain of a pass is LDS gather -> median -> LDS write.
+__device__ void ini_sweep(const IniLevel &L, int *sIR, int op) {
+    if (threadIdx.x >= 64) return;
+    const int lane = threadIdx.x;
+    if (L.nPass == 0) return;
+    SwIn r0 = ini_sw_load(L, 0, lane), r1 = ini_sw_load(L, 1, lane), r2 = ini_sw_load(L, 2, lane), r3 = ini_sw_load(L, 3, lane);
+    for (int p = 0; p < L.nPass; p += 4) {
+        ini_sw_point(r0, sIR, op); r0 = ini_sw_load(L, p + 4, lane);
+        ini_sw_point(r1, sIR, op); r1 = ini_sw_load(L, p + 5, lane);
+        ini_sw_point(r2, sIR, op); r2 = ini_sw_load(L, p + 6, lane);
+        ini_sw_point(r3, sIR, op); r3 = ini_sw_load(L, p + 7, lane);
+    }
+}
+
+__device__ void ini_fill(const IniLevel &L, int *sIR, int pending, const float *idv) {
+    const int nt = blockDim.x;
+    for (int j0 = threadIdx.x; j0 < L.n; j0 += 4 * nt) {
+        int g[4], gn[4]; float r[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int j = j0 + u * nt; const bool in = j < L.n; g[u] = in ? L.isGood[j] : 0; gn[u] = (in && pending) ? L.isGood_new[j] : 1; r[u] = in ? L.iR[j] : 0.0f; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int j = j0 + u * nt; if (j < L.n) sIR[j] = (g[u] && gn[u]) ? ini_key(r[u]) : INI_NOKEY; }
+    }
+    if (idv) {
+        const int m = L.nPass * 64;
+        for (int q0 = threadIdx.x; q0 < m; q0 += 4 * nt) {
+            int i[4]; float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int q = q0 + u * nt; i[u] = (q < m) ? L.sched[q] : -1; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) v[u] = (i[u] >= 0) ? idv[i[u]] : 0.0f;
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int q = q0 + u * nt; if (q < m) L.schedIdv[q] = v[u]; }
+        }
+    }
+}
+
+// optReg(lvl) (:430-459).  pending: an accepted step has not been applied to the arrays yet (lazy applyStep) - use its view.
+__device__ void ini_opt_reg(const IniLevel &L, int *sIR, int snapped, int pending, IniCtl *dbg) {
+    if (!snapped) { for (int j = threadIdx.x; j < L.n; j += blockDim.x) L.iR[j] = 1.0f; __syncthreads(); return; }
+    ini_fill(L, sIR, pending, pending ? L.idepth_new : L.idepth);
+    __syncthreads();
+#ifdef LDSO_STAMPS
+    const long long t0_ = wall_clock64();
+#endif
+    ini_sweep(L, sIR, 0);
+#ifdef LDSO_STAMPS
+    if (threadIdx.x == 0) { dbg->dbgSweepTicks += wall_clock64() - t0_; dbg->dbgSweepPasses += L.nPass; dbg->dbgSweeps++; }
+#endif
+    __syncthreads();
+    for (int j = threadIdx.x; j < L.n; j += blockDim.x) { const int kk = sIR[j]; if (kk != INI_NOKEY) L.iR[j] = ini_unkey(kk); }
+    __syncthreads();
+}
+
+__device__ void ini_flush_apply(const IniLevel &L) {   // applyStep (:673-687) for every point of the level
+    const int nt = blockDim.x;
+    for (int j0 = threadIdx.x; j0 < L.n; j0 += 4 * nt) {
+        int g[4], gn[4]; float r[4], e0[4], e1[4], idn[4], lh[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int j = min(j0 + u * nt, L.n - 1);
+            g[u] = L.isGood[j]; gn[u] = L.isGood_new[j]; r[u] = L.iR[j]; e0[u] = L.energy_new0[j]; e1[u] = L.energy_new1[j]; idn[u] = L.idepth_new[j]; lh[u] = L.lastHessian_new[j];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int j = j0 + u * nt;
+            if (j >= L.n) continue;
+            if (!g[u]) { L.idepth[j] = r[u]; L.idepth_new[j] = r[u]; continue; }
+            L.energy0[j] = e0[u]; L.energy1[j] = e1[u]; L.isGood[j] = gn[u]; L.idepth[j] = idn[u]; L.lastHessian[j] = lh[u];
+        }
+    }
+    __syncthreads();
+}
+
+#define INI_BEGIN 0
+#define INI_STEP 1
+#define INI_STAGE 2
+
+__global__ __launch_bounds__(INI_CT) void k_ini_ctl(IniParams P, int phase) {
+    IniCtl *ctl = P.ctl;
+    extern __shared__ int sIR[];
+    __shared__ double sSum[INI_NPART];
+    __shared__ double sPart[INI_CT / 128][128];
+    __shared__ float sX[8];
+    __shared__ int sFlag[4];
+    const int tid = threadIdx.x;
+    const int top = P.levels - 1;
+
+    if (phase == INI_BEGIN) {                                   // trackFrame :42-69 + resetPoints' neighbour average at the top level
+        const int snapped = ctl->snapped;
+        if (!snapped) {
+            for (int l = 0; l < P.levels; l++) {
+                const IniLevel &L = P.L[l];
+                for (int j = tid; j < L.n; j += blockDim.x) { L.iR[j] = 1.0f; L.idepth_new[j] = 1.0f; L.lastHessian[j] = 0.0f; }
+            }
+        }
+        if (tid == 0) {
+            if (!snapped) { ctl->Tcur[3] = 0; ctl->Tcur[7] = 0; ctl->Tcur[11] = 0; }
+            if (P.firstExposure > 0 && P.newExposure > 0) { ctl->aCur = logf(P.newExposure / P.firstExposure); ctl->bCur = 0; }
+            for (int q = 0; q < 12; q++) ctl->Tnew[q] = ctl->Tcur[q];
+            ctl->aNew = ctl->aCur; ctl->bNew = ctl->bCur;
+            ctl->lvl = top; ctl->mode = 0; ctl->done = 0; ctl->evals = 0; ctl->applyPending = 0; ctl->iteration = 0; ctl->fails = 0; ctl->lambda = 0.1f;
+            for (int q = 0; q < 8; q++) ctl->inc[q] = 0;
+        }
+        __syncthreads();
+        const IniLevel &L = P.L[top];
+        ini_fill(L, sIR, 0, nullptr);
+        __syncthreads();
+        ini_sweep(L, sIR, 1);
+        __syncthreads();
+        for (int j = tid; j < L.n; j += blockDim.x) {
+            const int kk = sIR[j];
+            if (!L.isGood[j] && kk != INI_NOKEY) { const float v = ini_unkey(kk); L.isGood[j] = 1; L.iR[j] = v; L.idepth[j] = v; L.idepth_new[j] = v; }
+        }
+        return;
+    }
+
+    if (phase == INI_STEP && ctl->done) return;
+#ifdef LDSO_STAMPS
+    const long long tk0_ = wall_clock64();
+    struct TkEnd { IniCtl *c; long long t0; __device__ ~TkEnd() { if (threadIdx.x == 0) c->dbgCtlTicks += wall_clock64() - t0; } } tkEnd_{ctl, tk0_};
+#endif
+    const int lvl = ctl->lvl;
+    const IniLevel &L = P.L[lvl];
+    const int n = L.n;
+    // ---- sum the partial rows ----
+    {
+        const int nblk = ini_nblocks(n, INI_MAXBLK);
+        const int c = tid & 127, part = tid >> 7;              // 8 row slices
+        double s = 0.0;
+        if (c < PR_N) {
+#pragma unroll 8
+            for (int r = part; r < nblk; r += INI_CT / 128) s += (double) P.part[(size_t) r * INI_NPART + c];
+        }
+        sPart[part][c] = s;
+        __syncthreads();
+        if (tid < 128) { double a = 0.0; for (int q = 0; q < INI_CT / 128; q++) a += sPart[q][tid]; sSum[tid] = a; }
+        __syncthreads();
+    }
+    const float alphaK = 2.5f * 2.5f, alphaW = 150.0f * 150.0f;
+    if (tid < 64) {                                             // H_new, Hsc_new (:389-401)
+        const int r = tid >> 3, c = tid & 7, lo = min(r, c), hi = max(r, c);
+        ctl->Hn[tid] = (float) sSum[lo * 9 - (lo * (lo - 1)) / 2 + (hi - lo)];
+        ctl->Hscn[tid] = (float) sSum[PR_SC + lo * 9 + hi];
+    } else if (tid < 72) {
+        const int r = tid - 64;
+        ctl->bn[r] = (float) sSum[r * 9 - (r * (r - 1)) / 2 + (8 - r)];
+        ctl->bscn[r] = (float) sSum[PR_SC + r * 9 + 8];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const double *T = ctl->Tnew;
+        const double tsq = T[3] * T[3] + T[7] * T[7] + T[11] * T[11];
+        float alphaEnergy = (float) ((double) alphaW * (0.0 + tsq * (double) n));
+        float alphaOpt;
+        if (alphaEnergy > alphaK * (float) n) { alphaOpt = 0; alphaEnergy = alphaK * (float) n; } else alphaOpt = alphaW;
+        ctl->Hn[0] += alphaOpt * n; ctl->Hn[9] += alphaOpt * n; ctl->Hn[18] += alphaOpt * n;
+        double lg[6];
+        ld::se3_log(T, lg);
+        for (int q = 0; q < 3; q++) ctl->bn[q] += (float) lg[q] * alphaOpt * n;
+        ctl->resNew[0] = (float) sSum[PR_E]; ctl->resNew[1] = alphaEnergy; ctl->resNew[2] = (float) (2 * n);
+        if (ctl->snapped) { ctl->ec[0] = 1.0f * (float) sSum[PR_ECO]; ctl->ec[1] = 1.0f * (float) sSum[PR_ECN]; ctl->ec[2] = (float) sSum[PR_ECC]; }
+        else { ctl->ec[0] = 0; ctl->ec[1] = 0; ctl->ec[2] = (float) n; }
+    }
+    __syncthreads();
+    if (phase == INI_STAGE) return;
+
+    // ---- the decision of :120-158 ----
+    if (tid == 0) {
+        const int maxIterations[5] = {5, 5, 10, 30, 50};
+        int accept, quit = 0, doOpt = 0;
+        ctl->evals++;
+        if (ctl->mode == 0) {                                   // first evaluation of the level (:81-88)
+            accept = 1;
+            ctl->lambda = 0.1f; ctl->fails = 0; ctl->iteration = 0; ctl->mode = 1;
+        } else {
+            const float eTotalNew = (ctl->resNew[0] + ctl->resNew[1] + ctl->ec[1]);
+            const float eTotalOld = (ctl->resOld[0] + ctl->resOld[1] + ctl->ec[0]);
+            accept = eTotalOld > eTotalNew;
+            if (accept) {
+                if (ctl->resNew[1] == alphaK * (float) n) ctl->snapped = 1;
+                for (int q = 0; q < 12; q++) ctl->Tcur[q] = ctl->Tnew[q];
+                ctl->aCur = ctl->aNew; ctl->bCur = ctl->bNew;
+                doOpt = 1;
+                ctl->lambda *= 0.5f; ctl->fails = 0;
+                if (ctl->lambda < 0.0001f) ctl->lambda = 0.0001f;
+            } else {
+                ctl->fails++;
+                ctl->lambda *= 4;
+                if (ctl->lambda > 10000) ctl->lambda = 10000;
+            }
+            float nrm = 0;
+            for (int q = 0; q < 8; q++) nrm += ctl->inc[q] * ctl->inc[q];
+            nrm = sqrtf(nrm);
+            if (!(nrm > 1e-4f) || ctl->iteration >= maxIterations[lvl] || ctl->fails >= 2) quit = 1;
+            else ctl->iteration++;
+        }
+        if (accept) {
+            for (int q = 0; q < 64; q++) { ctl->H[q] = ctl->Hn[q]; ctl->Hsc[q] = ctl->Hscn[q]; }
+            for (int q = 0; q < 8; q++) { ctl->b[q] = ctl->bn[q]; ctl->bsc[q] = ctl->bscn[q]; }
+            for (int q = 0; q < 3; q++) ctl->resOld[q] = ctl->resNew[q];
+            ctl->applyPending = 1; ctl->jbSel ^= 1;
+        } else ctl->applyPending = 0;
+        sFlag[0] = accept; sFlag[1] = quit; sFlag[2] = doOpt; sFlag[3] = ctl->snapped;
+    }
+    __syncthreads();
+    const int accept = sFlag[0], quit = sFlag[1], doOpt = sFlag[2], snapped = sFlag[3];
+    if (doOpt) ini_opt_reg(L, sIR, snapped, 1, ctl);                 // applyStep (pending) + optReg (:137-138)
+
+    if (quit) {
+        if (accept) ini_flush_apply(L);
+        if (tid == 0) ctl->applyPending = 0;
+        if (lvl > 0) {                                          // propagateDown(lvl) (:498-522) into level lvl-1
+            const IniLevel &F = P.L[lvl - 1];
+            const int nt = blockDim.x;
+            for (int j0 = tid; j0 < F.n; j0 += 4 * nt) {
+                int pa[4], pg[4], fg[4]; float plh[4], pir[4], fir[4], flh[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) { const int j = min(j0 + u * nt, F.n - 1); pa[u] = F.parent[j]; fg[u] = F.isGood[j]; fir[u] = F.iR[j]; flh[u] = F.lastHessian[j]; }
+#pragma unroll
+                for (int u = 0; u < 4; u++) { pg[u] = L.isGood[pa[u]]; plh[u] = L.lastHessian[pa[u]]; pir[u] = L.iR[pa[u]]; }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int j = j0 + u * nt;
+                    if (j >= F.n) continue;
+                    if (!pg[u] || plh[u] < 0.1f) continue;
+                    if (!fg[u]) {
+                        const float r = pir[u];
+                        F.iR[j] = r; F.idepth[j] = r; F.idepth_new[j] = r; F.isGood[j] = 1; F.lastHessian[j] = 0;
+                    } else {
+                        const float newiR = (fir[u] * flh[u] * 2 + pir[u] * plh[u]) / (flh[u] * 2 + plh[u]);
+                        F.iR[j] = newiR; F.idepth[j] = newiR; F.idepth_new[j] = newiR;
+                    }
+                }
+            }
+            __syncthreads();
+            ini_opt_reg(F, sIR, snapped, 0, ctl);
+            if (tid == 0) {
+                ctl->lvl = lvl - 1; ctl->mode = 0;
+                for (int q = 0; q < 12; q++) ctl->Tnew[q] = ctl->Tcur[q];
+                ctl->aNew = ctl->aCur; ctl->bNew = ctl->bCur;
+            }
+        } else {                                                // :165-177
+            for (int s = 0; s + 1 < P.levels; s++) {            // propagateUp(s) (:462-496)
+                const IniLevel &S = P.L[s], &D = P.L[s + 1];
+                for (int p = tid; p < D.n; p += blockDim.x) {
+                    float a = 0, sum = 0;
+                    for (int q = D.childOff[p]; q < D.childOff[p + 1]; q++) {
+                        const int c = D.childIdx[q];
+                        if (!S.isGood[c]) continue;
+                        a += S.iR[c] * S.lastHessian[c];
+                        sum += S.lastHessian[c];
+                    }
+                    D.iRSumNum[p] = sum;
+                    if (sum > 0) { const float r = a / sum; D.iR[p] = r; D.idepth[p] = r; D.isGood[p] = 1; }
+                    else D.iR[p] = a;
+                }
+                __syncthreads();
+                ini_opt_reg(D, sIR, snapped, 0, ctl);
+            }
+            if (tid == 0) {
+                ctl->frameID++;
+                if (!ctl->snapped) ctl->snappedAt = 0;
+                if (ctl->snapped && ctl->snappedAt == 0) ctl->snappedAt = ctl->frameID;
+                ctl->ready = ctl->snapped && ctl->frameID > ctl->snappedAt + 5;
+                ctl->done = 1;
+            }
+        }
+        return;
+    }
+
+    // ---- next increment (:90-111) ----
+    if (tid < 64) {
+        const int i = tid >> 3, j = tid & 7;
+        const float lambda = ctl->lambda;
+        const float wMi = (i < 3) ? 1.0f : (i < 6) ? 0.5f : (i == 6) ? 10.0f : 1000.0f, wMj = (j < 3) ? 1.0f : (j < 6) ? 0.5f : (j == 6) ? 10.0f : 1000.0f;
+        float Hl = ctl->H[tid];
+        if (i == j) Hl *= (1 + lambda);
+        Hl -= ctl->Hsc[tid] * (1 / (1 + lambda));
+        const float sc = (0.01f / (L.w * L.h));
+        Hl = ((wMi * Hl) * wMj) * sc;
+        float bl = 0.0f;
+        if (tid < 8) {
+            const float wMr = (tid < 3) ? 1.0f : (tid < 6) ? 0.5f : (tid == 6) ? 10.0f : 1000.0f;
+            bl = ctl->b[tid] - ctl->bsc[tid] * (1 / (1 + lambda));
+            bl = (wMr * bl) * sc;
+        }
+        ini_ldlt_wave(Hl, bl, P.fixAffine ? 6 : 8, sX);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double xi[6], E[12], Tn[12];
+        for (int q = 0; q < 8; q++) {
+            const float wMr = (q < 3) ? 1.0f : (q < 6) ? 0.5f : (q == 6) ? 10.0f : 1000.0f;
+            ctl->inc[q] = (P.fixAffine && q >= 6) ? 0.0f : -(wMr * sX[q]);
+        }
+        for (int q = 0; q < 6; q++) xi[q] = (double) ctl->inc[q];
+        ld::se3_exp(xi, E);
+        ld::se3_mul(E, ctl->Tcur, Tn);
+        for (int q = 0; q < 12; q++) ctl->Tnew[q] = Tn[q];
+        ctl->aNew = ctl->aCur + ctl->inc[6];
+        ctl->bNew = ctl->bCur + ctl->inc[7];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// host
+// ---------------------------------------------------------------------------------------------------------
+struct ldso_initializer {
+    int device = 0, w = 0, h = 0, levels = 0;
+    hipStream_t stream = nullptr;
+    bool ownStream = false;
+    IniParams P;
+    std::vector<void *> allocs, levelAllocs;
+    float *d_first[INI_MAXL] = {nullptr}, *d_new[INI_MAXL] = {nullptr};
+    float *d_color = nullptr;
+    int n[INI_MAXL] = {0};
+    size_t ldsBytes = 0;
+    bool haveFirst = false, haveNew = false;
+};
+
+template <class T> static int ini_alloc(std::vector<void *> &v, T **p, size_t n) {
+    void *q = nullptr;
+    CHK(hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T)));
+    CHK(hipMemset(q, 0, std::max<size_t>(n, 1) * sizeof(T)));
+    v.push_back(q);
+    *p = (T *) q;
+    return LDSO_OK;
+}
+#define IA(vec, ptr, n) do { int r_ = ini_alloc(vec, &(ptr), (n)); if (r_ != LDSO_OK) return r_; } while (0)
+
+// upload helper: host vector -> new device array
+template <class T> static int ini_upload(ldso_initializer *H, T **dst, const std::vector<T> &src) {
+    IA(H->levelAllocs, *dst, src.size());
+    if (!src.empty()) CHK(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return LDSO_OK;
+}
+
+static int ini_sync(ldso_initializer *H) { CHK(hipStreamSynchronize(H->stream)); return LDSO_OK; }
+
+// SoA <-> record conversion
+#define INI_FIELDS(X) X(u) X(v) X(idepth) X(idepth_new) X(iR) X(iRSumNum) X(lastHessian) X(lastHessian_new) X(maxstep) X(outlierTH)
+
+static int ini_put_points(ldso_initializer *H, int l, const ldso_init_point_t *pts) {
+    IniLevel &L = H->P.L[l];
+    const int n = H->n[l];
+    std::vector<float> f(n);
+    std::vector<int> g(n);
+#define X(name) for (int i = 0; i < n; i++) f[i] = pts[i].name; if (n) CHK(hipMemcpy(L.name, f.data(), (size_t) n * 4, hipMemcpyHostToDevice));
+    INI_FIELDS(X)
+#undef X
+#define XE(dst, expr) for (int i = 0; i < n; i++) f[i] = pts[i].expr; if (n) CHK(hipMemcpy(L.dst, f.data(), (size_t) n * 4, hipMemcpyHostToDevice));
+    XE(energy0, energy[0]) XE(energy1, energy[1]) XE(energy_new0, energy_new[0]) XE(energy_new1, energy_new[1])
+#undef XE
+#define XI(dst, expr) for (int i = 0; i < n; i++) g[i] = pts[i].expr; if (n) CHK(hipMemcpy(L.dst, g.data(), (size_t) n * 4, hipMemcpyHostToDevice));
+    XI(isGood, isGood) XI(isGood_new, isGood_new)
+#undef XI
+    return LDSO_OK;
+}
+
+extern "C" {
+
+int ldso_init_create(int device, int w, int h, int levels, ldso_initializer_t **out) {
+    REQ(out && w > 16 && h > 16 && levels >= 1 && levels <= INI_MAXL && (w >> (levels - 1)) >= 8, "ldso_init_create: bad arguments (at most 5 pyramid levels)");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { ldso_set_error("no HIP device visible"); return LDSO_E_NODEVICE; }
+    REQ(device >= 0 && device < ndev, "ldso_init_create: device index out of range");
+    CHK(hipSetDevice(device));
+    ldso_initializer *H = new ldso_initializer();
+    H->device = device; H->w = w; H->h = h; H->levels = levels;
+    CHK(hipStreamCreateWithFlags(&H->stream, hipStreamNonBlocking));
+    H->ownStream = true;
+    memset(&H->P, 0, sizeof(H->P));
+    H->P.levels = levels; H->P.fixAffine = 1; H->P.huberTH = 9.0f; H->P.firstExposure = 1; H->P.newExposure = 1;
+    for (int l = 0; l < levels; l++) {
+        const size_t npx = (size_t) (w >> l) * (h >> l);
+        IA(H->allocs, H->d_first[l], npx * 3); IA(H->allocs, H->d_new[l], npx * 3);
+        H->P.L[l].first = H->d_first[l]; H->P.L[l].cur = H->d_new[l];
+        H->P.L[l].w = w >> l; H->P.L[l].h = h >> l;
+    }
+    IA(H->allocs, H->d_color, (size_t) w * h);
+    IA(H->allocs, H->P.ctl, 1);
+    IA(H->allocs, H->P.part, (size_t) INI_MAXBLK * INI_NPART);
+    IniCtl c; memset(&c, 0, sizeof(c));
+    c.Tcur[0] = c.Tcur[5] = c.Tcur[10] = 1.0; c.Tnew[0] = c.Tnew[5] = c.Tnew[10] = 1.0; c.frameID = -1; c.done = 1;
+    CHK(hipMemcpy(H->P.ctl, &c, sizeof(c), hipMemcpyHostToDevice));
+    *out = H;
+    return LDSO_OK;
+}
+
+int ldso_init_destroy(ldso_initializer_t *H) {
+    if (!H) return LDSO_OK;
+    hipSetDevice(H->device);
+    hipDeviceSynchronize();
+    for (void *p : H->allocs) hipFree(p);
+    for (void *p : H->levelAllocs) hipFree(p);
+    if (H->ownStream && H->stream) hipStreamDestroy(H->stream);
+    delete H;
+    return LDSO_OK;
+}
+
+int ldso_init_set_stream(ldso_initializer_t *H, void *s) {
+    REQ(H, "null handle");
+    if (H->ownStream && H->stream) { hipStreamSynchronize(H->stream); if (s) { hipStreamDestroy(H->stream); H->ownStream = false; } }
+    if (s) { H->stream = (hipStream_t) s; H->ownStream = false; }
+    else if (!H->ownStream) { CHK(hipStreamCreateWithFlags(&H->stream, hipStreamNonBlocking)); H->ownStream = true; }
+    return LDSO_OK;
+}
+
+static int ini_images(ldso_initializer *H, const float *irr, float *const *levels) {
+    CHK(hipSetDevice(H->device));
+    CHK(hipMemcpyAsync(H->d_color, irr, (size_t) H->w * H->h * 4, hipMemcpyHostToDevice, H->stream));
+    CHK(img_launch_make_images(H->d_color, H->w, H->h, H->levels, levels, H->stream));
+    CHK(hipStreamSynchronize(H->stream));      // the host buffer may be reused by the caller
+    return LDSO_OK;
+}
+
+int ldso_init_set_first(ldso_initializer_t *H, const float calib[4], const float *irradiance, float ab_exposure,
+                        const ldso_init_point_t *const *points, const int *n_points, float huberTH, int fixAffine) {
+    REQ(H && calib && irradiance && points && n_points, "ldso_init_set_first: null argument");
+    CHK(hipSetDevice(H->device));
+    CHK(hipStreamSynchronize(H->stream));
+    for (void *p : H->levelAllocs) hipFree(p);
+    H->levelAllocs.clear();
+    H->P.huberTH = huberTH; H->P.fixAffine = fixAffine ? 1 : 0; H->P.firstExposure = ab_exposure;
+    // makeK (:689-715): doubles from the float level-0 intrinsics
+    double fx[INI_MAXL], fy[INI_MAXL], cx[INI_MAXL], cy[INI_MAXL];
+    fx[0] = calib[0]; fy[0] = calib[1]; cx[0] = calib[2]; cy[0] = calib[3];
+    for (int l = 1; l < H->levels; l++) {
+        fx[l] = fx[l - 1] * 0.5; fy[l] = fy[l - 1] * 0.5;
+        cx[l] = (cx[0] + 0.5) / ((int) 1 << l) - 0.5; cy[l] = (cy[0] + 0.5) / ((int) 1 << l) - 0.5;
+    }
+    size_t maxN = 64;
+    for (int l = 0; l < H->levels; l++) {
+        IniLevel &L = H->P.L[l];
+        const int n = n_points[l];
+        REQ(n >= 0 && n <= 36000, "ldso_init_set_first: more than 36000 points on one level (LDS working set of the sweeps)");
+        REQ(n == 0 || points[l], "ldso_init_set_first: null point array");
+        H->n[l] = n; L.n = n;
+        maxN = std::max<size_t>(maxN, n);
+        L.fx = (float) fx[l]; L.fy = (float) fy[l]; L.cx = (float) cx[l]; L.cy = (float) cy[l];
+        // K^-1 of the upper-triangular K in double (Eigen's cofactor inverse gives the same entries up to 1 ulp of double)
+        for (int q = 0; q < 9; q++) L.Ki[q] = 0;
+        L.Ki[0] = 1.0 / fx[l]; L.Ki[2] = -cx[l] / fx[l]; L.Ki[4] = 1.0 / fy[l]; L.Ki[5] = -cy[l] / fy[l]; L.Ki[8] = 1.0;
+#define X(name) IA(H->levelAllocs, L.name, n);
+        INI_FIELDS(X)
+        X(energy0) X(energy1) X(energy_new0) X(energy_new1) X(isGood) X(isGood_new)
+#undef X
+        IA(H->levelAllocs, L.jb[0], (size_t) n * 10); IA(H->levelAllocs, L.jb[1], (size_t) n * 10);
+        const ldso_init_point_t *pts = points[l];
+        const int nUp = (l + 1 < H->levels) ? n_points[l + 1] : 0, nDown = (l > 0) ? n_points[l - 1] : 0;
+        std::vector<int> parent(n), nb((size_t) n * INI_NB, -1);
+        for (int i = 0; i < n; i++) {
+            parent[i] = pts[i].parent;
+            REQ(l + 1 >= H->levels || (parent[i] >= 0 && parent[i] < nUp), "ldso_init_set_first: parent index out of range");
+            for (int q = 0; q < 10; q++) {
+                const int j = pts[i].neighbours[q];
+                REQ(j >= -1 && j < n, "ldso_init_set_first: neighbour index out of range");
+                nb[(size_t) i * INI_NB + q] = j;
+            }
+        }
+        { int r_ = ini_upload(H, &L.parent, parent); if (r_ != LDSO_OK) return r_; }
+        { int r_ = ini_upload(H, &L.nb, nb); if (r_ != LDSO_OK) return r_; }
+        // sweep schedule: dep(i) = max(dep(j) + 1 over neighbours j < i, dep(k) over readers k < i of i)
+        std::vector<int> dep(n, 0);
+        {
+            std::vector<int> rd(n, 0);      // max dep of the lower-indexed readers seen so far
+            for (int i = 0; i < n; i++) {
+                int d = rd[i];
+                for (int q = 0; q < 10; q++) { const int j = nb[(size_t) i * INI_NB + q]; if (j >= 0 && j < i) d = std::max(d, dep[j] + 1); }
+                dep[i] = d;
+                for (int q = 0; q < 10; q++) { const int j = nb[(size_t) i * INI_NB + q]; if (j > i) rd[j] = std::max(rd[j], d); }
+            }
+        }
+        int nDep = 0;
+        for (int i = 0; i < n; i++) nDep = std::max(nDep, dep[i] + 1);
+        std::vector<std::vector<int>> byDep(nDep);
+        for (int i = 0; i < n; i++) byDep[dep[i]].push_back(i);
+        std::vector<int> sched;
+        for (int d = 0; d < nDep; d++)
+            for (size_t o = 0; o < byDep[d].size(); o += 64) {
+                for (size_t q = 0; q < 64; q++) sched.push_back(o + q < byDep[d].size() ? byDep[d][o + q] : -1);
+            }
+        L.nPass = (int) (sched.size() / 64);
+        sched.resize(sched.size() + (size_t) INI_SWPAD * 64, -1);
+        { int *p = nullptr; int r_ = ini_upload(H, &p, sched); if (r_ != LDSO_OK) return r_; L.sched = p; }
+        {
+            std::vector<int> snb(sched.size() * INI_NB, -1);
+            for (size_t q = 0; q < sched.size(); q++) if (sched[q] >= 0) for (int e = 0; e < INI_NB; e++) snb[q * INI_NB + e] = nb[(size_t) sched[q] * INI_NB + e];
+            int *p = nullptr; int r_ = ini_upload(H, &p, snb); if (r_ != LDSO_OK) return r_; L.schedNb = p;
+            IA(H->levelAllocs, L.schedIdv, sched.size());
+        }
+        // children lists (points of level l-1 whose parent is p), ascending child index
+        std::vector<int> off(n + 1, 0), idx(nDown);
+        if (l > 0) {
+            const ldso_init_point_t *ch = points[l - 1];
+            for (int c = 0; c < nDown; c++) { REQ(ch[c].parent >= 0 && ch[c].parent < n, "ldso_init_set_first: parent index out of range"); off[ch[c].parent + 1]++; }
+            for (int p = 0; p < n; p++) off[p + 1] += off[p];
+            std::vector<int> cur(off.begin(), off.end() - 1);
+            for (int c = 0; c < nDown; c++) idx[cur[ch[c].parent]++] = c;
+        }
+        { int *p = nullptr; int r_ = ini_upload(H, &p, off); if (r_ != LDSO_OK) return r_; L.childOff = p; }
+        { int *p = nullptr; int r_ = ini_upload(H, &p, idx); if (r_ != LDSO_OK) return r_; L.childIdx = p; }
+        { int r_ = ini_put_points(H, l, pts); if (r_ != LDSO_OK) return r_; }
+    }
+    H->ldsBytes = maxN * sizeof(float);
+    CHK(hipFuncSetAttribute((const void *) k_ini_ctl, hipFuncAttributeMaxDynamicSharedMemorySize, (int) H->ldsBytes));
+    // state of setFirst (:612-614)
+    IniCtl c; memset(&c, 0, sizeof(c));
+    c.Tcur[0] = c.Tcur[5] = c.Tcur[10] = 1.0; c.Tnew[0] = c.Tnew[5] = c.Tnew[10] = 1.0; c.done = 1;
+    CHK(hipMemcpy(H->P.ctl, &c, sizeof(c), hipMemcpyHostToDevice));
+    { int r_ = ini_images(H, irradiance, H->d_first); if (r_ != LDSO_OK) return r_; }
+    H->haveFirst = true; H->haveNew = false;
+    return LDSO_OK;
+}
+
+int ldso_init_set_new_frame(ldso_initializer_t *H, const float *irradiance, float ab_exposure) {
+    REQ(H && irradiance, "ldso_init_set_new_frame: null argument");
+    REQ(H->haveFirst, "ldso_init_set_new_frame: no first frame");
+    H->P.newExposure = ab_exposure;
+    int r_ = ini_images(H, irradiance, H->d_new);
+    if (r_ != LDSO_OK) return r_;
+    H->haveNew = true;
+    return LDSO_OK;
+}
+
+int ldso_init_get_state(ldso_initializer_t *H, ldso_init_state_t *s) {
+    REQ(H && s, "null argument");
+    CHK(hipSetDevice(H->device));
+    IniCtl c;
+    CHK(hipMemcpyAsync(&c, H->P.ctl, sizeof(c), hipMemcpyDeviceToHost, H->stream));
+    CHK(hipStreamSynchronize(H->stream));
+    memcpy(s->thisToNext, c.Tcur, sizeof(c.Tcur));
+    s->aff_a = c.aCur; s->aff_b = c.bCur; s->snapped = c.snapped; s->snappedAt = c.snappedAt; s->frameID = c.frameID;
+    s->ready = c.snapped && c.frameID > c.snappedAt + 5; s->evals = c.evals; s->pad_ = 0;
+    return LDSO_OK;
+}
+
+int ldso_init_set_state(ldso_initializer_t *H, const ldso_init_state_t *s) {
+    REQ(H && s, "null argument");
+    CHK(hipSetDevice(H->device));
+    IniCtl c;
+    CHK(hipMemcpyAsync(&c, H->P.ctl, sizeof(c), hipMemcpyDeviceToHost, H->stream));
+    CHK(hipStreamSynchronize(H->stream));
+    memcpy(c.Tcur, s->thisToNext, sizeof(c.Tcur)); memcpy(c.Tnew, s->thisToNext, sizeof(c.Tnew));
+    c.aCur = (float) s->aff_a; c.bCur = (float) s->aff_b; c.aNew = c.aCur; c.bNew = c.bCur;
+    c.snapped = s->snapped; c.snappedAt = s->snappedAt; c.frameID = s->frameID;
+    CHK(hipMemcpyAsync(H->P.ctl, &c, sizeof(c), hipMemcpyHostToDevice, H->stream));
+    CHK(hipStreamSynchronize(H->stream));
+    return LDSO_OK;
+}
+
+int ldso_init_track_frame(ldso_initializer_t *H, const float *irradiance, float ab_exposure, ldso_init_state_t *state_out) {
+    REQ(H, "null handle");
+    REQ(H->haveFirst, "ldso_init_track_frame: no first frame");
+    CHK(hipSetDevice(H->device));
+    if (irradiance) { int r_ = ldso_init_set_new_frame(H, irradiance, ab_exposure); if (r_ != LDSO_OK) return r_; }
+    REQ(H->haveNew, "ldso_init_track_frame: no new frame");
+    const int maxIterations[5] = {5, 5, 10, 30, 50};
+    int pairs = 0;
+    for (int l = 0; l < H->levels; l++) pairs += maxIterations[l] + 2;
+    hipLaunchKernelGGL(k_ini_ctl, dim3(1), dim3(INI_CT), H->ldsBytes, H->stream, H->P, INI_BEGIN);
+    for (int p = 0; p < pairs; p++) {
+        hipLaunchKernelGGL(k_ini_eval, dim3(INI_MAXBLK), dim3(INI_NT), 0, H->stream, H->P, 0);
+        hipLaunchKernelGGL(k_ini_ctl, dim3(1), dim3(INI_CT), H->ldsBytes, H->stream, H->P, INI_STEP);
+    }
+    CHK(hipGetLastError());
+    ldso_init_state_t st;
+    int r_ = ldso_init_get_state(H, &st);
+    if (r_ != LDSO_OK) return r_;
+    bool fin = true;
+    for (int q = 0; q < 12; q++) fin = fin && std::isfinite(st.thisToNext[q]);
+    if (state_out) *state_out = st;
+    if (!fin) { ldso_set_error("ldso_init_track_frame: non-finite pose"); return LDSO_E_NONFINITE; }
+    return LDSO_OK;
+}
+
+// debug (LDSO_STAMPS builds): accumulated device-side ticks (100 MHz): sweep ticks, sweep passes, control-kernel ticks, sweeps
+int ldso_init_debug_counters(ldso_initializer_t *H, long long out[4]) {
+    REQ(H && out, "null argument");
+    CHK(hipSetDevice(H->device));
+    CHK(hipStreamSynchronize(H->stream));
+    IniCtl c;
+    CHK(hipMemcpy(&c, H->P.ctl, sizeof(c), hipMemcpyDeviceToHost));
+    out[0] = c.dbgSweepTicks; out[1] = c.dbgSweepPasses; out[2] = c.dbgCtlTicks; out[3] = c.dbgSweeps;
+    return LDSO_OK;
+}
+
+int ldso_init_get_points(ldso_initializer_t *H, int l, ldso_init_point_t *out) {
+    REQ(H && out && l >= 0 && l < H->levels, "ldso_init_get_points: bad argument");
+    CHK(hipSetDevice(H->device));
+    CHK(hipStreamSynchronize(H->stream));
+    IniCtl c;
+    CHK(hipMemcpy(&c, H->P.ctl, sizeof(c), hipMemcpyDeviceToHost));
+    REQ(!c.applyPending, "ldso_init_get_points: a step is pending (internal)");
+    const IniLevel &L = H->P.L[l];
+    const int n = H->n[l];
+    std::vector<float> f(n);
+    std::vector<int> g(n), nb((size_t) n * INI_NB);
+#define X(name) if (n) CHK(hipMemcpy(f.data(), L.name, n * 4, hipMemcpyDeviceToHost)); for (int i = 0; i < n; i++) out[i].name = f[i];
+    INI_FIELDS(X)
+#undef X
+#define XE(src, expr) if (n) CHK(hipMemcpy(f.data(), L.src, n * 4, hipMemcpyDeviceToHost)); for (int i = 0; i < n; i++) out[i].expr = f[i];
+    XE(energy0, energy[0]) XE(energy1, energy[1]) XE(energy_new0, energy_new[0]) XE(energy_new1, energy_new[1])
+#undef XE
+#define XI(src, expr) if (n) CHK(hipMemcpy(g.data(), L.src, n * 4, hipMemcpyDeviceToHost)); for (int i = 0; i < n; i++) out[i].expr = g[i];
+    XI(isGood, isGood) XI(isGood_new, isGood_new) XI(parent, parent)
+#undef XI
+    if (n) CHK(hipMemcpy(nb.data(), L.nb, (size_t) n * INI_NB * 4, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; i++) for (int q = 0; q < 10; q++) out[i].neighbours[q] = nb[(size_t) i * INI_NB + q];
+    return LDSO_OK;
+}
+
+int ldso_init_set_points(ldso_initializer_t *H, int l, const ldso_init_point_t *pts) {
+    REQ(H && pts && l >= 0 && l < H->levels, "ldso_init_set_points: bad argument");
+    CHK(hipSetDevice(H->device));
+    CHK(hipStreamSynchronize(H->stream));
+    return ini_put_points(H, l, pts);
+}
+
+int ldso_init_calc_res_and_gs(ldso_initializer_t *H, int lvl, const double refToNew[12], double aff_a, double aff_b,
+                              float *Hm, float *b, float *Hsc, float *bsc, float *res, float *ec) {
+    REQ(H && refToNew && lvl >= 0 && lvl < H->levels, "ldso_init_calc_res_and_gs: bad argument");
+    REQ(H->haveFirst && H->haveNew, "ldso_init_calc_res_and_gs: frames missing");
+    CHK(hipSetDevice(H->device));
+    CHK(hipStreamSynchronize(H->stream));
+    IniCtl c;
+    CHK(hipMemcpy(&c, H->P.ctl, sizeof(c), hipMemcpyDeviceToHost));
+    memcpy(c.Tnew, refToNew, sizeof(c.Tnew));
+    c.aNew = (float) aff_a; c.bNew = (float) aff_b; c.lvl = lvl;
+    CHK(hipMemcpy(H->P.ctl, &c, sizeof(c), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_ini_eval, dim3(INI_MAXBLK), dim3(INI_NT), 0, H->stream, H->P, 1);
+    hipLaunchKernelGGL(k_ini_ctl, dim3(1), dim3(INI_CT), H->ldsBytes, H->stream, H->P, INI_STAGE);
+    CHK(hipGetLastError());
+    CHK(hipStreamSynchronize(H->stream));
+    CHK(hipMemcpy(&c, H->P.ctl, sizeof(c), hipMemcpyDeviceToHost));
+    if (Hm) memcpy(Hm, c.Hn, sizeof(c.Hn));
+    if (b) memcpy(b, c.bn, sizeof(c.bn));
+    if (Hsc) memcpy(Hsc, c.Hscn, sizeof(c.Hscn));
+    if (bsc) memcpy(bsc, c.bscn, sizeof(c.bscn));
+    if (res) memcpy(res, c.resNew, sizeof(c.resNew));
+    if (ec) memcpy(ec, c.ec, sizeof(c.ec));
+    return LDSO_OK;
+}
+
+}  // extern "C"

@@ -585,3 +585,104 @@ def make_config(name: str, **over) -> Window:
     kw = dict(CONFIGS[name])
     kw.update(over)
     return make_window(**kw)
+
+
+# ----------------------------------------------------------------------------------------------
+# monocular initialiser (CoarseInitializer)
+# ----------------------------------------------------------------------------------------------
+INIT_POINT_DTYPE = np.dtype([
+    ("u", "f4"), ("v", "f4"), ("idepth", "f4"), ("isGood", "i4"), ("energy", "f4", (2,)), ("isGood_new", "i4"), ("idepth_new", "f4"),
+    ("energy_new", "f4", (2,)), ("iR", "f4"), ("iRSumNum", "f4"), ("lastHessian", "f4"), ("lastHessian_new", "f4"), ("maxstep", "f4"),
+    ("parent", "i4"), ("parentDist", "f4"), ("neighbours", "i4", (10,)), ("neighboursDist", "f4", (10,)), ("my_type", "f4"),
+    ("outlierTH", "f4"), ("pad_", "f4"),
+], align=True)
+assert INIT_POINT_DTYPE.itemsize == 160
+
+INIT_STATE_DTYPE = np.dtype([
+    ("thisToNext", "f8", (12,)), ("aff_a", "f8"), ("aff_b", "f8"), ("snapped", "i4"), ("snappedAt", "i4"), ("frameID", "i4"),
+    ("ready", "i4"), ("evals", "i4"), ("pad_", "i4"),
+], align=True)
+assert INIT_STATE_DTYPE.itemsize == 136
+
+INIT_DENSITIES = (0.03, 0.05, 0.15, 0.5, 1.0)     # CoarseInitializer.cc:557
+
+
+def select_init_points(pyr, densities=INIT_DENSITIES, grad_th=8.0, outlier_th=12.0 * 12.0):
+    """Stand-in for the pixel selection of CoarseInitializer::setFirst (PixelSelector::makeMaps / makePixelStatus, not on the
+    path) plus an exact restatement of the point records (:567-603) and of makeNN (:717-783; k-d tree queries by scipy).
+    pyr: list of float32 [h,w,3] (I,dx,dy).  Returns one INIT_POINT_DTYPE array per level, points in raster order."""
+    from scipy.spatial import cKDTree
+    levels = len(pyr)
+    h0, w0 = pyr[0].shape[:2]
+    out = []
+    for lvl in range(levels):
+        hl, wl = pyr[lvl].shape[:2]
+        g2 = pyr[lvl][..., 1] ** 2 + pyr[lvl][..., 2] ** 2
+        want = densities[lvl] * w0 * h0
+        x0, x1, y0, y1 = 3, wl - 4, 3, hl - 4              # patternPadding + 1 .. wl - patternPadding - 2 (exclusive)
+        area = max(1, (x1 - x0) * (y1 - y0))
+        bs = max(1, int(round(np.sqrt(area / want))))
+        sel = np.zeros((hl, wl), dtype=bool)
+        sub = g2[y0:y1, x0:x1]
+        nby, nbx = (sub.shape[0] + bs - 1) // bs, (sub.shape[1] + bs - 1) // bs
+        pad = np.full((nby * bs, nbx * bs), -1.0, dtype=np.float32)
+        pad[:sub.shape[0], :sub.shape[1]] = sub
+        blk = pad.reshape(nby, bs, nbx, bs).transpose(0, 2, 1, 3).reshape(nby, nbx, bs * bs)
+        am = blk.argmax(axis=2)
+        mx = blk.max(axis=2)
+        by, bx = np.nonzero(mx > grad_th)
+        yy = y0 + by * bs + am[by, bx] // bs
+        xx = x0 + bx * bs + am[by, bx] % bs
+        sel[yy, xx] = True
+        ys, xs = np.nonzero(sel)                            # raster order
+        pts = np.zeros(len(xs), INIT_POINT_DTYPE)
+        pts["u"] = (xs + 0.1).astype(np.float32)
+        pts["v"] = (ys + 0.1).astype(np.float32)
+        pts["idepth"] = 1; pts["idepth_new"] = 1; pts["iR"] = 1; pts["isGood"] = 1
+        pts["my_type"] = 1
+        pts["outlierTH"] = 8 * outlier_th
+        pts["parent"] = -1; pts["parentDist"] = -1
+        pts["neighbours"] = -1
+        out.append(pts)
+    trees = [cKDTree(np.stack([p["u"], p["v"]], axis=1).astype(np.float32)) if len(p) else None for p in out]
+    for lvl in range(levels):
+        p = out[lvl]
+        if len(p) == 0:
+            continue
+        xy = np.stack([p["u"], p["v"]], axis=1).astype(np.float32)
+        k = min(10, len(p))
+        d, idx = trees[lvl].query(xy, k=k)
+        d = d.reshape(len(p), k); idx = idx.reshape(len(p), k)
+        df = np.exp(-(d.astype(np.float32) ** 2) * np.float32(0.05)).astype(np.float32)
+        p["neighbours"][:, :k] = idx
+        p["neighboursDist"][:, :k] = df * (np.float32(10) / df.sum(axis=1, keepdims=True))
+        if lvl < levels - 1 and trees[lvl + 1] is not None:
+            q = xy * np.float32(0.5) - np.float32(0.25)
+            d1, i1 = trees[lvl + 1].query(q, k=1)
+            p["parent"] = i1
+            p["parentDist"] = np.exp(-(d1.astype(np.float32) ** 2) * np.float32(0.05))
+    return out
+
+
+def make_init_sequence(w=640, h=480, n_frames=10, seed=20260925, fx=None, step=0.035, rot_deg=0.15, noise_sigma=0.5, levels=None):
+    """First frame + n_frames followers of the synthetic scene: camera translating (mostly sideways) by `step` scene units per
+    frame at depth ~3.  Returns dict(K4, levels, first (irradiance), frames [irradiance], T_first_to_k [4x4], depth0 [h,w])."""
+    rng = np.random.default_rng(seed)
+    fx = 400.0 if fx is None else fx
+    cx, cy = (w - 1) / 2.0, (h - 1) / 2.0
+    K = np.array([[fx, 0, cx], [0, fx, cy], [0, 0, 1]], dtype=np.float64)
+    levels = pyr_levels_used(w, h) if levels is None else levels
+    scene = Scene(rng, px=3.0 / fx)
+    nrng = np.random.default_rng(seed + 1)
+    first, depth0 = scene.render(np.eye(4), K, w, h, 0.0, 0.0, nrng, noise_sigma)
+    frames, poses = [], []
+    pos, rot = np.zeros(3), np.zeros(3)
+    for k in range(n_frames):
+        pos = pos + np.array([step * rng.uniform(0.8, 1.2), step * rng.uniform(-0.2, 0.2), step * rng.uniform(-0.2, 0.2)])
+        ax = rng.normal(size=3); ax /= np.linalg.norm(ax)
+        rot = rot + ax * np.deg2rad(rng.uniform(0.5, 1.0) * rot_deg)
+        T_c2w = np.eye(4); T_c2w[:3, :3] = so3_exp(rot); T_c2w[:3, 3] = pos
+        T_w2c = se3_inv(T_c2w)
+        img, _ = scene.render(T_w2c, K, w, h, 0.0, 0.0, nrng, noise_sigma)
+        frames.append(img); poses.append(T_w2c)          # first frame is the world frame: T_first_to_k = T_w2c
+    return dict(K4=np.array([fx, fx, cx, cy], dtype=np.float32), levels=levels, w=w, h=h, first=first, frames=frames, poses=poses, depth0=depth0)

@@ -3,7 +3,7 @@
 // include/internal/OptimizationBackend/MatrixAccumulators.h, restated with the same three-level
 // (1 / 1k / 1M) flush schedule on float counters:
 //   AccumulatorXX<i,j> (:20-66), Accumulator11 (:68-142), AccumulatorX<i> (:145-197),
-//   AccumulatorApprox (:749-1101), Accumulator9 (:1104-1645; only updateSSE_eighted is on the path).
+//   AccumulatorApprox (:749-1101), Accumulator9 (:1104-1645; updateSSE_eighted for the tracker, updateSSE / updateSingleWeighted for the initialiser).
 #pragma once
 #include <xmmintrin.h>
 #include "linalg.h"
@@ -38,6 +38,11 @@ struct AccumulatorX {
     void finish() { shiftUp(true); num = (size_t) (numIn1 + numIn1k + numIn1m); }
     void update(const Mat<float, I, 1> &L, float w) {   // :170-174
         for (int i = 0; i < I; i++) A[i] += w * L[i];
+        numIn1++;
+        shiftUp(false);
+    }
+    void updateNoWeight(const Mat<float, I, 1> &L) {   // :174-178
+        for (int i = 0; i < I; i++) A[i] += L[i];
         numIn1++;
         shiftUp(false);
     }
@@ -192,6 +197,33 @@ struct Accumulator9 {
             }
         }
         num += 4;
+        numIn1++;
+        shiftUp(false);
+    }
+    // entry (r,c>=r) += J_r * J_c per lane   (:1138-1247)
+    void updateSSE(const __m128 *J) {
+        float *pt = SSEData;
+        for (int r = 0; r < 9; r++)
+            for (int c = r; c < 9; c++) {
+                _mm_store_ps(pt, _mm_add_ps(_mm_load_ps(pt), _mm_mul_ps(J[r], J[c])));
+                pt += 4;
+            }
+        num += 4;
+        numIn1++;
+        shiftUp(false);
+    }
+    // lane `off` only: diagonal += J_r*J_r*w, then J_r *= w and (r,c>r) += J_c*J_r   (:1489-1614)
+    void updateSingleWeighted(const float *Jin, float w, int off = 0) {
+        float J[9];
+        for (int i = 0; i < 9; i++) J[i] = Jin[i];
+        float *pt = SSEData + off;
+        for (int r = 0; r < 9; r++) {
+            *pt += J[r] * J[r] * w;
+            pt += 4;
+            J[r] *= w;
+            for (int c = r + 1; c < 9; c++) { *pt += J[c] * J[r]; pt += 4; }
+        }
+        num++;
         numIn1++;
         shiftUp(false);
     }

@@ -385,3 +385,76 @@ def nullspaces(T_w2c, aff_a0, exposure):
     p, s, a = np.zeros(36), np.zeros(6), np.zeros(8)
     L.orc_nullspaces(_p(T), C.c_float(aff_a0), C.c_float(exposure), _p(p), _p(s), _p(a))
     return p.reshape(6, 6), s, a.reshape(4, 2)
+
+
+class OracleInitializer:
+    """CoarseInitializer restatement (oracle/initializer.cc)."""
+
+    def __init__(self, w, h, levels):
+        self.L = lib()
+        L = self.L
+        L.orc_init_create.restype = C.c_void_p
+        L.orc_init_track_frame.restype = C.c_int
+        self.w, self.h_, self.levels = w, h, levels
+        self.h = C.c_void_p(L.orc_init_create(C.c_int(w), C.c_int(h), C.c_int(levels)))
+        self.n = [0] * levels
+
+    def close(self):
+        if self.h:
+            self.L.orc_init_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_first(self, K4, pyr, exposure, points, huberTH=9.0, fixAffine=True):
+        arr, keep = _img_ptrs([pyr], self.levels)
+        pts = [np.ascontiguousarray(p, dtype=synth.INIT_POINT_DTYPE) for p in points]
+        pp = (C.c_void_p * self.levels)(*[p.ctypes.data for p in pts])
+        n = np.array([len(p) for p in pts], dtype=np.int32)
+        self.n = [int(x) for x in n]
+        k = np.ascontiguousarray(K4, dtype=np.float32)
+        self.L.orc_init_set_first(self.h, _p(k), arr, C.c_float(exposure), pp, _p(n), C.c_float(huberTH), C.c_int(1 if fixAffine else 0))
+
+    def set_new_frame(self, pyr, exposure=1.0):
+        arr, keep = _img_ptrs([pyr], self.levels)
+        self.L.orc_init_set_new_frame(self.h, arr, C.c_float(exposure))
+
+    def track_frame(self):
+        st = np.zeros((), synth.INIT_STATE_DTYPE)
+        self.L.orc_init_track_frame(self.h, _p(st))
+        return st
+
+    def state(self):
+        st = np.zeros((), synth.INIT_STATE_DTYPE)
+        self.L.orc_init_get_state(self.h, _p(st))
+        return st
+
+    def set_state(self, st):
+        st = np.ascontiguousarray(st, dtype=synth.INIT_STATE_DTYPE)
+        self.L.orc_init_set_state(self.h, _p(st))
+
+    def points(self, lvl):
+        out = np.zeros(self.n[lvl], synth.INIT_POINT_DTYPE)
+        self.L.orc_init_get_points(self.h, C.c_int(lvl), _p(out))
+        return out
+
+    def set_points(self, lvl, pts):
+        pts = np.ascontiguousarray(pts, dtype=synth.INIT_POINT_DTYPE)
+        assert len(pts) == self.n[lvl]
+        self.L.orc_init_set_points(self.h, C.c_int(lvl), _p(pts))
+
+    def calc_res_and_gs(self, lvl, T, a, b):
+        T = np.ascontiguousarray(np.asarray(T, dtype=np.float64)[:3, :4])
+        H = np.zeros((8, 8), np.float32); bo = np.zeros(8, np.float32); Hsc = np.zeros((8, 8), np.float32); bsc = np.zeros(8, np.float32)
+        res = np.zeros(3, np.float32); ec = np.zeros(3, np.float32)
+        self.L.orc_init_calc_res_and_gs(self.h, C.c_int(lvl), _p(T), C.c_double(a), C.c_double(b), _p(H), _p(bo), _p(Hsc), _p(bsc), _p(res), _p(ec))
+        return H, bo, Hsc, bsc, res, ec
+
+    def jb(self, lvl):
+        out = np.zeros((self.n[lvl], 10), np.float32)
+        self.L.orc_init_get_jb(self.h, C.c_int(lvl), _p(out))
+        return out
