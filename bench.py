@@ -186,6 +186,10 @@ def main():
                 out["tracer"] = tracer_line()
             except Exception as e:
                 out["tracer"] = {"error": repr(e)}
+            try:
+                out["initializer"] = initializer_line()
+            except Exception as e:
+                out["initializer"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -247,6 +251,29 @@ def tracer_line():
     t0 = time.perf_counter(); po.trace_on(ref, img, KRKi, Kt, aff); to = time.perf_counter() - t0
     return {"workload": f"{len(pts)} fresh immature points on {win.F} key frames, {win.w}x{win.h}", "gpu_trace_on_ms": round(float(np.median(tg[2:])) * 1e3, 4),
             "cpu_oracle_ms": round(to * 1e3, 3), "cpu_cores": 1, "status_counts_good_oob_outlier": [int(c[0]), int(c[1]), int(c[2])]}
+
+
+def initializer_line():
+    """Informational (SURVEY §8f rank 4): CoarseInitializer::trackFrame on a 640x480 sequence - one ldso_init_track_frame call per
+    frame (new image upload + makeImages + the whole LM loop on the device + state read-back) next to the oracle on one core."""
+    from ldso_amd import synth, binding
+    from oracle import pyoracle as po
+    seq = synth.make_init_sequence(640, 480, n_frames=4)
+    L = seq["levels"]
+    pyr0 = synth.make_images(seq["first"], L)
+    pts = synth.select_init_points(pyr0)
+    o = po.OracleInitializer(640, 480, L); o.set_first(seq["K4"], pyr0, 1.0, pts)
+    g = binding.Initializer(640, 480, L); g.set_first(seq["K4"], seq["first"], pts)
+    tg, tc, ev = [], [], []
+    for k, img in enumerate(seq["frames"]):
+        o.set_new_frame(synth.make_images(img, L), 1.0)
+        t0 = time.perf_counter(); so = o.track_frame(); tc.append(time.perf_counter() - t0)
+        t0 = time.perf_counter(); sg = g.track_frame(img, 1.0); tg.append(time.perf_counter() - t0)
+        ev.append((int(so["evals"]), int(sg["evals"])))
+    dT = float(np.abs(so["thisToNext"] - sg["thisToNext"]).max())
+    return {"workload": f"640x480, {L} levels, points per level {[len(p) for p in pts]}, 4 frames (snapped from the 2nd)",
+            "gpu_track_frame_ms": [round(t * 1e3, 3) for t in tg], "cpu_oracle_track_frame_ms": [round(t * 1e3, 2) for t in tc], "cpu_cores": 1,
+            "evaluations_cpu_gpu": ev, "max_abs_pose_diff_last_frame": dT}
 
 
 def cpu_baseline(win):

@@ -16,8 +16,19 @@ if os.environ.get("LDSO_STAMPS"):          # device-side phase stamps for script
     FLAGS.append("-DLDSO_STAMPS")
 
 
+FLAGFILE = os.path.join(HERE, "_obj", "flags.txt")
+
+
+def flags_changed() -> bool:
+    """Objects built with other flags (e.g. a LDSO_STAMPS debug build) must not be reused."""
+    try:
+        return open(FLAGFILE).read() != " ".join(FLAGS)
+    except OSError:
+        return True
+
+
 def needs_build() -> bool:
-    if not os.path.exists(OUT):
+    if not os.path.exists(OUT) or flags_changed():
         return True
     t = os.path.getmtime(OUT)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", f) for f in ("ldso_hip.h", "ldso_window.h")]
@@ -29,6 +40,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return OUT
     objs = []
     os.makedirs(os.path.join(HERE, "_obj"), exist_ok=True)
+    force = force or flags_changed()
     procs = []
     for s in SOURCES:
         src = os.path.join(CSRC, s)
@@ -56,6 +68,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if r.returncode != 0:
         sys.stderr.write(r.stdout)
         raise RuntimeError("link failed")
+    with open(FLAGFILE, "w") as f:
+        f.write(" ".join(FLAGS))
     return OUT
 
 
