@@ -115,3 +115,53 @@ def test_sequential_sweeps_exact():
         assert (po["isGood"] == pg["isGood"]).mean() > 0.998
         d = np.abs(po["iR"] - pg["iR"])
         assert np.median(d) < 1e-4, (lvl, np.median(d))
+
+
+def test_affine_free_and_sparse_levels():
+    """fixAffine = false (8x8 solve incl. the affine brightness pair) and levels with fewer than 10 points (neighbour slots -1):
+    same trajectory as the oracle."""
+    from ldso_amd import binding
+    from oracle import pyoracle
+    w, h = 160, 120
+    seq = synth.make_init_sequence(w, h, n_frames=4, fx=100.0, seed=5, levels=3)
+    L = seq["levels"]
+    pyr0 = synth.make_images(seq["first"], L)
+    pts = synth.select_init_points(pyr0, densities=(0.03, 0.05, 0.0002, 0.5, 1.0))
+    assert 0 < len(pts[2]) < 10 and np.any(pts[2]["neighbours"] == -1)
+    o = pyoracle.OracleInitializer(w, h, L)
+    o.set_first(seq["K4"], pyr0, 1.3, pts, fixAffine=False)
+    g = binding.Initializer(w, h, L)
+    g.set_first(seq["K4"], seq["first"], pts, exposure=1.3, fixAffine=False)
+    for k in range(4):
+        img = seq["frames"][k]
+        o.set_new_frame(synth.make_images(img, L), 1.1)
+        so = o.track_frame(); sg = g.track_frame(img, 1.1)
+        assert so["evals"] == sg["evals"] and so["snapped"] == sg["snapped"], (k, so["evals"], sg["evals"])
+        assert np.abs(so["thisToNext"] - sg["thisToNext"]).max() < 1e-4
+        assert abs(so["aff_a"] - sg["aff_a"]) < 1e-4 and abs(so["aff_b"] - sg["aff_b"]) < 1e-2, (so["aff_a"], sg["aff_a"], so["aff_b"], sg["aff_b"])
+    # each frame starts from logf(exposure ratio) = -0.167 (:66-68); the frames are rendered with equal brightness, so the free affine
+    # pair is optimised back towards a = 0
+    assert abs(sg["aff_a"]) < 0.05
+
+
+def test_initializer_rejects_bad_input():
+    from ldso_amd import binding
+    with pytest.raises(Exception):
+        binding.Initializer(320, 240, 6)                      # maxIterations[] has five levels
+    seq = synth.make_init_sequence(160, 120, n_frames=1, fx=100.0, levels=2)
+    pyr0 = synth.make_images(seq["first"], 2)
+    pts = synth.select_init_points(pyr0)
+    g = binding.Initializer(160, 120, 2)
+    with pytest.raises(Exception):
+        g.track_frame(seq["frames"][0])                       # no first frame yet
+    bad = [p.copy() for p in pts]
+    bad[0]["parent"][0] = len(pts[1]) + 5
+    with pytest.raises(Exception):
+        g.set_first(seq["K4"], seq["first"], bad)
+    bad = [p.copy() for p in pts]
+    bad[1]["neighbours"][0, 3] = len(pts[1])
+    with pytest.raises(Exception):
+        g.set_first(seq["K4"], seq["first"], bad)
+    g.set_first(seq["K4"], seq["first"], pts)
+    st = g.track_frame(seq["frames"][0])
+    assert st["frameID"] == 1
