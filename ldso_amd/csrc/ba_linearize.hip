@@ -194,14 +194,14 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D,
     const int oy = (k == 0) ? -2 : (k == 1 || k == 2) ? -1 : (k == 6) ? 1 : (k == 7) ? 2 : 0;
     const int W = D.w;
 
-    // top accumulators: slot group 0 in registers; a second group (F > 8) in per-lane LDS cells [91][256] - 182 register
-    // accumulators per lane would spill to scratch memory
-    float accA[LD_TOPN];
-    float *sAcc1 = sXa + FS * 8 + 64;           // [LD_TOPN][64 * LD_WAVES], NSG == 2 only
+    // top accumulators (13x13 symmetric block per slot), distributed over the 8 pattern lanes of the slot: lane k owns row k
+    // (13 columns) and, for k < 5, row k + 8 (columns 8..12) - 18 registers per lane and slot group instead of 91, updated from
+    // the per-residual 2x2 sums exactly as AccumulatorApprox::update / updateTopRight / updateBotRight do (MatrixAccumulators.h:893-1045)
+    float accR[NSG][18];
 #pragma unroll
     for (int g = 0; g < NSG; g++)
 #pragma unroll
-        for (int i = 0; i < LD_TOPN; i++) { if (g == 0) accA[i] = 0.0f; else sAcc1[i * 64 * LD_WAVES + tid] = 0.0f; }
+        for (int i = 0; i < 18; i++) accR[g][i] = 0.0f;
     double energySum = 0.0;     // sum of linearize() return values (slot leaders only)
     int nresA = 0, nresL = 0;
     float nidSum = 0.0f;
@@ -402,26 +402,32 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D,
 
             // ================= accumulate: active residual, mode 0 (AccumulatedTopHessian.cc) ==========
             const bool accHere = doLin && activeNew && compute;
+            // residual column: Jab_r uses the (possibly zeroed) JabF, Jab2 / JabJIdx the un-zeroed sums
+            const float z10 = (S.affineOptModeA < 0) ? 0.0f : 1.0f, z11 = (S.affineOptModeB < 0) ? 0.0f : 1.0f;
+            const float JI_r0 = sum8(resAcc * gx), JI_r1 = sum8(resAcc * gy);
+            const float Jab_r0 = z10 * sum8(drdA * hw * resAcc), Jab_r1 = z11 * sum8(hw * resAcc), rr = sum8(resAcc * resAcc);
             if (accHere) {
-                float v[13];
+                const float xr1 = (k == 0) ? x[0] : (k == 1) ? x[1] : (k == 2) ? x[2] : (k == 3) ? x[3] : (k == 4) ? x[4] : (k == 5) ? x[5] : (k == 6) ? x[6] : x[7];
+                const float yr1 = (k == 0) ? y[0] : (k == 1) ? y[1] : (k == 2) ? y[2] : (k == 3) ? y[3] : (k == 4) ? y[4] : (k == 5) ? y[5] : (k == 6) ? y[6] : y[7];
+                const float t1a = __builtin_fmaf(JI00, xr1, JI10 * yr1), t1b = __builtin_fmaf(JI10, xr1, JI11 * yr1);
 #pragma unroll
-                for (int i = 0; i < 10; i++) v[i] = __builtin_fmaf(gx, x[i], gy * y[i]);
-                v[10] = drdA * hw; v[11] = hw; v[12] = resAcc;
-                // Jab_r uses the (possibly zeroed) JabF, Jab2/JabJIdx the un-zeroed sums
-                const float z10 = (S.affineOptModeA < 0) ? 0.0f : 1.0f, z11 = (S.affineOptModeB < 0) ? 0.0f : 1.0f;
-#pragma unroll
-                for (int r = 0; r < 13; r++)
-#pragma unroll
-                    for (int c = r; c < 13; c++) {
-                        float a = v[r], b = v[c];
-                        if (r == 10 && c == 12) a *= z10;
-                        if (r == 11 && c == 12) a *= z11;
-                        if (g == 0) accA[tri13(r, c)] = __builtin_fmaf(a, b, accA[tri13(r, c)]);
-                        else sAcc1[tri13(r, c) * 64 * LD_WAVES + tid] = __builtin_fmaf(a, b, sAcc1[tri13(r, c) * 64 * LD_WAVES + tid]);
-                    }
+                for (int c = 0; c < 10; c++) accR[g][c] = __builtin_fmaf(t1a, x[c], __builtin_fmaf(t1b, y[c], accR[g][c]));
+                accR[g][10] = __builtin_fmaf(xr1, JabJI00, __builtin_fmaf(yr1, JabJI01, accR[g][10]));
+                accR[g][11] = __builtin_fmaf(xr1, JabJI10, __builtin_fmaf(yr1, JabJI11, accR[g][11]));
+                accR[g][12] = __builtin_fmaf(xr1, JI_r0, __builtin_fmaf(yr1, JI_r1, accR[g][12]));
+                // second row: 8, 9 (geometric) on lanes 0, 1; 10, 11 (affine) and 12 (residual) on lanes 2, 3, 4
+                const float xr2 = (k == 0) ? x[8] : x[9], yr2 = (k == 0) ? y[8] : y[9];
+                const float t2a = __builtin_fmaf(JI00, xr2, JI10 * yr2), t2b = __builtin_fmaf(JI10, xr2, JI11 * yr2);
+                const float g8 = __builtin_fmaf(t2a, x[8], t2b * y[8]), g9 = __builtin_fmaf(t2a, x[9], t2b * y[9]);
+                const float g10 = __builtin_fmaf(xr2, JabJI00, yr2 * JabJI01), g11 = __builtin_fmaf(xr2, JabJI10, yr2 * JabJI11), g12 = __builtin_fmaf(xr2, JI_r0, yr2 * JI_r1);
+                const bool geo = k < 2;
+                accR[g][13] += geo ? g8 : 0.0f;
+                accR[g][14] += geo ? g9 : 0.0f;
+                accR[g][15] += geo ? g10 : (k == 2) ? Jab00 : 0.0f;
+                accR[g][16] += geo ? g11 : (k == 2) ? Jab01 : (k == 3) ? Jab11 : 0.0f;
+                accR[g][17] += geo ? g12 : (k == 2) ? Jab_r0 : (k == 3) ? Jab_r1 : (k == 4) ? rr : 0.0f;
             }
             // per-slot contributions to the point sums (same value in all 8 lanes of the slot)
-            float JI_r0 = sum8(resAcc * gx), JI_r1 = sum8(resAcc * gy);
             float Ji2_0 = JI00 * Jpdd0 + JI10 * Jpdd1, Ji2_1 = JI10 * Jpdd0 + JI11 * Jpdd1;
             float sbd = accHere ? (JI_r0 * Jpdd0 + JI_r1 * Jpdd1) : 0.0f;
             float sHdd = accHere ? (Ji2_0 * Jpdd0 + Ji2_1 * Jpdd1) : 0.0f;
@@ -579,14 +585,18 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D,
 
     LSTAMP(6);
     // ================= block reduction of the top accumulators =============================================
-    // (1) over the 8 pattern lanes, (2) over the waves of the block through LDS, fixed order
+    // every lane stores the upper-triangle part of its rows (each of the 91 cells of a slot has exactly one writer), then the
+    // waves of the block are summed through LDS in fixed order
 #pragma unroll
-    for (int g = 0; g < NSG; g++)
+    for (int g = 0; g < NSG; g++) {
+        float *cell = sRed + (size_t) (wave * FS + g * 8 + s) * LD_TOPN;
+        const int b1 = k * 13 - (k * (k - 1)) / 2 - k;                       // tri13(k, c) = b1 + c
+        const int r2 = k + 8, b2 = r2 * 13 - (r2 * (r2 - 1)) / 2 - r2;
 #pragma unroll
-        for (int i = 0; i < LD_TOPN; i++) {
-            float a = sum8(g == 0 ? accA[i] : sAcc1[i * 64 * LD_WAVES + tid]);
-            if (k == 0) sRed[(wave * FS + g * 8 + s) * LD_TOPN + i] = a;
-        }
+        for (int c = 0; c < 13; c++) if (c >= k) cell[b1 + c] = accR[g][c];
+#pragma unroll
+        for (int c = 8; c < 13; c++) if (k < 5 && c >= r2) cell[b2 + c] = accR[g][13 + c - 8];
+    }
     // energy / counters: wave reduce, then LDS (own cells: no second barrier)
     double *sE = (double *) (sXa + FS * 8);
     int *sC = (int *) (sE + LD_WAVES);
@@ -624,8 +634,7 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D,
 // launcher
 // ---------------------------------------------------------------------------------------------------------
 size_t ba_linearize_lds_bytes(int FS, bool hasL) {
-    size_t fl = (size_t) FS * (sizeof(DevPair) / 4) + 2 * (size_t) FS * 64 + (size_t) LD_WAVES * FS * LD_TOPN + (hasL ? (size_t) LD_WAVES * FS * LD_TOPN : 0) + (size_t) FS * 8 + 64 +
-                (FS > 8 ? (size_t) LD_TOPN * 64 * LD_WAVES : 0);
+    size_t fl = (size_t) FS * (sizeof(DevPair) / 4) + 2 * (size_t) FS * 64 + (size_t) LD_WAVES * FS * LD_TOPN + (hasL ? (size_t) LD_WAVES * FS * LD_TOPN : 0) + (size_t) FS * 8 + 64;
     return fl * sizeof(float) + 256;
 }
 
