@@ -307,6 +307,7 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D,
             }
             bool laneBad = compute && (!centerOK || !pixOK || !isfinite(hit0));
             unsigned long long badMask = __ballot(laneBad);
+            if (pi == wave && g == 0) LSTAMP(4);
             bool anyBad = ((badMask >> (s * 8)) & 0xFFull) != 0;
             if (compute && anyBad) { newState = RES_OOB; ret = (double) newEnergy; compute = false; }
 
