@@ -64,6 +64,15 @@ __device__ __forceinline__ float seq8(float x, int k, int lane) {
     return __shfl(t, lane | 7, 64);
 }
 
+// sum over the 8 slots of a wave (lanes with equal k), result in every lane: slot pairs by row_ror:8, then the four rows by two
+// ds_bpermute butterflies (tree order; the sequential-order sums that decide residual states use seq8 above)
+__device__ __forceinline__ float sum_slots(float x, int a16, int a32) {
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128, 0xF, 0xF, true));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(a16, __builtin_bit_cast(int, x)));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(a32, __builtin_bit_cast(int, x)));
+    return x;
+}
+
 // flat index of entry (r,c), r<=c, in the packed upper triangle of a 13x13 matrix
 __host__ __device__ constexpr int tri13(int r, int c) { return r * 13 - (r * (r - 1)) / 2 + (c - r); }
 
@@ -193,6 +202,7 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D,
     const int ox = (k == 1 || k == 6) ? -1 : (k == 2) ? 1 : (k == 3) ? -2 : (k == 5) ? 2 : 0;     // staticPattern[8], Setting.cc:221
     const int oy = (k == 0) ? -2 : (k == 1 || k == 2) ? -1 : (k == 6) ? 1 : (k == 7) ? 2 : 0;
     const int W = D.w;
+    const int a16 = (lane ^ 16) << 2, a32 = (lane ^ 32) << 2;      // ds_bpermute addresses of sum_slots
 
     // top accumulators (13x13 symmetric block per slot), distributed over the 8 pattern lanes of the slot: lane k owns row k
     // (13 columns) and, for k < 5, row k + 8 (columns 8..12) - 18 registers per lane and slot group instead of 91, updated from
@@ -230,8 +240,7 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D,
                     const bool act = (t < F) && (q.rflat[g] >= 0) && (q.active[g] != 0);
                     float sres = seq8(sXa[t * 8 + k] * q.jp[g], k, lane);
                     sres = act ? sres : 0.0f;
-#pragma unroll
-                    for (int ss = 0; ss < 8; ss++) b -= __shfl(sres, ss * 8, 64);
+                    b -= sum_slots(sres, a16, a32);
                 }
                 if (isfinite(b)) step = -b * q.HdiF; else { step = q.pstep; if (lane == 0) B.scalars[4] = 1.0; }
             }
@@ -434,13 +443,10 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D,
             float sHdd = accHere ? (Ji2_0 * Jpdd0 + Ji2_1 * Jpdd1) : 0.0f;
             float sHc0 = accHere ? (x[0] * Ji2_0 + y[0] * Ji2_1) : 0.0f, sHc1 = accHere ? (x[1] * Ji2_0 + y[1] * Ji2_1) : 0.0f;
             float sHc2 = accHere ? (x[2] * Ji2_0 + y[2] * Ji2_1) : 0.0f, sHc3 = accHere ? (x[3] * Ji2_0 + y[3] * Ji2_1) : 0.0f;
-            // sequential sum over the 8 slots of this pass, ascending target (reference: p->residuals order)
-#pragma unroll
-            for (int ss = 0; ss < 8; ss++) {
-                bdA += __shfl(sbd, ss * 8, 64); HddA += __shfl(sHdd, ss * 8, 64);
-                HcdA0 += __shfl(sHc0, ss * 8, 64); HcdA1 += __shfl(sHc1, ss * 8, 64);
-                HcdA2 += __shfl(sHc2, ss * 8, 64); HcdA3 += __shfl(sHc3, ss * 8, 64);
-            }
+            // sum over the 8 slots of this pass
+            bdA += sum_slots(sbd, a16, a32); HddA += sum_slots(sHdd, a16, a32);
+            HcdA0 += sum_slots(sHc0, a16, a32); HcdA1 += sum_slots(sHc1, a16, a32);
+            HcdA2 += sum_slots(sHc2, a16, a32); HcdA3 += sum_slots(sHc3, a16, a32);
             if (accHere && k == 0) nresA++;
 
             // ================= linearised residual, mode 1 (AccumulatedTopHessian.cc:29-31,44-63) =======
@@ -490,12 +496,9 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D,
                     lsHdd = lJi0 * J.Jpdd[0] + lJi1 * J.Jpdd[1];
                     lH0 = lx[0] * lJi0 + ly[0] * lJi1; lH1 = lx[1] * lJi0 + ly[1] * lJi1; lH2 = lx[2] * lJi0 + ly[2] * lJi1; lH3 = lx[3] * lJi0 + ly[3] * lJi1;
                 }
-#pragma unroll
-                for (int ss = 0; ss < 8; ss++) {
-                    bdL += __shfl(lsbd, ss * 8, 64); HddL += __shfl(lsHdd, ss * 8, 64);
-                    HcdL0 += __shfl(lH0, ss * 8, 64); HcdL1 += __shfl(lH1, ss * 8, 64);
-                    HcdL2 += __shfl(lH2, ss * 8, 64); HcdL3 += __shfl(lH3, ss * 8, 64);
-                }
+                bdL += sum_slots(lsbd, a16, a32); HddL += sum_slots(lsHdd, a16, a32);
+                HcdL0 += sum_slots(lH0, a16, a32); HcdL1 += sum_slots(lH1, a16, a32);
+                HcdL2 += sum_slots(lH2, a16, a32); HcdL3 += sum_slots(lH3, a16, a32);
             }
 
             // ================= lifted Schur row: target block and this slot's share of the host block ==
@@ -511,8 +514,7 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D,
                     for (int j = 0; j < 8; j++) { tgt = __builtin_fmaf(aT[j], vj[j], tgt); hpart = __builtin_fmaf(aH[j], vj[j], hpart); }
                 }
             }
-#pragma unroll
-            for (int ss = 0; ss < 8; ss++) hostPart += __shfl(hpart, ss * 8 + k, 64);
+            hostPart += sum_slots(hpart, a16, a32);
             gT[g] = tgt;
             nActive += __popcll(__ballot(exists && activeNew && k == 0));
             if (FIX) numGood += __popcll(newGoodMask);
