@@ -15,7 +15,8 @@
 
 #define LD_MAXF LDSO_MAX_FRAMES
 #define LD_TOPN 91            // unique entries of the 13x13 symmetric relative Hessian block
-#define LD_WAVES 4            // waves per linearize block
+#define LD_WAVES 8            // waves per linearize block
+#define LD_PREFETCH 0         // 1: load the point record one point ahead (pays when a SIMD holds a single wave)
 #define LD_GEXTRA 8           // per-point extras appended to a G row: Hcd[4], bdSum, HdiF, pad, pad
 
 struct DevPair {

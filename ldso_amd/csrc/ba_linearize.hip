@@ -220,8 +220,13 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D,
     for (; pi < np; pi += LD_WAVES) {
         if (pi == wave) LSTAMP(2);
         const int p = p0 + pi;
+#if LD_PREFETCH
         const PtIn<NSG> q = nx;
         if (pi + LD_WAVES < np) load_point<NSG, HAS_L, FIX>(nx, B, cur, FS, p + LD_WAVES, s, k, stepMode);
+#else
+        if (pi != wave) load_point<NSG, HAS_L, FIX>(nx, B, cur, FS, p, s, k, stepMode);       // the first record was loaded before the staging
+        const PtIn<NSG> &q = nx;
+#endif
         const float pu = q.pu, pv = q.pv, priorF = MARG ? q.priorF * S.idepthFixPriorMargFac : q.priorF;
         const bool flagged = MARG ? (margFlags[p] != 0) : true;
         const float color = q.color, wgt = q.wgt;
