@@ -130,6 +130,11 @@ def main():
                     rocprof_us = round(float(row["AverageNs"]) / 1e3, 3)
     except Exception:
         rocprof_us = None
+    if rocprof_us is not None and world == 1 and args.config == "C3" and not args.no_prior:
+        # rocprofv3's per-dispatch duration of the same command is a little longer than the event-based figures (profiler attached,
+        # first launches included): quote the largest of the three so that `achieved` never exceeds what the committed profile shows
+        lin_us = max(lin_us, rocprof_us)
+        lin_s = lin_us * 1e-6
     achieved = alg_bytes / lin_s / 1e9 if lin_s > 0 else 0.0
 
     # HBM traffic of the dominant kernel per launch: rocprofv3 PMC counters cannot be read from inside this process; the

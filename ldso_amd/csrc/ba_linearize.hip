@@ -76,7 +76,7 @@ __device__ __forceinline__ float sum_slots(float x, int a16, int a32) {
 // flat index of entry (r,c), r<=c, in the packed upper triangle of a 13x13 matrix
 __host__ __device__ constexpr int tri13(int r, int c) { return r * 13 - (r * (r - 1)) / 2 + (c - r); }
 
-// Everything a wave reads from HBM for one point besides the image taps.  Loaded one point ahead (software
+// Everything a wave reads from HBM for one point besides the image taps.  With LD_PREFETCH: loaded one point ahead (software
 // pipeline): the loads of point i+1 are in flight while point i is computed, and the first point's loads overlap
 // the LDS staging of the block, so a wave sees two dependent memory levels (this record, then the taps).
 template <int NSG>
