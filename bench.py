@@ -44,11 +44,16 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: torch.cuda.is_available() is False (no CPU fallback)")
+    # debugging aid (never set by the driver): LDSO_BENCH_ONE_GPU=1 runs all ranks on GPU 0 over gloo, to exercise the N > 1 code
+    # path on a one-GPU box (RCCL refuses two ranks on one device)
+    one_gpu_debug = os.environ.get("LDSO_BENCH_ONE_GPU") == "1"
+    if one_gpu_debug:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("gloo" if one_gpu_debug else "nccl", rank=rank, world_size=world)
 
     from ldso_amd import synth, binding, dist as ldist
 

@@ -283,7 +283,6 @@ int ldso_ba_set_image_device(ldso_ba_t *H, int slot, const void *dev) {
 static int build_chunks(ldso_ba *H) {
     // host-major chunks over the local shard [pBegin,pEnd)
     BaDims &D = H->D;
-    const int Pn = D.pEnd - D.pBegin;
     // smallest multiple of 4 points per chunk that keeps the grid within one wave of workgroups (one per CU)
     int CH = 4;
     for (;; CH += 4) {

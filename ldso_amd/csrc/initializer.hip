@@ -760,8 +760,6 @@ template <class T> static int ini_upload(ldso_initializer *H, T **dst, const std
     return LDSO_OK;
 }
 
-static int ini_sync(ldso_initializer *H) { CHK(hipStreamSynchronize(H->stream)); return LDSO_OK; }
-
 // SoA <-> record conversion
 #define INI_FIELDS(X) X(u) X(v) X(idepth) X(idepth_new) X(iR) X(iRSumNum) X(lastHessian) X(lastHessian_new) X(maxstep) X(outlierTH)
 
