@@ -32,6 +32,8 @@ hipError_t ba_launch_activate(const BaPtrs &B, const BaDims &D, const ldso_setti
                               float minIdepthH_act, int GNIts, hipStream_t st);
 hipError_t ba_launch_marg_update(const BaPtrs &B, const BaDims &D, double w, hipStream_t st);
 hipError_t ba_launch_gn_solve(const BaPtrs &B, const BaDims &D, const ResSet &S, const ldso_settings_t &St, const SolveArgs &A, hipStream_t st);
+hipError_t ba_launch_reduce_solve(const BaPtrs &B, const BaDims &D, const ResSet &S, const ldso_settings_t &St, const SolveArgs &A, const ChunkStarts &chunkStart,
+                                  int atomicMode, float calibPrior, double l1, double il, hipStream_t st);
 
 static thread_local std::string g_err;
 void ldso_set_error(const std::string &s) { g_err = s; }
@@ -58,6 +60,7 @@ struct ldso_ba {
     float *imgSlots[LD_MAXF] = {nullptr};
     bool imgOwned[LD_MAXF] = {false};
     int32_t *d_chunkStart = nullptr;
+    int *d_waitCtr = nullptr;          // k_reduce_solve: producer counter (zero between launches)
     int32_t *d_margFlags = nullptr;
     float *d_color = nullptr;          // irradiance staging of ldso_ba_set_image_raw
     void *d_act = nullptr;             // staging of ldso_ba_activate_points: n immature records + n results
@@ -186,6 +189,7 @@ int ldso_ba_create(int device, int w, int h, int max_frames, int max_points, lds
     DA(B.Jlin, P * FS); DA(B.rtz, P * FS * 8);
     DA(B.chunk_p0, H->maxChunks); DA(B.chunk_n, H->maxChunks); DA(B.chunk_host, H->maxChunks);
     DA(H->d_chunkStart, F + 2);
+    DA(H->d_waitCtr, 4);
     DA(H->d_margFlags, P);
     DA(B.pairC, 2 * F * F * LD_PAIRC);
     const size_t GSPmax = (8 * FS + LD_GEXTRA + 15) / 16 * 16;
@@ -458,7 +462,7 @@ static void t_end(ldso_ba *H) { if (H->profile) hipEventRecord(H->timers.back().
 
 static int launch_solve(ldso_ba *H, const ResSet &S, unsigned flags, int iteration, double lambda, int logIdx, double *rout, const double *rin) {
     SolveArgs A;
-    A.flags = flags; A.iteration = iteration; A.lambda = lambda; A.hasL = H->hasL ? 1 : 0; A.hasPrior = H->hasPrior ? 1 : 0; A.GSP = H->GSP; A.logIdx = logIdx; A.reduceOut = rout; A.reduceIn = rin; A.itCheck = -1;
+    A.flags = flags; A.iteration = iteration; A.lambda = lambda; A.hasL = H->hasL ? 1 : 0; A.hasPrior = H->hasPrior ? 1 : 0; A.GSP = H->GSP; A.logIdx = logIdx; A.reduceOut = rout; A.reduceIn = rin; A.itCheck = -1; A.waitCtr = nullptr; A.waitTarget = 0;
     t_begin(H, 2);
     CHK(ba_launch_solve(H->B, H->D, S, H->settings, A, H->stream));
     t_end(H);
@@ -629,12 +633,26 @@ static int enqueue_iteration(ldso_ba *H, int iteration, double lambda, int logId
         GnInit gi; gi.enable = 1; gi.hasPrior = H->hasPrior ? 1 : 0; gi.calibPrior = H->settings.initialCalibHessian; gi.itCheck = -1;
         CHK(ba_launch_acc_init(H->B, H->D, gi, H->stream));
     }
-    RUN(launch_reduce(H, S, true, lambda, itCheck));      // accumulates HFinal / bFinal straight into B.acc (no k_gather on this path)
     (void) postOfPrev;
-    {
-        SolveArgs A;
-        A.flags = 0; A.iteration = iteration; A.lambda = lambda; A.hasL = H->hasL ? 1 : 0; A.hasPrior = H->hasPrior ? 1 : 0; A.GSP = H->GSP; A.logIdx = logIdx;
-        A.reduceOut = nullptr; A.reduceIn = nullptr; A.itCheck = itCheck;
+    SolveArgs A;
+    A.flags = 0; A.iteration = iteration; A.lambda = lambda; A.hasL = H->hasL ? 1 : 0; A.hasPrior = H->hasPrior ? 1 : 0; A.GSP = H->GSP; A.logIdx = logIdx;
+    A.reduceOut = nullptr; A.reduceIn = nullptr; A.itCheck = itCheck; A.waitCtr = nullptr; A.waitTarget = 0;
+    const int nT = H->GSP / 16;
+    const int nReduce = H->D.F * H->D.F * (H->hasL ? 2 : 1) + 4 * nT * (nT + 1) / 2 + 1;      // grid of ba_launch_reduce in atomic mode
+    if (nReduce + 2 <= H->numCU) {
+        // k_reduce (fp64 atomics straight into B.acc, no k_gather on this path) and the control step in ONE launch: the control
+        // workgroup waits on a device counter for the reduce workgroups (k_reduce_solve, ba_solve.hip).  Only while every workgroup
+        // of the launch gets its own CU (F <= 11): the fused kernel's LDS footprint allows one workgroup per CU.
+        A.waitCtr = H->d_waitCtr;
+        double lam = lambda;
+        if (H->settings.solverMode & LDSO_SOLVER_USE_GN) lam = 0;
+        if (H->settings.solverMode & LDSO_SOLVER_FIX_LAMBDA) lam = 1e-5;
+        const double l1 = 1 + lam, il = (double) (1.0f / (1 + lam));
+        t_begin(H, 2);
+        CHK(ba_launch_reduce_solve(H->B, H->D, S, H->settings, A, H->chunkStarts, (H->D.pBegin > 0) ? 2 : 1, H->settings.initialCalibHessian, l1, il, H->stream));
+        t_end(H);
+    } else {
+        RUN(launch_reduce(H, S, true, lambda, itCheck));
         t_begin(H, 2);
         CHK(ba_launch_gn_solve(H->B, H->D, S, H->settings, A, H->stream));
         t_end(H);
@@ -772,7 +790,7 @@ int ldso_ba_gn_solve_reduced(ldso_ba_t *H, const void *buf, int iteration, doubl
     const size_t n = H->D.n;
     SolveArgs A;
     A.flags = 0; A.iteration = iteration; A.lambda = lambda; A.hasL = H->hasL ? 1 : 0; A.hasPrior = H->hasPrior ? 1 : 0; A.GSP = H->GSP; A.logIdx = -1;
-    A.reduceOut = nullptr; A.reduceIn = (const double *) buf + n * n + n; A.itCheck = -1;
+    A.reduceOut = nullptr; A.reduceIn = (const double *) buf + n * n + n; A.itCheck = -1; A.waitCtr = nullptr; A.waitTarget = 0;
     t_begin(H, 2);
     CHK(ba_launch_gn_solve(H->B, H->D, S, H->settings, A, H->stream));
     t_end(H);

@@ -21,4 +21,6 @@ struct SolveArgs {
     double *reduceOut;          // multi-GPU: rank-local sums are exported here (SK_GATHER)
     const double *reduceIn;     // multi-GPU: all-reduced sums are read from here (SK_FROMREDUCED)
     int itCheck;                // k_gn_solve: >= 0 = un-forced optimize(): iteration index for the device-side `canbreak` early exit
+    int *waitCtr;               // k_reduce_solve: counter the reduce workgroups of the same launch increment when their sums are in B.acc
+    int waitTarget;             //                 ... and its value when all of them are done (0 / nullptr: no wait)
 };

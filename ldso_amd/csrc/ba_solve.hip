@@ -25,6 +25,7 @@
 #include "lie_dev.h"
 #include "ba_solve.h"
 
+#include "ba_reduce_body.h"
 #define NT 256
 #define TH_CAP 8192      // candidate energies staged in LDS up to this many points
 
@@ -437,9 +438,11 @@ struct SolveIO {
     double lambda;         // GN: LM lambda as passed to solveSystem
     int hasPrior;          // GN: HM / bM present
     const double *redScalars;  // GN, multi-GPU: all-reduced scalar sums (see k_gn_export), nullptr on one GPU
+    int *waitCtr;              // GN, fused kernel: HFinal / bFinal are complete when *waitCtr reaches waitTarget (nullptr: already complete)
+    int waitTarget;
 };
 
-template <int NB, int C, bool GN>
+template <int NB, int C, bool GN, bool WAIT = false>
 static __device__ void solve_core(const BaPtrs &B, const BaDims &D, const ResSet &S, const ldso_settings_t &St, int iteration, double *sm, SolveIO &io) {
     constexpr int M = 16 * NB;
     constexpr int CP = C + 2;      // row pitch of the panel buffers: 16-byte aligned rows, conflict-free 16-byte accesses at stride CP
@@ -461,24 +464,30 @@ static __device__ void solve_core(const BaPtrs &B, const BaDims &D, const ResSet
 
     // ---------------- prologue: every global load of the control step, issued back to back ----------------
     // GN: HFinal / bFinal (lower triangle) come straight from the accumulator k_reduce added into (B.acc)
-    double v[NTILE], dI[NB], dJ[NB];
+    double v[NTILE], dI[NB], dJ[NB], dS = 0.0;
     if (GN) { HF = B.acc; bF = HF + (size_t) n * n; }
-#pragma unroll
-    for (int a = 0; a < NB; a++) {
-        const int i = ty + 16 * a, j = tx + 16 * a;
-        dI[a] = (i < n) ? HF[(size_t) i * n + i] : 0.0;
-        dJ[a] = (j < n) ? HF[(size_t) j * n + j] : 0.0;
-    }
-#pragma unroll
-    for (int a = 0; a < NB; a++)
-#pragma unroll
-        for (int b = 0; b <= a; b++) {
-            const int i = ty + 16 * a, j = tx + 16 * b;
-            double q = 0.0;
-            if (j < n && (!GN || j <= i)) { if (i < n) q = HF[(size_t) i * n + j]; else if (i == n) q = bF[j]; }
-            v[a * (a + 1) / 2 + b] = q;
-        }
-    const double dS = (tid < n) ? HF[(size_t) tid * n + tid] : 0.0;
+#define LD_LOAD_H() do { \
+_Pragma("unroll") \
+        for (int a = 0; a < NB; a++) { \
+            const int i = ty + 16 * a, j = tx + 16 * a; \
+            dI[a] = (i < n) ? HF[(size_t) i * n + i] : 0.0; \
+            dJ[a] = (j < n) ? HF[(size_t) j * n + j] : 0.0; \
+        } \
+_Pragma("unroll") \
+        for (int a = 0; a < NB; a++) \
+_Pragma("unroll") \
+            for (int b = 0; b <= a; b++) { \
+                const int i = ty + 16 * a, j = tx + 16 * b; \
+                double q = 0.0; \
+                if (j < n && (!GN || j <= i)) { if (i < n) q = HF[(size_t) i * n + j]; else if (i == n) q = bF[j]; } \
+                v[a * (a + 1) / 2 + b] = q; \
+            } \
+        dS = (tid < n) ? HF[(size_t) tid * n + tid] : 0.0; \
+    } while (0)
+    // fused kernel (io.waitCtr): the system is still being accumulated by the reduce workgroups of this launch - everything that does
+    // not depend on it is loaded and staged first, the system after the wait below
+    constexpr bool waitH = GN && WAIT;
+    if constexpr (!waitH) { LD_LOAD_H(); }
     double nsv[4];
     if (ortho) {
 #pragma unroll
@@ -522,6 +531,15 @@ static __device__ void solve_core(const BaPtrs &B, const BaDims &D, const ResSet
     }
     if (NB == 4) {      // zero the square L buffer
         for (int i = tid; i < LSZ / 2; i += NT) st2(&sL[2 * i], 0.0, 0.0);
+    }
+    if constexpr (waitH) {
+        if (tid == 0) {
+            while (__hip_atomic_load(io.waitCtr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < io.waitTarget) __builtin_amdgcn_s_sleep(1);
+            *io.waitCtr = 0;                         // every producer has incremented: re-arm for the next launch
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        LD_LOAD_H();
     }
     if (tid < M) sSc[tid] = fast_rsqrt(dS + 10.0);
     {
@@ -709,11 +727,11 @@ static __device__ void solve_core(const BaPtrs &B, const BaDims &D, const ResSet
     __syncthreads();
 }
 
-template <bool GN>
+template <bool GN, bool WAIT = false>
 static __device__ void solve_core_dispatch(const BaPtrs &B, const BaDims &D, const ResSet &S, const ldso_settings_t &St, int iteration, double *sm, SolveIO &io) {
-    if (D.n + 1 <= 64) solve_core<4, 4, GN>(B, D, S, St, iteration, sm, io);
-    else if (D.n + 1 <= 112) solve_core<7, 4, GN>(B, D, S, St, iteration, sm, io);
-    else solve_core<9, 4, GN>(B, D, S, St, iteration, sm, io);
+    if (D.n + 1 <= 64) solve_core<4, 4, GN, WAIT>(B, D, S, St, iteration, sm, io);
+    else if (D.n + 1 <= 112) solve_core<7, 4, GN, WAIT>(B, D, S, St, iteration, sm, io);
+    else solve_core<9, 4, GN, WAIT>(B, D, S, St, iteration, sm, io);
 }
 
 // frame / calibration part of backupState, doStepFromBackup (+ canbreak), loadSateBackup on the working copies
@@ -809,7 +827,8 @@ __global__ __launch_bounds__(NT) void k_solve(BaPtrs B, BaDims D, ResSet S, ldso
 // The two blocks touch disjoint data: block 0 never reads frameEnergyTH (the linearize kernel takes the pair
 // maximum itself) and skips that word in its write-back; canbreak's sumNID is recomputed from the chunk sums.
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NT) void k_gn_solve(BaPtrs B, BaDims D, ResSet S, ldso_settings_t St, SolveArgs A) {
+template <bool WAIT>
+static __device__ __forceinline__ void gn_solve_body(const BaPtrs &B, const BaDims &D, const ResSet &S, const ldso_settings_t &St, const SolveArgs &A, const int role) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int tid = threadIdx.x, F = D.F, n = D.n;
     const int NBsel = (n + 1 <= 64) ? 4 : (n + 1 <= 112) ? 7 : 9;
@@ -817,7 +836,7 @@ __global__ __launch_bounds__(NT) void k_gn_solve(BaPtrs B, BaDims D, ResSet S, l
     if (LD_ITER_SKIPPED(B, A.itCheck)) return;
     const long long t0_ = wall_clock64();
 #define GSTAMP(i) do { if (LD_STAMP_ON && tid == 0) B.energyLog[40 + (i)] = (double) (wall_clock64() - t0_); } while (0)
-    if (blockIdx.x == 1) {
+    if (role == 1) {
         double *sW1 = sm;                        // block 1 never runs solve_core: its scratch starts at the base
         int *sHist = (int *) (sW1 + 64);
         int *sI = sHist + 256;
@@ -842,9 +861,9 @@ __global__ __launch_bounds__(NT) void k_gn_solve(BaPtrs B, BaDims D, ResSet S, l
     DevCalib *sCal = (DevCalib *) (sFr + F);
     if (LD_STAMP_ON && tid == 0) B.energyLog[39] = (double) t0_;
     SolveIO io;
-    io.fr = sFr; io.cal = sCal; io.adH = B.adHostF; io.adT = B.adTargetF; io.sRed = sW; io.sumNID = 0; io.lambda = A.lambda; io.hasPrior = A.hasPrior; io.redScalars = A.reduceIn;
+    io.fr = sFr; io.cal = sCal; io.adH = B.adHostF; io.adT = B.adTargetF; io.sRed = sW; io.sumNID = 0; io.lambda = A.lambda; io.hasPrior = A.hasPrior; io.redScalars = A.reduceIn; io.waitCtr = A.waitCtr; io.waitTarget = A.waitTarget;
     io.ldsAd = (F <= 8) ? (float *) (sCal + 1) : nullptr;
-    solve_core_dispatch<true>(B, D, S, St, A.iteration, sm, io);      // + mirrors, backupState, doStepFromBackup
+    solve_core_dispatch<true, WAIT>(B, D, S, St, A.iteration, sm, io);      // + mirrors, backupState, doStepFromBackup
     GSTAMP(4);
     GSTAMP(5);
     set_precalc<false>(B, D, sFr, sCal, io.adH, io.adT, &St, (float *) (sW + 8), io.sumNID, A.itCheck);      // + canbreak of doStepFromBackup
@@ -857,6 +876,35 @@ __global__ __launch_bounds__(NT) void k_gn_solve(BaPtrs B, BaDims D, ResSet S, l
         unsigned *gC = (unsigned *) B.calib; const unsigned *lC = (const unsigned *) sCal;
         for (int i = tid; i < (int) (sizeof(DevCalib) / 4); i += NT) gC[i] = lC[i];
     }
+}
+
+__global__ __launch_bounds__(NT) void k_gn_solve(BaPtrs B, BaDims D, ResSet S, ldso_settings_t St, SolveArgs A) {
+    gn_solve_body<false>(B, D, S, St, A, (int) blockIdx.x);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_reduce_solve — k_reduce and k_gn_solve of one GN iteration in ONE launch (single-GPU fast path): workgroup 0 is the control
+// step, workgroup 1 the statistics, workgroups 2.. the reduce workgroups.  The control workgroup stages everything that does not
+// depend on the system (frames, calibration, adjoints, nullspace projector, LDS set-up) while the reduce workgroups run, waits
+// until all of them have signalled (increment of a device counter once their atomics are acknowledged; acquire fence on the other side)
+// and only then loads HFinal / bFinal.  This removes one kernel boundary and hides the launch-to-first-data latency of the control
+// step (about 5 us of a 50 us iteration).  All workgroups of the launch are resident at once (F*F + 4*tiles + 3 <= 256 CUs), and the
+// waiting workgroup has the lowest index, so it never keeps a producer from being scheduled.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void k_reduce_solve(BaPtrs B, BaDims D, ResSet S, ldso_settings_t St, SolveArgs A, ChunkStarts chunkStart, int atomicMode,
+                                                     float calibPrior, double l1, double il) {
+    if (blockIdx.x >= 2) {
+        if (LD_ITER_SKIPPED(B, A.itCheck)) return;
+        reduce_body(B, D, S, chunkStart, A.hasL, A.GSP, atomicMode, A.hasPrior, calibPrior, l1, il, -1, (int) blockIdx.x - 2);
+        // Everything a reduce workgroup hands to the control workgroup went through device-scope atomics (performed at the memory
+        // side): waiting for their acknowledgement is enough - a release FENCE would also write the whole L2 back (the outputs of
+        // the previous k_linearize are still dirty there), which costs more than the kernel boundary this fusion removes.
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(A.waitCtr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    gn_solve_body<true>(B, D, S, St, A, (int) blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -942,6 +990,23 @@ hipError_t ba_launch_gn_solve(const BaPtrs &B, const BaDims &D, const ResSet &S,
     size_t lds = lds0 > stats + 64 ? lds0 : stats + 64;                         // block 1 aliases the base
     if (lds > 48 * 1024) hipFuncSetAttribute((const void *) k_gn_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
     hipLaunchKernelGGL(k_gn_solve, dim3(2), dim3(NT), lds, st, B, D, S, St, A);
+    return hipGetLastError();
+}
+
+// nReduce = workgroups of ba_launch_reduce in atomic mode (see there)
+hipError_t ba_launch_reduce_solve(const BaPtrs &B, const BaDims &D, const ResSet &S, const ldso_settings_t &St, const SolveArgs &A, const ChunkStarts &chunkStart,
+                                  int atomicMode, float calibPrior, double l1, double il, hipStream_t st) {
+    const int nT = A.GSP / 16;
+    const int nReduce = D.F * D.F * (A.hasL ? 2 : 1) + SCT_KS * nT * (nT + 1) / 2 + 1;
+    size_t mirror = (size_t) D.F * sizeof(DevFrame) + sizeof(DevCalib) + (D.F <= 8 ? (size_t) D.F * D.F * 128 * sizeof(float) : 0), stats = 64 * sizeof(double) + (256 + 8) * sizeof(int) + TH_CAP * sizeof(float);
+    size_t lds0 = solve_lds_common(D) + 64 * sizeof(double) + mirror + 64;
+    size_t lds = lds0 > stats + 64 ? lds0 : stats + 64;
+    const size_t ldsR = (size_t) (2 * SCT_SLAB * 16 + SCT_SLAB) * sizeof(float);
+    if (ldsR > lds) lds = ldsR;
+    if (lds > 48 * 1024) hipFuncSetAttribute((const void *) k_reduce_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+    SolveArgs A2 = A;
+    A2.waitTarget = nReduce;
+    hipLaunchKernelGGL(k_reduce_solve, dim3(nReduce + 2), dim3(NT), lds, st, B, D, S, St, A2, chunkStart, atomicMode, calibPrior, l1, il);
     return hipGetLastError();
 }
 
