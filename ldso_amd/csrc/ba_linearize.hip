@@ -91,16 +91,17 @@ struct PtIn {
 };
 
 template <int NSG, bool HAS_L, bool FIX>
-static __device__ __forceinline__ void load_point(PtIn<NSG> &q, const BaPtrs &B, const ResSet &cur, int FS, int p, int s, int k, int stepMode) {
+// indices are unsigned so that every access is base (SGPR pair) + 32-bit lane offset instead of a 64-bit per-lane address
+static __device__ __forceinline__ void load_point(PtIn<NSG> &q, const BaPtrs &B, const ResSet &cur, unsigned FS, unsigned p, unsigned s, unsigned k, int stepMode) {
     q.pu = B.pu[p]; q.pv = B.pv[p]; q.idp = B.pidepth[p]; q.idz = B.pidepth_zero[p]; q.priorF = B.ppriorF[p];
     q.color = B.pcolor[p * 8 + k]; q.wgt = B.pweights[p * 8 + k];
     q.maxRelBS = cur.maxRelBS[p]; q.numGood = cur.numGood[p];
 #pragma unroll
     for (int g = 0; g < NSG; g++) {
-        const int slot = p * FS + g * 8 + s;       // slot tables are dense [P][FS]: every index is readable
+        const unsigned slot = p * FS + g * 8 + s;       // slot tables are dense [P][FS]: every index is readable
         q.rflat[g] = B.rflat[slot]; q.rlin[g] = B.rlin[slot]; q.rnew[g] = FIX ? B.rnew[slot] : 0; q.rlidx[g] = HAS_L ? B.rlidx[slot] : 0;
         q.state[g] = cur.state[slot]; q.active[g] = cur.active[slot]; q.energy[g] = cur.energy[slot];
-        q.jp[g] = cur.JpJdF[slot * 8 + k]; q.cen[g] = cur.center[slot * 3 + (k < 3 ? k : 2)];
+        q.jp[g] = cur.JpJdF[slot * 8 + k]; q.cen[g] = cur.center[slot * 3 + (k < 3 ? k : 2u)];
     }
     if (stepMode & 1) {
         q.pstep = B.pstep[p]; q.bdSumF = cur.bdSumF[p]; q.HdiF = cur.HdiF[p]; q.nAct = cur.nActive[p];
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D,
 
     for (; pi < np; pi += LD_WAVES) {
         if (pi == wave) LSTAMP(2);
-        const int p = p0 + pi;
+        const unsigned p = (unsigned) (p0 + pi);
 #if LD_PREFETCH
         const PtIn<NSG> q = nx;
         if (pi + LD_WAVES < np) load_point<NSG, HAS_L, FIX>(nx, B, cur, FS, p + LD_WAVES, s, k, stepMode);
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D,
 #pragma unroll
         for (int g = 0; g < NSG; g++) {
             const int t = g * 8 + s;
-            const int slot = p * FS + t;
+            const unsigned slot = p * (unsigned) FS + (unsigned) t;
             const bool exists = (t < F) && (q.rflat[g] >= 0) && flagged;
             const bool isLin = MARG ? false : (exists && (q.rlin[g] != 0));
             // resetOOB (Residuals.h): MARG always; stepMode bit 1 = the optimize() preamble on every non-linearised residual (FullSystem.cc:744-748)
@@ -459,8 +460,8 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D,
                 const bool accL = isLin && activeNew;
                 float lsbd = 0, lsHdd = 0, lH0 = 0, lH1 = 0, lH2 = 0, lH3 = 0;
                 if (accL) {
-                    const ldso_rawjac_t &J = B.Jlin[q.rlidx[g]];
-                    const float *rtz = B.rtz + q.rlidx[g] * 8;
+                    const ldso_rawjac_t &J = B.Jlin[(unsigned) q.rlidx[g]];
+                    const float *rtz = B.rtz + (unsigned) q.rlidx[g] * 8u;
                     float dpx = 0, dpy = 0;
 #pragma unroll
                     for (int i = 0; i < 6; i++) { dpx += J.Jpdxi[0][i] * pr.dp[i]; dpy += J.Jpdxi[1][i] * pr.dp[i]; }
@@ -527,7 +528,7 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D,
 
             // ---- per-slot outputs (slot leader) ----------------------------------------------------------
             if (t < F) {
-                nxt.JpJdF[slot * 8 + k] = jp;
+                nxt.JpJdF[slot * 8 + (unsigned) k] = jp;
                 if (k == 0) {
                     nxt.state[slot] = newState;
                     nxt.active[slot] = activeNew;
@@ -537,7 +538,7 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D,
                     nxt.toRemove[slot] = toRemove;
                     if (doLin) energySum += ret;
                 }
-                if (k < 3) nxt.center[slot * 3 + k] = compute ? (k == 0 ? c0 : k == 1 ? c1 : c2) : q.cen[g];
+                if (k < 3) nxt.center[slot * 3 + (unsigned) k] = compute ? (k == 0 ? c0 : k == 1 ? c1 : c2) : q.cen[g];
             }
             if (B.dumpJ != nullptr && compute) {
                 ldso_rawjac_t &o = B.dumpJ[q.rflat[g]];
