@@ -91,22 +91,26 @@ struct PtIn {
 };
 
 template <int NSG, bool HAS_L, bool FIX>
-// indices are unsigned so that every access is base (SGPR pair) + 32-bit lane offset instead of a 64-bit per-lane address
+// element i of a device array with the BYTE offset computed in 32 bits: base pointer (kernel argument, SGPR pair) + zero-extended
+// lane offset is the addressing mode the hardware has (saddr + voffset); a 64-bit per-lane address costs two registers and a
+// 64-bit shift-add per access.  Every table of a window is far below 4 GB.
+#define AT(ptr, i) (*(decltype(ptr)) ((char *) (ptr) + (size_t) ((unsigned) (i) * (unsigned) sizeof(*(ptr)))))
+
 static __device__ __forceinline__ void load_point(PtIn<NSG> &q, const BaPtrs &B, const ResSet &cur, unsigned FS, unsigned p, unsigned s, unsigned k, int stepMode) {
-    q.pu = B.pu[p]; q.pv = B.pv[p]; q.idp = B.pidepth[p]; q.idz = B.pidepth_zero[p]; q.priorF = B.ppriorF[p];
-    q.color = B.pcolor[p * 8 + k]; q.wgt = B.pweights[p * 8 + k];
-    q.maxRelBS = cur.maxRelBS[p]; q.numGood = cur.numGood[p];
+    q.pu = AT(B.pu, p); q.pv = AT(B.pv, p); q.idp = AT(B.pidepth, p); q.idz = AT(B.pidepth_zero, p); q.priorF = AT(B.ppriorF, p);
+    q.color = AT(B.pcolor, p * 8 + k); q.wgt = AT(B.pweights, p * 8 + k);
+    q.maxRelBS = AT(cur.maxRelBS, p); q.numGood = AT(cur.numGood, p);
 #pragma unroll
     for (int g = 0; g < NSG; g++) {
         const unsigned slot = p * FS + g * 8 + s;       // slot tables are dense [P][FS]: every index is readable
-        q.rflat[g] = B.rflat[slot]; q.rlin[g] = B.rlin[slot]; q.rnew[g] = FIX ? B.rnew[slot] : 0; q.rlidx[g] = HAS_L ? B.rlidx[slot] : 0;
-        q.state[g] = cur.state[slot]; q.active[g] = cur.active[slot]; q.energy[g] = cur.energy[slot];
-        q.jp[g] = cur.JpJdF[slot * 8 + k]; q.cen[g] = cur.center[slot * 3 + (k < 3 ? k : 2u)];
+        q.rflat[g] = AT(B.rflat, slot); q.rlin[g] = AT(B.rlin, slot); q.rnew[g] = FIX ? AT(B.rnew, slot) : 0; q.rlidx[g] = HAS_L ? AT(B.rlidx, slot) : 0;
+        q.state[g] = AT(cur.state, slot); q.active[g] = AT(cur.active, slot); q.energy[g] = AT(cur.energy, slot);
+        q.jp[g] = AT(cur.JpJdF, slot * 8 + k); q.cen[g] = AT(cur.center, slot * 3 + (k < 3 ? k : 2u));
     }
     if (stepMode & 1) {
-        q.pstep = B.pstep[p]; q.bdSumF = cur.bdSumF[p]; q.HdiF = cur.HdiF[p]; q.nAct = cur.nActive[p];
+        q.pstep = AT(B.pstep, p); q.bdSumF = AT(cur.bdSumF, p); q.HdiF = AT(cur.HdiF, p); q.nAct = AT(cur.nActive, p);
 #pragma unroll
-        for (int i = 0; i < 4; i++) q.hcd[i] = cur.HcdA[p * 4 + i] + cur.HcdL[p * 4 + i];
+        for (int i = 0; i < 4; i++) q.hcd[i] = AT(cur.HcdA, p * 4 + i) + AT(cur.HcdL, p * 4 + i);
     }
 }
 
@@ -251,7 +255,7 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D,
                 if (isfinite(b)) step = -b * q.HdiF; else { step = q.pstep; if (lane == 0) B.scalars[4] = 1.0; }
             }
             const float ni = idp + 1.0f * step;
-            if (lane == 0) { B.pstep[p] = step; B.pidepth_backup[p] = idp; B.pidepth[p] = ni; B.pidepth_zero[p] = ni; }
+            if (lane == 0) { AT(B.pstep, p) = step; AT(B.pidepth_backup, p) = idp; AT(B.pidepth, p) = ni; AT(B.pidepth_zero, p) = ni; }
             idp = ni; idz = ni;
         }
         const float deltaF = idp - idz;
@@ -528,17 +532,17 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D,
 
             // ---- per-slot outputs (slot leader) ----------------------------------------------------------
             if (t < F) {
-                nxt.JpJdF[slot * 8 + (unsigned) k] = jp;
+                AT(nxt.JpJdF, slot * 8 + (unsigned) k) = jp;
                 if (k == 0) {
-                    nxt.state[slot] = newState;
-                    nxt.active[slot] = activeNew;
-                    nxt.energy[slot] = newEnergy;
-                    nxt.newEnergyWO[slot] = doLin ? newEnergyWO : -1.0f;
-                    if (t == F - 1) nxt.candE[p] = doLin ? newEnergyWO : -1.0f;
-                    nxt.toRemove[slot] = toRemove;
+                    AT(nxt.state, slot) = newState;
+                    AT(nxt.active, slot) = activeNew;
+                    AT(nxt.energy, slot) = newEnergy;
+                    AT(nxt.newEnergyWO, slot) = doLin ? newEnergyWO : -1.0f;
+                    if (t == F - 1) AT(nxt.candE, p) = doLin ? newEnergyWO : -1.0f;
+                    AT(nxt.toRemove, slot) = toRemove;
                     if (doLin) energySum += ret;
                 }
-                if (k < 3) nxt.center[slot * 3 + (unsigned) k] = compute ? (k == 0 ? c0 : k == 1 ? c1 : c2) : q.cen[g];
+                if (k < 3) AT(nxt.center, slot * 3 + (unsigned) k) = compute ? (k == 0 ? c0 : k == 1 ? c1 : c2) : q.cen[g];
             }
             if (B.dumpJ != nullptr && compute) {
                 ldso_rawjac_t &o = B.dumpJ[q.rflat[g]];
@@ -583,11 +587,11 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D,
             Grow[8 * FS + lane] = e;
         }
         if (lane == 0) {
-            nxt.HdiF[p] = HdiF; nxt.bdSumF[p] = bdSumF; nxt.idH[p] = idH;
-            nxt.HddA[p] = HddA; nxt.bdA[p] = bdA; nxt.HddL[p] = HddL; nxt.bdL[p] = bdL;
-            nxt.HcdA[p * 4 + 0] = HcdA0; nxt.HcdA[p * 4 + 1] = HcdA1; nxt.HcdA[p * 4 + 2] = HcdA2; nxt.HcdA[p * 4 + 3] = HcdA3;
-            nxt.HcdL[p * 4 + 0] = HcdL0; nxt.HcdL[p * 4 + 1] = HcdL1; nxt.HcdL[p * 4 + 2] = HcdL2; nxt.HcdL[p * 4 + 3] = HcdL3;
-            nxt.maxRelBS[p] = maxRelBS; nxt.numGood[p] = numGood; nxt.nActive[p] = nActive;
+            AT(nxt.HdiF, p) = HdiF; AT(nxt.bdSumF, p) = bdSumF; AT(nxt.idH, p) = idH;
+            AT(nxt.HddA, p) = HddA; AT(nxt.bdA, p) = bdA; AT(nxt.HddL, p) = HddL; AT(nxt.bdL, p) = bdL;
+            AT(nxt.HcdA, p * 4 + 0) = HcdA0; AT(nxt.HcdA, p * 4 + 1) = HcdA1; AT(nxt.HcdA, p * 4 + 2) = HcdA2; AT(nxt.HcdA, p * 4 + 3) = HcdA3;
+            AT(nxt.HcdL, p * 4 + 0) = HcdL0; AT(nxt.HcdL, p * 4 + 1) = HcdL1; AT(nxt.HcdL, p * 4 + 2) = HcdL2; AT(nxt.HcdL, p * 4 + 3) = HcdL3;
+            AT(nxt.maxRelBS, p) = maxRelBS; AT(nxt.numGood, p) = numGood; AT(nxt.nActive, p) = nActive;
             nidSum += fabsf(idp); nidCnt++;
         }
     }   // points of this wave
