@@ -179,7 +179,7 @@ __device__ __forceinline__ void aff_from_to_f(float expF, float expT, float aF, 
     b = bT - a * bF;
 }
 
-__device__ void tr_eval(const TrParams &P, int lvl, const double *T, float aff_a, float aff_b, float cutoffTH, double *out /*LDS TR_NACC*/,
+__device__ __forceinline__ void tr_eval(const TrParams &P, int lvl, const double *T, float aff_a, float aff_b, float cutoffTH, double *out /*LDS TR_NACC*/,
                         double *red /*LDS [nWaves][TR_NACC]*/, int i0, int istride) {
     const TrLevel &L = P.lv[lvl];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nW = blockDim.x >> 6;
@@ -303,7 +303,7 @@ __device__ void tr_eval(const TrParams &P, int lvl, const double *T, float aff_a
 
 // H (8x8), b (8) from the accumulated sums: divide by the padded n, apply the reference's scale swap.
 // One thread per entry (threads 0..71 of the block): no local arrays (they would live in scratch memory).
-__device__ void tr_hb(const double *acc, double *H, double *b) {
+__device__ __forceinline__ void tr_hb(const double *acc, double *H, double *b) {
     const int tid = threadIdx.x;
     if (tid >= 72) return;
     const int r = (tid < 64) ? (tid >> 3) : (tid - 64), c = (tid < 64) ? (tid & 7) : 8;
@@ -422,7 +422,7 @@ __device__ void ldlt8_wave(const double *H /*LDS 64, row major*/, const double *
     if (lane < 8) x[lane] = xr;
 }
 
-__device__ void tr_vec6(const double *acc, double *rs) {
+__device__ __forceinline__ void tr_vec6(const double *acc, double *rs) {
     rs[0] = (double) (float) acc[0];
     rs[1] = (double) (int) acc[1];
     rs[2] = (double) ((float) acc[2] / ((float) acc[4] + 0.1f));
@@ -441,8 +441,13 @@ __global__ __launch_bounds__(TR_NT) void k_tr_track(TrParams P, TrHyp *hyps) {
     __shared__ float sAff[2], sAffNew[2];
     __shared__ double sH[64], sB[8], sNb[8], sInc[8], sResOld[6], sResNew[6];
     __shared__ int sCtl[4];          // 0: continue LM loop, 1: accept, 2: abort (return false), 3: iterations
+#if LD_STAMP_ON_TR
+    // debug builds: device timing of tr_eval per level (dynamically indexed -> scratch memory: never in a product build)
     long long tEval = 0, tTot0 = wall_clock64(), tLv[5] = {0, 0, 0, 0, 0}; int nEval = 0, nLv[5] = {0, 0, 0, 0, 0};
 #define TEV(call) do { long long t_ = wall_clock64(); call; t_ = wall_clock64() - t_; tEval += t_; nEval++; if (lvl < 5) { tLv[lvl] += t_; nLv[lvl]++; } } while (0)
+#else
+#define TEV(call) do { call; } while (0)
+#endif
     __shared__ float sLambda, sCutRep;
     TrHyp &hy = hyps[blockIdx.x];
     const int tid = threadIdx.x;
@@ -554,7 +559,9 @@ __global__ __launch_bounds__(TR_NT) void k_tr_track(TrParams P, TrHyp *hyps) {
         if (sCtl[2]) break;
         if (levelCutoffRepeat > 1 && !haveRepeated) { lvl++; haveRepeated = true; }
     }
-    if (LD_STAMP_ON_TR && tid == 0) { hy.dbg[0] = (double) tEval; hy.dbg[1] = (double) (wall_clock64() - tTot0); hy.dbg[2] = nEval; for (int q = 0; q < 5; q++) hy.dbg[3 + q] = nLv[q] ? (double) tLv[q] / nLv[q] : 0.0; }
+#if LD_STAMP_ON_TR
+    if (tid == 0) { hy.dbg[0] = (double) tEval; hy.dbg[1] = (double) (wall_clock64() - tTot0); hy.dbg[2] = nEval; for (int q = 0; q < 5; q++) hy.dbg[3 + q] = nLv[q] ? (double) tLv[q] / nLv[q] : 0.0; }
+#endif
     if (tid == 0) {
         hy.iterations = sCtl[3];
         if (sCtl[2]) { hy.ok = 0; }
