@@ -53,7 +53,14 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo" if one_gpu_debug else "nccl", rank=rank, world_size=world)
+        if one_gpu_debug:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            # device_id binds the communicator to this rank's GPU up front (barrier() then never has to guess a device)
+            try:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            except TypeError:          # older torch without device_id
+                dist.init_process_group("nccl", rank=rank, world_size=world)
 
     from ldso_amd import synth, binding, dist as ldist
 
