@@ -55,7 +55,8 @@ struct IniLevel {
     int *isGood, *isGood_new, *parent, *nb;
     float *jb[2];                       // [n][10]
     const int *sched;                   // [nPass][64] point index or -1
-    const int *schedNb;                 // [nPass][64][INI_NB] neighbour rows in schedule order
+    const int *schedOff;                // [nPass][64] LDS byte offset of the point's key (dummy slot n*4 for idle lanes)
+    const int *schedNb;                 // [nPass][64][INI_NB] LDS byte offsets of the neighbours' keys in schedule order (dummy slot: none)
     float *schedIdv;                    // [nPass][64] idepth of the scheduled points (gathered before an optReg sweep)
     const int *childOff, *childIdx;     // children (points of level - 1) of every point of this level, ascending
 };
@@ -368,13 +369,15 @@ __device__ void ini_ldlt_wave(float a, float rhsLane, int nn, float *x /*LDS 8*/
 
 // The in-place sequential sweeps (see file header).  sIR[j] = key of iR of point j if it is good, INI_NOKEY otherwise; filled by the caller.
 // op 0: optReg (:439-457); op 1: neighbour average of resetPoints (:629-641).
-struct SwIn { int i; int4 a, b, c; float id; };
-// unconditional: the schedule arrays carry INI_SWPAD passes of padding (index -1) behind the last pass
+// Sweep inputs of one scheduled point: LDS BYTE offsets of its own key and of its 10 neighbours' keys (an absent neighbour and an
+// idle lane point at the dummy slot sK[n], which always holds INI_NOKEY - no clamps or selects in the loop), and its idepth.
+struct SwIn { int self; int4 a, b, c; float id; };
+// unconditional: the schedule arrays carry INI_SWPAD passes of padding (dummy slot) behind the last pass
 #define INI_SWPAD 8
 __device__ __forceinline__ SwIn ini_sw_load(const IniLevel &L, int p, int lane) {
     SwIn r;
     const size_t q = (size_t) p * 64 + lane;
-    r.i = L.sched[q];
+    r.self = L.schedOff[q];
     const int4 *row = (const int4 *) (L.schedNb + q * INI_NB);
     r.a = row[0]; r.b = row[1]; r.c = row[2];
     r.id = L.schedIdv[q];
@@ -386,19 +389,15 @@ __device__ __forceinline__ int ini_key(float f) { const int b = __builtin_bit_ca
 __device__ __forceinline__ float ini_unkey(int k) { return __builtin_bit_cast(float, k ^ ((k >> 31) & 0x7fffffff)); }
 #define CEI(a, b) do { const int lo_ = min(a, b), hi_ = max(a, b); a = lo_; b = hi_; } while (0)
 
-__device__ __forceinline__ void ini_sw_point(const SwIn &r, int *sK, int op) {
+template <int OP>
+__device__ __forceinline__ void ini_sw_point(const SwIn &r, int *sK, int dummyOff) {
     const float regWeight = 0.8f;
-    const int ci = r.i;
-    int v[10];
-    // branch-free gathers: clamp the index, select afterwards
-#define GK(dst, idx) do { const int k_ = sK[max(idx, 0)]; dst = ((idx) >= 0) ? k_ : INI_NOKEY; } while (0)
-    GK(v[0], r.a.x); GK(v[1], r.a.y); GK(v[2], r.a.z); GK(v[3], r.a.w);
-    GK(v[4], r.b.x); GK(v[5], r.b.y); GK(v[6], r.b.z); GK(v[7], r.b.w);
-    GK(v[8], r.c.x); GK(v[9], r.c.y);
-    int self;
-    GK(self, ci);
+    char *base = (char *) sK;
+#define GK(off) (*(const int *) (base + (off)))
+    int v[10] = {GK(r.a.x), GK(r.a.y), GK(r.a.z), GK(r.a.w), GK(r.b.x), GK(r.b.y), GK(r.b.z), GK(r.b.w), GK(r.c.x), GK(r.c.y)};
+    const int self = GK(r.self);
 #undef GK
-    if (op == 0) {
+    if (OP == 0) {
         int nnn = 0;
 #pragma unroll
         for (int q = 0; q < 10; q++) nnn += (v[q] != INI_NOKEY) ? 1 : 0;
@@ -413,31 +412,35 @@ __device__ __forceinline__ void ini_sw_point(const SwIn &r, int *sK, int op) {
         CEI(v[3], v[4]); CEI(v[5], v[6]);
         const int m = nnn >> 1;
         const int mk = (m == 0) ? v[0] : (m == 1) ? v[1] : (m == 2) ? v[2] : (m == 3) ? v[3] : (m == 4) ? v[4] : v[5];
-        if (self != INI_NOKEY && nnn > 2) sK[ci] = ini_key((1 - regWeight) * r.id + regWeight * ini_unkey(mk));
+        // the dummy slot is never good, so idle lanes never write
+        if (self != INI_NOKEY && nnn > 2) *(int *) (base + r.self) = ini_key((1 - regWeight) * r.id + regWeight * ini_unkey(mk));
     } else {
         float snd = 0, sn = 0;
 #pragma unroll
         for (int q = 0; q < 10; q++) if (v[q] != INI_NOKEY) { snd += ini_unkey(v[q]); sn += 1; }
-        if (ci >= 0 && self == INI_NOKEY && sn > 0) sK[ci] = ini_key(snd / sn);
+        if (r.self != dummyOff && self == INI_NOKEY && sn > 0) *(int *) (base + r.self) = ini_key(snd / sn);
     }
 }
-// Executed by wave 0.  The pass inputs (point index, neighbour row, idepth) are stored in schedule order, so every pass needs one
-// level of coalesced global loads, issued four passes ahead; the dependent chain of a pass is LDS gather -> median -> LDS write.
-__device__ void ini_sweep(const IniLevel &L, int *sIR, int op) {
+// Executed by wave 0.  The pass inputs are stored in schedule order, so every pass needs one level of coalesced global loads,
+// issued four passes ahead; the dependent chain of a pass is LDS gather -> median -> LDS write.
+template <int OP>
+__device__ void ini_sweep(const IniLevel &L, int *sIR) {
     if (threadIdx.x >= 64) return;
     const int lane = threadIdx.x;
     if (L.nPass == 0) return;
+    const int dummyOff = L.n * 4;
     SwIn r0 = ini_sw_load(L, 0, lane), r1 = ini_sw_load(L, 1, lane), r2 = ini_sw_load(L, 2, lane), r3 = ini_sw_load(L, 3, lane);
     for (int p = 0; p < L.nPass; p += 4) {
-        ini_sw_point(r0, sIR, op); r0 = ini_sw_load(L, p + 4, lane);
-        ini_sw_point(r1, sIR, op); r1 = ini_sw_load(L, p + 5, lane);
-        ini_sw_point(r2, sIR, op); r2 = ini_sw_load(L, p + 6, lane);
-        ini_sw_point(r3, sIR, op); r3 = ini_sw_load(L, p + 7, lane);
+        ini_sw_point<OP>(r0, sIR, dummyOff); r0 = ini_sw_load(L, p + 4, lane);
+        ini_sw_point<OP>(r1, sIR, dummyOff); r1 = ini_sw_load(L, p + 5, lane);
+        ini_sw_point<OP>(r2, sIR, dummyOff); r2 = ini_sw_load(L, p + 6, lane);
+        ini_sw_point<OP>(r3, sIR, dummyOff); r3 = ini_sw_load(L, p + 7, lane);
     }
 }
 
 __device__ void ini_fill(const IniLevel &L, int *sIR, int pending, const float *idv) {
     const int nt = blockDim.x;
+    if (threadIdx.x == 0) sIR[L.n] = INI_NOKEY;          // dummy slot of absent neighbours / idle lanes
     for (int j0 = threadIdx.x; j0 < L.n; j0 += 4 * nt) {
         int g[4], gn[4]; float r[4];
 #pragma unroll
@@ -467,7 +470,7 @@ __device__ void ini_opt_reg(const IniLevel &L, int *sIR, int snapped, int pendin
 #ifdef LDSO_STAMPS
     const long long t0_ = wall_clock64();
 #endif
-    ini_sweep(L, sIR, 0);
+    ini_sweep<0>(L, sIR);
 #ifdef LDSO_STAMPS
     if (threadIdx.x == 0) { dbg->dbgSweepTicks += wall_clock64() - t0_; dbg->dbgSweepPasses += L.nPass; dbg->dbgSweeps++; }
 #endif
@@ -530,7 +533,7 @@ __global__ __launch_bounds__(INI_CT) void k_ini_ctl(IniParams P, int phase) {
         const IniLevel &L = P.L[top];
         ini_fill(L, sIR, 0, nullptr);
         __syncthreads();
-        ini_sweep(L, sIR, 1);
+        ini_sweep<1>(L, sIR);
         __syncthreads();
         for (int j = tid; j < L.n; j += blockDim.x) {
             const int kk = sIR[j];
@@ -907,9 +910,15 @@ int ldso_init_set_first(ldso_initializer_t *H, const float calib[4], const float
         sched.resize(sched.size() + (size_t) INI_SWPAD * 64, -1);
         { int *p = nullptr; int r_ = ini_upload(H, &p, sched); if (r_ != LDSO_OK) return r_; L.sched = p; }
         {
-            std::vector<int> snb(sched.size() * INI_NB, -1);
-            for (size_t q = 0; q < sched.size(); q++) if (sched[q] >= 0) for (int e = 0; e < INI_NB; e++) snb[q * INI_NB + e] = nb[(size_t) sched[q] * INI_NB + e];
+            const int dummy = n * 4;
+            std::vector<int> snb(sched.size() * INI_NB, dummy), soff(sched.size(), dummy);
+            for (size_t q = 0; q < sched.size(); q++)
+                if (sched[q] >= 0) {
+                    soff[q] = sched[q] * 4;
+                    for (int e = 0; e < 10; e++) { const int j = nb[(size_t) sched[q] * INI_NB + e]; snb[q * INI_NB + e] = (j >= 0) ? j * 4 : dummy; }
+                }
             int *p = nullptr; int r_ = ini_upload(H, &p, snb); if (r_ != LDSO_OK) return r_; L.schedNb = p;
+            p = nullptr; r_ = ini_upload(H, &p, soff); if (r_ != LDSO_OK) return r_; L.schedOff = p;
             IA(H->levelAllocs, L.schedIdv, sched.size());
         }
         // children lists (points of level l-1 whose parent is p), ascending child index
@@ -925,7 +934,7 @@ int ldso_init_set_first(ldso_initializer_t *H, const float calib[4], const float
         { int *p = nullptr; int r_ = ini_upload(H, &p, idx); if (r_ != LDSO_OK) return r_; L.childIdx = p; }
         { int r_ = ini_put_points(H, l, pts); if (r_ != LDSO_OK) return r_; }
     }
-    H->ldsBytes = maxN * sizeof(float);
+    H->ldsBytes = (maxN + 1) * sizeof(float);
     CHK(hipFuncSetAttribute((const void *) k_ini_ctl, hipFuncAttributeMaxDynamicSharedMemorySize, (int) H->ldsBytes));
     // state of setFirst (:612-614)
     IniCtl c; memset(&c, 0, sizeof(c));
