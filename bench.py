@@ -248,7 +248,8 @@ def tracker_line():
         g.track_batch(guesses, [(a, b)] * 20, sc["levels"] - 1)
     tb = (time.perf_counter() - t0) / 10
     return {"workload": f"C2: {win.w}x{win.h} pair, {sc['levels']} levels, {len(sc['pts'])} reference points",
-            "gpu_track_ms": round(tg * 1e3, 4), "lm_iterations": int(rg["iterations"]), "gpu_track_batch20_ms": round(tb * 1e3, 4),
+            "gpu_track_ms": round(tg * 1e3, 4), "gpu_tracks_per_s": round(1.0 / tg, 1), "gpu_hypotheses_per_s_batch20": round(20.0 / tb, 1),
+            "lm_iterations": int(rg["iterations"]), "gpu_track_batch20_ms": round(tb * 1e3, 4),
             "cpu_oracle_track_ms": round(to * 1e3, 4), "cpu_cores": 1}
 
 
