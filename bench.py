@@ -240,6 +240,8 @@ def tracker_line():
 
     timeit(g, 3)
     tg, rg = timeit(g, 50)
+    ev, pcn = g.last_track_evals()
+    track_bytes = int(sum(int(e) * int(n) * 64 for e, n in zip(ev, pcn)))        # pc_n * (16 B point + 48 B taps) per calcRes
     to, ro = timeit(o, 5)
     guesses = [synth.se3_exp([0.002 * i, 0, 0, 0, 0.0005 * i, 0]) for i in range(20)]
     g.track_batch(guesses, [(a, b)] * 20, sc["levels"] - 1)
@@ -250,6 +252,8 @@ def tracker_line():
     return {"workload": f"C2: {win.w}x{win.h} pair, {sc['levels']} levels, {len(sc['pts'])} reference points",
             "gpu_track_ms": round(tg * 1e3, 4), "gpu_tracks_per_s": round(1.0 / tg, 1), "gpu_hypotheses_per_s_batch20": round(20.0 / tb, 1),
             "lm_iterations": int(rg["iterations"]), "gpu_track_batch20_ms": round(tb * 1e3, 4),
+            "evaluations_per_level": [int(e) for e in ev[:sc["levels"]]], "points_per_level": [int(n) for n in pcn[:sc["levels"]]],
+            "algorithmic_bytes_per_track": track_bytes, "algorithmic_GBps": round(track_bytes / tg / 1e9, 3),
             "cpu_oracle_track_ms": round(to * 1e3, 4), "cpu_cores": 1}
 
 

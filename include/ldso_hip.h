@@ -215,6 +215,8 @@ int ldso_tr_track_batch(ldso_tracker_t *t, int nhyp, double *T_ref2new_inout, fl
  * ldso_tr_track_batch call that ran every try with minRes = NaN: reproduces the sequential accept / abort / early-exit decisions
  * (a try counts as aborted at the level where its residual exceeds 1.5 x the `achievedRes` of the tries before it).  Host only.
  * best_out = index of the winning try or -1; tries_consumed_out = how many tries the sequential loop would have run. */
+/* calcRes evaluations per pyramid level of the last track (hypothesis 0 of a batch) and the reference point counts pc_n[lvl] */
+int ldso_tr_last_track_evals(ldso_tracker_t *t, int evals[5], int pc_n[5]);
 int ldso_tr_select_hypothesis(int nhyp, int coarsestLvl, const double *lastResiduals /*nhyp*5*/, const int *ok /*nhyp*/, double lastCoarseRMSE0,
                               double reTrackThreshold, int *best_out, int *tries_consumed_out, double achievedRes_out[5]);
 int ldso_tr_get_pc(ldso_tracker_t *t, int lvl, float *u, float *v, float *idepth, float *color, int *n);

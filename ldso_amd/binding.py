@@ -381,6 +381,12 @@ class Tracker:
         r = self.track_batch([T], [(a, b)], coarsest, min_res)
         return {k: (v[0] if isinstance(v, (list, np.ndarray)) else v) for k, v in r.items()}
 
+    def last_track_evals(self):
+        """(evals[5], pc_n[5]) of the last track: calcRes evaluations and reference points per pyramid level"""
+        ev = np.zeros(5, np.int32); pc = np.zeros(5, np.int32)
+        _chk(self.L.ldso_tr_last_track_evals(self.h, _p(ev), _p(pc)))
+        return ev, pc
+
     def track_batch(self, Ts, affs, coarsest, min_res=None):
         n = len(Ts)
         T = np.ascontiguousarray(np.stack([np.asarray(t)[:3, :4] for t in Ts]), np.float64).copy()

@@ -52,6 +52,7 @@ struct TrHyp {                 // one motion hypothesis in / result out
     double lastResiduals[5];
     double flow[3];
     int ok, iterations;
+    int evals[5], pad_;         // calcRes evaluations per pyramid level (algorithmic bytes of a track = sum evals[l] * pc_n[l] * 64 B)
     double dbg[12];             // LDSO_STAMPS builds: time in tr_eval / serial LM sections / evals count
 };
 
@@ -444,11 +445,13 @@ __global__ __launch_bounds__(TR_NT) void k_tr_track(TrParams P, TrHyp *hyps) {
 #if LD_STAMP_ON_TR
     // debug builds: device timing of tr_eval per level (dynamically indexed -> scratch memory: never in a product build)
     long long tEval = 0, tTot0 = wall_clock64(), tLv[5] = {0, 0, 0, 0, 0}; int nEval = 0, nLv[5] = {0, 0, 0, 0, 0};
-#define TEV(call) do { long long t_ = wall_clock64(); call; t_ = wall_clock64() - t_; tEval += t_; nEval++; if (lvl < 5) { tLv[lvl] += t_; nLv[lvl]++; } } while (0)
+#define TEV(call) do { long long t_ = wall_clock64(); call; t_ = wall_clock64() - t_; tEval += t_; nEval++; if (lvl < 5) { tLv[lvl] += t_; nLv[lvl]++; } if (threadIdx.x == 0) sEv[lvl]++; } while (0)
 #else
-#define TEV(call) do { call; } while (0)
+#define TEV(call) do { call; if (threadIdx.x == 0) sEv[lvl]++; } while (0)
 #endif
     __shared__ float sLambda, sCutRep;
+    __shared__ int sEv[5];
+    if (threadIdx.x < 5) sEv[threadIdx.x] = 0;
     TrHyp &hy = hyps[blockIdx.x];
     const int tid = threadIdx.x;
     if (tid < 12) sT[tid] = hy.T[tid];
@@ -564,6 +567,7 @@ __global__ __launch_bounds__(TR_NT) void k_tr_track(TrParams P, TrHyp *hyps) {
 #endif
     if (tid == 0) {
         hy.iterations = sCtl[3];
+        for (int q = 0; q < 5; q++) hy.evals[q] = sEv[q];
         if (sCtl[2]) { hy.ok = 0; }
         else {
             for (int i = 0; i < 12; i++) hy.T[i] = sT[i];
@@ -610,6 +614,7 @@ struct ldso_tracker {
     TrHyp *d_hyp = nullptr;
     double lastAcc[TR_NACC];
     bool haveAcc = false;
+    int lastEvals[5] = {0, 0, 0, 0, 0};      // of hypothesis 0 of the last track call
 };
 
 template <class T> static int tr_alloc(ldso_tracker *H, T **p, size_t n) {
@@ -846,6 +851,7 @@ int ldso_tr_track_batch(ldso_tracker_t *H, int nhyp, double *T_inout /*nhyp*12*/
         if (flow) memcpy(flow + i * 3, hy[i].flow, 24);
         if (ok) ok[i] = hy[i].ok;
         if (iterations) iterations[i] = hy[i].iterations;
+        if (i == 0) memcpy(H->lastEvals, hy[i].evals, sizeof(H->lastEvals));
         if (LD_STAMP_ON_TR && i == 0) fprintf(stderr, "[tr stamps] evals %d: %.1f us in tr_eval of %.1f us kernel; per-eval us by level 0..4: %.1f %.1f %.1f %.1f %.1f\n", (int) hy[i].dbg[2], hy[i].dbg[0] / 100.0, hy[i].dbg[1] / 100.0, hy[i].dbg[3] / 100, hy[i].dbg[4] / 100, hy[i].dbg[5] / 100, hy[i].dbg[6] / 100, hy[i].dbg[7] / 100);
     }
     return LDSO_OK;
@@ -879,6 +885,14 @@ int ldso_tr_select_hypothesis(int nhyp, int coarsestLvl, const double *lastResid
     *best = win;
     if (tries_consumed) *tries_consumed = tries;
     if (achievedRes_out) for (int l = 0; l < 5; l++) achievedRes_out[l] = achieved[l];
+    return LDSO_OK;
+}
+
+// calcRes evaluations per level of the last ldso_tr_track / hypothesis 0 of the last batch, and the reference point counts pc_n:
+// the algorithmic bytes of that track are sum_l evals[l] * pc_n[l] * 64 (16 B point + 48 B taps per evaluation)
+int ldso_tr_last_track_evals(ldso_tracker_t *H, int evals[5], int pc_n[5]) {
+    REQ(H && evals && pc_n, "null argument");
+    for (int l = 0; l < 5; l++) { evals[l] = H->lastEvals[l]; pc_n[l] = (l < H->levels) ? H->P.lv[l].n : 0; }
     return LDSO_OK;
 }
 
