@@ -760,7 +760,10 @@ __global__ __launch_bounds__(NT) void k_solve(BaPtrs B, BaDims D, ResSet S, ldso
     // the threshold pass (histogram + staged candidates) runs before the solve and is over when solve_core starts: it aliases its LDS
     int *sHist = (int *) sm;                 // 256
     int *sI = sHist + 256;                   // 8 (+ TH_CAP floats of candidate staging behind it)
-    const unsigned fl = A.flags;
+    // two workgroups (ba_launch_solve): the statistics of the last linearizeAll (POST / THRESH / LOG) run next to the control part;
+    // they touch disjoint data (frameEnergyTH is only written by the statistics and only read by k_linearize)
+    unsigned fl = A.flags;
+    if (gridDim.x == 2) fl &= (blockIdx.x == 1) ? (SK_POST | SK_THRESH | SK_LOG) : ~(unsigned) (SK_POST | SK_THRESH | SK_LOG);
 
     if (fl & SK_COLLECT) {
         // FullSystem::optimize preamble: resetOOB on every non-linearised residual (FullSystem.cc:744-748)
@@ -980,7 +983,10 @@ hipError_t ba_launch_solve(const BaPtrs &B, const BaDims &D, const ResSet &S, co
     size_t stats = (256 + 8) * sizeof(int) + TH_CAP * sizeof(float), core = solve_lds_common(D);
     size_t lds = (core > stats ? core : stats) + (7 * (size_t) D.n + 64) * sizeof(double) + 64;
     if (lds > 48 * 1024) hipFuncSetAttribute((const void *) k_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-    hipLaunchKernelGGL(k_solve, dim3(1), dim3(NT), lds, st, B, D, S, St, A);
+    // the tail of optimize(): statistics and the re-anchor / adjoint / precalc part are independent -> two workgroups
+    const unsigned fstats = SK_POST | SK_THRESH | SK_LOG, fctl = SK_REANCHOR | SK_ADJ | SK_NONULLSPACE | SK_PRECALC;
+    const bool split = (A.flags & fstats) && (A.flags & fctl) && !(A.flags & ~(fstats | fctl));
+    hipLaunchKernelGGL(k_solve, dim3(split ? 2 : 1), dim3(NT), lds, st, B, D, S, St, A);
     return hipGetLastError();
 }
 
