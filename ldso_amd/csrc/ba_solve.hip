@@ -179,8 +179,10 @@ static __device__ __forceinline__ void aff_from_to(float expF, float expT, float
 }
 
 // setAdjointsF + nullspace basis U (n x 7, columns with dropped singular values zeroed)
-static __device__ void set_adjoints(const BaPtrs &B, const BaDims &D, const ldso_settings_t &St, double *sW /*LDS scratch >= 7*n + 64 doubles*/, bool withNullspace) {
+static __device__ void set_adjoints(const BaPtrs &B, const BaDims &D, const ldso_settings_t &St, double *sW /*LDS scratch >= 7*n + 64 doubles*/, bool withNullspace,
+                                    double *sBig /*LDS >= 37 * F * F doubles (the solve-core region, idle here)*/) {
     const int tid = threadIdx.x, F = D.F, n = D.n;
+    // (1) one lane per pair: Adj(T_t T_h^-1) at the evaluation points and the affine factor -> LDS
     for (int i = tid; i < F * F; i += NT) {
         int h = i % F, t = i / F;      // slot h + t*F
         const DevFrame &fh = B.frames[h], &ft = B.frames[t];
@@ -188,19 +190,27 @@ static __device__ void set_adjoints(const BaPtrs &B, const BaDims &D, const ldso
         ld::se3_inv(fh.evalPT, Ti);
         ld::se3_mul(ft.evalPT, Ti, T);
         ld::se3_adj(T, Adj);
-        double AH[64], AT[64];
-        for (int r = 0; r < 8; r++) for (int c = 0; c < 8; c++) { AH[r * 8 + c] = (r == c) ? 1.0 : 0.0; AT[r * 8 + c] = (r == c) ? 1.0 : 0.0; }
-        for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) AH[r * 8 + c] = -Adj[c * 6 + r];
         float a, b;
         aff_from_to(fh.ab_exposure, ft.ab_exposure, (float) (fh.state_zero[6] * 10.0), (float) (fh.state_zero[7] * 1000.0),
                     (float) (ft.state_zero[6] * 10.0), (float) (ft.state_zero[7] * 1000.0), a, b);
-        AT[6 * 8 + 6] = -(double) a; AH[6 * 8 + 6] = (double) a; AT[7 * 8 + 7] = -1; AH[7 * 8 + 7] = (double) a;
-        const double rs[8] = {0.5, 0.5, 0.5, 1.0, 1.0, 1.0, 10.0, 1000.0};
-        for (int r = 0; r < 8; r++) for (int c = 0; c < 8; c++) { AH[r * 8 + c] *= rs[r]; AT[r * 8 + c] *= rs[r]; }
-        for (int e = 0; e < 64; e++) {
-            B.adHost[(size_t) i * 64 + e] = AH[e]; B.adTarget[(size_t) i * 64 + e] = AT[e];
-            B.adHostF[(size_t) i * 64 + e] = (float) AH[e]; B.adTargetF[(size_t) i * 64 + e] = (float) AT[e];
-        }
+#pragma unroll
+        for (int e = 0; e < 36; e++) sBig[i * 37 + e] = Adj[e];
+        sBig[i * 37 + 36] = (double) a;
+    }
+    __syncthreads();
+    // (2) one thread per entry of the two 8x8 adjoints (EnergyFunctional.cc:431-489), coalesced stores of the four tables
+    for (int idx = tid; idx < F * F * 64; idx += NT) {
+        const int i = idx >> 6, e = idx & 63, r = e >> 3, c = e & 7;
+        const double *Adj = sBig + i * 37;
+        const double a = Adj[36];
+        double AH = (r == c) ? 1.0 : 0.0, AT = AH;
+        if (r < 6 && c < 6) AH = -Adj[c * 6 + r];
+        if (e == 6 * 8 + 6) { AT = -a; AH = a; }
+        if (e == 7 * 8 + 7) { AT = -1.0; AH = a; }
+        const double rs = (r < 3) ? 0.5 : (r < 6) ? 1.0 : (r == 6) ? 10.0 : 1000.0;
+        AH *= rs; AT *= rs;
+        B.adHost[idx] = AH; B.adTarget[idx] = AT;
+        B.adHostF[idx] = (float) AH; B.adTargetF[idx] = (float) AT;
     }
     if (!withNullspace) { __syncthreads(); return; }
     // ---- N = [6 pose | 1 scale] nullspaces, columns normalised (FullSystem.cc:1711-1760, EF.cc:691-694) -----
@@ -784,7 +794,7 @@ __global__ __launch_bounds__(NT) void k_solve(BaPtrs B, BaDims D, ResSet S, ldso
         }
         __syncthreads();
     }
-    if (fl & SK_ADJ) set_adjoints(B, D, St, sW, !(fl & SK_NONULLSPACE));
+    if (fl & SK_ADJ) set_adjoints(B, D, St, sW, !(fl & SK_NONULLSPACE), sm);
 
     if (fl & SK_EXPORT) {
         // multi-GPU: rank-local scalar sums ride in the all-reduce buffer
