@@ -642,7 +642,7 @@ static int enqueue_iteration(ldso_ba *H, int iteration, double lambda, int logId
     if (nReduce + 2 <= H->numCU) {
         // k_reduce (fp64 atomics straight into B.acc, no k_gather on this path) and the control step in ONE launch: the control
         // workgroup waits on a device counter for the reduce workgroups (k_reduce_solve, ba_solve.hip).  Only while every workgroup
-        // of the launch gets its own CU (F <= 11): the fused kernel's LDS footprint allows one workgroup per CU.
+        // of the launch gets its own CU (F <= 8; from F = 9 the Schur part alone has 180 workgroups): the fused kernel's LDS footprint allows one workgroup per CU.
         A.waitCtr = H->d_waitCtr;
         double lam = lambda;
         if (H->settings.solverMode & LDSO_SOLVER_USE_GN) lam = 0;
