@@ -41,6 +41,7 @@ static __device__ __forceinline__ void reduce_body(const BaPtrs &B, const BaDims
         const int h = pair / F, t = pair % F;        // pairC index [h*F + t]
         const float *part = which ? S.topL : S.topA;
         const int c0 = chunkStart.v[h], c1 = chunkStart.v[h + 1];
+        if (bid == 0 && c1 > c0) RSTAMP(22);
         // adjoints of this pair -> LDS (issued together with the partial loads: one latency level)
         __shared__ double sAH[64], sAT[64];
         __shared__ double sPart[PA_SLICES][LD_TOPN];
@@ -58,6 +59,7 @@ static __device__ __forceinline__ void reduce_body(const BaPtrs &B, const BaDims
                 for (int u = 0; u < PA_UNROLL; u++) a += (double) q[u];
             }
             sPart[slice][ent] = a;
+            if (bid == 0 && a != 12345.678) RSTAMP(23);      // (stamps builds) the comparison makes the stamp wait for the loaded partials
         }
         __syncthreads();
         if (bid == 0) RSTAMP(20);
