@@ -54,7 +54,13 @@ static __device__ __forceinline__ void reduce_body(const BaPtrs &B, const BaDims
             for (int cb = c0 + slice; cb < c1; cb += PA_SLICES * PA_UNROLL) {
                 float q[PA_UNROLL];
 #pragma unroll
-                for (int u = 0; u < PA_UNROLL; u++) { int c = cb + u * PA_SLICES; q[u] = (c < c1) ? part[((size_t) c * FS + t) * LD_TOPN + ent] : 0.0f; }
+                for (int u = 0; u < PA_UNROLL; u++) {
+                    // branch-free: clamp the chunk index, mask the value (a branch per load breaks the sequential instruction
+                    // prefetch right at the cold start of the kernel)
+                    const int c = cb + u * PA_SLICES, cc = max(min(c, c1 - 1), 0);
+                    const float v = part[((unsigned) cc * (unsigned) FS + (unsigned) t) * LD_TOPN + (unsigned) ent];
+                    q[u] = (c < c1) ? v : 0.0f;
+                }
 #pragma unroll
                 for (int u = 0; u < PA_UNROLL; u++) a += (double) q[u];
             }
