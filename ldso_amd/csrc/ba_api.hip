@@ -638,7 +638,7 @@ static int enqueue_iteration(ldso_ba *H, int iteration, double lambda, int logId
     A.flags = 0; A.iteration = iteration; A.lambda = lambda; A.hasL = H->hasL ? 1 : 0; A.hasPrior = H->hasPrior ? 1 : 0; A.GSP = H->GSP; A.logIdx = logIdx;
     A.reduceOut = nullptr; A.reduceIn = nullptr; A.itCheck = itCheck; A.waitCtr = nullptr; A.waitTarget = 0;
     const int nT = H->GSP / 16;
-    const int nReduce = H->D.F * H->D.F * (H->hasL ? 2 : 1) + 4 * nT * (nT + 1) / 2 + 1;      // grid of ba_launch_reduce in atomic mode
+    const int nReduce = H->D.F * H->D.F * (H->hasL ? 2 : 1) + LD_SCT_KS * nT * (nT + 1) / 2 + 1;      // grid of ba_launch_reduce in atomic mode
     if (nReduce + 2 <= H->numCU) {
         // k_reduce (fp64 atomics straight into B.acc, no k_gather on this path) and the control step in ONE launch: the control
         // workgroup waits on a device counter for the reduce workgroups (k_reduce_solve, ba_solve.hip).  Only while every workgroup

@@ -8,7 +8,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define SC_SLAB 128     // points staged per LDS slab (one slab per split at the C3 window: a single load level)
 #define PA_SLICES 2     // Part A: interleaved slices of a pair's chunk range (2 x 91 threads)
 #define PA_UNROLL 24    // Part A: partial loads in flight per thread
-#define SCT_KS 4         // atomic mode: K-splits per Schur tile
+#define SCT_KS LD_SCT_KS // atomic mode: K-splits per Schur tile
 #define SCT_SLAB 512    // atomic mode: points staged per LDS slab of a tile block
 #define SC_MAXT 12      // tiles per wave: GSP=144 (FS=16) -> 45 upper tiles / 4 waves
 
@@ -145,7 +145,7 @@ static __device__ __forceinline__ void reduce_body(const BaPtrs &B, const BaDims
         const int pa = P0 + ks * per, pb = min(P0 + Pn, pa + per);
         const int wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
         const int wcol = 8 * FS + 5;
-        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, acc2 = acc;
         for (int base = pa; base < pb; base += SCT_SLAB) {
             const int cnt = min(SCT_SLAB, pb - base), rows = (cnt + 3) & ~3;
             __syncthreads();
@@ -156,12 +156,15 @@ static __device__ __forceinline__ void reduce_body(const BaPtrs &B, const BaDims
 #pragma unroll
                 for (int u = 0; u < 16; u++) {
                     const int e = tid + u * 256, r = e >> 3, half = (e >> 2) & 1, c4 = e & 3;
-                    q[u] = make_float4(0.f, 0.f, 0.f, 0.f);
                     const int col = (half ? tj : ti) * 16 + c4 * 4;
-                    if (r < cnt && col < GS) q[u] = *(const float4 *) (S.G + (size_t) (base + r) * GS + col);
+                    // branch-free (clamped address, masked value): straight-line code keeps the instruction prefetch going at the
+                    // cold start of the kernel
+                    const float4 v = *(const float4 *) (S.G + (unsigned) ((base + min(r, cnt - 1)) * GS + min(col, GS - 4)));
+                    const bool in = r < cnt && col < GS;
+                    q[u] = make_float4(in ? v.x : 0.f, in ? v.y : 0.f, in ? v.z : 0.f, in ? v.w : 0.f);
                 }
 #pragma unroll
-                for (int u = 0; u < 2; u++) { const int r = tid + u * 256; wq[u] = (r < cnt) ? S.G[(size_t) (base + r) * GS + wcol] : 0.f; }
+                for (int u = 0; u < 2; u++) { const int r = tid + u * 256; const float v = S.G[(unsigned) ((base + min(r, cnt - 1)) * GS + wcol)]; wq[u] = (r < cnt) ? v : 0.f; }
 #pragma unroll
                 for (int u = 0; u < 16; u++) {
                     const int e = tid + u * 256, r = e >> 3, half = (e >> 2) & 1, c4 = e & 3;
@@ -171,17 +174,24 @@ static __device__ __forceinline__ void reduce_body(const BaPtrs &B, const BaDims
                 for (int u = 0; u < 2; u++) { const int r = tid + u * 256; if (r < rows) sWc[r] = wq[u]; }
             }
             __syncthreads();
+            if (bb == 0) RSTAMP(25);
+            // two independent accumulation chains per wave (an MFMA depends on the previous one through its accumulator)
 #pragma unroll 4
-            for (int k0 = wave * 4; k0 < rows; k0 += 16) {
-                const float a = sAc[(k0 + lk) * 16 + li] * sWc[k0 + lk];
-                const float b = sBc[(k0 + lk) * 16 + li];
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+            for (int k0 = wave * 4; k0 < rows; k0 += 32) {
+                const int k1 = k0 + 16;
+                const float a0 = sAc[(k0 + lk) * 16 + li] * sWc[k0 + lk], b0 = sBc[(k0 + lk) * 16 + li];
+                const bool in1 = k1 < rows;
+                const int k1c = in1 ? k1 : k0;
+                const float a1 = in1 ? sAc[(k1c + lk) * 16 + li] * sWc[k1c + lk] : 0.f, b1 = sBc[(k1c + lk) * 16 + li];
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc2, 0, 0, 0);
             }
         }
         __syncthreads();
+        if (bb == 0) RSTAMP(26);
         float *sR = sT_;      // [4 waves][256]
 #pragma unroll
-        for (int r = 0; r < 4; r++) sR[wave * 256 + (lk * 4 + r) * 16 + li] = acc[r];
+        for (int r = 0; r < 4; r++) sR[wave * 256 + (lk * 4 + r) * 16 + li] = acc[r] + acc2[r];
         __syncthreads();
         {
             const float v = ((sR[tid] + sR[256 + tid]) + sR[512 + tid]) + sR[768 + tid];
@@ -196,6 +206,7 @@ static __device__ __forceinline__ void reduce_body(const BaPtrs &B, const BaDims
                 else acc_add(&B.acc[(size_t) max(I, J) * n + min(I, J)], -(double) v * il);
             }
         }
+        if (bb == 0) RSTAMP(27);
         return;
     }
     if (atomicMode == 2) return;      // ranks > 0 of a sharded window: the prior / lambda terms are added once, by rank 0
@@ -229,6 +240,7 @@ static __device__ __forceinline__ void reduce_body(const BaPtrs &B, const BaDims
             const double dterm = prH + (hasPrior ? B.HM[(size_t) tid * n + tid] : 0.0);
             acc_add(&B.acc[(size_t) tid * n + tid], dterm * (l1 - 1.0));
         }
+        RSTAMP(28);
         return;
     }
 

@@ -543,12 +543,14 @@ _Pragma("unroll") \
         for (int i = tid; i < LSZ / 2; i += NT) st2(&sL[2 * i], 0.0, 0.0);
     }
     if constexpr (waitH) {
+        if (LD_STAMP_ON && tid == 0) B.energyLog[47] = (double) wall_clock64();
         if (tid == 0) {
             while (__hip_atomic_load(io.waitCtr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < io.waitTarget) __builtin_amdgcn_s_sleep(1);
             *io.waitCtr = 0;                         // every producer has incremented: re-arm for the next launch
         }
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (LD_STAMP_ON && tid == 0) B.energyLog[48] = (double) wall_clock64();
         LD_LOAD_H();
     }
     if (tid < M) sSc[tid] = fast_rsqrt(dS + 10.0);
@@ -907,14 +909,23 @@ __global__ __launch_bounds__(NT) void k_gn_solve(BaPtrs B, BaDims D, ResSet S, l
 __global__ __launch_bounds__(NT) void k_reduce_solve(BaPtrs B, BaDims D, ResSet S, ldso_settings_t St, SolveArgs A, ChunkStarts chunkStart, int atomicMode,
                                                      float calibPrior, double l1, double il) {
     if (blockIdx.x >= 2) {
+        const long long tStart_ = LD_STAMP_ON ? wall_clock64() : 0;
         if (LD_ITER_SKIPPED(B, A.itCheck)) return;
-        reduce_body(B, D, S, chunkStart, A.hasL, A.GSP, atomicMode, A.hasPrior, calibPrior, l1, il, -1, (int) blockIdx.x - 2);
+        // dispatch order = index order: the Schur tile workgroups (the longest) get the lowest indices, then the pair workgroups,
+        // the extras workgroup last; reduce_body numbers them pairs | tiles | extras
+        const int nT_ = A.GSP / 16, nTiles = SCT_KS * nT_ * (nT_ + 1) / 2, nPair = D.F * D.F * (A.hasL ? 2 : 1);
+        const int q = (int) blockIdx.x - 2;
+        const int bid = (q < nTiles) ? nPair + q : (q < nTiles + nPair) ? q - nTiles : q;
+        reduce_body(B, D, S, chunkStart, A.hasL, A.GSP, atomicMode, A.hasPrior, calibPrior, l1, il, -1, bid);
         // Everything a reduce workgroup hands to the control workgroup went through device-scope atomics (performed at the memory
         // side): waiting for their acknowledgement is enough - a release FENCE would also write the whole L2 back (the outputs of
         // the previous k_linearize are still dirty there), which costs more than the kernel boundary this fusion removes.
         __builtin_amdgcn_s_waitcnt(0);
         __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(A.waitCtr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) {
+            const int prev = __hip_atomic_fetch_add(A.waitCtr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (LD_STAMP_ON && prev == A.waitTarget - 1) { B.energyLog[29] = (double) wall_clock64(); B.energyLog[30] = (double) bid; B.energyLog[31] = (double) tStart_; }      // who was last, and when
+        }
         return;
     }
     gn_solve_body<true>(B, D, S, St, A, (int) blockIdx.x);
