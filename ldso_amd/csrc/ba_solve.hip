@@ -476,23 +476,26 @@ static __device__ void solve_core(const BaPtrs &B, const BaDims &D, const ResSet
     // GN: HFinal / bFinal (lower triangle) come straight from the accumulator k_reduce added into (B.acc)
     double v[NTILE], dI[NB], dJ[NB], dS = 0.0;
     if (GN) { HF = B.acc; bF = HF + (size_t) n * n; }
+// branch-free (clamped offsets, masked values): bFinal follows HFinal in memory, so row n of the augmented system is HF[n*n + j].
+// Straight-line code matters here: in the fused kernel these loads are the first instructions after the wait (cold instruction cache).
 #define LD_LOAD_H() do { \
+        const int nn_ = n * n + n - 1; \
 _Pragma("unroll") \
         for (int a = 0; a < NB; a++) { \
             const int i = ty + 16 * a, j = tx + 16 * a; \
-            dI[a] = (i < n) ? HF[(size_t) i * n + i] : 0.0; \
-            dJ[a] = (j < n) ? HF[(size_t) j * n + j] : 0.0; \
+            const double vi = HF[min(i * n + i, nn_)], vj = HF[min(j * n + j, nn_)]; \
+            dI[a] = (i < n) ? vi : 0.0; \
+            dJ[a] = (j < n) ? vj : 0.0; \
         } \
 _Pragma("unroll") \
         for (int a = 0; a < NB; a++) \
 _Pragma("unroll") \
             for (int b = 0; b <= a; b++) { \
                 const int i = ty + 16 * a, j = tx + 16 * b; \
-                double q = 0.0; \
-                if (j < n && (!GN || j <= i)) { if (i < n) q = HF[(size_t) i * n + j]; else if (i == n) q = bF[j]; } \
-                v[a * (a + 1) / 2 + b] = q; \
+                const double q = HF[min(i * n + j, nn_)]; \
+                v[a * (a + 1) / 2 + b] = (j < n && (!GN || j <= i) && i <= n) ? q : 0.0; \
             } \
-        dS = (tid < n) ? HF[(size_t) tid * n + tid] : 0.0; \
+        { const double q = HF[min(tid * n + tid, nn_)]; dS = (tid < n) ? q : 0.0; } \
     } while (0)
     // fused kernel (io.waitCtr): the system is still being accumulated by the reduce workgroups of this launch - everything that does
     // not depend on it is loaded and staged first, the system after the wait below
