@@ -183,10 +183,11 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f32 residual/Jacobian/accumulate, f64 stitch+solve",
+            "dtype": "f32",      # residuals, Jacobians and accumulators as the reference; the stitch and the solve are f64 (see config.arithmetic)
             "data": "synthetic",
             "config": {"workload": f"{args.config}: {F} KF x {P} pt x 8 px, {win.w}x{win.h}, R={R}, forced GN iterations, "
                                    + ("no prior" if args.no_prior else "synthetic rank-6 marginalisation prior H_M/b_M"),
+                       "arithmetic": "f32 residuals / Jacobians / accumulators as the reference, f64 stitch and solve",
                        "parallelism": "1 GPU" if world == 1 else f"points sharded over {world} GPUs, RCCL all-reduce of the stitched system per iteration"},
             "roofline": {"bound": "hbm", "kernel": "k_linearize", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(achieved / 8000.0, 5), "traffic": traffic, "traffic_source": traffic_src,
