@@ -64,7 +64,7 @@ int ldso_ba_set_settings(ldso_ba_t *h, const ldso_settings_t *s);
  * `slot` (0..max_frames-1).  Done once per new keyframe; slots are recycled on marginalisation. */
 int ldso_ba_set_image(ldso_ba_t *h, int slot, const float *dI_level0_host);
 /* Same, the pyramid level already being device-resident (zero-copy hand-over, not retained after the
- * next ldso_ba_set_image* on that slot). */
+ * next ldso_ba_set_image* on that slot).  A resident window that uses the slot follows the new buffer. */
 int ldso_ba_set_image_device(ldso_ba_t *h, int slot, const void *dI_level0_dev);
 /* The same slot from the RAW level-0 irradiance (w*h floats): FrameHessian::makeImages level 0 (FrameHessian.cc:44-113: copy +
  * central-difference gradients) runs on the device, 4 instead of 12 bytes per pixel cross PCIe.  ldso_ba_get_image: test fetch. */
@@ -77,9 +77,11 @@ int ldso_ba_get_image(ldso_ba_t *h, int slot, float *out_w_h_3);
 int ldso_ba_set_window(ldso_ba_t *h, int F, const int32_t *image_slot, int P, const ldso_point_t *points,
                        int R, const ldso_residual_t *residuals, const ldso_rawjac_t *linJ, const float *lin_res_toZeroF);
 /* Frame / calibration state (FrameHessian::setState..., CalibHessian::setValue) and the
- * marginalisation prior HM,bM ((8F+4)^2 row-major, (8F+4); NULL = zero).  Also performs
+ * marginalisation prior HM,bM ((8F+4)^2 row-major, (8F+4); NULL = zero).  ldso_ba_set_frames also performs
  * EnergyFunctional::setAdjointsF (EnergyFunctional.cc:431-489) and FullSystem::setPrecalcValues
- * (FullSystem.cc:1423-1431) on the device. */
+ * (FullSystem.cc:1423-1431) on the device.  Lifetime of the prior: ldso_ba_set_window resets it to zero (the
+ * dimension 8F+4 changes with the window); ldso_ba_set_frames leaves it alone, so the two calls below may
+ * come in either order after ldso_ba_set_window. */
 int ldso_ba_set_frames(ldso_ba_t *h, const ldso_frame_t *frames, const ldso_calib_t *calib);
 int ldso_ba_set_prior(ldso_ba_t *h, const double *HM, const double *bM);
 
@@ -160,6 +162,9 @@ int ldso_ba_get_system(ldso_ba_t *h, double *HA, double *bA, double *HL, double 
 /* RawResidualJacobian of selected residuals (for fixLinearizationF callers): recomputed on demand at the
  * current state, or - with ldso_ba_set_debug_dump(h,1) - the copy written by the last linearize pass. */
 int ldso_ba_set_debug_dump(ldso_ba_t *h, int enable);
+/* Debug / test: run the reduce and the control step of a fast-path iteration as two launches (k_reduce, k_gn_solve) even where
+ * the fused k_reduce_solve launch applies - the two schedules must agree (tests/test_ba_gpu.py::test_fused_launch_stress). */
+int ldso_ba_set_debug_split_launch(ldso_ba_t *h, int enable);
 int ldso_ba_get_jacobians(ldso_ba_t *h, const int32_t *res_ids, int n, ldso_rawjac_t *out);
 /* Pair precalc [h*F+t][27] as FrameFramePrecalc: KRKi 9, Kt 3, R0 9, t0 3, aff 2, b0 1. */
 int ldso_ba_get_precalc(ldso_ba_t *h, float *out);

@@ -274,6 +274,9 @@ class BA:
     def set_debug_dump(self, enable=True):
         _chk(self.L.ldso_ba_set_debug_dump(self.h, C.c_int(1 if enable else 0)))
 
+    def set_debug_split_launch(self, enable=True):
+        _chk(self.L.ldso_ba_set_debug_split_launch(self.h, C.c_int(1 if enable else 0)))
+
     def get_precalc(self):
         out = np.zeros((self.F, self.F, 27), np.float32)
         _chk(self.L.ldso_ba_get_precalc(self.h, _p(out)))

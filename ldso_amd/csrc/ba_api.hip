@@ -79,6 +79,8 @@ struct ldso_ba {
     double tsum[5] = {0, 0, 0, 0, 0};
     int tcnt[5] = {0, 0, 0, 0, 0};
     int lastIterations = 0;
+    bool noFusedLaunch = false;        // debug: k_reduce and k_gn_solve as two launches even where the fused k_reduce_solve applies
+    double neverStop = 1e300;          // source of the LD_SC_STOP reset (outlives the asynchronous copy)
 };
 
 extern "C" {
@@ -162,13 +164,23 @@ static int alloc_set(ldso_ba *H, ResSet &S) {
     return LDSO_OK;
 }
 
+static int create_body(ldso_ba *H, int device, int w, int h, int max_frames, int max_points);
+
 int ldso_ba_create(int device, int w, int h, int max_frames, int max_points, ldso_ba_t **out) {
     REQ(out && w > 8 && h > 8 && max_frames >= 2 && max_frames <= LD_MAXF && max_points > 0, "ldso_ba_create: bad arguments");
+    *out = nullptr;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { ldso_set_error("no HIP device visible"); return LDSO_E_NODEVICE; }
     REQ(device >= 0 && device < ndev, "ldso_ba_create: device index out of range");
     CHK(hipSetDevice(device));
     ldso_ba *H = new ldso_ba();
+    const int r = create_body(H, device, w, h, max_frames, max_points);
+    if (r != LDSO_OK) { const std::string keep = g_err; ldso_ba_destroy(H); g_err = keep; return r; }      // nothing of a half-built handle leaks
+    *out = H;
+    return LDSO_OK;
+}
+
+static int create_body(ldso_ba *H, int device, int w, int h, int max_frames, int max_points) {
     H->device = device; H->w = w; H->h = h; H->maxF = max_frames; H->maxP = max_points;
     H->FSmax = (max_frames + 7) / 8 * 8;
     H->maxChunks = max_points / 4 + max_frames + 4;
@@ -202,7 +214,6 @@ int ldso_ba_create(int device, int w, int h, int max_frames, int max_points, lds
     int r;
     if ((r = alloc_set(H, H->sets[0])) != LDSO_OK) return r;
     if ((r = alloc_set(H, H->sets[1])) != LDSO_OK) return r;
-    *out = H;
     return LDSO_OK;
 }
 
@@ -240,11 +251,16 @@ int ldso_ba_set_settings(ldso_ba_t *H, const ldso_settings_t *s) {
     return LDSO_OK;
 }
 
+// a slot changed its buffer: the resident window keeps reading the slot, so its image pointers follow
+static void rebind_slot(ldso_ba *H, int slot) {
+    for (int f = 0; f < H->D.F && f < (int) H->imageSlot.size(); f++) if (H->imageSlot[f] == slot) H->B.img[f] = H->imgSlots[slot];
+}
+
 int ldso_ba_set_image(ldso_ba_t *H, int slot, const float *src) {
     REQ(H && src && slot >= 0 && slot < H->maxF, "ldso_ba_set_image: bad arguments");
     CHK(hipSetDevice(H->device));
     size_t bytes = (size_t) H->w * H->h * 3 * sizeof(float);
-    if (!H->imgOwned[slot]) { void *p; CHK(hipMalloc(&p, bytes)); H->imgSlots[slot] = (float *) p; H->imgOwned[slot] = true; }
+    if (!H->imgOwned[slot]) { void *p; CHK(hipMalloc(&p, bytes)); H->imgSlots[slot] = (float *) p; H->imgOwned[slot] = true; rebind_slot(H, slot); }
     CHK(hipMemcpyAsync(H->imgSlots[slot], src, bytes, hipMemcpyHostToDevice, H->stream));
     CHK(hipStreamSynchronize(H->stream));
     return LDSO_OK;
@@ -257,7 +273,7 @@ int ldso_ba_set_image_raw(ldso_ba_t *H, int slot, const float *irradiance) {
     REQ(H && irradiance && slot >= 0 && slot < H->maxF, "ldso_ba_set_image_raw: bad arguments");
     CHK(hipSetDevice(H->device));
     const size_t n = (size_t) H->w * H->h;
-    if (!H->imgOwned[slot]) { void *q; CHK(hipMalloc(&q, n * 12)); H->imgSlots[slot] = (float *) q; H->imgOwned[slot] = true; }
+    if (!H->imgOwned[slot]) { void *q; CHK(hipMalloc(&q, n * 12)); H->imgSlots[slot] = (float *) q; H->imgOwned[slot] = true; rebind_slot(H, slot); }
     if (!H->d_color) CHK(hipMalloc(&H->d_color, n * sizeof(float)));
     CHK(hipMemcpyAsync(H->d_color, irradiance, n * sizeof(float), hipMemcpyHostToDevice, H->stream));
     float *lv[1] = {H->imgSlots[slot]};
@@ -277,8 +293,15 @@ int ldso_ba_get_image(ldso_ba_t *H, int slot, float *out) {
 
 int ldso_ba_set_image_device(ldso_ba_t *H, int slot, const void *dev) {
     REQ(H && dev && slot >= 0 && slot < H->maxF, "ldso_ba_set_image_device: bad arguments");
-    if (H->imgOwned[slot] && H->imgSlots[slot]) { hipFree(H->imgSlots[slot]); H->imgOwned[slot] = false; }
+    CHK(hipSetDevice(H->device));
+    float *old = H->imgSlots[slot];
+    if (H->imgOwned[slot] && old) {
+        CHK(hipStreamSynchronize(H->stream));      // a kernel of the resident window may still be reading the slot
+        hipFree(old); H->imgOwned[slot] = false;
+    }
     H->imgSlots[slot] = (float *) dev;
+    // the resident window keeps reading this slot: re-resolve its image pointers (no dangling B.img)
+    for (int f = 0; f < H->D.F && f < (int) H->imageSlot.size(); f++) if (H->imageSlot[f] == slot) H->B.img[f] = H->imgSlots[slot];
     return LDSO_OK;
 }
 
@@ -387,6 +410,10 @@ int ldso_ba_set_window(ldso_ba_t *H, int F, const int32_t *image_slot, int P, co
         CHK(hipMemsetAsync(S.G, 0, (size_t) P * D.GS * 4, H->stream));
     }
     CHK(hipMemsetAsync(B.pstep, 0, (size_t) P * 4, H->stream));
+    // a new window has a new dimension 8F+4: the marginalisation prior starts at zero (ldso_ba_set_prior follows when there is one)
+    CHK(hipMemsetAsync(B.HM, 0, (size_t) D.n * D.n * 8, H->stream));
+    CHK(hipMemsetAsync(B.bM, 0, (size_t) D.n * 8, H->stream));
+    H->hasPrior = false;
     CHK(hipMemsetAsync(B.scalars, 0, 16 * 8, H->stream));
     CHK(hipMemsetAsync(B.scPart, 0, (size_t) LD_SC_SPLITS * H->GSP * H->GSP * 4, H->stream));
     CHK(hipStreamSynchronize(H->stream));
@@ -428,10 +455,6 @@ int ldso_ba_set_frames(ldso_ba_t *H, const ldso_frame_t *fr, const ldso_calib_t 
     for (int i = 0; i < 4; i++) { dc.value[i] = calib->value[i]; dc.value_zero[i] = calib->value_zero[i]; dc.value_backup[i] = calib->value[i]; }
     CHK(hipMemcpyAsync(H->B.frames, df.data(), F * sizeof(DevFrame), hipMemcpyHostToDevice, H->stream));
     CHK(hipMemcpyAsync(H->B.calib, &dc, sizeof(dc), hipMemcpyHostToDevice, H->stream));
-    size_t n = H->D.n;
-    CHK(hipMemsetAsync(H->B.HM, 0, n * n * 8, H->stream));
-    CHK(hipMemsetAsync(H->B.bM, 0, n * 8, H->stream));
-    H->hasPrior = false;
     CHK(hipStreamSynchronize(H->stream));
     // first precalc needs valid calib floats for the adjoint-independent parts; adjoints, then precalc
     return launch_solve(H, H->sets[H->cur], SK_ADJ | SK_PRECALC);
@@ -590,8 +613,12 @@ int ldso_ba_backup_state(ldso_ba_t *H) {
     return LDSO_OK;
 }
 
+#define REQ_UNSHARDED(name) REQ(H->D.pBegin == 0 && H->D.pEnd == H->D.P, name ": not available on a sharded handle (ldso_ba_set_shard): " \
+                                    "use ldso_ba_gn_reduce_local / ldso_ba_gn_solve_reduced or ldso_ba_reduce_local / ldso_ba_solve_reduced around the all-reduce")
+
 int ldso_ba_solve_system(ldso_ba_t *H, int iteration, double lambda) {
     REQ(H && H->D.P > 0, "no window");
+    REQ_UNSHARDED("ldso_ba_solve_system");
     CHK(hipSetDevice(H->device));
     const ResSet &S = H->sets[H->cur];
     RUN(launch_reduce(H, S));
@@ -639,7 +666,7 @@ static int enqueue_iteration(ldso_ba *H, int iteration, double lambda, int logId
     A.reduceOut = nullptr; A.reduceIn = nullptr; A.itCheck = itCheck; A.waitCtr = nullptr; A.waitTarget = 0;
     const int nT = H->GSP / 16;
     const int nReduce = H->D.F * H->D.F * (H->hasL ? 2 : 1) + LD_SCT_KS * nT * (nT + 1) / 2 + 1;      // grid of ba_launch_reduce in atomic mode
-    if (nReduce + 2 <= H->numCU) {
+    if (nReduce + 2 <= H->numCU && !H->noFusedLaunch) {
         // k_reduce (fp64 atomics straight into B.acc, no k_gather on this path) and the control step in ONE launch: the control
         // workgroup waits on a device counter for the reduce workgroups (k_reduce_solve, ba_solve.hip).  Only while every workgroup
         // of the launch gets its own CU (F <= 8; from F = 9 the Schur part alone has 180 workgroups): the fused kernel's LDS footprint allows one workgroup per CU.
@@ -664,7 +691,9 @@ static int enqueue_iteration(ldso_ba *H, int iteration, double lambda, int logId
 
 int ldso_ba_enqueue_gn(ldso_ba_t *H, int first_iteration, int iters) {
     REQ(H && H->D.P > 0 && iters >= 0, "bad arguments");
+    REQ_UNSHARDED("ldso_ba_enqueue_gn");
     CHK(hipSetDevice(H->device));
+    CHK(hipMemsetAsync(H->d_waitCtr, 0, 4 * sizeof(int), H->stream));      // an aborted launch must not leave the producer counter armed
     for (int i = 0; i < iters; i++) RUN(enqueue_iteration(H, first_iteration + i, 1e-1, -1, true));
     return LDSO_OK;
 }
@@ -677,7 +706,9 @@ int ldso_ba_sync(ldso_ba_t *H) {
 
 int ldso_ba_optimize(ldso_ba_t *H, int mnumOptIts, int force_all, float *rmse_out, int *iters_out) {
     REQ(H && H->D.P > 0, "no window");
+    REQ_UNSHARDED("ldso_ba_optimize");
     CHK(hipSetDevice(H->device));
+    CHK(hipMemsetAsync(H->d_waitCtr, 0, 4 * sizeof(int), H->stream));      // an aborted launch must not leave the producer counter armed
     if (!H->settings.forceAcceptStep) { ldso_set_error("ldso_ba_optimize runs the forceAcceptStep=true schedule; drive LM rejection through the step-wise calls"); return LDSO_E_UNSUPPORTED; }
     const int F = H->D.F;
     if (F < 2) { if (rmse_out) *rmse_out = 0; return LDSO_OK; }
@@ -690,8 +721,7 @@ int ldso_ba_optimize(ldso_ba_t *H, int mnumOptIts, int force_all, float *rmse_ou
     int done = 0;
     double lambda = 1e-1;
     {   // no iteration has asked to stop yet
-        const double never = 1e300;
-        CHK(hipMemcpyAsync(H->B.scalars + LD_SC_STOP, &never, sizeof(double), hipMemcpyHostToDevice, H->stream));
+        CHK(hipMemcpyAsync(H->B.scalars + LD_SC_STOP, &H->neverStop, sizeof(double), hipMemcpyHostToDevice, H->stream));
     }
     for (int it = 0; it < mnumOptIts; it++) {
         // un-forced: the device decides (canbreak && it >= minOptIterations, FullSystem.cc:829); later iterations become no-ops
@@ -938,6 +968,12 @@ int ldso_ba_get_system(ldso_ba_t *H, double *HA, double *bA, double *HL, double 
         if (bs[m]) memcpy(bs[m], sys.data() + m * blk + n * n, n * 8);
     }
     if (x) memcpy(x, xx.data(), n * 8);
+    return LDSO_OK;
+}
+
+int ldso_ba_set_debug_split_launch(ldso_ba_t *H, int enable) {
+    REQ(H, "null handle");
+    H->noFusedLaunch = enable != 0;
     return LDSO_OK;
 }
 

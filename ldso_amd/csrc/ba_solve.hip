@@ -549,7 +549,7 @@ _Pragma("unroll") \
         if (LD_STAMP_ON && tid == 0) B.energyLog[47] = (double) wall_clock64();
         if (tid == 0) {
             while (__hip_atomic_load(io.waitCtr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < io.waitTarget) __builtin_amdgcn_s_sleep(1);
-            *io.waitCtr = 0;                         // every producer has incremented: re-arm for the next launch
+            __hip_atomic_store(io.waitCtr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // every producer has incremented: re-arm for the next launch
         }
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");

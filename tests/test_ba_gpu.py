@@ -337,6 +337,61 @@ def test_two_rank_fast_path_equals_single_gpu(small, with_prior):
     assert blockrel(np.tril(tot[:n * n].reshape(n, n)), np.tril(r[:n * n].reshape(n, n)), 4) < 5e-3
 
 
+@pytest.mark.parametrize("name", ["small", "C3"])
+def test_fused_launch_stress(name):
+    """the fused k_reduce_solve launch hands HFinal / bFinal from the reduce workgroups to the control workgroup inside
+    one launch (device counter).  Many optimize() calls, alternating forced / un-forced: every fused run must reproduce the split
+    schedule (k_reduce -> k_gn_solve as two launches, ordered by the kernel boundary) — a lost signal or a stale read shows up as
+    a different energy log.  The fp64 atomics only reorder sums, hence 1e-12 instead of bit equality."""
+    win = synth.add_synthetic_prior(copy.deepcopy(get_window(name)))
+    ref = {}
+    for force in (True, False):
+        g = binding.BA.from_window(win)
+        g.set_debug_split_launch(True)
+        rm, its = g.optimize(6, force_all=force)
+        ref[force] = (np.array(g.get_energy_log()), g.get_frames()["frames"]["state"].copy(), its)
+    g = binding.BA.from_window(win)
+    for r in range(40):
+        force = (r % 2 == 0)
+        g.load_window(win)
+        rm, its = g.optimize(6, force_all=force)
+        el, st = np.array(g.get_energy_log()), g.get_frames()["frames"]["state"]
+        assert its == ref[force][2], (r, its)
+        assert rel(el, ref[force][0]) < 1e-12, (r, el, ref[force][0])
+        assert np.abs(st - ref[force][1]).max() < 1e-9, r
+
+
+def test_sharded_handle_rejects_single_gpu_entry_points(small):
+    """a handle that owns only a shard of the points must not run the unsharded solve silently."""
+    g = binding.BA.from_window(small)
+    g.set_shard(0, small.P // 2)
+    g.collect_active(); g.linearize_all(False); g.apply_res()
+    for call in (lambda: g.optimize(2, force_all=True), lambda: g.enqueue_gn(0, 1), lambda: g.solve_system(0)):
+        with pytest.raises(binding.LdsoError) as e:
+            call()
+        assert e.value.code == -1 or "sharded" in str(e.value)
+    g.set_shard(0, small.P)
+    g.solve_system(0)
+
+
+def test_prior_survives_set_frames(small):
+    """ldso_ba_set_prior before ldso_ba_set_frames must not lose the prior (set_window resets it, set_frames does not)."""
+    w1 = synth.add_synthetic_prior(copy.deepcopy(small))
+    a = binding.BA.from_window(w1)
+    b = binding.BA(w1.w, w1.h, w1.F, w1.P)
+    b.set_settings(w1.settings)
+    for f in range(w1.F):
+        b.set_image(f, w1.images[f][0])
+    b.set_window(np.arange(w1.F), w1.points, w1.residuals, w1.lin_J, w1.lin_res_toZeroF)
+    b.set_prior(w1.HM, w1.bM)
+    b.set_frames(w1.frames, w1.calib)
+    ra, _ = a.optimize(3, force_all=True); rb, _ = b.optimize(3, force_all=True)
+    assert ra == rb and rel(b.get_energy_log(), a.get_energy_log()) < 1e-12
+    c = binding.BA.from_window(small)
+    rc, _ = c.optimize(3, force_all=True)
+    assert rc != ra                                                # the prior matters on this window
+
+
 def test_edge_points_without_residuals_and_oob(tiny):
     """points with no residuals, OOB residuals (point projected outside the image) and an all-OUTLIER point."""
     w2 = copy.deepcopy(tiny)
