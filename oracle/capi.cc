@@ -138,6 +138,16 @@ void orc_destroy(void *h) { delete (OrcWindow *) h; }
 void orc_set_force_all_iterations(void *h, int v) { ((OrcWindow *) h)->fs.forceAllIterations = v != 0; }
 
 void orc_collect_active(void *h) { ((OrcWindow *) h)->fs.collectActiveResiduals(); }
+// the activeResiduals list of collectActiveResiduals WITHOUT its resetOOB: continue from a transplanted mid-optimisation state
+void orc_collect_active_keep_states(void *h) {
+    FullSystem &fs = ((OrcWindow *) h)->fs;
+    fs.activeResiduals.clear();
+    for (FrameHessian *fr : fs.frames)
+        for (PointHessian *ph : fr->features)
+            if (ph->status == PS_ACTIVE && !ph->alreadyRemoved)
+                for (auto &r : ph->residuals)
+                    if (!r->isLinearized) fs.activeResiduals.push_back(r);
+}
 
 double orc_linearize_all(void *h, int fix) { return ((OrcWindow *) h)->fs.linearizeAll(fix != 0)[0]; }
 

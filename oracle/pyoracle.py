@@ -93,8 +93,11 @@ class OracleWindow:
             pass
 
     # --- stage calls -----------------------------------------------------------------------------
-    def collect_active(self):
-        self.L.orc_collect_active(self.h)
+    def collect_active(self, reset_oob=True):
+        if reset_oob:
+            self.L.orc_collect_active(self.h)
+        else:
+            self.L.orc_collect_active_keep_states(self.h)
 
     def linearize_all(self, fix=False) -> float:
         return float(self.L.orc_linearize_all(self.h, C.c_int(1 if fix else 0)))
