@@ -310,20 +310,13 @@ int ldso_ba_set_image_device(ldso_ba_t *H, int slot, const void *dev) {
 static int build_chunks(ldso_ba *H) {
     // host-major chunks over the local shard [pBegin,pEnd)
     BaDims &D = H->D;
-    // k_linearize shapes (ba_linearize.hip): a wavefront holds PPW = 64 / FS points.  Small windows: one point group per
-    // one-wave workgroup (every residual of the window starts at once: the latency-optimal shape, up to 2 workgroups per CU).
-    // Large windows: four-wave workgroups that walk several point groups, at most one workgroup per CU (fewer, fatter partials).
-    const int PPW = 64 / D.FS;
-    auto count = [&](int CH) {
+    // smallest multiple of 4 points per chunk that keeps the grid within one wave of workgroups (one per CU)
+    int CH = 4;
+    for (;; CH += 4) {
         int cnt = 0, run = 0, prev = -1;
         for (int q = D.pBegin; q < D.pEnd; q++) { int hq = H->h_phost[q]; if (hq != prev) { cnt += (run + CH - 1) / CH; run = 0; prev = hq; } run++; }
-        return cnt + (run + CH - 1) / CH;
-    };
-    int CH = PPW;
-    D.lnw = 1;
-    if (count(CH) > 2 * H->numCU) {
-        D.lnw = 4;
-        for (CH = 4 * PPW; count(CH) > H->numCU && CH < 4096; CH += 4 * PPW) {}
+        cnt += (run + CH - 1) / CH;
+        if (cnt <= H->numCU || CH >= 1024) break;
     }
     std::vector<int32_t> p0, cn, ch, cs(D.F + 1, 0);
     int p = D.pBegin;

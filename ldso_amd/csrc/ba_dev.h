@@ -15,6 +15,8 @@
 
 #define LD_MAXF LDSO_MAX_FRAMES
 #define LD_TOPN 91            // unique entries of the 13x13 symmetric relative Hessian block
+#define LD_WAVES 8            // waves per linearize block
+#define LD_PREFETCH 0         // 1: load the point record one point ahead (pays when a SIMD holds a single wave)
 #define LD_GEXTRA 8           // per-point extras appended to a G row: Hcd[4], bdSum, HdiF, pad, pad
 
 struct DevPair {
@@ -70,7 +72,6 @@ struct ResSet {
 
 struct BaDims {
     int32_t F, FS, P, R, n, GS, w, h, nChunks, nL, nsg;
-    int32_t lnw;               // waves per k_linearize workgroup (1: one point group per workgroup; 4: several groups per wave)
     int32_t pBegin, pEnd;      // shard of points owned by this rank
     float wM3G, hM3G;
 };
