@@ -118,7 +118,8 @@ int ldso_frame_set_evalPT(ldso_frame_t *f, const double worldToCam[12], const do
 int ldso_frame_set_prior(ldso_frame_t *f, const ldso_settings_t *s) {
     if (!f || !s) return LDSO_E_INVALID;
     for (int i = 0; i < 8; i++) f->prior[i] = 0;
-    const double initialRotPrior = 1e11, initialTransPrior = 1e10, initialAffBPrior = 1e14, initialAffAPrior = 1e14;   // Setting.cc:18-21
+    // Setting.cc:18-21: `float` globals in the reference - the double prior vector receives the float values (1e11f = 99999997952, 1e14f = 100000000376832)
+    const double initialRotPrior = (double) 1e11f, initialTransPrior = (double) 1e10f, initialAffBPrior = (double) 1e14f, initialAffAPrior = (double) 1e14f;
     if (f->frameID == 0) {
         for (int i = 0; i < 3; i++) { f->prior[i] = initialTransPrior; f->prior[3 + i] = initialRotPrior; }
         if (s->solverMode & LDSO_SOLVER_REMOVE_POSEPRIOR) for (int i = 0; i < 6; i++) f->prior[i] = 0;

@@ -330,16 +330,19 @@ class Window:
 
 
 def frame_prior(frame_id, s):
-    """FrameHessian::getPrior (FrameHessian.h:129-154) with default priors (Setting.cc:18-21)."""
+    """FrameHessian::getPrior (FrameHessian.h:129-154) with default priors (Setting.cc:18-21).  The reference's settings are
+    `float` globals, so the values that reach the double prior vector are float32(1e10), float32(1e11) = 99999997952 and
+    float32(1e14) = 100000000376832 (pinned against the reference-compiled getPrior, tests/test_ref_pin.py)."""
+    f32 = lambda v: float(np.float32(v))
     p = np.zeros(8)
     if frame_id == 0:
-        p[0:3] = 1e10
-        p[3:6] = 1e11
-        p[6] = 1e14
-        p[7] = 1e14
+        p[0:3] = f32(1e10)
+        p[3:6] = f32(1e11)
+        p[6] = f32(1e14)
+        p[7] = f32(1e14)
     else:
-        p[6] = 1e14 if s["affineOptModeA"] < 0 else float(s["affineOptModeA"])
-        p[7] = 1e14 if s["affineOptModeB"] < 0 else float(s["affineOptModeB"])
+        p[6] = f32(1e14) if s["affineOptModeA"] < 0 else float(s["affineOptModeA"])
+        p[7] = f32(1e14) if s["affineOptModeB"] < 0 else float(s["affineOptModeB"])
     return p
 
 

@@ -1,4 +1,4 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY (see linalg.h / backend.h headers).  PARITY UNPINNED.
+// ORACLE — TEST INFRASTRUCTURE ONLY (see linalg.h / backend.h headers).  Pinned to reference-compiled code by tests/test_ref_pin.py (see linalg.h).
 #include "backend.h"
 
 namespace orc {

@@ -1,4 +1,4 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY (see linalg.h header).  PARITY UNPINNED (no reference tests).
+// ORACLE — TEST INFRASTRUCTURE ONLY (see linalg.h header).  Pinned to reference-compiled code by tests/test_ref_pin.py (see linalg.h).
 //
 // backend.h — CPU restatement of the windowed photometric bundle-adjustment hot path of LDSO:
 //   src/internal/Residuals.cc:13-242                      PointFrameResidual::linearize / fixLinearizationF

@@ -1,4 +1,4 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY (see linalg.h / backend.h headers).  PARITY UNPINNED.
+// ORACLE — TEST INFRASTRUCTURE ONLY (see linalg.h / backend.h headers).  Pinned to reference-compiled code by tests/test_ref_pin.py.
 // capi.cc — C entry points so that tests/ (ctypes) can drive the CPU restatement with the same
 // flattened window images (include/ldso_window.h) that the HIP library consumes.
 #include "backend.h"

@@ -1,8 +1,11 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY.  CPU restatement of the reference (tum-vision/LDSO) hot path.
 // Nothing under oracle/ may be imported, linked or executed by the product path (ldso_amd/);
 // only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, as the checker.
-// PARITY UNPINNED: the reference ships no tests/golden vectors and cannot be built here
-// (Eigen3/OpenCV/glog/Pangolin absent), see DESIGN.md.
+// PARITY PINNED for the BA hot path and makeImages: the reference ships no tests / golden vectors and its own build needs
+// Eigen3 / OpenCV / glog / Pangolin (absent), but its hot-path translation units compile unmodified against the header shim
+// oracle/ref_shim (oracle/Makefile `ref` -> oracle/_ref/libldso_ref.so); tests/test_ref_pin.py holds this restatement to that
+// library BIT FOR BIT and tests/golden/ref_*.npz are its outputs.  Not pinned: what the shim itself replaces (Eigen's product /
+// reduction order, LDLT / SVD / inverse, Sophus) and the restated FullSystem loops; see DESIGN.md section 3.
 //
 // linalg.h — the small dense linear algebra the reference gets from Eigen3 (system dependency, version
 // unpinned; cmake/FindEigen3.cmake:18-25).  Restated from Eigen's published algorithms:

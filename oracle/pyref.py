@@ -1,0 +1,179 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.  ctypes wrapper of oracle/_ref/libldso_ref.so: the reference's own hot-path translation
+units compiled unmodified from /root/reference against the header shim oracle/ref_shim (see oracle/ref_driver.cc).  Built by
+`make -C oracle ref` where /root/reference exists (this container); the .so then travels to the GPU box with the repo snapshot.
+Only tests/ use it: it pins the oracle (oracle/*.cc, the CPU restatement) to reference-compiled code."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from ldso_amd import synth
+from .pyoracle import _p, _img_ptrs
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def lib_path() -> str:
+    return os.path.join(_HERE, "_ref", "libldso_ref.so")
+
+
+def available() -> bool:
+    """True when the reference-compiled library exists or can be built here (needs /root/reference)."""
+    if os.path.exists(lib_path()):
+        return True
+    if not os.path.isdir("/root/reference"):
+        return False
+    try:
+        subprocess.run(["make", "-C", _HERE, "ref"], check=True, capture_output=True)
+    except Exception:
+        return False
+    return os.path.exists(lib_path())
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not available():
+            raise RuntimeError("oracle/_ref/libldso_ref.so is missing and /root/reference is not here to build it")
+        L = C.CDLL(lib_path())
+        L.ref_create.restype = C.c_void_p
+        L.ref_linearize_all.restype = C.c_double
+        _LIB = L
+    return _LIB
+
+
+class RefWindow:
+    """The reference's EnergyFunctional / PointFrameResidual / accumulators on one flattened window (same inputs as OracleWindow)."""
+
+    def __init__(self, win: synth.Window):
+        self.L = lib()
+        self.win = win
+        self.F, self.P, self.R = win.F, win.P, win.R
+        imgs, self._keep = _img_ptrs(win.images[: win.F], win.levels)
+        self.frames = np.ascontiguousarray(win.frames)
+        self.points = np.ascontiguousarray(win.points)
+        self.residuals = np.ascontiguousarray(win.residuals)
+        linJ = np.ascontiguousarray(win.lin_J) if win.lin_J is not None else None
+        rtz = np.ascontiguousarray(win.lin_res_toZeroF, dtype=np.float32) if win.lin_res_toZeroF is not None else None
+        self._keep += [linJ, rtz]
+        HM = np.ascontiguousarray(win.HM, dtype=np.float64)
+        bM = np.ascontiguousarray(win.bM, dtype=np.float64)
+        s = np.ascontiguousarray(win.settings)
+        c = np.ascontiguousarray(win.calib)
+        self.h = C.c_void_p(self.L.ref_create(
+            C.c_int(win.w), C.c_int(win.h), C.c_int(win.levels), _p(s), _p(c), C.c_int(self.F), _p(self.frames), imgs,
+            C.c_int(self.P), _p(self.points), C.c_int(self.R), _p(self.residuals), _p(linJ), _p(rtz), _p(HM), _p(bM), C.c_int(0)))
+
+    def close(self):
+        if self.h:
+            self.L.ref_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def collect_active(self, reset_oob=True):
+        self.L.ref_collect_active(self.h, C.c_int(1 if reset_oob else 0))
+
+    def linearize_all(self) -> float:
+        return float(self.L.ref_linearize_all(self.h))
+
+    def apply_res(self):
+        self.L.ref_apply_res(self.h)
+
+    def set_frame_energy_th(self, f, th):
+        self.L.ref_set_frame_energy_th(self.h, C.c_int(f), C.c_float(th))
+
+    def solve_system(self, iteration: int, lam: float = 1e-1):
+        self.L.ref_solve_system(self.h, C.c_int(iteration), C.c_double(lam))
+
+    def num_frames(self):
+        return int(self.L.ref_num_frames(self.h))
+
+    def counts(self):
+        a, l, m = C.c_int(), C.c_int(), C.c_int()
+        self.L.ref_counts(self.h, C.byref(a), C.byref(l), C.byref(m))
+        return a.value, l.value, m.value
+
+    def get_residuals(self, with_J=True):
+        out = np.zeros(self.R, synth.RES_OUT_DTYPE)
+        J = np.zeros(self.R, synth.RAWJAC_DTYPE) if with_J else None
+        st = np.zeros(self.R, np.int32); act = np.zeros(self.R, np.int32)
+        rtz = np.zeros((self.R, 8), np.float32); lin = np.zeros(self.R, np.int32); alive = np.zeros(self.R, np.int32)
+        self.L.ref_get_residuals(self.h, _p(out), _p(J), _p(st), _p(act), _p(rtz), _p(lin), _p(alive))
+        return dict(out=out, J=J, state_state=st, is_active=act, res_toZeroF=rtz, is_linearized=lin, alive=alive)
+
+    def get_points(self):
+        out = np.zeros(self.P, synth.POINT_OUT_DTYPE)
+        status = np.zeros(self.P, np.int32)
+        self.L.ref_get_points(self.h, _p(out), _p(status))
+        return out, status
+
+    def get_frames(self):
+        F = self.num_frames()
+        fr = np.zeros(F, synth.FRAME_DTYPE); step = np.zeros((F, 10)); cv = np.zeros(4); cs = np.zeros(4); pre = np.zeros((F, 12))
+        self.L.ref_get_frames(self.h, _p(fr), _p(step), _p(cv), _p(cs), _p(pre))
+        return dict(frames=fr, step=step, calib_value=cv, calib_step=cs, pre_worldToCam=pre)
+
+    def get_precalc(self):
+        F = self.num_frames()
+        out = np.zeros((F, F, 27), np.float32)
+        self.L.ref_get_precalc(self.h, _p(out))
+        return out
+
+    def get_adjoints(self):
+        F = self.num_frames()
+        ah = np.zeros((F * F, 8, 8)); at = np.zeros((F * F, 8, 8)); d = np.zeros((F * F, 8), np.float32)
+        self.L.ref_get_adjoints(self.h, _p(ah), _p(at), _p(d))
+        return ah, at, d
+
+    def get_accumulators(self):
+        F = self.num_frames()
+        d = dict(topA=np.zeros((F * F, 13, 13), np.float32), topL=np.zeros((F * F, 13, 13), np.float32),
+                 accD=np.zeros((F * F * F, 8, 8), np.float32), accE=np.zeros((F * F, 8, 4), np.float32),
+                 accEB=np.zeros((F * F, 8), np.float32), accHcc=np.zeros((4, 4), np.float32), accbc=np.zeros(4, np.float32))
+        self.L.ref_get_accumulators(self.h, _p(d["topA"]), _p(d["topL"]), _p(d["accD"]), _p(d["accE"]), _p(d["accEB"]), _p(d["accHcc"]), _p(d["accbc"]))
+        return d
+
+    def get_system(self):
+        n = 8 * self.num_frames() + 4
+        d = dict(lastHS=np.zeros((n, n)), lastbS=np.zeros(n), x=np.zeros(n))
+        self.L.ref_get_system(self.h, _p(d["lastHS"]), _p(d["lastbS"]), _p(d["x"]))
+        return d
+
+    def get_prior(self):
+        n = 8 * self.num_frames() + 4
+        HM = np.zeros((n, n)); bM = np.zeros(n)
+        self.L.ref_get_prior(self.h, _p(HM), _p(bM))
+        return HM, bM
+
+    def flag_points(self, status):
+        st = np.ascontiguousarray(status, np.int32)
+        self.L.ref_flag_points(self.h, _p(st))
+
+    def drop_points(self):
+        self.L.ref_drop_points(self.h)
+
+    def marginalize_points(self):
+        self.L.ref_marginalize_points(self.h)
+
+    def marginalize_frame(self, idx):
+        self.L.ref_marginalize_frame(self.h, C.c_int(idx))
+
+
+def make_images(color, levels):
+    """FrameHessian::makeImages of the reference on a raw irradiance image: list of [h_l, w_l, 3] float32 levels."""
+    L = lib()
+    h, w = color.shape
+    col = np.ascontiguousarray(color, np.float32)
+    outs = [np.zeros(((h >> l), (w >> l), 3), np.float32) for l in range(levels)]
+    arr = (C.c_void_p * levels)(*[o.ctypes.data for o in outs])
+    L.ref_make_images(C.c_int(w), C.c_int(h), C.c_int(levels), _p(col), arr)
+    return outs

@@ -1,0 +1,513 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.  Driver of the REFERENCE-COMPILED library oracle/_ref/libldso_ref.so.
+//
+// The hot-path translation units of /root/reference are compiled where they lie, unmodified (oracle/Makefile, target _ref):
+//   src/internal/Residuals.cc, src/internal/OptimizationBackend/{AccumulatedTopHessian,AccumulatedSCHessian,EnergyFunctional}.cc,
+//   include/internal/OptimizationBackend/MatrixAccumulators.h, src/internal/{FrameFramePrecalc,FrameHessian,GlobalCalib,PointHessian,
+//   ImmaturePoint}.cc, src/frontend/{CoarseTracker,CoarseInitializer,PixelSelector2}.cc, src/{Setting,Camera}.cc
+// against the header shim oracle/ref_shim (Eigen / Sophus / glog / DBoW3 / OpenCV stand-ins, see ref_shim/Eigen/Core for what
+// that replaces).  This file builds the reference's own object graph (Frame / FrameHessian / Feature / Point / PointHessian /
+// PointFrameResidual / CalibHessian / EnergyFunctional) from the flattened window of include/ldso_window.h and exposes the
+// reference's functions one by one through the same C entry points as oracle/capi.cc (prefix ref_ instead of orc_), so that
+// tests/test_ref_pin.py can run the oracle's restatement and the reference side by side on identical inputs.
+//
+// What is NOT compiled from the reference: FullSystem.cc (needs the whole front end, OpenCV, the viewer).  The few lines of it
+// this driver needs are restated below, each citing its source: setPrecalcValues (:1423-1431), getNullspaces (:1711-1760),
+// the residual loop of linearizeAll_Reductor (:1442-1470, without setNewFrameEnergyTH), the re-linearise / fix loop of
+// flagPointsForRemoval (:1241-1250), the residual drop of marginalizeFrame (:602-640); and the out-of-line constructors of
+// Frame / Point (src/Frame.cc:15-17, src/Point.cc:25-27; those files carry the map I/O and do not compile without OpenCV).
+#include <vector>
+#include <memory>
+#include <map>
+#include <set>
+#include <mutex>
+#include <thread>
+#include <functional>
+#include <condition_variable>
+#include <cstring>
+#include <cstdio>
+#include <iostream>
+#include <fstream>
+#include <Eigen/Core>
+#define private public
+#define protected public
+#include "Frame.h"
+#include "Feature.h"
+#include "Point.h"
+#include "Camera.h"
+#include "Settings.h"
+#include "internal/FrameHessian.h"
+#include "internal/PointHessian.h"
+#include "internal/CalibHessian.h"
+#include "internal/Residuals.h"
+#include "internal/GlobalCalib.h"
+#include "internal/GlobalFuncs.h"
+#include "internal/ImmaturePoint.h"
+#include "internal/OptimizationBackend/EnergyFunctional.h"
+#include "frontend/CoarseTracker.h"
+#undef private
+#undef protected
+#include "../include/ldso_window.h"
+
+using namespace ldso;
+using namespace ldso::internal;
+
+// ---- out-of-line members of the reference's data classes that live in translation units we cannot compile ----------------
+namespace ldso {
+unsigned long Frame::nextId = 0;
+Frame::Frame() { id = nextId++; }                        // src/Frame.cc:15-17
+Frame::Frame(double timestamp) { id = nextId++; this->timeStamp = timestamp; }
+void Frame::CreateFH(shared_ptr<Frame> frame) { frameHessian = shared_ptr<internal::FrameHessian>(new internal::FrameHessian(frame)); }      // src/Frame.cc:37-39
+unsigned long Point::mNextId = 0;
+Point::Point() { id = mNextId++; }                       // src/Point.cc:25-27
+void Point::ReleasePH() { if (mpPH) { mpPH->point = nullptr; mpPH = nullptr; } }
+void Feature::ReleaseImmature() { if (ip) { ip->feature = nullptr; ip = nullptr; } }
+void Feature::ReleaseMapPoint() { if (point) point->ReleasePH(); }
+}  // namespace ldso
+
+namespace {
+
+struct RefWindow {
+    shared_ptr<Camera> cam;
+    shared_ptr<CalibHessian> Hcalib;
+    shared_ptr<EnergyFunctional> ef;
+    IndexThreadReduce<Vec10> red;
+    std::vector<shared_ptr<Frame>> frames;
+    std::vector<shared_ptr<PointHessian>> pointByFlat;
+    std::vector<shared_ptr<PointFrameResidual>> resByFlat;
+    std::vector<shared_ptr<PointFrameResidual>> activeResiduals;
+    std::vector<std::vector<float>> imageStore;
+    int levels = 0;
+};
+
+static void apply_settings(const ldso_settings_t *s) {
+    setting_huberTH = s->huberTH; setting_outlierTHSumComponent = s->outlierTHSumComponent;
+    setting_affineOptModeA = s->affineOptModeA; setting_affineOptModeB = s->affineOptModeB;
+    setting_frameEnergyTHN = s->frameEnergyTHN; setting_frameEnergyTHFacMedian = s->frameEnergyTHFacMedian;
+    setting_frameEnergyTHConstWeight = s->frameEnergyTHConstWeight; setting_overallEnergyTHWeight = s->overallEnergyTHWeight;
+    setting_initialCalibHessian = s->initialCalibHessian; setting_margWeightFac = s->margWeightFac;
+    setting_idepthFixPriorMargFac = s->idepthFixPriorMargFac; setting_thOptIterations = s->thOptIterations;
+    setting_coarseCutoffTH = s->coarseCutoffTH; setting_minOptIterations = s->minOptIterations;
+    setting_solverMode = s->solverMode; setting_forceAceptStep = s->forceAcceptStep != 0; setting_solverModeDelta = s->solverModeDelta;
+    multiThreading = false;
+}
+
+static SE3 se3_from34(const double *m) {
+    Mat33 R; Vec3 t;
+    for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) R(i, j) = m[i * 4 + j]; t[i] = m[i * 4 + 3]; }
+    return SE3(R, t);
+}
+
+// FullSystem::setPrecalcValues (FullSystem.cc:1423-1431)
+static void set_precalc(RefWindow *W) {
+    for (auto &fr : W->frames) {
+        fr->frameHessian->targetPrecalc.resize(W->frames.size());
+        for (size_t i = 0; i < W->frames.size(); i++)
+            fr->frameHessian->targetPrecalc[i].Set(fr->frameHessian, W->frames[i]->frameHessian, W->Hcalib);
+    }
+    W->ef->setDeltaF(W->Hcalib);
+}
+
+// FullSystem::getNullspaces (FullSystem.cc:1711-1760)
+static std::vector<VecX> get_nullspaces(RefWindow *W, std::vector<VecX> &np, std::vector<VecX> &ns, std::vector<VecX> &na, std::vector<VecX> &nb) {
+    np.clear(); ns.clear(); na.clear(); nb.clear();
+    int n = CPARS + W->frames.size() * 8;
+    std::vector<VecX> pre;
+    for (int i = 0; i < 6; i++) {
+        VecX v(n); v.setZero();
+        for (auto fr : W->frames) {
+            auto fh = fr->frameHessian;
+            v.segment<6>(CPARS + fh->idx * 8) = fh->nullspaces_pose.col(i);
+            v.segment<3>(CPARS + fh->idx * 8) *= SCALE_XI_TRANS_INVERSE;
+            v.segment<3>(CPARS + fh->idx * 8 + 3) *= SCALE_XI_ROT_INVERSE;
+        }
+        pre.push_back(v); np.push_back(v);
+    }
+    for (int i = 0; i < 2; i++) {
+        VecX v(n); v.setZero();
+        for (auto fr : W->frames) {
+            auto fh = fr->frameHessian;
+            v.segment<2>(CPARS + fh->idx * 8 + 6) = fh->nullspaces_affine.col(i).head<2>();
+            v[CPARS + fh->idx * 8 + 6] *= SCALE_A_INVERSE;
+            v[CPARS + fh->idx * 8 + 7] *= SCALE_B_INVERSE;
+        }
+        pre.push_back(v);
+        if (i == 0) na.push_back(v);
+        if (i == 1) nb.push_back(v);
+    }
+    VecX v(n); v.setZero();
+    for (auto fr : W->frames) {
+        auto fh = fr->frameHessian;
+        v.segment<6>(CPARS + fh->idx * 8) = fh->nullspaces_scale;
+        v.segment<3>(CPARS + fh->idx * 8) *= SCALE_XI_TRANS_INVERSE;
+        v.segment<3>(CPARS + fh->idx * 8 + 3) *= SCALE_XI_ROT_INVERSE;
+    }
+    pre.push_back(v); ns.push_back(v);
+    return pre;
+}
+
+static void put_jac(const RawResidualJacobian &J, ldso_rawjac_t &j) {
+    for (int k = 0; k < 8; k++) { j.resF[k] = J.resF[k]; j.JIdx[0][k] = J.JIdx[0][k]; j.JIdx[1][k] = J.JIdx[1][k]; j.JabF[0][k] = J.JabF[0][k]; j.JabF[1][k] = J.JabF[1][k]; }
+    for (int k = 0; k < 6; k++) { j.Jpdxi[0][k] = J.Jpdxi[0][k]; j.Jpdxi[1][k] = J.Jpdxi[1][k]; }
+    for (int k = 0; k < 4; k++) { j.Jpdc[0][k] = J.Jpdc[0][k]; j.Jpdc[1][k] = J.Jpdc[1][k]; }
+    j.Jpdd[0] = J.Jpdd[0]; j.Jpdd[1] = J.Jpdd[1];
+    j.JIdx2[0] = J.JIdx2(0, 0); j.JIdx2[1] = J.JIdx2(0, 1); j.JIdx2[2] = J.JIdx2(1, 0); j.JIdx2[3] = J.JIdx2(1, 1);
+    j.JabJIdx[0] = J.JabJIdx(0, 0); j.JabJIdx[1] = J.JabJIdx(0, 1); j.JabJIdx[2] = J.JabJIdx(1, 0); j.JabJIdx[3] = J.JabJIdx(1, 1);
+    j.Jab2[0] = J.Jab2(0, 0); j.Jab2[1] = J.Jab2(0, 1); j.Jab2[2] = J.Jab2(1, 0); j.Jab2[3] = J.Jab2(1, 1);
+}
+
+}  // namespace
+
+extern "C" {
+
+void *ref_create(int w, int h, int levels, const ldso_settings_t *settings, const ldso_calib_t *calib,
+                 int F, const ldso_frame_t *frames, const float *const *images,
+                 int P, const ldso_point_t *points, int R, const ldso_residual_t *residuals,
+                 const ldso_rawjac_t *linJ, const float *lin_res_toZeroF,
+                 const double *HM, const double *bM, int /*multithreading*/) {
+    RefWindow *W = new RefWindow();
+    apply_settings(settings);
+    W->levels = levels;
+    // globals of GlobalCalib.cc: K from the scaled calibration value (CalibHessian.h:86-100: value_scaled = SCALE_F / SCALE_C * value)
+    Eigen::Matrix3f K = Eigen::Matrix3f::Zero();
+    K(0, 0) = (float) (SCALE_F * calib->value[0]); K(1, 1) = (float) (SCALE_F * calib->value[1]);
+    K(0, 2) = (float) (SCALE_C * calib->value[2]); K(1, 2) = (float) (SCALE_C * calib->value[3]); K(2, 2) = 1;
+    setGlobalCalib(w, h, K);
+    pyrLevelsUsed = levels;
+
+    W->cam.reset(new Camera(K(0, 0), K(1, 1), K(0, 2), K(1, 2)));
+    W->cam->CreateCH(W->cam);
+    W->Hcalib = W->cam->mpCH;
+    VecC v0, vz;
+    for (int i = 0; i < 4; i++) { v0[i] = calib->value[i]; vz[i] = calib->value_zero[i]; }
+    W->Hcalib->value_zero = vz;
+    W->Hcalib->setValue(v0);
+
+    W->ef.reset(new EnergyFunctional());
+    W->ef->red = &W->red;
+    W->imageStore.resize((size_t) F * levels);
+    for (int f = 0; f < F; f++) {
+        const ldso_frame_t &in = frames[f];
+        shared_ptr<Frame> fr(new Frame());
+        fr->id = in.frameID;                          // FrameHessian::getPrior keys on frame->id == 0
+        fr->CreateFH(fr);
+        shared_ptr<FrameHessian> fh = fr->frameHessian;
+        fh->frameID = in.frameID; fh->ab_exposure = in.ab_exposure; fh->frameEnergyTH = in.frameEnergyTH;
+        for (int l = 0; l < PYR_LEVELS; l++) { fh->dIp[l] = nullptr; fh->absSquaredGrad[l] = nullptr; }
+        for (int l = 0; l < levels; l++) {
+            size_t n = (size_t) (w >> l) * (h >> l) * 3;
+            const float *src = images[f * levels + l];
+            if (src) { W->imageStore[f * levels + l].assign(src, src + n); fh->dIp[l] = (Vec3f *) W->imageStore[f * levels + l].data(); }
+        }
+        fh->dI = fh->dIp[0];
+        fh->worldToCam_evalPT = se3_from34(in.worldToCam_evalPT);
+        Vec10 st, sz;
+        for (int i = 0; i < 10; i++) { st[i] = in.state[i]; sz[i] = in.state_zero[i]; }
+        fh->state_zero = sz;
+        fh->setState(st);
+        for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) fh->nullspaces_pose(r, c) = in.nullspaces_pose[r * 6 + c];
+        for (int r = 0; r < 6; r++) fh->nullspaces_scale[r] = in.nullspaces_scale[r];
+        for (int r = 0; r < 4; r++) for (int c = 0; c < 2; c++) fh->nullspaces_affine(r, c) = in.nullspaces_affine[r * 2 + c];
+        W->frames.push_back(fr);
+    }
+    for (auto &fr : W->frames) W->ef->insertFrame(fr->frameHessian, W->Hcalib);
+    // EnergyFunctional::insertFrame sets idx = frames.size() (1-based) and relies on makeIDX for the window index
+    W->pointByFlat.resize(P);
+    W->resByFlat.resize(R);
+    for (int k = 0; k < P; k++) {
+        const ldso_point_t &in = points[k];
+        shared_ptr<Frame> host = W->frames[in.host];
+        shared_ptr<Feature> feat(new Feature(in.u, in.v, host));
+        feat->status = Feature::FeatureStatus::VALID;
+        shared_ptr<Point> pt(new Point());
+        pt->status = Point::PointStatus::ACTIVE;
+        pt->mHostFeature = feat;
+        feat->point = pt;
+        shared_ptr<PointHessian> p(new PointHessian());
+        pt->mpPH = p; p->point = pt;
+        host->features.push_back(feat);
+        p->u = in.u; p->v = in.v;
+        p->setIdepth(in.idepth);
+        p->setIdepthZero(in.idepth_zero);
+        memcpy(p->color, in.color, sizeof(p->color));
+        memcpy(p->weights, in.weights, sizeof(p->weights));
+        p->hasDepthPrior = in.priorF != 0;
+        p->takeData();
+        p->priorF = in.priorF;
+        W->pointByFlat[k] = p;
+        W->ef->nPoints++;
+        for (int j = 0; j < in.res_count; j++) {
+            int ri = in.res_begin + j;
+            const ldso_residual_t &rin = residuals[ri];
+            shared_ptr<PointFrameResidual> r(new PointFrameResidual(p, W->frames[rin.host]->frameHessian, W->frames[rin.target]->frameHessian));
+            r->state_state = (ResState) rin.state_state;
+            r->state_energy = rin.state_energy;
+            r->isLinearized = rin.is_linearized != 0;
+            r->isActiveAndIsGoodNEW = rin.is_active != 0;
+            r->isNew = rin.is_new != 0;
+            if (r->isLinearized && linJ) {
+                const ldso_rawjac_t &j74 = linJ[ri];
+                RawResidualJacobian &J = *r->J;
+                for (int i = 0; i < 8; i++) { J.resF[i] = j74.resF[i]; J.JIdx[0][i] = j74.JIdx[0][i]; J.JIdx[1][i] = j74.JIdx[1][i]; J.JabF[0][i] = j74.JabF[0][i]; J.JabF[1][i] = j74.JabF[1][i]; }
+                for (int i = 0; i < 6; i++) { J.Jpdxi[0][i] = j74.Jpdxi[0][i]; J.Jpdxi[1][i] = j74.Jpdxi[1][i]; }
+                for (int i = 0; i < 4; i++) { J.Jpdc[0][i] = j74.Jpdc[0][i]; J.Jpdc[1][i] = j74.Jpdc[1][i]; }
+                J.Jpdd[0] = j74.Jpdd[0]; J.Jpdd[1] = j74.Jpdd[1];
+                J.JIdx2(0, 0) = j74.JIdx2[0]; J.JIdx2(0, 1) = j74.JIdx2[1]; J.JIdx2(1, 0) = j74.JIdx2[2]; J.JIdx2(1, 1) = j74.JIdx2[3];
+                J.JabJIdx(0, 0) = j74.JabJIdx[0]; J.JabJIdx(0, 1) = j74.JabJIdx[1]; J.JabJIdx(1, 0) = j74.JabJIdx[2]; J.JabJIdx(1, 1) = j74.JabJIdx[3];
+                J.Jab2(0, 0) = j74.Jab2[0]; J.Jab2(0, 1) = j74.Jab2[1]; J.Jab2(1, 0) = j74.Jab2[2]; J.Jab2(1, 1) = j74.Jab2[3];
+                for (int i = 0; i < 8; i++) r->res_toZeroF[i] = lin_res_toZeroF[ri * 8 + i];
+            }
+            p->residuals.push_back(r);
+            if (r->isLinearized && linJ) W->ef->insertResidual(r); else W->ef->nResiduals++;      // insertResidual = takeData + counters (EF.cc:26-30)
+            W->resByFlat[ri] = r;
+        }
+        for (auto &r : p->residuals) {      // FullSystem.cc:446-469 sets lastResiduals on activation
+            if (r->target.lock() == W->frames.back()->frameHessian) p->lastResiduals[0] = {r, ResState::IN};
+            else if (F >= 2 && r->target.lock() == W->frames[F - 2]->frameHessian) p->lastResiduals[1] = {r, ResState::IN};
+        }
+    }
+    int n = 8 * F + 4;
+    if (HM) for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) W->ef->HM(i, j) = HM[i * n + j];
+    if (bM) for (int i = 0; i < n; i++) W->ef->bM[i] = bM[i];
+    W->ef->makeIDX();
+    set_precalc(W);
+    return W;
+}
+
+void ref_destroy(void *h) {
+    RefWindow *W = (RefWindow *) h;
+    // ~FrameHessian delete[]s its pyramid levels (FrameHessian.h:24-29); here they point into imageStore
+    for (auto &fh : W->ef->frames) for (int l = 0; l < PYR_LEVELS; l++) { fh->dIp[l] = nullptr; fh->absSquaredGrad[l] = nullptr; }
+    for (auto &fr : W->frames) if (fr->frameHessian) for (int l = 0; l < PYR_LEVELS; l++) { fr->frameHessian->dIp[l] = nullptr; fr->frameHessian->absSquaredGrad[l] = nullptr; }
+    delete W;
+}
+
+// the activeResiduals list of FullSystem::optimize (FullSystem.cc:735-755); reset_oob = the resetOOB of that loop
+void ref_collect_active(void *h, int reset_oob) {
+    RefWindow *W = (RefWindow *) h;
+    W->activeResiduals.clear();
+    for (auto &fr : W->frames)
+        for (auto &feat : fr->features)
+            if (feat->status == Feature::FeatureStatus::VALID && feat->point->status == Point::PointStatus::ACTIVE)
+                for (auto &r : feat->point->mpPH->residuals)
+                    if (!r->isLinearized) { W->activeResiduals.push_back(r); if (reset_oob) r->resetOOB(); }
+}
+
+// the residual loop of FullSystem::linearizeAll_Reductor (FullSystem.cc:1442-1470): PointFrameResidual::linearize on every
+// active residual; returns the energy sum.  (setNewFrameEnergyTH is FullSystem code and is not part of this call.)
+double ref_linearize_all(void *h) {
+    RefWindow *W = (RefWindow *) h;
+    double E = 0;
+    for (auto &r : W->activeResiduals) E += r->linearize(W->Hcalib);
+    return E;
+}
+
+void ref_apply_res(void *h) { RefWindow *W = (RefWindow *) h; for (auto &r : W->activeResiduals) r->applyRes(true); }
+
+void ref_set_frame_energy_th(void *h, int f, float th) { ((RefWindow *) h)->frames[f]->frameHessian->frameEnergyTH = th; }
+
+void ref_set_precalc(void *h) { set_precalc((RefWindow *) h); }
+
+// FullSystem::solveSystem (FullSystem.cc:1694-1704): nullspaces, then EnergyFunctional::solveSystemF
+void ref_solve_system(void *h, int iteration, double lambda) {
+    RefWindow *W = (RefWindow *) h;
+    W->ef->lastNullspaces_forLogging = get_nullspaces(W, W->ef->lastNullspaces_pose, W->ef->lastNullspaces_scale, W->ef->lastNullspaces_affA, W->ef->lastNullspaces_affB);
+    W->ef->solveSystemF(iteration, lambda, W->Hcalib);
+}
+
+int ref_num_frames(void *h) { return ((RefWindow *) h)->ef->nFrames; }
+void ref_counts(void *h, int *a, int *l, int *m) { auto ef = ((RefWindow *) h)->ef; *a = ef->resInA; *l = ef->resInL; *m = ef->resInM; }
+
+void ref_get_residuals(void *h, ldso_res_out_t *out, ldso_rawjac_t *J, int32_t *state_state, int32_t *is_active, float *res_toZeroF, int32_t *is_linearized, int32_t *alive) {
+    RefWindow *W = (RefWindow *) h;
+    std::set<PointFrameResidual *> live;
+    for (auto &p : W->pointByFlat) for (auto &r : p->residuals) live.insert(r.get());
+    for (size_t i = 0; i < W->resByFlat.size(); i++) {
+        PointFrameResidual *r = W->resByFlat[i].get();
+        if (out) {
+            out[i].state_NewEnergy = (float) r->state_NewEnergy;
+            out[i].state_NewEnergyWithOutlier = (float) r->state_NewEnergyWithOutlier;
+            out[i].state_NewState = r->state_NewState;
+            for (int k = 0; k < 3; k++) out[i].centerProjectedTo[k] = r->centerProjectedTo[k];
+            for (int k = 0; k < 8; k++) out[i].JpJdF[k] = r->JpJdF[k];
+        }
+        if (J) put_jac(*r->J, J[i]);
+        if (state_state) state_state[i] = r->state_state;
+        if (is_active) is_active[i] = r->isActiveAndIsGoodNEW ? 1 : 0;
+        if (res_toZeroF) for (int k = 0; k < 8; k++) res_toZeroF[i * 8 + k] = r->res_toZeroF[k];
+        if (is_linearized) is_linearized[i] = r->isLinearized ? 1 : 0;
+        if (alive) alive[i] = live.count(r) ? 1 : 0;
+    }
+}
+
+void ref_get_points(void *h, ldso_point_out_t *out, int32_t *status) {
+    RefWindow *W = (RefWindow *) h;
+    for (size_t i = 0; i < W->pointByFlat.size(); i++) {
+        PointHessian *p = W->pointByFlat[i].get();
+        if (out) {
+            ldso_point_out_t &o = out[i];
+            o.step = p->step; o.HdiF = p->HdiF; o.bdSumF = p->bdSumF; o.idepth_hessian = p->idepth_hessian;
+            o.Hdd_accAF = p->Hdd_accAF; o.bd_accAF = p->bd_accAF; o.Hdd_accLF = p->Hdd_accLF; o.bd_accLF = p->bd_accLF;
+            for (int k = 0; k < 4; k++) { o.Hcd_accAF[k] = p->Hcd_accAF[k]; o.Hcd_accLF[k] = p->Hcd_accLF[k]; }
+            o.idepth = p->idepth; o.maxRelBaseline = p->maxRelBaseline; o.numGoodResiduals = p->numGoodResiduals;
+        }
+        if (status) status[i] = p->alreadyRemoved ? 100 + (int) p->point->status : (int) p->point->status;
+    }
+}
+
+void ref_get_frames(void *h, ldso_frame_t *out, double *step, double *calib_value, double *calib_step, double *pre_worldToCam) {
+    RefWindow *W = (RefWindow *) h;
+    for (size_t f = 0; f < W->ef->frames.size(); f++) {
+        FrameHessian *fh = W->ef->frames[f].get();
+        if (out) {
+            ldso_frame_t &o = out[f];
+            Eigen::Matrix<double, 3, 4> M = fh->worldToCam_evalPT.matrix3x4();
+            for (int i = 0; i < 3; i++) for (int j = 0; j < 4; j++) o.worldToCam_evalPT[i * 4 + j] = M(i, j);
+            for (int i = 0; i < 10; i++) { o.state[i] = fh->state[i]; o.state_zero[i] = fh->state_zero[i]; }
+            for (int i = 0; i < 8; i++) o.prior[i] = fh->prior[i];
+            for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) o.nullspaces_pose[r * 6 + c] = fh->nullspaces_pose(r, c);
+            for (int r = 0; r < 6; r++) o.nullspaces_scale[r] = fh->nullspaces_scale[r];
+            for (int r = 0; r < 4; r++) for (int c = 0; c < 2; c++) o.nullspaces_affine[r * 2 + c] = fh->nullspaces_affine(r, c);
+            o.ab_exposure = fh->ab_exposure; o.frameEnergyTH = fh->frameEnergyTH; o.frameID = fh->frameID; o.pad_ = 0;
+        }
+        if (step) for (int i = 0; i < 10; i++) step[f * 10 + i] = fh->step[i];
+        if (pre_worldToCam) {
+            Eigen::Matrix<double, 3, 4> M = fh->PRE_worldToCam.matrix3x4();
+            for (int i = 0; i < 3; i++) for (int j = 0; j < 4; j++) pre_worldToCam[f * 12 + i * 4 + j] = M(i, j);
+        }
+    }
+    if (calib_value) for (int i = 0; i < 4; i++) calib_value[i] = W->Hcalib->value[i];
+    if (calib_step) for (int i = 0; i < 4; i++) calib_step[i] = W->Hcalib->step[i];
+}
+
+// F*F pair precalc: 9 KRKi, 3 Kt, 9 R0, 3 t0, 2 aff, 1 b0 (27 floats, matrices row-major) at [h*F + t]
+void ref_get_precalc(void *h, float *out) {
+    RefWindow *W = (RefWindow *) h;
+    int F = W->ef->frames.size();
+    for (int a = 0; a < F; a++)
+        for (int t = 0; t < F; t++) {
+            const FrameFramePrecalc &p = W->ef->frames[a]->targetPrecalc[t];
+            float *o = out + (a * F + t) * 27;
+            for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { o[i * 3 + j] = p.PRE_KRKiTll(i, j); o[12 + i * 3 + j] = p.PRE_RTll_0(i, j); }
+            for (int i = 0; i < 3; i++) { o[9 + i] = p.PRE_KtTll[i]; o[21 + i] = p.PRE_tTll_0[i]; }
+            o[24] = p.PRE_aff_mode[0]; o[25] = p.PRE_aff_mode[1]; o[26] = p.PRE_b0_mode;
+        }
+}
+
+// adjoints: adHost / adTarget F*F*64 doubles (row-major 8x8) at [h + t*F]; adHTdeltaF F*F*8 floats
+void ref_get_adjoints(void *h, double *adHost, double *adTarget, float *adHTdeltaF) {
+    EnergyFunctional *ef = ((RefWindow *) h)->ef.get();
+    int n = ef->nFrames * ef->nFrames;
+    for (int i = 0; i < n; i++) {
+        for (int r = 0; r < 8; r++) for (int c = 0; c < 8; c++) {
+            if (adHost) adHost[i * 64 + r * 8 + c] = ef->adHost[i](r, c);
+            if (adTarget) adTarget[i * 64 + r * 8 + c] = ef->adTarget[i](r, c);
+        }
+        if (adHTdeltaF) for (int c = 0; c < 8; c++) adHTdeltaF[i * 8 + c] = ef->adHTdeltaF[i][c];
+    }
+}
+
+// raw fp32 accumulators after the last solve (single-thread slot 0), row-major:
+// topA/topL: F*F*169 at [h + t*F]; accD F^3*64; accE F^2*32; accEB F^2*8; accHcc 16; accbc 4
+void ref_get_accumulators(void *h, float *topA, float *topL, float *accD, float *accE, float *accEB, float *accHcc, float *accbc) {
+    EnergyFunctional *ef = ((RefWindow *) h)->ef.get();
+    int F = ef->nFrames;
+    for (int i = 0; i < F * F; i++) {
+        if (topA) { ef->accSSE_top_A->acc[0][i].finish(); for (int r = 0; r < 13; r++) for (int c = 0; c < 13; c++) topA[i * 169 + r * 13 + c] = ef->accSSE_top_A->acc[0][i].H(r, c); }
+        if (topL) { ef->accSSE_top_L->acc[0][i].finish(); for (int r = 0; r < 13; r++) for (int c = 0; c < 13; c++) topL[i * 169 + r * 13 + c] = ef->accSSE_top_L->acc[0][i].H(r, c); }
+        if (accE) for (int r = 0; r < 8; r++) for (int c = 0; c < 4; c++) accE[i * 32 + r * 4 + c] = ef->accSSE_bot->accE[0][i].A1m(r, c);
+        if (accEB) for (int r = 0; r < 8; r++) accEB[i * 8 + r] = ef->accSSE_bot->accEB[0][i].A1m(r, 0);
+    }
+    if (accD) for (int i = 0; i < F * F * F; i++) for (int r = 0; r < 8; r++) for (int c = 0; c < 8; c++) accD[i * 64 + r * 8 + c] = ef->accSSE_bot->accD[0][i].A1m(r, c);
+    if (accHcc) for (int r = 0; r < 4; r++) for (int c = 0; c < 4; c++) accHcc[r * 4 + c] = ef->accSSE_bot->accHcc[0].A1m(r, c);
+    if (accbc) for (int r = 0; r < 4; r++) accbc[r] = ef->accSSE_bot->accbc[0].A1m(r, 0);
+}
+
+// what EnergyFunctional keeps of the last solve: lastHS = H_A + H_L + H_M - H_sc, lastbS, lastX (EF.cc:296-345)
+void ref_get_system(void *h, double *lastHS, double *lastbS, double *x) {
+    EnergyFunctional *ef = ((RefWindow *) h)->ef.get();
+    int n = ef->lastHS.rows();
+    if (lastHS) for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) lastHS[i * n + j] = ef->lastHS(i, j);
+    if (lastbS) for (int i = 0; i < n; i++) lastbS[i] = ef->lastbS[i];
+    if (x) for (int i = 0; i < (int) ef->lastX.size(); i++) x[i] = ef->lastX[i];
+}
+
+void ref_get_prior(void *h, double *HM, double *bM) {
+    EnergyFunctional *ef = ((RefWindow *) h)->ef.get();
+    int n = ef->HM.rows();
+    for (int i = 0; i < n; i++) { for (int j = 0; j < n; j++) HM[i * n + j] = ef->HM(i, j); bM[i] = ef->bM[i]; }
+}
+
+// ---- marginalisation ---------------------------------------------------------------------------------------------------------
+// status per flat point as decided by FullSystem::flagPointsForRemoval (host policy, taken from the caller): 0 keep, 3 marginalise
+// (PS_MARGINALIZED), 1 / 2 drop.  For the points to marginalise the loop of FullSystem.cc:1241-1250 runs on the reference objects:
+// resetOOB, linearize, applyRes(true), fixLinearizationF for the active ones.
+void ref_flag_points(void *h, const int32_t *status) {
+    RefWindow *W = (RefWindow *) h;
+    for (size_t i = 0; i < W->pointByFlat.size(); i++) {
+        shared_ptr<PointHessian> ph = W->pointByFlat[i];
+        int st = status[i] % 100;
+        if (st == 3) {
+            for (auto &r : ph->residuals) {
+                r->resetOOB();
+                r->linearize(W->Hcalib);
+                r->isLinearized = false;
+                r->applyRes(true);
+                if (r->isActive()) r->fixLinearizationF(W->ef);
+            }
+            ph->point->status = Point::PointStatus::MARGINALIZED;
+        } else if (st == 1 || st == 2) {
+            ph->point->status = (st == 1) ? Point::PointStatus::OUTLIER : Point::PointStatus::OUT;
+        }
+    }
+}
+void ref_drop_points(void *h) { ((RefWindow *) h)->ef->dropPointsF(); }
+void ref_marginalize_points(void *h) {
+    RefWindow *W = (RefWindow *) h;
+    W->ef->lastNullspaces_forLogging = get_nullspaces(W, W->ef->lastNullspaces_pose, W->ef->lastNullspaces_scale, W->ef->lastNullspaces_affA, W->ef->lastNullspaces_affB);
+    W->ef->marginalizePointsF();
+    for (auto &p : W->ef->allPointsToMarg) p->alreadyRemoved = true;
+}
+// FullSystem::marginalizeFrame (FullSystem.cc:602-640): EnergyFunctional::marginalizeFrame, then drop the residuals that target it
+void ref_marginalize_frame(void *h, int idx) {
+    RefWindow *W = (RefWindow *) h;
+    shared_ptr<FrameHessian> fh = W->ef->frames[idx];
+    W->ef->marginalizeFrame(fh);
+    for (auto &fr : W->frames) {
+        if (fr->frameHessian == fh) continue;
+        for (auto &feat : fr->features) {
+            if (feat->status != Feature::FeatureStatus::VALID || feat->point->status != Point::PointStatus::ACTIVE) continue;
+            shared_ptr<PointHessian> ph = feat->point->mpPH;
+            size_t n = ph->residuals.size();
+            for (size_t i = 0; i < n; i++) {
+                shared_ptr<PointFrameResidual> r = ph->residuals[i];
+                if (r->target.lock() == fh) {
+                    if (ph->lastResiduals[0].first == r) ph->lastResiduals[0].first = nullptr;
+                    else if (ph->lastResiduals[1].first == r) ph->lastResiduals[1].first = nullptr;
+                    W->ef->dropResidual(r);
+                    i--; n--;
+                }
+            }
+        }
+    }
+    for (size_t i = 0; i < W->frames.size(); i++) if (W->frames[i]->frameHessian == fh) { W->frames.erase(W->frames.begin() + i); break; }
+    W->ef->setAdjointsF(W->Hcalib);
+    set_precalc(W);
+}
+
+// ---- FrameHessian::makeImages (FrameHessian.cc:44-113) -----------------------------------------------------------------------
+// out[l]: (w>>l)*(h>>l)*3 floats
+void ref_make_images(int w, int h, int levels, const float *color, float *const *out) {
+    Eigen::Matrix3f K = Eigen::Matrix3f::Identity();
+    K(0, 0) = K(1, 1) = 1; K(0, 2) = w / 2.0f; K(1, 2) = h / 2.0f;
+    setGlobalCalib(w, h, K);
+    pyrLevelsUsed = levels;
+    setting_enableLoopClosing = false;
+    shared_ptr<Frame> fr(new Frame());
+    fr->CreateFH(fr);
+    shared_ptr<FrameHessian> fh = fr->frameHessian;
+    std::vector<float> c(color, color + (size_t) w * h);
+    fh->makeImages(c.data(), nullptr);
+    for (int l = 0; l < levels; l++) memcpy(out[l], fh->dIp[l], (size_t) (w >> l) * (h >> l) * 12);
+}
+
+}  // extern "C"

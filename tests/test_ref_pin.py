@@ -1,0 +1,146 @@
+"""The oracle (oracle/*.cc, the CPU restatement every GPU parity test is checked against) pinned to REFERENCE-COMPILED code:
+oracle/_ref/libldso_ref.so is built from the reference's own hot-path translation units, unmodified, where they lie under
+/root/reference (oracle/Makefile `ref`, oracle/ref_driver.cc), against a header shim for the absent third-party headers
+(oracle/ref_shim: what it replaces is stated in ref_shim/Eigen/Core).  On identical windows the two must agree BIT FOR BIT on
+everything the reference's own source spells out: per-residual Jacobians / energies / states (Residuals.cc), the hand-written SSE
+accumulators (MatrixAccumulators.h, AccumulatedTopHessian.cc, AccumulatedSCHessian.cc), the per-point Schur quantities, the stitched
+system, the step and the back-substitution (EnergyFunctional.cc), the pair precalc (FrameFramePrecalc.cc), fixLinearizationF and the
+marginalisation (EnergyFunctional.cc:72-222), makeImages (FrameHessian.cc:44-113).
+Runs wherever the library exists or can be built (this container); skipped otherwise."""
+import copy
+
+import numpy as np
+import pytest
+
+from conftest import get_window
+from ldso_amd import synth
+from oracle import pyoracle as po, pyref as pr
+
+pytestmark = pytest.mark.skipif(not pr.available(), reason="oracle/_ref/libldso_ref.so missing and /root/reference not present to build it")
+
+
+def _same(a, b, what):
+    assert np.array_equal(np.asarray(a), np.asarray(b)), f"{what}: max |diff| {np.abs(np.asarray(a, float) - np.asarray(b, float)).max()}"
+
+
+def _close(a, b, tol, what):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    assert np.abs(a - b).max() <= tol * np.abs(b).max(), f"{what}: max |diff| {np.abs(a - b).max()} of {np.abs(b).max()}"
+
+
+def _stage(win, iteration=0, x_tol=0.0):
+    o, r = po.OracleWindow(win), pr.RefWindow(win)
+    _same(o.get_precalc(), r.get_precalc(), "FrameFramePrecalc::Set")
+    for a, b, n in zip(o.get_adjoints(), r.get_adjoints(), ("adHost", "adTarget", "adHTdeltaF")):
+        _same(a, b, n)
+    o.collect_active(); r.collect_active()
+    Eo, Er = o.linearize_all(False), r.linearize_all()
+    assert Eo == Er
+    ro, rr = o.get_residuals(), r.get_residuals()
+    for k in ("state_NewState", "state_NewEnergy", "state_NewEnergyWithOutlier"):
+        _same(ro["out"][k], rr["out"][k], k)
+    lin = win.residuals["is_linearized"].astype(bool)
+    ok = (ro["out"]["state_NewState"] != 1) & ~lin
+    _same(ro["out"]["centerProjectedTo"][ok], rr["out"]["centerProjectedTo"][ok], "centerProjectedTo")      # never written on an early OOB return
+    for k in ro["J"].dtype.names:
+        _same(ro["J"][k][ok], rr["J"][k][ok], "J." + k)
+    o.apply_res(); r.apply_res()
+    ro, rr = o.get_residuals(), r.get_residuals()
+    for k in ("state_state", "is_active"):
+        _same(ro[k], rr[k], k)
+    _same(ro["out"]["JpJdF"], rr["out"]["JpJdF"], "JpJdF (takeData)")
+    o.backup_state(); o.solve_system(iteration); r.solve_system(iteration)
+    ao, ar = o.get_accumulators(), r.get_accumulators()
+    for k in ao:
+        _same(ao[k], ar[k], "accumulator " + k)
+    pto, _ = o.get_points(); ptr, _ = r.get_points()
+    for k in pto.dtype.names:
+        if k != "step":
+            _same(pto[k], ptr[k], "point." + k)
+    so, sr = o.get_system(), r.get_system()
+    for k in ("lastHS", "lastbS"):
+        _same(so[k], sr[k], k)
+    if x_tol == 0.0:
+        _same(so["x"], sr["x"], "x")
+        _same(pto["step"], ptr["step"], "point step")
+    else:      # orthogonalize(): projector built from an SVD and three dense products whose association differs between the two sides
+        assert np.abs(so["x"] - sr["x"]).max() <= x_tol * np.abs(so["x"]).max()
+        assert np.abs(pto["step"] - ptr["step"]).max() <= 1e-6 * np.abs(pto["step"]).max()
+    assert o.counts() == r.counts()
+    fo, fr = o.get_frames(), r.get_frames()
+    if x_tol == 0.0:
+        _same(fo["step"], fr["step"], "frame step"); _same(fo["calib_step"], fr["calib_step"], "calib step")
+    _same(fo["frames"]["prior"], fr["frames"]["prior"], "FrameHessian::getPrior")
+    return o, r
+
+
+@pytest.mark.parametrize("name", ["tiny", "small"])
+def test_stage_bit_exact(name):
+    _stage(get_window(name))
+
+
+def test_stage_bit_exact_orthogonalized_iteration(small):
+    """iteration >= 2: x is projected off the gauge nullspaces (EnergyFunctional::orthogonalize, EF.cc:685-717)."""
+    _stage(small, iteration=2, x_tol=1e-10)
+
+
+def test_stage_bit_exact_with_prior_and_linearized_residuals(small):
+    """H_M / b_M present and a third of the residuals linearised: addPoint<1> (res_toZeroF + J delta), H_L, b_M + H_M delta."""
+    w = po.make_mixed_window(synth.add_synthetic_prior(copy.deepcopy(small)))
+    assert 0 < w.residuals["is_linearized"].sum() < w.R
+    o, r = _stage(w)
+    assert r.counts()[1] > 0
+
+
+def test_full_size_c3_bit_exact():
+    """BASELINE configs[2] (7 KF x 2000 pt, 640x480) with the marginalisation prior: the bench window."""
+    _stage(synth.add_synthetic_prior(copy.deepcopy(get_window("C3"))))
+
+
+def test_marginalization_bit_exact(small):
+    """flagPointsForRemoval's relinearise + fixLinearizationF (Residuals.cc:216-242), marginalizePointsF (EF.cc:165-222, addPoint<2>)
+    and marginalizeFrame (EF.cc:72-151) after three GN iterations of the oracle; the reference graph is rebuilt from the oracle's
+    post-optimize state, the host policy (which points go) is taken from the oracle."""
+    win = synth.add_synthetic_prior(copy.deepcopy(small))
+    o = po.OracleWindow(win); o.set_force_all_iterations(True)
+    o.optimize(3)
+    ex, fo = o.export_window(), o.get_frames()
+    w2 = copy.deepcopy(win)
+    w2.points, w2.residuals, w2.lin_J, w2.lin_res_toZeroF = ex["points"], ex["residuals"], ex["lin_J"], ex["lin_res_toZeroF"]
+    w2.frames = fo["frames"]
+    w2.calib = w2.calib.copy(); w2.calib["value"] = fo["calib_value"]
+    assert np.array_equal(ex["orig_point"], np.arange(win.P))
+    o2, r = o, pr.RefWindow(w2)                       # the oracle keeps going; the reference graph holds the same state
+    o2.flag_frame(0); o2.flag_points_for_removal()
+    _, status = o2.get_points()
+    assert (status % 100 == 3).sum() > 10
+    r.flag_points(status)
+    ro, rr = o2.get_residuals(), r.get_residuals()
+    ro = {k: (v[ex["orig_res"]] if v is not None else None) for k, v in ro.items()}      # oracle flat order -> exported order
+    marg = np.isin(w2.residuals["point"], np.nonzero(status % 100 == 3)[0])
+    act = marg & (rr["is_active"] != 0)
+    assert act.sum() > 10
+    _same(ro["res_toZeroF"][act], rr["res_toZeroF"][act], "fixLinearizationF res_toZeroF")
+    _same(ro["is_active"][marg], rr["is_active"][marg], "is_active of re-linearised residuals")
+    o2.drop_points(); r.drop_points()
+    o2.marginalize_points(); r.marginalize_points()
+    # fp64 from here on: M - Msc and HM += margWeightFac * H are evaluated through the shim's / the oracle's own matrix operators,
+    # whose association of the scalar factor differs by one rounding
+    for a, b, n in zip(o2.get_prior(), r.get_prior(), ("HM after marginalizePointsF", "bM after marginalizePointsF")):
+        _close(a, b, 1e-15, n)
+    o2.marginalize_frame(0); r.marginalize_frame(0)
+    (HMo, bMo), (HMr, bMr) = o2.get_prior(), r.get_prior()
+    assert HMo.shape == HMr.shape == (8 * (win.F - 1) + 4,) * 2
+    _close(HMo, HMr, 1e-12, "HM after marginalizeFrame"); _close(bMo, bMr, 1e-12, "bM after marginalizeFrame")
+    _close(o2.get_precalc(), r.get_precalc(), 1e-7, "precalc after marginalizeFrame")      # the reference graph got its poses through a [R|t] round trip
+
+
+@pytest.mark.parametrize("w,h,levels", [(160, 128, 3), (640, 480, 4)])
+def test_make_images_bit_exact(w, h, levels):
+    rng = np.random.default_rng(3)
+    color = (rng.random((h, w)) * 255).astype(np.float32)
+    a, b = po.make_images(color, levels), pr.make_images(color, levels)
+    for l in range(levels):
+        # the border rows of the gradient channels are never written by makeImages (memset of 3*w*h BYTES, FrameHessian.cc:50): compare the interior
+        _same(a[l][1:-1, :, :], b[l][1:-1, :, :], f"makeImages level {l}")
+        _same(a[l][:, :, 0], b[l][:, :, 0], f"makeImages intensity level {l}")
