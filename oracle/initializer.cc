@@ -1,4 +1,4 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY (not part of the product path; see linalg.h header).  PARITY UNPINNED: the reference ships
+// ORACLE — TEST INFRASTRUCTURE ONLY (not part of the product path; see linalg.h header).  Pinned to the reference-compiled translation unit by tests/test_ref_pin.py (traceOn byte-identical; trackFrame to 1e-6). The reference ships
 // no tests or fixtures for the initialiser; the restatement is validated by tests/test_init_oracle.py (finite differences of the
 // energy against b, explicit Schur complement, pose/depth recovery on synthetic scenes).
 //

@@ -177,3 +177,125 @@ def make_images(color, levels):
     arr = (C.c_void_p * levels)(*[o.ctypes.data for o in outs])
     L.ref_make_images(C.c_int(w), C.c_int(h), C.c_int(levels), _p(col), arr)
     return outs
+
+
+class RefTracker:
+    """The reference's CoarseTracker (src/frontend/CoarseTracker.cc compiled unmodified), same inputs as pyoracle.OracleTracker."""
+
+    def __init__(self, w, h, levels, settings, calib):
+        self.L = lib()
+        self.L.ref_tr_create.restype = C.c_void_p
+        self.levels = levels
+        s = np.ascontiguousarray(settings); c = np.ascontiguousarray(calib)
+        self.h = C.c_void_p(self.L.ref_tr_create(C.c_int(w), C.c_int(h), C.c_int(levels), _p(s), _p(c)))
+
+    def close(self):
+        if self.h:
+            self.L.ref_tr_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_ref(self, pyr, a, b, exposure, pts):
+        arr, keep = _img_ptrs([pyr], self.levels)
+        pts = np.ascontiguousarray(pts, dtype=np.float32)
+        self.L.ref_tr_set_ref(self.h, arr, C.c_float(a), C.c_float(b), C.c_float(exposure), _p(pts), C.c_int(len(pts)))
+
+    def set_new_frame(self, pyr, exposure=1.0):
+        arr, keep = _img_ptrs([pyr], self.levels)
+        self.L.ref_tr_set_new_frame(self.h, arr, C.c_float(exposure))
+
+    def pc(self, lvl):
+        n = self.L.ref_tr_pc_n(self.h, C.c_int(lvl))
+        u, v, d, c = (np.zeros(n, np.float32) for _ in range(4))
+        self.L.ref_tr_get_pc(self.h, C.c_int(lvl), _p(u), _p(v), _p(d), _p(c))
+        return u, v, d, c
+
+    def K(self):
+        fx, fy, cx, cy = (np.zeros(self.levels, np.float32) for _ in range(4))
+        self.L.ref_tr_get_K(self.h, _p(fx), _p(fy), _p(cx), _p(cy))
+        return fx, fy, cx, cy
+
+    def calc_res(self, lvl, T, a, b, cutoff):
+        T = np.ascontiguousarray(T[:3, :4], dtype=np.float64)
+        rs = np.zeros(6)
+        n = self.L.ref_tr_calc_res(self.h, C.c_int(lvl), _p(T), C.c_float(a), C.c_float(b), C.c_float(cutoff), _p(rs))
+        return rs, n
+
+    def warped(self, n):
+        bufs = [np.zeros(n, np.float32) for _ in range(8)]
+        self.L.ref_tr_get_warped(self.h, *[_p(b) for b in bufs])
+        return dict(zip(["idepth", "u", "v", "dx", "dy", "residual", "weight", "refColor"], bufs))
+
+    def calc_gs(self, lvl, T, a, b):
+        T = np.ascontiguousarray(T[:3, :4], dtype=np.float64)
+        H = np.zeros((8, 8)); bb = np.zeros(8)
+        self.L.ref_tr_calc_gs(self.h, C.c_int(lvl), _p(T), C.c_float(a), C.c_float(b), _p(H), _p(bb))
+        return H, bb
+
+    def track(self, T, a, b, coarsest, min_res=None):
+        T = np.ascontiguousarray(T[:3, :4], dtype=np.float64).copy()
+        ab = np.array([a, b], np.float32)
+        mr = np.full(5, np.nan) if min_res is None else np.asarray(min_res, np.float64)
+        lr = np.zeros(5); fl = np.zeros(3)
+        ok = self.L.ref_tr_track(self.h, _p(T), _p(ab), C.c_int(coarsest), _p(mr), _p(lr), _p(fl))
+        return dict(ok=bool(ok), T=T, a=float(ab[0]), b=float(ab[1]), lastResiduals=lr, flow=fl)
+
+
+def trace_on(points, dI_level0, KRKi, Kt, aff, settings=None):
+    """ImmaturePoint::traceOn of the reference over immature-point records (modified in place) -> counts[6]; as pyoracle.trace_on."""
+    L = lib()
+    s = np.ascontiguousarray(synth.default_trace_settings() if settings is None else settings)
+    img = np.ascontiguousarray(dI_level0, np.float32)
+    h, w = img.shape[:2]
+    K1 = np.ascontiguousarray(KRKi, np.float32); K2 = np.ascontiguousarray(Kt, np.float32); A = np.ascontiguousarray(aff, np.float32)
+    counts = np.zeros(6, np.int32)
+    assert points.flags["C_CONTIGUOUS"] and points.dtype == synth.IMMATURE_DTYPE
+    L.ref_trace_on(C.c_int(len(points)), _p(points), _p(img), C.c_int(w), C.c_int(h), C.c_int(len(K1)), _p(K1), _p(K2), _p(A), _p(s), _p(counts))
+    return counts
+
+
+class RefInitializer:
+    """The reference's CoarseInitializer::trackFrame (CoarseInitializer.cc compiled unmodified); points arrive as records."""
+
+    def __init__(self, w, h, levels):
+        self.L = lib()
+        self.L.ref_init_create.restype = C.c_void_p
+        self.levels = levels
+        self.h = C.c_void_p(self.L.ref_init_create(C.c_int(w), C.c_int(h), C.c_int(levels)))
+        self.n = [0] * levels
+
+    def close(self):
+        if self.h:
+            self.L.ref_init_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_first(self, K4, pyr, exposure, points, huberTH=9.0, fixAffine=True):
+        arr, keep = _img_ptrs([pyr], self.levels)
+        pts = [np.ascontiguousarray(p, dtype=synth.INIT_POINT_DTYPE) for p in points]
+        pp = (C.c_void_p * self.levels)(*[p.ctypes.data for p in pts])
+        n = np.array([len(p) for p in pts], dtype=np.int32)
+        self.n = [int(x) for x in n]
+        k = np.ascontiguousarray(K4, dtype=np.float32)
+        self.L.ref_init_set_first(self.h, _p(k), arr, C.c_float(exposure), pp, _p(n), C.c_float(huberTH), C.c_int(1 if fixAffine else 0))
+
+    def track_frame(self, pyr, exposure=1.0):
+        arr, keep = _img_ptrs([pyr], self.levels)
+        st = np.zeros((), synth.INIT_STATE_DTYPE)
+        self.L.ref_init_track_frame(self.h, arr, C.c_float(exposure), _p(st))
+        return st
+
+    def points(self, lvl):
+        out = np.zeros(self.n[lvl], synth.INIT_POINT_DTYPE)
+        self.L.ref_init_get_points(self.h, C.c_int(lvl), _p(out))
+        return out

@@ -44,6 +44,7 @@
 #include "internal/ImmaturePoint.h"
 #include "internal/OptimizationBackend/EnergyFunctional.h"
 #include "frontend/CoarseTracker.h"
+#include "frontend/CoarseInitializer.h"
 #undef private
 #undef protected
 #include "../include/ldso_window.h"
@@ -508,6 +509,263 @@ void ref_make_images(int w, int h, int levels, const float *color, float *const 
     std::vector<float> c(color, color + (size_t) w * h);
     fh->makeImages(c.data(), nullptr);
     for (int l = 0; l < levels; l++) memcpy(out[l], fh->dIp[l], (size_t) (w >> l) * (h >> l) * 12);
+}
+
+
+// ---- CoarseTracker (src/frontend/CoarseTracker.cc, compiled unmodified) --------------------------------------------------------
+namespace {
+struct RefTracker {
+    shared_ptr<Camera> cam;
+    shared_ptr<CoarseTracker> tr;
+    shared_ptr<Frame> refFrame, newFrame;
+    std::vector<shared_ptr<FrameHessian>> fhs;
+    std::vector<shared_ptr<PointFrameResidual>> keep;
+    std::vector<std::vector<float>> refImgs, newImgs;
+    int levels = 0, w = 0, h = 0;
+};
+static void detach_images(shared_ptr<Frame> &fr) { if (fr && fr->frameHessian) for (int l = 0; l < PYR_LEVELS; l++) { fr->frameHessian->dIp[l] = nullptr; fr->frameHessian->absSquaredGrad[l] = nullptr; } }
+static shared_ptr<Frame> make_frame(std::vector<std::vector<float>> &store, const float *const *dIp, int w, int h, int levels, float exposure) {
+    shared_ptr<Frame> fr(new Frame());
+    fr->CreateFH(fr);
+    auto fh = fr->frameHessian;
+    for (int l = 0; l < PYR_LEVELS; l++) { fh->dIp[l] = nullptr; fh->absSquaredGrad[l] = nullptr; }
+    store.resize(levels);
+    for (int l = 0; l < levels; l++) { size_t n = (size_t) (w >> l) * (h >> l) * 3; store[l].assign(dIp[l], dIp[l] + n); fh->dIp[l] = (Vec3f *) store[l].data(); }
+    fh->dI = fh->dIp[0];
+    fh->ab_exposure = exposure;
+    return fr;
+}
+}  // namespace
+
+void *ref_tr_create(int w, int h, int levels, const ldso_settings_t *settings, const ldso_calib_t *calib) {
+    RefTracker *T = new RefTracker();
+    apply_settings(settings);
+    T->levels = levels; T->w = w; T->h = h;
+    Eigen::Matrix3f K = Eigen::Matrix3f::Zero();
+    K(0, 0) = (float) (SCALE_F * calib->value[0]); K(1, 1) = (float) (SCALE_F * calib->value[1]);
+    K(0, 2) = (float) (SCALE_C * calib->value[2]); K(1, 2) = (float) (SCALE_C * calib->value[3]); K(2, 2) = 1;
+    setGlobalCalib(w, h, K);
+    pyrLevelsUsed = levels;
+    for (int l = 0; l < levels; l++) { wG[l] = w >> l; hG[l] = h >> l; }
+    T->cam.reset(new Camera(K(0, 0), K(1, 1), K(0, 2), K(1, 2)));
+    T->cam->CreateCH(T->cam);
+    VecC v0, vz;
+    for (int i = 0; i < 4; i++) { v0[i] = calib->value[i]; vz[i] = calib->value_zero[i]; }
+    T->cam->mpCH->value_zero = vz;
+    T->cam->mpCH->setValue(v0);
+    T->tr.reset(new CoarseTracker(w, h));
+    T->tr->makeK(T->cam->mpCH);
+    return T;
+}
+void ref_tr_destroy(void *h) { RefTracker *T = (RefTracker *) h; detach_images(T->refFrame); detach_images(T->newFrame); delete T; }
+
+// setCoarseTrackingRef on a reference frame whose active points are given as (Ku, Kv, new_idepth, HdiF) x n: each becomes a
+// Feature / Point / PointHessian with lastResiduals[0] = an active IN residual towards the reference frame (what makeCoarseDepthL0 reads)
+void ref_tr_set_ref(void *h, const float *const *ref_dIp, float ref_a, float ref_b, float ref_exposure, const float *pts, int n) {
+    RefTracker *T = (RefTracker *) h;
+    detach_images(T->refFrame);
+    T->refFrame = make_frame(T->refImgs, ref_dIp, T->w, T->h, T->levels, ref_exposure);
+    auto fh = T->refFrame->frameHessian;
+    Vec10 ss = Vec10::Zero(); ss[6] = ref_a; ss[7] = ref_b;
+    fh->state_scaled = ss;                               // lastRef->aff_g2l() reads state_scaled[6..7] (FrameHessian.h:64-66)
+    T->keep.clear();
+    for (int i = 0; i < n; i++) {
+        shared_ptr<Feature> feat(new Feature(pts[i * 4], pts[i * 4 + 1], T->refFrame));
+        feat->status = Feature::FeatureStatus::VALID;
+        shared_ptr<Point> pt(new Point());
+        pt->status = Point::PointStatus::ACTIVE;
+        pt->mHostFeature = feat; feat->point = pt;
+        shared_ptr<PointHessian> ph(new PointHessian());
+        pt->mpPH = ph; ph->point = pt;
+        ph->HdiF = pts[i * 4 + 3];
+        shared_ptr<PointFrameResidual> r(new PointFrameResidual(ph, fh, fh));
+        r->centerProjectedTo = Vec3f(pts[i * 4], pts[i * 4 + 1], pts[i * 4 + 2]);
+        r->isActiveAndIsGoodNEW = true;
+        r->state_state = ResState::IN;
+        ph->lastResiduals[0] = {r, ResState::IN};
+        T->keep.push_back(r);
+        T->refFrame->features.push_back(feat);
+    }
+    T->fhs.clear(); T->fhs.push_back(fh);
+    T->tr->setCoarseTrackingRef(T->fhs);
+}
+void ref_tr_set_new_frame(void *h, const float *const *new_dIp, float exposure) {
+    RefTracker *T = (RefTracker *) h;
+    detach_images(T->newFrame);
+    T->newFrame = make_frame(T->newImgs, new_dIp, T->w, T->h, T->levels, exposure);
+    T->tr->newFrame = T->newFrame->frameHessian;
+}
+int ref_tr_pc_n(void *h, int lvl) { return ((RefTracker *) h)->tr->pc_n[lvl]; }
+void ref_tr_get_pc(void *h, int lvl, float *u, float *v, float *idepth, float *color) {
+    CoarseTracker *tr = ((RefTracker *) h)->tr.get();
+    int n = tr->pc_n[lvl];
+    memcpy(u, tr->pc_u[lvl], n * 4); memcpy(v, tr->pc_v[lvl], n * 4); memcpy(idepth, tr->pc_idepth[lvl], n * 4); memcpy(color, tr->pc_color[lvl], n * 4);
+}
+void ref_tr_get_K(void *h, float *fx, float *fy, float *cx, float *cy) {
+    RefTracker *T = (RefTracker *) h;
+    for (int l = 0; l < T->levels; l++) { fx[l] = T->tr->fx[l]; fy[l] = T->tr->fy[l]; cx[l] = T->tr->cx[l]; cy[l] = T->tr->cy[l]; }
+}
+int ref_tr_calc_res(void *h, int lvl, const double *T_ref2new, float a, float b, float cutoffTH, double *rs_out) {
+    CoarseTracker *tr = ((RefTracker *) h)->tr.get();
+    Vec6 rs = tr->calcRes(lvl, se3_from34(T_ref2new), AffLight(a, b), cutoffTH);
+    for (int i = 0; i < 6; i++) rs_out[i] = rs[i];
+    return tr->buf_warped_n;
+}
+void ref_tr_get_warped(void *h, float *idepth, float *u, float *v, float *dx, float *dy, float *residual, float *weight, float *refColor) {
+    CoarseTracker *tr = ((RefTracker *) h)->tr.get();
+    int n = tr->buf_warped_n;
+    memcpy(idepth, tr->buf_warped_idepth, n * 4); memcpy(u, tr->buf_warped_u, n * 4); memcpy(v, tr->buf_warped_v, n * 4);
+    memcpy(dx, tr->buf_warped_dx, n * 4); memcpy(dy, tr->buf_warped_dy, n * 4); memcpy(residual, tr->buf_warped_residual, n * 4);
+    memcpy(weight, tr->buf_warped_weight, n * 4); memcpy(refColor, tr->buf_warped_refColor, n * 4);
+}
+void ref_tr_calc_gs(void *h, int lvl, const double *T_ref2new, float a, float b, double *H_out, double *b_out) {
+    CoarseTracker *tr = ((RefTracker *) h)->tr.get();
+    Mat88 H; Vec8 bb;
+    tr->calcGSSSE(lvl, H, bb, se3_from34(T_ref2new), AffLight(a, b));
+    for (int i = 0; i < 8; i++) { for (int j = 0; j < 8; j++) H_out[i * 8 + j] = H(i, j); b_out[i] = bb[i]; }
+}
+int ref_tr_track(void *h, double *T_inout, float *ab_inout, int coarsestLvl, const double *minResForAbort, double *lastResiduals, double *flow) {
+    RefTracker *T = (RefTracker *) h;
+    SE3 pose = se3_from34(T_inout);
+    AffLight aff(ab_inout[0], ab_inout[1]);
+    Vec5 mr; for (int i = 0; i < 5; i++) mr[i] = minResForAbort[i];
+    bool ok = T->tr->trackNewestCoarse(T->newFrame->frameHessian, pose, aff, coarsestLvl, mr);
+    Eigen::Matrix<double, 3, 4> M = pose.matrix3x4();
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 4; j++) T_inout[i * 4 + j] = M(i, j);
+    ab_inout[0] = aff.a; ab_inout[1] = aff.b;
+    for (int i = 0; i < 5; i++) lastResiduals[i] = T->tr->lastResiduals[i];
+    for (int i = 0; i < 3; i++) flow[i] = T->tr->lastFlowIndicators[i];
+    return ok ? 1 : 0;
+}
+
+
+// ---- ImmaturePoint::traceOn (src/internal/ImmaturePoint.cc:47-310, compiled unmodified) under the loop of
+//      FullSystem::traceNewCoarse (FullSystem.cc:1012-1050): every immature point against the new frame; counts[6] per status -----
+void ref_trace_on(int n, ldso_immature_t *pts, const float *dI, int w, int h, int n_hosts, const float *KRKi, const float *Kt, const float *aff,
+                  const ldso_trace_settings_t *s, int *counts) {
+    setting_maxPixSearch = s->maxPixSearch; setting_trace_stepsize = s->trace_stepsize; setting_trace_GNThreshold = s->trace_GNThreshold;
+    setting_trace_extraSlackOnTH = s->trace_extraSlackOnTH; setting_trace_slackInterval = s->trace_slackInterval;
+    setting_trace_minImprovementFactor = s->trace_minImprovementFactor; setting_huberTH = s->huberTH;
+    setting_trace_GNIterations = s->trace_GNIterations; setting_minTraceTestRadius = s->minTraceTestRadius;
+    Eigen::Matrix3f K = Eigen::Matrix3f::Identity(); K(0, 2) = w / 2.0f; K(1, 2) = h / 2.0f;
+    setGlobalCalib(w, h, K);
+    shared_ptr<Camera> cam(new Camera(1, 1, w / 2.0, h / 2.0));
+    cam->CreateCH(cam);
+    // the new frame (target of the search) and a blank host frame for the ImmaturePoint constructor, whose results are then
+    // replaced by the record's (the constructor samples the HOST image, which the records already carry)
+    std::vector<std::vector<float>> store, blankStore;
+    const float *lv[1] = {dI};
+    shared_ptr<Frame> fr = make_frame(store, lv, w, h, 1, 1.0f);
+    std::vector<float> blank((size_t) w * h * 3, 0.0f);
+    const float *bl[1] = {blank.data()};
+    shared_ptr<Frame> host = make_frame(blankStore, bl, w, h, 1, 1.0f);
+    if (counts) for (int i = 0; i < 6; i++) counts[i] = 0;
+    for (int i = 0; i < n; i++) {
+        ldso_immature_t &q = pts[i];
+        if (q.host < 0 || q.host >= n_hosts) continue;
+        shared_ptr<Feature> feat(new Feature(q.u, q.v, host));
+        float uc = std::min(std::max(q.u, 8.0f), (float) w - 9), vc = std::min(std::max(q.v, 8.0f), (float) h - 9);
+        feat->uv = Vec2f(uc, vc);                                  // keep the constructor's sampling inside the blank image
+        shared_ptr<ImmaturePoint> ip(new ImmaturePoint(host, feat, 1, cam->mpCH));
+        feat->uv = Vec2f(q.u, q.v);
+        memcpy(ip->color, q.color, sizeof(q.color)); memcpy(ip->weights, q.weights, sizeof(q.weights));
+        ip->gradH(0, 0) = q.gradH[0]; ip->gradH(0, 1) = q.gradH[1]; ip->gradH(1, 0) = q.gradH[2]; ip->gradH(1, 1) = q.gradH[3];
+        ip->energyTH = q.energyTH; ip->idepth_min = q.idepth_min; ip->idepth_max = q.idepth_max; ip->quality = q.quality;
+        ip->lastTraceStatus = (ImmaturePointStatus) q.lastTraceStatus;
+        ip->lastTraceUV = Vec2f(q.lastTraceUV[0], q.lastTraceUV[1]); ip->lastTracePixelInterval = q.lastTracePixelInterval;
+        Mat33f M; Vec3f t; Vec2f a;
+        for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) M(r, c) = KRKi[9 * q.host + r * 3 + c]; t[r] = Kt[3 * q.host + r]; }
+        a[0] = aff[2 * q.host]; a[1] = aff[2 * q.host + 1];
+        ImmaturePointStatus st = ip->traceOn(fr->frameHessian, M, t, a, cam->mpCH);
+        q.idepth_min = ip->idepth_min; q.idepth_max = ip->idepth_max; q.quality = ip->quality; q.lastTraceStatus = (int) ip->lastTraceStatus;
+        q.lastTraceUV[0] = ip->lastTraceUV[0]; q.lastTraceUV[1] = ip->lastTraceUV[1]; q.lastTracePixelInterval = ip->lastTracePixelInterval;
+        if (counts && (int) st >= 0 && (int) st < 6) counts[(int) st]++;
+    }
+    detach_images(fr); detach_images(host);
+}
+
+
+// ---- CoarseInitializer::trackFrame (src/frontend/CoarseInitializer.cc, compiled unmodified).  setFirst's pixel selection and
+//      k-d tree are upstream of the hot path: the points arrive as records, and the state setFirst leaves behind (:608-616) is set here.
+namespace {
+struct RefInit {
+    shared_ptr<Camera> cam;
+    shared_ptr<CoarseInitializer> ci;
+    shared_ptr<Frame> first, cur;
+    std::vector<std::vector<float>> firstImgs, newImgs;
+    int w, h, levels;
+};
+static void pnt_from(const ldso_init_point_t &q, Pnt &p) {
+    p.u = q.u; p.v = q.v; p.idepth = q.idepth; p.isGood = q.isGood != 0; p.energy = Vec2f(q.energy[0], q.energy[1]); p.isGood_new = q.isGood_new != 0;
+    p.idepth_new = q.idepth_new; p.energy_new = Vec2f(q.energy_new[0], q.energy_new[1]); p.iR = q.iR; p.iRSumNum = q.iRSumNum;
+    p.lastHessian = q.lastHessian; p.lastHessian_new = q.lastHessian_new; p.maxstep = q.maxstep; p.parent = q.parent; p.parentDist = q.parentDist;
+    for (int i = 0; i < 10; i++) { p.neighbours[i] = q.neighbours[i]; p.neighboursDist[i] = q.neighboursDist[i]; }
+    p.my_type = q.my_type; p.outlierTH = q.outlierTH;
+}
+static void pnt_to(const Pnt &p, ldso_init_point_t &q) {
+    q.u = p.u; q.v = p.v; q.idepth = p.idepth; q.isGood = p.isGood; q.energy[0] = p.energy[0]; q.energy[1] = p.energy[1]; q.isGood_new = p.isGood_new;
+    q.idepth_new = p.idepth_new; q.energy_new[0] = p.energy_new[0]; q.energy_new[1] = p.energy_new[1]; q.iR = p.iR; q.iRSumNum = p.iRSumNum;
+    q.lastHessian = p.lastHessian; q.lastHessian_new = p.lastHessian_new; q.maxstep = p.maxstep; q.parent = p.parent; q.parentDist = p.parentDist;
+    for (int i = 0; i < 10; i++) { q.neighbours[i] = p.neighbours[i]; q.neighboursDist[i] = p.neighboursDist[i]; }
+    q.my_type = p.my_type; q.outlierTH = p.outlierTH; q.pad_ = 0;
+}
+}  // namespace
+
+void *ref_init_create(int w, int h, int levels) {
+    RefInit *I = new RefInit();
+    I->w = w; I->h = h; I->levels = levels;
+    Eigen::Matrix3f K = Eigen::Matrix3f::Identity(); K(0, 2) = w / 2.0f; K(1, 2) = h / 2.0f;
+    setGlobalCalib(w, h, K);
+    pyrLevelsUsed = levels;
+    for (int l = 0; l < levels; l++) { wG[l] = w >> l; hG[l] = h >> l; }
+    I->ci.reset(new CoarseInitializer(w, h));
+    return I;
+}
+void ref_init_destroy(void *p) { RefInit *I = (RefInit *) p; detach_images(I->first); detach_images(I->cur); delete I; }
+void ref_init_set_first(void *p, const float *calib, const float *const *dIp, float exposure, const ldso_init_point_t *const *points, const int *n_points,
+                        float huberTH, int fixAffine) {
+    RefInit *I = (RefInit *) p;
+    pyrLevelsUsed = I->levels;
+    for (int l = 0; l < I->levels; l++) { wG[l] = I->w >> l; hG[l] = I->h >> l; }
+    setting_huberTH = huberTH;
+    I->cam.reset(new Camera(calib[0], calib[1], calib[2], calib[3]));
+    I->cam->CreateCH(I->cam);
+    CoarseInitializer *c = I->ci.get();
+    c->makeK(I->cam->mpCH);
+    detach_images(I->first);
+    I->first = make_frame(I->firstImgs, dIp, I->w, I->h, I->levels, exposure);
+    c->firstFrame = I->first->frameHessian;
+    c->fixAffine = fixAffine != 0;
+    for (int l = 0; l < I->levels; l++) {
+        if (c->points[l] != 0) delete[] c->points[l];
+        c->points[l] = new Pnt[n_points[l] > 0 ? n_points[l] : 1];
+        for (int i = 0; i < n_points[l]; i++) pnt_from(points[l][i], c->points[l][i]);
+        c->numPoints[l] = n_points[l];
+    }
+    // the state CoarseInitializer::setFirst leaves behind (CoarseInitializer.cc:608-616)
+    c->thisToNext = SE3();
+    c->snapped = false;
+    c->frameID = c->snappedAt = 0;
+    for (int i = 0; i < I->levels; i++) c->dGrads[i].setZero();
+}
+int ref_init_track_frame(void *p, const float *const *dIp, float exposure, ldso_init_state_t *s) {
+    RefInit *I = (RefInit *) p;
+    pyrLevelsUsed = I->levels;
+    detach_images(I->cur);
+    I->cur = make_frame(I->newImgs, dIp, I->w, I->h, I->levels, exposure);
+    CoarseInitializer *c = I->ci.get();
+    int r = c->trackFrame(I->cur->frameHessian) ? 1 : 0;
+    if (s) {
+        Eigen::Matrix<double, 3, 4> M = c->thisToNext.matrix3x4();
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 4; j++) s->thisToNext[i * 4 + j] = M(i, j);
+        s->aff_a = c->thisToNext_aff.a; s->aff_b = c->thisToNext_aff.b;
+        s->snapped = c->snapped; s->snappedAt = c->snappedAt; s->frameID = c->frameID; s->ready = r; s->evals = 0; s->pad_ = 0;
+    }
+    return r;
+}
+void ref_init_get_points(void *p, int lvl, ldso_init_point_t *out) {
+    CoarseInitializer *c = ((RefInit *) p)->ci.get();
+    for (int i = 0; i < c->numPoints[lvl]; i++) pnt_to(c->points[lvl][i], out[i]);
 }
 
 }  // extern "C"

@@ -1,4 +1,4 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY (not part of the product path).  PARITY UNPINNED: the reference ships no tests or
+// ORACLE — TEST INFRASTRUCTURE ONLY (not part of the product path).  Pinned to the reference-compiled translation unit by tests/test_ref_pin.py (traceOn byte-identical; trackFrame to 1e-6). The reference ships no tests or
 // fixtures for this function; the restatement is validated by tests/test_trace_oracle.py (depth recovery on synthetic scenes).
 //
 // CPU restatement of ImmaturePoint::traceOn (reference src/internal/ImmaturePoint.cc:47-310) and of the loop of

@@ -1,4 +1,4 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY (see linalg.h header).  PARITY UNPINNED.
+// ORACLE — TEST INFRASTRUCTURE ONLY (see linalg.h header).  Pinned BIT FOR BIT to the reference-compiled CoarseTracker.cc by tests/test_ref_pin.py (see linalg.h).
 // tracker.cc — restatement of src/frontend/CoarseTracker.cc:61-632.
 #include "tracker.h"
 

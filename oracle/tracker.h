@@ -1,4 +1,4 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY (see linalg.h header).  PARITY UNPINNED.
+// ORACLE — TEST INFRASTRUCTURE ONLY (see linalg.h header).  Pinned BIT FOR BIT to the reference-compiled CoarseTracker.cc by tests/test_ref_pin.py (see linalg.h).
 // tracker.h — CPU restatement of CoarseTracker (src/frontend/CoarseTracker.cc:30-632,
 // include/frontend/CoarseTracker.h:17-127): makeK, makeCoarseDepthL0, calcRes, calcGSSSE,
 // trackNewestCoarse.  The object graph inputs of makeCoarseDepthL0 (points with lastResiduals[0] IN)

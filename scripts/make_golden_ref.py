@@ -34,4 +34,19 @@ rng = np.random.default_rng(3)
 color = (rng.random((128, 160)) * 255).astype(np.float32)      # 160x128: three pyramid levels by the rule of GlobalCalib.cc:24
 lv = pr.make_images(color, 3)
 np.savez_compressed('tests/golden/ref_make_images.npz', color=color, **{f"l{l}": lv[l] for l in range(3)})
+# CoarseTracker (calcRes / calcGSSSE / trackNewestCoarse) and ImmaturePoint::traceOn
+from tracker_common import tracker_scenario
+sc = tracker_scenario('small'); w = sc['win']
+tr = pr.RefTracker(w.w, w.h, sc['levels'], w.settings, w.calib)
+tr.set_ref(sc['ref_pyr'], sc['ref_aff'][0], sc['ref_aff'][1], 1.0, sc['pts']); tr.set_new_frame(sc['new_pyr'], 1.0)
+a, b = sc['new_aff']
+rs, n = tr.calc_res(1, np.eye(4), a, b, 20.0); H, bb = tr.calc_gs(1, np.eye(4), a, b)
+t = tr.track(np.eye(4), a, b, sc['levels'] - 1)
+np.savez_compressed('tests/golden/ref_tracker_small.npz', pc_n=np.array([len(tr.pc(l)[0]) for l in range(sc['levels'])]), pc0=np.stack(tr.pc(0)),
+                    rs=rs, n=n, H=H, b=bb, T=t['T'], ab=np.array([t['a'], t['b']]), lastResiduals=t['lastResiduals'], flow=t['flow'])
+win = synth.make_config('small', extra_frames=1)
+pts, _ = synth.make_immature_points(win, 60)
+KRKi, Kt, aff = synth.trace_poses(win, win.F)
+counts = pr.trace_on(pts, win.images[win.F][0], KRKi, Kt, aff)
+np.savez_compressed('tests/golden/ref_trace_small.npz', records=np.frombuffer(pts.tobytes(), dtype=np.uint8), counts=counts)
 print('written', sorted(f for f in os.listdir('tests/golden') if f.startswith('ref_')))

@@ -106,3 +106,64 @@ def test_gpu_make_images_matches_reference_vectors():
     b.set_image_raw(0, g["color"])
     out = b.get_image(0)
     assert np.array_equal(out[1:-1], g["l0"][1:-1]) and np.array_equal(out[:, :, 0], g["l0"][:, :, 0])
+
+
+def _tracker(cls_module):
+    from tracker_common import tracker_scenario
+    sc = tracker_scenario("small"); w = sc["win"]
+    return sc, w
+
+
+def test_oracle_tracker_reproduces_reference_vectors():
+    g = np.load(os.path.join(G, "ref_tracker_small.npz"))
+    sc, w = _tracker(po)
+    tr = po.OracleTracker(w.w, w.h, sc["levels"], w.settings, w.calib)
+    tr.set_ref(sc["ref_pyr"], sc["ref_aff"][0], sc["ref_aff"][1], 1.0, sc["pts"]); tr.set_new_frame(sc["new_pyr"], 1.0)
+    a, b = sc["new_aff"]
+    assert np.array_equal([len(tr.pc(l)[0]) for l in range(sc["levels"])], g["pc_n"]) and np.array_equal(np.stack(tr.pc(0)), g["pc0"])
+    rs, n = tr.calc_res(1, np.eye(4), a, b, 20.0); H, bb = tr.calc_gs(1, np.eye(4), a, b)
+    assert n == int(g["n"]) and np.array_equal(rs, g["rs"]) and np.array_equal(H, g["H"]) and np.array_equal(bb, g["b"])
+    t = tr.track(np.eye(4), a, b, sc["levels"] - 1)
+    assert np.array_equal(t["T"], g["T"]) and np.array_equal([t["a"], t["b"]], g["ab"]) and np.array_equal(t["flow"], g["flow"])
+    assert np.array_equal(t["lastResiduals"], g["lastResiduals"], equal_nan=True)
+
+
+def test_oracle_trace_on_reproduces_reference_vectors():
+    g = np.load(os.path.join(G, "ref_trace_small.npz"))
+    win = synth.make_config('small', extra_frames=1)
+    pts, _ = synth.make_immature_points(win, 60)
+    KRKi, Kt, aff = synth.trace_poses(win, win.F)
+    counts = po.trace_on(pts, win.images[win.F][0], KRKi, Kt, aff)
+    assert np.array_equal(counts, g["counts"]) and pts.tobytes() == g["records"].tobytes()
+
+
+@pytest.mark.gpu
+def test_gpu_tracker_matches_reference_vectors():
+    from ldso_amd import binding
+    g = np.load(os.path.join(G, "ref_tracker_small.npz"))
+    sc, w = _tracker(po)
+    tr = binding.Tracker(w.w, w.h, sc["levels"], w.settings, w.calib)
+    tr.set_ref(sc["ref_pyr"], sc["ref_aff"][0], sc["ref_aff"][1], 1.0, sc["pts"]); tr.set_new_frame(sc["new_pyr"], 1.0)
+    a, b = sc["new_aff"]
+    assert np.array_equal([len(tr.pc(l)[0]) for l in range(sc["levels"])], g["pc_n"])            # point clouds: index-exact
+    u, v, d, c = tr.pc(0)
+    assert np.array_equal(u, g["pc0"][0]) and np.array_equal(v, g["pc0"][1]) and rel(d, g["pc0"][2]) < 1e-6 and rel(c, g["pc0"][3]) < 1e-6
+    rs, n = tr.calc_res(1, np.eye(4), a, b, 20.0); H, bb = tr.calc_gs(1, np.eye(4), a, b)
+    assert n == int(g["n"]) and abs(rs[0] - g["rs"][0]) <= 1e-4 * g["rs"][0]
+    assert blockrel(H, g["H"], 8) < 1e-4 and rel(bb, g["b"]) < 1e-4
+    t = tr.track(np.eye(4), a, b, sc["levels"] - 1)
+    assert np.abs(t["T"] - g["T"]).max() < 2e-2 and abs(t["lastResiduals"][0] - g["lastResiduals"][0]) < 1e-3 * g["lastResiduals"][0]
+
+
+@pytest.mark.gpu
+def test_gpu_trace_on_matches_reference_vectors():
+    from ldso_amd import binding
+    g = np.load(os.path.join(G, "ref_trace_small.npz"))
+    win = synth.make_config('small', extra_frames=1)
+    pts, _ = synth.make_immature_points(win, 60)
+    KRKi, Kt, aff = synth.trace_poses(win, win.F)
+    t = binding.Tracer(win.w, win.h, len(pts))
+    t.set_frame(win.images[win.F][0]); t.set_points(pts)
+    c = t.trace_on(KRKi, Kt, aff)
+    assert np.array_equal(np.asarray(c)[:3], g["counts"][:3])
+    assert t.get_points().tobytes() == g["records"].tobytes()                                     # byte-identical records

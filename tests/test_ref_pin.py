@@ -144,3 +144,78 @@ def test_make_images_bit_exact(w, h, levels):
         # the border rows of the gradient channels are never written by makeImages (memset of 3*w*h BYTES, FrameHessian.cc:50): compare the interior
         _same(a[l][1:-1, :, :], b[l][1:-1, :, :], f"makeImages level {l}")
         _same(a[l][:, :, 0], b[l][:, :, 0], f"makeImages intensity level {l}")
+
+
+@pytest.mark.parametrize("cfg,levels", [("small", None), ("C3", 5)])
+def test_coarse_tracker_bit_exact(cfg, levels):
+    """CoarseTracker.cc compiled unmodified: makeK, makeCoarseDepthL0 (point clouds of every level), calcRes (all warped buffers),
+    calcGSSSE (hand-written SSE accumulation) and the whole trackNewestCoarse LM loop."""
+    from tracker_common import tracker_scenario
+    sc = tracker_scenario(cfg) if levels is None else tracker_scenario(cfg, levels=levels)
+    w = sc["win"]
+    o = po.OracleTracker(w.w, w.h, sc["levels"], w.settings, w.calib); r = pr.RefTracker(w.w, w.h, sc["levels"], w.settings, w.calib)
+    for t in (o, r):
+        t.set_ref(sc["ref_pyr"], sc["ref_aff"][0], sc["ref_aff"][1], 1.0, sc["pts"]); t.set_new_frame(sc["new_pyr"], 1.0)
+    for a, b, n in zip(o.K(), r.K(), ("fx", "fy", "cx", "cy")):
+        _same(a, b, "makeK " + n)
+    for l in range(sc["levels"]):
+        for a, b, n in zip(o.pc(l), r.pc(l), ("pc_u", "pc_v", "pc_idepth", "pc_color")):
+            _same(a, b, f"{n}[{l}]")
+    a, b = sc["new_aff"]
+    T0 = np.eye(4)
+    for l in range(sc["levels"]):
+        (rso, no), (rsr, nr) = o.calc_res(l, T0, a, b, 20.0), r.calc_res(l, T0, a, b, 20.0)
+        assert no == nr
+        _same(rso, rsr, f"calcRes[{l}]")
+        wo, wr = o.warped(no), r.warped(nr)
+        for k in wo:
+            _same(wo[k], wr[k], f"buf_warped_{k}[{l}]")
+        (Ho, bo), (Hr, br) = o.calc_gs(l, T0, a, b), r.calc_gs(l, T0, a, b)
+        _same(Ho, Hr, f"calcGSSSE H[{l}]"); _same(bo, br, f"calcGSSSE b[{l}]")
+    to, tr = o.track(T0, a, b, sc["levels"] - 1), r.track(T0, a, b, sc["levels"] - 1)
+    assert to["ok"] == tr["ok"] and to["a"] == tr["a"] and to["b"] == tr["b"]
+    _same(to["T"], tr["T"], "trackNewestCoarse pose"); _same(to["flow"], tr["flow"], "lastFlowIndicators")
+    assert np.array_equal(to["lastResiduals"], tr["lastResiduals"], equal_nan=True)
+
+
+def test_trace_on_bit_exact():
+    """ImmaturePoint::traceOn (ImmaturePoint.cc:47-310): epipolar search, Gauss-Newton refinement and interval update of 300
+    immature points against a new frame - the records after the call are byte-identical."""
+    win = synth.make_config('small', extra_frames=1)
+    pts, _ = synth.make_immature_points(win, 60)
+    KRKi, Kt, aff = synth.trace_poses(win, win.F)
+    a, b = pts.copy(), pts.copy()
+    ca = po.trace_on(a, win.images[win.F][0], KRKi, Kt, aff)
+    cb = pr.trace_on(b, win.images[win.F][0], KRKi, Kt, aff)
+    assert np.array_equal(ca, cb) and ca[0] > 100
+    assert a.tobytes() == b.tobytes()
+    # second round on the updated intervals (the GN refinement and the skip / bad-condition exits are reached from here)
+    ca = po.trace_on(a, win.images[win.F][0], KRKi, Kt, aff); cb = pr.trace_on(b, win.images[win.F][0], KRKi, Kt, aff)
+    assert np.array_equal(ca, cb) and a.tobytes() == b.tobytes()
+
+
+def test_coarse_initializer_tracks_the_reference():
+    """CoarseInitializer::trackFrame (CoarseInitializer.cc compiled unmodified) over a 5-frame sequence from identical point records:
+    identical control flow (snapping frame, frame counters, isGood sets), pose to 1e-6, inverse depths to 1e-4.  Not bit-exact: the
+    restatement associates a few float expressions of calcResAndGS differently from the shim's operators (observed 4e-9 after the
+    first frame, 4e-7 after the fifth)."""
+    seq = synth.make_init_sequence(160, 120, n_frames=5, fx=100.0, seed=11, levels=3)
+    L = seq['levels']
+    pyr0 = synth.make_images(seq['first'], L)
+    ipts = synth.select_init_points(pyr0)
+    o = po.OracleInitializer(160, 120, L); o.set_first(seq['K4'], pyr0, 1.0, ipts)
+    r = pr.RefInitializer(160, 120, L); r.set_first(seq['K4'], pyr0, 1.0, ipts)
+    snapped_seen = False
+    for k in range(5):
+        pyr = synth.make_images(seq['frames'][k], L)
+        o.set_new_frame(pyr, 1.0)
+        so, sr = o.track_frame(), r.track_frame(pyr, 1.0)
+        for f in ("snapped", "snappedAt", "frameID", "ready"):
+            assert int(so[f]) == int(sr[f]), (k, f)
+        assert np.abs(so["thisToNext"] - sr["thisToNext"]).max() < 1e-6 and abs(so["aff_a"] - sr["aff_a"]) < 1e-6 and abs(so["aff_b"] - sr["aff_b"]) < 1e-5
+        snapped_seen |= bool(sr["snapped"])
+        for l in range(L):
+            a, b = o.points(l), r.points(l)
+            assert np.array_equal(a["isGood"], b["isGood"]) and np.array_equal(a["isGood_new"], b["isGood_new"])
+            _close(a["idepth"], b["idepth"], 1e-4, f"idepth[{l}] frame {k}"); _close(a["iR"], b["iR"], 1e-4, f"iR[{l}] frame {k}")
+    assert snapped_seen
