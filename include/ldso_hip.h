@@ -147,6 +147,12 @@ int ldso_ba_sync(ldso_ba_t *h);
 size_t ldso_ba_gn_reduce_doubles(ldso_ba_t *h);
 int ldso_ba_gn_reduce_local(ldso_ba_t *h, void *reduce_buf_dev, double lambda);
 int ldso_ba_gn_solve_reduced(ldso_ba_t *h, const void *reduce_buf_dev, int iteration, double lambda);
+/* The same sharded iteration with the collective inside, for a C / C++ host (north_star: host code stays C++): `iters` forced
+ * Gauss-Newton iterations of this rank's shard - k_reduce into the handle's all-reduce buffer, ncclAllReduce (RCCL, fp64 sum, in
+ * place, ~29 KB + 8 P bytes at F = 7) on the handle's stream, replicated solve, linearize of the shard - enqueued without a host
+ * synchronisation.  `nccl_comm` is an ncclComm_t created by the caller (one rank per GPU, ncclCommInitRank); ncclAllReduce is
+ * resolved at run time from the RCCL already in the process, else from librccl.so.  Every rank calls it with the same arguments. */
+int ldso_ba_enqueue_gn_rccl(ldso_ba_t *h, void *nccl_comm, int first_iteration, int iters);
 int ldso_ba_reduce_local(ldso_ba_t *h, void *reduce_buf_dev);
 int ldso_ba_solve_reduced(ldso_ba_t *h, const void *reduce_buf_dev, int iteration, double lambda, int do_step);
 

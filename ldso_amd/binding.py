@@ -229,6 +229,9 @@ class BA:
     def gn_solve_reduced(self, buf_ptr: int, iteration, lam=1e-1):
         _chk(self.L.ldso_ba_gn_solve_reduced(self.h, C.c_void_p(buf_ptr), C.c_int(iteration), C.c_double(lam)))
 
+    def enqueue_gn_rccl(self, comm_ptr: int, first_iteration, iters):
+        _chk(self.L.ldso_ba_enqueue_gn_rccl(self.h, C.c_void_p(comm_ptr), C.c_int(first_iteration), C.c_int(iters)))
+
     def reduce_local(self, buf_ptr: int):
         _chk(self.L.ldso_ba_reduce_local(self.h, C.c_void_p(buf_ptr)))
 

@@ -13,6 +13,8 @@
 #include <cstdio>
 #include <cmath>
 #include <algorithm>
+#include <dlfcn.h>
+#include <rccl/rccl.h>      // types only: ncclAllReduce is resolved at run time (the process may already hold an RCCL, e.g. PyTorch's)
 #include "../../include/ldso_hip.h"
 #include "ba_dev.h"
 #include "ba_solve.h"
@@ -80,6 +82,7 @@ struct ldso_ba {
     int tcnt[5] = {0, 0, 0, 0, 0};
     int lastIterations = 0;
     bool noFusedLaunch = false;        // debug: k_reduce and k_gn_solve as two launches even where the fused k_reduce_solve applies
+    double *distBuf = nullptr;         // ldso_ba_enqueue_gn_rccl: all-reduce buffer [HFinal | bFinal | scalars | candidates]
     double neverStop = 1e300;          // source of the LD_SC_STOP reset (outlives the asynchronous copy)
 };
 
@@ -226,6 +229,7 @@ int ldso_ba_destroy(ldso_ba_t *H) {
     for (int i = 0; i < LD_MAXF; i++) if (H->imgOwned[i] && H->imgSlots[i]) hipFree(H->imgSlots[i]);
     if (H->d_color) hipFree(H->d_color);
     if (H->d_act) hipFree(H->d_act);
+    if (H->distBuf) hipFree(H->distBuf);
     for (auto &t : H->timers) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
     if (H->ownStream && H->stream) hipStreamDestroy(H->stream);
     delete H;
@@ -830,6 +834,36 @@ int ldso_ba_gn_solve_reduced(ldso_ba_t *H, const void *buf, int iteration, doubl
     return LDSO_OK;
 }
 
+// ---- the sharded iteration with the collective inside, for a C / C++ host (no torch): RCCL's ncclAllReduce on the handle's stream ----
+typedef ncclResult_t (*allreduce_fn)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
+static allreduce_fn find_allreduce() {
+    static allreduce_fn fn = nullptr;
+    if (fn) return fn;
+    fn = (allreduce_fn) dlsym(RTLD_DEFAULT, "ncclAllReduce");          // an RCCL already in the process (the caller created `comm` with it)
+    if (!fn) {
+        void *lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (lib) fn = (allreduce_fn) dlsym(lib, "ncclAllReduce");
+    }
+    return fn;
+}
+
+int ldso_ba_enqueue_gn_rccl(ldso_ba_t *H, void *nccl_comm, int first_iteration, int iters) {
+    REQ(H && nccl_comm && H->D.P > 0 && iters >= 0, "ldso_ba_enqueue_gn_rccl: bad arguments");
+    CHK(hipSetDevice(H->device));
+    allreduce_fn allreduce = find_allreduce();
+    if (!allreduce) { ldso_set_error("ldso_ba_enqueue_gn_rccl: ncclAllReduce not found (librccl.so)"); return LDSO_E_UNSUPPORTED; }
+    const size_t nd = ldso_ba_gn_reduce_doubles(H);
+    if (!H->distBuf) { void *q = nullptr; CHK(hipMalloc(&q, ((size_t) (8 * H->maxF + 4) * (8 * H->maxF + 5) + 8 + H->maxP) * sizeof(double))); H->distBuf = (double *) q; }
+    for (int i = 0; i < iters; i++) {
+        RUN(ldso_ba_gn_reduce_local(H, H->distBuf, 1e-1));
+        const ncclResult_t r = allreduce(H->distBuf, H->distBuf, nd, ncclDouble, ncclSum, (ncclComm_t) nccl_comm, H->stream);
+        if (r != ncclSuccess) { ldso_set_error("ldso_ba_enqueue_gn_rccl: ncclAllReduce failed"); return LDSO_E_HIP; }
+        RUN(ldso_ba_gn_solve_reduced(H, H->distBuf, first_iteration + i, 1e-1));
+    }
+    return LDSO_OK;
+}
+
 // FullSystem::optimizeImmaturePoint (FullSystem.cc:892-1010) for n immature points against the key frames of the window that is
 // resident in the handle (ldso_ba_set_image*, ldso_ba_set_window, ldso_ba_set_frames: images, calibration, current poses).
 int ldso_ba_activate_points(ldso_ba_t *H, int n, const ldso_immature_t *pts, int min_obs, float min_idepth_hessian, int gn_iterations, ldso_activation_t *out) {
@@ -840,6 +874,7 @@ int ldso_ba_activate_points(ldso_ba_t *H, int n, const ldso_immature_t *pts, int
     for (int f = 0; f < H->D.F; f++) REQ(H->B.img[f] != nullptr, "ldso_ba_activate_points: a key-frame image is missing");
     if (n > H->actCap) {
         if (H->d_act) hipFree(H->d_act);
+    if (H->distBuf) hipFree(H->distBuf);
         H->d_act = nullptr; H->actCap = 0;
         CHK(hipMalloc(&H->d_act, (size_t) n * (sizeof(ldso_immature_t) + sizeof(ldso_activation_t))));
         H->actCap = n;

@@ -392,6 +392,40 @@ def test_prior_survives_set_frames(small):
     assert rc != ra                                                # the prior matters on this window
 
 
+def test_enqueue_gn_rccl_with_a_one_rank_communicator(small):
+    """The C / C++ entry of the sharded iteration (ncclAllReduce inside, no torch.distributed): with a one-rank RCCL communicator it
+    must reproduce the single-GPU fast path.  (RCCL refuses two ranks on one device, so more ranks need more GPUs.)"""
+    import ctypes as C
+    import os
+    import torch
+    rccl = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"), mode=C.RTLD_GLOBAL)
+
+    class UID(C.Structure):
+        _fields_ = [("b", C.c_char * 128)]
+    uid = UID()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UID, C.c_int]
+    torch.cuda.set_device(0)
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        win = synth.add_synthetic_prior(copy.deepcopy(small))
+        a = binding.BA.from_window(win); b = binding.BA.from_window(win)
+        for g in (a, b):
+            g.collect_active(); g.linearize_all(False); g.apply_res()
+        a.enqueue_gn(0, 4); a.sync()
+        b.enqueue_gn_rccl(comm.value, 0, 4); b.sync()
+        fa, fb = a.get_frames(), b.get_frames()
+        assert rel(fb["frames"]["state"], fa["frames"]["state"]) < 5e-3          # same band as the two-handle test (different partial-sum boundaries)
+        assert rel(fb["frames"]["frameEnergyTH"], fa["frames"]["frameEnergyTH"]) < 1e-3
+        assert rel(b.get_points()["idepth"], a.get_points()["idepth"]) < 5e-3
+        ea = a.get_residuals()["out"]["state_NewEnergy"].astype(np.float64).sum(); eb = b.get_residuals()["out"]["state_NewEnergy"].astype(np.float64).sum()
+        assert abs(ea - eb) <= 1e-4 * ea
+    finally:
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        rccl.ncclCommDestroy(comm)
+
+
 def test_edge_points_without_residuals_and_oob(tiny):
     """points with no residuals, OOB residuals (point projected outside the image) and an all-OUTLIER point."""
     w2 = copy.deepcopy(tiny)
