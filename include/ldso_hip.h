@@ -109,6 +109,10 @@ int ldso_ba_solve_system(ldso_ba_t *h, int iteration, double lambda);
 int ldso_ba_do_step(ldso_ba_t *h, int *canbreak_out);
 /* FullSystem::loadSateBackup (FullSystem.cc:1675-1692). */
 int ldso_ba_load_state_backup(ldso_ba_t *h);
+/* EnergyFunctional::calcMEnergyF and calcLEnergyF_MT (EnergyFunctional.cc:353-378, 627-682) at the current state: the prior /
+ * linearised-residual energies of the LM accept test (FullSystem.cc:805-826).  ldso_ba_optimize uses them when
+ * settings.forceAcceptStep == 0 (accept / loadSateBackup + lambda *= 100, one host round trip per stage). */
+int ldso_ba_calc_lm_energies(ldso_ba_t *h, double *energy_M, double *energy_L);
 /* FullSystem::optimize(mnumOptIts) (FullSystem.cc:725-864) with everything on the device and no host
  * synchronisation inside the loop.  force_all_iterations != 0 ignores `canbreak` (BASELINE config C3).
  * rmse_out = the function's return value; iterations_out = GN iterations executed. */

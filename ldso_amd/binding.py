@@ -180,6 +180,11 @@ class BA:
         _chk(self.L.ldso_ba_optimize(self.h, C.c_int(niters), C.c_int(1 if force_all else 0), C.byref(rm), C.byref(it)))
         return rm.value, it.value
 
+    def calc_lm_energies(self):
+        m, l = C.c_double(), C.c_double()
+        _chk(self.L.ldso_ba_calc_lm_energies(self.h, C.byref(m), C.byref(l)))
+        return m.value, l.value
+
     def marginalize_points(self, flags):
         """EnergyFunctional::marginalizePointsF for the flagged points -> (HM, bM)"""
         flags = np.ascontiguousarray(flags, np.int32)

@@ -32,6 +32,7 @@ hipError_t ba_launch_acc_init(const BaPtrs &B, const BaDims &D, const GnInit &gi
 hipError_t ba_launch_gn_export(const BaPtrs &B, const BaDims &D, const ResSet &S, double *tail, hipStream_t st);
 hipError_t ba_launch_activate(const BaPtrs &B, const BaDims &D, const ldso_settings_t &S, const ldso_immature_t *d_pts, ldso_activation_t *d_out, int n, int minObs,
                               float minIdepthH_act, int GNIts, hipStream_t st);
+hipError_t ba_launch_lm_energies(const BaPtrs &B, const BaDims &D, const ResSet &S, float calibPrior, bool hasPrior, hipStream_t st);
 hipError_t ba_launch_marg_update(const BaPtrs &B, const BaDims &D, double w, hipStream_t st);
 hipError_t ba_launch_gn_solve(const BaPtrs &B, const BaDims &D, const ResSet &S, const ldso_settings_t &St, const SolveArgs &A, hipStream_t st);
 hipError_t ba_launch_reduce_solve(const BaPtrs &B, const BaDims &D, const ResSet &S, const ldso_settings_t &St, const SolveArgs &A, const ChunkStarts &chunkStart,
@@ -709,12 +710,79 @@ int ldso_ba_sync(ldso_ba_t *H) {
     return LDSO_OK;
 }
 
+// EnergyFunctional::calcMEnergyF / calcLEnergyF_MT (EnergyFunctional.cc:353-378, 627-682) at the current state: the two extra
+// terms of the LM accept test (FullSystem.cc:805-826).  (With setting_forceAceptStep the reference skips them, FullSystem.cc:1694-1704.)
+int ldso_ba_calc_lm_energies(ldso_ba_t *H, double *energy_M, double *energy_L) {
+    REQ(H && H->D.P > 0, "no window");
+    CHK(hipSetDevice(H->device));
+    CHK(ba_launch_lm_energies(H->B, H->D, H->sets[H->cur], H->settings.initialCalibHessian, H->hasPrior, H->stream));
+    double sc[16];
+    RUN(read_scalars(H, sc));
+    if (energy_M) *energy_M = sc[12];
+    if (energy_L) *energy_L = sc[13];
+    return LDSO_OK;
+}
+
+// FullSystem::optimize with setting_forceAceptStep = false (FullSystem.cc:777-831): every iteration is accepted or rejected on
+// E_P + E_L + E_M; a rejected step restores the backup (loadSateBackup), re-linearises and multiplies lambda by 100.  One host
+// round trip per stage - this is not the default schedule of the reference (Setting.cc:73) and not the timed path.
+static int optimize_lm(ldso_ba *H, int mnumOptIts, int force_all, float *rmse_out, int *iters_out) {
+    const int F = H->D.F;
+    if (!force_all) { if (F < 3) mnumOptIts = 20; if (F < 4) mnumOptIts = 15; }
+    REQ(mnumOptIts + 2 < 64, "too many iterations");
+    std::vector<double> elog;
+    RUN(ldso_ba_collect_active(H));
+    double lastE = 0, lastL = 0, lastM = 0;
+    RUN(ldso_ba_linearize_all(H, 0, &lastE));
+    RUN(ldso_ba_calc_lm_energies(H, &lastM, &lastL));
+    elog.push_back(lastE);
+    RUN(ldso_ba_apply_res(H));
+    double lambda = 1e-1;
+    int done = 0;
+    for (int it = 0; it < mnumOptIts; it++) {
+        RUN(ldso_ba_backup_state(H));
+        RUN(ldso_ba_solve_system(H, it, lambda));
+        int canbreak = 0;
+        RUN(ldso_ba_do_step(H, &canbreak));
+        double newE = 0, newL = 0, newM = 0;
+        RUN(ldso_ba_linearize_all(H, 0, &newE));
+        RUN(ldso_ba_calc_lm_energies(H, &newM, &newL));
+        elog.push_back(newE);
+        done = it + 1;
+        if (newE + newL + newM < lastE + lastL + lastM) {
+            RUN(ldso_ba_apply_res(H));
+            lastE = newE; lastL = newL; lastM = newM;
+            lambda *= 0.25;
+        } else {
+            RUN(ldso_ba_load_state_backup(H));
+            RUN(ldso_ba_linearize_all(H, 0, &lastE));
+            H->pendingApply = false;                 // the re-linearisation at the restored state is not applied (FullSystem.cc:821-826)
+            RUN(ldso_ba_calc_lm_energies(H, &lastM, &lastL));
+            lambda *= 1e2;
+        }
+        if (canbreak && it >= H->settings.minOptIterations && !force_all) break;
+    }
+    RUN(launch_solve(H, H->sets[H->cur], SK_REANCHOR | SK_ADJ | SK_NONULLSPACE | SK_PRECALC));
+    double Efix = 0;
+    RUN(ldso_ba_linearize_all(H, 1, &Efix));
+    elog.push_back(Efix);
+    CHK(hipMemsetAsync(H->B.energyLog, 0, 64 * 8, H->stream));
+    CHK(hipMemcpyAsync(H->B.energyLog, elog.data(), elog.size() * sizeof(double), hipMemcpyHostToDevice, H->stream));
+    double sc[16];
+    RUN(read_scalars(H, sc));
+    H->lastIterations = (int) elog.size() - 2;
+    if (iters_out) *iters_out = done;
+    if (rmse_out) *rmse_out = sqrtf((float) (sc[0] / (8 * sc[9])));
+    if (!std::isfinite(sc[0]) || sc[4] != 0.0) return LDSO_E_NONFINITE;
+    return LDSO_OK;
+}
+
 int ldso_ba_optimize(ldso_ba_t *H, int mnumOptIts, int force_all, float *rmse_out, int *iters_out) {
     REQ(H && H->D.P > 0, "no window");
     REQ_UNSHARDED("ldso_ba_optimize");
     CHK(hipSetDevice(H->device));
     CHK(hipMemsetAsync(H->d_waitCtr, 0, 4 * sizeof(int), H->stream));      // an aborted launch must not leave the producer counter armed
-    if (!H->settings.forceAcceptStep) { ldso_set_error("ldso_ba_optimize runs the forceAcceptStep=true schedule; drive LM rejection through the step-wise calls"); return LDSO_E_UNSUPPORTED; }
+    if (!H->settings.forceAcceptStep) return optimize_lm(H, mnumOptIts, force_all, rmse_out, iters_out);
     const int F = H->D.F;
     if (F < 2) { if (rmse_out) *rmse_out = 0; return LDSO_OK; }
     if (!force_all) { if (F < 3) mnumOptIts = 20; if (F < 4) mnumOptIts = 15; }

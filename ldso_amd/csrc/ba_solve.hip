@@ -998,6 +998,65 @@ __global__ __launch_bounds__(256) void k_point_step(BaPtrs B, BaDims D, ResSet S
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// k_lm_energies — the two energies of the LM accept test (FullSystem.cc:805-826):
+//   scalars[12] = EnergyFunctional::calcMEnergyF (EnergyFunctional.cc:353-359):  delta^T (2 b_M + H_M delta)
+//   scalars[13] = EnergyFunctional::calcLEnergyF_MT (:361-378, calcLEnergyPt :627-682): prior terms of frames / calibration /
+//                 points + the linearised residuals' (2 res_toZeroF + J delta) . J delta
+// One workgroup; sums in double (the reference accumulates the point part in float Accumulator11: same value to ~1e-6).
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_lm_energies(BaPtrs B, BaDims D, ResSet S, float calibPrior, int hasPrior) {
+    __shared__ double sDelta[8 * LD_MAXF + 4];
+    __shared__ double sRed[8];
+    const int tid = threadIdx.x, F = D.F, n = D.n;
+    for (int i = tid; i < n; i += 256) sDelta[i] = (i < 4) ? (double) B.calib->cDeltaF[i] : B.frames[(i - 4) >> 3].delta[(i - 4) & 7];
+    __syncthreads();
+    // ---- M energy ----
+    double em = 0.0;
+    if (hasPrior) for (int i = tid; i < n; i += 256) {
+        double hd = 0.0;
+        for (int j = 0; j < n; j++) hd += B.HM[(size_t) i * n + j] * sDelta[j];
+        em += sDelta[i] * (2.0 * B.bM[i] + hd);
+    }
+    // ---- L energy: frame and calibration priors ----
+    double el = 0.0;
+    for (int i = tid; i < F * 8; i += 256) { const DevFrame &f = B.frames[i >> 3]; const double dp = f.delta_prior[i & 7]; el += dp * f.prior[i & 7] * dp; }
+    if (tid < 4) { const float c = B.calib->cDeltaF[tid]; el += (double) (c * calibPrior * c); }
+    // ---- L energy: points ----
+    const float cD0 = B.calib->cDeltaF[0], cD1 = B.calib->cDeltaF[1], cD2 = B.calib->cDeltaF[2], cD3 = B.calib->cDeltaF[3];
+    for (int p = D.pBegin + tid; p < D.pEnd; p += 256) {
+        const float dd = B.pidepth[p] - B.pidepth_zero[p];
+        const int h = B.phost[p];
+        double e = 0.0;
+        for (int t = 0; t < F; t++) {
+            const int slot = p * D.FS + t;
+            if (B.rflat[slot] < 0 || !B.rlin[slot] || !S.active[slot]) continue;
+            const ldso_rawjac_t &J = B.Jlin[B.rlidx[slot]];
+            const float *rtz = B.rtz + (size_t) B.rlidx[slot] * 8;
+            const float *dp = B.pairs[h * F + t].dp;
+            float jx = 0, jy = 0;
+            for (int i = 0; i < 6; i++) { jx += J.Jpdxi[0][i] * dp[i]; jy += J.Jpdxi[1][i] * dp[i]; }
+            jx = jx + (((J.Jpdc[0][0] * cD0 + J.Jpdc[0][1] * cD1) + J.Jpdc[0][2] * cD2) + J.Jpdc[0][3] * cD3) + J.Jpdd[0] * dd;
+            jy = jy + (((J.Jpdc[1][0] * cD0 + J.Jpdc[1][1] * cD1) + J.Jpdc[1][2] * cD2) + J.Jpdc[1][3] * cD3) + J.Jpdd[1] * dd;
+            for (int i = 0; i < 8; i++) {
+                const float Jd = ((J.JIdx[0][i] * jx + J.JIdx[1][i] * jy) + J.JabF[0][i] * dp[6]) + J.JabF[1][i] * dp[7];
+                e += (double) (Jd * ((rtz[i] + rtz[i]) + Jd));
+            }
+        }
+        e += (double) (dd * dd * B.ppriorF[p]);
+        el += e;
+    }
+    em = wave_sum(em); el = wave_sum(el);
+    if ((tid & 63) == 0) { sRed[tid >> 6] = em; sRed[4 + (tid >> 6)] = el; }
+    __syncthreads();
+    if (tid == 0) { B.scalars[12] = sRed[0] + sRed[1] + sRed[2] + sRed[3]; B.scalars[13] = sRed[4] + sRed[5] + sRed[6] + sRed[7]; }
+}
+
+hipError_t ba_launch_lm_energies(const BaPtrs &B, const BaDims &D, const ResSet &S, float calibPrior, bool hasPrior, hipStream_t st) {
+    hipLaunchKernelGGL(k_lm_energies, dim3(1), dim3(256), 0, st, B, D, S, calibPrior, hasPrior ? 1 : 0);
+    return hipGetLastError();
+}
+
 static size_t solve_lds_common(const BaDims &D) {
     const int n = D.n, NBsel = (n + 1 <= 64) ? 4 : (n + 1 <= 112) ? 7 : 9;
     return solve_core_lds_doubles(NBsel, n) * sizeof(double);

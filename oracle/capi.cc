@@ -170,6 +170,13 @@ int orc_energy_log(void *h, double *out, int cap) {
     return fs.energyLog.size();
 }
 
+// EnergyFunctional::calcMEnergyF / calcLEnergyF_MT (EnergyFunctional.cc:353-378) regardless of setting_forceAceptStep
+void orc_calc_lm_energies(void *h, double *EM, double *EL) {
+    EnergyFunctional *ef = ((OrcWindow *) h)->fs.ef;
+    *EM = ef->calcMEnergyF();
+    *EL = ef->calcLEnergyF_MT();
+}
+
 int orc_num_frames(void *h) { return ((OrcWindow *) h)->fs.ef->nFrames; }
 int orc_num_active_residuals(void *h) { return ((OrcWindow *) h)->fs.activeResiduals.size(); }
 int orc_num_all_points(void *h) { return ((OrcWindow *) h)->fs.ef->allPoints.size(); }

@@ -117,6 +117,11 @@ class OracleWindow:
     def solve_system(self, iteration: int, lam: float = 1e-1):
         self.L.orc_solve_system(self.h, C.c_int(iteration), C.c_double(lam))
 
+    def calc_lm_energies(self):
+        m, l = C.c_double(), C.c_double()
+        self.L.orc_calc_lm_energies(self.h, C.byref(m), C.byref(l))
+        return m.value, l.value
+
     def set_force_all_iterations(self, v=True):
         self.L.orc_set_force_all_iterations(self.h, C.c_int(1 if v else 0))
 

@@ -94,6 +94,11 @@ class RefWindow:
     def solve_system(self, iteration: int, lam: float = 1e-1):
         self.L.ref_solve_system(self.h, C.c_int(iteration), C.c_double(lam))
 
+    def calc_lm_energies(self):
+        m, l = C.c_double(), C.c_double()
+        self.L.ref_calc_lm_energies(self.h, C.byref(m), C.byref(l))
+        return m.value, l.value
+
     def num_frames(self):
         return int(self.L.ref_num_frames(self.h))
 

@@ -315,6 +315,12 @@ void ref_solve_system(void *h, int iteration, double lambda) {
     W->ef->solveSystemF(iteration, lambda, W->Hcalib);
 }
 
+void ref_calc_lm_energies(void *h, double *EM, double *EL) {
+    EnergyFunctional *ef = ((RefWindow *) h)->ef.get();
+    *EM = ef->calcMEnergyF();
+    *EL = ef->calcLEnergyF_MT();
+}
+
 int ref_num_frames(void *h) { return ((RefWindow *) h)->ef->nFrames; }
 void ref_counts(void *h, int *a, int *l, int *m) { auto ef = ((RefWindow *) h)->ef; *a = ef->resInA; *l = ef->resInL; *m = ef->resInM; }
 

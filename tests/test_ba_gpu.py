@@ -392,6 +392,30 @@ def test_prior_survives_set_frames(small):
     assert rc != ra                                                # the prior matters on this window
 
 
+def test_lm_energies_and_rejection_path(small):
+    """setting_forceAceptStep = false (FullSystem.cc:805-826): calcMEnergyF / calcLEnergyF_MT on the device, and ldso_ba_optimize
+    accepting / rejecting steps like the oracle's loop.  The window (a third of the residuals frozen at a perturbed linearisation
+    point + a marginalisation prior) makes the second Gauss-Newton step overshoot, so steps ARE rejected."""
+    w = po.make_mixed_window(synth.add_synthetic_prior(copy.deepcopy(small)))
+    o, g = po.OracleWindow(w), binding.BA.from_window(w)
+    (mo, lo), (mg, lg) = o.calc_lm_energies(), g.calc_lm_energies()
+    assert abs(mg - mo) <= 1e-9 * abs(mo) and abs(lg - lo) <= 1e-5 * abs(lo) and lo > 0 and mo != 0
+    w.settings = w.settings.copy(); w.settings["forceAcceptStep"] = 0
+    o = po.OracleWindow(w); o.set_force_all_iterations(True)
+    g = binding.BA.from_window(w)
+    rmo = o.optimize(6); rmg, its = g.optimize(6, force_all=True)
+    eo, eg = o.energy_log(), g.get_energy_log()
+    assert its == 6 and len(eo) == len(eg) == 8
+    assert eo[2] > 2 * eo[1]                                                     # the overshooting step ...
+    assert abs(eo[-1] - eo[1]) <= 1e-9 * eo[1]                                   # ... was rejected: the window ends at the last accepted state
+    assert np.all(np.abs(eg - eo) <= 5e-4 * np.abs(eo)), (eo, eg)
+    assert abs(rmg - rmo) <= 5e-4 * rmo
+    ro, rg = o.get_residuals(False), g.get_residuals()
+    assert (ro["state_state"] != rg["state_state"]).sum() <= 2e-3 * w.R
+    fo, fg = o.get_frames(), g.get_frames()
+    assert rel(fg["frames"]["state"], fo["frames"]["state"]) < 5e-3
+
+
 def test_enqueue_gn_rccl_with_a_one_rank_communicator(small):
     """The C / C++ entry of the sharded iteration (ncclAllReduce inside, no torch.distributed): with a one-rank RCCL communicator it
     must reproduce the single-GPU fast path.  (RCCL refuses two ranks on one device, so more ranks need more GPUs.)"""

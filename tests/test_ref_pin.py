@@ -92,6 +92,13 @@ def test_stage_bit_exact_with_prior_and_linearized_residuals(small):
     assert r.counts()[1] > 0
 
 
+def test_lm_energies_pinned(small):
+    """calcMEnergyF / calcLEnergyF_MT (EnergyFunctional.cc:353-378, 627-682: hand-written SSE over the linearised residuals)."""
+    w = po.make_mixed_window(synth.add_synthetic_prior(copy.deepcopy(small)))
+    (mo, lo), (mr, lr) = po.OracleWindow(w).calc_lm_energies(), pr.RefWindow(w).calc_lm_energies()
+    assert mo == mr and abs(lo - lr) <= 1e-9 * abs(lr) and lr > 0
+
+
 def test_full_size_c3_bit_exact():
     """BASELINE configs[2] (7 KF x 2000 pt, 640x480) with the marginalisation prior: the bench window."""
     _stage(synth.add_synthetic_prior(copy.deepcopy(get_window("C3"))))
