@@ -279,6 +279,10 @@ def main():
                     raise
                 except Exception as ex:
                     out[key] = {"error": repr(ex)}
+            try:
+                out["batched"] = batched_line(args, local_rank)
+            except Exception as ex:
+                out["batched"] = {"error": repr(ex)}
             for key, fn in (("tracker", tracker_line), ("tracer", tracer_line), ("initializer", initializer_line)):
                 try:
                     out[key] = fn()          # informational lines; never fail the BA metric on them
@@ -287,6 +291,46 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def batched_line(args, local_rank, Bs=(8, 32)):
+    """Batched windows: B independent C3 windows per launch (ldso_ba_batch_*), three launches per iteration for the
+    whole batch.  Aggregate GN iterations/s over the batch and the roofline of the batched k_linearize (B x the algorithmic bytes of
+    one window / its launch time)."""
+    from ldso_amd import synth, binding
+    win = synth.make_config("C3")
+    synth.add_synthetic_prior(win)
+    tstream = torch.cuda.Stream()
+    torch.cuda.set_stream(tstream)
+    out = {"workload": f"B independent C3 windows ({win.F} KF x {win.P} pt, R = {win.R}) per launch, forced GN iterations"}
+    handles = []
+    for B in Bs:
+        while len(handles) < B:
+            g = binding.BA.from_window(win, device=local_rank, stream=tstream.cuda_stream)
+            g.collect_active(); g.linearize_all(False); g.apply_res()
+            handles.append(g)
+        bt = binding.BABatch(handles[:B])
+        bt.enqueue_gn(0, 10); torch.cuda.synchronize()
+        blocks, total, steps = [], 0.0, 50
+        while total < 0.05 or len(blocks) < 3:
+            t0 = time.perf_counter()
+            bt.enqueue_gn(2, steps)
+            torch.cuda.synchronize()
+            d = time.perf_counter() - t0
+            blocks.append(d); total += d
+        dt = float(np.median(blocks))
+        lin_us = bt.time_linearize(50)
+        alg = B * (436 * win.R + 112 * win.P)
+        ok = bool(np.all(np.isfinite(handles[B - 1].get_frames()["frames"]["state"])))
+        out[f"B{B}"] = {"gn_iters_per_s_aggregate": round(B * steps / dt, 1), "ms_per_batch_iteration": round(dt / steps * 1e3, 5),
+                        "mresiduals_per_s": round(B * steps * win.R / dt / 1e6, 1),
+                        "k_linearize": {"avg_launch_us": round(lin_us, 3), "algorithmic_bytes_per_launch": alg, "achieved_GBps": round(alg / (lin_us * 1e-6) / 1e9, 1),
+                                        "frac_of_8TBps": round(alg / (lin_us * 1e-6) / 1e9 / 8000.0, 5)},
+                        "state_finite": ok}
+        bt.close()
+    for g in handles:
+        g.close()
+    return out
 
 
 def tracker_line():

@@ -151,6 +151,18 @@ int ldso_ba_sync(ldso_ba_t *h);
 size_t ldso_ba_gn_reduce_doubles(ldso_ba_t *h);
 int ldso_ba_gn_reduce_local(ldso_ba_t *h, void *reduce_buf_dev, double lambda);
 int ldso_ba_gn_solve_reduced(ldso_ba_t *h, const void *reduce_buf_dev, int iteration, double lambda);
+/* Batched windows (one 7-keyframe window is tiny for an MI355X): the forced Gauss-Newton iteration of n
+ * INDEPENDENT windows (several agents, sequences or hypotheses) with three launches per iteration for the whole batch
+ * (k_reduce_batch -> k_gn_solve_batch -> k_linearize_batch).  Per-window arithmetic is that of ldso_ba_enqueue_gn.  The handles
+ * share one device and one stream, hold windows of the same slot-table width (all F <= 8 or all F in 9..16) without linearised
+ * residuals, and have been brought to the same stage (window set, ldso_ba_linearize_all + ldso_ba_apply_res).  Results are
+ * fetched per handle as usual. */
+typedef struct ldso_ba_batch ldso_ba_batch_t;
+int ldso_ba_batch_create(ldso_ba_t *const *handles, int n, ldso_ba_batch_t **out);
+int ldso_ba_batch_enqueue_gn(ldso_ba_batch_t *b, int first_iteration, int iters);
+int ldso_ba_batch_destroy(ldso_ba_batch_t *b);
+/* bench / profiling: average duration [us] of the batched k_linearize over `reps` back-to-back launches (HIP events on the batch's stream) */
+int ldso_ba_batch_time_linearize(ldso_ba_batch_t *b, int reps, double *avg_us);
 /* The same sharded iteration with the collective inside, for a C / C++ host (north_star: host code stays C++): `iters` forced
  * Gauss-Newton iterations of this rank's shard - k_reduce into the handle's all-reduce buffer, ncclAllReduce (RCCL, fp64 sum, in
  * place, ~29 KB + 8 P bytes at F = 7) on the handle's stream, replicated solve, linearize of the shard - enqueued without a host

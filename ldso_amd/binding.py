@@ -311,6 +311,39 @@ class BA:
         return ms.value, n.value
 
 
+class BABatch:
+    """ldso_ba_batch_*: the GN iteration of several independent windows per launch."""
+
+    def __init__(self, handles):
+        self.L = lib()
+        self.handles = list(handles)
+        arr = (C.c_void_p * len(self.handles))(*[h.h for h in self.handles])
+        self.h = C.c_void_p()
+        _chk(self.L.ldso_ba_batch_create(arr, C.c_int(len(self.handles)), C.byref(self.h)))
+
+    def enqueue_gn(self, first_iteration, iters):
+        _chk(self.L.ldso_ba_batch_enqueue_gn(self.h, C.c_int(first_iteration), C.c_int(iters)))
+
+    def sync(self):
+        self.handles[0].sync()
+
+    def time_linearize(self, reps=50):
+        us = C.c_double()
+        _chk(self.L.ldso_ba_batch_time_linearize(self.h, C.c_int(reps), C.byref(us)))
+        return us.value
+
+    def close(self):
+        if self.h:
+            self.L.ldso_ba_batch_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Tracker:
     """CoarseTracker handle (src/frontend/CoarseTracker.cc) on one GPU."""
 

@@ -32,6 +32,9 @@ hipError_t ba_launch_acc_init(const BaPtrs &B, const BaDims &D, const GnInit &gi
 hipError_t ba_launch_gn_export(const BaPtrs &B, const BaDims &D, const ResSet &S, double *tail, hipStream_t st);
 hipError_t ba_launch_activate(const BaPtrs &B, const BaDims &D, const ldso_settings_t &S, const ldso_immature_t *d_pts, ldso_activation_t *d_out, int n, int minObs,
                               float minIdepthH_act, int GNIts, hipStream_t st);
+hipError_t ba_launch_linearize_batch(const BatchItem *d_items, int nWin, int totalChunks, int FS, int cur, const ldso_settings_t &S, int stepMode, float calibPrior, hipStream_t st);
+hipError_t ba_launch_reduce_batch(const BatchItem *d_items, int nWin, int totalBlocks, int cur, float calibPrior, double l1, double il, hipStream_t st);
+hipError_t ba_launch_gn_solve_batch(const BatchItem *d_items, int nWin, const BaDims &Dmax, int cur, const ldso_settings_t &St, int iteration, double lambda, hipStream_t st);
 hipError_t ba_launch_lm_energies(const BaPtrs &B, const BaDims &D, const ResSet &S, float calibPrior, bool hasPrior, hipStream_t st);
 hipError_t ba_launch_marg_update(const BaPtrs &B, const BaDims &D, double w, hipStream_t st);
 hipError_t ba_launch_gn_solve(const BaPtrs &B, const BaDims &D, const ResSet &S, const ldso_settings_t &St, const SolveArgs &A, hipStream_t st);
@@ -899,6 +902,118 @@ int ldso_ba_gn_solve_reduced(ldso_ba_t *H, const void *buf, int iteration, doubl
     t_end(H);
     RUN(launch_linearize(H, false, 1));
     H->cur ^= 1;
+    return LDSO_OK;
+}
+
+// ---- batched windows: B independent windows per launch ---------------------------------------------------------------------------
+// One 7-keyframe window is tiny for an MI355X (SURVEY 7 hard part 1, 8e): a batch runs the Gauss-Newton iteration of several
+// independent windows (several agents / sequences / hypotheses) with three launches per iteration for ALL of them: k_reduce_batch
+// (every window's reduce workgroups) -> k_gn_solve_batch (two control workgroups per window) -> k_linearize_batch (every window's
+// chunks).  Per-window arithmetic is exactly that of ldso_ba_enqueue_gn's split schedule; the windows only share the launches.
+struct ldso_ba_batch {
+    std::vector<ldso_ba *> h;
+    BatchItem *d_items = nullptr;
+    std::vector<BatchItem> items;
+    int totalChunks = 0, totalReduce = 0, FS = 0, cur = 0;
+    BaDims Dmax;
+};
+
+static int batch_refresh(ldso_ba_batch *Bt) {
+    int lin = 0, red = 0;
+    ldso_ba *H0 = Bt->h[0];
+    for (size_t i = 0; i < Bt->h.size(); i++) {
+        ldso_ba *H = Bt->h[i];
+        BatchItem &it = Bt->items[i];
+        if (H->B.acc != H->ownAcc) H->B.acc = H->ownAcc;
+        it.B = H->B; it.D = H->D; it.set[0] = H->sets[0]; it.set[1] = H->sets[1]; it.cs = H->chunkStarts;
+        it.hasPrior = H->hasPrior ? 1 : 0; it.GSP = H->GSP; it.linBlock0 = lin; it.redBlock0 = red;
+        const int nT = H->GSP / 16;
+        lin += H->D.nChunks;
+        red += H->D.F * H->D.F + LD_SCT_KS * nT * (nT + 1) / 2 + 1;
+    }
+    Bt->totalChunks = lin; Bt->totalReduce = red;
+    CHK(hipMemcpyAsync(Bt->d_items, Bt->items.data(), Bt->items.size() * sizeof(BatchItem), hipMemcpyHostToDevice, H0->stream));
+    return LDSO_OK;
+}
+
+int ldso_ba_batch_create(ldso_ba_t *const *handles, int n, ldso_ba_batch_t **out) {
+    REQ(handles && n >= 1 && out, "ldso_ba_batch_create: bad arguments");
+    ldso_ba *H0 = handles[0];
+    REQ(H0 && H0->D.P > 0, "ldso_ba_batch_create: window 0 is not set");
+    for (int i = 0; i < n; i++) {
+        ldso_ba *H = handles[i];
+        REQ(H && H->D.P > 0, "ldso_ba_batch_create: every handle needs a resident window");
+        REQ(H->device == H0->device && H->stream == H0->stream, "ldso_ba_batch_create: the handles of a batch share one device and one stream (ldso_ba_set_stream)");
+        REQ(H->D.FS == H0->D.FS, "ldso_ba_batch_create: the windows of a batch use the same slot-table width (all F <= 8 or all 9 <= F <= 16)");
+        REQ(!H->hasL, "ldso_ba_batch_create: windows with linearised residuals run on their own handle");
+        REQ(H->D.pBegin == 0 && H->D.pEnd == H->D.P, "ldso_ba_batch_create: sharded handles cannot be batched");
+        REQ(H->settings.forceAcceptStep && !H->pendingApply, "ldso_ba_batch_create: forced-accept schedule, no pending linearisation");
+    }
+    CHK(hipSetDevice(H0->device));
+    ldso_ba_batch *Bt = new ldso_ba_batch();
+    Bt->h.assign(handles, handles + n);
+    Bt->items.resize(n);
+    Bt->FS = H0->D.FS;
+    Bt->Dmax = H0->D;
+    for (int i = 0; i < n; i++) if (handles[i]->D.F > Bt->Dmax.F) Bt->Dmax = handles[i]->D;
+    void *q = nullptr;
+    if (hipMalloc(&q, (size_t) n * sizeof(BatchItem)) != hipSuccess) { delete Bt; ldso_set_error("ldso_ba_batch_create: hipMalloc failed"); return LDSO_E_HIP; }
+    Bt->d_items = (BatchItem *) q;
+    *out = Bt;
+    return LDSO_OK;
+}
+
+int ldso_ba_batch_destroy(ldso_ba_batch_t *Bt) {
+    if (!Bt) return LDSO_OK;
+    hipSetDevice(Bt->h[0]->device);
+    hipStreamSynchronize(Bt->h[0]->stream);
+    if (Bt->d_items) hipFree(Bt->d_items);
+    delete Bt;
+    return LDSO_OK;
+}
+
+// `iters` forced Gauss-Newton iterations of every window of the batch: 3 launches per iteration for the whole batch, no host
+// synchronisation.  Every window must hold an applied linearisation (ldso_ba_linearize_all + ldso_ba_apply_res, or a previous
+// optimize / enqueue) and all of them must be at the same ping-pong parity (true after identical call sequences).
+int ldso_ba_batch_enqueue_gn(ldso_ba_batch_t *Bt, int first_iteration, int iters) {
+    REQ(Bt && iters >= 0, "ldso_ba_batch_enqueue_gn: bad arguments");
+    ldso_ba *H0 = Bt->h[0];
+    CHK(hipSetDevice(H0->device));
+    for (ldso_ba *H : Bt->h) REQ(H->cur == H0->cur && !H->pendingApply, "ldso_ba_batch_enqueue_gn: the windows of a batch must be at the same stage");
+    RUN(batch_refresh(Bt));
+    double lam = 1e-1;
+    if (H0->settings.solverMode & LDSO_SOLVER_USE_GN) lam = 0;
+    if (H0->settings.solverMode & LDSO_SOLVER_FIX_LAMBDA) lam = 1e-5;
+    const double l1 = 1 + lam, il = (double) (1.0f / (1 + lam));
+    int cur = H0->cur;
+    for (int i = 0; i < iters; i++) {
+        CHK(ba_launch_reduce_batch(Bt->d_items, (int) Bt->h.size(), Bt->totalReduce, cur, H0->settings.initialCalibHessian, l1, il, H0->stream));
+        CHK(ba_launch_gn_solve_batch(Bt->d_items, (int) Bt->h.size(), Bt->Dmax, cur, H0->settings, first_iteration + i, 1e-1, H0->stream));
+        CHK(ba_launch_linearize_batch(Bt->d_items, (int) Bt->h.size(), Bt->totalChunks, Bt->FS, cur, H0->settings, 1, H0->settings.initialCalibHessian, H0->stream));
+        cur ^= 1;
+    }
+    for (ldso_ba *H : Bt->h) H->cur = cur;
+    return LDSO_OK;
+}
+
+// average duration of the batched k_linearize for bench.py's roofline: `reps` back-to-back launches on the applied state (read set ->
+// scratch set, no point step: idempotent) between one pair of HIP events on the batch's stream
+int ldso_ba_batch_time_linearize(ldso_ba_batch_t *Bt, int reps, double *avg_us) {
+    REQ(Bt && reps > 0 && avg_us, "ldso_ba_batch_time_linearize: bad arguments");
+    ldso_ba *H0 = Bt->h[0];
+    CHK(hipSetDevice(H0->device));
+    RUN(batch_refresh(Bt));
+    hipEvent_t a, b;
+    CHK(hipEventCreate(&a)); CHK(hipEventCreate(&b));
+    CHK(ba_launch_linearize_batch(Bt->d_items, (int) Bt->h.size(), Bt->totalChunks, Bt->FS, H0->cur, H0->settings, 0, H0->settings.initialCalibHessian, H0->stream));
+    CHK(hipEventRecord(a, H0->stream));
+    for (int i = 0; i < reps; i++) CHK(ba_launch_linearize_batch(Bt->d_items, (int) Bt->h.size(), Bt->totalChunks, Bt->FS, H0->cur, H0->settings, 0, H0->settings.initialCalibHessian, H0->stream));
+    CHK(hipEventRecord(b, H0->stream));
+    CHK(hipEventSynchronize(b));
+    float ms = 0;
+    CHK(hipEventElapsedTime(&ms, a, b));
+    hipEventDestroy(a); hipEventDestroy(b);
+    *avg_us = (double) ms * 1e3 / reps;
     return LDSO_OK;
 }
 

@@ -114,6 +114,16 @@ struct ChunkStarts {
     int32_t v[LD_MAXF + 1];
 };
 
+// One window of a batch (ldso_ba_batch_*): everything the kernels of a GN iteration take as arguments for a single window, in
+// device memory.  linBlock0 / redBlock0 = first workgroup of this window in the batched k_linearize / k_reduce launches.
+struct BatchItem {
+    BaPtrs B;
+    BaDims D;
+    ResSet set[2];
+    ChunkStarts cs;
+    int32_t hasPrior, GSP, linBlock0, redBlock0;
+};
+
 // GN fast path: what k_linearize needs to initialise B.acc for the solve that follows it
 struct GnInit {
     int enable, hasPrior;

@@ -123,16 +123,18 @@ static __device__ __forceinline__ void load_point(PtIn<NSG> &q, const BaPtrs &B,
 // (fixLinearizationF, Residuals.cc:216-242: res_toZeroF = resF - [JIdx (Jp delta) + JabF delta_ab]); the top / Schur accumulators
 // then take addPoint<2> (resApprox = res_toZeroF) with priorF * idepthFixPriorMargFac and no prior shift.  Unflagged points
 // contribute nothing.  The output set is scratch (never applied).
+// The body is shared by k_linearize (one window: everything arrives as kernel arguments, i.e. in scalar registers) and
+// k_linearize_batch (many independent windows per launch: the descriptors live in device memory).  chunk = index of the
+// workgroup's chunk inside ITS window, gridBlocks = workgroups of that window (partition of the accumulator initialisation).
 template <int NSG, bool HAS_L, bool FIX, bool MARG>
-__global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D, ResSet cur, ResSet nxt, ldso_settings_t S, int stepMode, GnInit gi,
-                                                             const int32_t *__restrict__ margFlags) {
+static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaDims &D, const ResSet &cur, const ResSet &nxt, const ldso_settings_t &S, const int stepMode,
+                                                      const GnInit &gi, const int32_t *__restrict__ margFlags, const int chunk, const int gridBlocks) {
     if (LD_ITER_SKIPPED(B, gi.itCheck)) return;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int FS = D.FS, F = D.F;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, s = lane >> 3, k = lane & 7;
-    const int chunk = blockIdx.x;
     const long long t0_ = wall_clock64();
-#define LSTAMP(i) do { if (LD_STAMP_ON && blockIdx.x == 0 && tid == 0) B.energyLog[8 + (i)] = (double) (wall_clock64() - t0_); } while (0)
+#define LSTAMP(i) do { if (LD_STAMP_ON && chunk == 0 && tid == 0) B.energyLog[8 + (i)] = (double) (wall_clock64() - t0_); } while (0)
     const int p0 = B.chunk_p0[chunk], np = B.chunk_n[chunk], h = B.chunk_host[chunk];
 
     // ---- LDS carve: pair structs of this host, float adjoints of this host, reduction scratch --------
@@ -146,8 +148,8 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D,
     if (gi.enable) {
         // initialise the HFinal / bFinal accumulator of the k_reduce that follows (lower triangle) with H_M and the diagonal
         // priors (EnergyFunctional.cc:257-291; the lambda scaling of these terms is added by k_reduce); b starts at zero.
-        const int n = D.n, N1 = n * n + n, per = (N1 + (int) gridDim.x - 1) / (int) gridDim.x;
-        const int z0 = blockIdx.x * per, z1 = min(N1, z0 + per);
+        const int n = D.n, N1 = n * n + n, per = (N1 + gridBlocks - 1) / gridBlocks;
+        const int z0 = chunk * per, z1 = min(N1, z0 + per);
         for (int e = z0 + tid; e < z1; e += blockDim.x) {
             double v = 0.0;
             if (e < n * n) {
@@ -643,6 +645,24 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D,
     }
 }
 
+template <int NSG, bool HAS_L, bool FIX, bool MARG>
+__global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D, ResSet cur, ResSet nxt, ldso_settings_t S, int stepMode, GnInit gi,
+                                                             const int32_t *__restrict__ margFlags) {
+    linearize_body<NSG, HAS_L, FIX, MARG>(B, D, cur, nxt, S, stepMode, gi, margFlags, (int) blockIdx.x, (int) gridDim.x);
+}
+
+// Batched windows (one 7-keyframe window is tiny for the chip): the chunks of nWin independent windows in one
+// launch.  Workgroup -> window by the prefix of chunk counts (items[w].linBlock0); `cur` = which residual set is the applied one
+// (all windows of a batch iterate in lockstep).
+template <int NSG>
+__global__ __launch_bounds__(64 * LD_WAVES) void k_linearize_batch(const BatchItem *__restrict__ items, int nWin, int cur, ldso_settings_t S, int stepMode, float calibPrior) {
+    int w = 0;
+    for (int i = 1; i < nWin; i++) if ((int) blockIdx.x >= items[i].linBlock0) w = i;
+    const BatchItem &it = items[w];
+    GnInit gi; gi.enable = 1; gi.hasPrior = it.hasPrior; gi.calibPrior = calibPrior; gi.itCheck = -1;
+    linearize_body<NSG, false, false, false>(it.B, it.D, it.set[cur], it.set[cur ^ 1], S, stepMode, gi, nullptr, (int) blockIdx.x - it.linBlock0, it.D.nChunks);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // launcher
 // ---------------------------------------------------------------------------------------------------------
@@ -680,4 +700,17 @@ hipError_t ba_launch_linearize_marg(const BaPtrs &B, const BaDims &D, const ResS
     const GnInit gi{0, 0, 0.0f};
     if (D.nsg == 1) return launch_one<1, false, false, true>(B, D, cur, nxt, S, 0, gi, st, margFlags);
     return launch_one<2, false, false, true>(B, D, cur, nxt, S, 0, gi, st, margFlags);
+}
+
+hipError_t ba_launch_linearize_batch(const BatchItem *d_items, int nWin, int totalChunks, int FS, int cur, const ldso_settings_t &S, int stepMode, float calibPrior, hipStream_t st) {
+    if (totalChunks == 0) return hipSuccess;
+    const size_t lds = ba_linearize_lds_bytes(FS, false);
+    if (FS == 8) {
+        if (lds > 48 * 1024) (void) hipFuncSetAttribute((const void *) k_linearize_batch<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+        hipLaunchKernelGGL(k_linearize_batch<1>, dim3(totalChunks), dim3(64 * LD_WAVES), lds, st, d_items, nWin, cur, S, stepMode, calibPrior);
+    } else {
+        if (lds > 48 * 1024) (void) hipFuncSetAttribute((const void *) k_linearize_batch<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+        hipLaunchKernelGGL(k_linearize_batch<2>, dim3(totalChunks), dim3(64 * LD_WAVES), lds, st, d_items, nWin, cur, S, stepMode, calibPrior);
+    }
+    return hipGetLastError();
 }

@@ -935,6 +935,43 @@ __global__ __launch_bounds__(NT) void k_reduce_solve(BaPtrs B, BaDims D, ResSet 
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Batched windows: k_reduce and the control step of nWin independent windows, one launch each (the fused k_reduce_solve needs
+// every workgroup of a window resident at once - with many windows per launch a kernel boundary orders the two instead).
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void k_reduce_batch(const BatchItem *__restrict__ items, int nWin, int cur, float calibPrior, double l1, double il) {
+    int w = 0;
+    for (int i = 1; i < nWin; i++) if ((int) blockIdx.x >= items[i].redBlock0) w = i;
+    const BatchItem &it = items[w];
+    reduce_body(it.B, it.D, it.set[cur], it.cs, 0, it.GSP, 1, it.hasPrior, calibPrior, l1, il, -1, (int) blockIdx.x - it.redBlock0);
+}
+
+__global__ __launch_bounds__(NT) void k_gn_solve_batch(const BatchItem *__restrict__ items, int cur, ldso_settings_t St, int iteration, double lambda) {
+    const BatchItem &it = items[blockIdx.x >> 1];
+    SolveArgs A;
+    A.flags = 0; A.iteration = iteration; A.lambda = lambda; A.hasL = 0; A.hasPrior = it.hasPrior; A.GSP = it.GSP; A.logIdx = -1;
+    A.reduceOut = nullptr; A.reduceIn = nullptr; A.itCheck = -1; A.waitCtr = nullptr; A.waitTarget = 0;
+    gn_solve_body<false>(it.B, it.D, it.set[cur], St, A, (int) (blockIdx.x & 1));
+}
+
+hipError_t ba_launch_reduce_batch(const BatchItem *d_items, int nWin, int totalBlocks, int cur, float calibPrior, double l1, double il, hipStream_t st) {
+    const size_t lds = (size_t) (2 * SCT_SLAB * 16 + SCT_SLAB) * sizeof(float);
+    if (lds > 48 * 1024) (void) hipFuncSetAttribute((const void *) k_reduce_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+    hipLaunchKernelGGL(k_reduce_batch, dim3(totalBlocks), dim3(NT), lds, st, d_items, nWin, cur, calibPrior, l1, il);
+    return hipGetLastError();
+}
+
+// Dmax: the window of the batch with the most frames (LDS of the control step)
+hipError_t ba_launch_gn_solve_batch(const BatchItem *d_items, int nWin, const BaDims &Dmax, int cur, const ldso_settings_t &St, int iteration, double lambda, hipStream_t st) {
+    size_t mirror = (size_t) Dmax.F * sizeof(DevFrame) + sizeof(DevCalib) + (Dmax.F <= 8 ? (size_t) Dmax.F * Dmax.F * 128 * sizeof(float) : 0), stats = 64 * sizeof(double) + (256 + 8) * sizeof(int) + TH_CAP * sizeof(float);
+    const int n = Dmax.n, NBsel = (n + 1 <= 64) ? 4 : (n + 1 <= 112) ? 7 : 9;
+    size_t lds0 = solve_core_lds_doubles(NBsel, n) * sizeof(double) + 64 * sizeof(double) + mirror + 64;
+    size_t lds = lds0 > stats + 64 ? lds0 : stats + 64;
+    if (lds > 48 * 1024) (void) hipFuncSetAttribute((const void *) k_gn_solve_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+    hipLaunchKernelGGL(k_gn_solve_batch, dim3(2 * nWin), dim3(NT), lds, st, d_items, cur, St, iteration, lambda);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // k_gn_export (multi-GPU fast path): rank-local scalar sums and newest-frame energy candidates into the tail of the all-reduce
 // buffer  [HFinal lower | bFinal | 8 scalars | P candidates (value+1, 0 = none)]  whose head k_reduce accumulated (B.acc).
 // ---------------------------------------------------------------------------------------------------------

@@ -392,6 +392,49 @@ def test_prior_survives_set_frames(small):
     assert rc != ra                                                # the prior matters on this window
 
 
+def test_batched_windows_equal_individual_runs():
+    """ldso_ba_batch_*: five independent windows (different scenes, point counts and frame counts <= 8, one with a prior) iterated by
+    three launches per iteration for the whole batch; every window must end where its own ldso_ba_enqueue_gn (split schedule) ends."""
+    import torch
+    ts = torch.cuda.Stream(); torch.cuda.set_stream(ts)
+    st = ts.cuda_stream
+    wins = [synth.make_window(F=5, P=400, w=320, h=240, fx=200.0, seed=31), synth.make_window(F=5, P=333, w=320, h=240, fx=200.0, seed=32),
+            synth.make_window(F=7, P=500, w=320, h=240, fx=200.0, seed=33), synth.make_window(F=4, P=150, w=256, h=192, fx=160.0, seed=34),
+            synth.add_synthetic_prior(synth.make_window(F=6, P=420, w=320, h=240, fx=200.0, seed=35))]
+    solo, batch = [], []
+    for w in wins:
+        for lst in (solo, batch):
+            g = binding.BA.from_window(w, stream=st)
+            g.collect_active(); g.linearize_all(False); g.apply_res()
+            lst.append(g)
+    for g in solo:
+        g.set_debug_split_launch(True)
+        g.enqueue_gn(0, 5)
+    b = binding.BABatch(batch)
+    b.enqueue_gn(0, 3); b.enqueue_gn(3, 2)
+    b.sync(); torch.cuda.synchronize()
+    for w, gs, gb in zip(wins, solo, batch):
+        fs, fb = gs.get_frames(), gb.get_frames()
+        assert np.abs(fb["frames"]["state"] - fs["frames"]["state"]).max() <= 1e-9 * np.abs(fs["frames"]["state"]).max()
+        assert np.array_equal(fb["frames"]["frameEnergyTH"], fs["frames"]["frameEnergyTH"])
+        ps, pb = gs.get_points(), gb.get_points()
+        assert rel(pb["idepth"], ps["idepth"]) < 1e-6 and rel(pb["HdiF"], ps["HdiF"]) < 1e-5
+        rs, rb = gs.get_residuals(), gb.get_residuals()
+        assert np.array_equal(rs["state_state"], rb["state_state"]) and rel(rb["out"]["state_NewEnergy"], rs["out"]["state_NewEnergy"]) < 1e-5
+    # and against the oracle: the batch is the reference's loop on every window
+    for w, gb in zip(wins[:2], batch[:2]):
+        o = po.OracleWindow(w)
+        o.collect_active(); o.linearize_all(False); o.apply_res()
+        E = 0.0
+        for it in range(5):
+            o.backup_state(); o.solve_system(it); o.do_step(); E = o.linearize_all(False); o.apply_res()
+        Eg = gb.get_residuals()["out"]["state_NewEnergy"].astype(np.float64)
+        ro = o.get_residuals(False)
+        Eo = ro["out"]["state_NewEnergy"].astype(np.float64)
+        assert abs(Eg.sum() - Eo.sum()) <= 1e-4 * Eo.sum()
+    b.close()
+
+
 def test_lm_energies_and_rejection_path(small):
     """setting_forceAceptStep = false (FullSystem.cc:805-826): calcMEnergyF / calcLEnergyF_MT on the device, and ldso_ba_optimize
     accepting / rejecting steps like the oracle's loop.  The window (a third of the residuals frozen at a perturbed linearisation
