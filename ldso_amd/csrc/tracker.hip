@@ -18,6 +18,7 @@
 #include <cmath>
 #include "../../include/ldso_hip.h"
 #include "lie_dev.h"
+#include <cstdlib>
 
 void ldso_set_error(const std::string &s);
 #define CHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { ldso_set_error(std::string(#call) + ": " + hipGetErrorString(e_)); return LDSO_E_HIP; } } while (0)
@@ -433,9 +434,89 @@ __device__ __forceinline__ void tr_vec6(const double *acc, double *rs) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// trackNewestCoarse: one workgroup per hypothesis
+// Cooperative evaluation: G workgroups share ONE hypothesis.  Workgroup 0 of the group runs the LM loop (it is the only one that
+// decides anything); for every calcRes / calcGSSSE evaluation it publishes the candidate (pose, affine, level, cut-off) in device
+// memory and bumps a sequence number, every workgroup of the group evaluates an interleaved 1/nAct share of the level's points
+// (nAct grows with the level size: the coarsest levels stay on the leader alone), the helpers store their 52 partial sums and bump a
+// counter, the leader adds the partials in workgroup order (deterministic).  The hand-over uses device-scope atomics only (performed
+// at the memory side, visible across the XCDs' L2s) - the same scheme as k_reduce_solve.  All workgroups of a launch must be
+// resident (the host bounds nhyp * G by the CU count).
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(TR_NT) void k_tr_track(TrParams P, TrHyp *hyps) {
+#define TR_GMAX 8
+struct TrCoop {
+    double T[12];
+    float a, b, cutoff;
+    int lvl;                  // -1: the track is over
+    int seq;                  // bumped by the leader after the fields above are visible
+    int done;                 // cumulative count of helper acknowledgements
+    int pad_[2];
+    double part[TR_GMAX][TR_NACC];
+};
+template <class T_> __device__ __forceinline__ T_ tr_ld(const T_ *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <class T_> __device__ __forceinline__ void tr_st(T_ *p, T_ v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int tr_nact(int n, int G) { const int per = TR_NT * TR_U; return max(1, min(G, (n + per - 1) / per)); }
+
+// leader side of one evaluation (all threads of the leader workgroup)
+template <int G>
+__device__ __forceinline__ void tr_eval_lead(const TrParams &P, int lvl, const double *T, float a, float b, float cutoff, double *sAcc, double *sRed, TrCoop *co, int &seq, int &acks) {
+    if (G == 1) { tr_eval(P, lvl, T, a, b, cutoff, sAcc, sRed, 0, TR_NT); return; }
+    const int tid = threadIdx.x, nAct = tr_nact(P.lv[lvl].n, G);
+    if (nAct > 1) {
+        if (tid < 12) tr_st(&co->T[tid], T[tid]);
+        if (tid == 12) { tr_st(&co->a, a); tr_st(&co->b, b); tr_st(&co->cutoff, cutoff); tr_st(&co->lvl, lvl); }
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        ++seq;
+        if (tid == 0) tr_st(&co->seq, seq);
+    }
+    tr_eval(P, lvl, T, a, b, cutoff, sAcc, sRed, 0, nAct * TR_NT);
+    if (nAct > 1) {
+        acks += nAct - 1;
+        if (tid == 0) while (tr_ld(&co->done) < acks) __builtin_amdgcn_s_sleep(1);
+        __syncthreads();
+        if (tid < TR_NACC) { double s_ = sAcc[tid]; for (int g = 1; g < nAct; g++) s_ += tr_ld(&co->part[g][tid]); sAcc[tid] = s_; }
+        __syncthreads();
+    }
+}
+
+// helper workgroups: evaluate shares until the leader says the track is over
+template <int G>
+__device__ void tr_helper_loop(const TrParams &P, TrCoop *co, int g, double *sAcc, double *sRed, double *sT, float *sF, int *sI) {
+    const int tid = threadIdx.x;
+    int seq = 0;
+    for (;;) {
+        if (tid == 0) { int s_; while ((s_ = tr_ld(&co->seq)) <= seq) __builtin_amdgcn_s_sleep(1); sI[1] = s_; }
+        __syncthreads();
+        const int s_ = sI[1];
+        if (tid < 12) sT[tid] = tr_ld(&co->T[tid]);
+        if (tid == 12) { sF[0] = tr_ld(&co->a); sF[1] = tr_ld(&co->b); sF[2] = tr_ld(&co->cutoff); sI[0] = tr_ld(&co->lvl); }
+        __syncthreads();
+        // seqlock: the leader only moves on from a command once every workgroup that takes part in it has acknowledged, so a command this
+        // workgroup takes part in is stable while it is read; a torn read can only belong to commands it sits out - read again
+        if (tid == 0) sI[2] = (tr_ld(&co->seq) == s_) ? 1 : 0;
+        __syncthreads();
+        const int stable = sI[2], lvl = sI[0];
+        __syncthreads();
+        if (!stable) continue;
+        seq = s_;
+        if (lvl < 0) return;
+        const int nAct = tr_nact(P.lv[lvl].n, G);
+        if (g < nAct) {
+            tr_eval(P, lvl, sT, sF[0], sF[1], sF[2], sAcc, sRed, g * TR_NT, nAct * TR_NT);
+            if (tid < TR_NACC) tr_st(&co->part[g][tid], sAcc[tid]);
+            __builtin_amdgcn_s_waitcnt(0);
+            __syncthreads();
+            if (tid == 0) __hip_atomic_fetch_add(&co->done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// trackNewestCoarse: G workgroups per hypothesis (G = 1: one workgroup runs everything)
+// ---------------------------------------------------------------------------------------------------------
+template <int G>
+__global__ __launch_bounds__(TR_NT) void k_tr_track(TrParams P, TrHyp *hyps, TrCoop *coop) {
     __shared__ double sAcc[TR_NACC];
     __shared__ double sRed[(TR_NT / 16) * TR_NACC];
     __shared__ double sT[12], sTnew[12];
@@ -451,9 +532,13 @@ __global__ __launch_bounds__(TR_NT) void k_tr_track(TrParams P, TrHyp *hyps) {
 #endif
     __shared__ float sLambda, sCutRep;
     __shared__ int sEv[5];
+    __shared__ float sCoF[4];
     if (threadIdx.x < 5) sEv[threadIdx.x] = 0;
-    TrHyp &hy = hyps[blockIdx.x];
+    TrHyp &hy = hyps[blockIdx.x / G];
+    TrCoop *co = (G > 1) ? coop + blockIdx.x / G : nullptr;
     const int tid = threadIdx.x;
+    int coSeq = 0, coAcks = 0;
+    if (G > 1 && (blockIdx.x % G) != 0) { tr_helper_loop<G>(P, co, (int) (blockIdx.x % G), sAcc, sRed, sT, sCoF, sCtl); return; }
     if (tid < 12) sT[tid] = hy.T[tid];
     if (tid == 0) { sAff[0] = hy.a; sAff[1] = hy.b; sCtl[3] = 0; sCtl[2] = 0; for (int i = 0; i < 5; i++) hy.lastResiduals[i] = NAN; for (int i = 0; i < 3; i++) hy.flow[i] = 1000; }
     __syncthreads();
@@ -463,12 +548,12 @@ __global__ __launch_bounds__(TR_NT) void k_tr_track(TrParams P, TrHyp *hyps) {
 
     for (int lvl = hy.coarsestLvl; lvl >= 0; lvl--) {
         float levelCutoffRepeat = 1;
-        TEV(tr_eval(P, lvl, sT, sAff[0], sAff[1], P.coarseCutoffTH * levelCutoffRepeat, sAcc, sRed, 0, TR_NT););
+        TEV(tr_eval_lead<G>(P, lvl, sT, sAff[0], sAff[1], P.coarseCutoffTH * levelCutoffRepeat, sAcc, sRed, co, coSeq, coAcks););
         if (tid == 0) tr_vec6(sAcc, sResOld);
         __syncthreads();
         while (sResOld[5] > 0.6 && levelCutoffRepeat < 50) {
             levelCutoffRepeat *= 2;
-            TEV(tr_eval(P, lvl, sT, sAff[0], sAff[1], P.coarseCutoffTH * levelCutoffRepeat, sAcc, sRed, 0, TR_NT););
+            TEV(tr_eval_lead<G>(P, lvl, sT, sAff[0], sAff[1], P.coarseCutoffTH * levelCutoffRepeat, sAcc, sRed, co, coSeq, coAcks););
             if (tid == 0) tr_vec6(sAcc, sResOld);
             __syncthreads();
         }
@@ -530,7 +615,7 @@ __global__ __launch_bounds__(TR_NT) void k_tr_track(TrParams P, TrHyp *hyps) {
                 sCtl[0] = (sqrt(nrm) > 1e-3) ? 1 : 0;          // continue after this iteration?
             }
             __syncthreads();
-            TEV(tr_eval(P, lvl, sTnew, sAffNew[0], sAffNew[1], P.coarseCutoffTH * levelCutoffRepeat, sAcc, sRed, 0, TR_NT););
+            TEV(tr_eval_lead<G>(P, lvl, sTnew, sAffNew[0], sAffNew[1], P.coarseCutoffTH * levelCutoffRepeat, sAcc, sRed, co, coSeq, coAcks););
             if (tid == 0) {
                 tr_vec6(sAcc, sResNew);
                 sCtl[1] = ((sResNew[0] / sResNew[1]) < (sResOld[0] / sResOld[1])) ? 1 : 0;
@@ -565,6 +650,9 @@ __global__ __launch_bounds__(TR_NT) void k_tr_track(TrParams P, TrHyp *hyps) {
 #if LD_STAMP_ON_TR
     if (tid == 0) { hy.dbg[0] = (double) tEval; hy.dbg[1] = (double) (wall_clock64() - tTot0); hy.dbg[2] = nEval; for (int q = 0; q < 5; q++) hy.dbg[3 + q] = nLv[q] ? (double) tLv[q] / nLv[q] : 0.0; }
 #endif
+    if (G > 1) {      // release the helper workgroups
+        if (tid == 0) { tr_st(&co->lvl, -1); __builtin_amdgcn_s_waitcnt(0); tr_st(&co->seq, coSeq + 1); }
+    }
     if (tid == 0) {
         hy.iterations = sCtl[3];
         for (int q = 0; q < 5; q++) hy.evals[q] = sEv[q];
@@ -612,6 +700,8 @@ struct ldso_tracker {
     int *d_total = nullptr;
     double *d_T = nullptr, *d_acc = nullptr;
     TrHyp *d_hyp = nullptr;
+    TrCoop *d_coop = nullptr;         // cooperative evaluation: one record per hypothesis
+    int numCU = 256;
     double lastAcc[TR_NACC];
     bool haveAcc = false;
     int lastEvals[5] = {0, 0, 0, 0, 0};      // of hypothesis 0 of the last track call
@@ -655,7 +745,8 @@ int ldso_tr_create(int device, int w, int h, int levels, ldso_tracker_t **out) {
         L.idepth += 64; L.wsum += 64; L.wsum_bak += 64;
         TA(L.blockCnt, n / 256 + 2);
     }
-    TA(H->d_total, 1); TA(H->d_T, 12); TA(H->d_acc, TR_NACC); TA(H->d_hyp, 128);
+    TA(H->d_total, 1); TA(H->d_T, 12); TA(H->d_acc, TR_NACC); TA(H->d_hyp, 128); TA(H->d_coop, 128);
+    { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) H->numCU = pr.multiProcessorCount; }
     *out = H;
     return LDSO_OK;
 }
@@ -840,7 +931,14 @@ int ldso_tr_track_batch(ldso_tracker_t *H, int nhyp, double *T_inout /*nhyp*12*/
         for (int k = 0; k < 5; k++) hy[i].minRes[k] = minRes ? minRes[k] : NAN;
     }
     CHK(hipMemcpyAsync(H->d_hyp, hy.data(), nhyp * sizeof(TrHyp), hipMemcpyHostToDevice, H->stream));
-    hipLaunchKernelGGL(k_tr_track, dim3(nhyp), dim3(TR_NT), 0, H->stream, H->P, H->d_hyp);
+    // few hypotheses: TR_GMAX workgroups share each of them on the large levels (all workgroups resident: nhyp * G <= CUs);
+    // many hypotheses fill the chip by themselves
+    if (nhyp * TR_GMAX <= H->numCU && !getenv("LDSO_TR_NO_COOP")) {
+        CHK(hipMemsetAsync(H->d_coop, 0, (size_t) nhyp * sizeof(TrCoop), H->stream));
+        hipLaunchKernelGGL(k_tr_track<TR_GMAX>, dim3(nhyp * TR_GMAX), dim3(TR_NT), 0, H->stream, H->P, H->d_hyp, H->d_coop);
+    } else {
+        hipLaunchKernelGGL(k_tr_track<1>, dim3(nhyp), dim3(TR_NT), 0, H->stream, H->P, H->d_hyp, (TrCoop *) nullptr);
+    }
     CHK(hipGetLastError());
     CHK(hipMemcpyAsync(hy.data(), H->d_hyp, nhyp * sizeof(TrHyp), hipMemcpyDeviceToHost, H->stream));
     CHK(hipStreamSynchronize(H->stream));
