@@ -24,7 +24,7 @@ void ldso_set_error(const std::string &s);
 #define CHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { ldso_set_error(std::string(#call) + ": " + hipGetErrorString(e_)); return LDSO_E_HIP; } } while (0)
 #define REQ(cond, msg) do { if (!(cond)) { ldso_set_error(msg); return LDSO_E_INVALID; } } while (0)
 
-#define TR_NT 512          // one workgroup per hypothesis; 512 threads -> 256 VGPRs per lane (no spills in tr_eval)
+#define TR_NT 256          // 4 wavefronts, one per SIMD: 512 registers (VGPR + AGPR) per lane - tr_eval keeps 4 points per lane in flight without scratch spills
 #define TR_MAXL LDSO_PYR_LEVELS
 
 struct TrLevel {
@@ -181,16 +181,25 @@ __device__ __forceinline__ void aff_from_to_f(float expF, float expT, float aF, 
     b = bT - a * bF;
 }
 
-__device__ __forceinline__ void tr_eval(const TrParams &P, int lvl, const double *T, float aff_a, float aff_b, float cutoffTH, double *out /*LDS TR_NACC*/,
-                        double *red /*LDS [nWaves][TR_NACC]*/, int i0, int istride) {
+// A workgroup's share of a level: nAct workgroups split the n points into contiguous chunks (multiples of 64); a workgroup
+// works with only as many wavefronts as its share needs (TR_U points per lane), so the small levels pay the 52-value reduction
+// on few wavefronts.  The points of the first pass stay in registers across the evaluations of a level (they do not depend on the
+// candidate pose): an evaluation then costs ONE memory latency (the tap gather) instead of two.
+struct TrPts { float id[TR_U], x[TR_U], y[TR_U], col[TR_U]; int lvl; };
+
+__device__ __forceinline__ void tr_eval(const TrParams &P, int lvl, const float *Rt /*LDS: R row major (9), t (3)*/, float aff_a, float aff_b, float cutoffTH,
+                        double *out /*LDS TR_NACC*/, float *red /*LDS [TR_NT/16][TR_NACC]*/, int g, int nAct, TrPts &pc) {
     const TrLevel &L = P.lv[lvl];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nW = blockDim.x >> 6;
     const int wl = L.w, hl = L.h;
     const float fxl = L.fx, fyl = L.fy, cxl = L.cx, cyl = L.cy;
+    const int share = (((L.n + nAct - 1) / nAct) + 63) & ~63;
+    const int lo = g * share, hi = min(L.n, lo + share);
+    const int nWact = max(1, min(nW, (hi - lo + 64 * TR_U - 1) / (64 * TR_U))), nth = nWact * 64;
     // RKi = R.cast<float>() * Ki ; t.cast<float>()
-    float R[9], RKi[9], t[3];
-    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) R[r * 3 + c] = (float) T[r * 4 + c]; t[r] = (float) T[r * 4 + 3]; }
-    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) RKi[r * 3 + c] = (R[r * 3 + 0] * L.Ki[0 * 3 + c] + R[r * 3 + 1] * L.Ki[1 * 3 + c]) + R[r * 3 + 2] * L.Ki[2 * 3 + c];
+    float RKi[9], t[3];
+    for (int r = 0; r < 3; r++) t[r] = Rt[9 + r];
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) RKi[r * 3 + c] = (Rt[r * 3 + 0] * L.Ki[0 * 3 + c] + Rt[r * 3 + 1] * L.Ki[1 * 3 + c]) + Rt[r * 3 + 2] * L.Ki[2 * 3 + c];
     float affA, affB;
     aff_from_to_f(P.ref_exposure, P.new_exposure, P.ref_a, P.ref_b, aff_a, aff_b, affA, affB);
     const float maxEnergy = 2 * P.huberTH * cutoffTH - P.huberTH * P.huberTH;
@@ -200,22 +209,13 @@ __device__ __forceinline__ void tr_eval(const TrParams &P, int lvl, const double
 #pragma unroll
     for (int q = 0; q < TR_NACC; q++) acc[q] = 0.f;
 
-    // TR_U points per thread and pass: all point-cloud loads of a pass are issued together, then all 12-float tap gathers,
-    // so a pass costs two memory latencies instead of 2 x TR_U (a single workgroup runs the whole level).
-    for (int ib = i0 + tid; ib < L.n; ib += istride * TR_U) {
-        float id[TR_U], x[TR_U], y[TR_U], col[TR_U];
-        bool in[TR_U];
-#pragma unroll
-        for (int u_ = 0; u_ < TR_U; u_++) {
-            const int i = ib + u_ * istride;
-            in[u_] = i < L.n;
-            const int ic = in[u_] ? i : 0;
-            id[u_] = L.pc_idepth[ic]; x[u_] = L.pc_u[ic]; y[u_] = L.pc_v[ic]; col[u_] = L.pc_color[ic];
-        }
+    // one pass: TR_U points per lane; all 12-float tap gathers of a pass are issued together
+    auto pass = [&](const float (&id)[TR_U], const float (&x)[TR_U], const float (&y)[TR_U], const float (&col)[TR_U], int ib) {
         float uu[TR_U], vv[TR_U], Ku[TR_U], Kv[TR_U], nid[TR_U], tap[TR_U][12];
-        bool ok[TR_U];
+        bool ok[TR_U], in[TR_U];
 #pragma unroll
         for (int u_ = 0; u_ < TR_U; u_++) {
+            in[u_] = ib + u_ * nth < hi;
             float p0 = ((RKi[0] * x[u_] + RKi[1] * y[u_]) + RKi[2] * 1.0f) + t[0] * id[u_];
             float p1 = ((RKi[3] * x[u_] + RKi[4] * y[u_]) + RKi[5] * 1.0f) + t[1] * id[u_];
             float p2 = ((RKi[6] * x[u_] + RKi[7] * y[u_]) + RKi[8] * 1.0f) + t[2] * id[u_];
@@ -231,7 +231,7 @@ __device__ __forceinline__ void tr_eval(const TrParams &P, int lvl, const double
         }
 #pragma unroll
         for (int u_ = 0; u_ < TR_U; u_++) {
-            const int i = ib + u_ * istride;
+            const int i = ib + u_ * nth;
             if (in[u_] && lvl == 0 && i % 32 == 0) {
                 const float *Ki = L.Ki;
                 const float xx = x[u_], yy = y[u_], idd = id[u_];
@@ -286,20 +286,45 @@ __device__ __forceinline__ void tr_eval(const TrParams &P, int lvl, const double
                 }
             }
         }
-    }
-    // block reduction, fixed order: the 16 lanes of a DPP row in float (the per-lane sums are float already), then the
-    // 4 rows x nW waves in double by 52 threads
+    };
+
+    if (tid < nth) {
+        if (pc.lvl != lvl) {                     // uniform: first evaluation of this level
 #pragma unroll
-    for (int q = 0; q < TR_NACC; q++) {
-        float v = acc[q];
-        v += tr_dpp<0xB1>(v);      // quad_perm [1,0,3,2]
-        v += tr_dpp<0x4E>(v);      // quad_perm [2,3,0,1]
-        v += tr_dpp<0x141>(v);     // row_half_mirror
-        v += tr_dpp<0x140>(v);     // row_mirror          -> every lane holds the sum of its 16-lane row
-        if ((lane & 15) == 0) red[((wave << 2) + (lane >> 4)) * TR_NACC + q] = (double) v;
+            for (int u_ = 0; u_ < TR_U; u_++) {
+                const int i = lo + tid + u_ * nth;
+                const int ic = i < hi ? i : 0;
+                pc.id[u_] = L.pc_idepth[ic]; pc.x[u_] = L.pc_u[ic]; pc.y[u_] = L.pc_v[ic]; pc.col[u_] = L.pc_color[ic];
+            }
+        }
+        pass(pc.id, pc.x, pc.y, pc.col, lo + tid);
+        for (int ib = lo + tid + nth * TR_U; ib < hi; ib += nth * TR_U) {
+            float id[TR_U], x[TR_U], y[TR_U], col[TR_U];
+#pragma unroll
+            for (int u_ = 0; u_ < TR_U; u_++) {
+                const int i = ib + u_ * nth;
+                const int ic = i < hi ? i : 0;
+                id[u_] = L.pc_idepth[ic]; x[u_] = L.pc_u[ic]; y[u_] = L.pc_v[ic]; col[u_] = L.pc_color[ic];
+            }
+            pass(id, x, y, col, ib);
+        }
+    }
+    pc.lvl = lvl;
+    // block reduction, fixed order: the 16 lanes of a DPP row in float (the per-lane sums are float already), then the
+    // 4 rows x nWact waves in double by 52 threads
+    if (wave < nWact) {
+#pragma unroll
+        for (int q = 0; q < TR_NACC; q++) {
+            float v = acc[q];
+            v += tr_dpp<0xB1>(v);      // quad_perm [1,0,3,2]
+            v += tr_dpp<0x4E>(v);      // quad_perm [2,3,0,1]
+            v += tr_dpp<0x141>(v);     // row_half_mirror
+            v += tr_dpp<0x140>(v);     // row_mirror          -> every lane holds the sum of its 16-lane row
+            if ((lane & 15) == 0) red[((wave << 2) + (lane >> 4)) * TR_NACC + q] = v;
+        }
     }
     __syncthreads();
-    if (tid < TR_NACC) { double s = 0; for (int r = 0; r < nW * 4; r++) s += red[r * TR_NACC + tid]; out[tid] = s; }
+    if (tid < TR_NACC) { double s = 0; for (int r = 0; r < nWact * 4; r++) s += (double) red[r * TR_NACC + tid]; out[tid] = s; }
     __syncthreads();
 }
 
@@ -433,80 +458,130 @@ __device__ __forceinline__ void tr_vec6(const double *acc, double *rs) {
     rs[5] = (double) ((float) (int) acc[5] / (float) (int) acc[1]);
 }
 
+// The step when an affine parameter is fixed (setting_affineOptModeA/B < 0; CoarseTracker.cc:129-166): rare, single thread, kept out
+// of line so that its 8x8 temporaries (scratch memory) stay out of the tracking kernel's register allocation.
+__device__ __attribute__((noinline)) void tr_solve_fixed_affine(const double *sH, const double *sB, const double *sNb, float lambda, bool fixA, bool fixB, double *sInc) {
+    double Hl[64], inc[8];
+    for (int i = 0; i < 64; i++) Hl[i] = sH[i];
+    for (int i = 0; i < 8; i++) { Hl[i * 8 + i] *= (1 + lambda); inc[i] = 0; }
+    if (fixA && fixB) {
+        double H6[36], x6[6];
+        for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) H6[i * 6 + j] = Hl[i * 8 + j];
+        small_ldlt_solve(H6, sNb, x6, 6);
+        for (int i = 0; i < 6; i++) inc[i] = x6[i];
+    } else if (fixB) {
+        double H7[49], x7[7];
+        for (int i = 0; i < 7; i++) for (int j = 0; j < 7; j++) H7[i * 7 + j] = Hl[i * 8 + j];
+        small_ldlt_solve(H7, sNb, x7, 7);
+        for (int i = 0; i < 7; i++) inc[i] = x7[i];
+    } else {
+        double bs[8], H7[49], x7[7], nb7[7];
+        for (int i = 0; i < 8; i++) bs[i] = sB[i];
+        for (int i = 0; i < 8; i++) Hl[i * 8 + 6] = Hl[i * 8 + 7];
+        for (int j = 0; j < 8; j++) Hl[6 * 8 + j] = Hl[7 * 8 + j];
+        bs[6] = bs[7];
+        for (int i = 0; i < 7; i++) { nb7[i] = -bs[i]; for (int j = 0; j < 7; j++) H7[i * 7 + j] = Hl[i * 8 + j]; }
+        small_ldlt_solve(H7, nb7, x7, 7);
+        for (int i = 0; i < 6; i++) inc[i] = x7[i];
+        inc[7] = x7[6];
+    }
+    for (int i = 0; i < 8; i++) sInc[i] = inc[i];
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Cooperative evaluation: G workgroups share ONE hypothesis.  Workgroup 0 of the group runs the LM loop (it is the only one that
 // decides anything); for every calcRes / calcGSSSE evaluation it publishes the candidate (pose, affine, level, cut-off) in device
-// memory and bumps a sequence number, every workgroup of the group evaluates an interleaved 1/nAct share of the level's points
-// (nAct grows with the level size: the coarsest levels stay on the leader alone), the helpers store their 52 partial sums and bump a
-// counter, the leader adds the partials in workgroup order (deterministic).  The hand-over uses device-scope atomics only (performed
-// at the memory side, visible across the XCDs' L2s) - the same scheme as k_reduce_solve.  All workgroups of a launch must be
-// resident (the host bounds nhyp * G by the CU count).
+// memory under a new sequence number, every workgroup of the group evaluates a contiguous 1/nAct share of the level's points
+// (nAct grows with the level size: the coarse levels stay on the leader alone), the helpers store their 52 partial sums, the
+// leader adds them in workgroup order (deterministic).  The hand-over is made of self-validating 64-bit words (payload | sequence
+// number) written and read with device-scope relaxed atomics (performed at the memory side, visible across the XCDs' L2s): one
+// memory round trip per direction, no fences, no counters.  All workgroups of a launch must be resident (the host bounds
+// nhyp * G by the CU count); sequence numbers grow over the launches of a handle, so nothing has to be cleared in between.
 // ---------------------------------------------------------------------------------------------------------
-#define TR_GMAX 8
+#define TR_GMAX 16
+#define TR_COOP_MIN (TR_NT * TR_U + 1)     // a level one workgroup evaluates in a single pass stays on the leader (cheaper than a hand-over)
+#define TR_COOP_PER (TR_NT * TR_U)         // target share per workgroup on the shared levels: one pass
 struct TrCoop {
-    double T[12];
-    float a, b, cutoff;
-    int lvl;                  // -1: the track is over
-    int seq;                  // bumped by the leader after the fields above are visible
-    int done;                 // cumulative count of helper acknowledgements
-    int pad_[2];
-    double part[TR_GMAX][TR_NACC];
+    // every 64-bit word carries (payload << 32 | sequence number): a word is valid by itself, no fence / second round trip needed
+    unsigned long long cmd[16];                          // R (9), t (3) as float, affine a, b, cut-off, level (-1: the track is over)
+    unsigned long long part[TR_GMAX][TR_NACC][2];        // a helper's partial sums: low / high half of the double
 };
-template <class T_> __device__ __forceinline__ T_ tr_ld(const T_ *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-template <class T_> __device__ __forceinline__ void tr_st(T_ *p, T_ v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ int tr_nact(int n, int G) { const int per = TR_NT * TR_U; return max(1, min(G, (n + per - 1) / per)); }
+__device__ __forceinline__ unsigned long long tr_ld(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void tr_st(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int tr_nact(int n, int G) { return (G == 1 || n < TR_COOP_MIN) ? 1 : min(G, (n + TR_COOP_PER - 1) / TR_COOP_PER); }
 
 // leader side of one evaluation (all threads of the leader workgroup)
 template <int G>
-__device__ __forceinline__ void tr_eval_lead(const TrParams &P, int lvl, const double *T, float a, float b, float cutoff, double *sAcc, double *sRed, TrCoop *co, int &seq, int &acks) {
-    if (G == 1) { tr_eval(P, lvl, T, a, b, cutoff, sAcc, sRed, 0, TR_NT); return; }
+__device__ __forceinline__ void tr_eval_lead(const TrParams &P, int lvl, const double *T, float a, float b, float cutoff, double *sAcc, float *sRed, float *sRt,
+                                             TrCoop *co, int &seq, TrPts &pc) {
     const int tid = threadIdx.x, nAct = tr_nact(P.lv[lvl].n, G);
-    if (nAct > 1) {
-        if (tid < 12) tr_st(&co->T[tid], T[tid]);
-        if (tid == 12) { tr_st(&co->a, a); tr_st(&co->b, b); tr_st(&co->cutoff, cutoff); tr_st(&co->lvl, lvl); }
-        __builtin_amdgcn_s_waitcnt(0);
-        __syncthreads();
+    if (tid < 12) sRt[tid] = (float) T[tid < 9 ? (tid / 3) * 4 + tid % 3 : (tid - 9) * 4 + 3];
+    __syncthreads();
+    if (G > 1 && nAct > 1) {
         ++seq;
-        if (tid == 0) tr_st(&co->seq, seq);
+        if (tid < 16) {
+            const unsigned pl = tid < 12 ? __builtin_bit_cast(unsigned, sRt[tid]) : tid == 12 ? __builtin_bit_cast(unsigned, a) : tid == 13 ? __builtin_bit_cast(unsigned, b)
+                              : tid == 14 ? __builtin_bit_cast(unsigned, cutoff) : (unsigned) lvl;
+            tr_st(&co->cmd[tid], ((unsigned long long) pl << 32) | (unsigned) seq);
+        }
     }
-    tr_eval(P, lvl, T, a, b, cutoff, sAcc, sRed, 0, nAct * TR_NT);
-    if (nAct > 1) {
-        acks += nAct - 1;
-        if (tid == 0) while (tr_ld(&co->done) < acks) __builtin_amdgcn_s_sleep(1);
-        __syncthreads();
-        if (tid < TR_NACC) { double s_ = sAcc[tid]; for (int g = 1; g < nAct; g++) s_ += tr_ld(&co->part[g][tid]); sAcc[tid] = s_; }
+    tr_eval(P, lvl, sRt, a, b, cutoff, sAcc, sRed, 0, nAct, pc);
+    if (G > 1 && nAct > 1) {
+        if (tid < TR_NACC) {
+            // all helpers' words are requested together (one memory round trip once they are there), added in workgroup order
+            unsigned long long w0[G > 1 ? G - 1 : 1], w1[G > 1 ? G - 1 : 1];
+            bool ok;
+            do {
+                ok = true;
+#pragma unroll
+                for (int g = 1; g < G; g++) if (g < nAct) {
+                    w0[g - 1] = tr_ld(&co->part[g][tid][0]); w1[g - 1] = tr_ld(&co->part[g][tid][1]);
+                }
+#pragma unroll
+                for (int g = 1; g < G; g++) if (g < nAct) ok = ok && ((unsigned) w0[g - 1] == (unsigned) seq) && ((unsigned) w1[g - 1] == (unsigned) seq);
+            } while (!ok);
+            double s_ = sAcc[tid];
+#pragma unroll
+            for (int g = 1; g < G; g++) if (g < nAct) s_ += __builtin_bit_cast(double, (w1[g - 1] & 0xFFFFFFFF00000000ull) | (w0[g - 1] >> 32));
+            sAcc[tid] = s_;
+        }
         __syncthreads();
     }
 }
 
 // helper workgroups: evaluate shares until the leader says the track is over
 template <int G>
-__device__ void tr_helper_loop(const TrParams &P, TrCoop *co, int g, double *sAcc, double *sRed, double *sT, float *sF, int *sI) {
+__device__ void tr_helper_loop(const TrParams &P, TrCoop *co, int g, int seq, double *sAcc, float *sRed, float *sRt, float *sF, int *sI) {
     const int tid = threadIdx.x;
-    int seq = 0;
+    TrPts pc; pc.lvl = -1;
     for (;;) {
-        if (tid == 0) { int s_; while ((s_ = tr_ld(&co->seq)) <= seq) __builtin_amdgcn_s_sleep(1); sI[1] = s_; }
+        if (tid < 64) {
+            // the 16 command words are read by one instruction; they belong to one command when their sequence numbers agree (a
+            // command this workgroup takes part in is stable until it has answered; torn reads only happen on commands it sits out)
+            unsigned long long w; unsigned tag, t0; bool ok;
+            do {
+                w = tr_ld(&co->cmd[tid & 15]); tag = (unsigned) w;
+                t0 = (unsigned) __builtin_amdgcn_readfirstlane((int) tag);
+                ok = (__builtin_amdgcn_ballot_w64(tag != t0) == 0ull) && ((int) (t0 - (unsigned) seq) > 0);
+                if (!ok) __builtin_amdgcn_s_sleep(1);
+            } while (!ok);
+            const unsigned pl = (unsigned) (w >> 32);
+            if (tid < 12) sRt[tid] = __builtin_bit_cast(float, pl);
+            else if (tid < 15) sF[tid - 12] = __builtin_bit_cast(float, pl);
+            else if (tid == 15) { sI[0] = (int) pl; sI[1] = (int) t0; }
+        }
         __syncthreads();
-        const int s_ = sI[1];
-        if (tid < 12) sT[tid] = tr_ld(&co->T[tid]);
-        if (tid == 12) { sF[0] = tr_ld(&co->a); sF[1] = tr_ld(&co->b); sF[2] = tr_ld(&co->cutoff); sI[0] = tr_ld(&co->lvl); }
-        __syncthreads();
-        // seqlock: the leader only moves on from a command once every workgroup that takes part in it has acknowledged, so a command this
-        // workgroup takes part in is stable while it is read; a torn read can only belong to commands it sits out - read again
-        if (tid == 0) sI[2] = (tr_ld(&co->seq) == s_) ? 1 : 0;
-        __syncthreads();
-        const int stable = sI[2], lvl = sI[0];
-        __syncthreads();
-        if (!stable) continue;
-        seq = s_;
+        const int lvl = sI[0];
+        seq = sI[1];
         if (lvl < 0) return;
         const int nAct = tr_nact(P.lv[lvl].n, G);
         if (g < nAct) {
-            tr_eval(P, lvl, sT, sF[0], sF[1], sF[2], sAcc, sRed, g * TR_NT, nAct * TR_NT);
-            if (tid < TR_NACC) tr_st(&co->part[g][tid], sAcc[tid]);
-            __builtin_amdgcn_s_waitcnt(0);
-            __syncthreads();
-            if (tid == 0) __hip_atomic_fetch_add(&co->done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            tr_eval(P, lvl, sRt, sF[0], sF[1], sF[2], sAcc, sRed, g, nAct, pc);
+            if (tid < TR_NACC) {
+                const unsigned long long u = __builtin_bit_cast(unsigned long long, sAcc[tid]);
+                tr_st(&co->part[g][tid][0], (u << 32) | (unsigned) seq);
+                tr_st(&co->part[g][tid][1], (u & 0xFFFFFFFF00000000ull) | (unsigned) seq);
+            }
         }
         __syncthreads();
     }
@@ -516,9 +591,11 @@ __device__ void tr_helper_loop(const TrParams &P, TrCoop *co, int g, double *sAc
 // trackNewestCoarse: G workgroups per hypothesis (G = 1: one workgroup runs everything)
 // ---------------------------------------------------------------------------------------------------------
 template <int G>
-__global__ __launch_bounds__(TR_NT) void k_tr_track(TrParams P, TrHyp *hyps, TrCoop *coop) {
+__global__ __launch_bounds__(TR_NT) void k_tr_track(const TrParams *__restrict__ Pp, TrHyp *hyps, TrCoop *coop, int seq0) {
+    const TrParams &P = *Pp;      // device memory, not a by-value argument: a dynamically indexed kernel argument would be copied to scratch memory
     __shared__ double sAcc[TR_NACC];
-    __shared__ double sRed[(TR_NT / 16) * TR_NACC];
+    __shared__ float sRed[(TR_NT / 16) * TR_NACC];
+    __shared__ float sRt[12];
     __shared__ double sT[12], sTnew[12];
     __shared__ float sAff[2], sAffNew[2];
     __shared__ double sH[64], sB[8], sNb[8], sInc[8], sResOld[6], sResNew[6];
@@ -537,8 +614,9 @@ __global__ __launch_bounds__(TR_NT) void k_tr_track(TrParams P, TrHyp *hyps, TrC
     TrHyp &hy = hyps[blockIdx.x / G];
     TrCoop *co = (G > 1) ? coop + blockIdx.x / G : nullptr;
     const int tid = threadIdx.x;
-    int coSeq = 0, coAcks = 0;
-    if (G > 1 && (blockIdx.x % G) != 0) { tr_helper_loop<G>(P, co, (int) (blockIdx.x % G), sAcc, sRed, sT, sCoF, sCtl); return; }
+    int coSeq = seq0;
+    if (G > 1 && (blockIdx.x % G) != 0) { tr_helper_loop<G>(P, co, (int) (blockIdx.x % G), seq0, sAcc, sRed, sRt, sCoF, sCtl); return; }
+    TrPts pc; pc.lvl = -1;
     if (tid < 12) sT[tid] = hy.T[tid];
     if (tid == 0) { sAff[0] = hy.a; sAff[1] = hy.b; sCtl[3] = 0; sCtl[2] = 0; for (int i = 0; i < 5; i++) hy.lastResiduals[i] = NAN; for (int i = 0; i < 3; i++) hy.flow[i] = 1000; }
     __syncthreads();
@@ -548,12 +626,12 @@ __global__ __launch_bounds__(TR_NT) void k_tr_track(TrParams P, TrHyp *hyps, TrC
 
     for (int lvl = hy.coarsestLvl; lvl >= 0; lvl--) {
         float levelCutoffRepeat = 1;
-        TEV(tr_eval_lead<G>(P, lvl, sT, sAff[0], sAff[1], P.coarseCutoffTH * levelCutoffRepeat, sAcc, sRed, co, coSeq, coAcks););
+        TEV(tr_eval_lead<G>(P, lvl, sT, sAff[0], sAff[1], P.coarseCutoffTH * levelCutoffRepeat, sAcc, sRed, sRt, co, coSeq, pc););
         if (tid == 0) tr_vec6(sAcc, sResOld);
         __syncthreads();
         while (sResOld[5] > 0.6 && levelCutoffRepeat < 50) {
             levelCutoffRepeat *= 2;
-            TEV(tr_eval_lead<G>(P, lvl, sT, sAff[0], sAff[1], P.coarseCutoffTH * levelCutoffRepeat, sAcc, sRed, co, coSeq, coAcks););
+            TEV(tr_eval_lead<G>(P, lvl, sT, sAff[0], sAff[1], P.coarseCutoffTH * levelCutoffRepeat, sAcc, sRed, sRt, co, coSeq, pc););
             if (tid == 0) tr_vec6(sAcc, sResOld);
             __syncthreads();
         }
@@ -570,37 +648,10 @@ __global__ __launch_bounds__(TR_NT) void k_tr_track(TrParams P, TrHyp *hyps, TrC
             if (tid == 0) {
                 sCtl[3]++;
                 const float lambda = sLambda;
-                double Hl[64], nb[8], inc[8];
-                for (int i = 0; i < 8; i++) { inc[i] = sInc[i]; nb[i] = sNb[i]; }
+                double inc[8];
                 const bool fixA = P.affineOptModeA < 0, fixB = P.affineOptModeB < 0;
-                if (fixA || fixB) { for (int i = 0; i < 64; i++) Hl[i] = sH[i]; for (int i = 0; i < 8; i++) Hl[i * 8 + i] *= (1 + lambda); }
-                if (fixA && fixB) {
-                    double H6[36], x6[6];
-                    for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) H6[i * 6 + j] = Hl[i * 8 + j];
-                    small_ldlt_solve(H6, nb, x6, 6);
-                    for (int i = 0; i < 6; i++) inc[i] = x6[i];
-                    inc[6] = 0; inc[7] = 0;
-                }
-                if (!fixA && fixB) {
-                    double H7[49], x7[7];
-                    for (int i = 0; i < 7; i++) for (int j = 0; j < 7; j++) H7[i * 7 + j] = Hl[i * 8 + j];
-                    small_ldlt_solve(H7, nb, x7, 7);
-                    for (int i = 0; i < 7; i++) inc[i] = x7[i];
-                    inc[7] = 0;
-                }
-                if (fixA && !fixB) {
-                    double Hs[64], bs[8], H7[49], x7[7], nb7[7];
-                    for (int i = 0; i < 64; i++) Hs[i] = Hl[i];
-                    for (int i = 0; i < 8; i++) bs[i] = sB[i];
-                    for (int i = 0; i < 8; i++) Hs[i * 8 + 6] = Hs[i * 8 + 7];
-                    for (int j = 0; j < 8; j++) Hs[6 * 8 + j] = Hs[7 * 8 + j];
-                    bs[6] = bs[7];
-                    for (int i = 0; i < 7; i++) { nb7[i] = -bs[i]; for (int j = 0; j < 7; j++) H7[i * 7 + j] = Hs[i * 8 + j]; }
-                    small_ldlt_solve(H7, nb7, x7, 7);
-                    for (int i = 0; i < 8; i++) inc[i] = 0;
-                    for (int i = 0; i < 6; i++) inc[i] = x7[i];
-                    inc[7] = x7[6];
-                }
+                if (fixA || fixB) tr_solve_fixed_affine(sH, sB, sNb, lambda, fixA, fixB, sInc);
+                for (int i = 0; i < 8; i++) inc[i] = sInc[i];
                 float extrapFac = 1;
                 if (lambda < lambdaExtrapolationLimit) extrapFac = sqrtf((float) sqrt((double) (lambdaExtrapolationLimit / lambda)));
                 double incScaled[8], nrm = 0, sum = 0;
@@ -615,7 +666,7 @@ __global__ __launch_bounds__(TR_NT) void k_tr_track(TrParams P, TrHyp *hyps, TrC
                 sCtl[0] = (sqrt(nrm) > 1e-3) ? 1 : 0;          // continue after this iteration?
             }
             __syncthreads();
-            TEV(tr_eval_lead<G>(P, lvl, sTnew, sAffNew[0], sAffNew[1], P.coarseCutoffTH * levelCutoffRepeat, sAcc, sRed, co, coSeq, coAcks););
+            TEV(tr_eval_lead<G>(P, lvl, sTnew, sAffNew[0], sAffNew[1], P.coarseCutoffTH * levelCutoffRepeat, sAcc, sRed, sRt, co, coSeq, pc););
             if (tid == 0) {
                 tr_vec6(sAcc, sResNew);
                 sCtl[1] = ((sResNew[0] / sResNew[1]) < (sResOld[0] / sResOld[1])) ? 1 : 0;
@@ -651,7 +702,8 @@ __global__ __launch_bounds__(TR_NT) void k_tr_track(TrParams P, TrHyp *hyps, TrC
     if (tid == 0) { hy.dbg[0] = (double) tEval; hy.dbg[1] = (double) (wall_clock64() - tTot0); hy.dbg[2] = nEval; for (int q = 0; q < 5; q++) hy.dbg[3 + q] = nLv[q] ? (double) tLv[q] / nLv[q] : 0.0; }
 #endif
     if (G > 1) {      // release the helper workgroups
-        if (tid == 0) { tr_st(&co->lvl, -1); __builtin_amdgcn_s_waitcnt(0); tr_st(&co->seq, coSeq + 1); }
+        ++coSeq;
+        if (tid < 16) tr_st(&co->cmd[tid], ((unsigned long long) 0xFFFFFFFFu << 32) | (unsigned) coSeq);
     }
     if (tid == 0) {
         hy.iterations = sCtl[3];
@@ -673,13 +725,16 @@ __global__ __launch_bounds__(TR_NT) void k_tr_track(TrParams P, TrHyp *hyps, TrC
 }
 
 // stand-alone calcRes / calcGSSSE for the step-wise API (one workgroup)
-__global__ __launch_bounds__(TR_NT) void k_tr_calc(TrParams P, int lvl, const double *Tdev, float a, float b, float cutoffTH, double *outAcc) {
+__global__ __launch_bounds__(TR_NT) void k_tr_calc(const TrParams *__restrict__ Pp, int lvl, const double *Tdev, float a, float b, float cutoffTH, double *outAcc) {
+    const TrParams &P = *Pp;
     __shared__ double sAcc[TR_NACC];
-    __shared__ double sRed[(TR_NT / 16) * TR_NACC];
-    __shared__ double sT[12];
-    if (threadIdx.x < 12) sT[threadIdx.x] = Tdev[threadIdx.x];
+    __shared__ float sRed[(TR_NT / 16) * TR_NACC];
+    __shared__ float sRt[12];
+    const int tid = threadIdx.x;
+    if (tid < 12) sRt[tid] = (float) Tdev[tid < 9 ? (tid / 3) * 4 + tid % 3 : (tid - 9) * 4 + 3];
     __syncthreads();
-    tr_eval(P, lvl, sT, a, b, cutoffTH, sAcc, sRed, 0, TR_NT);
+    TrPts pc; pc.lvl = -1;
+    tr_eval(P, lvl, sRt, a, b, cutoffTH, sAcc, sRed, 0, 1, pc);
     if (threadIdx.x < TR_NACC) outAcc[threadIdx.x] = sAcc[threadIdx.x];
 }
 
@@ -700,8 +755,9 @@ struct ldso_tracker {
     int *d_total = nullptr;
     double *d_T = nullptr, *d_acc = nullptr;
     TrHyp *d_hyp = nullptr;
+    TrParams *d_P = nullptr, *h_P = nullptr, Pdev;   // device copy of P (what the kernels read), pinned staging buffer, what the device copy holds
     TrCoop *d_coop = nullptr;         // cooperative evaluation: one record per hypothesis
-    int numCU = 256;
+    int numCU = 256, coopSeq = 1;     // sequence numbers already used by earlier launches on d_coop
     double lastAcc[TR_NACC];
     bool haveAcc = false;
     int lastEvals[5] = {0, 0, 0, 0, 0};      // of hypothesis 0 of the last track call
@@ -716,6 +772,17 @@ template <class T> static int tr_alloc(ldso_tracker *H, T **p, size_t n) {
     return LDSO_OK;
 }
 #define TA(ptr, n) do { int r_ = tr_alloc(H, &(ptr), (n)); if (r_ != LDSO_OK) return r_; } while (0)
+
+// the kernels read TrParams from device memory: upload it when the host copy changed (stream ordered; the callers synchronise the
+// stream before they return, so the pinned staging buffer is free again)
+static int tr_sync_params(ldso_tracker *H) {
+    if (memcmp(&H->P, &H->Pdev, sizeof(TrParams)) == 0) return LDSO_OK;
+    CHK(hipStreamSynchronize(H->stream));
+    memcpy(H->h_P, &H->P, sizeof(TrParams));
+    CHK(hipMemcpyAsync(H->d_P, H->h_P, sizeof(TrParams), hipMemcpyHostToDevice, H->stream));
+    H->Pdev = H->P;
+    return LDSO_OK;
+}
 
 extern "C" {
 
@@ -745,7 +812,9 @@ int ldso_tr_create(int device, int w, int h, int levels, ldso_tracker_t **out) {
         L.idepth += 64; L.wsum += 64; L.wsum_bak += 64;
         TA(L.blockCnt, n / 256 + 2);
     }
-    TA(H->d_total, 1); TA(H->d_T, 12); TA(H->d_acc, TR_NACC); TA(H->d_hyp, 128); TA(H->d_coop, 128);
+    TA(H->d_total, 1); TA(H->d_T, 12); TA(H->d_acc, TR_NACC); TA(H->d_hyp, 128); TA(H->d_coop, 64); TA(H->d_P, 1);
+    CHK(hipHostMalloc((void **) &H->h_P, sizeof(TrParams)));
+    memset(&H->Pdev, 0xFF, sizeof(TrParams));
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) H->numCU = pr.multiProcessorCount; }
     *out = H;
     return LDSO_OK;
@@ -758,6 +827,7 @@ int ldso_tr_destroy(ldso_tracker_t *H) {
     for (void *p : H->allocs) hipFree(p);
     if (H->d_pts) hipFree(H->d_pts);
     if (H->d_color) hipFree(H->d_color);
+    if (H->h_P) hipHostFree(H->h_P);
     if (H->ownStream && H->stream) hipStreamDestroy(H->stream);
     delete H;
     return LDSO_OK;
@@ -883,7 +953,8 @@ int ldso_tr_get_new_frame_level(ldso_tracker_t *H, int lvl, float *out) {
 
 static int tr_calc(ldso_tracker *H, int lvl, const double *T, float a, float b, float cutoff) {
     CHK(hipMemcpyAsync(H->d_T, T, 12 * 8, hipMemcpyHostToDevice, H->stream));
-    hipLaunchKernelGGL(k_tr_calc, dim3(1), dim3(TR_NT), 0, H->stream, H->P, lvl, H->d_T, a, b, cutoff, H->d_acc);
+    { const int r_ = tr_sync_params(H); if (r_ != LDSO_OK) return r_; }
+    hipLaunchKernelGGL(k_tr_calc, dim3(1), dim3(TR_NT), 0, H->stream, H->d_P, lvl, H->d_T, a, b, cutoff, H->d_acc);
     CHK(hipGetLastError());
     CHK(hipMemcpyAsync(H->lastAcc, H->d_acc, TR_NACC * 8, hipMemcpyDeviceToHost, H->stream));
     CHK(hipStreamSynchronize(H->stream));
@@ -933,11 +1004,16 @@ int ldso_tr_track_batch(ldso_tracker_t *H, int nhyp, double *T_inout /*nhyp*12*/
     CHK(hipMemcpyAsync(H->d_hyp, hy.data(), nhyp * sizeof(TrHyp), hipMemcpyHostToDevice, H->stream));
     // few hypotheses: TR_GMAX workgroups share each of them on the large levels (all workgroups resident: nhyp * G <= CUs);
     // many hypotheses fill the chip by themselves
-    if (nhyp * TR_GMAX <= H->numCU && !getenv("LDSO_TR_NO_COOP")) {
-        CHK(hipMemsetAsync(H->d_coop, 0, (size_t) nhyp * sizeof(TrCoop), H->stream));
-        hipLaunchKernelGGL(k_tr_track<TR_GMAX>, dim3(nhyp * TR_GMAX), dim3(TR_NT), 0, H->stream, H->P, H->d_hyp, H->d_coop);
+    { const int r_ = tr_sync_params(H); if (r_ != LDSO_OK) return r_; }
+    const int G = getenv("LDSO_TR_NO_COOP") ? 1 : nhyp * 16 <= H->numCU ? 16 : nhyp * 8 <= H->numCU ? 8 : nhyp * 4 <= H->numCU ? 4 : 1;
+    if (G > 1) {
+        if (H->coopSeq > (1 << 30)) { CHK(hipMemsetAsync(H->d_coop, 0, 64 * sizeof(TrCoop), H->stream)); H->coopSeq = 1; }
+        if (G == 16) hipLaunchKernelGGL(k_tr_track<16>, dim3(nhyp * 16), dim3(TR_NT), 0, H->stream, H->d_P, H->d_hyp, H->d_coop, H->coopSeq);
+        else if (G == 8) hipLaunchKernelGGL(k_tr_track<8>, dim3(nhyp * 8), dim3(TR_NT), 0, H->stream, H->d_P, H->d_hyp, H->d_coop, H->coopSeq);
+        else hipLaunchKernelGGL(k_tr_track<4>, dim3(nhyp * 4), dim3(TR_NT), 0, H->stream, H->d_P, H->d_hyp, H->d_coop, H->coopSeq);
+        H->coopSeq += 1024;           // more than the evaluations of one track (5 levels x (50 iterations + 7 cut-off repeats) + 1)
     } else {
-        hipLaunchKernelGGL(k_tr_track<1>, dim3(nhyp), dim3(TR_NT), 0, H->stream, H->P, H->d_hyp, (TrCoop *) nullptr);
+        hipLaunchKernelGGL(k_tr_track<1>, dim3(nhyp), dim3(TR_NT), 0, H->stream, H->d_P, H->d_hyp, (TrCoop *) nullptr, 0);
     }
     CHK(hipGetLastError());
     CHK(hipMemcpyAsync(hy.data(), H->d_hyp, nhyp * sizeof(TrHyp), hipMemcpyDeviceToHost, H->stream));
