@@ -186,13 +186,25 @@ __device__ __forceinline__ void aff_from_to_f(float expF, float expT, float aF, 
 // on few wavefronts.  The points of the first pass stay in registers across the evaluations of a level (they do not depend on the
 // candidate pose): an evaluation then costs ONE memory latency (the tap gather) instead of two.
 struct TrPts { float id[TR_U], x[TR_U], y[TR_U], col[TR_U]; int lvl; };
+// pointers read from TrParams are generic to the compiler (flat loads); they all point to device memory
+typedef const __attribute__((address_space(1))) float *tr_gptr;
 
+#if LD_STAMP_ON_TR
+__device__ long long g_trPh[5][8];      // debug: per level, time in the phases of tr_eval (wave 0 of workgroup 0), and the evaluation count
+#define TPH(k) do { if (threadIdx.x == 0 && blockIdx.x == 0) { long long n_ = wall_clock64(); g_trPh[lvl][k] += n_ - tph_; tph_ = n_; } } while (0)
+#else
+#define TPH(k) do { } while (0)
+#endif
 __device__ __forceinline__ void tr_eval(const TrParams &P, int lvl, const float *Rt /*LDS: R row major (9), t (3)*/, float aff_a, float aff_b, float cutoffTH,
                         double *out /*LDS TR_NACC*/, float *red /*LDS [TR_NT/16][TR_NACC]*/, int g, int nAct, TrPts &pc) {
     const TrLevel &L = P.lv[lvl];
+#if LD_STAMP_ON_TR
+    long long tph_ = wall_clock64();
+#endif
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nW = blockDim.x >> 6;
     const int wl = L.w, hl = L.h;
     const float fxl = L.fx, fyl = L.fy, cxl = L.cx, cyl = L.cy;
+    const tr_gptr gImg = (tr_gptr) L.newImg, gId = (tr_gptr) L.pc_idepth, gU = (tr_gptr) L.pc_u, gV = (tr_gptr) L.pc_v, gCol = (tr_gptr) L.pc_color;
     const int share = (((L.n + nAct - 1) / nAct) + 63) & ~63;
     const int lo = g * share, hi = min(L.n, lo + share);
     const int nWact = max(1, min(nW, (hi - lo + 64 * TR_U - 1) / (64 * TR_U))), nth = nWact * 64;
@@ -208,6 +220,8 @@ __device__ __forceinline__ void tr_eval(const TrParams &P, int lvl, const float 
     float acc[TR_NACC];
 #pragma unroll
     for (int q = 0; q < TR_NACC; q++) acc[q] = 0.f;
+    if (__builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, RKi[0] + affA + (float) nth)) == 0x7fc01234) acc[0] = 1;   // keeps the set-up ahead of the stamp
+    TPH(0);
 
     // one pass: TR_U points per lane; all 12-float tap gathers of a pass are issued together
     auto pass = [&](const float (&id)[TR_U], const float (&x)[TR_U], const float (&y)[TR_U], const float (&col)[TR_U], int ib) {
@@ -224,8 +238,8 @@ __device__ __forceinline__ void tr_eval(const TrParams &P, int lvl, const float 
             nid[u_] = id[u_] / p2;
             ok[u_] = in[u_] && (Ku[u_] > 2 && Kv[u_] > 2 && Ku[u_] < wl - 3 && Kv[u_] < hl - 3 && nid[u_] > 0);
             const int ix = ok[u_] ? (int) Ku[u_] : 0, iy = ok[u_] ? (int) Kv[u_] : 0;
-            const float *bp = L.newImg + 3 * (ix + iy * wl);
-            const float *bq = bp + 3 * wl;
+            const tr_gptr bp = gImg + 3 * (ix + iy * wl);
+            const tr_gptr bq = bp + 3 * wl;
 #pragma unroll
             for (int c = 0; c < 6; c++) { tap[u_][c] = bp[c]; tap[u_][6 + c] = bq[c]; }
         }
@@ -294,7 +308,7 @@ __device__ __forceinline__ void tr_eval(const TrParams &P, int lvl, const float 
             for (int u_ = 0; u_ < TR_U; u_++) {
                 const int i = lo + tid + u_ * nth;
                 const int ic = i < hi ? i : 0;
-                pc.id[u_] = L.pc_idepth[ic]; pc.x[u_] = L.pc_u[ic]; pc.y[u_] = L.pc_v[ic]; pc.col[u_] = L.pc_color[ic];
+                pc.id[u_] = gId[ic]; pc.x[u_] = gU[ic]; pc.y[u_] = gV[ic]; pc.col[u_] = gCol[ic];
             }
         }
         pass(pc.id, pc.x, pc.y, pc.col, lo + tid);
@@ -304,28 +318,41 @@ __device__ __forceinline__ void tr_eval(const TrParams &P, int lvl, const float 
             for (int u_ = 0; u_ < TR_U; u_++) {
                 const int i = ib + u_ * nth;
                 const int ic = i < hi ? i : 0;
-                id[u_] = L.pc_idepth[ic]; x[u_] = L.pc_u[ic]; y[u_] = L.pc_v[ic]; col[u_] = L.pc_color[ic];
+                id[u_] = gId[ic]; x[u_] = gU[ic]; y[u_] = gV[ic]; col[u_] = gCol[ic];
             }
             pass(id, x, y, col, ib);
         }
     }
     pc.lvl = lvl;
+    if (__builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, acc[0] + acc[51] + acc[20])) == 0x7fc01234) acc[1] = 1;
+    TPH(1);
     // block reduction, fixed order: the 16 lanes of a DPP row in float (the per-lane sums are float already), then the
     // 4 rows x nWact waves in double by 52 threads
     if (wave < nWact) {
+        // four sweeps over the 52 sums (independent instructions within a sweep: a per-sum chain would stall on every DPP hazard)
 #pragma unroll
-        for (int q = 0; q < TR_NACC; q++) {
-            float v = acc[q];
-            v += tr_dpp<0xB1>(v);      // quad_perm [1,0,3,2]
-            v += tr_dpp<0x4E>(v);      // quad_perm [2,3,0,1]
-            v += tr_dpp<0x141>(v);     // row_half_mirror
-            v += tr_dpp<0x140>(v);     // row_mirror          -> every lane holds the sum of its 16-lane row
-            if ((lane & 15) == 0) red[((wave << 2) + (lane >> 4)) * TR_NACC + q] = v;
+        for (int q = 0; q < TR_NACC; q++) acc[q] += tr_dpp<0xB1>(acc[q]);       // quad_perm [1,0,3,2]
+#pragma unroll
+        for (int q = 0; q < TR_NACC; q++) acc[q] += tr_dpp<0x4E>(acc[q]);       // quad_perm [2,3,0,1]
+#pragma unroll
+        for (int q = 0; q < TR_NACC; q++) acc[q] += tr_dpp<0x141>(acc[q]);      // row_half_mirror
+#pragma unroll
+        for (int q = 0; q < TR_NACC; q++) acc[q] += tr_dpp<0x140>(acc[q]);      // row_mirror -> every lane holds the sum of its 16-lane row
+        if ((lane & 15) == 0) {
+            float4 *dst = reinterpret_cast<float4 *>(red + ((wave << 2) + (lane >> 4)) * TR_NACC);
+#pragma unroll
+            for (int q = 0; q < TR_NACC; q += 4) dst[q >> 2] = make_float4(acc[q], acc[q + 1], acc[q + 2], acc[q + 3]);
         }
     }
+    TPH(2);
     __syncthreads();
+    TPH(3);
     if (tid < TR_NACC) { double s = 0; for (int r = 0; r < nWact * 4; r++) s += (double) red[r * TR_NACC + tid]; out[tid] = s; }
     __syncthreads();
+    TPH(4);
+#if LD_STAMP_ON_TR
+    if (threadIdx.x == 0 && blockIdx.x == 0) g_trPh[lvl][7]++;
+#endif
 }
 
 // H (8x8), b (8) from the accumulated sums: divide by the padded n, apply the reference's scale swap.
@@ -389,64 +416,67 @@ __device__ __forceinline__ double tr_bcast64(double v, int l) {
     return __builtin_bit_cast(double, ((unsigned long long) hi << 32) | lo);
 }
 
-// Eigen-style LDL^T (pivot = largest remaining |diagonal|, D^+ on zero pivots) of the 8x8 system by ONE wavefront:
-// lane i*8+j holds A[i][j].  Replaces the single-thread small_ldlt_solve on the LM critical path (its dynamically indexed
-// local arrays live in scratch memory: ~60 us per solve against ~2 us here).  Must be called by all 64 lanes of a wave;
-// x (8 entries) is written by lanes 0..7.
+template <int CTRL> __device__ __forceinline__ double tr_dpp64(double v) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned) __builtin_amdgcn_update_dpp(0, (int) (u & 0xFFFFFFFFu), CTRL, 0xF, 0xF, true);
+    const unsigned hi = (unsigned) __builtin_amdgcn_update_dpp(0, (int) (u >> 32), CTRL, 0xF, 0xF, true);
+    return __builtin_bit_cast(double, ((unsigned long long) hi << 32) | lo);
+}
+
+// Eigen-style LDL^T (pivot = first largest remaining |diagonal|, D^+ on zero pivots) of the 8x8 system by ONE wavefront, on the
+// LM critical path (once per iteration).  Lane i*8+j holds A[i][j] (the full symmetric matrix; after step k the lanes of row k hold
+// L[j][k]).  Every 8-lane group also carries the diagonal, the right-hand side and the permutation (entry j in lane j of the group):
+//   - the pivot search is a 3-step DPP maximum inside the groups + one ballot (no broadcasts of the 8 diagonal entries),
+//   - the forward substitution rides along the elimination (y_j -= L[j][k] y_k uses the L[j][k] the lane computes anyway),
+//   - one division sequence per step (L[j][k] = A[j][k] / d, computed where it is used),
+//   - the back substitution's L entries are fetched in one batch before its dependent chain, the permutation is undone by the
+//     indexed store of the result.
+// Must be called by all 64 lanes of a wave; x (8 entries) is written by lanes 0..7.
 __device__ void ldlt8_wave(const double *H /*LDS 64, row major*/, const double *rhs /*LDS 8*/, double diagScale, double *x /*LDS 8*/) {
     const int lane = threadIdx.x & 63, i = lane >> 3, j = lane & 7;
     double a = H[lane];
     if (i == j) a *= diagScale;
-    int tr[8];
+    double dg = H[j * 9] * diagScale;         // the same product as lane (j,j)'s a: the two stay bit-identical
+    double y = rhs[j];
+    int pidx = j;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-        // pivot: first largest |A[q][q]|, q >= k   (uniform)
-        int idx = k;
-        double best = fabs(tr_bcast64(a, k * 9));
-#pragma unroll
-        for (int q = k + 1; q < 8; q++) { const double d = fabs(tr_bcast64(a, q * 9)); if (d > best) { best = d; idx = q; } }
-        tr[k] = idx;
+        const double m = (j >= k) ? fabs(dg) : -1.0;
+        double mm = m;
+        mm = __builtin_fmax(mm, tr_dpp64<0xB1>(mm));        // quad_perm [1,0,3,2]
+        mm = __builtin_fmax(mm, tr_dpp64<0x4E>(mm));        // quad_perm [2,3,0,1]
+        mm = __builtin_fmax(mm, tr_dpp64<0x141>(mm));       // row_half_mirror: the maximum of the 8-lane group
+        const unsigned cand = (unsigned) (__builtin_amdgcn_ballot_w64(m == mm) & 0xFFull);
+        const int idx = cand ? __builtin_ctz(cand) : k;     // uniform
         if (idx != k) {
             const int si = (i == k) ? idx : (i == idx) ? k : i, sj = (j == k) ? idx : (j == idx) ? k : j;
             a = tr_shfl64(a, si * 8 + sj);
+            dg = tr_shfl64(dg, i * 8 + sj); y = tr_shfl64(y, i * 8 + sj);
+            pidx = __builtin_amdgcn_ds_bpermute((i * 8 + sj) << 2, pidx);
         }
-        const double d = tr_bcast64(a, k * 9);
+        const double d = tr_bcast64(dg, k), yk = tr_bcast64(y, k);
+        const bool valid = fabs(d) > 0.0;                    // uniform (Eigen leaves the column as it is under a zero pivot)
         const double ci = tr_shfl64(a, i * 8 + k), cj = tr_shfl64(a, j * 8 + k);
-        if (fabs(d) > 0.0) {
-            if (i > k && j > k) a -= ci * (cj / d);
-            else if (j == k && i > k) a = ci / d;             // L[i][k]
-            else if (i == k && j > k) a = cj / d;             // mirror (unused)
+        const double Lj = valid ? cj / d : cj;               // L[j][k]
+        if (j > k) {
+            if (valid) {
+                if (i > k) a -= ci * Lj;
+                else if (i == k) a = Lj;
+                dg -= cj * Lj;
+            }
+            y -= yk * Lj;
         }
     }
-    // solve: x = P^T L^-T D^+ L^-1 P b ; lane r (< 8) holds x_r
-    double xr = (lane < 8) ? rhs[lane] : 0.0;
+    double xr = (fabs(dg) > 2.2250738585072014e-308) ? y / dg : 0.0;
+    double Lc[8];
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const int t_ = tr[k];
-        if (t_ != k) { const int src = (lane == k) ? t_ : (lane == t_) ? k : lane; xr = tr_shfl64(xr, src & 63); }
-    }
+    for (int c = 1; c < 8; c++) Lc[c] = tr_shfl64(a, j * 8 + c);         // lane r of a group: L[c][r] (row r of the lanes, column c)
 #pragma unroll
-    for (int c = 0; c < 7; c++) {                  // forward: x_r -= L[r][c] x_c, r > c
+    for (int c = 7; c >= 1; c--) {                                        // x_r -= L[c][r] x_c, r < c
         const double xc = tr_bcast64(xr, c);
-        const double l = tr_shfl64(a, (lane & 7) * 8 + c);      // lane r reads L[r][c]
-        if (lane < 8 && lane > c) xr -= l * xc;
+        if (j < c) xr -= Lc[c] * xc;
     }
-    {
-        const double dr = tr_shfl64(a, (lane & 7) * 9);
-        xr = (fabs(dr) > 2.2250738585072014e-308) ? xr / dr : 0.0;
-    }
-#pragma unroll
-    for (int c = 7; c >= 1; c--) {                 // backward: x_r -= L[c][r] x_c, r < c
-        const double xc = tr_bcast64(xr, c);
-        const double l = tr_shfl64(a, c * 8 + (lane & 7));      // lane r reads L[c][r]
-        if (lane < c) xr -= l * xc;
-    }
-#pragma unroll
-    for (int k = 7; k >= 0; k--) {
-        const int t_ = tr[k];
-        if (t_ != k) { const int src = (lane == k) ? t_ : (lane == t_) ? k : lane; xr = tr_shfl64(xr, src & 63); }
-    }
-    if (lane < 8) x[lane] = xr;
+    if (lane < 8) x[pidx] = xr;
 }
 
 __device__ __forceinline__ void tr_vec6(const double *acc, double *rs) {
@@ -594,7 +624,7 @@ template <int G>
 __global__ __launch_bounds__(TR_NT) void k_tr_track(const TrParams *__restrict__ Pp, TrHyp *hyps, TrCoop *coop, int seq0) {
     const TrParams &P = *Pp;      // device memory, not a by-value argument: a dynamically indexed kernel argument would be copied to scratch memory
     __shared__ double sAcc[TR_NACC];
-    __shared__ float sRed[(TR_NT / 16) * TR_NACC];
+    __shared__ __attribute__((aligned(16))) float sRed[(TR_NT / 16) * TR_NACC];
     __shared__ float sRt[12];
     __shared__ double sT[12], sTnew[12];
     __shared__ float sAff[2], sAffNew[2];
@@ -602,7 +632,7 @@ __global__ __launch_bounds__(TR_NT) void k_tr_track(const TrParams *__restrict__
     __shared__ int sCtl[4];          // 0: continue LM loop, 1: accept, 2: abort (return false), 3: iterations
 #if LD_STAMP_ON_TR
     // debug builds: device timing of tr_eval per level (dynamically indexed -> scratch memory: never in a product build)
-    long long tEval = 0, tTot0 = wall_clock64(), tLv[5] = {0, 0, 0, 0, 0}; int nEval = 0, nLv[5] = {0, 0, 0, 0, 0};
+    long long tEval = 0, tS1 = 0, tS2 = 0, tS3 = 0, tQ = 0, tTot0 = wall_clock64(), tLv[5] = {0, 0, 0, 0, 0}; int nEval = 0, nLv[5] = {0, 0, 0, 0, 0};
 #define TEV(call) do { long long t_ = wall_clock64(); call; t_ = wall_clock64() - t_; tEval += t_; nEval++; if (lvl < 5) { tLv[lvl] += t_; nLv[lvl]++; } if (threadIdx.x == 0) sEv[lvl]++; } while (0)
 #else
 #define TEV(call) do { call; if (threadIdx.x == 0) sEv[lvl]++; } while (0)
@@ -641,10 +671,16 @@ __global__ __launch_bounds__(TR_NT) void k_tr_track(const TrParams *__restrict__
 
         for (int iteration = 0; iteration < maxIterations[lvl]; iteration++) {
             // H (1 + lambda on the diagonal) x = -b: wave 0 solves the 8x8 system lane-parallel (CoarseTracker.cc:120-128)
+#if LD_STAMP_ON_TR
+            tQ = wall_clock64();
+#endif
             if (tid < 8) sNb[tid] = -sB[tid];
             __syncthreads();
             if (tid < 64) ldlt8_wave(sH, sNb, (double) (1 + sLambda), sInc);
             __syncthreads();
+#if LD_STAMP_ON_TR
+            tS1 += wall_clock64() - tQ; tQ = wall_clock64();
+#endif
             if (tid == 0) {
                 sCtl[3]++;
                 const float lambda = sLambda;
@@ -666,7 +702,13 @@ __global__ __launch_bounds__(TR_NT) void k_tr_track(const TrParams *__restrict__
                 sCtl[0] = (sqrt(nrm) > 1e-3) ? 1 : 0;          // continue after this iteration?
             }
             __syncthreads();
+#if LD_STAMP_ON_TR
+            tS2 += wall_clock64() - tQ;
+#endif
             TEV(tr_eval_lead<G>(P, lvl, sTnew, sAffNew[0], sAffNew[1], P.coarseCutoffTH * levelCutoffRepeat, sAcc, sRed, sRt, co, coSeq, pc););
+#if LD_STAMP_ON_TR
+            tQ = wall_clock64();
+#endif
             if (tid == 0) {
                 tr_vec6(sAcc, sResNew);
                 sCtl[1] = ((sResNew[0] / sResNew[1]) < (sResOld[0] / sResOld[1])) ? 1 : 0;
@@ -686,6 +728,9 @@ __global__ __launch_bounds__(TR_NT) void k_tr_track(const TrParams *__restrict__
                 }
             }
             __syncthreads();
+#if LD_STAMP_ON_TR
+            tS3 += wall_clock64() - tQ;
+#endif
             if (!sCtl[0]) break;
         }
         if (tid == 0) {
@@ -699,7 +744,7 @@ __global__ __launch_bounds__(TR_NT) void k_tr_track(const TrParams *__restrict__
         if (levelCutoffRepeat > 1 && !haveRepeated) { lvl++; haveRepeated = true; }
     }
 #if LD_STAMP_ON_TR
-    if (tid == 0) { hy.dbg[0] = (double) tEval; hy.dbg[1] = (double) (wall_clock64() - tTot0); hy.dbg[2] = nEval; for (int q = 0; q < 5; q++) hy.dbg[3 + q] = nLv[q] ? (double) tLv[q] / nLv[q] : 0.0; }
+    if (tid == 0) { hy.dbg[0] = (double) tEval; hy.dbg[1] = (double) (wall_clock64() - tTot0); hy.dbg[2] = nEval; for (int q = 0; q < 5; q++) hy.dbg[3 + q] = nLv[q] ? (double) tLv[q] / nLv[q] : 0.0; hy.dbg[8] = (double) tS1; hy.dbg[9] = (double) tS2; hy.dbg[10] = (double) tS3; }
 #endif
     if (G > 1) {      // release the helper workgroups
         ++coSeq;
@@ -728,7 +773,7 @@ __global__ __launch_bounds__(TR_NT) void k_tr_track(const TrParams *__restrict__
 __global__ __launch_bounds__(TR_NT) void k_tr_calc(const TrParams *__restrict__ Pp, int lvl, const double *Tdev, float a, float b, float cutoffTH, double *outAcc) {
     const TrParams &P = *Pp;
     __shared__ double sAcc[TR_NACC];
-    __shared__ float sRed[(TR_NT / 16) * TR_NACC];
+    __shared__ __attribute__((aligned(16))) float sRed[(TR_NT / 16) * TR_NACC];
     __shared__ float sRt[12];
     const int tid = threadIdx.x;
     if (tid < 12) sRt[tid] = (float) Tdev[tid < 9 ? (tid / 3) * 4 + tid % 3 : (tid - 9) * 4 + 3];
@@ -1026,7 +1071,11 @@ int ldso_tr_track_batch(ldso_tracker_t *H, int nhyp, double *T_inout /*nhyp*12*/
         if (ok) ok[i] = hy[i].ok;
         if (iterations) iterations[i] = hy[i].iterations;
         if (i == 0) memcpy(H->lastEvals, hy[i].evals, sizeof(H->lastEvals));
-        if (LD_STAMP_ON_TR && i == 0) fprintf(stderr, "[tr stamps] evals %d: %.1f us in tr_eval of %.1f us kernel; per-eval us by level 0..4: %.1f %.1f %.1f %.1f %.1f\n", (int) hy[i].dbg[2], hy[i].dbg[0] / 100.0, hy[i].dbg[1] / 100.0, hy[i].dbg[3] / 100, hy[i].dbg[4] / 100, hy[i].dbg[5] / 100, hy[i].dbg[6] / 100, hy[i].dbg[7] / 100);
+#if LD_STAMP_ON_TR
+        if (i == 0) { long long ph[5][8]; hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_trPh), sizeof(ph)); long long z[5][8] = {}; hipMemcpyToSymbol(HIP_SYMBOL(g_trPh), z, sizeof(z));
+            for (int l = 0; l < 5; l++) if (ph[l][7]) fprintf(stderr, "[tr phases] lvl %d: setup %.2f pass %.2f dpp %.2f barrier %.2f sum %.2f us per eval (%d evals)\n", l, ph[l][0] / 100.0 / ph[l][7], ph[l][1] / 100.0 / ph[l][7], ph[l][2] / 100.0 / ph[l][7], ph[l][3] / 100.0 / ph[l][7], ph[l][4] / 100.0 / ph[l][7], (int) ph[l][7]); }
+#endif
+        if (LD_STAMP_ON_TR && i == 0) fprintf(stderr, "[tr stamps] evals %d: %.1f us in tr_eval of %.1f us kernel; per-eval us by level 0..4: %.1f %.1f %.1f %.1f %.1f; solve %.1f step %.1f post %.1f us\n", (int) hy[i].dbg[2], hy[i].dbg[0] / 100.0, hy[i].dbg[1] / 100.0, hy[i].dbg[3] / 100, hy[i].dbg[4] / 100, hy[i].dbg[5] / 100, hy[i].dbg[6] / 100, hy[i].dbg[7] / 100, hy[i].dbg[8] / 100, hy[i].dbg[9] / 100, hy[i].dbg[10] / 100);
     }
     return LDSO_OK;
 }
