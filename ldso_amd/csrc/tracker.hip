@@ -207,7 +207,9 @@ __device__ __forceinline__ void tr_eval(const TrParams &P, int lvl, const float 
     const tr_gptr gImg = (tr_gptr) L.newImg, gId = (tr_gptr) L.pc_idepth, gU = (tr_gptr) L.pc_u, gV = (tr_gptr) L.pc_v, gCol = (tr_gptr) L.pc_color;
     const int share = (((L.n + nAct - 1) / nAct) + 63) & ~63;
     const int lo = g * share, hi = min(L.n, lo + share);
-    const int nWact = max(1, min(nW, (hi - lo + 64 * TR_U - 1) / (64 * TR_U))), nth = nWact * 64;
+    // latency first: the share is spread over all wavefronts (one per SIMD) before a lane takes a second point
+    const int nWact = max(1, min(nW, (hi - lo + 63) / 64)), nth = nWact * 64;
+    const int nU = min(TR_U, max(1, (hi - lo + nth - 1) / nth));          // points per lane in the first pass (uniform)
     // RKi = R.cast<float>() * Ki ; t.cast<float>()
     float RKi[9], t[3];
     for (int r = 0; r < 3; r++) t[r] = Rt[9 + r];
@@ -224,11 +226,12 @@ __device__ __forceinline__ void tr_eval(const TrParams &P, int lvl, const float 
     TPH(0);
 
     // one pass: TR_U points per lane; all 12-float tap gathers of a pass are issued together
-    auto pass = [&](const float (&id)[TR_U], const float (&x)[TR_U], const float (&y)[TR_U], const float (&col)[TR_U], int ib) {
+    auto pass = [&](const float (&id)[TR_U], const float (&x)[TR_U], const float (&y)[TR_U], const float (&col)[TR_U], int ib, int nu) {
         float uu[TR_U], vv[TR_U], Ku[TR_U], Kv[TR_U], nid[TR_U], tap[TR_U][12];
         bool ok[TR_U], in[TR_U];
 #pragma unroll
         for (int u_ = 0; u_ < TR_U; u_++) {
+            if (u_ >= nu) { ok[u_] = false; in[u_] = false; continue; }          // uniform
             in[u_] = ib + u_ * nth < hi;
             float p0 = ((RKi[0] * x[u_] + RKi[1] * y[u_]) + RKi[2] * 1.0f) + t[0] * id[u_];
             float p1 = ((RKi[3] * x[u_] + RKi[4] * y[u_]) + RKi[5] * 1.0f) + t[1] * id[u_];
@@ -245,6 +248,7 @@ __device__ __forceinline__ void tr_eval(const TrParams &P, int lvl, const float 
         }
 #pragma unroll
         for (int u_ = 0; u_ < TR_U; u_++) {
+            if (u_ >= nu) break;                                                   // uniform
             const int i = ib + u_ * nth;
             if (in[u_] && lvl == 0 && i % 32 == 0) {
                 const float *Ki = L.Ki;
@@ -311,7 +315,7 @@ __device__ __forceinline__ void tr_eval(const TrParams &P, int lvl, const float 
                 pc.id[u_] = gId[ic]; pc.x[u_] = gU[ic]; pc.y[u_] = gV[ic]; pc.col[u_] = gCol[ic];
             }
         }
-        pass(pc.id, pc.x, pc.y, pc.col, lo + tid);
+        pass(pc.id, pc.x, pc.y, pc.col, lo + tid, nU);
         for (int ib = lo + tid + nth * TR_U; ib < hi; ib += nth * TR_U) {
             float id[TR_U], x[TR_U], y[TR_U], col[TR_U];
 #pragma unroll
@@ -320,7 +324,7 @@ __device__ __forceinline__ void tr_eval(const TrParams &P, int lvl, const float 
                 const int ic = i < hi ? i : 0;
                 id[u_] = gId[ic]; x[u_] = gU[ic]; y[u_] = gV[ic]; col[u_] = gCol[ic];
             }
-            pass(id, x, y, col, ib);
+            pass(id, x, y, col, ib, TR_U);
         }
     }
     pc.lvl = lvl;
@@ -347,7 +351,15 @@ __device__ __forceinline__ void tr_eval(const TrParams &P, int lvl, const float 
     TPH(2);
     __syncthreads();
     TPH(3);
-    if (tid < TR_NACC) { double s = 0; for (int r = 0; r < nWact * 4; r++) s += (double) red[r * TR_NACC + tid]; out[tid] = s; }
+    if (tid < TR_NACC) {
+        float rv[TR_NT / 16];
+#pragma unroll
+        for (int r = 0; r < TR_NT / 16; r++) rv[r] = (r < nWact * 4) ? red[r * TR_NACC + tid] : 0.f;      // all reads in flight together
+        double s = 0;
+#pragma unroll
+        for (int r = 0; r < TR_NT / 16; r++) if (r < nWact * 4) s += (double) rv[r];
+        out[tid] = s;
+    }
     __syncthreads();
     TPH(4);
 #if LD_STAMP_ON_TR
@@ -529,8 +541,8 @@ __device__ __attribute__((noinline)) void tr_solve_fixed_affine(const double *sH
 // nhyp * G by the CU count); sequence numbers grow over the launches of a handle, so nothing has to be cleared in between.
 // ---------------------------------------------------------------------------------------------------------
 #define TR_GMAX 16
-#define TR_COOP_MIN (TR_NT * TR_U + 1)     // a level one workgroup evaluates in a single pass stays on the leader (cheaper than a hand-over)
-#define TR_COOP_PER (TR_NT * TR_U)         // target share per workgroup on the shared levels: one pass
+#define TR_COOP_MIN 512        // smaller levels stay on the leader: less than the ~1.4 us of a hand-over to win
+#define TR_COOP_PER 64         // finest share: one wavefront with one point per lane
 struct TrCoop {
     // every 64-bit word carries (payload << 32 | sequence number): a word is valid by itself, no fence / second round trip needed
     unsigned long long cmd[16];                          // R (9), t (3) as float, affine a, b, cut-off, level (-1: the track is over)
