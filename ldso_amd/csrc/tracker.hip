@@ -60,14 +60,36 @@ struct TrHyp {                 // one motion hypothesis in / result out
 // ---------------------------------------------------------------------------------------------------------
 // makeCoarseDepthL0
 // ---------------------------------------------------------------------------------------------------------
-__global__ void k_tr_scatter(const float *pts, int n, float *idepth, float *wsum, int w) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
+// The reference adds the points to the level-0 maps one after the other (CoarseTracker.cc:268-283): float sums in point order.
+// Deterministic and in that order here: a first kernel counts the points per pixel, the second lets the lowest-indexed point of a
+// pixel add all of that pixel's points in index order (collisions are rare: a scan over the point list per colliding pixel).
+// Points that round to a pixel outside the image (the reference would write out of bounds) are ignored.
+__device__ __forceinline__ int tr_pt_pixel(const float *pts, int i, int w, int h) {
+    const int u = (int) (pts[4 * i + 0] + 0.5f), v = (int) (pts[4 * i + 1] + 0.5f);
+    return (u >= 0 && u < w && v >= 0 && v < h) ? u + w * v : -1;
+}
+__global__ void k_tr_scatter_count(const float *pts, int n, int *cnt, int w, int h) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    int u = (int) (pts[4 * i + 0] + 0.5f), v = (int) (pts[4 * i + 1] + 0.5f);
-    float new_idepth = pts[4 * i + 2];
-    float weight = sqrtf((float) (1e-3 / ((double) pts[4 * i + 3] + 1e-12)));
-    atomicAdd(&idepth[u + w * v], new_idepth * weight);
-    atomicAdd(&wsum[u + w * v], weight);
+    const int px = tr_pt_pixel(pts, i, w, h);
+    if (px >= 0) atomicAdd(&cnt[px], 1);
+}
+__global__ void k_tr_scatter(const float *pts, int n, float *idepth, float *wsum, const int *cnt, int w, int h) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int px = tr_pt_pixel(pts, i, w, h);
+    if (px < 0) return;
+    float sid = 0.f, sw = 0.f;
+    const int j0 = (cnt[px] == 1) ? i : 0, j1 = (cnt[px] == 1) ? i + 1 : n;
+    for (int j = j0; j < j1; j++) {
+        if (j != i && tr_pt_pixel(pts, j, w, h) != px) continue;
+        if (j < i) return;                    // an earlier point owns this pixel
+        const float new_idepth = pts[4 * j + 2];
+        const float weight = sqrtf((float) (1e-3 / ((double) pts[4 * j + 3] + 1e-12)));
+        sid += new_idepth * weight;
+        sw += weight;
+    }
+    idepth[px] = sid; wsum[px] = sw;
 }
 
 __global__ void k_tr_pool(const float *id_lm, const float *ws_lm, float *id_l, float *ws_l, int wl, int hl, int wlm1) {
@@ -869,7 +891,7 @@ int ldso_tr_create(int device, int w, int h, int levels, ldso_tracker_t **out) {
         L.idepth += 64; L.wsum += 64; L.wsum_bak += 64;
         TA(L.blockCnt, n / 256 + 2);
     }
-    TA(H->d_total, 1); TA(H->d_T, 12); TA(H->d_acc, TR_NACC); TA(H->d_hyp, 128); TA(H->d_coop, 64); TA(H->d_P, 1);
+    TA(H->d_total, TR_MAXL); TA(H->d_T, 12); TA(H->d_acc, TR_NACC); TA(H->d_hyp, 128); TA(H->d_coop, 64); TA(H->d_P, 1);
     CHK(hipHostMalloc((void **) &H->h_P, sizeof(TrParams)));
     memset(&H->Pdev, 0xFF, sizeof(TrParams));
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) H->numCU = pr.multiProcessorCount; }
@@ -945,7 +967,12 @@ int ldso_tr_set_ref(ldso_tracker_t *H, const float *const *ref_dIp, float ref_a,
     TrLevel *lv = H->P.lv;
     CHK(hipMemsetAsync(lv[0].idepth, 0, (size_t) lv[0].w * lv[0].h * 4, H->stream));
     CHK(hipMemsetAsync(lv[0].wsum, 0, (size_t) lv[0].w * lv[0].h * 4, H->stream));
-    if (n) hipLaunchKernelGGL(k_tr_scatter, dim3((n + 255) / 256), dim3(256), 0, H->stream, H->d_pts, n, lv[0].idepth, lv[0].wsum, lv[0].w);
+    if (n) {
+        int *cnt = reinterpret_cast<int *>(lv[0].wsum_bak);         // free until the dilation below
+        CHK(hipMemsetAsync(cnt, 0, (size_t) lv[0].w * lv[0].h * 4, H->stream));
+        hipLaunchKernelGGL(k_tr_scatter_count, dim3((n + 255) / 256), dim3(256), 0, H->stream, H->d_pts, n, cnt, lv[0].w, lv[0].h);
+        hipLaunchKernelGGL(k_tr_scatter, dim3((n + 255) / 256), dim3(256), 0, H->stream, H->d_pts, n, lv[0].idepth, lv[0].wsum, cnt, lv[0].w, lv[0].h);
+    }
     for (int l = 1; l < H->levels; l++) {
         int npx = lv[l].w * lv[l].h;
         hipLaunchKernelGGL(k_tr_pool, dim3((npx + 255) / 256), dim3(256), 0, H->stream, lv[l - 1].idepth, lv[l - 1].wsum, lv[l].idepth, lv[l].wsum, lv[l].w, lv[l].h, lv[l - 1].w);
@@ -959,13 +986,13 @@ int ldso_tr_set_ref(ldso_tracker_t *H, const float *const *ref_dIp, float ref_a,
         int ni = (lv[l].w - 4) * (lv[l].h - 4);
         int nb = (ni + 255) / 256;
         hipLaunchKernelGGL(k_tr_count, dim3(nb), dim3(256), 0, H->stream, lv[l]);
-        hipLaunchKernelGGL(k_tr_scan, dim3(1), dim3(1024), 0, H->stream, lv[l].blockCnt, nb, H->d_total);
+        hipLaunchKernelGGL(k_tr_scan, dim3(1), dim3(1024), 0, H->stream, lv[l].blockCnt, nb, H->d_total + l);
         hipLaunchKernelGGL(k_tr_write, dim3(nb), dim3(256), 0, H->stream, lv[l]);
-        int tot = 0;
-        CHK(hipMemcpyAsync(&tot, H->d_total, 4, hipMemcpyDeviceToHost, H->stream));
-        CHK(hipStreamSynchronize(H->stream));
-        lv[l].n = tot;
     }
+    int tot[TR_MAXL] = {0};
+    CHK(hipMemcpyAsync(tot, H->d_total, (size_t) H->levels * 4, hipMemcpyDeviceToHost, H->stream));      // one read-back for all levels
+    CHK(hipStreamSynchronize(H->stream));
+    for (int l = 0; l < H->levels; l++) lv[l].n = tot[l];
     CHK(hipGetLastError());
     return LDSO_OK;
 }
