@@ -37,13 +37,13 @@ def committed_profile(config, what):
                     if "k_linearize" in row["Name"]:
                         return round(float(row["AverageNs"]) / 1e3, 3), os.path.relpath(cand[-1], ROOT)
         else:
-            cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
-            if cand:
-                pj = json.load(open(cand[-1]))
+            cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json")), key=lambda f: os.path.basename(f)[:3])
+            for fn in reversed(cand):                               # latest round first
+                pj = json.load(open(fn))
                 if pj.get("config", "C3") == config:
                     for kname, kv in pj["kernels"].items():
-                        if kname.startswith("k_linearize"):
-                            return kv["hbm_bytes_per_launch_corrected"], os.path.relpath(cand[-1], ROOT)
+                        if kname.startswith("k_linearize") and "batch" not in kname:
+                            return kv["hbm_bytes_per_launch_corrected"], os.path.relpath(fn, ROOT)
     except Exception:
         pass
     return None, None

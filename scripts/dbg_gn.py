@@ -16,7 +16,6 @@ for rep in range(3):
     g.L.ldso_ba_get_energy_log(g.h, buf.ctypes.data_as(C.c_void_p), C.c_int(64))
     t0 = buf[39]
     print('block0 [us]: reaches the wait', (buf[47] - t0) / 100, 'wait over', (buf[48] - t0) / 100, 'loads done', (buf[41] - t0) / 100, 'factor done', (buf[42] - t0) / 100, 'backsub done', (buf[43] - t0) / 100, 'core done', buf[44] / 100, 'canbreak', buf[45] / 100, 'precalc', buf[46] / 100)
-    print('round k=8 cycles: p1 loads', buf[27]-buf[26], 'pivot+row', buf[28]-buf[27], 'stores', buf[29]-buf[28], 'barrier', buf[30]-buf[29], 'p2 loads', buf[31]-buf[30], 'p2 fma', buf[32]-buf[31], 'publish', buf[33]-buf[32], 'barrier', buf[34]-buf[33])
     print('k_reduce [us]: A start', buf[22]/100, 'A partials in', buf[23]/100, 'A loads', buf[20]/100, 'A end', buf[21]/100, '| B loads', buf[22]/100, 'B mfma', buf[23]/100, 'B end', buf[24]/100)
     print('last reduce workgroup: bid', int(buf[30]), 'signals at', (buf[29] - t0) / 100, 'us after the control workgroup started; it had started at', (buf[31] - t0) / 100, 'us')
     print('k_reduce part B tile 0 [us]: staged', buf[25]/100, 'mfma done', buf[26]/100, 'end', buf[27]/100, '| extras end', buf[28]/100)

@@ -12,44 +12,55 @@ def find(pattern):
     return c[0] if c else None
 
 
-ks = find("stats/**/*kernel_stats.csv")
-if ks:
+for d in sorted(glob.glob(os.path.join(out, "stats_*"))):
+    if not os.path.isdir(d):
+        continue
+    name = os.path.basename(d)[len("stats_"):]
+    ks = find(os.path.basename(d) + "/**/*kernel_stats.csv")
+    if not ks:
+        print("no kernel stats for", name)
+        continue
     rows = list(csv.reader(open(ks)))
-    with open(os.path.join(dst, f"{tag}_bench_C3_kernel_stats.csv"), "w", newline="") as f:
+    with open(os.path.join(dst, f"{tag}_{name}_kernel_stats.csv"), "w", newline="") as f:
         csv.writer(f, quoting=csv.QUOTE_NONNUMERIC).writerows(rows)
-    for r in rows[1:8]:
-        print(r[0][:60], "calls", r[1], "avg ns", r[3])
+    print("==", name)
+    for r in rows[1:7]:
+        print("  ", r[0][:70], "calls", r[1], "avg ns", r[3])
 
 # calibration of the gfx950 FETCH_SIZE unit: scripts/micro/pmc_calib.hip (see profiles/r01_pmc_traffic.json "calibration")
-res = {"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, with --kernel-trace only) around `python bench.py --steps 40 --warmup 5 "
-               "--no-cpu-baseline`; KB per launch as reported; corrected = 2 x FETCH_SIZE + WRITE_SIZE (gfx950: FETCH_SIZE tallies 128-B requests at 64 B; "
-               "calibrated with scripts/micro/pmc_calib.hip: 256 MB of 4-byte coalesced loads report 0.5000x, stores 1.000x)",
-       "workload": "C3 with synthetic prior", "kernels": {}}
-for C in ("FETCH_SIZE", "WRITE_SIZE"):
-    cc = find(f"pmc_{C}/**/*counter_collection.csv")
-    if not cc:
+for cfg in ("C3", "C4", "C5"):
+    res = {"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, with --kernel-trace only) around `python bench.py --steps 40 --warmup 5 "
+                   f"--no-cpu-baseline --no-extras --config {cfg}`; KB per launch as reported; corrected = 2 x FETCH_SIZE + WRITE_SIZE (gfx950: FETCH_SIZE "
+                   "tallies 128-B requests at 64 B; calibrated with scripts/micro/pmc_calib.hip: 256 MB of 4-byte coalesced loads report 0.5000x, stores 1.000x)",
+           "config": cfg, "kernels": {}}
+    for C in ("FETCH_SIZE", "WRITE_SIZE"):
+        cc = find(f"pmc_{cfg}_{C}/**/*counter_collection.csv")
+        if not cc:
+            continue
+        acc = defaultdict(list)
+        keep = []
+        for r in csv.DictReader(open(cc)):
+            if r["Counter_Name"] != C:
+                continue
+            name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+            acc[name].append(float(r["Counter_Value"]))
+            if len(keep) < 499 and name.startswith("k_"):
+                keep.append(r)
+        if keep:
+            with open(os.path.join(dst, f"{tag}_pmc_{cfg}_{C}_counter_collection.csv"), "w", newline="") as f:
+                w = csv.DictWriter(f, fieldnames=list(keep[0].keys())); w.writeheader(); w.writerows(keep)
+        for name, v in acc.items():
+            if not name.startswith("k_"):
+                continue
+            d = res["kernels"].setdefault(name, {})
+            d[f"{C}_KB_mean"] = round(sum(v) / len(v), 3)
+            d[f"launches_{C}"] = len(v)
+    if not res["kernels"]:
         continue
-    acc = defaultdict(list)
-    keep = []
-    for r in csv.DictReader(open(cc)):
-        if r["Counter_Name"] != C:
-            continue
-        name = r["Kernel_Name"].split("(")[0].replace("void ", "")
-        acc[name].append(float(r["Counter_Value"]))
-        if len(keep) < 499 and name.startswith("k_"):
-            keep.append(r)
-    if keep:
-        with open(os.path.join(dst, f"{tag}_pmc_{C}_counter_collection.csv"), "w", newline="") as f:
-            w = csv.DictWriter(f, fieldnames=list(keep[0].keys())); w.writeheader(); w.writerows(keep)
-    for name, v in acc.items():
-        if not name.startswith("k_"):
-            continue
-        d = res["kernels"].setdefault(name, {})
-        d[f"{C}_KB_mean"] = round(sum(v) / len(v), 3)
-        d[f"launches_{C}"] = len(v)
-for name, d in res["kernels"].items():
-    if "FETCH_SIZE_KB_mean" in d and "WRITE_SIZE_KB_mean" in d:
-        d["hbm_bytes_per_launch_corrected"] = int(round((2 * d["FETCH_SIZE_KB_mean"] + d["WRITE_SIZE_KB_mean"]) * 1024))
-json.dump(res, open(os.path.join(dst, f"{tag}_pmc_traffic.json"), "w"), indent=1)
-for name, d in res["kernels"].items():
-    print(name, d)
+    for name, d in res["kernels"].items():
+        if "FETCH_SIZE_KB_mean" in d and "WRITE_SIZE_KB_mean" in d:
+            d["hbm_bytes_per_launch_corrected"] = int(round((2 * d["FETCH_SIZE_KB_mean"] + d["WRITE_SIZE_KB_mean"]) * 1024))
+    json.dump(res, open(os.path.join(dst, f"{tag}_pmc_traffic_{cfg}.json"), "w"), indent=1)
+    print("== pmc", cfg)
+    for name, d in res["kernels"].items():
+        print("  ", name, d)
