@@ -61,33 +61,36 @@ struct TrHyp {                 // one motion hypothesis in / result out
 // makeCoarseDepthL0
 // ---------------------------------------------------------------------------------------------------------
 // The reference adds the points to the level-0 maps one after the other (CoarseTracker.cc:268-283): float sums in point order.
-// Deterministic and in that order here: a first kernel counts the points per pixel, the second lets the lowest-indexed point of a
-// pixel add all of that pixel's points in index order (collisions are rare: a scan over the point list per colliding pixel).
-// Points that round to a pixel outside the image (the reference would write out of bounds) are ignored.
+// Deterministic and in that order here, without float atomics: a first kernel threads the points of every pixel into a list
+// (integer atomics: the list order is arbitrary, its content is not), the second lets the lowest-indexed point of a pixel add all of
+// the pixel's points in ascending index order (lists are short: a selection walk).  Points that round to a pixel outside the image
+// (the reference would write out of bounds) are ignored.
 __device__ __forceinline__ int tr_pt_pixel(const float *pts, int i, int w, int h) {
     const int u = (int) (pts[4 * i + 0] + 0.5f), v = (int) (pts[4 * i + 1] + 0.5f);
     return (u >= 0 && u < w && v >= 0 && v < h) ? u + w * v : -1;
 }
-__global__ void k_tr_scatter_count(const float *pts, int n, int *cnt, int w, int h) {
+__global__ void k_tr_scatter_link(const float *pts, int n, int *head /*w*h, -1*/, int *next /*n*/, int w, int h) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int px = tr_pt_pixel(pts, i, w, h);
-    if (px >= 0) atomicAdd(&cnt[px], 1);
+    if (px >= 0) next[i] = atomicExch(&head[px], i);
 }
-__global__ void k_tr_scatter(const float *pts, int n, float *idepth, float *wsum, const int *cnt, int w, int h) {
+__global__ void k_tr_scatter(const float *pts, int n, float *idepth, float *wsum, const int *head, const int *next, int w, int h) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int px = tr_pt_pixel(pts, i, w, h);
     if (px < 0) return;
+    for (int j = head[px]; j >= 0; j = next[j]) if (j < i) return;       // an earlier point owns this pixel
     float sid = 0.f, sw = 0.f;
-    const int j0 = (cnt[px] == 1) ? i : 0, j1 = (cnt[px] == 1) ? i + 1 : n;
-    for (int j = j0; j < j1; j++) {
-        if (j != i && tr_pt_pixel(pts, j, w, h) != px) continue;
-        if (j < i) return;                    // an earlier point owns this pixel
-        const float new_idepth = pts[4 * j + 2];
-        const float weight = sqrtf((float) (1e-3 / ((double) pts[4 * j + 3] + 1e-12)));
+    int cur = i;
+    while (cur >= 0) {
+        const float new_idepth = pts[4 * cur + 2];
+        const float weight = sqrtf((float) (1e-3 / ((double) pts[4 * cur + 3] + 1e-12)));
         sid += new_idepth * weight;
         sw += weight;
+        int nxt = -1;                                                     // the smallest index above cur
+        for (int j = head[px]; j >= 0; j = next[j]) if (j > cur && (nxt < 0 || j < nxt)) nxt = j;
+        cur = nxt;
     }
     idepth[px] = sid; wsum[px] = sw;
 }
@@ -829,6 +832,7 @@ struct ldso_tracker {
     std::vector<void *> allocs;
     float *d_newImg[TR_MAXL] = {nullptr}, *d_refImg[TR_MAXL] = {nullptr};
     float *d_pts = nullptr;
+    int *d_next = nullptr;            // per-point list links of the level-0 scatter
     float *d_color = nullptr;          // level-0 irradiance staging of ldso_tr_set_new_frame_image
     int ptsCap = 0;
     int *d_total = nullptr;
@@ -905,6 +909,7 @@ int ldso_tr_destroy(ldso_tracker_t *H) {
     hipDeviceSynchronize();
     for (void *p : H->allocs) hipFree(p);
     if (H->d_pts) hipFree(H->d_pts);
+    if (H->d_next) hipFree(H->d_next);
     if (H->d_color) hipFree(H->d_color);
     if (H->h_P) hipHostFree(H->h_P);
     if (H->ownStream && H->stream) hipStreamDestroy(H->stream);
@@ -961,17 +966,25 @@ int ldso_tr_set_ref(ldso_tracker_t *H, const float *const *ref_dIp, float ref_a,
         CHK(hipMemcpyAsync(H->d_refImg[l], ref_dIp[l], bytes, hipMemcpyHostToDevice, H->stream));
     }
     H->P.ref_a = ref_a; H->P.ref_b = ref_b; H->P.ref_exposure = ref_exposure;
-    if (n > H->ptsCap) { if (H->d_pts) hipFree(H->d_pts); void *q; CHK(hipMalloc(&q, (size_t) n * 16)); H->d_pts = (float *) q; H->ptsCap = n; }
+    if (n > H->ptsCap) {
+        if (H->d_pts) hipFree(H->d_pts);
+    if (H->d_next) hipFree(H->d_next);
+        if (H->d_next) hipFree(H->d_next);
+        H->d_pts = nullptr; H->d_next = nullptr; H->ptsCap = 0;
+        void *q; CHK(hipMalloc(&q, (size_t) n * 16)); H->d_pts = (float *) q;
+        CHK(hipMalloc(&q, (size_t) n * 4)); H->d_next = (int *) q;
+        H->ptsCap = n;
+    }
     if (n) CHK(hipMemcpyAsync(H->d_pts, pts, (size_t) n * 16, hipMemcpyHostToDevice, H->stream));
     // makeCoarseDepthL0
     TrLevel *lv = H->P.lv;
     CHK(hipMemsetAsync(lv[0].idepth, 0, (size_t) lv[0].w * lv[0].h * 4, H->stream));
     CHK(hipMemsetAsync(lv[0].wsum, 0, (size_t) lv[0].w * lv[0].h * 4, H->stream));
     if (n) {
-        int *cnt = reinterpret_cast<int *>(lv[0].wsum_bak);         // free until the dilation below
-        CHK(hipMemsetAsync(cnt, 0, (size_t) lv[0].w * lv[0].h * 4, H->stream));
-        hipLaunchKernelGGL(k_tr_scatter_count, dim3((n + 255) / 256), dim3(256), 0, H->stream, H->d_pts, n, cnt, lv[0].w, lv[0].h);
-        hipLaunchKernelGGL(k_tr_scatter, dim3((n + 255) / 256), dim3(256), 0, H->stream, H->d_pts, n, lv[0].idepth, lv[0].wsum, cnt, lv[0].w, lv[0].h);
+        int *head = reinterpret_cast<int *>(lv[0].wsum_bak);        // free until the dilation below
+        CHK(hipMemsetAsync(head, 0xFF, (size_t) lv[0].w * lv[0].h * 4, H->stream));
+        hipLaunchKernelGGL(k_tr_scatter_link, dim3((n + 255) / 256), dim3(256), 0, H->stream, H->d_pts, n, head, H->d_next, lv[0].w, lv[0].h);
+        hipLaunchKernelGGL(k_tr_scatter, dim3((n + 255) / 256), dim3(256), 0, H->stream, H->d_pts, n, lv[0].idepth, lv[0].wsum, head, H->d_next, lv[0].w, lv[0].h);
     }
     for (int l = 1; l < H->levels; l++) {
         int npx = lv[l].w * lv[l].h;
