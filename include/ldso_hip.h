@@ -49,6 +49,25 @@ int ldso_settings_default(ldso_settings_t *s);
 int ldso_pyr_levels_used(int w, int h);
 
 /* ------------------------------------------------------------------------------------------------
+ * FrameHessian::dIp resident in HBM: one image pyramid per frame, built on the device from the raw irradiance
+ * (FrameHessian::makeImages, FrameHessian.cc:44-113: level l >= 1 is the 2x2 mean of level l-1, pixels are (I, dx, dy) with
+ * central-difference gradients) and shared BY POINTER between the coarse tracker (CoarseTracker.cc:248-256, :636-642: fh->dIp[lvl]),
+ * the immature-point tracer (ImmaturePoint.cc:89: frame->dI) and the bundle adjustment (Residuals.cc:84: target->dI) - the
+ * reference shares the same host arrays the same way.  4 bytes per pixel cross PCIe once per frame; every consumer below is
+ * zero-copy and stream-ordered after the build (hipStreamWaitEvent on the pyramid's event, no host synchronisation).  The caller keeps
+ * a pyramid alive while a consumer refers to it (until the consumer's next set_* call for that role / slot).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct ldso_pyramid ldso_pyramid_t;
+int ldso_pyr_create(int device, int w, int h, int levels, ldso_pyramid_t **out);
+int ldso_pyr_destroy(ldso_pyramid_t *p);
+/* irradiance: w*h floats on the host / on the device; enqueued on hip_stream (NULL: the default stream) */
+int ldso_pyr_make_images(ldso_pyramid_t *p, const float *irradiance, void *hip_stream);
+int ldso_pyr_make_images_device(ldso_pyramid_t *p, const void *irradiance_dev, void *hip_stream);
+/* device pointer and size of a level ((w>>lvl)*(h>>lvl)*3 floats); ldso_pyr_get_level: test fetch to the host */
+int ldso_pyr_level(ldso_pyramid_t *p, int lvl, const void **dev_ptr, int *wl, int *hl);
+int ldso_pyr_get_level(ldso_pyramid_t *p, int lvl, float *out);
+
+/* ------------------------------------------------------------------------------------------------
  * Windowed bundle adjustment (EnergyFunctional + the optimisation slice of FullSystem).
  * ---------------------------------------------------------------------------------------------- */
 typedef struct ldso_ba ldso_ba_t;
@@ -69,6 +88,8 @@ int ldso_ba_set_image_device(ldso_ba_t *h, int slot, const void *dI_level0_dev);
 /* The same slot from the RAW level-0 irradiance (w*h floats): FrameHessian::makeImages level 0 (FrameHessian.cc:44-113: copy +
  * central-difference gradients) runs on the device, 4 instead of 12 bytes per pixel cross PCIe.  ldso_ba_get_image: test fetch. */
 int ldso_ba_set_image_raw(ldso_ba_t *h, int slot, const float *irradiance);
+/* The slot from level 0 of a resident ldso_pyramid_t (zero-copy, as ldso_ba_set_image_device, ordered after the pyramid's build). */
+int ldso_ba_set_image_pyramid(ldso_ba_t *h, int slot, ldso_pyramid_t *pyr);
 int ldso_ba_get_image(ldso_ba_t *h, int slot, float *out_w_h_3);
 
 /* Describe the window: EnergyFunctional::frames / allPoints / p->residuals after makeIDX
@@ -226,6 +247,10 @@ int ldso_tr_set_new_frame(ldso_tracker_t *t, const float *const *new_dIp, float 
  * gradients per level, FrameHessian.cc:44-113) is built on the device.  ldso_tr_get_new_frame_level: test fetch of one level. */
 int ldso_tr_set_new_frame_image(ldso_tracker_t *t, const float *irradiance, float exposure);
 int ldso_tr_get_new_frame_level(ldso_tracker_t *t, int lvl, float *out);
+/* Both frames as resident ldso_pyramid_t (zero-copy): the frame that was tracked becomes the next reference without any copy. */
+int ldso_tr_set_new_frame_pyramid(ldso_tracker_t *t, ldso_pyramid_t *pyr, float exposure);
+int ldso_tr_set_ref_pyramid(ldso_tracker_t *t, ldso_pyramid_t *pyr, float ref_aff_a, float ref_aff_b, float ref_exposure,
+                            const float *pts, int n);
 /* CoarseTracker::calcRes (CoarseTracker.cc:440-572). rs_out = Vec6; returns buf_warped_n via n_warped. */
 int ldso_tr_calc_res(ldso_tracker_t *t, int lvl, const double T_ref2new[12], float aff_a, float aff_b, float cutoffTH,
                      double rs_out[6], int *n_warped);
@@ -263,6 +288,7 @@ int ldso_trace_get_points(ldso_tracer_t *t, ldso_immature_t *points_out);
 /* the new frame: level-0 image as FrameHessian::dIp[0] (w*h*3 floats), or the raw irradiance (makeImages on the device) */
 int ldso_trace_set_frame(ldso_tracer_t *t, const float *dI_level0);
 int ldso_trace_set_frame_raw(ldso_tracer_t *t, const float *irradiance);
+int ldso_trace_set_frame_pyramid(ldso_tracer_t *t, ldso_pyramid_t *pyr);
 /* per host key frame h < n_hosts (FullSystem.cc:1025-1032): KRKi[h] = K R K^-1 (row-major 3x3), Kt[h] = K t,
  * aff[h] = AffLight::fromToVecExposure(host, new).  counts_out[6] (optional): points per resulting LDSO_IPS_* status. */
 int ldso_trace_on(ldso_tracer_t *t, int n_hosts, const float *KRKi, const float *Kt, const float *aff, int *counts_out);

@@ -60,6 +60,43 @@ def default_settings() -> np.ndarray:
     return s
 
 
+class Pyramid:
+    """FrameHessian::dIp of one frame resident in HBM (ldso_pyramid_t), shared zero-copy by Tracker / Tracer / BA."""
+
+    def __init__(self, w, h, levels, device=0):
+        self.L = lib()
+        self.h = C.c_void_p()
+        _chk(self.L.ldso_pyr_create(C.c_int(device), C.c_int(w), C.c_int(h), C.c_int(levels), C.byref(self.h)))
+        self.w, self.hh, self.levels = w, h, levels
+
+    def close(self):
+        if self.h:
+            self.L.ldso_pyr_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def make_images(self, irradiance, stream=None):
+        a = np.ascontiguousarray(irradiance, np.float32)
+        assert a.size == self.w * self.hh
+        _chk(self.L.ldso_pyr_make_images(self.h, _p(a), C.c_void_p(stream)))
+        return self
+
+    def level_ptr(self, lvl):
+        ptr, wl, hl = C.c_void_p(), C.c_int(), C.c_int()
+        _chk(self.L.ldso_pyr_level(self.h, C.c_int(lvl), C.byref(ptr), C.byref(wl), C.byref(hl)))
+        return ptr.value, wl.value, hl.value
+
+    def get_level(self, lvl):
+        out = np.zeros((self.hh >> lvl, self.w >> lvl, 3), np.float32)
+        _chk(self.L.ldso_pyr_get_level(self.h, C.c_int(lvl), _p(out)))
+        return out
+
+
 class BA:
     """Windowed bundle adjustment handle (EnergyFunctional + FullSystem::optimize slice) on one GPU."""
 
@@ -108,6 +145,10 @@ class BA:
     def set_image_raw(self, slot, irradiance):
         a = np.ascontiguousarray(irradiance, np.float32)
         _chk(self.L.ldso_ba_set_image_raw(self.h, C.c_int(slot), _p(a)))
+
+    def set_image_pyramid(self, slot, pyr: "Pyramid"):
+        _chk(self.L.ldso_ba_set_image_pyramid(self.h, C.c_int(slot), pyr.h))
+        self._pyramids = getattr(self, "_pyramids", {}); self._pyramids[slot] = pyr          # keep it alive while the slot refers to it
 
     def get_image(self, slot):
         out = np.zeros((self.hh, self.w, 3), np.float32)
@@ -386,6 +427,15 @@ class Tracker:
         a = np.ascontiguousarray(irradiance, np.float32)
         _chk(self.L.ldso_tr_set_new_frame_image(self.h, _p(a), C.c_float(exposure)))
 
+    def set_new_frame_pyramid(self, pyr: "Pyramid", exposure=1.0):
+        _chk(self.L.ldso_tr_set_new_frame_pyramid(self.h, pyr.h, C.c_float(exposure)))
+        self._new_pyr = pyr
+
+    def set_ref_pyramid(self, pyr: "Pyramid", a, b, exposure, pts):
+        pts = np.ascontiguousarray(pts, np.float32)
+        _chk(self.L.ldso_tr_set_ref_pyramid(self.h, pyr.h, C.c_float(a), C.c_float(b), C.c_float(exposure), _p(pts), C.c_int(len(pts))))
+        self._ref_pyr = pyr
+
     def get_new_frame_level(self, lvl):
         out = np.zeros((self.hh >> lvl, self.w >> lvl, 3), np.float32)
         _chk(self.L.ldso_tr_get_new_frame_level(self.h, C.c_int(lvl), _p(out)))
@@ -485,6 +535,10 @@ class Tracer:
     def set_frame_raw(self, irradiance):
         a = np.ascontiguousarray(irradiance, np.float32)
         _chk(self.L.ldso_trace_set_frame_raw(self.h, _p(a)))
+
+    def set_frame_pyramid(self, pyr: "Pyramid"):
+        _chk(self.L.ldso_trace_set_frame_pyramid(self.h, pyr.h))
+        self._pyr = pyr
 
     def trace_on(self, KRKi, Kt, aff):
         K1 = np.ascontiguousarray(KRKi, np.float32); K2 = np.ascontiguousarray(Kt, np.float32); A = np.ascontiguousarray(aff, np.float32)

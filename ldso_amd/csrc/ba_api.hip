@@ -17,6 +17,7 @@
 #include <rccl/rccl.h>      // types only: ncclAllReduce is resolved at run time (the process may already hold an RCCL, e.g. PyTorch's)
 #include "../../include/ldso_hip.h"
 #include "ba_dev.h"
+#include "pyramid.h"
 #include "ba_solve.h"
 #include "lie_dev.h"
 
@@ -312,6 +313,15 @@ int ldso_ba_set_image_device(ldso_ba_t *H, int slot, const void *dev) {
     // the resident window keeps reading this slot: re-resolve its image pointers (no dangling B.img)
     for (int f = 0; f < H->D.F && f < (int) H->imageSlot.size(); f++) if (H->imageSlot[f] == slot) H->B.img[f] = H->imgSlots[slot];
     return LDSO_OK;
+}
+
+// image slot from a resident ldso_pyramid_t (level 0 = FrameHessian::dI): zero-copy, ordered after the pyramid's build on this stream
+int ldso_ba_set_image_pyramid(ldso_ba_t *H, int slot, ldso_pyramid_t *pyr) {
+    REQ(H && pyr && slot >= 0 && slot < H->maxF, "ldso_ba_set_image_pyramid: bad arguments");
+    REQ(pyr->built && pyr->device == H->device && pyr->w == H->w && pyr->h == H->h, "ldso_ba_set_image_pyramid: pyramid does not match the handle (device, size) or holds no image");
+    CHK(hipSetDevice(H->device));
+    CHK(hipStreamWaitEvent(H->stream, pyr->ready, 0));
+    return ldso_ba_set_image_device(H, slot, pyr->lv[0]);
 }
 
 #define H2D(dst, vec) do { int r_ = h2d(H, (dst), (vec)); if (r_ != LDSO_OK) return r_; } while (0)

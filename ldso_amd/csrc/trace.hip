@@ -16,7 +16,7 @@
 #include "../../include/ldso_hip.h"
 
 void ldso_set_error(const std::string &s);
-extern "C" hipError_t img_launch_make_images(const float *d_color, int w, int h, int levels, float *const *d_levels, hipStream_t st);
+#include "pyramid.h"
 
 struct TraceArgs {
     ldso_immature_t *pts;
@@ -248,6 +248,7 @@ struct ldso_tracer {
     ldso_trace_settings_t settings;
     ldso_immature_t *d_pts = nullptr;
     float *d_img = nullptr, *d_color = nullptr, *d_pose = nullptr;      // pose: [LDSO_MAX_FRAMES][14]
+    const float *img = nullptr;       // the frame traced on: d_img, or level 0 of a shared ldso_pyramid_t
     int *d_counts = nullptr;
     bool haveFrame = false;
 };
@@ -323,7 +324,7 @@ int ldso_trace_set_frame(ldso_tracer_t *T, const float *dI) {
     TCHK(hipSetDevice(T->device));
     TCHK(hipMemcpyAsync(T->d_img, dI, (size_t) T->w * T->h * 12, hipMemcpyHostToDevice, T->stream));
     TCHK(hipStreamSynchronize(T->stream));
-    T->haveFrame = true;
+    T->haveFrame = true; T->img = T->d_img;
     return LDSO_OK;
 }
 
@@ -334,7 +335,17 @@ int ldso_trace_set_frame_raw(ldso_tracer_t *T, const float *irradiance) {
     float *lv[1] = {T->d_img};
     TCHK(img_launch_make_images(T->d_color, T->w, T->h, 1, lv, T->stream));
     TCHK(hipStreamSynchronize(T->stream));
-    T->haveFrame = true;
+    T->haveFrame = true; T->img = T->d_img;
+    return LDSO_OK;
+}
+
+// the new frame as a resident ldso_pyramid_t (zero-copy: ImmaturePoint::traceOn samples frame->dI = level 0)
+int ldso_trace_set_frame_pyramid(ldso_tracer_t *T, ldso_pyramid_t *pyr) {
+    TREQ(T && pyr, "ldso_trace_set_frame_pyramid: bad arguments");
+    TREQ(pyr->built && pyr->device == T->device && pyr->w == T->w && pyr->h == T->h, "ldso_trace_set_frame_pyramid: pyramid does not match the tracer (device, size) or holds no image");
+    TCHK(hipSetDevice(T->device));
+    TCHK(hipStreamWaitEvent(T->stream, pyr->ready, 0));
+    T->haveFrame = true; T->img = pyr->lv[0];
     return LDSO_OK;
 }
 
@@ -350,7 +361,7 @@ int ldso_trace_on(ldso_tracer_t *T, int n_hosts, const float *KRKi, const float 
     TCHK(hipMemsetAsync(T->d_counts, 0, 8 * 4, T->stream));
     if (T->n > 0) {
         TraceArgs A;
-        A.pts = T->d_pts; A.n = T->n; A.img = T->d_img; A.w = T->w; A.h = T->h;
+        A.pts = T->d_pts; A.n = T->n; A.img = T->img; A.w = T->w; A.h = T->h;
         A.KRKi = T->d_pose; A.Kt = T->d_pose + n_hosts * 9; A.aff = T->d_pose + n_hosts * 12; A.nHosts = n_hosts;
         A.s = T->settings; A.counts = T->d_counts;
         const int waves = T->n, blocks = (waves + 3) / 4;

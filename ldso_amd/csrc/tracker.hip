@@ -18,6 +18,7 @@
 #include <cmath>
 #include "../../include/ldso_hip.h"
 #include "lie_dev.h"
+#include "pyramid.h"
 #include <cstdlib>
 
 void ldso_set_error(const std::string &s);
@@ -957,6 +958,8 @@ int ldso_tr_make_k(ldso_tracker_t *H, const ldso_calib_t *calib) {
     return LDSO_OK;
 }
 
+static int tr_set_ref_common(ldso_tracker_t *H, float ref_a, float ref_b, float ref_exposure, const float *pts, int n);
+
 int ldso_tr_set_ref(ldso_tracker_t *H, const float *const *ref_dIp, float ref_a, float ref_b, float ref_exposure, const float *pts, int n) {
     REQ(H && ref_dIp && (pts || n == 0) && n >= 0, "ldso_tr_set_ref: bad arguments");
     CHK(hipSetDevice(H->device));
@@ -964,7 +967,23 @@ int ldso_tr_set_ref(ldso_tracker_t *H, const float *const *ref_dIp, float ref_a,
         REQ(ref_dIp[l], "ldso_tr_set_ref: missing pyramid level");
         size_t bytes = (size_t) H->P.lv[l].w * H->P.lv[l].h * 3 * sizeof(float);
         CHK(hipMemcpyAsync(H->d_refImg[l], ref_dIp[l], bytes, hipMemcpyHostToDevice, H->stream));
+        H->P.lv[l].refImg = H->d_refImg[l];
     }
+    return tr_set_ref_common(H, ref_a, ref_b, ref_exposure, pts, n);
+}
+
+// the reference keyframe's pyramid already resident (ldso_pyramid_t, zero-copy: the tracker reads the pyramid's levels until the next
+// ldso_tr_set_ref*; the caller keeps the pyramid alive that long)
+int ldso_tr_set_ref_pyramid(ldso_tracker_t *H, ldso_pyramid_t *pyr, float ref_a, float ref_b, float ref_exposure, const float *pts, int n) {
+    REQ(H && pyr && (pts || n == 0) && n >= 0, "ldso_tr_set_ref_pyramid: bad arguments");
+    REQ(pyr->built && pyr->device == H->device && pyr->w == H->w && pyr->h == H->h && pyr->levels >= H->levels, "ldso_tr_set_ref_pyramid: pyramid does not match the tracker (device, size, levels) or holds no image");
+    CHK(hipSetDevice(H->device));
+    CHK(hipStreamWaitEvent(H->stream, pyr->ready, 0));
+    for (int l = 0; l < H->levels; l++) H->P.lv[l].refImg = pyr->lv[l];
+    return tr_set_ref_common(H, ref_a, ref_b, ref_exposure, pts, n);
+}
+
+static int tr_set_ref_common(ldso_tracker_t *H, float ref_a, float ref_b, float ref_exposure, const float *pts, int n) {
     H->P.ref_a = ref_a; H->P.ref_b = ref_b; H->P.ref_exposure = ref_exposure;
     if (n > H->ptsCap) {
         if (H->d_pts) hipFree(H->d_pts);
@@ -1017,6 +1036,7 @@ int ldso_tr_set_new_frame(ldso_tracker_t *H, const float *const *new_dIp, float 
         REQ(new_dIp[l], "ldso_tr_set_new_frame: missing pyramid level");
         size_t bytes = (size_t) H->P.lv[l].w * H->P.lv[l].h * 3 * sizeof(float);
         CHK(hipMemcpyAsync(H->d_newImg[l], new_dIp[l], bytes, hipMemcpyHostToDevice, H->stream));
+        H->P.lv[l].newImg = H->d_newImg[l];
     }
     H->P.new_exposure = exposure;
     CHK(hipStreamSynchronize(H->stream));
@@ -1034,8 +1054,20 @@ int ldso_tr_set_new_frame_image(ldso_tracker_t *H, const float *irradiance, floa
     if (!H->d_color) CHK(hipMalloc(&H->d_color, n * sizeof(float)));
     CHK(hipMemcpyAsync(H->d_color, irradiance, n * sizeof(float), hipMemcpyHostToDevice, H->stream));
     CHK(img_launch_make_images(H->d_color, H->w, H->h, H->levels, H->d_newImg, H->stream));
+    for (int l = 0; l < H->levels; l++) H->P.lv[l].newImg = H->d_newImg[l];
     H->P.new_exposure = exposure;
     CHK(hipStreamSynchronize(H->stream));
+    return LDSO_OK;
+}
+
+// the frame to be tracked as a resident ldso_pyramid_t (zero-copy; stream-ordered after the pyramid's build, no host synchronisation)
+int ldso_tr_set_new_frame_pyramid(ldso_tracker_t *H, ldso_pyramid_t *pyr, float exposure) {
+    REQ(H && pyr, "ldso_tr_set_new_frame_pyramid: bad arguments");
+    REQ(pyr->built && pyr->device == H->device && pyr->w == H->w && pyr->h == H->h && pyr->levels >= H->levels, "ldso_tr_set_new_frame_pyramid: pyramid does not match the tracker (device, size, levels) or holds no image");
+    CHK(hipSetDevice(H->device));
+    CHK(hipStreamWaitEvent(H->stream, pyr->ready, 0));
+    for (int l = 0; l < H->levels; l++) H->P.lv[l].newImg = pyr->lv[l];
+    H->P.new_exposure = exposure;
     return LDSO_OK;
 }
 
@@ -1043,7 +1075,7 @@ int ldso_tr_set_new_frame_image(ldso_tracker_t *H, const float *irradiance, floa
 int ldso_tr_get_new_frame_level(ldso_tracker_t *H, int lvl, float *out) {
     REQ(H && out && lvl >= 0 && lvl < H->levels, "ldso_tr_get_new_frame_level: bad arguments");
     CHK(hipSetDevice(H->device));
-    CHK(hipMemcpyAsync(out, H->d_newImg[lvl], (size_t) H->P.lv[lvl].w * H->P.lv[lvl].h * 3 * sizeof(float), hipMemcpyDeviceToHost, H->stream));
+    CHK(hipMemcpyAsync(out, H->P.lv[lvl].newImg, (size_t) H->P.lv[lvl].w * H->P.lv[lvl].h * 3 * sizeof(float), hipMemcpyDeviceToHost, H->stream));
     CHK(hipStreamSynchronize(H->stream));
     return LDSO_OK;
 }
