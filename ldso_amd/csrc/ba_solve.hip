@@ -432,7 +432,8 @@ static __device__ __forceinline__ void st2(double *p, double a, double b) { *(do
 static __host__ __device__ inline size_t solve_core_lds_doubles(int NB, int n) {
     size_t M = 16 * NB;
     size_t L = (NB == 4) ? M * (M + 2) : M * (M + 1) / 2;
-    return L + 2 * (M + 8) /*D,Y*/ + 30 * M /*F,G,panel (up to 8 columns, pitch 10)*/ + 2 * M /*scale,x*/ + 7 * (size_t) n + 16;
+    // NB == 4 (MFMA variant): two panel buffers [M][6] + per-wave private copies of F and G (4 waves x 2 x [64][4]) = 44 M
+    return L + 2 * (M + 8) /*D,Y*/ + (NB == 4 ? 46 : 30) * M /*F,G,panel (up to 8 columns, pitch 10)*/ + 2 * M /*scale,x*/ + 7 * (size_t) n + 16;
 }
 
 // GN = true (k_gn_solve): the prologue also mirrors the frames / calibration (and, when they fit, the float
@@ -452,7 +453,9 @@ struct SolveIO {
     int waitTarget;
 };
 
-template <int NB, int C, bool GN, bool WAIT = false>
+typedef double __attribute__((ext_vector_type(4))) ld_d4;
+
+template <int NB, int C, bool GN, bool WAIT = false, bool MF = false>
 static __device__ void solve_core(const BaPtrs &B, const BaDims &D, const ResSet &S, const ldso_settings_t &St, int iteration, double *sm, SolveIO &io) {
     constexpr int M = 16 * NB;
     constexpr int CP = C + 2;      // row pitch of the panel buffers: 16-byte aligned rows, conflict-free 16-byte accesses at stride CP
@@ -463,10 +466,10 @@ static __device__ void solve_core(const BaPtrs &B, const BaDims &D, const ResSet
     double *sL = sm;                       // L (see LIX)
     double *sD = sL + LSZ;                 // [M + 8]
     double *sY = sD + M + 8;               // [M + 8]
-    double *sFp = sY + M + 8;              // [M][CP]
-    double *sGp = sFp + CP * M;            // [M][CP]
-    double *sPn = sGp + CP * M;            // [M][CP]
-    double *sSc = sPn + CP * M;            // [M]
+    double *sFp = sY + M + 8;              // [M][CP]        (MF: panel buffer A)
+    double *sGp = sFp + CP * M;            // [M][CP]        (MF: panel buffer B)
+    double *sPn = sGp + CP * M;            // [M][CP]        (MF: per-wave copies of F, then of G: 2 x 4 x [64][4])
+    double *sSc = sPn + (MF ? 2 * 4 * 64 * 4 : CP * M);            // [M]
     double *sx = sSc + M;                  // [M]
     double *sNs = sx + M;                  // [7][n]
     const double *HF = B.sys + 3 * (n * n + n), *bF = HF + n * n;      // assembled by k_gather (step-wise path)
@@ -475,6 +478,14 @@ static __device__ void solve_core(const BaPtrs &B, const BaDims &D, const ResSet
     // ---------------- prologue: every global load of the control step, issued back to back ----------------
     // GN: HFinal / bFinal (lower triangle) come straight from the accumulator k_reduce added into (B.acc)
     double v[NTILE], dI[NB], dJ[NB], dS = 0.0;
+    // MF (n + 1 <= 64): the trailing update runs on the fp64 matrix cores (v_mfma_f64_16x16x4_f64).  The ten 16x16 tiles of the lower
+    // triangle live in MFMA accumulator layout, three slots per wavefront: lane l, register r of a slot <-> element
+    // (16 ta + (l >> 4) + 4 r, 16 tb + (l & 15)) of tile (ta, tb); wave w holds (w,0) | (w+1,w... see the packed tables) - 15 = no tile.
+    static_assert(!MF || (NB == 4 && C == 4), "the MFMA variant is written for the 64x64 system, 4 columns per round");
+    const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int mta[3] = {(0x3210 >> (4 * wv)) & 15, (0xF321 >> (4 * wv)) & 15, (0xF332 >> (4 * wv)) & 15};
+    const int mtb[3] = {0, (0xF111 >> (4 * wv)) & 15, (0xF322 >> (4 * wv)) & 15};
+    ld_d4 Dv[3];
     if (GN) { HF = B.acc; bF = HF + (size_t) n * n; }
 // branch-free (clamped offsets, masked values): bFinal follows HFinal in memory, so row n of the augmented system is HF[n*n + j].
 // Straight-line code matters here: in the fused kernel these loads are the first instructions after the wait (cold instruction cache).
@@ -497,10 +508,22 @@ _Pragma("unroll") \
             } \
         { const double q = HF[min(tid * n + tid, nn_)]; dS = (tid < n) ? q : 0.0; } \
     } while (0)
+#define LD_LOAD_H_MF() do { \
+        const int nn_ = n * n + n - 1; \
+_Pragma("unroll") \
+        for (int s_ = 0; s_ < 3; s_++) \
+_Pragma("unroll") \
+            for (int r = 0; r < 4; r++) { \
+                const int i = 16 * mta[s_] + (lane >> 4) + 4 * r, j = 16 * mtb[s_] + (lane & 15); \
+                const double q = HF[min(i * n + j, nn_)]; \
+                Dv[s_][r] = (mta[s_] < 4 && j < n && (!GN || j <= i) && i <= n) ? q : 0.0; \
+            } \
+        { const double q = HF[min(tid * n + tid, nn_)]; dS = (tid < n) ? q : 0.0; } \
+    } while (0)
     // fused kernel (io.waitCtr): the system is still being accumulated by the reduce workgroups of this launch - everything that does
     // not depend on it is loaded and staged first, the system after the wait below
     constexpr bool waitH = GN && WAIT;
-    if constexpr (!waitH) { LD_LOAD_H(); }
+    if constexpr (!waitH) { if constexpr (MF) { LD_LOAD_H_MF(); } else { LD_LOAD_H(); } }
     double nsv[4];
     if (ortho) {
 #pragma unroll
@@ -554,10 +577,27 @@ _Pragma("unroll") \
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         if (LD_STAMP_ON && tid == 0) B.energyLog[48] = (double) wall_clock64();
-        LD_LOAD_H();
+        if constexpr (MF) { LD_LOAD_H_MF(); } else { LD_LOAD_H(); }
     }
     if (tid < M) sSc[tid] = fast_rsqrt(dS + 10.0);
-    {
+    if constexpr (MF) {
+        __syncthreads();
+#pragma unroll
+        for (int s_ = 0; s_ < 3; s_++) {
+            const double sj = sSc[min(16 * mtb[s_] + (lane & 15), M - 1)];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int i = 16 * mta[s_] + (lane >> 4) + 4 * r;
+                const double si = (i == n) ? 1.0 : sSc[min(i, M - 1)];
+                Dv[s_][r] = si * Dv[s_][r] * sj;
+            }
+        }
+        // first panel (columns 0..3): the tiles of tile column 0 (slot 0 of every wave)
+        if ((lane & 15) < C) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) sFp[(16 * mta[0] + (lane >> 4) + 4 * r) * CP + (lane & 15)] = Dv[0][r];
+        }
+    } else {
         double sI[NB], sJ[NB];
 #pragma unroll
         for (int a = 0; a < NB; a++) { sI[a] = (ty + 16 * a == n) ? 1.0 : fast_rsqrt(dI[a] + 10.0); sJ[a] = fast_rsqrt(dJ[a] + 10.0); }
@@ -567,7 +607,7 @@ _Pragma("unroll") \
             for (int b = 0; b <= a; b++) v[a * (a + 1) / 2 + b] = sI[a] * v[a * (a + 1) / 2 + b] * sJ[b];
     }
     // first panel (columns 0..C-1)
-    if (tx < C) {
+    if (!MF && tx < C) {
 #pragma unroll
         for (int a = 0; a < NB; a++) sPn[(ty + 16 * a) * CP + tx] = v[a * (a + 1) / 2];
     }
@@ -582,18 +622,21 @@ _Pragma("unroll") \
         // c[r][q] (r >= q) = column q of the block after the eliminations 0..q-1 (unscaled), d_q = c[q][q], inv_q = 1/d_q;
         // g_q = A[i][k+q] after the eliminations 0..q-1, f_q = g_q / d_q = L[i][k+q].  Every update is written as
         // x -= (product of already known values) * inv_q, so that pivot d_{q+1} is ONE fma behind the reciprocal of d_q.
-        if (tid < M) {
-            const int i = tid;
+        // MF: every wavefront replays phase 1 for all 64 rows (lane = row) - the four copies run side by side on the four SIMDs and
+        // spare the hand-over of F / G through a workgroup barrier; the panel buffers alternate (one barrier per round)
+        if (MF || tid < M) {
+            const int i = MF ? lane : tid;
+            const double *sPr = MF ? (((k >> 2) & 1) ? sGp : sFp) : sPn;
             double c[C][C], g[C], f[C], inv[C];
 #pragma unroll
             for (int r = 0; r < C; r++)
 #pragma unroll
                 for (int q2 = 0; q2 <= r; q2 += 2) {
-                    const double2 w = ld2(&sPn[(k + r) * CP + q2]);
+                    const double2 w = ld2(&sPr[(k + r) * CP + q2]);
                     c[r][q2] = w.x; if (q2 + 1 < C) c[r][q2 + 1] = w.y;
                 }
 #pragma unroll
-            for (int q2 = 0; q2 < C; q2 += 2) { const double2 w = ld2(&sPn[i * CP + q2]); g[q2] = w.x; g[q2 + 1] = w.y; }
+            for (int q2 = 0; q2 < C; q2 += 2) { const double2 w = ld2(&sPr[i * CP + q2]); g[q2] = w.x; g[q2 + 1] = w.y; }
 #pragma unroll
             for (int q = 0; q < C; q++) {
                 const double d = c[q][q];
@@ -615,23 +658,55 @@ _Pragma("unroll") \
             }
             const bool below = (i >= k + C);
             const bool rowOn = below && (i <= n), colOn = below && (i < n);
+            if constexpr (MF) {
+                double *Fw = sPn + wv * 256, *Gw = sPn + 1024 + wv * 256;       // this wave's own copies: [64 rows][4]
 #pragma unroll
-            for (int q2 = 0; q2 < C; q2 += 2) {
-                st2(&sFp[i * CP + q2], rowOn ? f[q2] : 0.0, rowOn ? f[q2 + 1] : 0.0);
-                st2(&sGp[i * CP + q2], colOn ? g[q2] : 0.0, colOn ? g[q2 + 1] : 0.0);
+                for (int q2 = 0; q2 < C; q2 += 2) {
+                    st2(&Fw[i * 4 + q2], rowOn ? f[q2] : 0.0, rowOn ? f[q2 + 1] : 0.0);
+                    st2(&Gw[i * 4 + q2], colOn ? g[q2] : 0.0, colOn ? g[q2 + 1] : 0.0);
+                }
+            } else {
+#pragma unroll
+                for (int q2 = 0; q2 < C; q2 += 2) {
+                    st2(&sFp[i * CP + q2], rowOn ? f[q2] : 0.0, rowOn ? f[q2 + 1] : 0.0);
+                    st2(&sGp[i * CP + q2], colOn ? g[q2] : 0.0, colOn ? g[q2 + 1] : 0.0);
+                }
             }
-            if (i > k && i < n) {                 // L[i][k+q] for the rows of the pivot block (q < i-k) and all rows below it
+            const bool keeper = !MF || wv == 0;          // L, y, D are stored once (MF: by wave 0)
+            if (keeper && i > k && i < n) {       // L[i][k+q] for the rows of the pivot block (q < i-k) and all rows below it
 #pragma unroll
                 for (int q = 0; q < C; q++) if (i > k + q) sL[LIX(i, k + q)] = f[q];
             }
-            if (i == n) {                         // forward-substituted rhs (k + C <= n + C - 1 < M + C: sY has C spare entries)
+            if (keeper && i == n) {               // forward-substituted rhs (k + C <= n + C - 1 < M + C: sY has C spare entries)
 #pragma unroll
                 for (int q2 = 0; q2 < C; q2 += 2) st2(&sY[k + q2], g[q2], g[q2 + 1]);
             }
-            if (i == k) {
+            if (keeper && i == k) {
 #pragma unroll
                 for (int q2 = 0; q2 < C; q2 += 2) st2(&sD[k + q2], c[q2][q2], c[q2 + 1][q2 + 1]);
             }
+        }
+        if constexpr (MF) {
+            // ---------------- phase 2 on the matrix cores: one v_mfma_f64_16x16x4_f64 per live tile (D -= F_rows G_cols^T) -------------
+            // A operand: lane l supplies F[16 ta + (l & 15)][l >> 4], B operand: G[16 tb + (l & 15)][l >> 4] - read back from this
+            // wave's own LDS copies (same wave wrote them: no barrier).  Tile columns left of the next panel are finished.
+            const int bDone = (k + C) >> 4, c0 = (k + C) & 15;
+            const double *Fw = sPn + wv * 256, *Gw = sPn + 1024 + wv * 256;
+            double *sPw = ((k >> 2) & 1) ? sFp : sGp;
+#pragma unroll
+            for (int s_ = 0; s_ < 3; s_++) {
+                if (mta[s_] > 3 || mtb[s_] < bDone) continue;          // uniform per wave
+                const double aop = -Fw[(16 * mta[s_] + (lane & 15)) * 4 + (lane >> 4)];
+                const double bop = Gw[(16 * mtb[s_] + (lane & 15)) * 4 + (lane >> 4)];
+                Dv[s_] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, Dv[s_], 0, 0, 0);
+                // owners of columns k+C .. k+2C-1 publish them as the next panel
+                if (mtb[s_] == bDone && (lane & 15) >= c0 && (lane & 15) < c0 + C) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) sPw[(16 * mta[s_] + (lane >> 4) + 4 * r) * CP + (lane & 15) - c0] = Dv[s_][r];
+                }
+            }
+            __syncthreads();
+            continue;
         }
         __syncthreads();
         // ---------------- phase 2 (branch free: finished columns have G = 0, finished rows F = 0) ----------------
@@ -744,7 +819,7 @@ _Pragma("unroll") \
 
 template <bool GN, bool WAIT = false>
 static __device__ void solve_core_dispatch(const BaPtrs &B, const BaDims &D, const ResSet &S, const ldso_settings_t &St, int iteration, double *sm, SolveIO &io) {
-    if (D.n + 1 <= 64) solve_core<4, 4, GN, WAIT>(B, D, S, St, iteration, sm, io);
+    if (D.n + 1 <= 64) solve_core<4, 4, GN, WAIT, true>(B, D, S, St, iteration, sm, io);
     else if (D.n + 1 <= 112) solve_core<7, 4, GN, WAIT>(B, D, S, St, iteration, sm, io);
     else solve_core<9, 4, GN, WAIT>(B, D, S, St, iteration, sm, io);
 }
