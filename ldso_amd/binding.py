@@ -21,7 +21,8 @@ class LdsoError(RuntimeError):
 
 
 def lib_path() -> str:
-    return os.path.join(_HERE, "libldso_hip.so")
+    # LDSO_HIP_LIB: an alternative build of the same library (kernel experiments: scripts/build_variant.sh), never a CPU substitute
+    return os.environ.get("LDSO_HIP_LIB") or os.path.join(_HERE, "libldso_hip.so")
 
 
 def lib():
