@@ -106,6 +106,32 @@ def test_track_batch_equals_single():
         assert np.array_equal(singles[i]["T"], batch["T"][i]) and singles[i]["iterations"] == batch["iterations"][i]
 
 
+@pytest.mark.parametrize("nhyp", [1, 16, 17, 33, 70])
+def test_cooperative_group_sizes_agree(nhyp):
+    """ldso_tr_track_batch picks G = 16 / 8 / 4 / 1 cooperating workgroups per hypothesis from the hypothesis count (nhyp * G <= CUs).
+    The variants differ only in how the 52 sums are grouped: every hypothesis of every batch size must land on the oracle's pose
+    (LM convergence tolerance) with the same accept flag, on the full-size pair where all five levels are shared."""
+    sc = tracker_scenario("C3", levels=5)
+    o, g = make_pair(sc)
+    a, b = sc["new_aff"]
+    L = sc["levels"]
+    rng = np.random.default_rng(nhyp)
+    guesses = [synth.se3_exp(np.concatenate([rng.normal(0, 2e-3, 3), rng.normal(0, 5e-4, 3)])) for _ in range(nhyp)]
+    guesses[0] = np.eye(4)
+    batch = g.track_batch(guesses, [(a, b)] * nhyp, L - 1)
+    assert all(batch["ok"])
+    for i in sorted({0, nhyp // 2, nhyp - 1}):
+        ro = o.track(guesses[i], a, b, L - 1)
+        assert ro["ok"]
+        assert np.abs(batch["T"][i] - ro["T"]).max() < 2e-5, (i, np.abs(batch["T"][i] - ro["T"]).max())
+        assert abs(batch["iterations"][i] - ro["iterations"]) <= 2
+        single = g.track(guesses[i], a, b, L - 1)                      # G = 16
+        assert np.abs(batch["T"][i] - single["T"]).max() < 2e-5
+    # all hypotheses converge to the same pose (they start close to each other)
+    Ts = np.array(batch["T"])
+    assert np.abs(Ts - Ts[0]).max() < 1e-4
+
+
 def test_abort_on_min_res():
     sc = tracker_scenario("small")
     o, g = make_pair(sc)
