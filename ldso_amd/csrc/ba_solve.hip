@@ -756,14 +756,30 @@ _Pragma("unroll") \
             for (int kk = 63; kk >= 1; kk--) { double xk = readlane_f64(xi, kk); xi = __builtin_fma(-row[kk], xk, xi); }
             if (lane < n) sx[lane] = xi * sSc[lane];
         } else {
-            for (int i = lane; i < n; i += 64) { double d = sD[i]; sx[i] = (fabs(d) > TINY) ? sY[i] / d : 0.0; }
-            __builtin_amdgcn_wave_barrier();
-            for (int kk = n - 1; kk > 0; kk--) {           // column oriented: x_i -= L[k][i] x_k for i < k
-                const double xk = sx[kk];
-                for (int i = lane; i < kk; i += 64) sx[i] -= sL[LIX(kk, i)] * xk;
-                __builtin_amdgcn_wave_barrier();
+            // lane l owns x_i for i = l, l + 64, (l + 128) in registers; x_k is broadcast with v_readlane (no LDS round trip and no
+            // wave barrier per column: the column-oriented LDS version took 15 us at n = 100); the L entries do not depend on x and
+            // are loaded ahead of the dependent chain (the loop carries no LDS store)
+            constexpr int NSEG = (M + 63) / 64;
+            double xr[NSEG];
+#pragma unroll
+            for (int sg = 0; sg < NSEG; sg++) {
+                const int i = lane + 64 * sg;
+                const double d = sD[min(i, M - 1)];
+                xr[sg] = (i < n && fabs(d) > TINY) ? sY[min(i, M - 1)] / d : 0.0;
             }
-            for (int i = lane; i < n; i += 64) sx[i] *= sSc[i];
+#pragma unroll 4
+            for (int kk = n - 1; kk > 0; kk--) {           // x_i -= L[k][i] x_k for i < k
+                double lk[NSEG];
+#pragma unroll
+                for (int sg = 0; sg < NSEG; sg++) { const int i = lane + 64 * sg; lk[sg] = (i < kk) ? sL[LIX(kk, min(i, kk))] : 0.0; }
+                double xk = 0.0;
+#pragma unroll
+                for (int sg = 0; sg < NSEG; sg++) if ((kk >> 6) == sg) xk = readlane_f64(xr[sg], kk & 63);      // uniform
+#pragma unroll
+                for (int sg = 0; sg < NSEG; sg++) xr[sg] = __builtin_fma(-lk[sg], xk, xr[sg]);
+            }
+#pragma unroll
+            for (int sg = 0; sg < NSEG; sg++) { const int i = lane + 64 * sg; if (i < n) sx[i] = xr[sg] * sSc[i]; }
         }
         // orthogonalize x against the gauge nullspaces (x -= U U^T x): 8 lanes per nullspace vector
         if (ortho) {
