@@ -196,9 +196,6 @@ __global__ void k_tr_write(TrLevel L) {
 #define TR_NACC 52
 #define TR_U 4            // points per thread and pass of tr_eval
 
-template <int CTRL> __device__ __forceinline__ float tr_dpp(float x) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
-}
 __device__ __forceinline__ float tr_readlane(float x, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), l)); }
 
 __device__ __forceinline__ void aff_from_to_f(float expF, float expT, float aF, float bF, float aT, float bT, float &a, float &b) {
@@ -212,6 +209,13 @@ __device__ __forceinline__ void aff_from_to_f(float expF, float expT, float aF, 
 // on few wavefronts.  The points of the first pass stay in registers across the evaluations of a level (they do not depend on the
 // candidate pose): an evaluation then costs ONE memory latency (the tap gather) instead of two.
 struct TrPts { float id[TR_U], x[TR_U], y[TR_U], col[TR_U]; int lvl; };
+// LDS scratch of tr_eval: per wavefront the staged vectors U | V ([16][TR_UVP] floats each), then one 16x16 result per wavefront
+#define TR_UVP 68                                   // row pitch: lane l of an MFMA reads bank 4 (l & 15) + (l >> 4) (+ 4 m): conflict-free
+#define TR_LDS_FLOATS ((TR_NT / 64) * (2 * 16 * TR_UVP + 256))
+// accumulator q of the 52 sums <-> entry (row, col) of M = sum_p u_p v_p^T (see tr_eval): q < 7: (9 + q, 9); then the upper triangle of the 9x9
+static __device__ const unsigned char TR_QROW[TR_NACC] = {9, 10, 11, 12, 13, 14, 15, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 3, 3, 3, 3, 3, 3, 4, 4, 4, 4, 4, 5, 5, 5, 5, 6, 6, 6, 7, 7, 8};
+static __device__ const unsigned char TR_QCOL[TR_NACC] = {9, 9, 9, 9, 9, 9, 9, 0, 1, 2, 3, 4, 5, 6, 7, 8, 1, 2, 3, 4, 5, 6, 7, 8, 2, 3, 4, 5, 6, 7, 8, 3, 4, 5, 6, 7, 8, 4, 5, 6, 7, 8, 5, 6, 7, 8, 6, 7, 8, 7, 8, 8};
+typedef float __attribute__((ext_vector_type(4))) tr_f4;
 // pointers read from TrParams are generic to the compiler (flat loads); they all point to device memory
 typedef const __attribute__((address_space(1))) float *tr_gptr;
 
@@ -222,7 +226,7 @@ __device__ long long g_trPh[5][8];      // debug: per level, time in the phases 
 #define TPH(k) do { } while (0)
 #endif
 __device__ __forceinline__ void tr_eval(const TrParams &P, int lvl, const float *Rt /*LDS: R row major (9), t (3)*/, float aff_a, float aff_b, float cutoffTH,
-                        double *out /*LDS TR_NACC*/, float *red /*LDS [TR_NT/16][TR_NACC]*/, int g, int nAct, TrPts &pc) {
+                        double *out /*LDS TR_NACC*/, float *red /*LDS TR_LDS_FLOATS*/, int g, int nAct, TrPts &pc) {
     const TrLevel &L = P.lv[lvl];
 #if LD_STAMP_ON_TR
     long long tph_ = wall_clock64();
@@ -245,10 +249,17 @@ __device__ __forceinline__ void tr_eval(const TrParams &P, int lvl, const float 
     const float maxEnergy = 2 * P.huberTH * cutoffTH - P.huberTH * P.huberTH;
     const float b0 = P.ref_b;
 
-    float acc[TR_NACC];
+    // The 52 sums are entries of ONE matrix M = sum_p u_p v_p^T with u = [hw J (9) | E, terms, 3 flow sums, saturated, warped] and
+    // v = [J (9) | 1 | 0 ...]: the fp32 matrix cores do the 45 products per point AND the reduction over the points
+    // (v_mfma_f32_16x16x4_f32: 4 points per instruction) - no per-lane accumulators, no 52-value cross-lane reduction.  Every lane
+    // stages its point's u, v in the wave's LDS scratch ([component][point], conflict-free pitch) and reads them back as operands
+    // (same wave: no barrier); M accumulates in 2 x 4 registers per lane.
+    float *sU = red + wave * (2 * 16 * TR_UVP), *sV = sU + 16 * TR_UVP;
+    tr_f4 Dm0 = {0.f, 0.f, 0.f, 0.f}, Dm1 = {0.f, 0.f, 0.f, 0.f};
+    if (tid < nth) {
 #pragma unroll
-    for (int q = 0; q < TR_NACC; q++) acc[q] = 0.f;
-    if (__builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, RKi[0] + affA + (float) nth)) == 0x7fc01234) acc[0] = 1;   // keeps the set-up ahead of the stamp
+        for (int c = 10; c < 16; c++) sV[c * TR_UVP + lane] = 0.f;            // components 10..15 of v stay zero
+    }
     TPH(0);
 
     // one pass: TR_U points per lane; all 12-float tap gathers of a pass are issued together
@@ -276,6 +287,11 @@ __device__ __forceinline__ void tr_eval(const TrParams &P, int lvl, const float 
         for (int u_ = 0; u_ < TR_U; u_++) {
             if (u_ >= nu) break;                                                   // uniform
             const int i = ib + u_ * nth;
+            float uv[16], vj[9];
+#pragma unroll
+            for (int c = 0; c < 16; c++) uv[c] = 0.f;
+#pragma unroll
+            for (int c = 0; c < 9; c++) vj[c] = 0.f;
             if (in[u_] && lvl == 0 && i % 32 == 0) {
                 const float *Ki = L.Ki;
                 const float xx = x[u_], yy = y[u_], idd = id[u_];
@@ -287,47 +303,54 @@ __device__ __forceinline__ void tr_eval(const TrParams &P, int lvl, const float 
                 float r0 = (((RKi[0] * xx + RKi[1] * yy) + RKi[2] * 1.0f)) - t[0] * idd, r1 = (((RKi[3] * xx + RKi[4] * yy) + RKi[5] * 1.0f)) - t[1] * idd,
                       r2 = (((RKi[6] * xx + RKi[7] * yy) + RKi[8] * 1.0f)) - t[2] * idd;
                 float Ku3 = fxl * (r0 / r2) + cxl, Kv3 = fyl * (r1 / r2) + cyl;
-                acc[2] += (KuT - xx) * (KuT - xx) + (KvT - yy) * (KvT - yy);
-                acc[2] += (KuT2 - xx) * (KuT2 - xx) + (KvT2 - yy) * (KvT2 - yy);
-                acc[3] += (Ku[u_] - xx) * (Ku[u_] - xx) + (Kv[u_] - yy) * (Kv[u_] - yy);
-                acc[3] += (Ku3 - xx) * (Ku3 - xx) + (Kv3 - yy) * (Kv3 - yy);
-                acc[4] += 2;
+                uv[11] = ((KuT - xx) * (KuT - xx) + (KvT - yy) * (KvT - yy)) + ((KuT2 - xx) * (KuT2 - xx) + (KvT2 - yy) * (KvT2 - yy));
+                uv[12] = ((Ku[u_] - xx) * (Ku[u_] - xx) + (Kv[u_] - yy) * (Kv[u_] - yy)) + ((Ku3 - xx) * (Ku3 - xx) + (Kv3 - yy) * (Kv3 - yy));
+                uv[13] = 2;
             }
-            if (!ok[u_]) continue;
-            const float refColor = col[u_], u = uu[u_], v = vv[u_], new_idepth = nid[u_];
-            const int ix = (int) Ku[u_], iy = (int) Kv[u_];
-            float dx = Ku[u_] - ix, dy = Kv[u_] - iy, dxdy = dx * dy;
-            float w11 = dxdy, w01 = dy - dxdy, w10 = dx - dxdy, w00 = 1 - dx - dy + dxdy;
-            const float *tp = tap[u_];
-            float h0 = ((w11 * tp[9] + w01 * tp[6]) + w10 * tp[3]) + w00 * tp[0];
-            float h1 = ((w11 * tp[10] + w01 * tp[7]) + w10 * tp[4]) + w00 * tp[1];
-            float h2 = ((w11 * tp[11] + w01 * tp[8]) + w10 * tp[5]) + w00 * tp[2];
-            if (!isfinite(h0)) continue;
-            float residual = h0 - (float) (affA * refColor + affB);
-            float hw = fabsf(residual) < P.huberTH ? 1 : P.huberTH / fabsf(residual);
-            if (fabsf(residual) > cutoffTH) {
-                acc[0] += maxEnergy; acc[1] += 1; acc[5] += 1;
-            } else {
-                acc[0] += hw * residual * residual * (2 - hw); acc[1] += 1; acc[6] += 1;
-                // calcGSSSE row (CoarseTracker.cc:592-615)
-                float ddx = h1 * fxl, ddy = h2 * fyl;
-                float J[9];
-                J[0] = new_idepth * ddx;
-                J[1] = new_idepth * ddy;
-                J[2] = 0 - new_idepth * (u * ddx + v * ddy);
-                J[3] = 0 - ((u * v) * ddx + ddy * (1 + v * v));
-                J[4] = (u * v) * ddy + ddx * (1 + u * u);
-                J[5] = u * ddy - v * ddx;
-                J[6] = affA * (b0 - refColor);
-                J[7] = -1;
-                J[8] = residual;
-                int q = 7;
+            if (ok[u_]) {
+                const float refColor = col[u_], u = uu[u_], v = vv[u_], new_idepth = nid[u_];
+                const int ix = (int) Ku[u_], iy = (int) Kv[u_];
+                float dx = Ku[u_] - ix, dy = Kv[u_] - iy, dxdy = dx * dy;
+                float w11 = dxdy, w01 = dy - dxdy, w10 = dx - dxdy, w00 = 1 - dx - dy + dxdy;
+                const float *tp = tap[u_];
+                float h0 = ((w11 * tp[9] + w01 * tp[6]) + w10 * tp[3]) + w00 * tp[0];
+                float h1 = ((w11 * tp[10] + w01 * tp[7]) + w10 * tp[4]) + w00 * tp[1];
+                float h2 = ((w11 * tp[11] + w01 * tp[8]) + w10 * tp[5]) + w00 * tp[2];
+                if (isfinite(h0)) {
+                    float residual = h0 - (float) (affA * refColor + affB);
+                    float hw = fabsf(residual) < P.huberTH ? 1 : P.huberTH / fabsf(residual);
+                    uv[10] = 1;
+                    if (fabsf(residual) > cutoffTH) {
+                        uv[9] = maxEnergy; uv[14] = 1;
+                    } else {
+                        uv[9] = hw * residual * residual * (2 - hw); uv[15] = 1;
+                        // calcGSSSE row (CoarseTracker.cc:592-615)
+                        float ddx = h1 * fxl, ddy = h2 * fyl;
+                        vj[0] = new_idepth * ddx;
+                        vj[1] = new_idepth * ddy;
+                        vj[2] = 0 - new_idepth * (u * ddx + v * ddy);
+                        vj[3] = 0 - ((u * v) * ddx + ddy * (1 + v * v));
+                        vj[4] = (u * v) * ddy + ddx * (1 + u * u);
+                        vj[5] = u * ddy - v * ddx;
+                        vj[6] = affA * (b0 - refColor);
+                        vj[7] = -1;
+                        vj[8] = residual;
 #pragma unroll
-                for (int r = 0; r < 9; r++) {
-                    float jw = J[r] * hw;
-#pragma unroll
-                    for (int c = r; c < 9; c++) { acc[q] = __builtin_fmaf(jw, J[c], acc[q]); q++; }
+                        for (int r = 0; r < 9; r++) uv[r] = vj[r] * hw;
+                    }
                 }
+            }
+            // stage (all lanes of the wave: a lane without a valid point contributes u = 0), then 16 MFMAs over the 64 points
+#pragma unroll
+            for (int c = 0; c < 16; c++) sU[c * TR_UVP + lane] = uv[c];
+#pragma unroll
+            for (int c = 0; c < 9; c++) sV[c * TR_UVP + lane] = vj[c];
+            sV[9 * TR_UVP + lane] = 1.f;
+#pragma unroll
+            for (int m = 0; m < 16; m += 2) {
+                const int o0 = (lane & 15) * TR_UVP + 4 * m + (lane >> 4);
+                Dm0 = __builtin_amdgcn_mfma_f32_16x16x4f32(sU[o0], sV[o0], Dm0, 0, 0, 0);
+                Dm1 = __builtin_amdgcn_mfma_f32_16x16x4f32(sU[o0 + 4], sV[o0 + 4], Dm1, 0, 0, 0);
             }
         }
     };
@@ -354,36 +377,25 @@ __device__ __forceinline__ void tr_eval(const TrParams &P, int lvl, const float 
         }
     }
     pc.lvl = lvl;
-    if (__builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, acc[0] + acc[51] + acc[20])) == 0x7fc01234) acc[1] = 1;
     TPH(1);
-    // block reduction, fixed order: the 16 lanes of a DPP row in float (the per-lane sums are float already), then the
-    // 4 rows x nWact waves in double by 52 threads
+    // one 16x16 result per wavefront: lane l, register r holds M[(l >> 4) * 4 + r][l & 15]
+    float *sM = red + (TR_NT / 64) * (2 * 16 * TR_UVP);
     if (wave < nWact) {
-        // four sweeps over the 52 sums (independent instructions within a sweep: a per-sum chain would stall on every DPP hazard)
+        const tr_f4 Dm = Dm0 + Dm1;
 #pragma unroll
-        for (int q = 0; q < TR_NACC; q++) acc[q] += tr_dpp<0xB1>(acc[q]);       // quad_perm [1,0,3,2]
-#pragma unroll
-        for (int q = 0; q < TR_NACC; q++) acc[q] += tr_dpp<0x4E>(acc[q]);       // quad_perm [2,3,0,1]
-#pragma unroll
-        for (int q = 0; q < TR_NACC; q++) acc[q] += tr_dpp<0x141>(acc[q]);      // row_half_mirror
-#pragma unroll
-        for (int q = 0; q < TR_NACC; q++) acc[q] += tr_dpp<0x140>(acc[q]);      // row_mirror -> every lane holds the sum of its 16-lane row
-        if ((lane & 15) == 0) {
-            float4 *dst = reinterpret_cast<float4 *>(red + ((wave << 2) + (lane >> 4)) * TR_NACC);
-#pragma unroll
-            for (int q = 0; q < TR_NACC; q += 4) dst[q >> 2] = make_float4(acc[q], acc[q + 1], acc[q + 2], acc[q + 3]);
-        }
+        for (int r = 0; r < 4; r++) sM[wave * 256 + ((lane >> 4) * 4 + r) * 16 + (lane & 15)] = Dm[r];
     }
     TPH(2);
     __syncthreads();
     TPH(3);
     if (tid < TR_NACC) {
-        float rv[TR_NT / 16];
+        const int o = TR_QROW[tid] * 16 + TR_QCOL[tid];
+        float rv[TR_NT / 64];
 #pragma unroll
-        for (int r = 0; r < TR_NT / 16; r++) rv[r] = (r < nWact * 4) ? red[r * TR_NACC + tid] : 0.f;      // all reads in flight together
+        for (int w_ = 0; w_ < TR_NT / 64; w_++) rv[w_] = (w_ < nWact) ? sM[w_ * 256 + o] : 0.f;
         double s = 0;
 #pragma unroll
-        for (int r = 0; r < TR_NT / 16; r++) if (r < nWact * 4) s += (double) rv[r];
+        for (int w_ = 0; w_ < TR_NT / 64; w_++) if (w_ < nWact) s += (double) rv[w_];
         out[tid] = s;
     }
     __syncthreads();
@@ -662,7 +674,7 @@ template <int G>
 __global__ __launch_bounds__(TR_NT) void k_tr_track(const TrParams *__restrict__ Pp, TrHyp *hyps, TrCoop *coop, int seq0) {
     const TrParams &P = *Pp;      // device memory, not a by-value argument: a dynamically indexed kernel argument would be copied to scratch memory
     __shared__ double sAcc[TR_NACC];
-    __shared__ __attribute__((aligned(16))) float sRed[(TR_NT / 16) * TR_NACC];
+    __shared__ __attribute__((aligned(16))) float sRed[TR_LDS_FLOATS];
     __shared__ float sRt[12];
     __shared__ double sT[12], sTnew[12];
     __shared__ float sAff[2], sAffNew[2];
@@ -811,7 +823,7 @@ __global__ __launch_bounds__(TR_NT) void k_tr_track(const TrParams *__restrict__
 __global__ __launch_bounds__(TR_NT) void k_tr_calc(const TrParams *__restrict__ Pp, int lvl, const double *Tdev, float a, float b, float cutoffTH, double *outAcc) {
     const TrParams &P = *Pp;
     __shared__ double sAcc[TR_NACC];
-    __shared__ __attribute__((aligned(16))) float sRed[(TR_NT / 16) * TR_NACC];
+    __shared__ __attribute__((aligned(16))) float sRed[TR_LDS_FLOATS];
     __shared__ float sRt[12];
     const int tid = threadIdx.x;
     if (tid < 12) sRt[tid] = (float) Tdev[tid < 9 ? (tid / 3) * 4 + tid % 3 : (tid - 9) * 4 + 3];

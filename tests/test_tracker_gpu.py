@@ -123,10 +123,11 @@ def test_cooperative_group_sizes_agree(nhyp):
     for i in sorted({0, nhyp // 2, nhyp - 1}):
         ro = o.track(guesses[i], a, b, L - 1)
         assert ro["ok"]
-        assert np.abs(batch["T"][i] - ro["T"]).max() < 2e-5, (i, np.abs(batch["T"][i] - ro["T"]).max())
+        # LM stops at |inc| <= 1e-3: end poses of runs that differ only in the summation order of the float sums agree to a fraction of it
+        assert np.abs(batch["T"][i] - ro["T"]).max() < 1e-4, (i, np.abs(batch["T"][i] - ro["T"]).max())
         assert abs(batch["iterations"][i] - ro["iterations"]) <= 2
         single = g.track(guesses[i], a, b, L - 1)                      # G = 16
-        assert np.abs(batch["T"][i] - single["T"]).max() < 2e-5
+        assert np.abs(batch["T"][i] - single["T"]).max() < 1e-4
     # all hypotheses converge to the same pose (they start close to each other)
     Ts = np.array(batch["T"])
     assert np.abs(Ts - Ts[0]).max() < 1e-4
