@@ -80,6 +80,9 @@ struct ldso_ba {
     std::vector<void *> allocs;
     // host staging of the window (for shard rebuilds)
     std::vector<int32_t> h_phost;
+    // window upload: ONE pinned staging arena -> ONE device arena -> one scatter kernel (k_win_scatter) instead of ~25 copies + ~20 fills
+    char *h_stage = nullptr, *d_stage = nullptr;
+    size_t stageCap = 0;
     // profiling
     bool profile = false;
     std::vector<Timer> timers;
@@ -150,6 +153,47 @@ template <class T> static int dalloc(ldso_ba *H, T **p, size_t n) {
     return LDSO_OK;
 }
 #define DA(ptr, n) do { int r_ = dalloc(H, &(ptr), (n)); if (r_ != LDSO_OK) return r_; } while (0)
+// One entry of the upload table at the head of the staging arena: copy `words` 32-bit words from arena offset `src` (bytes) to `dst`,
+// or fill `dst` with zeros (src == LD_XFER_ZERO).
+struct WinXfer { void *dst; unsigned long long src; unsigned long long words; };
+#define LD_XFER_ZERO 0xFFFFFFFFFFFFFFFFull
+#define LD_XFER_MAX 96
+__global__ __launch_bounds__(256) void k_win_scatter(const char *__restrict__ arena, int nEntries) {
+    const WinXfer *tab = reinterpret_cast<const WinXfer *>(arena);
+    for (int e = 0; e < nEntries; e++) {
+        const WinXfer x = tab[e];
+        unsigned *dst = static_cast<unsigned *>(x.dst);
+        const size_t n = (size_t) x.words, stride = (size_t) gridDim.x * blockDim.x;
+        if (x.src == LD_XFER_ZERO) { for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = 0u; }
+        else {
+            const unsigned *src = reinterpret_cast<const unsigned *>(arena + x.src);
+            for (size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+        }
+    }
+}
+// host side of the arena: reserve (16-byte aligned) room, remember where it goes
+struct WinStage {
+    char *base; size_t cap, used; WinXfer *tab; int n;
+    template <class T> T *put(T *dst, size_t count) {          // room for `count` elements that will land at dst; returns where to write them
+        const size_t bytes = (count * sizeof(T) + 15) & ~(size_t) 15;
+        if (n >= LD_XFER_MAX || used + bytes > cap) return nullptr;
+        T *p = reinterpret_cast<T *>(base + used);
+        if (count) { tab[n].dst = dst; tab[n].src = used; tab[n].words = count * sizeof(T) / 4; n++; }
+        used += bytes;
+        return p;
+    }
+    template <class T> bool again(T *dst, const T *staged, size_t count) {      // the same staged data to a second destination
+        if (n >= LD_XFER_MAX) return false;
+        if (count) { tab[n].dst = dst; tab[n].src = (size_t) (reinterpret_cast<const char *>(staged) - base); tab[n].words = count * sizeof(T) / 4; n++; }
+        return true;
+    }
+    template <class T> bool zero(T *dst, size_t count) {
+        if (n >= LD_XFER_MAX) return false;
+        if (count) { tab[n].dst = dst; tab[n].src = LD_XFER_ZERO; tab[n].words = count * sizeof(T) / 4; n++; }
+        return true;
+    }
+};
+
 template <class T> static int h2d(ldso_ba *H, T *dst, const std::vector<T> &src) {
     if (src.empty()) return LDSO_OK;
     CHK(hipMemcpyAsync(dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, H->stream));
@@ -233,6 +277,8 @@ int ldso_ba_destroy(ldso_ba_t *H) {
     for (void *p : H->allocs) hipFree(p);
     for (int i = 0; i < LD_MAXF; i++) if (H->imgOwned[i] && H->imgSlots[i]) hipFree(H->imgSlots[i]);
     if (H->d_color) hipFree(H->d_color);
+    if (H->h_stage) hipHostFree(H->h_stage);
+    if (H->d_stage) hipFree(H->d_stage);
     if (H->d_act) hipFree(H->d_act);
     if (H->distBuf) hipFree(H->distBuf);
     for (auto &t : H->timers) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
@@ -375,20 +421,46 @@ int ldso_ba_set_window(ldso_ba_t *H, int F, const int32_t *image_slot, int P, co
         B.img[f] = H->imgSlots[image_slot[f]];
     }
     const int FS = D.FS;
-    std::vector<float> pu(P), pv(P), pid(P), pidz(P), ppr(P), pcol((size_t) P * 8), pwt((size_t) P * 8);
+    const size_t PS = (size_t) P * FS;
+    // ---- staging arena: everything the window needs goes over PCIe in ONE copy and is distributed (or zero-filled) by ONE kernel ----
+    size_t nLin = 0;
+    for (int i = 0; i < R; i++) nLin += res[i].is_linearized ? 1 : 0;
+    REQ(nLin == 0 || (linJ && lin_rtz), "ldso_ba_set_window: linearised residual without linJ / lin_res_toZeroF");
+    auto A16 = [](size_t b) { return (b + 15) & ~(size_t) 15; };
+    const size_t tabBytes = A16(LD_XFER_MAX * sizeof(WinXfer));
+    const size_t need = tabBytes + 5 * A16((size_t) P * 4) + 2 * A16((size_t) P * 32) + A16((size_t) P * 4) + 4 * A16(PS * 4) + A16(nLin * sizeof(ldso_rawjac_t)) + A16(nLin * 32)
+                      + 3 * A16(PS * 4) + A16(PS * 32) + 64;
+    if (need > H->stageCap) {
+        CHK(hipStreamSynchronize(H->stream));
+        if (H->h_stage) hipHostFree(H->h_stage);
+        if (H->d_stage) hipFree(H->d_stage);
+        H->h_stage = nullptr; H->d_stage = nullptr; H->stageCap = 0;
+        const size_t cap = need + need / 4;
+        CHK(hipHostMalloc((void **) &H->h_stage, cap));
+        CHK(hipMalloc((void **) &H->d_stage, cap));
+        H->stageCap = cap;
+    }
+    WinStage W{H->h_stage, H->stageCap, tabBytes, reinterpret_cast<WinXfer *>(H->h_stage), 0};
+    float *pu = W.put(B.pu, P), *pv = W.put(B.pv, P), *pid = W.put(B.pidepth, P), *pidz = W.put(B.pidepth_zero, P), *ppr = W.put(B.ppriorF, P);
+    float *pcol = W.put(B.pcolor, (size_t) P * 8), *pwt = W.put(B.pweights, (size_t) P * 8);
+    int32_t *phost = W.put(B.phost, P);
+    int32_t *rflat = W.put(B.rflat, PS), *rlin = W.put(B.rlin, PS), *rnew = W.put(B.rnew, PS), *rlidx = W.put(B.rlidx, PS);
+    ldso_rawjac_t *Jl = W.put(B.Jlin, nLin);
+    float *rtz = W.put(B.rtz, nLin * 8);
+    int32_t *st = W.put(H->sets[0].state, PS), *act = W.put(H->sets[0].active, PS);
+    float *en = W.put(H->sets[0].energy, PS), *jp = W.put(H->sets[0].JpJdF, PS * 8);
+    REQ(pu && pv && pid && pidz && ppr && pcol && pwt && phost && rflat && rlin && rnew && rlidx && Jl && rtz && st && act && en && jp, "ldso_ba_set_window: staging arena too small (internal)");
     H->h_phost.resize(P);
     for (int i = 0; i < P; i++) {
         pu[i] = pts[i].u; pv[i] = pts[i].v; pid[i] = pts[i].idepth; pidz[i] = pts[i].idepth_zero; ppr[i] = pts[i].priorF;
         REQ(pts[i].host >= 0 && pts[i].host < F, "ldso_ba_set_window: point host out of range");
-        H->h_phost[i] = pts[i].host;
+        H->h_phost[i] = pts[i].host; phost[i] = pts[i].host;
         memcpy(&pcol[(size_t) i * 8], pts[i].color, 32); memcpy(&pwt[(size_t) i * 8], pts[i].weights, 32);
     }
-    const size_t PS = (size_t) P * FS;
-    std::vector<int32_t> rflat(PS, -1), rlin(PS, 0), rnew(PS, 0), rlidx(PS, -1), st(PS, LDSO_RES_OOB), act(PS, 0);
-    std::vector<float> en(PS, 0.f), jp(PS * 8, 0.f);
-    std::vector<ldso_rawjac_t> Jl;
-    std::vector<float> rtz;
+    for (size_t q = 0; q < PS; q++) { rflat[q] = -1; rlin[q] = 0; rnew[q] = 0; rlidx[q] = -1; st[q] = LDSO_RES_OOB; act[q] = 0; en[q] = 0.f; }
+    memset(jp, 0, PS * 8 * sizeof(float));
     H->flat2slot.assign(R, -1);
+    size_t nl = 0;
     for (int i = 0; i < R; i++) {
         const ldso_residual_t &r = res[i];
         REQ(r.point >= 0 && r.point < P && r.target >= 0 && r.target < F && r.host == pts[r.point].host && r.target != r.host, "ldso_ba_set_window: bad residual indices");
@@ -398,10 +470,10 @@ int ldso_ba_set_window(ldso_ba_t *H, int F, const int32_t *image_slot, int P, co
         st[slot] = r.state_state; act[slot] = r.is_active ? 1 : 0; en[slot] = r.state_energy;
         H->flat2slot[i] = (int32_t) slot;
         if (r.is_linearized) {
-            REQ(linJ && lin_rtz, "ldso_ba_set_window: linearised residual without linJ / lin_res_toZeroF");
-            rlidx[slot] = (int32_t) Jl.size();
-            Jl.push_back(linJ[i]);
-            for (int k = 0; k < 8; k++) rtz.push_back(lin_rtz[(size_t) i * 8 + k]);
+            rlidx[slot] = (int32_t) nl;
+            Jl[nl] = linJ[i];
+            for (int k = 0; k < 8; k++) rtz[nl * 8 + k] = lin_rtz[(size_t) i * 8 + k];
+            nl++;
             // takeData (Residuals.h:123-128)
             const ldso_rawjac_t &J = linJ[i];
             float v0 = J.JIdx2[0] * J.Jpdd[0] + J.JIdx2[1] * J.Jpdd[1], v1 = J.JIdx2[2] * J.Jpdd[0] + J.JIdx2[3] * J.Jpdd[1];
@@ -410,31 +482,24 @@ int ldso_ba_set_window(ldso_ba_t *H, int F, const int32_t *image_slot, int P, co
             jp[slot * 8 + 7] = J.JabJIdx[2] * J.Jpdd[0] + J.JabJIdx[3] * J.Jpdd[1];
         }
     }
-    D.nL = (int) Jl.size();
+    D.nL = (int) nLin;
     H->hasL = D.nL > 0;
-    H2D(B.pu, pu); H2D(B.pv, pv); H2D(B.pidepth, pid); H2D(B.pidepth_zero, pidz); H2D(B.pidepth_backup, pid); H2D(B.ppriorF, ppr);
-    H2D(B.pcolor, pcol); H2D(B.pweights, pwt); H2D(B.phost, H->h_phost);
-    H2D(B.rflat, rflat); H2D(B.rlin, rlin); H2D(B.rnew, rnew); H2D(B.rlidx, rlidx);
-    H2D(B.Jlin, Jl); H2D(B.rtz, rtz);
     H->cur = 0; H->pendingApply = false;
-    for (int s = 0; s < 2; s++) {
-        ResSet &S = H->sets[s];
-        H2D(S.state, st); H2D(S.active, act); H2D(S.energy, en); H2D(S.JpJdF, jp);
-        CHK(hipMemsetAsync(S.newEnergyWO, 0, PS * 4, H->stream));
-        CHK(hipMemsetAsync(S.center, 0, PS * 12, H->stream));
-        CHK(hipMemsetAsync(S.toRemove, 0, PS * 4, H->stream));
-        CHK(hipMemsetAsync(S.maxRelBS, 0, (size_t) P * 4, H->stream));
-        CHK(hipMemsetAsync(S.numGood, 0, (size_t) P * 4, H->stream));
-        CHK(hipMemsetAsync(S.nActive, 0, (size_t) P * 4, H->stream));
-        CHK(hipMemsetAsync(S.G, 0, (size_t) P * D.GS * 4, H->stream));
+    bool okT = W.again(B.pidepth_backup, pid, P);
+    okT = okT && W.again(H->sets[1].state, st, PS) && W.again(H->sets[1].active, act, PS) && W.again(H->sets[1].energy, en, PS) && W.again(H->sets[1].JpJdF, jp, PS * 8);
+    for (int s_ = 0; s_ < 2; s_++) {
+        ResSet &S = H->sets[s_];
+        okT = okT && W.zero(S.newEnergyWO, PS) && W.zero(S.center, PS * 3) && W.zero(S.toRemove, PS) && W.zero(S.maxRelBS, (size_t) P) && W.zero(S.numGood, (size_t) P)
+                  && W.zero(S.nActive, (size_t) P) && W.zero(S.G, (size_t) P * D.GS);
     }
-    CHK(hipMemsetAsync(B.pstep, 0, (size_t) P * 4, H->stream));
     // a new window has a new dimension 8F+4: the marginalisation prior starts at zero (ldso_ba_set_prior follows when there is one)
-    CHK(hipMemsetAsync(B.HM, 0, (size_t) D.n * D.n * 8, H->stream));
-    CHK(hipMemsetAsync(B.bM, 0, (size_t) D.n * 8, H->stream));
+    okT = okT && W.zero(B.pstep, (size_t) P) && W.zero(B.HM, (size_t) D.n * D.n) && W.zero(B.bM, (size_t) D.n) && W.zero(B.scalars, (size_t) 16)
+              && W.zero(B.scPart, (size_t) LD_SC_SPLITS * H->GSP * H->GSP);
+    REQ(okT, "ldso_ba_set_window: upload table overflow (internal)");
     H->hasPrior = false;
-    CHK(hipMemsetAsync(B.scalars, 0, 16 * 8, H->stream));
-    CHK(hipMemsetAsync(B.scPart, 0, (size_t) LD_SC_SPLITS * H->GSP * H->GSP * 4, H->stream));
+    CHK(hipMemcpyAsync(H->d_stage, H->h_stage, W.used, hipMemcpyHostToDevice, H->stream));
+    hipLaunchKernelGGL(k_win_scatter, dim3(256), dim3(256), 0, H->stream, (const char *) H->d_stage, W.n);
+    CHK(hipGetLastError());
     CHK(hipStreamSynchronize(H->stream));
     return build_chunks(H);
 }
