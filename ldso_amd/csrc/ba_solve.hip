@@ -37,7 +37,7 @@ static __device__ __forceinline__ double wave_sum(double v) {
 // ---------------------------------------------------------------------------------------------------------
 // setNewFrameEnergyTH: k-th smallest of the newest frame's residual energies by a 4-pass radix select
 // ---------------------------------------------------------------------------------------------------------
-static __device__ void post_sums(const BaPtrs &B, const BaDims &D, const ResSet &S, double *sD /*8 doubles*/) {
+static __device__ __forceinline__ void post_sums(const BaPtrs &B, const BaDims &D, const ResSet &S, double *sD /*8 doubles*/) {
     const int tid = threadIdx.x;
     // ---- energy sum + counters over the chunks, fixed order -----------------------------------------------
     {
@@ -63,7 +63,7 @@ static __device__ void post_sums(const BaPtrs &B, const BaDims &D, const ResSet 
 }
 
 // resInA / resInL of the accumulate that produced this set (EnergyFunctional.cc:558,573)
-static __device__ void res_counts(const BaPtrs &B, const BaDims &D, const ResSet &S, double *sD /*8 doubles*/) {
+static __device__ __forceinline__ void res_counts(const BaPtrs &B, const BaDims &D, const ResSet &S, double *sD /*8 doubles*/) {
     const int tid = threadIdx.x;
     double na = 0, nl = 0;
     for (int c = tid; c < D.nChunks; c += NT) { na += S.chunkCnt[c * 2]; nl += S.chunkCnt[c * 2 + 1]; }
@@ -77,7 +77,7 @@ static __device__ void res_counts(const BaPtrs &B, const BaDims &D, const ResSet
 // candidates: active-set residuals targeting the newest frame with state_NewEnergyWithOutlier >= 0,
 // written compactly by the linearize kernel (S.candE[p], -1 = no candidate).
 // extE (multi-GPU): all-reduced array of P doubles holding value+1 for candidates and 0 otherwise.
-static __device__ void post_thresh(const BaPtrs &B, const BaDims &D, const ResSet &S, const ldso_settings_t &St,
+static __device__ __forceinline__ void post_thresh(const BaPtrs &B, const BaDims &D, const ResSet &S, const ldso_settings_t &St,
                                    const double *extE, float *sVal /*LDS, TH_CAP floats*/, int *sHist /*256 ints*/, int *sI /*8 ints*/) {
     const int tid = threadIdx.x;
     const int F = D.F;
@@ -179,7 +179,7 @@ static __device__ __forceinline__ void aff_from_to(float expF, float expT, float
 }
 
 // setAdjointsF + nullspace basis U (n x 7, columns with dropped singular values zeroed)
-static __device__ void set_adjoints(const BaPtrs &B, const BaDims &D, const ldso_settings_t &St, double *sW /*LDS scratch >= 7*n + 64 doubles*/, bool withNullspace,
+static __device__ __forceinline__ void set_adjoints(const BaPtrs &B, const BaDims &D, const ldso_settings_t &St, double *sW /*LDS scratch >= 7*n + 64 doubles*/, bool withNullspace,
                                     double *sBig /*LDS >= 37 * F * F doubles (the solve-core region, idle here)*/) {
     const int tid = threadIdx.x, F = D.F, n = D.n;
     // (1) one lane per pair: Adj(T_t T_h^-1) at the evaluation points and the affine factor -> LDS
@@ -298,7 +298,7 @@ static __device__ __forceinline__ void canbreak_final(const BaPtrs &B, const lds
 // FULL = false (inside a GN iteration): the linearisation-point part of a pair (R0, t0, b0: functions of evalPT and
 // state_zero only) is left untouched.
 template <bool FULL>
-static __device__ void set_precalc(const BaPtrs &B, const BaDims &D, DevFrame *fr, DevCalib *cal, const float *adH, const float *adT,
+static __device__ __forceinline__ void set_precalc(const BaPtrs &B, const BaDims &D, DevFrame *fr, DevCalib *cal, const float *adH, const float *adT,
                                    const ldso_settings_t *cbSt = nullptr, float *cbF = nullptr, float cbNID = 0.0f, int cbIter = -1) {
     const int tid = threadIdx.x, F = D.F;
     DevCalib &C = *cal;
@@ -456,7 +456,7 @@ struct SolveIO {
 typedef double __attribute__((ext_vector_type(4))) ld_d4;
 
 template <int NB, int C, bool GN, bool WAIT = false, bool MF = false>
-static __device__ void solve_core(const BaPtrs &B, const BaDims &D, const ResSet &S, const ldso_settings_t &St, int iteration, double *sm, SolveIO &io) {
+static __device__ __forceinline__ void solve_core(const BaPtrs &B, const BaDims &D, const ResSet &S, const ldso_settings_t &St, int iteration, double *sm, SolveIO &io) {
     constexpr int M = 16 * NB;
     constexpr int CP = C + 2;      // row pitch of the panel buffers: 16-byte aligned rows, conflict-free 16-byte accesses at stride CP
     constexpr int NTILE = NB * (NB + 1) / 2;
@@ -834,7 +834,7 @@ _Pragma("unroll") \
 }
 
 template <bool GN, bool WAIT = false>
-static __device__ void solve_core_dispatch(const BaPtrs &B, const BaDims &D, const ResSet &S, const ldso_settings_t &St, int iteration, double *sm, SolveIO &io) {
+static __device__ __forceinline__ void solve_core_dispatch(const BaPtrs &B, const BaDims &D, const ResSet &S, const ldso_settings_t &St, int iteration, double *sm, SolveIO &io) {
     if (D.n + 1 <= 64) solve_core<4, 4, GN, WAIT, true>(B, D, S, St, iteration, sm, io);
     else if (D.n + 1 <= 112) solve_core<7, 4, GN, WAIT>(B, D, S, St, iteration, sm, io);
     else solve_core<9, 4, GN, WAIT>(B, D, S, St, iteration, sm, io);
@@ -847,7 +847,7 @@ static __device__ void frames_backup(DevFrame *fr, DevCalib *cal, int F) {
     if (tid == 0) for (int i = 0; i < 4; i++) cal->value_backup[i] = cal->value[i];
     __syncthreads();
 }
-static __device__ void frames_step(const BaPtrs &B, const ldso_settings_t &St, DevFrame *fr, DevCalib *cal, int F, float sumNID, double *sRed) {
+static __device__ __forceinline__ void frames_step(const BaPtrs &B, const ldso_settings_t &St, DevFrame *fr, DevCalib *cal, int F, float sumNID, double *sRed) {
     const int tid = threadIdx.x;
     if (tid < F) for (int i = 0; i < 10; i++) fr[tid].state[i] = fr[tid].state_backup[i] + fr[tid].step[i];
     if (tid == 0) for (int i = 0; i < 4; i++) cal->value[i] = cal->value_backup[i] + cal->step[i] * (double) 1.0f;
