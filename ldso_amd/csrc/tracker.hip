@@ -850,7 +850,7 @@ struct ldso_tracker {
     int ptsCap = 0;
     int *d_total = nullptr;
     double *d_T = nullptr, *d_acc = nullptr;
-    TrHyp *d_hyp = nullptr;
+    TrHyp *d_hyp = nullptr, *h_hyp = nullptr;      // device records, pinned staging copy (no pageable-memory detour on the per-track round trip)
     TrParams *d_P = nullptr, *h_P = nullptr, Pdev;   // device copy of P (what the kernels read), pinned staging buffer, what the device copy holds
     TrCoop *d_coop = nullptr;         // cooperative evaluation: one record per hypothesis
     int numCU = 256, coopSeq = 1;     // sequence numbers already used by earlier launches on d_coop
@@ -910,6 +910,7 @@ int ldso_tr_create(int device, int w, int h, int levels, ldso_tracker_t **out) {
     }
     TA(H->d_total, TR_MAXL); TA(H->d_T, 12); TA(H->d_acc, TR_NACC); TA(H->d_hyp, 128); TA(H->d_coop, 64); TA(H->d_P, 1);
     CHK(hipHostMalloc((void **) &H->h_P, sizeof(TrParams)));
+    CHK(hipHostMalloc((void **) &H->h_hyp, 128 * sizeof(TrHyp)));
     memset(&H->Pdev, 0xFF, sizeof(TrParams));
     { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0) H->numCU = pr.multiProcessorCount; }
     *out = H;
@@ -925,6 +926,7 @@ int ldso_tr_destroy(ldso_tracker_t *H) {
     if (H->d_next) hipFree(H->d_next);
     if (H->d_color) hipFree(H->d_color);
     if (H->h_P) hipHostFree(H->h_P);
+    if (H->h_hyp) hipHostFree(H->h_hyp);
     if (H->ownStream && H->stream) hipStreamDestroy(H->stream);
     delete H;
     return LDSO_OK;
@@ -1135,14 +1137,14 @@ int ldso_tr_track_batch(ldso_tracker_t *H, int nhyp, double *T_inout /*nhyp*12*/
                         double *lastResiduals /*nhyp*5*/, double *flow /*nhyp*3*/, int *ok /*nhyp*/, int *iterations /*nhyp*/) {
     REQ(H && nhyp >= 1 && nhyp <= 128 && T_inout && aff_inout && coarsestLvl >= 0 && coarsestLvl < 5 && coarsestLvl < H->levels, "ldso_tr_track: bad arguments");
     CHK(hipSetDevice(H->device));
-    std::vector<TrHyp> hy(nhyp);
+    TrHyp *hy = H->h_hyp;             // the stream is synchronised before this function returns: the buffer is free again
     for (int i = 0; i < nhyp; i++) {
         memset(&hy[i], 0, sizeof(TrHyp));
         memcpy(hy[i].T, T_inout + i * 12, 96);
         hy[i].a = aff_inout[2 * i]; hy[i].b = aff_inout[2 * i + 1]; hy[i].coarsestLvl = coarsestLvl;
         for (int k = 0; k < 5; k++) hy[i].minRes[k] = minRes ? minRes[k] : NAN;
     }
-    CHK(hipMemcpyAsync(H->d_hyp, hy.data(), nhyp * sizeof(TrHyp), hipMemcpyHostToDevice, H->stream));
+    CHK(hipMemcpyAsync(H->d_hyp, hy, nhyp * sizeof(TrHyp), hipMemcpyHostToDevice, H->stream));
     // few hypotheses: TR_GMAX workgroups share each of them on the large levels (all workgroups resident: nhyp * G <= CUs);
     // many hypotheses fill the chip by themselves
     { const int r_ = tr_sync_params(H); if (r_ != LDSO_OK) return r_; }
@@ -1157,7 +1159,7 @@ int ldso_tr_track_batch(ldso_tracker_t *H, int nhyp, double *T_inout /*nhyp*12*/
         hipLaunchKernelGGL(k_tr_track<1>, dim3(nhyp), dim3(TR_NT), 0, H->stream, H->d_P, H->d_hyp, (TrCoop *) nullptr, 0);
     }
     CHK(hipGetLastError());
-    CHK(hipMemcpyAsync(hy.data(), H->d_hyp, nhyp * sizeof(TrHyp), hipMemcpyDeviceToHost, H->stream));
+    CHK(hipMemcpyAsync(hy, H->d_hyp, nhyp * sizeof(TrHyp), hipMemcpyDeviceToHost, H->stream));
     CHK(hipStreamSynchronize(H->stream));
     for (int i = 0; i < nhyp; i++) {
         memcpy(T_inout + i * 12, hy[i].T, 96);
