@@ -880,13 +880,43 @@ __global__ __launch_bounds__(NT) void k_solve(BaPtrs B, BaDims D, ResSet S, ldso
     if (fl & SK_POST) post_sums(B, D, S, sW);
 
     if (fl & SK_REANCHOR) {
-        if (tid == 0) {
-            DevFrame &f = B.frames[F - 1];
-            for (int i = 0; i < 12; i++) f.evalPT[i] = f.PRE_w2c[i];
-            double a = f.state[6], b = f.state[7];
+        // FrameHessian::setEvalPT + setStateZero of the newest frame (FrameHessian.cc:12-42).  The numeric nullspaces are 14 independent
+        // exp / mul / mul / log chains (6 directions x +-eps, scale up / down): one lane each - the same operations as ld::frame_nullspaces
+        // (bit-identical), a fourteenth of its latency (it was 30 us of the 39 us tail on one lane)
+        DevFrame &f = B.frames[F - 1];
+        double *sLp = sW;                  // [14][6] logs
+        double *sEv = sW + 96;             // the new evalPT
+        if (tid < 12) sEv[tid] = f.PRE_w2c[tid];
+        __syncthreads();
+        if (tid < 14) {
+            double Ti[12], Am[12], Bm[12], lg[6];
+            ld::se3_inv(sEv, Ti);
+            if (tid < 12) {
+                double eps[6] = {0, 0, 0, 0, 0, 0}, E[12];
+                const double e_ = (tid & 1) ? -1e-3 : 1e-3;
+#pragma unroll
+                for (int q = 0; q < 6; q++) eps[q] = (q == (tid >> 1)) ? e_ : 0.0;
+                ld::se3_exp(eps, E); ld::se3_mul(sEv, E, Am); ld::se3_mul(Am, Ti, Bm); ld::se3_log(Bm, lg);
+            } else {
+                double Tp[12];
+                for (int i = 0; i < 12; i++) Tp[i] = sEv[i];
+                if (tid == 12) { for (int i = 0; i < 3; i++) Tp[i * 4 + 3] *= 1.00001; } else { for (int i = 0; i < 3; i++) Tp[i * 4 + 3] /= 1.00001; }
+                ld::se3_mul(Tp, Ti, Am); ld::se3_log(Am, lg);
+            }
+#pragma unroll
+            for (int r = 0; r < 6; r++) sLp[tid * 6 + r] = lg[r];
+        }
+        __syncthreads();
+        if (tid < 36) { const int r = tid / 6, i = tid % 6; f.ns_pose[r * 6 + i] = (sLp[(2 * i) * 6 + r] - sLp[(2 * i + 1) * 6 + r]) / 2e-3; }
+        else if (tid < 42) { const int r = tid - 36; f.ns_scale[r] = (sLp[12 * 6 + r] - sLp[13 * 6 + r]) / 2e-3; }
+        else if (tid < 54) f.evalPT[tid - 42] = sEv[tid - 42];
+        else if (tid == 54) {
+            const double a = f.state[6], b = f.state[7];
             for (int i = 0; i < 10; i++) { f.state[i] = 0; f.state_zero[i] = 0; }
             f.state[6] = a; f.state[7] = b; f.state_zero[6] = a; f.state_zero[7] = b;
-            frame_nullspaces(f);
+            for (int i = 0; i < 8; i++) f.ns_affine[i] = 0;
+            f.ns_affine[0] = 1;
+            f.ns_affine[3] = (double) (expf((float) (a * 10.0)) * f.ab_exposure);
         }
         __syncthreads();
     }
