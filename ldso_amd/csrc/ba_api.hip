@@ -81,6 +81,7 @@ struct ldso_ba {
     // host staging of the window (for shard rebuilds)
     std::vector<int32_t> h_phost;
     // window upload: ONE pinned staging arena -> ONE device arena -> one scatter kernel (k_win_scatter) instead of ~25 copies + ~20 fills
+    int *h_stop = nullptr, *d_stop = nullptr;      // host-mapped word (and its device address): which iteration ended an un-forced optimize() loop
     char *h_stage = nullptr, *d_stage = nullptr;
     size_t stageCap = 0;
     // profiling
@@ -241,6 +242,8 @@ static int create_body(ldso_ba *H, int device, int w, int h, int max_frames, int
     ldso_settings_default(&H->settings);
     CHK(hipStreamCreateWithFlags(&H->stream, hipStreamNonBlocking));
     H->ownStream = true;
+    CHK(hipHostMalloc((void **) &H->h_stop, 4 * sizeof(int), hipHostMallocMapped));
+    CHK(hipHostGetDevicePointer((void **) &H->d_stop, H->h_stop, 0));
     memset(&H->B, 0, sizeof(H->B));
     memset(&H->D, 0, sizeof(H->D));
     BaPtrs &B = H->B;
@@ -277,6 +280,7 @@ int ldso_ba_destroy(ldso_ba_t *H) {
     for (void *p : H->allocs) hipFree(p);
     for (int i = 0; i < LD_MAXF; i++) if (H->imgOwned[i] && H->imgSlots[i]) hipFree(H->imgSlots[i]);
     if (H->d_color) hipFree(H->d_color);
+    if (H->h_stop) hipHostFree(H->h_stop);
     if (H->h_stage) hipHostFree(H->h_stage);
     if (H->d_stage) hipFree(H->d_stage);
     if (H->d_act) hipFree(H->d_act);
@@ -569,7 +573,7 @@ static void t_end(ldso_ba *H) { if (H->profile) hipEventRecord(H->timers.back().
 
 static int launch_solve(ldso_ba *H, const ResSet &S, unsigned flags, int iteration, double lambda, int logIdx, double *rout, const double *rin) {
     SolveArgs A;
-    A.flags = flags; A.iteration = iteration; A.lambda = lambda; A.hasL = H->hasL ? 1 : 0; A.hasPrior = H->hasPrior ? 1 : 0; A.GSP = H->GSP; A.logIdx = logIdx; A.reduceOut = rout; A.reduceIn = rin; A.itCheck = -1; A.waitCtr = nullptr; A.waitTarget = 0;
+    A.flags = flags; A.iteration = iteration; A.lambda = lambda; A.hasL = H->hasL ? 1 : 0; A.hasPrior = H->hasPrior ? 1 : 0; A.GSP = H->GSP; A.logIdx = logIdx; A.reduceOut = rout; A.reduceIn = rin; A.itCheck = -1; A.waitCtr = nullptr; A.waitTarget = 0; A.hostStop = nullptr; A.lastIt = -1;
     t_begin(H, 2);
     CHK(ba_launch_solve(H->B, H->D, S, H->settings, A, H->stream));
     t_end(H);
@@ -737,7 +741,7 @@ int ldso_ba_load_state_backup(ldso_ba_t *H) {
 
 // one GN iteration = solveSystem + doStepFromBackup + linearizeAll(false) + applyRes: 4 launches (k_reduce, k_gather,
 // k_gn_solve, k_linearize with the point step fused in), no host sync
-static int enqueue_iteration(ldso_ba *H, int iteration, double lambda, int logIdx, bool postOfPrev, int itCheck = -1) {
+static int enqueue_iteration(ldso_ba *H, int iteration, double lambda, int logIdx, bool postOfPrev, int itCheck = -1, int lastIt = -1) {
     const ResSet &S = H->sets[H->cur];
     if (H->B.acc != H->ownAcc) {      // the accumulator was lent to an all-reduce buffer: take it back (and re-initialise)
         H->B.acc = H->ownAcc;
@@ -747,7 +751,7 @@ static int enqueue_iteration(ldso_ba *H, int iteration, double lambda, int logId
     (void) postOfPrev;
     SolveArgs A;
     A.flags = 0; A.iteration = iteration; A.lambda = lambda; A.hasL = H->hasL ? 1 : 0; A.hasPrior = H->hasPrior ? 1 : 0; A.GSP = H->GSP; A.logIdx = logIdx;
-    A.reduceOut = nullptr; A.reduceIn = nullptr; A.itCheck = itCheck; A.waitCtr = nullptr; A.waitTarget = 0;
+    A.reduceOut = nullptr; A.reduceIn = nullptr; A.itCheck = itCheck; A.waitCtr = nullptr; A.waitTarget = 0; A.hostStop = (itCheck >= 0) ? H->d_stop : nullptr; A.lastIt = lastIt;
     const int nT = H->GSP / 16;
     const int nReduce = H->D.F * H->D.F * (H->hasL ? 2 : 1) + LD_SCT_KS * nT * (nT + 1) / 2 + 1;      // grid of ba_launch_reduce in atomic mode
     if (nReduce + 2 <= H->numCU && !H->noFusedLaunch) {
@@ -874,16 +878,33 @@ int ldso_ba_optimize(ldso_ba_t *H, int mnumOptIts, int force_all, float *rmse_ou
     {   // no iteration has asked to stop yet
         CHK(hipMemcpyAsync(H->B.scalars + LD_SC_STOP, &H->neverStop, sizeof(double), hipMemcpyHostToDevice, H->stream));
     }
+    volatile int *stopWord = H->h_stop;
+    *stopWord = -1;
     for (int it = 0; it < mnumOptIts; it++) {
         // un-forced: the device decides (canbreak && it >= minOptIterations, FullSystem.cc:829); later iterations become no-ops
-        RUN(enqueue_iteration(H, it, lambda, it, true, force_all ? -1 : it));    // POST/THRESH/LOG of the previous linearize ride along
+        RUN(enqueue_iteration(H, it, lambda, it, true, force_all ? -1 : it, mnumOptIts - 1));    // POST/THRESH/LOG of the previous linearize ride along
         lambda *= 0.25;
     }
     done = mnumOptIts;
-    if (!force_all) {
-        double sc[16];
-        RUN(read_scalars(H, sc));                   // ONE host round trip for the whole loop
-        if (sc[LD_SC_STOP] < (double) mnumOptIts) done = (int) sc[LD_SC_STOP] + 1;
+    if (!force_all && mnumOptIts > 0) {
+        // The control step of the iteration that ends the loop writes its index into a host-mapped word: the host learns `done` while the
+        // GPU is still busy and enqueues the tail right behind the iterations that turned into no-ops (no stream synchronisation, which
+        // cost a 40 us bubble).  The stream is polled as well so that a failed launch cannot hang the caller.
+        int spins = 0;
+        while (*stopWord < 0) {
+            if ((++spins & 0x3FF) == 0) {
+                const hipError_t q = hipStreamQuery(H->stream);
+                if (q == hipSuccess) break;                         // everything ran: the word is final (or the loop never reported)
+                if (q != hipErrorNotReady) CHK(q);
+            }
+        }
+        int stopIt = *stopWord;
+        if (stopIt < 0) {                                           // not reported (cannot happen on a healthy run): fall back to the device scalar
+            double sc[16];
+            RUN(read_scalars(H, sc));
+            stopIt = (sc[LD_SC_STOP] < (double) mnumOptIts) ? (int) sc[LD_SC_STOP] : mnumOptIts - 1;
+        }
+        done = stopIt + 1;
         if ((mnumOptIts - done) & 1) H->cur ^= 1;   // the skipped iterations never wrote / applied a residual set
     }
     // tail: statistics of the last linearize, re-anchor the newest frame, adjoints, precalc, linearizeAll(true)
@@ -971,7 +992,7 @@ int ldso_ba_gn_solve_reduced(ldso_ba_t *H, const void *buf, int iteration, doubl
     const size_t n = H->D.n;
     SolveArgs A;
     A.flags = 0; A.iteration = iteration; A.lambda = lambda; A.hasL = H->hasL ? 1 : 0; A.hasPrior = H->hasPrior ? 1 : 0; A.GSP = H->GSP; A.logIdx = -1;
-    A.reduceOut = nullptr; A.reduceIn = (const double *) buf + n * n + n; A.itCheck = -1; A.waitCtr = nullptr; A.waitTarget = 0;
+    A.reduceOut = nullptr; A.reduceIn = (const double *) buf + n * n + n; A.itCheck = -1; A.waitCtr = nullptr; A.waitTarget = 0; A.hostStop = nullptr; A.lastIt = -1;
     t_begin(H, 2);
     CHK(ba_launch_gn_solve(H->B, H->D, S, H->settings, A, H->stream));
     t_end(H);

@@ -23,4 +23,6 @@ struct SolveArgs {
     int itCheck;                // k_gn_solve: >= 0 = un-forced optimize(): iteration index for the device-side `canbreak` early exit
     int *waitCtr;               // k_reduce_solve: counter the reduce workgroups of the same launch increment when their sums are in B.acc
     int waitTarget;             //                 ... and its value when all of them are done (0 / nullptr: no wait)
+    int *hostStop;              // un-forced optimize(): host-mapped word that receives the index of the iteration that ended the loop (canbreak, or the
+    int lastIt;                 //                       last enqueued iteration lastIt) as soon as the device knows it - no stream synchronisation
 };

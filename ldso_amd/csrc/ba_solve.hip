@@ -299,7 +299,7 @@ static __device__ __forceinline__ void canbreak_final(const BaPtrs &B, const lds
 // state_zero only) is left untouched.
 template <bool FULL>
 static __device__ __forceinline__ void set_precalc(const BaPtrs &B, const BaDims &D, DevFrame *fr, DevCalib *cal, const float *adH, const float *adT,
-                                   const ldso_settings_t *cbSt = nullptr, float *cbF = nullptr, float cbNID = 0.0f, int cbIter = -1) {
+                                   const ldso_settings_t *cbSt = nullptr, float *cbF = nullptr, float cbNID = 0.0f, int cbIter = -1, int *hostStop = nullptr, int lastIt = -1) {
     const int tid = threadIdx.x, F = D.F;
     DevCalib &C = *cal;
     if (cbF != nullptr) canbreak_partial(fr, F, cbF);
@@ -324,6 +324,10 @@ static __device__ __forceinline__ void set_precalc(const BaPtrs &B, const BaDims
         canbreak_final(B, *cbSt, cbF, cbNID);
         // un-forced optimize(): end the loop after this iteration (FullSystem.cc:829)
         if (cbIter >= 0 && B.scalars[3] != 0.0 && cbIter >= cbSt->minOptIterations && (double) cbIter < B.scalars[LD_SC_STOP]) B.scalars[LD_SC_STOP] = (double) cbIter;
+        // tell the host at once which iteration ended the loop (it then enqueues the tail behind the iterations that turn into no-ops
+        // instead of synchronising with the stream first); iterations after the stop return at their first instruction and never get here
+        if (hostStop != nullptr && cbIter >= 0 && (B.scalars[LD_SC_STOP] == (double) cbIter || cbIter == lastIt))
+            __hip_atomic_store(hostStop, cbIter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     for (int i = tid; i < F * F; i += NT) {
         const int h = i / F, t = i % F;
@@ -1005,7 +1009,7 @@ static __device__ __forceinline__ void gn_solve_body(const BaPtrs &B, const BaDi
     solve_core_dispatch<true, WAIT>(B, D, S, St, A.iteration, sm, io);      // + mirrors, backupState, doStepFromBackup
     GSTAMP(4);
     GSTAMP(5);
-    set_precalc<false>(B, D, sFr, sCal, io.adH, io.adT, &St, (float *) (sW + 8), io.sumNID, A.itCheck);      // + canbreak of doStepFromBackup
+    set_precalc<false>(B, D, sFr, sCal, io.adH, io.adT, &St, (float *) (sW + 8), io.sumNID, A.itCheck, A.hostStop, A.lastIt);      // + canbreak of doStepFromBackup
     GSTAMP(6);
     // write the mirrors back (all but frameEnergyTH, which block 1 owns)
     {
@@ -1070,7 +1074,7 @@ __global__ __launch_bounds__(NT) void k_gn_solve_batch(const BatchItem *__restri
     const BatchItem &it = items[blockIdx.x >> 1];
     SolveArgs A;
     A.flags = 0; A.iteration = iteration; A.lambda = lambda; A.hasL = 0; A.hasPrior = it.hasPrior; A.GSP = it.GSP; A.logIdx = -1;
-    A.reduceOut = nullptr; A.reduceIn = nullptr; A.itCheck = -1; A.waitCtr = nullptr; A.waitTarget = 0;
+    A.reduceOut = nullptr; A.reduceIn = nullptr; A.itCheck = -1; A.waitCtr = nullptr; A.waitTarget = 0; A.hostStop = nullptr; A.lastIt = -1;
     gn_solve_body<false>(it.B, it.D, it.set[cur], St, A, (int) (blockIdx.x & 1));
 }
 
