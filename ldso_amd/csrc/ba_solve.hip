@@ -33,6 +33,26 @@ static __device__ __forceinline__ double wave_sum(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// the same sum over the 64 lanes through DPP row operations + four v_readlane (a dependent ds_bpermute costs 30 ns, a DPP step 7 ns):
+// for the serial chains that are made of wave sums (the one-sided Jacobi of the nullspace basis)
+template <int CTRL> static __device__ __forceinline__ double dpp_f64(double v) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned) __builtin_amdgcn_update_dpp(0, (int) (u & 0xFFFFFFFFu), CTRL, 0xF, 0xF, true);
+    const unsigned hi = (unsigned) __builtin_amdgcn_update_dpp(0, (int) (u >> 32), CTRL, 0xF, 0xF, true);
+    return __builtin_bit_cast(double, ((unsigned long long) hi << 32) | lo);
+}
+static __device__ __forceinline__ double readlane_d(double v, int lane) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned) __builtin_amdgcn_readlane((int) (u & 0xFFFFFFFFu), lane), hi = (unsigned) __builtin_amdgcn_readlane((int) (u >> 32), lane);
+    return __builtin_bit_cast(double, ((unsigned long long) hi << 32) | lo);
+}
+static __device__ __forceinline__ double wave_sum_dpp(double v) {
+    v += dpp_f64<0xB1>(v);       // quad_perm [1,0,3,2]
+    v += dpp_f64<0x4E>(v);       // quad_perm [2,3,0,1]
+    v += dpp_f64<0x141>(v);      // row_half_mirror
+    v += dpp_f64<0x140>(v);      // row_mirror: every lane holds the sum of its 16-lane row
+    return (readlane_d(v, 0) + readlane_d(v, 16)) + (readlane_d(v, 32) + readlane_d(v, 48));
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // setNewFrameEnergyTH: k-th smallest of the newest frame's residual energies by a 4-pass radix select
@@ -234,7 +254,7 @@ static __device__ __forceinline__ void set_adjoints(const BaPtrs &B, const BaDim
         for (int c = 0; c < 7; c++) {
             double s = 0;
             for (int r = lane; r < n; r += 64) s += N[c * n + r] * N[c * n + r];
-            s = sqrt(wave_sum(s));
+            s = sqrt(wave_sum_dpp(s));
             for (int r = lane; r < n; r += 64) N[c * n + r] /= s;
         }
         for (int sweep = 0; sweep < 30; sweep++) {
@@ -243,7 +263,7 @@ static __device__ __forceinline__ void set_adjoints(const BaPtrs &B, const BaDim
                 for (int q = p + 1; q < 7; q++) {
                     double al = 0, be = 0, ga = 0;
                     for (int r = lane; r < n; r += 64) { double a = N[p * n + r], b = N[q * n + r]; al += a * a; be += b * b; ga += a * b; }
-                    al = wave_sum(al); be = wave_sum(be); ga = wave_sum(ga);
+                    al = wave_sum_dpp(al); be = wave_sum_dpp(be); ga = wave_sum_dpp(ga);
                     if (ga == 0) continue;
                     off = fmax(off, fabs(ga) / sqrt(al * be + 1e-300));
                     double zeta = (be - al) / (2 * ga);
@@ -257,7 +277,7 @@ static __device__ __forceinline__ void set_adjoints(const BaPtrs &B, const BaDim
         for (int c = 0; c < 7; c++) {
             double s = 0;
             for (int r = lane; r < n; r += 64) s += N[c * n + r] * N[c * n + r];
-            sv[c] = sqrt(wave_sum(s));
+            sv[c] = sqrt(wave_sum_dpp(s));
             maxSv = fmax(maxSv, sv[c]);
         }
         for (int c = 0; c < 7; c++) {
