@@ -185,7 +185,7 @@ hipError_t ba_launch_marg_update(const BaPtrs &B, const BaDims &D, double w, hip
 __global__ __launch_bounds__(256) void k_marg_frame(BaPtrs B, BaDims D, int idx, double *W, double *outH, double *outb) {
     const int tid = threadIdx.x, n = D.n, nd = n - 8;
     double *Hs = W, *bs = W + (size_t) n * n;
-    __shared__ double sSV[8 * LD_MAXF + 4], sHpi[64], sLU[64], sBli[8];
+    __shared__ double sSV[8 * LD_MAXF + 4], sHpi[64], sLU[64], sBLI[(8 * LD_MAXF + 4) * 8];
     __shared__ int sPiv[8];
     auto perm = [&](int i) { const int io = 4 + 8 * idx; return (i < io) ? i : (i < nd) ? i + 8 : io + (i - nd); };
     // permuted copy + the frame's prior on its (now trailing) diagonal block
@@ -234,16 +234,23 @@ __global__ __launch_bounds__(256) void k_marg_frame(BaPtrs B, BaDims D, int idx,
     if (tid < 64) sHpi[tid] = hsym;
     __syncthreads();
     // Schur complement of the trailing block: row i of the result needs bli[i][:] = sum_k Hs[nd+k][i] hpi[k][:]
-    for (int i = 0; i < nd; i++) {
-        if (tid < 8) { double s_ = 0; for (int k = 0; k < 8; k++) s_ += Hs[(size_t) (nd + k) * n + i] * sHpi[k * 8 + tid]; sBli[tid] = s_; }
-        __syncthreads();
-        for (int j = tid; j <= nd; j += 256) {
-            double s_ = 0;
-            if (j < nd) { for (int k = 0; k < 8; k++) s_ += sBli[k] * Hs[(size_t) (nd + k) * n + j]; Hs[(size_t) i * n + j] -= s_; }
-            else { for (int k = 0; k < 8; k++) s_ += sBli[k] * bs[nd + k]; bs[i] -= s_; }
-        }
-        __syncthreads();
+    // (the trailing rows nd.. are only read: all rows of bli first, then every entry of the result on its own thread - the same sums in
+    // the same order as the row-by-row loop, without its 2 nd barriers)
+    for (int e = tid; e < nd * 8; e += 256) {
+        const int i = e >> 3, c = e & 7;
+        double s_ = 0;
+        for (int k = 0; k < 8; k++) s_ += Hs[(size_t) (nd + k) * n + i] * sHpi[k * 8 + c];
+        sBLI[e] = s_;
     }
+    __syncthreads();
+    for (int e = tid; e < nd * (nd + 1); e += 256) {
+        const int i = e / (nd + 1), j = e % (nd + 1);
+        const double *bl = sBLI + i * 8;
+        double s_ = 0;
+        if (j < nd) { for (int k = 0; k < 8; k++) s_ += bl[k] * Hs[(size_t) (nd + k) * n + j]; Hs[(size_t) i * n + j] -= s_; }
+        else { for (int k = 0; k < 8; k++) s_ += bl[k] * bs[nd + k]; bs[i] -= s_; }
+    }
+    __syncthreads();
     // unscale and symmetrise
     for (int e = tid; e < nd * nd; e += 256) {
         const int i = e / nd, j = e % nd;

@@ -3,7 +3,7 @@
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/optprof
 rm -rf "$OUT"; mkdir -p "$OUT"
-rocprofv3 --kernel-trace -d "$OUT" -o opt --output-format csv -- python scripts/time_optimize.py > "$OUT/run.log" 2>&1
+rocprofv3 --kernel-trace -d "$OUT" -o opt --output-format csv -- python ${SCRIPT:-scripts/time_optimize.py} > "$OUT/run.log" 2>&1
 python - <<PY
 import csv, glob
 f = sorted(glob.glob("$OUT/**/opt_kernel_trace.csv", recursive=True))
