@@ -1008,26 +1008,36 @@ int ldso_ba_gn_solve_reduced(ldso_ba_t *H, const void *buf, int iteration, doubl
 // chunks).  Per-window arithmetic is exactly that of ldso_ba_enqueue_gn's split schedule; the windows only share the launches.
 struct ldso_ba_batch {
     std::vector<ldso_ba *> h;
-    BatchItem *d_items = nullptr;
+    BatchItem *d_items = nullptr;      // [n] numbered over the whole batch, then [n] numbered per half (see ldso_ba_batch_enqueue_gn)
     std::vector<BatchItem> items;
     int totalChunks = 0, totalReduce = 0, FS = 0, cur = 0;
+    int n0 = 0;                        // windows in the first half (= all of them for batches under 4 windows)
+    int halfChunks[2] = {0, 0}, halfReduce[2] = {0, 0};
+    hipStream_t aux = nullptr;         // second stream: the two halves run half an iteration apart
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, evEnd = nullptr;
     BaDims Dmax;
 };
 
 static int batch_refresh(ldso_ba_batch *Bt) {
-    int lin = 0, red = 0;
     ldso_ba *H0 = Bt->h[0];
-    for (size_t i = 0; i < Bt->h.size(); i++) {
-        ldso_ba *H = Bt->h[i];
-        BatchItem &it = Bt->items[i];
-        if (H->B.acc != H->ownAcc) H->B.acc = H->ownAcc;
-        it.B = H->B; it.D = H->D; it.set[0] = H->sets[0]; it.set[1] = H->sets[1]; it.cs = H->chunkStarts;
-        it.hasPrior = H->hasPrior ? 1 : 0; it.GSP = H->GSP; it.linBlock0 = lin; it.redBlock0 = red;
-        const int nT = H->GSP / 16;
-        lin += H->D.nChunks;
-        red += H->D.F * H->D.F + LD_SCT_KS * nT * (nT + 1) / 2 + 1;
+    const size_t n = Bt->h.size();
+    for (int pass = 0; pass < 2; pass++) {          // pass 0: blocks numbered over the whole batch; pass 1: per half
+        int lin = 0, red = 0;
+        for (size_t i = 0; i < n; i++) {
+            ldso_ba *H = Bt->h[i];
+            BatchItem &it = Bt->items[pass * n + i];
+            if (pass == 1 && (int) i == Bt->n0) { Bt->halfChunks[0] = lin; Bt->halfReduce[0] = red; lin = 0; red = 0; }
+            if (H->B.acc != H->ownAcc) H->B.acc = H->ownAcc;
+            it.B = H->B; it.D = H->D; it.set[0] = H->sets[0]; it.set[1] = H->sets[1]; it.cs = H->chunkStarts;
+            it.hasPrior = H->hasPrior ? 1 : 0; it.GSP = H->GSP; it.linBlock0 = lin; it.redBlock0 = red;
+            const int nT = H->GSP / 16;
+            lin += H->D.nChunks;
+            red += H->D.F * H->D.F + LD_SCT_KS * nT * (nT + 1) / 2 + 1;
+        }
+        if (pass == 0) { Bt->totalChunks = lin; Bt->totalReduce = red; }
+        else if (Bt->n0 == (int) n) { Bt->halfChunks[0] = lin; Bt->halfReduce[0] = red; Bt->halfChunks[1] = 0; Bt->halfReduce[1] = 0; }
+        else { Bt->halfChunks[1] = lin; Bt->halfReduce[1] = red; }
     }
-    Bt->totalChunks = lin; Bt->totalReduce = red;
     CHK(hipMemcpyAsync(Bt->d_items, Bt->items.data(), Bt->items.size() * sizeof(BatchItem), hipMemcpyHostToDevice, H0->stream));
     return LDSO_OK;
 }
@@ -1048,13 +1058,20 @@ int ldso_ba_batch_create(ldso_ba_t *const *handles, int n, ldso_ba_batch_t **out
     CHK(hipSetDevice(H0->device));
     ldso_ba_batch *Bt = new ldso_ba_batch();
     Bt->h.assign(handles, handles + n);
-    Bt->items.resize(n);
+    Bt->items.resize(2 * (size_t) n);
+    Bt->n0 = (n >= 4) ? n / 2 : n;
     Bt->FS = H0->D.FS;
     Bt->Dmax = H0->D;
     for (int i = 0; i < n; i++) if (handles[i]->D.F > Bt->Dmax.F) Bt->Dmax = handles[i]->D;
     void *q = nullptr;
-    if (hipMalloc(&q, (size_t) n * sizeof(BatchItem)) != hipSuccess) { delete Bt; ldso_set_error("ldso_ba_batch_create: hipMalloc failed"); return LDSO_E_HIP; }
+    if (hipMalloc(&q, 2 * (size_t) n * sizeof(BatchItem)) != hipSuccess) { delete Bt; ldso_set_error("ldso_ba_batch_create: hipMalloc failed"); return LDSO_E_HIP; }
     Bt->d_items = (BatchItem *) q;
+    if (Bt->n0 < n) {
+        if (hipStreamCreateWithFlags(&Bt->aux, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&Bt->ev0, hipEventDisableTiming) != hipSuccess
+            || hipEventCreateWithFlags(&Bt->ev1, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&Bt->evEnd, hipEventDisableTiming) != hipSuccess) {
+            ldso_ba_batch_destroy(Bt); ldso_set_error("ldso_ba_batch_create: stream / event creation failed"); return LDSO_E_HIP;
+        }
+    }
     *out = Bt;
     return LDSO_OK;
 }
@@ -1063,6 +1080,10 @@ int ldso_ba_batch_destroy(ldso_ba_batch_t *Bt) {
     if (!Bt) return LDSO_OK;
     hipSetDevice(Bt->h[0]->device);
     hipStreamSynchronize(Bt->h[0]->stream);
+    if (Bt->aux) { hipStreamSynchronize(Bt->aux); hipStreamDestroy(Bt->aux); }
+    if (Bt->ev0) hipEventDestroy(Bt->ev0);
+    if (Bt->ev1) hipEventDestroy(Bt->ev1);
+    if (Bt->evEnd) hipEventDestroy(Bt->evEnd);
     if (Bt->d_items) hipFree(Bt->d_items);
     delete Bt;
     return LDSO_OK;
@@ -1082,12 +1103,24 @@ int ldso_ba_batch_enqueue_gn(ldso_ba_batch_t *Bt, int first_iteration, int iters
     if (H0->settings.solverMode & LDSO_SOLVER_FIX_LAMBDA) lam = 1e-5;
     const double l1 = 1 + lam, il = (double) (1.0f / (1 + lam));
     int cur = H0->cur;
+    // The control step of a batch occupies two workgroups per window for ~30 us: the batch runs as two halves on two streams, the second
+    // half an iteration behind the first, so that one half's reduce + control step overlap the other half's (chip-filling) linearisation.
+    const int n = (int) Bt->h.size(), n0 = Bt->n0, n1 = n - n0;
+    const BatchItem *itA = Bt->d_items + n, *itB = Bt->d_items + n + n0;
+    if (n1 > 0 && iters > 0) { CHK(hipEventRecord(Bt->ev0, H0->stream)); CHK(hipStreamWaitEvent(Bt->aux, Bt->ev0, 0)); }
     for (int i = 0; i < iters; i++) {
-        CHK(ba_launch_reduce_batch(Bt->d_items, (int) Bt->h.size(), Bt->totalReduce, cur, H0->settings.initialCalibHessian, l1, il, H0->stream));
-        CHK(ba_launch_gn_solve_batch(Bt->d_items, (int) Bt->h.size(), Bt->Dmax, cur, H0->settings, first_iteration + i, 1e-1, H0->stream));
-        CHK(ba_launch_linearize_batch(Bt->d_items, (int) Bt->h.size(), Bt->totalChunks, Bt->FS, cur, H0->settings, 1, H0->settings.initialCalibHessian, H0->stream));
+        CHK(ba_launch_reduce_batch(itA, n0, Bt->halfReduce[0], cur, H0->settings.initialCalibHessian, l1, il, H0->stream));
+        CHK(ba_launch_gn_solve_batch(itA, n0, Bt->Dmax, cur, H0->settings, first_iteration + i, 1e-1, H0->stream));
+        if (n1 > 0 && i == 0) { CHK(hipEventRecord(Bt->ev1, H0->stream)); CHK(hipStreamWaitEvent(Bt->aux, Bt->ev1, 0)); }
+        CHK(ba_launch_linearize_batch(itA, n0, Bt->halfChunks[0], Bt->FS, cur, H0->settings, 1, H0->settings.initialCalibHessian, H0->stream));
+        if (n1 > 0) {
+            CHK(ba_launch_reduce_batch(itB, n1, Bt->halfReduce[1], cur, H0->settings.initialCalibHessian, l1, il, Bt->aux));
+            CHK(ba_launch_gn_solve_batch(itB, n1, Bt->Dmax, cur, H0->settings, first_iteration + i, 1e-1, Bt->aux));
+            CHK(ba_launch_linearize_batch(itB, n1, Bt->halfChunks[1], Bt->FS, cur, H0->settings, 1, H0->settings.initialCalibHessian, Bt->aux));
+        }
         cur ^= 1;
     }
+    if (n1 > 0 && iters > 0) { CHK(hipEventRecord(Bt->evEnd, Bt->aux)); CHK(hipStreamWaitEvent(H0->stream, Bt->evEnd, 0)); }      // ldso_ba_sync(handle) covers both halves
     for (ldso_ba *H : Bt->h) H->cur = cur;
     return LDSO_OK;
 }

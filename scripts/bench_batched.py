@@ -1,0 +1,7 @@
+"""bench.py's batched-windows line alone (B = 8, 32).  Run on the GPU box."""
+import sys, json
+sys.path.insert(0, '.')
+import bench, argparse
+ap = argparse.ArgumentParser(); ap.add_argument("--steps", type=int, default=100); ap.add_argument("--warmup", type=int, default=10); ap.add_argument("--no-prior", action="store_true")
+args = ap.parse_args()
+print(json.dumps(bench.batched_line(args, 0)))
