@@ -33,7 +33,7 @@ hipError_t ba_launch_acc_init(const BaPtrs &B, const BaDims &D, const GnInit &gi
 hipError_t ba_launch_gn_export(const BaPtrs &B, const BaDims &D, const ResSet &S, double *tail, hipStream_t st);
 hipError_t ba_launch_activate(const BaPtrs &B, const BaDims &D, const ldso_settings_t &S, const ldso_immature_t *d_pts, ldso_activation_t *d_out, int n, int minObs,
                               float minIdepthH_act, int GNIts, hipStream_t st);
-hipError_t ba_launch_linearize_batch(const BatchItem *d_items, int nWin, int totalChunks, int FS, int cur, const ldso_settings_t &S, int stepMode, float calibPrior, hipStream_t st);
+hipError_t ba_launch_linearize_batch(const BatchItem *d_items, int nWin, int totalChunks, int FS, int cur, const ldso_settings_t &S, int stepMode, float calibPrior, hipStream_t st, int itCheck = -1);
 hipError_t ba_launch_reduce_batch(const BatchItem *d_items, int nWin, int totalBlocks, int cur, float calibPrior, double l1, double il, hipStream_t st);
 hipError_t ba_launch_gn_solve_batch(const BatchItem *d_items, int nWin, const BaDims &Dmax, int cur, const ldso_settings_t &St, int iteration, double lambda, hipStream_t st);
 hipError_t ba_launch_lm_energies(const BaPtrs &B, const BaDims &D, const ResSet &S, float calibPrior, bool hasPrior, hipStream_t st);
@@ -81,6 +81,11 @@ struct ldso_ba {
     // host staging of the window (for shard rebuilds)
     std::vector<int32_t> h_phost;
     // window upload: ONE pinned staging arena -> ONE device arena -> one scatter kernel (k_win_scatter) instead of ~25 copies + ~20 fills
+    // the window's descriptors in device memory (one BatchItem): the plain linearisation of the GN iteration reads them from there - passed
+    // as kernel arguments, the ~150 pointers outgrow the scalar registers (400 SGPR spill moves in the kernel)
+    BatchItem *d_item = nullptr, *h_item = nullptr;
+    BatchItem itemShadow;
+    bool itemValid = false;
     int *h_stop = nullptr, *d_stop = nullptr;      // host-mapped word (and its device address): which iteration ended an un-forced optimize() loop
     char *h_stage = nullptr, *d_stage = nullptr;
     size_t stageCap = 0;
@@ -242,6 +247,8 @@ static int create_body(ldso_ba *H, int device, int w, int h, int max_frames, int
     ldso_settings_default(&H->settings);
     CHK(hipStreamCreateWithFlags(&H->stream, hipStreamNonBlocking));
     H->ownStream = true;
+    CHK(hipHostMalloc((void **) &H->h_item, sizeof(BatchItem)));
+    { void *q_ = nullptr; CHK(hipMalloc(&q_, sizeof(BatchItem))); H->d_item = (BatchItem *) q_; }
     CHK(hipHostMalloc((void **) &H->h_stop, 4 * sizeof(int), hipHostMallocMapped));
     CHK(hipHostGetDevicePointer((void **) &H->d_stop, H->h_stop, 0));
     memset(&H->B, 0, sizeof(H->B));
@@ -280,6 +287,8 @@ int ldso_ba_destroy(ldso_ba_t *H) {
     for (void *p : H->allocs) hipFree(p);
     for (int i = 0; i < LD_MAXF; i++) if (H->imgOwned[i] && H->imgSlots[i]) hipFree(H->imgSlots[i]);
     if (H->d_color) hipFree(H->d_color);
+    if (H->h_item) hipHostFree(H->h_item);
+    if (H->d_item) hipFree(H->d_item);
     if (H->h_stop) hipHostFree(H->h_stop);
     if (H->h_stage) hipHostFree(H->h_stage);
     if (H->d_stage) hipFree(H->d_stage);
@@ -579,9 +588,28 @@ static int launch_solve(ldso_ba *H, const ResSet &S, unsigned flags, int iterati
     t_end(H);
     return LDSO_OK;
 }
+// the handle's BatchItem in device memory, uploaded when it changed (window, image slots, accumulator lent to an all-reduce buffer, prior)
+static int refresh_item(ldso_ba *H) {
+    BatchItem it;
+    memset(&it, 0, sizeof(it));
+    it.B = H->B; it.D = H->D; it.set[0] = H->sets[0]; it.set[1] = H->sets[1]; it.cs = H->chunkStarts;
+    it.hasPrior = H->hasPrior ? 1 : 0; it.GSP = H->GSP; it.linBlock0 = 0; it.redBlock0 = 0;
+    if (H->itemValid && memcmp(&it, &H->itemShadow, sizeof(it)) == 0) return LDSO_OK;
+    CHK(hipStreamSynchronize(H->stream));            // the pinned copy may still be in flight (rare: the descriptors change per key frame)
+    memcpy(H->h_item, &it, sizeof(it));
+    CHK(hipMemcpyAsync(H->d_item, H->h_item, sizeof(it), hipMemcpyHostToDevice, H->stream));
+    H->itemShadow = it; H->itemValid = true;
+    return LDSO_OK;
+}
+
 static int launch_linearize(ldso_ba *H, bool fix, int stepMode = 0, int itCheck = -1) {
     t_begin(H, 0);
     GnInit gi; gi.enable = (H->D.pBegin > 0) ? 2 : 1; gi.hasPrior = H->hasPrior ? 1 : 0; gi.calibPrior = H->settings.initialCalibHessian; gi.itCheck = itCheck;
+    if (!fix && !H->hasL && gi.enable == 1) {
+        // the plain linearisation (GN iterations): descriptors from device memory (k_linearize_batch with one window)
+        { const int r_ = refresh_item(H); if (r_ != LDSO_OK) return r_; }
+        CHK(ba_launch_linearize_batch(H->d_item, 1, H->D.nChunks, H->D.FS, H->cur, H->settings, stepMode, gi.calibPrior, H->stream, itCheck));
+    } else
     CHK(ba_launch_linearize(H->B, H->D, H->sets[H->cur], H->sets[H->cur ^ 1], H->settings, H->hasL, fix, stepMode, gi, H->stream));
     t_end(H);
     if (H->profile) { t_begin(H, 4); t_end(H); }      // empty event pair: calibrates the event overhead (which = 4)

@@ -655,11 +655,11 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D,
 // launch.  Workgroup -> window by the prefix of chunk counts (items[w].linBlock0); `cur` = which residual set is the applied one
 // (all windows of a batch iterate in lockstep).
 template <int NSG>
-__global__ __launch_bounds__(64 * LD_WAVES) void k_linearize_batch(const BatchItem *__restrict__ items, int nWin, int cur, ldso_settings_t S, int stepMode, float calibPrior) {
+__global__ __launch_bounds__(64 * LD_WAVES) void k_linearize_batch(const BatchItem *__restrict__ items, int nWin, int cur, ldso_settings_t S, int stepMode, float calibPrior, int itCheck) {
     int w = 0;
     for (int i = 1; i < nWin; i++) if ((int) blockIdx.x >= items[i].linBlock0) w = i;
     const BatchItem &it = items[w];
-    GnInit gi; gi.enable = 1; gi.hasPrior = it.hasPrior; gi.calibPrior = calibPrior; gi.itCheck = -1;
+    GnInit gi; gi.enable = 1; gi.hasPrior = it.hasPrior; gi.calibPrior = calibPrior; gi.itCheck = itCheck;
     linearize_body<NSG, false, false, false>(it.B, it.D, it.set[cur], it.set[cur ^ 1], S, stepMode, gi, nullptr, (int) blockIdx.x - it.linBlock0, it.D.nChunks);
 }
 
@@ -702,15 +702,15 @@ hipError_t ba_launch_linearize_marg(const BaPtrs &B, const BaDims &D, const ResS
     return launch_one<2, false, false, true>(B, D, cur, nxt, S, 0, gi, st, margFlags);
 }
 
-hipError_t ba_launch_linearize_batch(const BatchItem *d_items, int nWin, int totalChunks, int FS, int cur, const ldso_settings_t &S, int stepMode, float calibPrior, hipStream_t st) {
+hipError_t ba_launch_linearize_batch(const BatchItem *d_items, int nWin, int totalChunks, int FS, int cur, const ldso_settings_t &S, int stepMode, float calibPrior, hipStream_t st, int itCheck) {
     if (totalChunks == 0) return hipSuccess;
     const size_t lds = ba_linearize_lds_bytes(FS, false);
     if (FS == 8) {
         if (lds > 48 * 1024) (void) hipFuncSetAttribute((const void *) k_linearize_batch<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-        hipLaunchKernelGGL(k_linearize_batch<1>, dim3(totalChunks), dim3(64 * LD_WAVES), lds, st, d_items, nWin, cur, S, stepMode, calibPrior);
+        hipLaunchKernelGGL(k_linearize_batch<1>, dim3(totalChunks), dim3(64 * LD_WAVES), lds, st, d_items, nWin, cur, S, stepMode, calibPrior, itCheck);
     } else {
         if (lds > 48 * 1024) (void) hipFuncSetAttribute((const void *) k_linearize_batch<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-        hipLaunchKernelGGL(k_linearize_batch<2>, dim3(totalChunks), dim3(64 * LD_WAVES), lds, st, d_items, nWin, cur, S, stepMode, calibPrior);
+        hipLaunchKernelGGL(k_linearize_batch<2>, dim3(totalChunks), dim3(64 * LD_WAVES), lds, st, d_items, nWin, cur, S, stepMode, calibPrior, itCheck);
     }
     return hipGetLastError();
 }
