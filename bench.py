@@ -41,9 +41,12 @@ def committed_profile(config, what):
             for fn in reversed(cand):                               # latest round first
                 pj = json.load(open(fn))
                 if pj.get("config", "C3") == config:
-                    for kname, kv in pj["kernels"].items():
-                        if kname.startswith("k_linearize") and "batch" not in kname:
-                            return kv["hbm_bytes_per_launch_corrected"], os.path.relpath(fn, ROOT)
+                    # the GN-iteration kernel = the k_linearize* entry with the most launches (k_linearize_batch<1> with one window from
+                    # round 2 on, k_linearize<...> before and for windows with linearised residuals)
+                    cands = [(kv.get("launches_FETCH_SIZE", 0), kv["hbm_bytes_per_launch_corrected"]) for kname, kv in pj["kernels"].items()
+                             if kname.startswith("k_linearize") and "hbm_bytes_per_launch_corrected" in kv]
+                    if cands:
+                        return max(cands)[1], os.path.relpath(fn, ROOT)
     except Exception:
         pass
     return None, None

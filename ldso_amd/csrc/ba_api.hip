@@ -605,7 +605,7 @@ static int refresh_item(ldso_ba *H) {
 static int launch_linearize(ldso_ba *H, bool fix, int stepMode = 0, int itCheck = -1) {
     t_begin(H, 0);
     GnInit gi; gi.enable = (H->D.pBegin > 0) ? 2 : 1; gi.hasPrior = H->hasPrior ? 1 : 0; gi.calibPrior = H->settings.initialCalibHessian; gi.itCheck = itCheck;
-    if (!fix && !H->hasL && gi.enable == 1) {
+    if (!fix && !H->hasL && gi.enable == 1 && H->D.FS == 8) {      // (two slot groups, F > 8: the argument-based kernel is the faster one, 43.0 against 45.6 us at C5)
         // the plain linearisation (GN iterations): descriptors from device memory (k_linearize_batch with one window)
         { const int r_ = refresh_item(H); if (r_ != LDSO_OK) return r_; }
         CHK(ba_launch_linearize_batch(H->d_item, 1, H->D.nChunks, H->D.FS, H->cur, H->settings, stepMode, gi.calibPrior, H->stream, itCheck));
