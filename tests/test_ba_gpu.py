@@ -52,7 +52,16 @@ def stage_compare(win, check_J=True):
     for k in ("bA", "bL", "bsc", "bFinal"):
         assert rel(sg[k], so[k]) < TOL, k
     assert np.linalg.norm(sg["HFinal"] @ sg["x"] - sg["bFinal"]) / np.linalg.norm(sg["bFinal"]) < 1e-8     # backward error
-    assert rel(sg["x"], so["x"]) < 5e-2                                                                       # gauge-limited
+    # x itself is only determined up to the weakly constrained gauge directions (cond ~1e5 after scaling: two fp64 solvers agree on it
+    # to ~1e-3).  What must agree tightly: the GPU's x solves the ORACLE's system, reaches the oracle's model decrease, and lies within
+    # 1e-5 of the oracle's x in the energy norm of that system
+    Ho, bo, xo, xg = so["HFinal"], so["bFinal"], so["x"], sg["x"]
+    assert np.linalg.norm(Ho @ xg - bo) / np.linalg.norm(bo) < 1e-6
+    dec = lambda x: float(x @ bo - 0.5 * x @ Ho @ x)
+    assert abs(dec(xg) - dec(xo)) <= 1e-9 * abs(dec(xo))
+    d = xg - xo
+    assert np.sqrt(abs(d @ Ho @ d)) <= 1e-5 * np.sqrt(abs(xo @ Ho @ xo))
+    assert rel(sg["x"], so["x"]) < 5e-2                                                                       # gauge-limited (loose by nature)
     assert o.counts()[:2] == g.get_counts()
     pto, _ = o.get_points(); ptg = g.get_points()
     for k in ("HdiF", "bdSumF", "idepth_hessian", "Hdd_accAF", "bd_accAF", "Hcd_accAF", "Hdd_accLF", "bd_accLF", "Hcd_accLF"):
@@ -61,7 +70,7 @@ def stage_compare(win, check_J=True):
     cbo, cbg = o.do_step(), g.do_step()
     assert cbo == cbg
     fo, fg = o.get_frames(), g.get_frames()
-    assert rel(fg["step"], fo["step"]) < 5e-2
+    assert rel(fg["step"], fo["step"]) < 5e-2                       # the frame part of -x: gauge-limited like x
     Eo, Eg = o.linearize_all(False), g.linearize_all(False)
     assert abs(Eo - Eg) <= 5 * TOL * abs(Eo)
     return o, g
