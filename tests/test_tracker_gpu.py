@@ -1,5 +1,5 @@
 """GPU parity of CoarseTracker (C-ABI ldso_tr_*) against the oracle: makeCoarseDepthL0 point clouds exact,
-calcRes / calcGSSSE within 1e-4, trackNewestCoarse end result within the LM convergence tolerance."""
+calcRes / calcGSSSE within 1e-4, trackNewestCoarse end pose within 1e-4 of the motion with the same iteration count."""
 import numpy as np
 import pytest
 
@@ -89,8 +89,11 @@ def test_track_matches_oracle(name, levels):
     To[:3, :4] = ro["T"]; Tg[:3, :4] = rg["T"]
     d = np.linalg.norm(synth.se3_log(Tg @ np.linalg.inv(To)))
     m = np.linalg.norm(synth.se3_log(To))
-    assert d < 2e-2 * m + 1e-5                                       # LM stops at |inc| <= 1e-3
-    assert rel(rg["lastResiduals"][:sc["levels"]], ro["lastResiduals"][:sc["levels"]]) < 1e-2
+    # the LM loop stops at |inc| <= 1e-3, but device and oracle take the same accept / reject path: observed d / m = 2e-6 (the float sums
+    # are grouped differently), residuals 3e-6, identical iteration counts
+    assert d < 1e-4 * m + 1e-6
+    assert abs(rg["iterations"] - ro["iterations"]) <= 1
+    assert rel(rg["lastResiduals"][:sc["levels"]], ro["lastResiduals"][:sc["levels"]]) < 1e-4
     err = np.linalg.norm(synth.se3_log(Tg @ np.linalg.inv(sc["T_true"])))
     assert err < 0.25 * np.linalg.norm(synth.se3_log(sc["T_true"]))
 
