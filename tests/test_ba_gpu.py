@@ -133,6 +133,23 @@ def test_optimize_canbreak_path(small):
     assert abs(rmo - rmg) <= 5 * TOL * rmo
 
 
+@pytest.mark.parametrize("F,P", [(12, 500), (3, 300), (2, 200)])
+def test_optimize_canbreak_other_window_shapes(F, P):
+    """The device-side loop end (host-mapped stop word) on the split-launch path (F = 12: k_reduce | k_gn_solve | k_linearize) and on the
+    small windows whose iteration budget the reference changes (FullSystem.cc:729-731: F < 3 -> 20, F < 4 -> 15)."""
+    win = synth.make_window(F=F, P=P, w=320, h=240, fx=200.0, seed=7 + F)
+    o = po.OracleWindow(win)
+    g = binding.BA.from_window(win)
+    rmo = o.optimize(6)
+    rmg, its = g.optimize(6, force_all=False)
+    assert its == len(o.energy_log()) - 2
+    assert abs(rmo - rmg) <= 5 * TOL * rmo
+    assert rel(g.get_energy_log(), o.energy_log()) < 5 * TOL
+    # and once more on the same handle: the stop word is re-armed per call
+    rmg2, its2 = g.optimize(6, force_all=False)
+    assert its2 >= 1 and np.isfinite(rmg2)
+
+
 def _optimize_compare(win, its=5, tol_e=5 * TOL):
     o = po.OracleWindow(win); o.set_force_all_iterations(True)
     g = binding.BA.from_window(win)
