@@ -1148,10 +1148,11 @@ int ldso_tr_track_batch(ldso_tracker_t *H, int nhyp, double *T_inout /*nhyp*12*/
     // few hypotheses: TR_GMAX workgroups share each of them on the large levels (all workgroups resident: nhyp * G <= CUs);
     // many hypotheses fill the chip by themselves
     { const int r_ = tr_sync_params(H); if (r_ != LDSO_OK) return r_; }
-    const int G = getenv("LDSO_TR_NO_COOP") ? 1 : nhyp * 16 <= H->numCU ? 16 : nhyp * 8 <= H->numCU ? 8 : nhyp * 4 <= H->numCU ? 4 : 1;
+    const int G = getenv("LDSO_TR_NO_COOP") ? 1 : nhyp * 16 <= H->numCU ? 16 : nhyp * 12 <= H->numCU ? 12 : nhyp * 8 <= H->numCU ? 8 : nhyp * 4 <= H->numCU ? 4 : 1;
     if (G > 1) {
         if (H->coopSeq > (1 << 30)) { CHK(hipMemsetAsync(H->d_coop, 0, 64 * sizeof(TrCoop), H->stream)); H->coopSeq = 1; }
         if (G == 16) hipLaunchKernelGGL(k_tr_track<16>, dim3(nhyp * 16), dim3(TR_NT), 0, H->stream, H->d_P, H->d_hyp, H->d_coop, H->coopSeq);
+        else if (G == 12) hipLaunchKernelGGL(k_tr_track<12>, dim3(nhyp * 12), dim3(TR_NT), 0, H->stream, H->d_P, H->d_hyp, H->d_coop, H->coopSeq);
         else if (G == 8) hipLaunchKernelGGL(k_tr_track<8>, dim3(nhyp * 8), dim3(TR_NT), 0, H->stream, H->d_P, H->d_hyp, H->d_coop, H->coopSeq);
         else hipLaunchKernelGGL(k_tr_track<4>, dim3(nhyp * 4), dim3(TR_NT), 0, H->stream, H->d_P, H->d_hyp, H->d_coop, H->coopSeq);
         H->coopSeq += 1024;           // more than the evaluations of one track (5 levels x (50 iterations + 7 cut-off repeats) + 1)

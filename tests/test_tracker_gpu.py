@@ -111,7 +111,7 @@ def test_track_batch_equals_single():
 
 @pytest.mark.parametrize("nhyp", [1, 16, 17, 33, 70])
 def test_cooperative_group_sizes_agree(nhyp):
-    """ldso_tr_track_batch picks G = 16 / 8 / 4 / 1 cooperating workgroups per hypothesis from the hypothesis count (nhyp * G <= CUs).
+    """ldso_tr_track_batch picks G = 16 / 12 / 8 / 4 / 1 cooperating workgroups per hypothesis from the hypothesis count (nhyp * G <= CUs).
     The variants differ only in how the 52 sums are grouped: every hypothesis of every batch size must land on the oracle's pose
     (LM convergence tolerance) with the same accept flag, on the full-size pair where all five levels are shared."""
     sc = tracker_scenario("C3", levels=5)
