@@ -579,8 +579,12 @@ __device__ __attribute__((noinline)) void tr_solve_fixed_affine(const double *sH
 // nhyp * G by the CU count); sequence numbers grow over the launches of a handle, so nothing has to be cleared in between.
 // ---------------------------------------------------------------------------------------------------------
 #define TR_GMAX 16
+#ifndef TR_COOP_MIN
 #define TR_COOP_MIN 512        // smaller levels stay on the leader: less than the ~1.4 us of a hand-over to win
+#endif
+#ifndef TR_COOP_PER
 #define TR_COOP_PER 64         // finest share: one wavefront with one point per lane
+#endif
 struct TrCoop {
     // every 64-bit word carries (payload << 32 | sequence number): a word is valid by itself, no fence / second round trip needed
     unsigned long long cmd[16];                          // R (9), t (3) as float, affine a, b, cut-off, level (-1: the track is over)
