@@ -109,7 +109,7 @@ def test_track_batch_equals_single():
         assert np.array_equal(singles[i]["T"], batch["T"][i]) and singles[i]["iterations"] == batch["iterations"][i]
 
 
-@pytest.mark.parametrize("nhyp", [1, 16, 17, 33, 70])
+@pytest.mark.parametrize("nhyp", [1, 16, 17, 21, 32, 33, 64, 70, 128])
 def test_cooperative_group_sizes_agree(nhyp):
     """ldso_tr_track_batch picks G = 16 / 12 / 8 / 4 / 1 cooperating workgroups per hypothesis from the hypothesis count (nhyp * G <= CUs).
     The variants differ only in how the 52 sums are grouped: every hypothesis of every batch size must land on the oracle's pose
