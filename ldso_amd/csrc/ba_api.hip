@@ -1082,6 +1082,7 @@ int ldso_ba_batch_create(ldso_ba_t *const *handles, int n, ldso_ba_batch_t **out
         REQ(!H->hasL, "ldso_ba_batch_create: windows with linearised residuals run on their own handle");
         REQ(H->D.pBegin == 0 && H->D.pEnd == H->D.P, "ldso_ba_batch_create: sharded handles cannot be batched");
         REQ(H->settings.forceAcceptStep && !H->pendingApply, "ldso_ba_batch_create: forced-accept schedule, no pending linearisation");
+        REQ(memcmp(&H->settings, &H0->settings, sizeof(H0->settings)) == 0, "ldso_ba_batch_create: the batched kernels run with ONE ldso_settings_t: every handle of a batch must have been created with identical settings");
     }
     CHK(hipSetDevice(H0->device));
     ldso_ba_batch *Bt = new ldso_ba_batch();
@@ -1214,7 +1215,6 @@ int ldso_ba_activate_points(ldso_ba_t *H, int n, const ldso_immature_t *pts, int
     for (int f = 0; f < H->D.F; f++) REQ(H->B.img[f] != nullptr, "ldso_ba_activate_points: a key-frame image is missing");
     if (n > H->actCap) {
         if (H->d_act) hipFree(H->d_act);
-    if (H->distBuf) hipFree(H->distBuf);
         H->d_act = nullptr; H->actCap = 0;
         CHK(hipMalloc(&H->d_act, (size_t) n * (sizeof(ldso_immature_t) + sizeof(ldso_activation_t))));
         H->actCap = n;

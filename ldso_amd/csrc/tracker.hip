@@ -13,6 +13,7 @@
 // dependent launches, and batches hypotheses across workgroups (FullSystem::trackNewCoarse tries up to 83).
 #include <hip/hip_runtime.h>
 #include <vector>
+#include <mutex>
 #include <string>
 #include <cstring>
 #include <cmath>
@@ -585,6 +586,8 @@ __device__ __attribute__((noinline)) void tr_solve_fixed_affine(const double *sH
 #ifndef TR_COOP_PER
 #define TR_COOP_PER 64         // finest share: one wavefront with one point per lane
 #endif
+#define TR_COOP_SLOTS 128       // = the maximum number of hypotheses of ldso_tr_track_batch: coop[] is indexed by hypothesis
+#define TR_SPIN_LIMIT 500000000ll   // bail-out of the hand-over polls: 5 s of the 100 MHz wall clock (a track takes < 1 ms)
 struct TrCoop {
     // every 64-bit word carries (payload << 32 | sequence number): a word is valid by itself, no fence / second round trip needed
     unsigned long long cmd[16];                          // R (9), t (3) as float, affine a, b, cut-off, level (-1: the track is over)
@@ -597,7 +600,7 @@ __device__ __forceinline__ int tr_nact(int n, int G) { return (G == 1 || n < TR_
 // leader side of one evaluation (all threads of the leader workgroup)
 template <int G>
 __device__ __forceinline__ void tr_eval_lead(const TrParams &P, int lvl, const double *T, float a, float b, float cutoff, double *sAcc, float *sRed, float *sRt,
-                                             TrCoop *co, int &seq, TrPts &pc) {
+                                             TrCoop *co, int &seq, TrPts &pc, int *sAbort) {
     const int tid = threadIdx.x, nAct = tr_nact(P.lv[lvl].n, G);
     if (tid < 12) sRt[tid] = (float) T[tid < 9 ? (tid / 3) * 4 + tid % 3 : (tid - 9) * 4 + 3];
     __syncthreads();
@@ -615,6 +618,7 @@ __device__ __forceinline__ void tr_eval_lead(const TrParams &P, int lvl, const d
             // all helpers' words are requested together (one memory round trip once they are there), added in workgroup order
             unsigned long long w0[G > 1 ? G - 1 : 1], w1[G > 1 ? G - 1 : 1];
             bool ok;
+            unsigned spins = 0; long long t0 = 0;
             do {
                 ok = true;
 #pragma unroll
@@ -623,6 +627,9 @@ __device__ __forceinline__ void tr_eval_lead(const TrParams &P, int lvl, const d
                 }
 #pragma unroll
                 for (int g = 1; g < G; g++) if (g < nAct) ok = ok && ((unsigned) w0[g - 1] == (unsigned) seq) && ((unsigned) w1[g - 1] == (unsigned) seq);
+                // a helper workgroup that never becomes resident (CUs held by another process / a masked device) must not hang the
+                // stream: give up after TR_SPIN_LIMIT, the track then reports an error instead of a pose
+                if (!ok && (++spins & 1023u) == 0) { const long long now = wall_clock64(); if (t0 == 0) t0 = now; else if (now - t0 > TR_SPIN_LIMIT) { *sAbort = 1; break; } }
             } while (!ok);
             double s_ = sAcc[tid];
 #pragma unroll
@@ -643,16 +650,20 @@ __device__ void tr_helper_loop(const TrParams &P, TrCoop *co, int g, int seq, do
             // the 16 command words are read by one instruction; they belong to one command when their sequence numbers agree (a
             // command this workgroup takes part in is stable until it has answered; torn reads only happen on commands it sits out)
             unsigned long long w; unsigned tag, t0; bool ok;
+            unsigned spins = 0; long long c0 = 0; bool dead = false;
             do {
                 w = tr_ld(&co->cmd[tid & 15]); tag = (unsigned) w;
                 t0 = (unsigned) __builtin_amdgcn_readfirstlane((int) tag);
                 ok = (__builtin_amdgcn_ballot_w64(tag != t0) == 0ull) && ((int) (t0 - (unsigned) seq) > 0);
-                if (!ok) __builtin_amdgcn_s_sleep(1);
+                if (!ok) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if ((++spins & 1023u) == 0) { const long long now = wall_clock64(); if (c0 == 0) c0 = now; else if (now - c0 > 2 * TR_SPIN_LIMIT) { dead = true; break; } }   // wave-uniform: the leader is gone
+                }
             } while (!ok);
             const unsigned pl = (unsigned) (w >> 32);
             if (tid < 12) sRt[tid] = __builtin_bit_cast(float, pl);
             else if (tid < 15) sF[tid - 12] = __builtin_bit_cast(float, pl);
-            else if (tid == 15) { sI[0] = (int) pl; sI[1] = (int) t0; }
+            else if (tid == 15) { sI[0] = dead ? -1 : (int) pl; sI[1] = (int) t0; }
         }
         __syncthreads();
         const int lvl = sI[0];
@@ -683,7 +694,7 @@ __global__ __launch_bounds__(TR_NT) void k_tr_track(const TrParams *__restrict__
     __shared__ double sT[12], sTnew[12];
     __shared__ float sAff[2], sAffNew[2];
     __shared__ double sH[64], sB[8], sNb[8], sInc[8], sResOld[6], sResNew[6];
-    __shared__ int sCtl[4];          // 0: continue LM loop, 1: accept, 2: abort (return false), 3: iterations
+    __shared__ int sCtl[5];          // 0: continue LM loop, 1: accept, 2: abort (return false), 3: iterations, 4: hand-over timed out (error)
 #if LD_STAMP_ON_TR
     // debug builds: device timing of tr_eval per level (dynamically indexed -> scratch memory: never in a product build)
     long long tEval = 0, tS1 = 0, tS2 = 0, tS3 = 0, tQ = 0, tTot0 = wall_clock64(), tLv[5] = {0, 0, 0, 0, 0}; int nEval = 0, nLv[5] = {0, 0, 0, 0, 0};
@@ -702,7 +713,7 @@ __global__ __launch_bounds__(TR_NT) void k_tr_track(const TrParams *__restrict__
     if (G > 1 && (blockIdx.x % G) != 0) { tr_helper_loop<G>(P, co, (int) (blockIdx.x % G), seq0, sAcc, sRed, sRt, sCoF, sCtl); return; }
     TrPts pc; pc.lvl = -1;
     if (tid < 12) sT[tid] = hy.T[tid];
-    if (tid == 0) { sAff[0] = hy.a; sAff[1] = hy.b; sCtl[3] = 0; sCtl[2] = 0; for (int i = 0; i < 5; i++) hy.lastResiduals[i] = NAN; for (int i = 0; i < 3; i++) hy.flow[i] = 1000; }
+    if (tid == 0) { sAff[0] = hy.a; sAff[1] = hy.b; sCtl[3] = 0; sCtl[2] = 0; sCtl[4] = 0; for (int i = 0; i < 5; i++) hy.lastResiduals[i] = NAN; for (int i = 0; i < 3; i++) hy.flow[i] = 1000; }
     __syncthreads();
     const int maxIterations[5] = {10, 20, 50, 50, 50};
     const float lambdaExtrapolationLimit = 0.001f;
@@ -710,12 +721,12 @@ __global__ __launch_bounds__(TR_NT) void k_tr_track(const TrParams *__restrict__
 
     for (int lvl = hy.coarsestLvl; lvl >= 0; lvl--) {
         float levelCutoffRepeat = 1;
-        TEV(tr_eval_lead<G>(P, lvl, sT, sAff[0], sAff[1], P.coarseCutoffTH * levelCutoffRepeat, sAcc, sRed, sRt, co, coSeq, pc););
+        TEV(tr_eval_lead<G>(P, lvl, sT, sAff[0], sAff[1], P.coarseCutoffTH * levelCutoffRepeat, sAcc, sRed, sRt, co, coSeq, pc, &sCtl[4]););
         if (tid == 0) tr_vec6(sAcc, sResOld);
         __syncthreads();
-        while (sResOld[5] > 0.6 && levelCutoffRepeat < 50) {
+        while (sResOld[5] > 0.6 && levelCutoffRepeat < 50 && !sCtl[4]) {
             levelCutoffRepeat *= 2;
-            TEV(tr_eval_lead<G>(P, lvl, sT, sAff[0], sAff[1], P.coarseCutoffTH * levelCutoffRepeat, sAcc, sRed, sRt, co, coSeq, pc););
+            TEV(tr_eval_lead<G>(P, lvl, sT, sAff[0], sAff[1], P.coarseCutoffTH * levelCutoffRepeat, sAcc, sRed, sRt, co, coSeq, pc, &sCtl[4]););
             if (tid == 0) tr_vec6(sAcc, sResOld);
             __syncthreads();
         }
@@ -759,10 +770,11 @@ __global__ __launch_bounds__(TR_NT) void k_tr_track(const TrParams *__restrict__
 #if LD_STAMP_ON_TR
             tS2 += wall_clock64() - tQ;
 #endif
-            TEV(tr_eval_lead<G>(P, lvl, sTnew, sAffNew[0], sAffNew[1], P.coarseCutoffTH * levelCutoffRepeat, sAcc, sRed, sRt, co, coSeq, pc););
+            TEV(tr_eval_lead<G>(P, lvl, sTnew, sAffNew[0], sAffNew[1], P.coarseCutoffTH * levelCutoffRepeat, sAcc, sRed, sRt, co, coSeq, pc, &sCtl[4]););
 #if LD_STAMP_ON_TR
             tQ = wall_clock64();
 #endif
+            if (sCtl[4]) break;
             if (tid == 0) {
                 tr_vec6(sAcc, sResNew);
                 sCtl[1] = ((sResNew[0] / sResNew[1]) < (sResOld[0] / sResOld[1])) ? 1 : 0;
@@ -794,7 +806,7 @@ __global__ __launch_bounds__(TR_NT) void k_tr_track(const TrParams *__restrict__
             if (lr > 1.5 * hy.minRes[lvl]) sCtl[2] = 1;
         }
         __syncthreads();
-        if (sCtl[2]) break;
+        if (sCtl[2] || sCtl[4]) break;
         if (levelCutoffRepeat > 1 && !haveRepeated) { lvl++; haveRepeated = true; }
     }
 #if LD_STAMP_ON_TR
@@ -807,7 +819,8 @@ __global__ __launch_bounds__(TR_NT) void k_tr_track(const TrParams *__restrict__
     if (tid == 0) {
         hy.iterations = sCtl[3];
         for (int q = 0; q < 5; q++) hy.evals[q] = sEv[q];
-        if (sCtl[2]) { hy.ok = 0; }
+        if (sCtl[4]) { hy.ok = -2; }      // the host turns this into LDSO_E_HIP
+        else if (sCtl[2]) { hy.ok = 0; }
         else {
             for (int i = 0; i < 12; i++) hy.T[i] = sT[i];
             float a = sAff[0], b = sAff[1];
@@ -912,7 +925,7 @@ int ldso_tr_create(int device, int w, int h, int levels, ldso_tracker_t **out) {
         L.idepth += 64; L.wsum += 64; L.wsum_bak += 64;
         TA(L.blockCnt, n / 256 + 2);
     }
-    TA(H->d_total, TR_MAXL); TA(H->d_T, 12); TA(H->d_acc, TR_NACC); TA(H->d_hyp, 128); TA(H->d_coop, 64); TA(H->d_P, 1);
+    TA(H->d_total, TR_MAXL); TA(H->d_T, 12); TA(H->d_acc, TR_NACC); TA(H->d_hyp, 128); TA(H->d_coop, TR_COOP_SLOTS); TA(H->d_P, 1);
     CHK(hipHostMalloc((void **) &H->h_P, sizeof(TrParams)));
     CHK(hipHostMalloc((void **) &H->h_hyp, 128 * sizeof(TrHyp)));
     memset(&H->Pdev, 0xFF, sizeof(TrParams));
@@ -1005,7 +1018,6 @@ static int tr_set_ref_common(ldso_tracker_t *H, float ref_a, float ref_b, float 
     H->P.ref_a = ref_a; H->P.ref_b = ref_b; H->P.ref_exposure = ref_exposure;
     if (n > H->ptsCap) {
         if (H->d_pts) hipFree(H->d_pts);
-    if (H->d_next) hipFree(H->d_next);
         if (H->d_next) hipFree(H->d_next);
         H->d_pts = nullptr; H->d_next = nullptr; H->ptsCap = 0;
         void *q; CHK(hipMalloc(&q, (size_t) n * 16)); H->d_pts = (float *) q;
@@ -1137,6 +1149,21 @@ int ldso_tr_calc_gs(ldso_tracker_t *H, int lvl, const double T[12], float a, flo
     return LDSO_OK;
 }
 
+// Cooperative launches (G > 1) spin-wait across workgroups: forward progress needs every workgroup of the launch resident.  One launch
+// alone is (nhyp * G <= #CUs, one 256-thread workgroup per CU whatever else runs: other kernels finish and free their CUs); two such
+// launches from different handles could each hold CUs with spinning leaders while the other's helpers wait for a CU.  Within a process
+// they are therefore chained per device through an event; across processes (or under a CU mask) the bounded spins of the kernel turn a
+// would-be hang into LDSO_E_HIP.
+static std::mutex g_coopMutex;
+static hipEvent_t g_coopLast[64] = {nullptr};
+static int tr_coop_chain_begin(ldso_tracker_t *H) {
+    if (H->device < 0 || H->device >= 64) return LDSO_OK;
+    hipEvent_t &e = g_coopLast[H->device];
+    if (!e) CHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    else CHK(hipStreamWaitEvent(H->stream, e, 0));
+    return LDSO_OK;
+}
+
 int ldso_tr_track_batch(ldso_tracker_t *H, int nhyp, double *T_inout /*nhyp*12*/, float *aff_inout /*nhyp*2*/, int coarsestLvl, const double minRes[5],
                         double *lastResiduals /*nhyp*5*/, double *flow /*nhyp*3*/, int *ok /*nhyp*/, int *iterations /*nhyp*/) {
     REQ(H && nhyp >= 1 && nhyp <= 128 && T_inout && aff_inout && coarsestLvl >= 0 && coarsestLvl < 5 && coarsestLvl < H->levels, "ldso_tr_track: bad arguments");
@@ -1154,18 +1181,25 @@ int ldso_tr_track_batch(ldso_tracker_t *H, int nhyp, double *T_inout /*nhyp*12*/
     { const int r_ = tr_sync_params(H); if (r_ != LDSO_OK) return r_; }
     const int G = getenv("LDSO_TR_NO_COOP") ? 1 : nhyp * 16 <= H->numCU ? 16 : nhyp * 12 <= H->numCU ? 12 : nhyp * 8 <= H->numCU ? 8 : nhyp * 4 <= H->numCU ? 4 : 1;
     if (G > 1) {
-        if (H->coopSeq > (1 << 30)) { CHK(hipMemsetAsync(H->d_coop, 0, 64 * sizeof(TrCoop), H->stream)); H->coopSeq = 1; }
+        std::lock_guard<std::mutex> lk(g_coopMutex);
+        { const int r_ = tr_coop_chain_begin(H); if (r_ != LDSO_OK) return r_; }
+        if (H->coopSeq > (1 << 30)) { CHK(hipMemsetAsync(H->d_coop, 0, TR_COOP_SLOTS * sizeof(TrCoop), H->stream)); H->coopSeq = 1; }
         if (G == 16) hipLaunchKernelGGL(k_tr_track<16>, dim3(nhyp * 16), dim3(TR_NT), 0, H->stream, H->d_P, H->d_hyp, H->d_coop, H->coopSeq);
         else if (G == 12) hipLaunchKernelGGL(k_tr_track<12>, dim3(nhyp * 12), dim3(TR_NT), 0, H->stream, H->d_P, H->d_hyp, H->d_coop, H->coopSeq);
         else if (G == 8) hipLaunchKernelGGL(k_tr_track<8>, dim3(nhyp * 8), dim3(TR_NT), 0, H->stream, H->d_P, H->d_hyp, H->d_coop, H->coopSeq);
         else hipLaunchKernelGGL(k_tr_track<4>, dim3(nhyp * 4), dim3(TR_NT), 0, H->stream, H->d_P, H->d_hyp, H->d_coop, H->coopSeq);
         H->coopSeq += 1024;           // more than the evaluations of one track (5 levels x (50 iterations + 7 cut-off repeats) + 1)
+        if (H->device >= 0 && H->device < 64) CHK(hipEventRecord(g_coopLast[H->device], H->stream));
     } else {
         hipLaunchKernelGGL(k_tr_track<1>, dim3(nhyp), dim3(TR_NT), 0, H->stream, H->d_P, H->d_hyp, (TrCoop *) nullptr, 0);
     }
     CHK(hipGetLastError());
     CHK(hipMemcpyAsync(hy, H->d_hyp, nhyp * sizeof(TrHyp), hipMemcpyDeviceToHost, H->stream));
     CHK(hipStreamSynchronize(H->stream));
+    for (int i = 0; i < nhyp; i++) if (hy[i].ok == -2) {
+        ldso_set_error("ldso_tr_track: the cooperating workgroups of a hypothesis did not become co-resident (device shared with another process or CU-masked?); set LDSO_TR_NO_COOP=1");
+        return LDSO_E_HIP;
+    }
     for (int i = 0; i < nhyp; i++) {
         memcpy(T_inout + i * 12, hy[i].T, 96);
         aff_inout[2 * i] = hy[i].a; aff_inout[2 * i + 1] = hy[i].b;

@@ -42,6 +42,7 @@ def lib():
         L = C.CDLL(lib_path())
         L.ref_create.restype = C.c_void_p
         L.ref_linearize_all.restype = C.c_double
+        L.ref_fs_optimize.restype = C.c_float
         _LIB = L
     return _LIB
 
@@ -78,6 +79,68 @@ class RefWindow:
             self.close()
         except Exception:
             pass
+
+    # --- the reference's own FullSystem members on this window (FullSystem.cc compiled unmodified; ref_driver.cc ref_fs_*) ---------
+    def fs_attach(self, multithreading=False):
+        self.L.ref_fs_attach(self.h, C.c_int(1 if multithreading else 0))
+
+    def fs_log(self) -> str:
+        n = self.L.ref_fs_log(self.h, None, C.c_int(0))
+        buf = C.create_string_buffer(n + 1)
+        self.L.ref_fs_log(self.h, buf, C.c_int(n + 1))
+        return buf.value.decode(errors="replace")
+
+    def fs_optimize(self, iterations: int):
+        """FullSystem::optimize (FullSystem.cc:725-864).  Returns (return value, energies printed by printOptRes: one before the loop
+        and one per executed iteration - the only place the reference reports them)."""
+        import re
+        rv = float(self.L.ref_fs_optimize(self.h, C.c_int(iterations)))
+        log = self.fs_log()
+        energies = [float(m) for m in re.findall(r"A\(([-0-9.eE+naif]+)\)=\(AV", log)]
+        return rv, np.array(energies)
+
+    def fs_is_lost(self) -> bool:
+        return bool(self.L.ref_fs_is_lost(self.h))
+
+    def fs_collect_active(self, reset_oob=True):
+        self.L.ref_fs_collect_active(self.h, C.c_int(1 if reset_oob else 0))
+
+    def fs_linearize_all(self, fix=False):
+        out = np.zeros(3)
+        self.L.ref_fs_linearize_all(self.h, C.c_int(1 if fix else 0), _p(out))
+        return out
+
+    def fs_apply_res(self):
+        self.L.ref_fs_apply_res(self.h)
+
+    def fs_set_new_frame_energy_th(self):
+        self.L.ref_fs_set_new_frame_energy_th(self.h)
+
+    def fs_backup_state(self, backup_last_step=False):
+        self.L.ref_fs_backup_state(self.h, C.c_int(1 if backup_last_step else 0))
+
+    def fs_do_step(self, stepfac=1.0) -> bool:
+        return bool(self.L.ref_fs_do_step(self.h, C.c_float(stepfac)))
+
+    def fs_load_state_backup(self):
+        self.L.ref_fs_load_state_backup(self.h)
+
+    def fs_solve_system(self, iteration: int, lam: float = 1e-1):
+        self.L.ref_fs_solve_system(self.h, C.c_int(iteration), C.c_double(lam))
+
+    def fs_calc_energies(self):
+        el, em = C.c_double(), C.c_double()
+        self.L.ref_fs_calc_energies(self.h, C.byref(el), C.byref(em))
+        return el.value, em.value
+
+    def fs_flag_frame(self, idx):
+        self.L.ref_fs_flag_frame(self.h, C.c_int(idx))
+
+    def fs_flag_points_for_removal(self):
+        self.L.ref_fs_flag_points_for_removal(self.h)
+
+    def fs_marginalize_frame(self, idx):
+        self.L.ref_fs_marginalize_frame(self.h, C.c_int(idx))
 
     def collect_active(self, reset_oob=True):
         self.L.ref_collect_active(self.h, C.c_int(1 if reset_oob else 0))

@@ -10,11 +10,15 @@
 // reference's functions one by one through the same C entry points as oracle/capi.cc (prefix ref_ instead of orc_), so that
 // tests/test_ref_pin.py can run the oracle's restatement and the reference side by side on identical inputs.
 //
-// What is NOT compiled from the reference: FullSystem.cc (needs the whole front end, OpenCV, the viewer).  The few lines of it
-// this driver needs are restated below, each citing its source: setPrecalcValues (:1423-1431), getNullspaces (:1711-1760),
-// the residual loop of linearizeAll_Reductor (:1442-1470, without setNewFrameEnergyTH), the re-linearise / fix loop of
-// flagPointsForRemoval (:1241-1250), the residual drop of marginalizeFrame (:602-640); and the out-of-line constructors of
-// Frame / Point (src/Frame.cc:15-17, src/Point.cc:25-27; those files carry the map I/O and do not compile without OpenCV).
+// Since round 3 src/frontend/FullSystem.cc and src/{Frame,Feature,Point}.cc are compiled into the library as well (unmodified; the
+// front-end pieces they refer to but never execute here - viewer, loop closing, corner detector, global map - are link-time stand-ins in
+// ref_stubs.cc).  The ref_fs_* entry points below attach a real FullSystem object to the window and call the reference's own
+// optimize / linearizeAll / setNewFrameEnergyTH / backupState / doStepFromBackup / loadSateBackup / solveSystem / calcLEnergy / calcMEnergy /
+// optimizeImmaturePoint / trackNewCoarse (private members: this file, and only this file, is compiled with `#define private public`).
+// The stage calls of the older entry points (ref_linearize_all, ref_solve_system, ref_flag_points, ref_marginalize_frame) keep their
+// restated FullSystem loops, each citing its source: setPrecalcValues (:1423-1431), getNullspaces (:1711-1760), the residual loop of
+// linearizeAll_Reductor (:1442-1470, without setNewFrameEnergyTH), the re-linearise / fix loop of flagPointsForRemoval (:1241-1250), the
+// residual drop of marginalizeFrame (:602-640) - tests/test_ref_pin.py checks them against the real members.
 #include <vector>
 #include <memory>
 #include <map>
@@ -27,7 +31,15 @@
 #include <cstdio>
 #include <iostream>
 #include <fstream>
+#include <sstream>
+#include <string>
+#include <deque>
+#include <list>
+#include <queue>
+#include <type_traits>
+#include <unistd.h>
 #include <Eigen/Core>
+#include <glog/logging.h>
 #define private public
 #define protected public
 #include "Frame.h"
@@ -45,25 +57,13 @@
 #include "internal/OptimizationBackend/EnergyFunctional.h"
 #include "frontend/CoarseTracker.h"
 #include "frontend/CoarseInitializer.h"
+#include "frontend/FullSystem.h"
 #undef private
 #undef protected
 #include "../include/ldso_window.h"
 
 using namespace ldso;
 using namespace ldso::internal;
-
-// ---- out-of-line members of the reference's data classes that live in translation units we cannot compile ----------------
-namespace ldso {
-unsigned long Frame::nextId = 0;
-Frame::Frame() { id = nextId++; }                        // src/Frame.cc:15-17
-Frame::Frame(double timestamp) { id = nextId++; this->timeStamp = timestamp; }
-void Frame::CreateFH(shared_ptr<Frame> frame) { frameHessian = shared_ptr<internal::FrameHessian>(new internal::FrameHessian(frame)); }      // src/Frame.cc:37-39
-unsigned long Point::mNextId = 0;
-Point::Point() { id = mNextId++; }                       // src/Point.cc:25-27
-void Point::ReleasePH() { if (mpPH) { mpPH->point = nullptr; mpPH = nullptr; } }
-void Feature::ReleaseImmature() { if (ip) { ip->feature = nullptr; ip = nullptr; } }
-void Feature::ReleaseMapPoint() { if (point) point->ReleasePH(); }
-}  // namespace ldso
 
 namespace {
 
@@ -78,6 +78,8 @@ struct RefWindow {
     std::vector<shared_ptr<PointFrameResidual>> activeResiduals;
     std::vector<std::vector<float>> imageStore;
     int levels = 0;
+    FullSystem *fs = nullptr;         // ref_fs_attach: the reference's own FullSystem driving this window
+    std::string fsLog;                // what the reference streamed into LOG(...) during the last ref_fs_* call (glog stand-in)
 };
 
 static void apply_settings(const ldso_settings_t *s) {
@@ -261,7 +263,9 @@ void *ref_create(int w, int h, int levels, const ldso_settings_t *settings, cons
             if (r->isLinearized && linJ) W->ef->insertResidual(r); else W->ef->nResiduals++;      // insertResidual = takeData + counters (EF.cc:26-30)
             W->resByFlat[ri] = r;
         }
-        for (auto &r : p->residuals) {      // FullSystem.cc:446-469 sets lastResiduals on activation
+        // a freshly activated point starts with lastResiduals = {nullptr, OOB} (FullSystem::optimizeImmaturePoint, FullSystem.cc:981-984) ...
+        p->lastResiduals[0] = {nullptr, ResState::OOB}; p->lastResiduals[1] = {nullptr, ResState::OOB};
+        for (auto &r : p->residuals) {      // ... and FullSystem.cc:446-469 / :1000-1006 point them at the residuals into the two newest frames
             if (r->target.lock() == W->frames.back()->frameHessian) p->lastResiduals[0] = {r, ResState::IN};
             else if (F >= 2 && r->target.lock() == W->frames[F - 2]->frameHessian) p->lastResiduals[1] = {r, ResState::IN};
         }
@@ -276,6 +280,12 @@ void *ref_create(int w, int h, int levels, const ldso_settings_t *settings, cons
 
 void ref_destroy(void *h) {
     RefWindow *W = (RefWindow *) h;
+    if (W->fs) {
+        // the FullSystem shares the window's objects; its tracker / initializer hold no frames here
+        for (auto &fr : W->fs->frames) if (fr->frameHessian) for (int l = 0; l < PYR_LEVELS; l++) { fr->frameHessian->dIp[l] = nullptr; fr->frameHessian->absSquaredGrad[l] = nullptr; }
+        W->ef->red = &W->red;
+        delete W->fs; W->fs = nullptr;
+    }
     // ~FrameHessian delete[]s its pyramid levels (FrameHessian.h:24-29); here they point into imageStore
     for (auto &fh : W->ef->frames) for (int l = 0; l < PYR_LEVELS; l++) { fh->dIp[l] = nullptr; fh->absSquaredGrad[l] = nullptr; }
     for (auto &fr : W->frames) if (fr->frameHessian) for (int l = 0; l < PYR_LEVELS; l++) { fr->frameHessian->dIp[l] = nullptr; fr->frameHessian->absSquaredGrad[l] = nullptr; }
@@ -357,7 +367,7 @@ void ref_get_points(void *h, ldso_point_out_t *out, int32_t *status) {
             for (int k = 0; k < 4; k++) { o.Hcd_accAF[k] = p->Hcd_accAF[k]; o.Hcd_accLF[k] = p->Hcd_accLF[k]; }
             o.idepth = p->idepth; o.maxRelBaseline = p->maxRelBaseline; o.numGoodResiduals = p->numGoodResiduals;
         }
-        if (status) status[i] = p->alreadyRemoved ? 100 + (int) p->point->status : (int) p->point->status;
+        if (status) status[i] = !p->point ? -1 /* released with its host frame (Frame::ReleaseAll) */ : p->alreadyRemoved ? 100 + (int) p->point->status : (int) p->point->status;
     }
 }
 
@@ -499,6 +509,60 @@ void ref_marginalize_frame(void *h, int idx) {
     for (size_t i = 0; i < W->frames.size(); i++) if (W->frames[i]->frameHessian == fh) { W->frames.erase(W->frames.begin() + i); break; }
     W->ef->setAdjointsF(W->Hcalib);
     set_precalc(W);
+}
+
+// ---- the reference's own FullSystem on this window (FullSystem.cc compiled unmodified) -------------------------------------------
+// ref_fs_attach builds a FullSystem (its constructor starts the idle mapping thread and allocates trackers / selector for wG[0] x hG[0])
+// and hands it the window: frames, the EnergyFunctional (ef->red = &threadReduce as FullSystem.cc:41 does) and the camera.
+static FullSystem *fs_of(RefWindow *W) {
+    if (!W->fs) {
+        setting_enableLoopClosing = false;
+        W->fs = new FullSystem(nullptr);
+        W->fs->linearizeOperation = true;
+        W->fs->ef = W->ef;
+        W->ef->red = &W->fs->threadReduce;
+        W->fs->Hcalib = W->cam;
+    }
+    W->fs->frames = W->frames;
+    return W->fs;
+}
+struct FsCall {          // capture LOG(...) for the duration of a call, write the frame list back afterwards
+    RefWindow *W; FullSystem *fs;
+    explicit FsCall(void *h) : W((RefWindow *) h), fs(fs_of(W)) { W->fsLog.clear(); ref_shim::log_capture_slot() = &W->fsLog; }
+    ~FsCall() { ref_shim::log_capture_slot() = nullptr; W->frames = fs->frames; W->activeResiduals = fs->activeResiduals; }
+};
+
+void ref_fs_attach(void *h, int multithreading) { FsCall c(h); multiThreading = multithreading != 0; }
+int ref_fs_log(void *h, char *out, int cap) {
+    RefWindow *W = (RefWindow *) h;
+    int n = (int) W->fsLog.size();
+    if (out && cap > 0) { int m = n < cap - 1 ? n : cap - 1; memcpy(out, W->fsLog.data(), m); out[m] = 0; }
+    return n;
+}
+// float FullSystem::optimize(int mnumOptIts) (FullSystem.cc:725-864); the per-iteration energies are in the log (printOptRes)
+float ref_fs_optimize(void *h, int iterations) { FsCall c(h); return c.fs->optimize(iterations); }
+int ref_fs_is_lost(void *h) { return ((RefWindow *) h)->fs && ((RefWindow *) h)->fs->isLost ? 1 : 0; }
+// the activeResiduals list of optimize (:735-755) - restated (it is inline in optimize); everything below is the reference's member
+void ref_fs_collect_active(void *h, int reset_oob) { ref_collect_active(h, reset_oob); FsCall c(h); c.fs->activeResiduals = c.W->activeResiduals; }
+// Vec3 FullSystem::linearizeAll(bool fixLinearization) (:1442-1492): linearize + setNewFrameEnergyTH (+ state bookkeeping / residual removal)
+void ref_fs_linearize_all(void *h, int fix, double out[3]) { FsCall c(h); c.fs->activeResiduals = c.W->activeResiduals; Vec3 e = c.fs->linearizeAll(fix != 0); for (int i = 0; i < 3; i++) out[i] = e[i]; }
+void ref_fs_apply_res(void *h) { FsCall c(h); c.fs->activeResiduals = c.W->activeResiduals; Vec10 st; c.fs->applyRes_Reductor(true, 0, (int) c.fs->activeResiduals.size(), &st, 0); }
+void ref_fs_set_new_frame_energy_th(void *h) { FsCall c(h); c.fs->activeResiduals = c.W->activeResiduals; c.fs->setNewFrameEnergyTH(); }
+void ref_fs_backup_state(void *h, int backup_last_step) { FsCall c(h); c.fs->activeResiduals = c.W->activeResiduals; c.fs->backupState(backup_last_step != 0); }
+int ref_fs_do_step(void *h, float stepfac) { FsCall c(h); c.fs->activeResiduals = c.W->activeResiduals; return c.fs->doStepFromBackup(stepfac, stepfac, stepfac, stepfac, stepfac) ? 1 : 0; }
+void ref_fs_load_state_backup(void *h) { FsCall c(h); c.fs->activeResiduals = c.W->activeResiduals; c.fs->loadSateBackup(); }
+void ref_fs_solve_system(void *h, int iteration, double lambda) { FsCall c(h); c.fs->activeResiduals = c.W->activeResiduals; c.fs->solveSystem(iteration, lambda); }
+void ref_fs_calc_energies(void *h, double *EL, double *EM) { FsCall c(h); *EL = c.fs->calcLEnergy(); *EM = c.fs->calcMEnergy(); }
+void ref_fs_set_precalc(void *h) { FsCall c(h); c.fs->setPrecalcValues(); }
+// FullSystem::flagPointsForRemoval (:1208-1290) and FullSystem::marginalizeFrame (:602-640): the members themselves
+void ref_fs_flag_points_for_removal(void *h) { FsCall c(h); c.fs->flagPointsForRemoval(); }
+void ref_fs_flag_frame(void *h, int idx) { ((RefWindow *) h)->ef->frames[idx]->flaggedForMarginalization = true; }
+void ref_fs_marginalize_frame(void *h, int idx) {
+    FsCall c(h);
+    shared_ptr<Frame> fr = c.fs->frames[idx];
+    // marginalizeFrame ends with frame->ReleaseAll(): ~FrameHessian would delete[] the pyramid, which lives in imageStore here
+    for (int l = 0; l < PYR_LEVELS; l++) { fr->frameHessian->dIp[l] = nullptr; fr->frameHessian->absSquaredGrad[l] = nullptr; }
+    c.fs->marginalizeFrame(fr);
 }
 
 // ---- FrameHessian::makeImages (FrameHessian.cc:44-113) -----------------------------------------------------------------------

@@ -1,11 +1,27 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY.  glog stand-in: LOG(x) << ... is swallowed, LOG(FATAL) aborts.
+// ORACLE — TEST INFRASTRUCTURE ONLY.  glog stand-in: LOG(x) << ... is swallowed, LOG(FATAL) aborts.  While ref_shim::log_capture points
+// at a string, everything streamed into LOG(...) is appended to it instead: FullSystem::optimize reports its per-iteration energies only
+// through printOptRes -> LOG(INFO) (FullSystem.cc:1795-1807), and the pin reads them from there (ref_driver.cc: ref_fs_optimize).
 #pragma once
 #include <cstdlib>
 #include <iostream>
+#include <sstream>
+#include <string>
+#include <type_traits>
+#include <utility>
 namespace ref_shim {
-struct NullLog { bool fatal; explicit NullLog(bool f) : fatal(f) {} ~NullLog() { if (fatal) { std::cerr << "LOG(FATAL) in reference code" << std::endl; std::abort(); } }
-    template <class T> NullLog &operator<<(const T &) { return *this; }
-    NullLog &operator<<(std::ostream &(*)(std::ostream &)) { return *this; } };
+inline std::string *&log_capture_slot() { static std::string *p = nullptr; return p; }
+template <class T, class = void> struct is_streamable : std::false_type {};
+template <class T> struct is_streamable<T, std::void_t<decltype(std::declval<std::ostream &>() << std::declval<const T &>())>> : std::true_type {};
+struct NullLog {
+    bool fatal; std::ostringstream *os;
+    explicit NullLog(bool f) : fatal(f), os(log_capture_slot() ? new std::ostringstream() : nullptr) {}
+    ~NullLog() {
+        if (os) { if (log_capture_slot()) *log_capture_slot() += os->str(); delete os; }
+        if (fatal) { std::cerr << "LOG(FATAL) in reference code" << std::endl; std::abort(); }
+    }
+    template <class T> NullLog &operator<<(const T &v) { if constexpr (is_streamable<T>::value) { if (os) *os << v; } return *this; }
+    NullLog &operator<<(std::ostream &(*f)(std::ostream &)) { if (os) *os << f; return *this; }
+};
 }
 #define INFO 0
 #define WARNING 1

@@ -8,11 +8,20 @@
 
 namespace Sophus {
 
+// Eigen::Quaterniond as FullSystem.cc uses it: Sophus::Quaterniond(w, x, y, z) in the motion-hypothesis list of trackNewCoarse (:228-303)
+// and the unit_quaternion() accessors of printResult (:1942-1945)
+struct Quaterniond {
+    double w_, x_, y_, z_;
+    Quaterniond(double w, double x, double y, double z) : w_(w), x_(x), y_(y), z_(z) {}
+    double w() const { return w_; } double x() const { return x_; } double y() const { return y_; } double z() const { return z_; }
+};
+
 class SO3d {
 public:
     orc::Quat q;
     SO3d() {}
     explicit SO3d(const orc::Quat &q_) : q(q_) {}
+    Quaterniond unit_quaternion() const { return Quaterniond(q.w, q.x, q.y, q.z); }
     Eigen::Matrix3d matrix() const { orc::Mat33 R = q.toRotationMatrix(); Eigen::Matrix3d m; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) m(i, j) = R(i, j); return m; }
     SO3d inverse() const { return SO3d(q.conjugate()); }
 };
@@ -27,6 +36,17 @@ public:
     SE3d(const Eigen::Base<DR, double, 3, 3> &R, const Eigen::Base<DT, double, 3, 1> &t) {
         orc::Mat33 Rm; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Rm(i, j) = R(i, j);
         T.q = orc::Quat::fromRotationMatrix(Rm); T.q.normalize();
+        for (int i = 0; i < 3; i++) T.t[i] = t[i];
+    }
+    // SE3(Matrix4): map I/O only (Frame.cc:163)
+    explicit SE3d(const Eigen::Matrix4d &m) {
+        orc::Mat33 Rm; for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) Rm(i, j) = m(i, j); T.t[i] = m(i, 3); }
+        T.q = orc::Quat::fromRotationMatrix(Rm); T.q.normalize();
+    }
+    // SE3(Quaternion, Point) -> SO3(Quaternion): the quaternion is normalised (thirdparty/sophus/so3.hpp: SO3Group(QuaternionBase) ctor)
+    template <class DT>
+    SE3d(const Quaterniond &q, const Eigen::Base<DT, double, 3, 1> &t) {
+        T.q = orc::Quat(q.w_, q.x_, q.y_, q.z_); T.q.normalize();
         for (int i = 0; i < 3; i++) T.t[i] = t[i];
     }
     static SE3d exp(const Eigen::Matrix<double, 6, 1> &a) { orc::Vec6 v; for (int i = 0; i < 6; i++) v[i] = a[i]; return SE3d(orc::SE3::exp(v)); }

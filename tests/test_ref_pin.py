@@ -226,3 +226,144 @@ def test_coarse_initializer_tracks_the_reference():
             assert np.array_equal(a["isGood"], b["isGood"]) and np.array_equal(a["isGood_new"], b["isGood_new"])
             _close(a["idepth"], b["idepth"], 1e-4, f"idepth[{l}] frame {k}"); _close(a["iR"], b["iR"], 1e-4, f"iR[{l}] frame {k}")
     assert snapped_seen
+
+
+# ---- the FullSystem.cc slice (round 3): the reference's own members, FullSystem.cc compiled unmodified --------------------------------
+def _compare_window_state(o, r, tol_state=1e-12, what=""):
+    """Everything optimize() leaves behind that the adapter writes back / the next stage reads."""
+    fo, fr = o.get_frames(), r.get_frames()
+    _same(fo["frames"]["frameEnergyTH"], fr["frames"]["frameEnergyTH"], what + "frameEnergyTH (setNewFrameEnergyTH)")
+    for k in ("state", "state_zero", "worldToCam_evalPT"):
+        assert np.abs(fo["frames"][k] - fr["frames"][k]).max() <= tol_state, what + k      # x passes through orthogonalize(): 1e-17 observed
+    assert np.abs(fo["step"] - fr["step"]).max() <= tol_state and np.abs(fo["calib_value"] - fr["calib_value"]).max() <= tol_state
+    assert np.abs(fo["pre_worldToCam"] - fr["pre_worldToCam"]).max() <= tol_state
+    (pto, so), (ptr, sr) = o.get_points(), r.get_points()
+    _same(so, sr, what + "point status")
+    for k in ("idepth", "maxRelBaseline", "numGoodResiduals"):
+        _same(pto[k], ptr[k], what + "point." + k)
+    _close(pto["HdiF"], ptr["HdiF"], 1e-6, what + "HdiF"); _close(pto["idepth_hessian"], ptr["idepth_hessian"], 1e-6, what + "idepth_hessian")
+    ro, rr = o.get_residuals(), r.get_residuals()
+    for k in ("state_state", "is_active", "alive", "is_linearized"):
+        _same(ro[k], rr[k], what + k)
+    live = rr["alive"] != 0
+    _same(ro["out"]["JpJdF"][live], rr["out"]["JpJdF"][live], what + "JpJdF")
+    _same(ro["out"]["state_NewEnergy"][live], rr["out"]["state_NewEnergy"][live], what + "state_NewEnergy")
+    assert o.counts() == r.counts()
+    return rr
+
+
+@pytest.mark.parametrize("name,iters", [("tiny", 6), ("small", 6), ("C3", 4)])
+def test_fullsystem_optimize_pinned(name, iters):
+    """float FullSystem::optimize(int) (FullSystem.cc:725-864) itself - activeResiduals, linearizeAll(false) + setNewFrameEnergyTH,
+    applyRes, backupState, solveSystem, doStepFromBackup incl. the `canbreak` rule, the final setEvalPT / linearizeAll(true) with residual
+    removal - against the oracle's restatement: return value and every printed energy identical, flags / thresholds / inverse depths bit
+    for bit, frame states to 1e-12 (x passes through orthogonalize(), see test_stage_bit_exact_orthogonalized_iteration)."""
+    win = synth.add_synthetic_prior(copy.deepcopy(get_window(name))) if name == "C3" else get_window(name)
+    o, r = po.OracleWindow(win), pr.RefWindow(win)
+    r.fs_attach()
+    rv_r, log_r = r.fs_optimize(iters)
+    rv_o = o.optimize(iters); log_o = o.energy_log()
+    assert rv_r == rv_o and np.isfinite(rv_r)
+    # printOptRes prints the energy once before the loop and once per executed iteration (%f: six decimals); the oracle's log also holds the
+    # final linearizeAll(true).  Equal length = the loop ended (canbreak && iteration >= setting_minOptIterations) at the same iteration.
+    assert len(log_o) == len(log_r) + 1, (log_o, log_r)
+    assert np.abs(log_o[:-1] - log_r).max() <= 1e-6 + 1e-12 * np.abs(log_r).max()
+    assert not r.fs_is_lost()
+    _compare_window_state(o, r)
+
+
+def test_fullsystem_optimize_drops_residuals_like_the_reference(small):
+    """linearizeAll(true) (FullSystem.cc:1472-1492) removes the residuals that ended OOB / OUTLIER and updates lastResiduals: a window whose
+    newest frame is badly perturbed so that residuals really go (the other tests rarely drop any)."""
+    win = copy.deepcopy(small)
+    win.frames["state"][-1, :3] += 0.08            # a few pixels of parallax error for every residual into / out of the newest frame
+    o, r = po.OracleWindow(win), pr.RefWindow(win)
+    r.fs_attach()
+    rv_r, log_r = r.fs_optimize(1)
+    rv_o = o.optimize(1)
+    assert rv_r == rv_o
+    rr = _compare_window_state(o, r)
+    assert 0 < (rr["alive"] == 0).sum() < win.R, "the scenario is meant to drop some residuals"
+
+
+def test_fullsystem_stage_members_pinned(small):
+    """The private members one by one, in the order optimize() calls them: linearizeAll(false) -> Vec3 + frameEnergyTH, applyRes_Reductor,
+    backupState, solveSystem, doStepFromBackup -> canbreak, loadSateBackup, calcLEnergy / calcMEnergy."""
+    win = po.make_mixed_window(synth.add_synthetic_prior(copy.deepcopy(small)))
+    win.settings = win.settings.copy(); win.settings["forceAcceptStep"] = 0          # calcLEnergy / calcMEnergy return 0 when steps are forced
+    o, r = po.OracleWindow(win), pr.RefWindow(win)
+    r.fs_attach()
+    o.collect_active(); r.fs_collect_active()
+    Eo, Er = o.linearize_all(False), r.fs_linearize_all(False)
+    assert Eo == Er[0] and Er[1] == 0 and Er[2] == 0
+    fo, fr = o.get_frames(), r.get_frames()
+    _same(fo["frames"]["frameEnergyTH"], fr["frames"]["frameEnergyTH"], "setNewFrameEnergyTH")
+    assert fr["frames"]["frameEnergyTH"][-1] != win.frames["frameEnergyTH"][-1]
+    (mo, lo), (lr, mr) = o.calc_lm_energies(), r.fs_calc_energies()
+    assert mo == mr and abs(lo - lr) <= 1e-9 * abs(lr) and lr > 0 and mr > 0
+    o.apply_res(); r.fs_apply_res()
+    for it in range(3):
+        o.backup_state(); r.fs_backup_state(it != 0)
+        o.solve_system(it); r.fs_solve_system(it)
+        so, sr = o.get_system(), r.get_system()
+        _same(so["lastHS"], sr["lastHS"], "lastHS"); _same(so["lastbS"], sr["lastbS"], "lastbS")
+        cb_o, cb_r = o.do_step(), r.fs_do_step(1.0)
+        assert cb_o == cb_r
+        fo, fr = o.get_frames(), r.get_frames()
+        assert np.abs(fo["frames"]["state"] - fr["frames"]["state"]).max() <= 1e-12
+        assert np.abs(fo["pre_worldToCam"] - fr["pre_worldToCam"]).max() <= 1e-12
+        _close(o.get_precalc(), r.get_precalc(), 1e-6, "precalc after doStepFromBackup")
+        (pto, _), (ptr, _) = o.get_points(), r.get_points()
+        _close(pto["idepth"], ptr["idepth"], 1e-6, "idepth after doStepFromBackup")
+        Eo, Er = o.linearize_all(False), r.fs_linearize_all(False)
+        assert abs(Eo - Er[0]) <= 1e-6 * abs(Er[0])
+        o.apply_res(); r.fs_apply_res()
+    # loadSateBackup (FullSystem.cc:1662-1680): back to the state of the last backupState
+    before = r.get_frames()["frames"]["state"].copy()
+    r.fs_load_state_backup()
+    after = r.get_frames()["frames"]["state"]
+    assert np.abs(after - before).max() > 0
+
+
+def test_fullsystem_canbreak_rule(small):
+    """doStepFromBackup's convergence test (FullSystem.cc:1617-1622) on both sides of the threshold: a zero step can break, the first real
+    step of a perturbed window cannot."""
+    o, r = po.OracleWindow(small), pr.RefWindow(small)
+    r.fs_attach()
+    o.collect_active(); r.fs_collect_active()
+    o.linearize_all(False); r.fs_linearize_all(False); o.apply_res(); r.fs_apply_res()
+    o.backup_state(); r.fs_backup_state(False)
+    assert o.do_step() and r.fs_do_step(1.0), "all steps are zero before the first solve: canbreak"
+    o.solve_system(0); r.fs_solve_system(0)
+    assert (not o.do_step()) and (not r.fs_do_step(1.0))
+
+
+def test_fullsystem_marginalization_members_pinned(small):
+    """FullSystem::flagPointsForRemoval (FullSystem.cc:1208-1270: OOB / inlier policy, re-linearise + fixLinearizationF) and
+    FullSystem::marginalizeFrame (:602-640) - the members themselves - against the oracle's restatement of both."""
+    win = synth.add_synthetic_prior(copy.deepcopy(small))
+    o, r = po.OracleWindow(win), pr.RefWindow(win)
+    r.fs_attach()
+    o.optimize(3); r.fs_optimize(3)
+    o.flag_frame(0); r.fs_flag_frame(0)
+    o.flag_points_for_removal(); r.fs_flag_points_for_removal()
+    (_, so), (_, sr) = o.get_points(), r.get_points()
+    _same(so % 100, sr % 100, "point status after flagPointsForRemoval")
+    assert (sr % 100 == 3).sum() > 10
+    ro, rr = o.get_residuals(), r.get_residuals()
+    marg = np.isin(win.residuals["point"], np.nonzero(sr % 100 == 3)[0]) & (rr["alive"] != 0)
+    act = marg & (rr["is_active"] != 0)
+    assert act.sum() > 10
+    _close(ro["res_toZeroF"][act], rr["res_toZeroF"][act], 1e-5, "fixLinearizationF res_toZeroF")
+    _same(ro["is_active"][marg], rr["is_active"][marg], "is_active of re-linearised residuals")
+    o.drop_points(); r.drop_points()
+    o.marginalize_points(); r.marginalize_points()
+    for a, b, n in zip(o.get_prior(), r.get_prior(), ("HM after marginalizePointsF", "bM after marginalizePointsF")):
+        _close(a, b, 1e-9, n)
+    o.marginalize_frame(0); r.fs_marginalize_frame(0)
+    (HMo, bMo), (HMr, bMr) = o.get_prior(), r.get_prior()
+    assert HMo.shape == HMr.shape == (8 * (win.F - 1) + 4,) * 2
+    _close(HMo, HMr, 1e-9, "HM after marginalizeFrame"); _close(bMo, bMr, 1e-9, "bM after marginalizeFrame")
+    assert o.num_frames() == r.num_frames() == win.F - 1
+    ro, rr = o.get_residuals(), r.get_residuals()
+    _same(ro["alive"], rr["alive"], "residuals dropped with the frame")
