@@ -1,0 +1,460 @@
+// ldso_gpu_adapter.cc — see ldso_gpu_adapter.h.  Compiles against the reference's headers (LDSO include/ + its Eigen / Sophus) and links
+// libldso_hip.so; every function is the replacement body of the reference member function it cites.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <deque>
+#include <iostream>
+#include <list>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <queue>
+#include <set>
+#include <sstream>
+#include <string>
+#include <thread>
+#include <vector>
+#include <unistd.h>
+
+#ifndef LDSO_ADAPTER_OPEN_PRIVATE
+#define LDSO_ADAPTER_OPEN_PRIVATE 1      // see the header: stands in for `friend class ldso::GpuBackend;` in FullSystem.h / CoarseTracker.h
+#endif
+#if LDSO_ADAPTER_OPEN_PRIVATE
+#include <Eigen/Core>
+#include <glog/logging.h>
+#define private public
+#define protected public
+#include "frontend/CoarseTracker.h"
+#include "frontend/FullSystem.h"
+#undef private
+#undef protected
+#endif
+#include "ldso_gpu_adapter.h"
+
+#include "internal/CalibHessian.h"
+#include "internal/FrameHessian.h"
+#include "internal/GlobalCalib.h"
+#include "internal/OptimizationBackend/EnergyFunctional.h"
+#include "internal/PointHessian.h"
+#include "internal/Residuals.h"
+
+using namespace ldso::internal;
+
+namespace ldso {
+
+namespace {
+
+void throwOn(int rc, const char *what) {
+    if (rc != LDSO_OK && rc != LDSO_E_NONFINITE) throw std::runtime_error(std::string(what) + ": " + ldso_last_error());
+}
+void toRowMajor34(const SE3 &T, double *m) {
+    Eigen::Matrix<double, 3, 4> M = T.matrix3x4();
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 4; j++) m[i * 4 + j] = M(i, j);
+}
+SE3 fromRowMajor34(const double *m) {
+    Mat33 R; Vec3 t;
+    for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) R(i, j) = m[i * 4 + j]; t[i] = m[i * 4 + 3]; }
+    return SE3(R, t);
+}
+ldso_calib_t flatCalib(const CalibHessian &c) {
+    ldso_calib_t o;
+    for (int i = 0; i < 4; i++) { o.value[i] = c.value[i]; o.value_zero[i] = c.value_zero[i]; }
+    return o;
+}
+ldso_settings_t flatSettings() {      // the setting_* globals the hot path reads (Settings.h), as the library's ldso_settings_t
+    ldso_settings_t s;
+    ldso_settings_default(&s);
+    s.huberTH = setting_huberTH; s.outlierTHSumComponent = setting_outlierTHSumComponent;
+    s.affineOptModeA = setting_affineOptModeA; s.affineOptModeB = setting_affineOptModeB;
+    s.frameEnergyTHN = setting_frameEnergyTHN; s.frameEnergyTHFacMedian = setting_frameEnergyTHFacMedian;
+    s.frameEnergyTHConstWeight = setting_frameEnergyTHConstWeight; s.overallEnergyTHWeight = setting_overallEnergyTHWeight;
+    s.initialCalibHessian = setting_initialCalibHessian; s.margWeightFac = setting_margWeightFac;
+    s.idepthFixPriorMargFac = setting_idepthFixPriorMargFac; s.thOptIterations = setting_thOptIterations;
+    s.coarseCutoffTH = setting_coarseCutoffTH; s.minOptIterations = setting_minOptIterations;
+    s.solverMode = setting_solverMode; s.forceAcceptStep = setting_forceAceptStep ? 1 : 0; s.solverModeDelta = setting_solverModeDelta;
+    return s;
+}
+void toRaw(const RawResidualJacobian &J, ldso_rawjac_t &j) {
+    for (int i = 0; i < 8; i++) { j.resF[i] = J.resF[i]; j.JIdx[0][i] = J.JIdx[0][i]; j.JIdx[1][i] = J.JIdx[1][i]; j.JabF[0][i] = J.JabF[0][i]; j.JabF[1][i] = J.JabF[1][i]; }
+    for (int i = 0; i < 6; i++) { j.Jpdxi[0][i] = J.Jpdxi[0][i]; j.Jpdxi[1][i] = J.Jpdxi[1][i]; }
+    for (int i = 0; i < 4; i++) { j.Jpdc[0][i] = J.Jpdc[0][i]; j.Jpdc[1][i] = J.Jpdc[1][i]; }
+    j.Jpdd[0] = J.Jpdd[0]; j.Jpdd[1] = J.Jpdd[1];
+    for (int a = 0; a < 2; a++) for (int b = 0; b < 2; b++) { j.JIdx2[a * 2 + b] = J.JIdx2(a, b); j.JabJIdx[a * 2 + b] = J.JabJIdx(a, b); j.Jab2[a * 2 + b] = J.Jab2(a, b); }
+}
+void fromRaw(const ldso_rawjac_t &j, RawResidualJacobian &J) {
+    for (int i = 0; i < 8; i++) { J.resF[i] = j.resF[i]; J.JIdx[0][i] = j.JIdx[0][i]; J.JIdx[1][i] = j.JIdx[1][i]; J.JabF[0][i] = j.JabF[0][i]; J.JabF[1][i] = j.JabF[1][i]; }
+    for (int i = 0; i < 6; i++) { J.Jpdxi[0][i] = j.Jpdxi[0][i]; J.Jpdxi[1][i] = j.Jpdxi[1][i]; }
+    for (int i = 0; i < 4; i++) { J.Jpdc[0][i] = j.Jpdc[0][i]; J.Jpdc[1][i] = j.Jpdc[1][i]; }
+    J.Jpdd[0] = j.Jpdd[0]; J.Jpdd[1] = j.Jpdd[1];
+    for (int a = 0; a < 2; a++) for (int b = 0; b < 2; b++) { J.JIdx2(a, b) = j.JIdx2[a * 2 + b]; J.JabJIdx(a, b) = j.JabJIdx[a * 2 + b]; J.Jab2(a, b) = j.Jab2[a * 2 + b]; }
+}
+
+}  // namespace
+
+GpuBackend::GpuBackend(int device, int maxFrames, int maxPoints) : device_(device), maxFrames_(maxFrames), maxPoints_(maxPoints) {
+    throwOn(ldso_ba_create(device, wG[0], hG[0], maxFrames, maxPoints, &ba_), "ldso_ba_create");
+    slotOwner_.assign(maxFrames, nullptr);
+}
+
+GpuBackend::~GpuBackend() {
+    for (auto &kv : trackers_) ldso_tr_destroy(kv.second);
+    if (ba_) ldso_ba_destroy(ba_);
+}
+
+const char *GpuBackend::lastError() const { return ldso_last_error(); }
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// Images: FrameHessian::dIp[0] of a key frame goes to the device once, when the frame first appears in the window; its slot is
+// recycled when the frame has left (FullSystem::marginalizeFrame).
+// ------------------------------------------------------------------------------------------------------------------------------------
+void GpuBackend::syncImageSlots(FullSystem &fs, std::vector<int32_t> &slots) {
+    std::set<FrameHessian *> live;
+    for (auto &fr : fs.frames) live.insert(fr->frameHessian.get());
+    for (size_t s = 0; s < slotOwner_.size(); s++)
+        if (slotOwner_[s] && !live.count(slotOwner_[s])) { slotOf_.erase(slotOwner_[s]); slotOwner_[s] = nullptr; }
+    slots.clear();
+    for (auto &fr : fs.frames) {
+        FrameHessian *fh = fr->frameHessian.get();
+        auto it = slotOf_.find(fh);
+        if (it == slotOf_.end()) {
+            size_t s = 0;
+            while (s < slotOwner_.size() && slotOwner_[s]) s++;
+            if (s == slotOwner_.size()) throw std::runtime_error("GpuBackend: more key frames than maxFrames");
+            throwOn(ldso_ba_set_image(ba_, (int) s, (const float *) fh->dIp[0]), "ldso_ba_set_image");      // Vec3f AoS (I, dx, dy): a straight copy
+            slotOwner_[s] = fh; it = slotOf_.emplace(fh, (int) s).first;
+        }
+        slots.push_back(it->second);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// Flatten the window in the reference's own orders: frames = FullSystem::frames (= EnergyFunctional::frames, idx = position), points in
+// the order of EnergyFunctional::makeIDX (EnergyFunctional.cc:380-401: frames, then the host frame's features), residuals in
+// PointHessian::residuals order; a residual's slot is (hostIDX, targetIDX).  allPoints / flat give the write-back its objects.
+// ------------------------------------------------------------------------------------------------------------------------------------
+int GpuBackend::uploadWindow(FullSystem &fs, std::vector<shared_ptr<PointHessian>> &allPoints, std::vector<shared_ptr<PointFrameResidual>> &flat) {
+    const ldso_settings_t st = flatSettings();
+    throwOn(ldso_ba_set_settings(ba_, &st), "ldso_ba_set_settings");
+    std::vector<int32_t> slots;
+    syncImageSlots(fs, slots);
+    const int F = (int) fs.frames.size();
+    std::vector<ldso_frame_t> Fv((size_t) F);
+    for (int f = 0; f < F; f++) {
+        FrameHessian &fh = *fs.frames[f]->frameHessian;
+        fh.idx = f;
+        ldso_frame_t &o = Fv[f];
+        memset(&o, 0, sizeof(o));
+        toRowMajor34(fh.get_worldToCam_evalPT(), o.worldToCam_evalPT);
+        for (int i = 0; i < 10; i++) { o.state[i] = fh.get_state()[i]; o.state_zero[i] = fh.get_state_zero()[i]; }
+        for (int i = 0; i < 8; i++) o.prior[i] = fh.prior[i];                                      // FrameHessian::takeData (FrameHessian.cc:115)
+        for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) o.nullspaces_pose[r * 6 + c] = fh.nullspaces_pose(r, c);
+        for (int r = 0; r < 6; r++) o.nullspaces_scale[r] = fh.nullspaces_scale[r];
+        for (int r = 0; r < 4; r++) for (int c = 0; c < 2; c++) o.nullspaces_affine[r * 2 + c] = fh.nullspaces_affine(r, c);
+        o.ab_exposure = fh.ab_exposure; o.frameEnergyTH = fh.frameEnergyTH; o.frameID = (int32_t) fh.frame->id;   // getPrior keys on frame->id == 0
+    }
+    allPoints.clear(); flat.clear();
+    std::vector<ldso_point_t> P; std::vector<ldso_residual_t> R; std::vector<ldso_rawjac_t> LJ; std::vector<float> RTZ, mrb; std::vector<int32_t> ngr;
+    bool anyLin = false;
+    for (int f = 0; f < F; f++)
+        for (shared_ptr<Feature> &feat : fs.frames[f]->features) {
+            if (!(feat->status == Feature::FeatureStatus::VALID && feat->point && feat->point->status == Point::PointStatus::ACTIVE)) continue;
+            shared_ptr<PointHessian> ph = feat->point->mpPH;
+            ldso_point_t p;
+            memset(&p, 0, sizeof(p));
+            p.u = ph->u; p.v = ph->v; p.idepth = ph->idepth; p.idepth_zero = ph->idepth_zero; p.priorF = ph->priorF;
+            memcpy(p.color, ph->color, sizeof(p.color)); memcpy(p.weights, ph->weights, sizeof(p.weights));
+            p.host = f; p.res_begin = (int32_t) R.size(); p.res_count = (int32_t) ph->residuals.size();
+            for (shared_ptr<PointFrameResidual> &r : ph->residuals) {
+                r->hostIDX = r->host.lock()->idx; r->targetIDX = r->target.lock()->idx;           // makeIDX
+                ldso_residual_t q;
+                q.point = (int32_t) P.size(); q.host = r->hostIDX; q.target = r->targetIDX; q.state_state = (int32_t) r->state_state;
+                q.is_linearized = r->isLinearized ? 1 : 0; q.is_active = r->isActive() ? 1 : 0; q.is_new = r->isNew ? 1 : 0; q.state_energy = (float) r->state_energy;
+                R.push_back(q); flat.push_back(r);
+                ldso_rawjac_t j;
+                memset(&j, 0, sizeof(j));
+                if (r->isLinearized) { toRaw(*r->J, j); anyLin = true; }
+                LJ.push_back(j);
+                for (int k = 0; k < 8; k++) RTZ.push_back(r->isLinearized ? r->res_toZeroF[k] : 0.0f);
+            }
+            P.push_back(p); allPoints.push_back(ph);
+            mrb.push_back(ph->maxRelBaseline); ngr.push_back(ph->numGoodResiduals);
+        }
+    if (P.empty()) return 0;
+    throwOn(ldso_ba_set_window(ba_, F, slots.data(), (int) P.size(), P.data(), (int) R.size(), R.data(), anyLin ? LJ.data() : nullptr, anyLin ? RTZ.data() : nullptr), "ldso_ba_set_window");
+    throwOn(ldso_ba_set_point_stats(ba_, mrb.data(), ngr.data()), "ldso_ba_set_point_stats");
+    const ldso_calib_t c = flatCalib(*fs.Hcalib->mpCH);
+    throwOn(ldso_ba_set_frames(ba_, Fv.data(), &c), "ldso_ba_set_frames");                      // setAdjointsF + setPrecalcValues on the device
+    const int n = CPARS + 8 * F;
+    if ((int) fs.ef->HM.rows() == n) {
+        std::vector<double> HM((size_t) n * n), bM((size_t) n);
+        for (int i = 0; i < n; i++) { for (int j = 0; j < n; j++) HM[(size_t) i * n + j] = fs.ef->HM(i, j); bM[i] = fs.ef->bM[i]; }
+        throwOn(ldso_ba_set_prior(ba_, HM.data(), bM.data()), "ldso_ba_set_prior");
+    }
+    return (int) P.size();
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// float FullSystem::optimize(int mnumOptIts)                                                                       FullSystem.cc:725-864
+// ------------------------------------------------------------------------------------------------------------------------------------
+float GpuBackend::optimize(FullSystem &fs, int mnumOptIts) {
+    if (fs.frames.size() < 2) return 0;
+    if (fs.frames.size() < 3) mnumOptIts = 20;
+    if (fs.frames.size() < 4) mnumOptIts = 15;
+
+    std::vector<shared_ptr<PointHessian>> allPoints;
+    std::vector<shared_ptr<PointFrameResidual>> flat;
+    if (uploadWindow(fs, allPoints, flat) == 0) return 0;
+    const int F = (int) fs.frames.size(), P = (int) allPoints.size(), R = (int) flat.size();
+
+    // activeResiduals (:735-755) stays what the reference's later stages expect: the non-linearised residuals in traversal order
+    fs.activeResiduals.clear();
+    for (auto &r : flat) if (!r->isLinearized) fs.activeResiduals.push_back(r);
+
+    // the whole loop of :757-843 and the tail :845-851 (re-anchor the newest frame, adjoints, precalc, linearizeAll(true)) on the device
+    float rmse = 0;
+    const int rc = ldso_ba_optimize(ba_, mnumOptIts, /*force_all_iterations*/ 0, &rmse, &lastIterations);
+    throwOn(rc, "ldso_ba_optimize");
+    if (rc == LDSO_E_NONFINITE) { LOG(WARNING) << "KF Tracking failed: LOST!"; fs.isLost = true; }         // :853-857
+
+    // ---- write back ----------------------------------------------------------------------------------------------------------------
+    std::vector<ldso_res_out_t> ro((size_t) R); std::vector<int32_t> st((size_t) R), act((size_t) R), rem((size_t) R);
+    std::vector<ldso_point_out_t> po((size_t) P); std::vector<ldso_frame_t> fo((size_t) F); std::vector<double> fstep((size_t) F * 10);
+    double cv[4], cs[4];
+    throwOn(ldso_ba_get_residuals(ba_, ro.data(), st.data(), act.data(), rem.data()), "ldso_ba_get_residuals");
+    throwOn(ldso_ba_get_points(ba_, po.data()), "ldso_ba_get_points");
+    throwOn(ldso_ba_get_frames(ba_, fo.data(), fstep.data(), cv, cs, nullptr), "ldso_ba_get_frames");
+    std::vector<ldso_rawjac_t> Jv;
+    if (writeBackJacobians) {
+        std::vector<int32_t> ids((size_t) R);
+        for (int i = 0; i < R; i++) ids[i] = i;
+        Jv.resize((size_t) R);
+        throwOn(ldso_ba_get_jacobians(ba_, ids.data(), R, Jv.data()), "ldso_ba_get_jacobians");
+    }
+
+    // calibration and frames: the states through the reference's own setters (they rebuild state_scaled, PRE_worldToCam / PRE_camToWorld);
+    // the newest frame was re-anchored (:845-848: setEvalPT(PRE_worldToCam, [0..0, a, b, 0, 0]))
+    VecC v, vs;
+    for (int i = 0; i < 4; i++) { v[i] = cv[i]; vs[i] = cs[i]; }
+    fs.Hcalib->mpCH->setValue(v); fs.Hcalib->mpCH->step = vs;
+    for (int f = 0; f < F; f++) {
+        FrameHessian &fh = *fs.frames[f]->frameHessian;
+        Vec10 s;
+        for (int i = 0; i < 10; i++) { s[i] = fo[f].state[i]; fh.step[i] = fstep[(size_t) f * 10 + i]; }
+        if (f == F - 1) fh.setEvalPT(fromRowMajor34(fo[f].worldToCam_evalPT), s); else fh.setState(s);
+        fh.frameEnergyTH = fo[f].frameEnergyTH;                                                  // setNewFrameEnergyTH (:1762-1793)
+    }
+    // points (doStepFromBackup :1595-1606, AccumulatedSCHessian.cc:9-51, the fixing pass :1521-1536)
+    for (int k = 0; k < P; k++) {
+        PointHessian &ph = *allPoints[k];
+        ph.setIdepth(po[k].idepth); ph.setIdepthZero(po[k].idepth);
+        ph.step = po[k].step; ph.HdiF = po[k].HdiF; ph.bdSumF = po[k].bdSumF; ph.idepth_hessian = po[k].idepth_hessian;
+        ph.Hdd_accAF = po[k].Hdd_accAF; ph.bd_accAF = po[k].bd_accAF; ph.Hdd_accLF = po[k].Hdd_accLF; ph.bd_accLF = po[k].bd_accLF;
+        for (int i = 0; i < 4; i++) { ph.Hcd_accAF[i] = po[k].Hcd_accAF[i]; ph.Hcd_accLF[i] = po[k].Hcd_accLF[i]; }
+        ph.maxRelBaseline = po[k].maxRelBaseline; ph.numGoodResiduals = po[k].numGoodResiduals;
+    }
+    // residuals: applyRes(true) of the fixing pass (Residuals.h:70-87), lastResiduals bookkeeping and removal (:1472-1489)
+    for (int i = 0; i < R; i++) {
+        PointFrameResidual &r = *flat[i];
+        if (r.isLinearized) continue;                                                            // not in activeResiduals: untouched by optimize()
+        r.state_NewEnergy = ro[i].state_NewEnergy; r.state_NewEnergyWithOutlier = ro[i].state_NewEnergyWithOutlier; r.state_NewState = (ResState) ro[i].state_NewState;
+        r.state_state = (ResState) st[i]; r.state_energy = ro[i].state_NewEnergy; r.isActiveAndIsGoodNEW = act[i] != 0;
+        for (int k = 0; k < 3; k++) r.centerProjectedTo[k] = ro[i].centerProjectedTo[k];
+        for (int k = 0; k < 8; k++) r.JpJdF[k] = ro[i].JpJdF[k];
+        if (writeBackJacobians && r.state_NewState != ResState::OOB) fromRaw(Jv[i], *r.J);
+    }
+    for (int i = 0; i < R; i++) {
+        shared_ptr<PointFrameResidual> &r = flat[i];
+        if (r->isLinearized) continue;
+        shared_ptr<PointHessian> ph = r->point.lock();
+        if (ph->lastResiduals[0].first == r) ph->lastResiduals[0].second = r->state_state;
+        else if (ph->lastResiduals[1].first == r) ph->lastResiduals[1].second = r->state_state;
+    }
+    for (int i = 0; i < R; i++) {
+        if (!rem[i]) continue;
+        shared_ptr<PointFrameResidual> r = flat[i];
+        shared_ptr<PointHessian> ph = r->point.lock();
+        if (ph->lastResiduals[0].first == r) ph->lastResiduals[0].first = 0;
+        else if (ph->lastResiduals[1].first == r) ph->lastResiduals[1].first = 0;
+        fs.ef->dropResidual(r);                                                                   // EnergyFunctional.cc:44-56
+    }
+    int resInA = 0, resInL = 0;
+    throwOn(ldso_ba_get_counts(ba_, &resInA, &resInL), "ldso_ba_get_counts");
+    fs.ef->resInA = resInA; fs.ef->resInL = resInL;
+
+    // host mirrors of what the device computed on its side (:849-851): adjoints, pair precalc, deltas - the reference's own functions
+    EFDeltaValid = false; EFAdjointsValid = false;
+    fs.ef->setAdjointsF(fs.Hcalib->mpCH);
+    fs.setPrecalcValues();
+
+    // :859-869 unchanged: hand the estimated poses to the frames
+    {
+        unique_lock<mutex> crlock(fs.shellPoseMutex);
+        for (auto fr : fs.frames) {
+            fr->setPose(fr->frameHessian->PRE_camToWorld.inverse());
+            if (fr->kfId >= fs.globalMap->getLatestOptimizedKfId()) fr->setPoseOpti(Sim3(fr->getPose().matrix()));
+            fr->aff_g2l = fr->frameHessian->aff_g2l();
+        }
+    }
+    return rmse;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// Point activation: the optimizeImmaturePoint calls of FullSystem::activatePointsMT_Reductor (:1196-1206) as one device call, then the
+// object construction of optimizeImmaturePoint's tail (:977-1008) on the host.
+// ------------------------------------------------------------------------------------------------------------------------------------
+void GpuBackend::activatePoints(FullSystem &fs, std::vector<shared_ptr<ImmaturePoint>> &toOptimize, std::vector<shared_ptr<PointHessian>> &optimized) {
+    optimized.assign(toOptimize.size(), nullptr);
+    if (toOptimize.empty()) return;
+    std::vector<shared_ptr<PointHessian>> allPoints; std::vector<shared_ptr<PointFrameResidual>> flat;
+    if (uploadWindow(fs, allPoints, flat) == 0) throw std::runtime_error("GpuBackend::activatePoints: the window holds no active point yet (activate on the host)");
+    const int F = (int) fs.frames.size();
+    std::vector<ldso_immature_t> in(toOptimize.size());
+    for (size_t k = 0; k < toOptimize.size(); k++) {
+        ImmaturePoint &ip = *toOptimize[k];
+        ldso_immature_t &q = in[k];
+        memset(&q, 0, sizeof(q));
+        q.u = ip.feature->uv[0]; q.v = ip.feature->uv[1];
+        memcpy(q.color, ip.color, sizeof(q.color)); memcpy(q.weights, ip.weights, sizeof(q.weights));
+        q.gradH[0] = ip.gradH(0, 0); q.gradH[1] = ip.gradH(0, 1); q.gradH[2] = ip.gradH(1, 0); q.gradH[3] = ip.gradH(1, 1);
+        q.energyTH = ip.energyTH; q.idepth_min = ip.idepth_min; q.idepth_max = ip.idepth_max; q.quality = ip.quality;
+        q.lastTraceStatus = (int32_t) ip.lastTraceStatus; q.lastTraceUV[0] = ip.lastTraceUV[0]; q.lastTraceUV[1] = ip.lastTraceUV[1];
+        q.lastTracePixelInterval = ip.lastTracePixelInterval;
+        q.host = ip.feature->host.lock()->frameHessian->idx;
+    }
+    std::vector<ldso_activation_t> out(toOptimize.size());
+    throwOn(ldso_ba_activate_points(ba_, (int) in.size(), in.data(), /*minObs*/ 1, setting_minIdepthH_act, setting_GNItsOnPointActivation, out.data()), "ldso_ba_activate_points");
+    for (size_t k = 0; k < toOptimize.size(); k++) {
+        if (!out[k].ok) continue;                                                                // return 0 / nullptr (:924-926, :945-947, :968-975)
+        shared_ptr<ImmaturePoint> point = toOptimize[k];
+        point->feature->CreateFromImmature();                                                    // :977
+        shared_ptr<PointHessian> p = point->feature->point->mpPH;
+        p->lastResiduals[0].first = nullptr; p->lastResiduals[0].second = ResState::OOB;
+        p->lastResiduals[1].first = nullptr; p->lastResiduals[1].second = ResState::OOB;
+        p->setIdepthZero(out[k].idepth); p->setIdepth(out[k].idepth);
+        shared_ptr<FrameHessian> host = point->feature->host.lock()->frameHessian;
+        for (int t = 0; t < F; t++) {
+            if (out[k].res_state[t] != 0) continue;                                              // ResState::IN only (:989)
+            shared_ptr<FrameHessian> target = fs.frames[t]->frameHessian;
+            shared_ptr<PointFrameResidual> r(new PointFrameResidual(p, host, target));
+            r->state_NewEnergy = r->state_energy = 0; r->state_NewState = ResState::OUTLIER; r->setState(ResState::IN);
+            p->residuals.push_back(r);
+            if (target == fs.frames.back()->frameHessian) { p->lastResiduals[0].first = r; p->lastResiduals[0].second = ResState::IN; }
+            else if (target == (fs.frames.size() < 2 ? nullptr : fs.frames[fs.frames.size() - 2]->frameHessian)) { p->lastResiduals[1].first = r; p->lastResiduals[1].second = ResState::IN; }
+        }
+        optimized[k] = p;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// CoarseTracker
+// ------------------------------------------------------------------------------------------------------------------------------------
+ldso_tracker_t *GpuBackend::trackerOf(CoarseTracker &tr) {
+    auto it = trackers_.find(&tr);
+    if (it != trackers_.end()) return it->second;
+    ldso_tracker_t *t = nullptr;
+    throwOn(ldso_tr_create(device_, wG[0], hG[0], pyrLevelsUsed, &t), "ldso_tr_create");
+    trackers_[&tr] = t;
+    return t;
+}
+
+// void CoarseTracker::makeK(shared_ptr<CalibHessian>)                                                            CoarseTracker.cc:219-246
+void GpuBackend::makeK(CoarseTracker &tr, shared_ptr<CalibHessian> HCalib) {
+    tr.makeK(HCalib);                                  // the host copies (w[], h[], K[] ...) other LDSO code reads; 20 scalar operations
+    ldso_tracker_t *t = trackerOf(tr);
+    const ldso_settings_t st = flatSettings();
+    throwOn(ldso_tr_set_settings(t, &st), "ldso_tr_set_settings");
+    const ldso_calib_t c = flatCalib(*HCalib);
+    throwOn(ldso_tr_make_k(t, &c), "ldso_tr_make_k");
+}
+
+// void CoarseTracker::setCoarseTrackingRef(std::vector<shared_ptr<FrameHessian>> &)                               CoarseTracker.cc:248-256
+void GpuBackend::setCoarseTrackingRef(CoarseTracker &tr, std::vector<shared_ptr<FrameHessian>> &frameHessians) {
+    tr.lastRef = frameHessians.back();
+    // makeCoarseDepthL0's inputs (:264-283): every active point whose newest residual is IN, as (Ku, Kv, new_idepth, HdiF); the scatter, the
+    // pyramid of the depth map, the dilation and the point-cloud build (:285-438) run on the device
+    std::vector<float> pts;
+    for (shared_ptr<FrameHessian> &fh : frameHessians)
+        for (shared_ptr<Feature> &feat : fh->frame->features) {
+            if (!(feat->status == Feature::FeatureStatus::VALID && feat->point->status == Point::PointStatus::ACTIVE)) continue;
+            shared_ptr<PointHessian> ph = feat->point->mpPH;
+            if (ph->lastResiduals[0].first != 0 && ph->lastResiduals[0].second == ResState::IN) {
+                shared_ptr<PointFrameResidual> r = ph->lastResiduals[0].first;
+                pts.push_back(r->centerProjectedTo[0]); pts.push_back(r->centerProjectedTo[1]); pts.push_back(r->centerProjectedTo[2]); pts.push_back(ph->HdiF);
+            }
+        }
+    tr.refFrameID = tr.lastRef->frame->id;
+    tr.lastRef_aff_g2l = tr.lastRef->aff_g2l();
+    tr.firstCoarseRMSE = -1;
+    const float *pyr[PYR_LEVELS];
+    for (int l = 0; l < pyrLevelsUsed; l++) pyr[l] = (const float *) tr.lastRef->dIp[l];
+    throwOn(ldso_tr_set_ref(trackerOf(tr), pyr, tr.lastRef_aff_g2l.a, tr.lastRef_aff_g2l.b, tr.lastRef->ab_exposure, pts.data(), (int) (pts.size() / 4)), "ldso_tr_set_ref");
+}
+
+// bool CoarseTracker::trackNewestCoarse(newFrameHessian, lastToNew_out, aff_g2l_out, coarsestLvl, minResForAbort)  CoarseTracker.cc:61-217
+bool GpuBackend::trackNewestCoarse(CoarseTracker &tr, shared_ptr<FrameHessian> newFrameHessian, SE3 &lastToNew_out, AffLight &aff_g2l_out, int coarsestLvl,
+                                   Vec5 minResForAbort) {
+    ldso_tracker_t *t = trackerOf(tr);
+    tr.newFrame = newFrameHessian;
+    if (trackerNewFrame_ != newFrameHessian.get()) {          // the pyramid goes over once per frame, not once per hypothesis
+        const float *pyr[PYR_LEVELS];
+        for (int l = 0; l < pyrLevelsUsed; l++) pyr[l] = (const float *) newFrameHessian->dIp[l];
+        throwOn(ldso_tr_set_new_frame(t, pyr, newFrameHessian->ab_exposure), "ldso_tr_set_new_frame");
+        trackerNewFrame_ = newFrameHessian.get();
+    }
+    double T[12], mr[5], lr[5], fl[3];
+    float ab[2] = {(float) aff_g2l_out.a, (float) aff_g2l_out.b};
+    toRowMajor34(lastToNew_out, T);
+    for (int i = 0; i < 5; i++) mr[i] = minResForAbort[i];
+    int ok = 0, its = 0;
+    throwOn(ldso_tr_track(t, T, ab, coarsestLvl, mr, lr, fl, &ok, &its), "ldso_tr_track");
+    for (int i = 0; i < 5; i++) tr.lastResiduals[i] = lr[i];
+    for (int i = 0; i < 3; i++) tr.lastFlowIndicators[i] = fl[i];
+    // `return false` from the level loop (:188-189, residual above 1.5 x minResForAbort) leaves the outputs untouched; the affine sanity
+    // checks (:202-211) fail AFTER "set!" (:198-199)
+    bool aborted = false;
+    for (int l = coarsestLvl; l >= 0 && !aborted; l--) aborted = lr[l] > 1.5 * mr[l];
+    if (!aborted) { lastToNew_out = fromRowMajor34(T); aff_g2l_out = AffLight(ab[0], ab[1]); }
+    return ok != 0;
+}
+
+// Vec4 FullSystem::trackNewCoarse(shared_ptr<FrameHessian> fh)                                                   FullSystem.cc:179-386
+Vec4 GpuBackend::trackNewCoarse(FullSystem &fs, shared_ptr<FrameHessian> fh) {
+    CoarseTracker &tr = *fs.coarseTracker;
+    ldso_tracker_t *t = trackerOf(tr);
+    shared_ptr<FrameHessian> lastF = tr.lastRef;
+    tr.newFrame = fh;
+    if (trackerNewFrame_ != fh.get()) {
+        const float *pyr[PYR_LEVELS];
+        for (int l = 0; l < pyrLevelsUsed; l++) pyr[l] = (const float *) fh->dIp[l];
+        throwOn(ldso_tr_set_new_frame(t, pyr, fh->ab_exposure), "ldso_tr_set_new_frame");
+        trackerNewFrame_ = fh.get();
+    }
+    double sprelast[12], slast[12], lastFw2c[12];
+    float aff_last[2] = {0, 0};
+    int posesValid = 0;
+    if (fs.allFrameHistory.size() != 2) {                    // :192-195: with two frames in the history the reference ends up with an empty try list (its TODO)
+        shared_ptr<Frame> s1 = fs.allFrameHistory[fs.allFrameHistory.size() - 2], s2 = fs.allFrameHistory[fs.allFrameHistory.size() - 3];
+        unique_lock<mutex> crlock(fs.shellPoseMutex);
+        toRowMajor34(s2->getPose(), sprelast); toRowMajor34(s1->getPose(), slast); toRowMajor34(lastF->frame->getPose(), lastFw2c);
+        aff_last[0] = (float) s1->aff_g2l.a; aff_last[1] = (float) s1->aff_g2l.b;
+        posesValid = (s1->poseValid && s2->poseValid && lastF->frame->poseValid) ? 1 : 0;
+    } else {
+        const double I[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+        memcpy(sprelast, I, sizeof(I)); memcpy(slast, I, sizeof(I)); toRowMajor34(lastF->frame->getPose(), lastFw2c);
+    }
+    double rmse[5], res4[4], w2c[12];
+    float aff_out[2];
+    int tries = 0, good = 0;
+    for (int i = 0; i < 5; i++) rmse[i] = fs.lastCoarseRMSE[i];
+    throwOn(ldso_tr_track_new_coarse(t, sprelast, slast, lastFw2c, posesValid, aff_last, rmse, setting_reTrackThreshold, res4, w2c, aff_out, &tries, &good), "ldso_tr_track_new_coarse");
+    if (!good) LOG(WARNING) << "BIG ERROR! tracking failed entirely. Take predicted pose and hope we may somehow recover." << endl;
+    for (int i = 0; i < 5; i++) fs.lastCoarseRMSE[i] = rmse[i];
+    fh->frame->setPose(fromRowMajor34(w2c));                                                     // :376-377
+    fh->frame->aff_g2l = AffLight(aff_out[0], aff_out[1]);
+    if (tr.firstCoarseRMSE < 0) tr.firstCoarseRMSE = rmse[0];
+    return Vec4(res4[0], res4[1], res4[2], res4[3]);
+}
+
+}  // namespace ldso

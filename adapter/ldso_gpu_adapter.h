@@ -1,0 +1,70 @@
+// ldso_gpu_adapter.h — the host-side drop-in: LDSO's own types in, libldso_hip.so (include/ldso_hip.h, C-ABI) underneath.
+//
+// This is the code INTEGRATION.md describes, as a real translation unit against the reference's headers
+// (include/frontend/FullSystem.h, include/frontend/CoarseTracker.h, include/internal/*.h): every function below is the new BODY of the
+// reference member function it names.  Nothing of LDSO's object graph changes: Frame / Feature / Point / FrameHessian / PointHessian /
+// PointFrameResidual / CalibHessian / EnergyFunctional stay the owners of all state; the library owns device memory only.
+//
+//   GpuBackend::optimize(fs, n)                     float FullSystem::optimize(int mnumOptIts)                      FullSystem.cc:725-864
+//   GpuBackend::makeK / setCoarseTrackingRef        CoarseTracker::makeK / setCoarseTrackingRef                     CoarseTracker.cc:219-256
+//   GpuBackend::trackNewestCoarse                   bool CoarseTracker::trackNewestCoarse(...)                      CoarseTracker.cc:61-217
+//   GpuBackend::trackNewCoarse(fs, fh)              Vec4 FullSystem::trackNewCoarse(shared_ptr<FrameHessian>)       FullSystem.cc:179-386
+//   GpuBackend::activatePoints(fs, ...)             the optimizeImmaturePoint loop of activatePointsMT              FullSystem.cc:892-1010,1196-1206
+//
+// The functions reach into private members of FullSystem / CoarseTracker (frames, ef, activeResiduals, allFrameHistory, lastCoarseRMSE,
+// shellPoseMutex ...): a maintainer makes them member functions or adds `friend class ldso::GpuBackend;` to the two classes.  The reference tree
+// is read-only in this repository, so ldso_gpu_adapter.cc opens the access specifiers for its own inclusion of the two headers instead
+// (LDSO_ADAPTER_OPEN_PRIVATE) - the class layout is unchanged, the object files link against the reference's own.
+#pragma once
+#include <map>
+#include <memory>
+#include <vector>
+
+#include "frontend/CoarseTracker.h"
+#include "frontend/FullSystem.h"
+#include "internal/ImmaturePoint.h"
+#include "ldso_hip.h"
+
+namespace ldso {
+
+class GpuBackend {
+public:
+    // One backend per FullSystem (the BA handle belongs to the mapping thread, the tracker handles to whoever holds the respective
+    // CoarseTracker - the reference's mutex discipline, FullSystem.h:272-306).  Image size / pyramid depth come from the globals of
+    // internal/GlobalCalib.h (wG[0], hG[0], pyrLevelsUsed), like the reference's own constructors.
+    GpuBackend(int device, int maxFrames, int maxPoints);
+    ~GpuBackend();
+    GpuBackend(const GpuBackend &) = delete;
+    GpuBackend &operator=(const GpuBackend &) = delete;
+
+    // ---- windowed bundle adjustment -------------------------------------------------------------------------------------------------
+    float optimize(FullSystem &fs, int mnumOptIts);
+    bool writeBackJacobians = true;      // also store RawResidualJacobian (296 B per residual) back into r->J (host code that still reads J)
+    int lastIterations = 0;              // GN iterations the device executed in the last optimize()
+
+    // ---- coarse tracker -------------------------------------------------------------------------------------------------------------
+    void makeK(CoarseTracker &tr, shared_ptr<CalibHessian> HCalib);
+    void setCoarseTrackingRef(CoarseTracker &tr, std::vector<shared_ptr<FrameHessian>> &frameHessians);
+    bool trackNewestCoarse(CoarseTracker &tr, shared_ptr<FrameHessian> newFrameHessian, SE3 &lastToNew_out, AffLight &aff_g2l_out, int coarsestLvl,
+                           Vec5 minResForAbort);
+    Vec4 trackNewCoarse(FullSystem &fs, shared_ptr<FrameHessian> fh);
+
+    // ---- point activation (the optimizeImmaturePoint calls of activatePointsMT_Reductor) ---------------------------------------------
+    // optimized[k] = the new PointHessian of toOptimize[k] or nullptr, exactly what FullSystem::optimizeImmaturePoint returns
+    void activatePoints(FullSystem &fs, std::vector<shared_ptr<internal::ImmaturePoint>> &toOptimize, std::vector<shared_ptr<PointHessian>> &optimized);
+
+    const char *lastError() const;
+
+private:
+    ldso_ba_t *ba_ = nullptr;
+    std::map<CoarseTracker *, ldso_tracker_t *> trackers_;          // the reference double-buffers two CoarseTrackers (FullSystem.h:296-297)
+    std::map<internal::FrameHessian *, int> slotOf_;                 // key frame -> image slot of the BA handle
+    std::vector<internal::FrameHessian *> slotOwner_;
+    int device_, maxFrames_, maxPoints_;
+    FrameHessian *trackerNewFrame_ = nullptr;                       // whose pyramid the tracker handle currently holds as "new frame"
+    ldso_tracker_t *trackerOf(CoarseTracker &tr);
+    int uploadWindow(FullSystem &fs, std::vector<shared_ptr<PointHessian>> &allPoints, std::vector<shared_ptr<PointFrameResidual>> &flat);
+    void syncImageSlots(FullSystem &fs, std::vector<int32_t> &slots);
+};
+
+}  // namespace ldso

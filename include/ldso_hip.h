@@ -105,6 +105,9 @@ int ldso_ba_set_window(ldso_ba_t *h, int F, const int32_t *image_slot, int P, co
  * come in either order after ldso_ba_set_window. */
 int ldso_ba_set_frames(ldso_ba_t *h, const ldso_frame_t *frames, const ldso_calib_t *calib);
 int ldso_ba_set_prior(ldso_ba_t *h, const double *HM, const double *bM);
+/* Optional, after ldso_ba_set_window: PointHessian::maxRelBaseline / numGoodResiduals of the P points as the reference's objects hold them
+ * (they persist across optimize() calls: FullSystem.cc:1521-1536, AccumulatedSCHessian.cc:14-21).  Without the call both start at zero. */
+int ldso_ba_set_point_stats(ldso_ba_t *h, const float *maxRelBaseline, const int32_t *numGoodResiduals);
 
 /* Multi-GPU: this rank owns points [begin,end) of the window (whole points only).
  * reduce_buf_dev is a caller-allocated device buffer of ldso_ba_reduce_doubles() doubles that the
@@ -271,6 +274,18 @@ int ldso_tr_track_batch(ldso_tracker_t *t, int nhyp, double *T_ref2new_inout, fl
 int ldso_tr_last_track_evals(ldso_tracker_t *t, int evals[5], int pc_n[5]);
 int ldso_tr_select_hypothesis(int nhyp, int coarsestLvl, const double *lastResiduals /*nhyp*5*/, const int *ok /*nhyp*/, double lastCoarseRMSE0,
                               double reTrackThreshold, int *best_out, int *tries_consumed_out, double achievedRes_out[5]);
+/* The motion-hypothesis list of FullSystem::trackNewCoarse (FullSystem.cc:189-309): worldToCam poses [R|t] (Frame::getPose()) of
+ * allFrameHistory[size-3] (sprelast), allFrameHistory[size-2] (slast) and coarseTracker->lastRef (lastF) -> up to 83 lastF_2_fh tries
+ * (out: 83 x 12 doubles).  poses_valid = 0 (one of the three poses invalid, :306-309): the identity alone.  Pure host function. */
+int ldso_tr_motion_hypotheses(const double sprelast_w2c[12], const double slast_w2c[12], const double lastF_w2c[12], int poses_valid,
+                              double *lastF_2_fh_tries_out, int *n_out);
+/* Vec4 FullSystem::trackNewCoarse(fh) (FullSystem.cc:179-386) on a tracker whose reference and new frame are set: hypothesis list, the try
+ * loop with its achievedRes abort thresholds and reTrackThreshold early exit (try 0 alone; the remaining tries, if the loop goes on, as one
+ * batched launch + ldso_tr_select_hypothesis), the pose / affine hand-over.  lastCoarseRMSE: FullSystem::lastCoarseRMSE in / out;
+ * result4 = (achievedRes[0], flowVecs); new_frame_w2c / aff_out = what :376-378 write into fh->frame; *good = 0: "tracking failed entirely". */
+int ldso_tr_track_new_coarse(ldso_tracker_t *t, const double sprelast_w2c[12], const double slast_w2c[12], const double lastF_w2c[12], int poses_valid,
+                             const float aff_last[2], double lastCoarseRMSE_inout[5], double reTrackThreshold, double result4[4],
+                             double new_frame_w2c[12], float aff_out[2], int *tries_consumed, int *good);
 int ldso_tr_get_pc(ldso_tracker_t *t, int lvl, float *u, float *v, float *idepth, float *color, int *n);
 
 /* ------------------------------------------------------------------------------------------------------------

@@ -442,6 +442,21 @@ class Tracker:
         _chk(self.L.ldso_tr_get_new_frame_level(self.h, C.c_int(lvl), _p(out)))
         return out
 
+    def motion_hypotheses(self, sprelast, slast, lastF, poses_valid=True):
+        P = [np.ascontiguousarray(np.asarray(m, np.float64)[:3, :4]) for m in (sprelast, slast, lastF)]
+        out = np.zeros((83, 3, 4)); n = C.c_int()
+        _chk(self.L.ldso_tr_motion_hypotheses(_p(P[0]), _p(P[1]), _p(P[2]), C.c_int(1 if poses_valid else 0), _p(out), C.byref(n)))
+        return out[: n.value]
+
+    def track_new_coarse(self, sprelast, slast, lastF, aff_last, last_rmse, retrack_threshold=1.5, poses_valid=True):
+        """ldso_tr_track_new_coarse: FullSystem::trackNewCoarse (FullSystem.cc:179-386); poses are worldToCam 4x4 / 3x4"""
+        P = [np.ascontiguousarray(np.asarray(m, np.float64)[:3, :4]) for m in (sprelast, slast, lastF)]
+        aff = np.asarray(aff_last, np.float32); rmse = np.ascontiguousarray(last_rmse, np.float64).copy()
+        res4 = np.zeros(4); w2c = np.zeros((3, 4)); aff_out = np.zeros(2, np.float32); tries, good = C.c_int(-1), C.c_int(-1)
+        _chk(self.L.ldso_tr_track_new_coarse(self.h, _p(P[0]), _p(P[1]), _p(P[2]), C.c_int(1 if poses_valid else 0), _p(aff), _p(rmse), C.c_double(retrack_threshold),
+                                             _p(res4), _p(w2c), _p(aff_out), C.byref(tries), C.byref(good)))
+        return dict(result=res4, w2c=w2c, aff=aff_out, lastCoarseRMSE=rmse, tries=tries.value, good=good.value)
+
     def select_hypothesis(self, batch, coarsest, last_coarse_rmse0=float("nan"), retrack_threshold=1.5):
         lr = np.ascontiguousarray(batch["lastResiduals"], np.float64)
         ok = np.ascontiguousarray(batch["ok"], np.int32)

@@ -517,6 +517,20 @@ int ldso_ba_set_window(ldso_ba_t *H, int F, const int32_t *image_slot, int P, co
     return build_chunks(H);
 }
 
+// PointHessian::maxRelBaseline / numGoodResiduals live across optimize() calls in the reference (FullSystem.cc:1521-1536 updates them in the
+// fixing pass, AccumulatedSCHessian.cc:14-21 zeroes maxRelBaseline of points without an active residual).  ldso_ba_set_window starts both at
+// zero; a caller that keeps the reference's objects seeds them here so that ldso_ba_get_points returns the values to store back.
+int ldso_ba_set_point_stats(ldso_ba_t *H, const float *maxRelBaseline, const int32_t *numGoodResiduals) {
+    REQ(H && H->D.P > 0 && maxRelBaseline && numGoodResiduals, "ldso_ba_set_point_stats: bad arguments / no window");
+    CHK(hipSetDevice(H->device));
+    for (int s_ = 0; s_ < 2; s_++) {
+        CHK(hipMemcpyAsync(H->sets[s_].maxRelBS, maxRelBaseline, (size_t) H->D.P * 4, hipMemcpyHostToDevice, H->stream));
+        CHK(hipMemcpyAsync(H->sets[s_].numGood, numGoodResiduals, (size_t) H->D.P * 4, hipMemcpyHostToDevice, H->stream));
+    }
+    CHK(hipStreamSynchronize(H->stream));
+    return LDSO_OK;
+}
+
 int ldso_ba_set_shard(ldso_ba_t *H, int pb, int pe) {
     REQ(H && pb >= 0 && pe >= pb && pe <= H->D.P, "ldso_ba_set_shard: bad range");
     H->D.pBegin = pb; H->D.pEnd = pe;

@@ -25,6 +25,7 @@
 void ldso_set_error(const std::string &s);
 #define CHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { ldso_set_error(std::string(#call) + ": " + hipGetErrorString(e_)); return LDSO_E_HIP; } } while (0)
 #define REQ(cond, msg) do { if (!(cond)) { ldso_set_error(msg); return LDSO_E_INVALID; } } while (0)
+#define RUN(x) do { int r_ = (x); if (r_ != LDSO_OK) return r_; } while (0)
 
 #define TR_NT 256          // 4 wavefronts, one per SIMD: 512 registers (VGPR + AGPR) per lane - tr_eval keeps 4 points per lane in flight without scratch spills
 #define TR_MAXL LDSO_PYR_LEVELS
@@ -1245,6 +1246,91 @@ int ldso_tr_select_hypothesis(int nhyp, int coarsestLvl, const double *lastResid
     *best = win;
     if (tries_consumed) *tries_consumed = tries;
     if (achievedRes_out) for (int l = 0; l < 5; l++) achievedRes_out[l] = achieved[l];
+    return LDSO_OK;
+}
+
+// The motion-hypothesis list of FullSystem::trackNewCoarse (FullSystem.cc:189-309) from the worldToCam poses (Frame::getPose()) of the two
+// frames before the new one in allFrameHistory (sprelast, slast) and of the tracker's reference key frame (lastF): constant / double / half /
+// zero motion, identity, and 3 x 26 small rotations about the constant-motion guess (rotDelta = 0.02, 0.03, 0.04 as the reference's float
+// counter produces them; Sophus' SO3 constructor normalises the quaternion (1, +-d, +-d, +-d)).  Pure host function.
+static void tr_quat_to_pose(double w, double x, double y, double z, double *T) {
+    const double n = sqrt(w * w + x * x + y * y + z * z);
+    w /= n; x /= n; y /= n; z /= n;
+    const double tx = 2 * x, ty = 2 * y, tz = 2 * z, twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    T[0] = 1 - (tyy + tzz); T[1] = txy - twz; T[2] = txz + twy; T[3] = 0;
+    T[4] = txy + twz; T[5] = 1 - (txx + tzz); T[6] = tyz - twx; T[7] = 0;
+    T[8] = txz - twy; T[9] = tyz + twx; T[10] = 1 - (txx + tyy); T[11] = 0;
+}
+int ldso_tr_motion_hypotheses(const double sprelast[12], const double slast[12], const double lastF[12], int poses_valid, double *out, int *n_out) {
+    REQ(sprelast && slast && lastF && out && n_out, "ldso_tr_motion_hypotheses: null argument");
+    const double I[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    if (!poses_valid) { memcpy(out, I, sizeof(I)); *n_out = 1; return LDSO_OK; }       // FullSystem.cc:306-309
+    double inv[12], fh_2_slast[12], lastF_2_slast[12], fi[12], cm[12], tmp[12], xi[6], h[12];
+    ld::se3_inv(slast, inv); ld::se3_mul(sprelast, inv, fh_2_slast);                    // slast_2_sprelast, "assumed to be the same as fh_2_slast"
+    ld::se3_inv(lastF, inv); ld::se3_mul(slast, inv, lastF_2_slast);
+    ld::se3_inv(fh_2_slast, fi);
+    int n = 0;
+    ld::se3_mul(fi, lastF_2_slast, cm); memcpy(out + 12 * n++, cm, 96);                 // constant motion
+    ld::se3_mul(fi, cm, tmp); memcpy(out + 12 * n++, tmp, 96);                          // double motion (a frame was skipped)
+    ld::se3_log(fh_2_slast, xi); for (int i = 0; i < 6; i++) xi[i] *= 0.5;
+    ld::se3_exp(xi, h); ld::se3_inv(h, tmp); ld::se3_mul(tmp, lastF_2_slast, h); memcpy(out + 12 * n++, h, 96);      // half motion
+    memcpy(out + 12 * n++, lastF_2_slast, 96);                                          // zero motion
+    memcpy(out + 12 * n++, I, 96);                                                      // zero motion from the key frame
+    static const int sgn[26][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {-1, 0, 0}, {0, -1, 0}, {0, 0, -1}, {1, 1, 0}, {0, 1, 1}, {1, 0, 1}, {-1, 1, 0}, {0, -1, 1}, {-1, 0, 1},
+                                      {1, -1, 0}, {0, 1, -1}, {1, 0, -1}, {-1, -1, 0}, {0, -1, -1}, {-1, 0, -1}, {-1, -1, -1}, {-1, -1, 1}, {-1, 1, -1}, {-1, 1, 1},
+                                      {1, -1, -1}, {1, -1, 1}, {1, 1, -1}, {1, 1, 1}};
+    for (float rotDelta = 0.02; rotDelta < 0.05; rotDelta += 0.01)
+        for (int k = 0; k < 26; k++) {
+            double q[12];
+            tr_quat_to_pose(1, sgn[k][0] * rotDelta, sgn[k][1] * rotDelta, sgn[k][2] * rotDelta, q);
+            ld::se3_mul(cm, q, out + 12 * n++);
+        }
+    *n_out = n;
+    return LDSO_OK;
+}
+
+// Vec4 FullSystem::trackNewCoarse (FullSystem.cc:179-386) on a tracker whose reference and new frame are set.  The reference runs its tries
+// one after the other and stops at the first one that is good enough (:355) - almost always the first.  Here: try 0 alone (cooperative
+// single-hypothesis launch); only if the loop would go on, ALL remaining tries in one batched launch, and ldso_tr_select_hypothesis replays
+// the sequential accept / abort / early-exit decisions on the residuals (a try the sequential loop would have aborted on a coarse level
+// counts as aborted).  lastCoarseRMSE: in / out (FullSystem::lastCoarseRMSE); result4 = (achievedRes[0], flow[0..2]); new_w2c = the pose
+// handed to the new frame (:376-377), aff_out its aff_g2l; good = 0 is the reference's "tracking failed entirely" branch (:359-365).
+int ldso_tr_track_new_coarse(ldso_tracker_t *H, const double sprelast[12], const double slast[12], const double lastF[12], int poses_valid, const float aff_last[2],
+                             double lastCoarseRMSE[5], double reTrackThreshold, double result4[4], double new_w2c[12], float aff_out[2], int *tries_consumed, int *good) {
+    REQ(H && aff_last && lastCoarseRMSE && result4 && new_w2c && aff_out, "ldso_tr_track_new_coarse: null argument");
+    std::vector<double> T(83 * 12), T0(83 * 12), lr(83 * 5), flow(83 * 3);
+    std::vector<float> aff(83 * 2);
+    std::vector<int> ok(83);
+    int n = 0;
+    RUN(ldso_tr_motion_hypotheses(sprelast, slast, lastF, poses_valid, T0.data(), &n));
+    T = T0;
+    for (int i = 0; i < n; i++) { aff[2 * i] = aff_last[0]; aff[2 * i + 1] = aff_last[1]; }
+    const int coarsest = H->levels - 1;
+    int best = -1, used = 0;
+    double achieved[5];
+    RUN(ldso_tr_track_batch(H, 1, T.data(), aff.data(), coarsest, nullptr, lr.data(), flow.data(), ok.data(), nullptr));
+    RUN(ldso_tr_select_hypothesis(1, coarsest, lr.data(), ok.data(), lastCoarseRMSE[0], reTrackThreshold, &best, &used, achieved));
+    const bool done = best == 0 && achieved[0] < lastCoarseRMSE[0] * reTrackThreshold;
+    if (!done && n > 1) {
+        RUN(ldso_tr_track_batch(H, n - 1, T.data() + 12, aff.data() + 2, coarsest, nullptr, lr.data() + 5, flow.data() + 3, ok.data() + 1, nullptr));
+        RUN(ldso_tr_select_hypothesis(n, coarsest, lr.data(), ok.data(), lastCoarseRMSE[0], reTrackThreshold, &best, &used, achieved));
+    }
+    double lastF_2_fh[12];
+    if (best >= 0) {
+        memcpy(lastF_2_fh, T.data() + 12 * best, 96);
+        aff_out[0] = aff[2 * best]; aff_out[1] = aff[2 * best + 1];
+        for (int i = 0; i < 3; i++) result4[1 + i] = flow[3 * best + i];
+    } else {
+        memcpy(lastF_2_fh, T0.data(), 96);
+        aff_out[0] = aff_last[0]; aff_out[1] = aff_last[1];
+        result4[1] = result4[2] = result4[3] = 0;
+    }
+    result4[0] = achieved[0];
+    for (int l = 0; l < 5; l++) lastCoarseRMSE[l] = achieved[l];
+    // camToWorld = lastF^-1 * lastF_2_fh^-1, the frame's pose is its inverse (:376-377) = lastF_2_fh * lastF
+    ld::se3_mul(lastF_2_fh, lastF, new_w2c);
+    if (tries_consumed) *tries_consumed = used;
+    if (good) *good = best >= 0 ? 1 : 0;
     return LDSO_OK;
 }
 

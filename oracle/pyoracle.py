@@ -275,6 +275,17 @@ def make_mixed_window(win: synth.Window, oldest=2, perturb_seed=7) -> synth.Wind
     return w2
 
 
+def _track_new_coarse(fn, h, sprelast, slast, lastF, aff_last, last_rmse, retrack_threshold, poses_valid, with_tries):
+    P = [np.ascontiguousarray(np.asarray(m, np.float64)[:3, :4]) for m in (sprelast, slast, lastF)]
+    aff = np.asarray(aff_last, np.float32); rmse = np.ascontiguousarray(last_rmse, np.float64).copy()
+    res4 = np.zeros(4); w2c = np.zeros((3, 4)); aff_out = np.zeros(2, np.float32); tries = C.c_int(-1)
+    args = [h, _p(P[0]), _p(P[1]), _p(P[2]), C.c_int(1 if poses_valid else 0), _p(aff), _p(rmse), C.c_double(retrack_threshold), _p(res4), _p(w2c), _p(aff_out)]
+    if with_tries:
+        args.append(C.byref(tries))
+    good = fn(*args)
+    return dict(result=res4, w2c=w2c, aff=aff_out, lastCoarseRMSE=rmse, tries=tries.value, good=good)
+
+
 class OracleTracker:
     def __init__(self, w, h, levels, settings, calib, fast=False):
         self.L = lib(fast)
@@ -332,6 +343,16 @@ class OracleTracker:
         bb = np.zeros(8)
         self.L.orc_tr_calc_gs(self.h, C.c_int(lvl), _p(T), C.c_float(a), C.c_float(b), _p(H), _p(bb))
         return H, bb
+
+    def track_new_coarse(self, sprelast, slast, lastF, aff_last, last_rmse, retrack_threshold=1.5, poses_valid=True):
+        """FullSystem::trackNewCoarse restated (tracker_capi.inc): poses are worldToCam 4x4 / 3x4."""
+        return _track_new_coarse(self.L.orc_tr_track_new_coarse, self.h, sprelast, slast, lastF, aff_last, last_rmse, retrack_threshold, poses_valid, True)
+
+    def motion_hypotheses(self, sprelast, slast, lastF, poses_valid=True):
+        P = [np.ascontiguousarray(np.asarray(m, np.float64)[:3, :4]) for m in (sprelast, slast, lastF)]
+        out = np.zeros((83, 3, 4))
+        n = self.L.orc_tr_motion_hypotheses(_p(P[0]), _p(P[1]), _p(P[2]), C.c_int(1 if poses_valid else 0), _p(out))
+        return out[:n]
 
     def track(self, T, a, b, coarsest, min_res=None):
         T = np.ascontiguousarray(T[:3, :4], dtype=np.float64).copy()

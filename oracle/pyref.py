@@ -11,7 +11,7 @@ import subprocess
 import numpy as np
 
 from ldso_amd import synth
-from .pyoracle import _p, _img_ptrs
+from .pyoracle import _p, _img_ptrs, _track_new_coarse
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
@@ -142,6 +142,19 @@ class RefWindow:
     def fs_marginalize_frame(self, idx):
         self.L.ref_fs_marginalize_frame(self.h, C.c_int(idx))
 
+    def get_pair_rt(self):
+        out = np.zeros((self.num_frames() ** 2, 14), np.float32)
+        self.L.ref_get_pair_rt(self.h, _p(out))
+        return out
+
+    def fs_activate_points(self, points, min_obs=1, min_idepth_hessian=100.0, gn_iterations=3):
+        """FullSystem::optimizeImmaturePoint (the member) per record: ok, idepth (NaN when rejected), res_state, numGoodRes; the function's
+        locals (energy, Hdd, bd, iterations) are not observable from outside and stay NaN / -1."""
+        pts = np.ascontiguousarray(points)
+        out = np.zeros(len(pts), synth.ACTIVATION_DTYPE)
+        self.L.ref_fs_activate_points(self.h, C.c_int(len(pts)), _p(pts), C.c_int(min_obs), C.c_float(min_idepth_hessian), C.c_int(gn_iterations), _p(out))
+        return out
+
     def collect_active(self, reset_oob=True):
         self.L.ref_collect_active(self.h, C.c_int(1 if reset_oob else 0))
 
@@ -236,6 +249,98 @@ class RefWindow:
         self.L.ref_marginalize_frame(self.h, C.c_int(idx))
 
 
+# ---- the compiled drop-in adapter (adapter/ldso_gpu_adapter.cc -> oracle/_ref/libldso_adapter.so) on reference object graphs ----------------
+_ADP = None
+
+
+def adapter_path() -> str:
+    return os.path.join(_HERE, "_ref", "libldso_adapter.so")
+
+
+def adapter_available() -> bool:
+    if os.path.exists(adapter_path()):
+        return True
+    if not os.path.isdir("/root/reference") or not available():
+        return False
+    try:
+        subprocess.run(["make", "-C", os.path.join(_HERE, "..", "adapter")], check=True, capture_output=True)
+    except Exception:
+        return False
+    return os.path.exists(adapter_path())
+
+
+def adapter_lib():
+    global _ADP
+    if _ADP is None:
+        from ldso_amd import binding
+        binding.lib()                      # the product library first (it decides how the HIP runtime is brought in)
+        lib()
+        A = C.CDLL(adapter_path())
+        A.adp_create.restype = C.c_void_p
+        A.adp_last_error.restype = C.c_char_p
+        _ADP = A
+        L = lib()
+        for f in ("ref_fs_handle", "ref_tr_prepare", "ref_tr_coarse_tracker", "ref_tr_frame_hessians", "ref_tr_new_frame_hessian", "ref_tr_calib_hessian"):
+            getattr(L, f).restype = C.c_void_p
+    return _ADP
+
+
+class GpuAdapter:
+    """ldso::GpuBackend (adapter/ldso_gpu_adapter.h) driven on the reference objects of a RefWindow / RefTracker."""
+
+    def __init__(self, max_frames=16, max_points=20000, device=0):
+        self.A = adapter_lib()
+        self.h = C.c_void_p(self.A.adp_create(C.c_int(device), C.c_int(max_frames), C.c_int(max_points)))
+        if not self.h:
+            raise RuntimeError(self.A.adp_last_error().decode())
+
+    def close(self):
+        if self.h:
+            self.A.adp_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise RuntimeError(self.A.adp_last_error().decode())
+
+    def optimize(self, ref_window: "RefWindow", iterations: int):
+        """GpuBackend::optimize(fs, n) in place of FullSystem::optimize on the window's reference objects -> (rmse, iterations, lost)"""
+        ref_window.fs_attach()
+        fs = C.c_void_p(ref_window.L.ref_fs_handle(ref_window.h))
+        rmse, its, lost = C.c_float(), C.c_int(), C.c_int()
+        self._chk(self.A.adp_optimize(self.h, fs, C.c_int(iterations), C.byref(rmse), C.byref(its), C.byref(lost)))
+        ref_window.L.ref_fs_sync_back(ref_window.h)
+        return rmse.value, its.value, bool(lost.value)
+
+    def track_new_coarse(self, ref_tracker: "RefTracker", sprelast, slast, lastF, aff_last, last_rmse, retrack_threshold=1.5, poses_valid=True):
+        """GpuBackend::makeK + setCoarseTrackingRef + trackNewCoarse in place of FullSystem::trackNewCoarse"""
+        L, h = ref_tracker.L, ref_tracker.h
+        P = [np.ascontiguousarray(np.asarray(m, np.float64)[:3, :4]) for m in (sprelast, slast, lastF)]
+        aff = np.asarray(aff_last, np.float32); rmse = np.ascontiguousarray(last_rmse, np.float64).copy()
+        fs = C.c_void_p(L.ref_tr_prepare(h, _p(P[0]), _p(P[1]), _p(P[2]), C.c_int(1 if poses_valid else 0), _p(aff), _p(rmse), C.c_double(retrack_threshold)))
+        res4 = np.zeros(4)
+        self._chk(self.A.adp_track_new_coarse(self.h, fs, C.c_void_p(L.ref_tr_coarse_tracker(h)), C.c_void_p(L.ref_tr_frame_hessians(h)),
+                                              C.c_void_p(L.ref_tr_new_frame_hessian(h)), C.c_void_p(L.ref_tr_calib_hessian(h)), _p(res4)))
+        w2c = np.zeros((3, 4)); aff_out = np.zeros(2, np.float32)
+        L.ref_tr_read_result(h, _p(rmse), _p(w2c), _p(aff_out))
+        return dict(result=res4, w2c=w2c, aff=aff_out, lastCoarseRMSE=rmse)
+
+    def track_newest_coarse(self, ref_tracker: "RefTracker", T, a, b, coarsest, min_res=None):
+        L, h = ref_tracker.L, ref_tracker.h
+        Tm = np.ascontiguousarray(np.asarray(T, np.float64)[:3, :4]).copy(); ab = np.array([a, b], np.float32)
+        mr = np.full(5, np.nan) if min_res is None else np.ascontiguousarray(min_res, np.float64)
+        lr = np.zeros(5); ok = C.c_int()
+        self._chk(self.A.adp_track_newest_coarse(self.h, C.c_void_p(L.ref_tr_coarse_tracker(h)), C.c_void_p(L.ref_tr_frame_hessians(h)), C.c_void_p(L.ref_tr_new_frame_hessian(h)),
+                                                 C.c_void_p(L.ref_tr_calib_hessian(h)), _p(Tm), _p(ab), C.c_int(coarsest), _p(mr), _p(lr), C.byref(ok)))
+        return dict(T=Tm, a=float(ab[0]), b=float(ab[1]), ok=bool(ok.value), lastResiduals=lr)
+
+
 def make_images(color, levels):
     """FrameHessian::makeImages of the reference on a raw irradiance image: list of [h_l, w_l, 3] float32 levels."""
     L = lib()
@@ -304,6 +409,10 @@ class RefTracker:
         H = np.zeros((8, 8)); bb = np.zeros(8)
         self.L.ref_tr_calc_gs(self.h, C.c_int(lvl), _p(T), C.c_float(a), C.c_float(b), _p(H), _p(bb))
         return H, bb
+
+    def track_new_coarse(self, sprelast, slast, lastF, aff_last, last_rmse, retrack_threshold=1.5, poses_valid=True):
+        """Vec4 FullSystem::trackNewCoarse (the member) with this tracker: poses are worldToCam 4x4 / 3x4."""
+        return _track_new_coarse(self.L.ref_tr_track_new_coarse, self.h, sprelast, slast, lastF, aff_last, last_rmse, retrack_threshold, poses_valid, False)
 
     def track(self, T, a, b, coarsest, min_res=None):
         T = np.ascontiguousarray(T[:3, :4], dtype=np.float64).copy()

@@ -533,6 +533,9 @@ struct FsCall {          // capture LOG(...) for the duration of a call, write t
 };
 
 void ref_fs_attach(void *h, int multithreading) { FsCall c(h); multiThreading = multithreading != 0; }
+// the FullSystem object itself, for the compiled drop-in adapter (adapter/adapter_capi.cc) that runs on this window instead of optimize()
+void *ref_fs_handle(void *h) { FsCall c(h); return c.fs; }
+void ref_fs_sync_back(void *h) { RefWindow *W = (RefWindow *) h; if (W->fs) { W->frames = W->fs->frames; W->activeResiduals = W->fs->activeResiduals; } }
 int ref_fs_log(void *h, char *out, int cap) {
     RefWindow *W = (RefWindow *) h;
     int n = (int) W->fsLog.size();
@@ -565,6 +568,61 @@ void ref_fs_marginalize_frame(void *h, int idx) {
     c.fs->marginalizeFrame(fr);
 }
 
+// current-state pair transforms as ImmaturePoint::linearizeResidual reads them (FrameFramePrecalc: PRE_RTll 9, PRE_tTll 3, PRE_aff_mode 2)
+// at [host*F + target]: the oracle's / the device's activation takes the same 14 floats
+void ref_get_pair_rt(void *h, float *out) {
+    RefWindow *W = (RefWindow *) h;
+    int F = W->ef->frames.size();
+    for (int a = 0; a < F; a++)
+        for (int t = 0; t < F; t++) {
+            const FrameFramePrecalc &p = W->ef->frames[a]->targetPrecalc[t];
+            float *o = out + (a * F + t) * 14;
+            for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) o[i * 3 + j] = p.PRE_RTll(i, j); o[9 + i] = p.PRE_tTll[i]; }
+            o[12] = p.PRE_aff_mode[0]; o[13] = p.PRE_aff_mode[1];
+        }
+}
+
+// shared_ptr<PointHessian> FullSystem::optimizeImmaturePoint(point, minObs, residuals) (FullSystem.cc:892-1010) - the member itself - for n
+// immature-point records against the key frames of the window.  Observable results: the verdict (non-null return), the new point's
+// inverse depth, and the caller-owned temporary residuals' final states (the energy / Hdd / bd locals of the function are not).
+void ref_fs_activate_points(void *h, int n, const ldso_immature_t *pts, int min_obs, float min_idepth_hessian, int gn_iterations, ldso_activation_t *out) {
+    FsCall c(h);
+    setting_minIdepthH_act = min_idepth_hessian; setting_GNItsOnPointActivation = gn_iterations;
+    const int F = (int) c.fs->frames.size(), w = wG[0], hh = hG[0];
+    for (int i = 0; i < n; i++) {
+        const ldso_immature_t &q = pts[i];
+        ldso_activation_t &o = out[i];
+        memset(&o, 0, sizeof(o));
+        for (int f = 0; f < LDSO_MAX_FRAMES; f++) o.res_state[f] = -1;
+        o.energy = o.Hdd = o.bd = NAN; o.iterations = -1;
+        shared_ptr<Frame> host = c.fs->frames[q.host];
+        shared_ptr<Feature> feat(new Feature(q.u, q.v, host));
+        float uc = std::min(std::max(q.u, 8.0f), (float) w - 9), vc = std::min(std::max(q.v, 8.0f), (float) hh - 9);
+        feat->uv = Vec2f(uc, vc);                                  // keep the constructor's own sampling inside the image; its results are replaced by the record's
+        shared_ptr<ImmaturePoint> ip(new ImmaturePoint(host, feat, 1, c.W->Hcalib));
+        feat->uv = Vec2f(q.u, q.v);
+        feat->ip = ip;
+        memcpy(ip->color, q.color, sizeof(q.color)); memcpy(ip->weights, q.weights, sizeof(q.weights));
+        ip->gradH(0, 0) = q.gradH[0]; ip->gradH(0, 1) = q.gradH[1]; ip->gradH(1, 0) = q.gradH[2]; ip->gradH(1, 1) = q.gradH[3];
+        ip->energyTH = q.energyTH; ip->idepth_min = q.idepth_min; ip->idepth_max = q.idepth_max; ip->quality = q.quality;
+        ip->lastTraceStatus = (ImmaturePointStatus) q.lastTraceStatus;
+        std::vector<shared_ptr<ImmaturePointTemporaryResidual>> tr;
+        for (int f = 0; f + 1 < F; f++) tr.push_back(shared_ptr<ImmaturePointTemporaryResidual>(new ImmaturePointTemporaryResidual()));
+        shared_ptr<PointHessian> ph = c.fs->optimizeImmaturePoint(ip, min_obs, tr);
+        o.ok = ph ? 1 : 0;
+        o.idepth = ph ? ph->idepth : NAN;
+        int good = 0;
+        for (auto &t : tr) {
+            shared_ptr<FrameHessian> tf = t->target.lock();
+            if (!tf) continue;
+            o.res_state[tf->idx] = (int) t->state_state;
+            if (t->state_state == ResState::IN) good++;
+        }
+        o.numGoodRes = good;
+        feat->ReleaseAll();
+    }
+}
+
 // ---- FrameHessian::makeImages (FrameHessian.cc:44-113) -----------------------------------------------------------------------
 // out[l]: (w>>l)*(h>>l)*3 floats
 void ref_make_images(int w, int h, int levels, const float *color, float *const *out) {
@@ -592,6 +650,7 @@ struct RefTracker {
     std::vector<shared_ptr<PointFrameResidual>> keep;
     std::vector<std::vector<float>> refImgs, newImgs;
     int levels = 0, w = 0, h = 0;
+    FullSystem *fs = nullptr;          // ref_tr_track_new_coarse: the reference's FullSystem around this tracker
 };
 static void detach_images(shared_ptr<Frame> &fr) { if (fr && fr->frameHessian) for (int l = 0; l < PYR_LEVELS; l++) { fr->frameHessian->dIp[l] = nullptr; fr->frameHessian->absSquaredGrad[l] = nullptr; } }
 static shared_ptr<Frame> make_frame(std::vector<std::vector<float>> &store, const float *const *dIp, int w, int h, int levels, float exposure) {
@@ -627,7 +686,56 @@ void *ref_tr_create(int w, int h, int levels, const ldso_settings_t *settings, c
     T->tr->makeK(T->cam->mpCH);
     return T;
 }
-void ref_tr_destroy(void *h) { RefTracker *T = (RefTracker *) h; detach_images(T->refFrame); detach_images(T->newFrame); delete T; }
+void ref_tr_destroy(void *h) { RefTracker *T = (RefTracker *) h; detach_images(T->refFrame); detach_images(T->newFrame); if (T->fs) { T->fs->allFrameHistory.clear(); delete T->fs; } delete T; }
+
+// Vec4 FullSystem::trackNewCoarse(shared_ptr<FrameHessian> fh) (FullSystem.cc:179-386) - the member itself: the motion-hypothesis list from
+// the poses of the last two frames and the reference key frame, the try loop with the growing achievedRes thresholds, the pose / affine
+// hand-over to the new frame.  The FullSystem gets this driver's tracker (reference + new frame set) and a three-frame history.
+// the FullSystem around this tracker with a three-frame history (sprelast, slast, the new frame): what trackNewCoarse reads
+static FullSystem *tr_prepare_history(RefTracker *T, const double *sprelast, const double *slast, const double *lastF, int posesValid, const float *aff_last,
+                                      const double *lastCoarseRMSE, double reTrackThreshold) {
+    if (!T->fs) { setting_enableLoopClosing = false; T->fs = new FullSystem(nullptr); }
+    FullSystem *fs = T->fs;
+    fs->coarseTracker = T->tr;
+    setting_reTrackThreshold = reTrackThreshold;
+    shared_ptr<Frame> f0(new Frame()), f1(new Frame());
+    f0->setPose(se3_from34(sprelast)); f1->setPose(se3_from34(slast)); T->refFrame->setPose(se3_from34(lastF));
+    f0->poseValid = f1->poseValid = T->refFrame->poseValid = posesValid != 0;
+    f1->aff_g2l = AffLight(aff_last[0], aff_last[1]);
+    fs->allFrameHistory.clear();
+    fs->allFrameHistory.push_back(f0); fs->allFrameHistory.push_back(f1); fs->allFrameHistory.push_back(T->newFrame);
+    for (int i = 0; i < 5; i++) fs->lastCoarseRMSE[i] = lastCoarseRMSE[i];
+    return fs;
+}
+// for the compiled drop-in adapter: the prepared FullSystem, the tracker's frame-hessian list and the new frame (borrowed pointers)
+void *ref_tr_prepare(void *h, const double *sprelast, const double *slast, const double *lastF, int posesValid, const float *aff_last,
+                     const double *lastCoarseRMSE, double reTrackThreshold) {
+    return tr_prepare_history((RefTracker *) h, sprelast, slast, lastF, posesValid, aff_last, lastCoarseRMSE, reTrackThreshold);
+}
+void *ref_tr_coarse_tracker(void *h) { return ((RefTracker *) h)->tr.get(); }
+void *ref_tr_frame_hessians(void *h) { return &((RefTracker *) h)->fhs; }
+void *ref_tr_new_frame_hessian(void *h) { return &((RefTracker *) h)->newFrame->frameHessian; }
+void *ref_tr_calib_hessian(void *h) { return &((RefTracker *) h)->cam->mpCH; }
+void ref_tr_read_result(void *h, double *lastCoarseRMSE, double *new_w2c, float *aff_out) {
+    RefTracker *T = (RefTracker *) h;
+    for (int i = 0; i < 5; i++) lastCoarseRMSE[i] = T->fs->lastCoarseRMSE[i];
+    Eigen::Matrix<double, 3, 4> M = T->newFrame->getPose().matrix3x4();
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 4; j++) new_w2c[i * 4 + j] = M(i, j);
+    aff_out[0] = T->newFrame->aff_g2l.a; aff_out[1] = T->newFrame->aff_g2l.b;
+}
+
+int ref_tr_track_new_coarse(void *h, const double *sprelast, const double *slast, const double *lastF, int posesValid, const float *aff_last,
+                            double *lastCoarseRMSE, double reTrackThreshold, double *result4, double *new_w2c, float *aff_out) {
+    RefTracker *T = (RefTracker *) h;
+    FullSystem *fs = tr_prepare_history(T, sprelast, slast, lastF, posesValid, aff_last, lastCoarseRMSE, reTrackThreshold);
+    Vec4 r = fs->trackNewCoarse(T->newFrame->frameHessian);
+    for (int i = 0; i < 4; i++) result4[i] = r[i];
+    for (int i = 0; i < 5; i++) lastCoarseRMSE[i] = fs->lastCoarseRMSE[i];
+    Eigen::Matrix<double, 3, 4> M = T->newFrame->getPose().matrix3x4();
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 4; j++) new_w2c[i * 4 + j] = M(i, j);
+    aff_out[0] = T->newFrame->aff_g2l.a; aff_out[1] = T->newFrame->aff_g2l.b;
+    return 0;
+}
 
 // setCoarseTrackingRef on a reference frame whose active points are given as (Ku, Kv, new_idepth, HdiF) x n: each becomes a
 // Feature / Point / PointHessian with lastResiduals[0] = an active IN residual towards the reference frame (what makeCoarseDepthL0 reads)

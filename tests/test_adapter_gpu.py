@@ -1,0 +1,118 @@
+"""The compiled drop-in adapter (adapter/ldso_gpu_adapter.cc: LDSO's own FullSystem / FrameHessian / PointHessian / PointFrameResidual /
+CoarseTracker objects in, libldso_hip.so underneath) against the reference itself: a window is built twice as reference objects
+(oracle/ref_driver.cc, libldso_ref.so = the reference's translation units compiled unmodified); the reference's own
+FullSystem::optimize() runs on one copy, ldso::GpuBackend::optimize() on the other, and every field the adapter writes back into the
+reference objects is compared: indices / states / flags exact (north_star: bit-exact point / residual indexing), floats within 1e-4.
+Same for FullSystem::trackNewCoarse / CoarseTracker::trackNewestCoarse.  Needs the GPU and the libraries built where /root/reference exists."""
+import copy
+
+import numpy as np
+import pytest
+
+from conftest import get_window
+from ldso_amd import synth
+from oracle import pyoracle as po, pyref as pr
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not (pr.available() and pr.adapter_available()), reason="oracle/_ref/libldso_ref.so / libldso_adapter.so not built")]
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def _compare_written_back(r_ref, r_adp, win, state_tol=2e-4):
+    fr, fa = r_ref.get_frames(), r_adp.get_frames()
+    assert _rel(fa["frames"]["frameEnergyTH"], fr["frames"]["frameEnergyTH"]) < 1e-4
+    # frame states: the reduced system is ill-conditioned along the gauge, compare the poses the states produce
+    assert np.abs(fa["pre_worldToCam"] - fr["pre_worldToCam"]).max() < state_tol
+    assert np.abs(fa["frames"]["worldToCam_evalPT"] - fr["frames"]["worldToCam_evalPT"]).max() < state_tol
+    assert np.abs(fa["frames"]["state"][:, 6:8] - fr["frames"]["state"][:, 6:8]).max() < state_tol * max(1.0, np.abs(fr["frames"]["state"][:, 6:8]).max())
+    assert np.array_equal(fa["frames"]["state"][-1, :6], np.zeros(6)) and np.array_equal(fa["frames"]["state_zero"][-1], fa["frames"]["state"][-1])   # re-anchored
+    assert _rel(fa["calib_value"], fr["calib_value"]) < 1e-4
+    (pr_, sr), (pa, sa) = r_ref.get_points(), r_adp.get_points()
+    assert np.array_equal(sa, sr)
+    assert np.array_equal(pa["numGoodResiduals"], pr_["numGoodResiduals"])
+    assert _rel(pa["idepth"], pr_["idepth"]) < 1e-3 and np.median(np.abs(pa["idepth"] - pr_["idepth"]) / np.abs(pr_["idepth"])) < 1e-4
+    assert _rel(pa["maxRelBaseline"], pr_["maxRelBaseline"]) < 1e-3
+    ok = pr_["HdiF"] > 0
+    assert np.median(np.abs(pa["HdiF"][ok] - pr_["HdiF"][ok]) / pr_["HdiF"][ok]) < 1e-4
+    rr, ra = r_ref.get_residuals(), r_adp.get_residuals()
+    for k in ("state_state", "is_active", "alive", "is_linearized"):
+        same = (ra[k] == rr[k])
+        assert same.mean() > 0.999, (k, (~same).sum())             # a residual sitting exactly on the outlier threshold may flip with 1e-6 state differences
+    live = (rr["alive"] != 0) & (ra["alive"] != 0) & (rr["is_active"] != 0) & (ra["is_active"] != 0)
+    assert live.sum() > 0.5 * win.R
+    e = np.abs(ra["out"]["state_NewEnergy"][live] - rr["out"]["state_NewEnergy"][live]) / np.maximum(rr["out"]["state_NewEnergy"][live], 1.0)
+    assert np.median(e) < 1e-4
+    j = np.abs(ra["out"]["JpJdF"][live] - rr["out"]["JpJdF"][live]).max(axis=1) / np.maximum(np.abs(rr["out"]["JpJdF"][live]).max(axis=1), 1e-3)
+    assert np.median(j) < 1e-4
+    assert np.abs(ra["out"]["centerProjectedTo"][live] - rr["out"]["centerProjectedTo"][live]).max() < 0.05       # pixels
+    # the Jacobians stored back into r->J
+    for k in ("Jpdxi", "Jpdc", "Jpdd", "JIdx2"):
+        a, b = ra["J"][k][live].reshape(live.sum(), -1), rr["J"][k][live].reshape(live.sum(), -1)
+        assert np.median(np.abs(a - b).max(axis=1) / np.maximum(np.abs(b).max(axis=1), 1e-6)) < 1e-4, k
+    assert r_adp.counts()[:2] == r_ref.counts()[:2] or abs(r_adp.counts()[0] - r_ref.counts()[0]) <= 2
+
+
+@pytest.mark.parametrize("name,iters", [("small", 6), ("C3", 6)])
+def test_adapter_optimize_equals_reference_optimize(name, iters):
+    win = synth.add_synthetic_prior(copy.deepcopy(get_window(name)))
+    r_ref, r_adp = pr.RefWindow(win), pr.RefWindow(win)
+    r_ref.fs_attach()
+    rv_ref, log_ref = r_ref.fs_optimize(iters)
+    A = pr.GpuAdapter(max_frames=win.F + 1, max_points=win.P + 16)
+    rv, its, lost = A.optimize(r_adp, iters)
+    assert not lost and not r_ref.fs_is_lost()
+    assert its == len(log_ref) - 1, "same number of GN iterations executed (canbreak at the same iteration)"
+    assert abs(rv - rv_ref) <= 1e-4 * rv_ref
+    _compare_written_back(r_ref, r_adp, win)
+    A.close()
+
+
+def test_adapter_optimize_with_linearized_residuals_and_a_second_call(small):
+    """a window with linearised residuals (H_L path, J / res_toZeroF flattened from the reference objects), optimised twice in a row through
+    the adapter: the second call re-flattens what the first wrote back (image slots are reused, maxRelBaseline / numGoodResiduals persist)."""
+    win = po.make_mixed_window(synth.add_synthetic_prior(copy.deepcopy(small)))
+    r_ref, r_adp = pr.RefWindow(win), pr.RefWindow(win)
+    r_ref.fs_attach()
+    A = pr.GpuAdapter(max_frames=win.F + 1, max_points=win.P + 16)
+    for rnd in range(2):
+        rv_ref, log_ref = r_ref.fs_optimize(2)
+        rv, its, lost = A.optimize(r_adp, 2)
+        assert not lost and abs(rv - rv_ref) <= 2e-4 * rv_ref, rnd
+        _compare_written_back(r_ref, r_adp, win, state_tol=5e-4)
+    A.close()
+
+
+@pytest.mark.parametrize("lost", [False, True])
+def test_adapter_track_new_coarse_equals_reference(lost):
+    from tracker_common import tracker_scenario
+    sc = tracker_scenario("small")
+    w = sc["win"]; F = w.F
+    w2c = w.truth["w2c"]
+    lastF, slast, sprelast = w2c[F - 1], w2c[F - 1], w2c[F - 2]
+    if lost:
+        ang = 0.06
+        Rz = np.array([[np.cos(ang), -np.sin(ang), 0, 0], [np.sin(ang), np.cos(ang), 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]])
+        sprelast = Rz @ slast
+    r1, r2 = (pr.RefTracker(w.w, w.h, sc["levels"], w.settings, w.calib) for _ in range(2))
+    for t in (r1, r2):
+        t.set_ref(sc["ref_pyr"], sc["ref_aff"][0], sc["ref_aff"][1], 1.0, sc["pts"]); t.set_new_frame(sc["new_pyr"], 1.0)
+    rmse0 = np.array([100.0] * 5) if not lost else np.array([0.05] * 5)
+    a = r1.track_new_coarse(sprelast, slast, lastF, sc["new_aff"], rmse0)
+    A = pr.GpuAdapter()
+    b = A.track_new_coarse(r2, sprelast, slast, lastF, sc["new_aff"], rmse0)
+    assert np.abs(a["w2c"] - b["w2c"]).max() < 1e-4
+    assert np.abs(a["aff"] - b["aff"]).max() < 1e-3 * max(1.0, np.abs(a["aff"]).max())
+    fin = np.isfinite(a["lastCoarseRMSE"])
+    assert np.array_equal(fin, np.isfinite(b["lastCoarseRMSE"]))
+    assert np.abs(a["lastCoarseRMSE"][fin] - b["lastCoarseRMSE"][fin]).max() <= 1e-3 * np.abs(a["lastCoarseRMSE"][fin]).max()
+    assert np.abs(a["result"] - b["result"]).max() <= 1e-3 * max(1.0, np.abs(a["result"]).max())
+    # one trackNewestCoarse through the adapter, incl. the abort rule (outputs untouched when a level exceeds 1.5 x minResForAbort)
+    t1 = r1.track(np.eye(4), sc["new_aff"][0], sc["new_aff"][1], sc["levels"] - 1)
+    t2 = A.track_newest_coarse(r2, np.eye(4), sc["new_aff"][0], sc["new_aff"][1], sc["levels"] - 1)
+    assert t1["ok"] == t2["ok"] and np.abs(t1["T"][:3] - t2["T"]).max() < 1e-4
+    t3 = A.track_newest_coarse(r2, np.eye(4), sc["new_aff"][0], sc["new_aff"][1], sc["levels"] - 1, min_res=np.full(5, 1e-3))
+    assert not t3["ok"] and np.array_equal(t3["T"], np.eye(4)[:3])
+    A.close()

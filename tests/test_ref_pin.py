@@ -367,3 +367,70 @@ def test_fullsystem_marginalization_members_pinned(small):
     assert o.num_frames() == r.num_frames() == win.F - 1
     ro, rr = o.get_residuals(), r.get_residuals()
     _same(ro["alive"], rr["alive"], "residuals dropped with the frame")
+
+
+def _traced_points(win, per_frame):
+    """immature points of the window's key frames, traced against the two extra frames so that they carry depth intervals"""
+    pts, true_id = synth.make_immature_points(win, per_frame)
+    for fidx in (win.F, win.F + 1):
+        KRKi, Kt, aff = synth.trace_poses(win, fidx)
+        po.trace_on(pts, win.images[fidx][0], KRKi, Kt, aff)
+    keep = np.isfinite(pts["idepth_max"]) & (pts["lastTraceStatus"] != 1)
+    return pts[keep].copy(), true_id[keep]
+
+
+@pytest.mark.parametrize("name,per_frame", [("small", 120), ("C3", 60)])
+def test_fullsystem_optimize_immature_point_pinned(name, per_frame):
+    """shared_ptr<PointHessian> FullSystem::optimizeImmaturePoint (FullSystem.cc:892-1010, the member; ImmaturePoint::linearizeResidual from
+    ImmaturePoint.cc compiled unmodified) against the oracle's restatement (oracle/trace.cc orc_activate_points) on the same records and
+    the same pair transforms: verdict, per-target residual states and the activated inverse depth bit for bit; incl. rejected candidates."""
+    win = synth.make_config(name, extra_frames=2)
+    pts, _ = _traced_points(win, per_frame)
+    pts = pts.copy()
+    pts["idepth_min"][0] = np.nan                                   # non-finite start: return 0 (:924-926)
+    pts["idepth_min"][1] = 50.0; pts["idepth_max"][1] = 60.0         # absurdly close: every residual OOB
+    pts["u"][2] = 2.0; pts["v"][2] = 2.0                             # the pattern leaves the target images
+    r = pr.RefWindow(win); r.fs_attach()
+    pairs = r.get_pair_rt()
+    K4 = np.asarray([np.float32(50.0 * v) for v in win.calib["value"]], np.float32)
+    a = po.activate_points(pts, [win.images[f][0] for f in range(win.F)], K4, pairs, win.w, win.h)
+    b = r.fs_activate_points(pts)
+    _same(a["ok"], b["ok"], "verdict"); _same(a["res_state"], b["res_state"], "temporary residual states"); _same(a["numGoodRes"], b["numGoodRes"], "numGoodRes")
+    ok = b["ok"] == 1
+    assert 0.3 < ok.mean() < 1.0 and b["ok"][0] == 0
+    _same(a["idepth"][ok].view(np.uint32), b["idepth"][ok].view(np.uint32), "activated inverse depth")
+
+
+def _track_new_coarse_scenario(cfg="small", levels=None, lost=False):
+    """A tracker with reference + new frame and the three poses trackNewCoarse builds its motion hypotheses from: the true poses of the two
+    frames before the new one (constant-motion guess = a good start) or, lost = True, wrong ones so that several tries are consumed."""
+    from tracker_common import tracker_scenario
+    sc = tracker_scenario(cfg) if levels is None else tracker_scenario(cfg, levels=levels)
+    w = sc["win"]; F = w.F
+    w2c = w.truth["w2c"]
+    lastF, slast, sprelast = w2c[F - 1], w2c[F - 1], w2c[F - 2]
+    if lost:      # the two previous frames suggest a rotation that did not happen: the first tries start far off
+        ang = 0.06
+        Rz = np.array([[np.cos(ang), -np.sin(ang), 0, 0], [np.sin(ang), np.cos(ang), 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]])
+        sprelast = Rz @ slast
+    return sc, w, sprelast, slast, lastF
+
+
+@pytest.mark.parametrize("lost", [False, True])
+def test_fullsystem_track_new_coarse_pinned(lost):
+    """Vec4 FullSystem::trackNewCoarse (FullSystem.cc:179-386, the member): the 83 motion hypotheses (:189-309), the try loop with the
+    growing achievedRes abort thresholds and the reTrackThreshold exit (:319-356), the pose / affine hand-over (:367-379) - against the
+    oracle's restatement (tracker_capi.inc): bit for bit (both sides compute poses through oracle/lie.h)."""
+    sc, w, sprelast, slast, lastF = _track_new_coarse_scenario(lost=lost)
+    o = po.OracleTracker(w.w, w.h, sc["levels"], w.settings, w.calib); r = pr.RefTracker(w.w, w.h, sc["levels"], w.settings, w.calib)
+    for t in (o, r):
+        t.set_ref(sc["ref_pyr"], sc["ref_aff"][0], sc["ref_aff"][1], 1.0, sc["pts"]); t.set_new_frame(sc["new_pyr"], 1.0)
+    rmse0 = np.array([100.0] * 5) if not lost else np.array([0.05] * 5)           # an unreachable lastCoarseRMSE[0] keeps the loop going (:355)
+    a = o.track_new_coarse(sprelast, slast, lastF, sc["new_aff"], rmse0)
+    b = r.track_new_coarse(sprelast, slast, lastF, sc["new_aff"], rmse0)
+    _same(a["result"], b["result"], "Vec4 result"); _same(a["w2c"], b["w2c"], "pose handed to the new frame"); _same(a["aff"], b["aff"], "aff_g2l")
+    assert np.array_equal(a["lastCoarseRMSE"], b["lastCoarseRMSE"], equal_nan=True)
+    assert a["tries"] == (1 if not lost else 83) and a["good"] == 1
+    T_true = w.truth["w2c"][w.F]
+    assert np.abs(b["w2c"] - T_true[:3]).max() < 5e-3                       # and it is the right pose
+    assert len(o.motion_hypotheses(sprelast, slast, lastF)) == 83 and len(o.motion_hypotheses(sprelast, slast, lastF, poses_valid=False)) == 1

@@ -57,3 +57,21 @@ def test_select_hypothesis_rejects_bad_arguments():
     best = C.c_int()
     assert L.ldso_tr_select_hypothesis(C.c_int(2), C.c_int(7), None, None, C.c_double(1.0), C.c_double(1.5), C.byref(best), None, None) != 0
     assert L.ldso_tr_select_hypothesis(C.c_int(2), C.c_int(3), None, None, C.c_double(1.0), C.c_double(1.5), C.byref(best), None, None) != 0
+
+
+def test_motion_hypotheses_match_the_oracle():
+    """ldso_tr_motion_hypotheses (pure host function of the product library) against the oracle's restatement of FullSystem.cc:189-309,
+    which tests/test_ref_pin.py pins to the reference's own trackNewCoarse: 83 tries, 1e-12 (matrix vs quaternion composition)."""
+    from oracle import pyoracle as po
+    from ldso_amd import synth
+    L = binding.lib()
+    rng = np.random.default_rng(4)
+    P = [np.ascontiguousarray(synth.se3_exp(rng.normal(0, 1, 6) * [0.3, 0.3, 0.3, 0.1, 0.1, 0.1])[:3, :4]) for _ in range(3)]
+    out = np.zeros((83, 3, 4)); n = C.c_int()
+    assert L.ldso_tr_motion_hypotheses(P[0].ctypes.data_as(C.c_void_p), P[1].ctypes.data_as(C.c_void_p), P[2].ctypes.data_as(C.c_void_p), C.c_int(1),
+                                       out.ctypes.data_as(C.c_void_p), C.byref(n)) == 0
+    ref = np.zeros((83, 3, 4))
+    m = po.lib().orc_tr_motion_hypotheses(P[0].ctypes.data_as(C.c_void_p), P[1].ctypes.data_as(C.c_void_p), P[2].ctypes.data_as(C.c_void_p), C.c_int(1), ref.ctypes.data_as(C.c_void_p))
+    assert n.value == m == 83 and np.abs(out - ref).max() < 1e-12
+    assert L.ldso_tr_motion_hypotheses(P[0].ctypes.data_as(C.c_void_p), P[1].ctypes.data_as(C.c_void_p), P[2].ctypes.data_as(C.c_void_p), C.c_int(0),
+                                       out.ctypes.data_as(C.c_void_p), C.byref(n)) == 0 and n.value == 1 and np.array_equal(out[0], np.eye(4)[:3])

@@ -203,3 +203,32 @@ def test_batched_hypotheses_reproduce_sequential_loop():
         assert best == win and used == tries
         assert np.array_equal(np.isnan(ach), np.isnan(achieved)) and np.allclose(ach[~np.isnan(ach)], achieved[~np.isnan(achieved)], rtol=0, atol=0)
     assert win >= 0
+
+
+@pytest.mark.parametrize("lost", [False, True])
+def test_track_new_coarse_matches_oracle(lost):
+    """ldso_tr_motion_hypotheses + ldso_tr_track_new_coarse = Vec4 FullSystem::trackNewCoarse (FullSystem.cc:179-386) against the oracle's
+    restatement (pinned bit for bit to the reference's own member, tests/test_ref_pin.py::test_fullsystem_track_new_coarse_pinned): the 83
+    hypotheses to 1e-12, same winner semantics (number of tries consumed), pose handed to the new frame to 1e-4, achievedRes to 1e-3 relative."""
+    sc = tracker_scenario("small")
+    o, g = make_pair(sc)
+    w = sc["win"]; F = w.F
+    w2c = w.truth["w2c"]
+    lastF, slast, sprelast = w2c[F - 1], w2c[F - 1], w2c[F - 2]
+    if lost:
+        ang = 0.06
+        Rz = np.array([[np.cos(ang), -np.sin(ang), 0, 0], [np.sin(ang), np.cos(ang), 0, 0], [0, 0, 1, 0], [0, 0, 0, 1]])
+        sprelast = Rz @ slast
+    ho, hg = o.motion_hypotheses(sprelast, slast, lastF), g.motion_hypotheses(sprelast, slast, lastF)
+    assert ho.shape == hg.shape == (83, 3, 4) and np.abs(ho - hg).max() < 1e-12
+    assert len(g.motion_hypotheses(sprelast, slast, lastF, poses_valid=False)) == 1
+    rmse0 = np.array([100.0] * 5) if not lost else np.array([0.05] * 5)
+    a = o.track_new_coarse(sprelast, slast, lastF, sc["new_aff"], rmse0)
+    b = g.track_new_coarse(sprelast, slast, lastF, sc["new_aff"], rmse0)
+    assert a["good"] == b["good"] == 1 and a["tries"] == b["tries"] == (1 if not lost else 83)
+    assert np.abs(a["w2c"] - b["w2c"]).max() < 1e-4
+    assert np.abs(a["aff"] - b["aff"]).max() < 1e-3 * max(1.0, np.abs(a["aff"]).max())
+    fin = np.isfinite(a["lastCoarseRMSE"])
+    assert np.array_equal(fin, np.isfinite(b["lastCoarseRMSE"]))
+    assert np.abs(a["lastCoarseRMSE"][fin] - b["lastCoarseRMSE"][fin]).max() <= 1e-3 * np.abs(a["lastCoarseRMSE"][fin]).max()
+    assert np.abs(a["result"] - b["result"]).max() <= 1e-3 * max(1.0, np.abs(a["result"]).max())
