@@ -258,7 +258,7 @@ static int create_body(ldso_ba *H, int device, int w, int h, int max_frames, int
     DA(B.frames, F); DA(B.calib, 1); DA(B.pairs, F * F); DA(B.pairRt, F * F * 12);
     DA(B.adHost, F * F * 64); DA(B.adTarget, F * F * 64); DA(B.adHostF, F * F * 64); DA(B.adTargetF, F * F * 64);
     DA(B.nsProj, nmax * 7); DA(B.HM, nmax * nmax); DA(B.bM, nmax);
-    DA(B.pu, P); DA(B.pv, P); DA(B.pidepth, P); DA(B.pidepth_zero, P); DA(B.pidepth_backup, P); DA(B.pstep, P); DA(B.ppriorF, P);
+    DA(B.pu, P); DA(B.pv, P); DA(B.pidepth, P); DA(B.pidepth_zero, P); DA(B.pidepth_backup, P); DA(B.pstep, P); DA(B.ppriorF, P); DA(B.pLastHdiF, P); DA(B.pLastBdSumF, P); DA(B.pLastIdH, P);
     DA(B.pcolor, P * 8); DA(B.pweights, P * 8); DA(B.phost, P);
     DA(B.rflat, P * FS); DA(B.rlin, P * FS); DA(B.rnew, P * FS); DA(B.rlidx, P * FS);
     DA(B.Jlin, P * FS); DA(B.rtz, P * FS * 8);
@@ -506,7 +506,7 @@ int ldso_ba_set_window(ldso_ba_t *H, int F, const int32_t *image_slot, int P, co
                   && W.zero(S.nActive, (size_t) P) && W.zero(S.G, (size_t) P * D.GS);
     }
     // a new window has a new dimension 8F+4: the marginalisation prior starts at zero (ldso_ba_set_prior follows when there is one)
-    okT = okT && W.zero(B.pstep, (size_t) P) && W.zero(B.HM, (size_t) D.n * D.n) && W.zero(B.bM, (size_t) D.n) && W.zero(B.scalars, (size_t) 16)
+    okT = okT && W.zero(B.pstep, (size_t) P) && W.zero(B.pLastHdiF, (size_t) P) && W.zero(B.pLastBdSumF, (size_t) P) && W.zero(B.pLastIdH, (size_t) P) && W.zero(B.HM, (size_t) D.n * D.n) && W.zero(B.bM, (size_t) D.n) && W.zero(B.scalars, (size_t) 16)
               && W.zero(B.scPart, (size_t) LD_SC_SPLITS * H->GSP * H->GSP);
     REQ(okT, "ldso_ba_set_window: upload table overflow (internal)");
     H->hasPrior = false;
@@ -1304,7 +1304,7 @@ int ldso_ba_get_points(ldso_ba_t *H, ldso_point_out_t *out) {
     const ResSet &S = H->sets[H->cur];
     std::vector<float> step, HdiF, bd, idH, HddA, bdA, HcdA, HddL, bdL, HcdL, idp, mrb;
     std::vector<int32_t> ng;
-    D2H(step, H->B.pstep, P); D2H(HdiF, S.HdiF, P); D2H(bd, S.bdSumF, P); D2H(idH, S.idH, P); D2H(HddA, S.HddA, P); D2H(bdA, S.bdA, P);
+    D2H(step, H->B.pstep, P); D2H(HdiF, H->B.pLastHdiF, P); D2H(bd, H->B.pLastBdSumF, P); D2H(idH, H->B.pLastIdH, P); D2H(HddA, S.HddA, P); D2H(bdA, S.bdA, P);
     D2H(HcdA, S.HcdA, P * 4); D2H(HddL, S.HddL, P); D2H(bdL, S.bdL, P); D2H(HcdL, S.HcdL, P * 4); D2H(idp, H->B.pidepth, P);
     D2H(mrb, S.maxRelBS, P); D2H(ng, S.numGood, P);
     CHK(hipStreamSynchronize(H->stream));

@@ -88,6 +88,8 @@ struct BaPtrs {
     double *HM, *bM;
     // points
     float *pu, *pv, *pidepth, *pidepth_zero, *pidepth_backup, *pstep, *ppriorF, *pcolor, *pweights;
+    float *pLastHdiF, *pLastBdSumF, *pLastIdH;    // PointHessian::{HdiF, bdSumF, idepth_hessian} as the LAST solveSystemF left them (AccumulatedSCHessian.cc:9-51): the
+                                                  // ResSet copies belong to the NEXT solve (the fused linearize pass already holds the new linearisation's Schur scalars)
     int32_t *phost;
     // residual slots
     int32_t *rflat, *rlin, *rnew, *rlidx;

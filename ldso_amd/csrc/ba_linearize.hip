@@ -258,6 +258,8 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
             }
             const float ni = idp + 1.0f * step;
             if (lane == 0) { AT(B.pstep, p) = step; AT(B.pidepth_backup, p) = idp; AT(B.pidepth, p) = ni; AT(B.pidepth_zero, p) = ni; }
+            // PointHessian::{HdiF, bdSumF, idepth_hessian} as the solve that produced this step left them (lanes 1..3: fire-and-forget stores)
+            if (lane == 1) AT(B.pLastHdiF, p) = q.HdiF; else if (lane == 2) AT(B.pLastBdSumF, p) = q.bdSumF; else if (lane == 3) AT(B.pLastIdH, p) = AT(cur.idH, p);
             idp = ni; idz = ni;
         }
         const float deltaF = idp - idz;

@@ -1153,6 +1153,7 @@ __global__ __launch_bounds__(256) void k_point_step(BaPtrs B, BaDims D, ResSet S
     if (mode & PS_LOAD) { float b = B.pidepth_backup[p]; B.pidepth[p] = b; B.pidepth_zero[p] = b; return; }   // loadSateBackup
     const int F = D.F, FS = D.FS, h = B.phost[p];
     float step = B.pstep[p];
+    if (mode & PS_RESUB) { B.pLastHdiF[p] = S.HdiF[p]; B.pLastBdSumF[p] = S.bdSumF[p]; B.pLastIdH[p] = S.idH[p]; }      // what this solve's accumulateSCF_MT left in the point
     if ((mode & PS_RESUB) && S.nActive[p] <= 0) step = 0.0f;
     if ((mode & PS_RESUB) && S.nActive[p] > 0) {
         float b = S.bdSumF[p];
