@@ -92,7 +92,7 @@ def parity_check(win, ba, stream):
     return res
 
 
-def measure(args, config, rank, local_rank, world, dist, steps, warmup, min_timed_s=0.05, with_parity=True):
+def measure(args, config, rank, local_rank, world, dist, steps, warmup, min_timed_s=2.0, with_parity=True):
     """One BASELINE window: median time of blocks of EXACTLY `steps` forced GN iterations + the live roofline of k_linearize."""
     from ldso_amd import synth, binding, dist as ldist
     win = synth.make_config(config)
@@ -136,10 +136,10 @@ def measure(args, config, rank, local_rank, world, dist, steps, warmup, min_time
     run(warmup, 0)
     fence()
     # The contract times EXACTLY `steps` iterations between two fences.  One such block is < 1 ms at the driver's --steps 20, so
-    # the block is repeated until >= 50 ms have been timed and the MEDIAN block is reported (every block bracketed by the fences,
-    # maximum over ranks per block).
+    # the block is repeated until >= min_timed_s (2 s for the headline window: long enough for the driver's GPU-busy sampling to see
+    # it) have been timed and the MEDIAN block is reported (every block bracketed by the fences, maximum over ranks per block).
     blocks, total = [], 0.0
-    while (total < min_timed_s or len(blocks) < 3) and len(blocks) < 2000:
+    while (total < min_timed_s or len(blocks) < 3) and len(blocks) < 200000:
         fence()
         t0 = time.perf_counter()
         run(steps, 2)
@@ -176,10 +176,14 @@ def measure(args, config, rank, local_rank, world, dist, steps, warmup, min_time
     # of the same command is printed next to it (profiles/ is regenerated in the commit that changes a kernel).
     lin_b2b = ba.time_linearize(100)
     lin_insitu = max(ktimes["k_linearize"]["avg_us"] - ev_ms * 1e3, 0.0)
-    lin_us = max(lin_b2b, lin_insitu)
-    achieved = alg_bytes / (lin_us * 1e-6) / 1e9 if lin_us > 0 else 0.0
+    lin_live_us = max(lin_b2b, lin_insitu)
     single = world == 1 and not args.no_prior and not dist_path
     rocprof_us, rocprof_src = committed_profile(config, "kernel_us") if single else (None, None)
+    # `achieved` / `frac` follow from the LONGER of (live HIP-event duration in this process, committed rocprofv3 --kernel-trace average of
+    # the same command under profiles/): a reader who recomputes frac from profiles/ gets this number or a better one, never a worse one.
+    lin_us = max(lin_live_us, rocprof_us or 0.0)
+    achieved = alg_bytes / (lin_us * 1e-6) / 1e9 if lin_us > 0 else 0.0
+    achieved_live = alg_bytes / (lin_live_us * 1e-6) / 1e9 if lin_live_us > 0 else 0.0
     # HBM traffic per launch: rocprofv3 PMC counters cannot be read from inside this process; the value is the committed
     # measurement of the same command (profiles/rNN_pmc_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, the guide's gfx950 correction)
     traffic, traffic_src = committed_profile(config, "traffic") if single else (None, None)
@@ -194,6 +198,8 @@ def measure(args, config, rank, local_rank, world, dist, steps, warmup, min_time
         "roofline": {"bound": "hbm", "kernel": "k_linearize", "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s",
                      "frac": round(achieved / 8000.0, 5), "traffic": traffic, "traffic_source": traffic_src,
                      "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": round(lin_us, 3),
+                     "avg_launch_us_source": "committed rocprofv3 average" if (rocprof_us or 0.0) >= lin_live_us else "live HIP events",
+                     "achieved_live": round(achieved_live, 2), "frac_live": round(achieved_live / 8000.0, 5), "avg_launch_us_live": round(lin_live_us, 3),
                      "avg_launch_us_back_to_back_100": round(lin_b2b, 3), "avg_launch_us_in_pipeline_events_minus_empty_pair": round(lin_insitu, 3),
                      "rocprofv3_avg_us_committed_profile": rocprof_us, "rocprofv3_profile": rocprof_src,
                      "step_achieved_GBps": round((alg_bytes + 8 * (8 * F + 4) ** 2) / (dt / steps) / 1e9, 2)},
@@ -212,6 +218,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the informational C4 / C5 / tracker / tracer / initialiser lines")
     ap.add_argument("--no-prior", action="store_true", help="window without the (synthetic) marginalisation prior H_M / b_M")
+    ap.add_argument("--min-timed-s", type=float, default=2.0, help="repeat the timed block of exactly --steps iterations until this much time has been measured (profiling runs pass a small value)")
     ap.add_argument("--force-dist-path", action="store_true", help="1 GPU only: run the multi-GPU step (reduce_local / solve_reduced) with a no-op all-reduce")
     args = ap.parse_args()
 
@@ -241,7 +248,7 @@ def main():
             except TypeError:          # older torch without device_id
                 dist.init_process_group("nccl", rank=rank, world_size=world)
 
-    m = measure(args, args.config, rank, local_rank, world, dist, args.steps, args.warmup)
+    m = measure(args, args.config, rank, local_rank, world, dist, args.steps, args.warmup, min_timed_s=args.min_timed_s)
     win = m.pop("win")
     if rank == 0:
         out = {
@@ -275,7 +282,7 @@ def main():
                 if cfg == args.config:
                     continue
                 try:
-                    e = measure(args, cfg, rank, local_rank, world, dist, min(args.steps, 100), min(args.warmup, 10), min_timed_s=0.03)
+                    e = measure(args, cfg, rank, local_rank, world, dist, min(args.steps, 100), min(args.warmup, 10), min_timed_s=0.2)
                     e.pop("win")
                     out[key] = e
                 except SystemExit:
@@ -296,7 +303,7 @@ def main():
         dist.destroy_process_group()
 
 
-def batched_line(args, local_rank, Bs=(8, 32)):
+def batched_line(args, local_rank, Bs=(8, 32), min_timed_s=0.2):
     """Batched windows: B independent C3 windows per launch (ldso_ba_batch_*), three launches per iteration for the
     whole batch.  Aggregate GN iterations/s over the batch and the roofline of the batched k_linearize (B x the algorithmic bytes of
     one window / its launch time)."""
@@ -305,17 +312,18 @@ def batched_line(args, local_rank, Bs=(8, 32)):
     synth.add_synthetic_prior(win)
     tstream = torch.cuda.Stream()
     torch.cuda.set_stream(tstream)
-    out = {"workload": f"B independent C3 windows ({win.F} KF x {win.P} pt, R = {win.R}) per launch, forced GN iterations"}
+    out = {"workload": f"B independent, DIFFERENT C3 windows (seeds 20260925 + i: own scene, images, poses, points; {win.F} KF x {win.P} pt, R = {win.R}) per launch, forced GN iterations"}
     handles = []
     for B in Bs:
         while len(handles) < B:
-            g = binding.BA.from_window(win, device=local_rank, stream=tstream.cuda_stream)
+            wi = win if not handles else synth.add_synthetic_prior(synth.make_config("C3", seed=20260925 + len(handles)))
+            g = binding.BA.from_window(wi, device=local_rank, stream=tstream.cuda_stream)
             g.collect_active(); g.linearize_all(False); g.apply_res()
             handles.append(g)
         bt = binding.BABatch(handles[:B])
         bt.enqueue_gn(0, 10); torch.cuda.synchronize()
         blocks, total, steps = [], 0.0, 50
-        while total < 0.05 or len(blocks) < 3:
+        while total < min_timed_s or len(blocks) < 3:
             t0 = time.perf_counter()
             bt.enqueue_gn(2, steps)
             torch.cuda.synchronize()
@@ -447,10 +455,55 @@ def cpu_baseline(win):
             d.append((t_opt(12, mt) - t_opt(2, mt)) / 10.0)
         res[key] = float(np.median(d))
     ncpu = os.cpu_count()
-    return {"value": round(1.0 / res["mt6"], 2), "unit": "GN iters/s", "cores": 6, "kind": "port",
+    port = {"value": round(1.0 / res["mt6"], 2), "unit": "GN iters/s", "cores": 6, "kind": "port",
             "sample": f"median per-iteration time of optimize(12)-optimize(2) over ~8 s, same {win.F} KF x {win.P} pt window, 6 worker threads "
                       f"(reference NUM_THREADS) on a {ncpu}-vCPU host; -O3 -march=native" if fast else "portable build",
-            "single_thread_value": round(1.0 / res["st1"], 2), "host_vcpus": ncpu}
+            "single_thread_value": round(1.0 / res["st1"], 2), "host_vcpus": ncpu,
+            "upper_bound_of_reference": True,      # the restatement has no shared_ptr / weak_ptr.lock() graph: it is faster than the code it restates
+            "window_recreated_per_sample": True}
+    ref = reference_compiled_baseline(win)
+    if ref is None:
+        return port
+    # the reference's own translation units are the baseline; the restatement's figure rides along
+    ref["port"] = port
+    return ref
+
+
+def reference_compiled_baseline(win):
+    """oracle/_ref/libldso_ref_fast.so: the reference's OWN FullSystem::optimize / EnergyFunctional / PointFrameResidual::linearize /
+    IndexThreadReduce (translation units compiled unmodified, -O3 x86-64-v3) on the same window, 6 worker threads (multiThreading = true,
+    NUM_THREADS = 6: the reference's default) and 1 thread.  Eigen / Sophus are the header shim of oracle/ref_shim (eager evaluation,
+    no expression templates): stated in the JSON.  None where the prebuilt library is absent."""
+    import copy
+    try:
+        from oracle import pyref as pr
+        if pr.lib_fast() is None:
+            return None
+    except Exception:
+        return None
+    w = copy.deepcopy(win)
+    w.settings = w.settings.copy(); w.settings["minOptIterations"] = 1000          # forced iterations: canbreak never ends the loop (FullSystem.cc:829)
+
+    def t_opt(n, mt):
+        r = pr.RefWindow(w, fast=True)
+        r.fs_attach(multithreading=mt)
+        t = r.fs_time_optimize(n)
+        r.close()
+        return t
+
+    res = {}
+    for mt, key in ((True, "mt6"), (False, "st1")):
+        d = []
+        t_end = time.perf_counter() + 8.0
+        while time.perf_counter() < t_end or len(d) < 3:
+            d.append((t_opt(12, mt) - t_opt(2, mt)) / 10.0)
+        res[key] = float(np.median(d))
+    return {"value": round(1.0 / res["mt6"], 2), "unit": "GN iters/s", "cores": 6, "kind": "reference",
+            "sample": f"the reference's FullSystem::optimize on the same {win.F} KF x {win.P} pt window: median per-iteration time of optimize(12)-optimize(2) "
+                      f"over ~8 s per mode, multiThreading = true (IndexThreadReduce, NUM_THREADS = 6) on a {os.cpu_count()}-vCPU host",
+            "single_thread_value": round(1.0 / res["st1"], 2), "host_vcpus": os.cpu_count(),
+            "build": "reference translation units compiled unmodified, g++ -O3 -march=x86-64-v3", "eigen": "shim (oracle/ref_shim: eager evaluation, no expression templates)",
+            "window_recreated_per_sample": True}
 
 
 if __name__ == "__main__":

@@ -162,6 +162,7 @@ int orc_do_step(void *h) { return ((OrcWindow *) h)->fs.doStepFromBackup(1, 1, 1
 void orc_solve_system(void *h, int iteration, double lambda) { ((OrcWindow *) h)->fs.solveSystem(iteration, lambda); }
 
 float orc_optimize(void *h, int niters) { return ((OrcWindow *) h)->fs.optimize(niters); }
+int orc_is_lost(void *h) { return ((OrcWindow *) h)->fs.isLost ? 1 : 0; }      // FullSystem::isLost after optimize (FullSystem.cc:853-857)
 
 int orc_energy_log(void *h, double *out, int cap) {
     FullSystem &fs = ((OrcWindow *) h)->fs;

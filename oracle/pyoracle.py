@@ -128,6 +128,9 @@ class OracleWindow:
     def optimize(self, niters: int) -> float:
         return float(self.L.orc_optimize(self.h, C.c_int(niters)))
 
+    def is_lost(self) -> bool:
+        return bool(self.L.orc_is_lost(self.h))
+
     def time_optimize(self, niters: int) -> float:
         return float(self.L.orc_time_optimize(self.h, C.c_int(niters)))
 

@@ -34,6 +34,33 @@ def available() -> bool:
     return os.path.exists(lib_path())
 
 
+_LIB_FAST = None
+
+
+def lib_fast():
+    """The same reference translation units at the reference's own optimisation level (-O3, x86-64-v3): bench.py's cpu_baseline only.
+    Returns None where the file is missing or the host lacks AVX2 / FMA (then the pin build is timed and the JSON says so)."""
+    global _LIB_FAST
+    if _LIB_FAST is None:
+        path = os.path.join(_HERE, "_ref", "libldso_ref_fast.so")
+        if not os.path.exists(path) and os.path.isdir("/root/reference"):
+            try:
+                subprocess.run(["make", "-C", _HERE, "ref_fast"], check=True, capture_output=True)
+            except Exception:
+                return None
+        try:
+            flags = open("/proc/cpuinfo").read()
+        except OSError:
+            flags = ""
+        if not os.path.exists(path) or " avx2" not in flags or " fma" not in flags:
+            return None
+        L = C.CDLL(path)
+        L.ref_create.restype = C.c_void_p
+        L.ref_fs_time_optimize.restype = C.c_double
+        _LIB_FAST = L
+    return _LIB_FAST
+
+
 def lib():
     global _LIB
     if _LIB is None:
@@ -43,6 +70,7 @@ def lib():
         L.ref_create.restype = C.c_void_p
         L.ref_linearize_all.restype = C.c_double
         L.ref_fs_optimize.restype = C.c_float
+        L.ref_fs_time_optimize.restype = C.c_double
         _LIB = L
     return _LIB
 
@@ -50,8 +78,8 @@ def lib():
 class RefWindow:
     """The reference's EnergyFunctional / PointFrameResidual / accumulators on one flattened window (same inputs as OracleWindow)."""
 
-    def __init__(self, win: synth.Window):
-        self.L = lib()
+    def __init__(self, win: synth.Window, fast: bool = False):
+        self.L = lib_fast() if fast else lib()
         self.win = win
         self.F, self.P, self.R = win.F, win.P, win.R
         imgs, self._keep = _img_ptrs(win.images[: win.F], win.levels)
@@ -98,6 +126,9 @@ class RefWindow:
         log = self.fs_log()
         energies = [float(m) for m in re.findall(r"A\(([-0-9.eE+naif]+)\)=\(AV", log)]
         return rv, np.array(energies)
+
+    def fs_time_optimize(self, iterations: int) -> float:
+        return float(self.L.ref_fs_time_optimize(self.h, C.c_int(iterations)))
 
     def fs_is_lost(self) -> bool:
         return bool(self.L.ref_fs_is_lost(self.h))

@@ -33,6 +33,7 @@
 #include <fstream>
 #include <sstream>
 #include <string>
+#include <chrono>
 #include <deque>
 #include <list>
 #include <queue>
@@ -544,6 +545,17 @@ int ref_fs_log(void *h, char *out, int cap) {
 }
 // float FullSystem::optimize(int mnumOptIts) (FullSystem.cc:725-864); the per-iteration energies are in the log (printOptRes)
 float ref_fs_optimize(void *h, int iterations) { FsCall c(h); return c.fs->optimize(iterations); }
+// wall time of one FullSystem::optimize(iterations) call (the cpu_baseline leg of bench.py: the reference's own code, shared_ptr graph,
+// IndexThreadReduce and all - with the header shim's Eigen, see ref_shim/Eigen/Core)
+double ref_fs_time_optimize(void *h, int iterations) {
+    RefWindow *W = (RefWindow *) h;
+    FullSystem *fs = fs_of(W);
+    auto t0 = std::chrono::steady_clock::now();
+    fs->optimize(iterations);
+    auto t1 = std::chrono::steady_clock::now();
+    W->frames = fs->frames; W->activeResiduals = fs->activeResiduals;
+    return std::chrono::duration<double>(t1 - t0).count();
+}
 int ref_fs_is_lost(void *h) { return ((RefWindow *) h)->fs && ((RefWindow *) h)->fs->isLost ? 1 : 0; }
 // the activeResiduals list of optimize (:735-755) - restated (it is inline in optimize); everything below is the reference's member
 void ref_fs_collect_active(void *h, int reset_oob) { ref_collect_active(h, reset_oob); FsCall c(h); c.fs->activeResiduals = c.W->activeResiduals; }

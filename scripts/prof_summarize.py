@@ -28,7 +28,7 @@ for d in sorted(glob.glob(os.path.join(out, "stats_*"))):
         print("  ", r[0][:70], "calls", r[1], "avg ns", r[3])
 
 # calibration of the gfx950 FETCH_SIZE unit: scripts/micro/pmc_calib.hip (see profiles/r01_pmc_traffic.json "calibration")
-for cfg in ("C3", "C4", "C5"):
+for cfg in ("C3", "C4", "C5", "B32"):
     res = {"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, with --kernel-trace only) around `python bench.py --steps 40 --warmup 5 "
                    f"--no-cpu-baseline --no-extras --config {cfg}`; KB per launch as reported; corrected = 2 x FETCH_SIZE + WRITE_SIZE (gfx950: FETCH_SIZE "
                    "tallies 128-B requests at 64 B; calibrated with scripts/micro/pmc_calib.hip: 256 MB of 4-byte coalesced loads report 0.5000x, stores 1.000x)",
@@ -64,3 +64,45 @@ for cfg in ("C3", "C4", "C5"):
     print("== pmc", cfg)
     for name, d in res["kernels"].items():
         print("  ", name, d)
+
+# SQ counters of the k_linearize kernels (two 8-slot passes per configuration): sums over the waves of a launch, averaged over the launches.
+# Units (MI355X_MICROARCH.md): SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over waves; SQ_BUSY_CYCLES per SE/XCD.
+sq = {"note": "rocprofv3 --kernel-trace --pmc <8 SQ counters> (two passes A / B) around the bench command of each configuration (C3, C5: bench.py --config; "
+              "B32: scripts/bench_batched.py --B 32 = 32 different windows per launch); per-launch means over the launches of the kernel named in `kernel`; "
+              "derived: valu_busy = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES (share of wave time with a VALU instruction executing), wait_any / wait_inst_any / "
+              "active_any = the three disjoint buckets of SQ_WAVE_CYCLES, valu_insts_per_wave = SQ_INSTS_VALU / SQ_WAVES.", "configs": {}}
+for cfg in ("C3", "C5", "B32"):
+    per = {}
+    for ps in ("A", "B"):
+        cc = find(f"sq_{cfg}_{ps}/**/*counter_collection.csv")
+        if not cc:
+            continue
+        acc = defaultdict(lambda: defaultdict(list))
+        for r in csv.DictReader(open(cc)):
+            name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+            if name.startswith("k_linearize"):
+                acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for name, cs in acc.items():
+            d = per.setdefault(name, {})
+            for c, v in cs.items():
+                d[c] = round(sum(v) / len(v), 1); d["launches_" + ps] = len(v)
+    if not per:
+        continue
+    # the GN-iteration kernel = the one with the most launches
+    name = max(per, key=lambda k: per[k].get("launches_A", 0))
+    d = per[name]
+    wc = d.get("SQ_WAVE_CYCLES", 0.0)
+    der = {}
+    if wc:
+        der = {"valu_busy": round(d.get("SQ_ACTIVE_INST_VALU", 0) / wc, 4), "wait_any": round(d.get("SQ_WAIT_ANY", 0) / wc, 4),
+               "wait_inst_any": round(d.get("SQ_WAIT_INST_ANY", 0) / wc, 4), "active_any": round(d.get("SQ_ACTIVE_INST_ANY", 0) / wc, 4)}
+    if d.get("SQ_WAVES"):
+        der["valu_insts_per_wave"] = round(d.get("SQ_INSTS_VALU", 0) / d["SQ_WAVES"], 1)
+        der["vmem_rd_insts_per_wave"] = round(d.get("SQ_INSTS_VMEM_RD", 0) / d["SQ_WAVES"], 1)
+        der["lds_insts_per_wave"] = round(d.get("SQ_INSTS_LDS", 0) / d["SQ_WAVES"], 1)
+    if d.get("SQ_LDS_IDX_ACTIVE"):
+        der["lds_bank_conflict_share"] = round(d.get("SQ_LDS_BANK_CONFLICT", 0) / d["SQ_LDS_IDX_ACTIVE"], 4)
+    sq["configs"][cfg] = {"kernel": name, "counters": d, "derived": der, "other_kernels": {k: v for k, v in per.items() if k != name}}
+    print("== sq", cfg, name, der)
+if sq["configs"]:
+    json.dump(sq, open(os.path.join(dst, f"{tag}_sq_linearize.json"), "w"), indent=1)

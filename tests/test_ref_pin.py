@@ -434,3 +434,40 @@ def test_fullsystem_track_new_coarse_pinned(lost):
     T_true = w.truth["w2c"][w.F]
     assert np.abs(b["w2c"] - T_true[:3]).max() < 5e-3                       # and it is the right pose
     assert len(o.motion_hypotheses(sprelast, slast, lastF)) == 83 and len(o.motion_hypotheses(sprelast, slast, lastF, poses_valid=False)) == 1
+
+
+def nonfinite_windows(base):
+    """The reference's failure semantics on four corrupted copies of a window: what it does is 'propagate non-finite numbers'."""
+    def imgs(w):
+        w = copy.deepcopy(w); w.images = [[l.copy() for l in im] for im in w.images]; return w
+    a = imgs(base); a.images[2][0][60:120, 80:200, 0] = np.nan          # NaN irradiance: hitColor[0] not finite -> OOB (Residuals.cc:142-145)
+    b = imgs(base); b.images[2][0][60:120, 80:200, 0] = np.inf          # Inf likewise
+    c = imgs(base); c.images[2][0][60:120, 80:200, 1] = np.nan          # NaN gradient: finite residual, NaN weight -> NaN energy -> isLost (FullSystem.cc:853-857)
+    d = copy.deepcopy(base); d.frames = d.frames.copy(); d.frames["state"][2, 0] = np.nan      # NaN pose: NaN precalc, every projection fails its bounds test
+    return {"nan_intensity": a, "inf_intensity": b, "nan_gradient": c, "nan_state": d}
+
+
+@pytest.mark.parametrize("case", ["nan_intensity", "inf_intensity", "nan_gradient", "nan_state"])
+def test_nonfinite_inputs_pinned(small, case):
+    """NaN / Inf pixels and a NaN frame state through the reference's own optimize() (Release semantics: asserts off) and the oracle's:
+    same residual states / removal, same energies (NaN where the reference's are NaN), same isLost."""
+    win = nonfinite_windows(small)[case]
+    o, r = po.OracleWindow(win), pr.RefWindow(win)
+    r.fs_attach()
+    rv_r, log_r = r.fs_optimize(3)
+    rv_o = o.optimize(3); log_o = o.energy_log()
+    assert (rv_r == rv_o) or (np.isnan(rv_r) and np.isnan(rv_o))
+    assert r.fs_is_lost() == o.is_lost() == (case == "nan_gradient")
+    assert len(log_o) == len(log_r) + 1
+    assert np.allclose(log_o[:-1], log_r, rtol=1e-12, atol=1e-6, equal_nan=True)
+    ro, rr = o.get_residuals(), r.get_residuals()
+    for k in ("state_state", "is_active", "alive"):
+        _same(ro[k], rr[k], k)
+    fo, fr = o.get_frames(), r.get_frames()
+    assert np.array_equal(np.isnan(fo["frames"]["state"]), np.isnan(fr["frames"]["state"]))
+    (pto, _), (ptr, _) = o.get_points(), r.get_points()
+    assert np.array_equal(pto["idepth"], ptr["idepth"], equal_nan=True)
+    if case in ("nan_intensity", "inf_intensity"):
+        assert 0 < (rr["alive"] == 0).sum() < win.R and np.isfinite(rv_r) and not np.isnan(fr["frames"]["state"]).any()
+    if case == "nan_state":
+        assert (rr["alive"] == 0).all() and np.isinf(rv_r)          # everything ends OOB; sqrtf(E / (8 * 0)) - and the reference does NOT flag isLost
