@@ -469,6 +469,25 @@ def cpu_baseline(win):
     return ref
 
 
+class _QuietCStdout:
+    """The reference's translation units printf() to stdout ("using pyramid levels ...", "destroyed ThreadReduce"): bench.py prints ONE JSON
+    line, so file descriptor 1 points at /dev/null while they run (and C stdio is flushed on both sides of the switch)."""
+    def __enter__(self):
+        import ctypes
+        self.libc = ctypes.CDLL(None)
+        sys.stdout.flush(); self.libc.fflush(None)
+        self.saved = os.dup(1)
+        self.null = os.open(os.devnull, os.O_WRONLY)
+        os.dup2(self.null, 1)
+        return self
+
+    def __exit__(self, *a):
+        sys.stdout.flush(); self.libc.fflush(None)
+        os.dup2(self.saved, 1)
+        os.close(self.saved); os.close(self.null)
+        return False
+
+
 def reference_compiled_baseline(win):
     """oracle/_ref/libldso_ref_fast.so: the reference's OWN FullSystem::optimize / EnergyFunctional / PointFrameResidual::linearize /
     IndexThreadReduce (translation units compiled unmodified, -O3 x86-64-v3) on the same window, 6 worker threads (multiThreading = true,
@@ -492,12 +511,13 @@ def reference_compiled_baseline(win):
         return t
 
     res = {}
-    for mt, key in ((True, "mt6"), (False, "st1")):
-        d = []
-        t_end = time.perf_counter() + 8.0
-        while time.perf_counter() < t_end or len(d) < 3:
-            d.append((t_opt(12, mt) - t_opt(2, mt)) / 10.0)
-        res[key] = float(np.median(d))
+    with _QuietCStdout():
+        for mt, key in ((True, "mt6"), (False, "st1")):
+            d = []
+            t_end = time.perf_counter() + 8.0
+            while time.perf_counter() < t_end or len(d) < 3:
+                d.append((t_opt(12, mt) - t_opt(2, mt)) / 10.0)
+            res[key] = float(np.median(d))
     return {"value": round(1.0 / res["mt6"], 2), "unit": "GN iters/s", "cores": 6, "kind": "reference",
             "sample": f"the reference's FullSystem::optimize on the same {win.F} KF x {win.P} pt window: median per-iteration time of optimize(12)-optimize(2) "
                       f"over ~8 s per mode, multiThreading = true (IndexThreadReduce, NUM_THREADS = 6) on a {os.cpu_count()}-vCPU host",

@@ -113,6 +113,12 @@ int ldso_ba_set_point_stats(ldso_ba_t *h, const float *maxRelBaseline, const int
  * reduce_buf_dev is a caller-allocated device buffer of ldso_ba_reduce_doubles() doubles that the
  * caller all-reduces (sum) between ldso_ba_reduce_local() and ldso_ba_solve_reduced(). */
 int ldso_ba_set_shard(ldso_ba_t *h, int point_begin, int point_end);
+/* Points per workgroup of the fused linearisation kernel: 0 (default) = as few as keep one window's grid within one workgroup per CU (the
+ * latency of a single window); n > 0 (multiple of 4) = fixed chunks of n points (ldso_ba_batch_create applies its own to the windows of a
+ * batch: many windows fill the launch, a workgroup then takes several points per wavefront).  The fp32 partial sums of the top Hessian
+ * are formed per chunk: two handles agree bit for bit only under the same chunking. */
+int ldso_ba_set_chunk_points(ldso_ba_t *h, int points_per_workgroup);
+int ldso_ba_get_chunk_points(ldso_ba_t *h, int *points_per_workgroup, int *workgroups);
 size_t ldso_ba_reduce_doubles(ldso_ba_t *h);
 
 /* --- the optimisation slice, one entry per reference function ------------------------------------ */
@@ -185,6 +191,8 @@ typedef struct ldso_ba_batch ldso_ba_batch_t;
 int ldso_ba_batch_create(ldso_ba_t *const *handles, int n, ldso_ba_batch_t **out);
 int ldso_ba_batch_enqueue_gn(ldso_ba_batch_t *b, int first_iteration, int iters);
 int ldso_ba_batch_destroy(ldso_ba_batch_t *b);
+/* points per workgroup ldso_ba_batch_create gave the windows of the batch (0: their single-window chunking was kept; ldso_ba_batch_destroy restores it) */
+int ldso_ba_batch_chunk_points(ldso_ba_batch_t *b, int *points_per_workgroup);
 /* bench / profiling: average duration [us] of the batched k_linearize over `reps` back-to-back launches (HIP events on the batch's stream) */
 int ldso_ba_batch_time_linearize(ldso_ba_batch_t *b, int reps, double *avg_us);
 /* The same sharded iteration with the collective inside, for a C / C++ host (north_star: host code stays C++): `iters` forced

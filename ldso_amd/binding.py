@@ -187,6 +187,14 @@ class BA:
     def set_shard(self, begin, end):
         _chk(self.L.ldso_ba_set_shard(self.h, C.c_int(begin), C.c_int(end)))
 
+    def set_chunk_points(self, n):
+        _chk(self.L.ldso_ba_set_chunk_points(self.h, C.c_int(n)))
+
+    def get_chunk_points(self):
+        n, w = C.c_int(), C.c_int()
+        _chk(self.L.ldso_ba_get_chunk_points(self.h, C.byref(n), C.byref(w)))
+        return n.value, w.value
+
     def reduce_doubles(self) -> int:
         return int(self.L.ldso_ba_reduce_doubles(self.h))
 
@@ -373,6 +381,11 @@ class BABatch:
         us = C.c_double()
         _chk(self.L.ldso_ba_batch_time_linearize(self.h, C.c_int(reps), C.byref(us)))
         return us.value
+
+    def chunk_points(self):
+        n = C.c_int()
+        _chk(self.L.ldso_ba_batch_chunk_points(self.h, C.byref(n)))
+        return n.value
 
     def close(self):
         if self.h:

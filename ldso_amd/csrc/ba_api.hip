@@ -33,7 +33,7 @@ hipError_t ba_launch_acc_init(const BaPtrs &B, const BaDims &D, const GnInit &gi
 hipError_t ba_launch_gn_export(const BaPtrs &B, const BaDims &D, const ResSet &S, double *tail, hipStream_t st);
 hipError_t ba_launch_activate(const BaPtrs &B, const BaDims &D, const ldso_settings_t &S, const ldso_immature_t *d_pts, ldso_activation_t *d_out, int n, int minObs,
                               float minIdepthH_act, int GNIts, hipStream_t st);
-hipError_t ba_launch_linearize_batch(const BatchItem *d_items, int nWin, int totalChunks, int FS, int cur, const ldso_settings_t &S, int stepMode, float calibPrior, hipStream_t st, int itCheck = -1);
+hipError_t ba_launch_linearize_batch(const BatchItem *d_items, const BatchBlock *d_blocks, int totalChunks, int FS, int cur, const ldso_settings_t &S, int stepMode, float calibPrior, hipStream_t st, int itCheck = -1);
 hipError_t ba_launch_reduce_batch(const BatchItem *d_items, int nWin, int totalBlocks, int cur, float calibPrior, double l1, double il, hipStream_t st);
 hipError_t ba_launch_gn_solve_batch(const BatchItem *d_items, int nWin, const BaDims &Dmax, int cur, const ldso_settings_t &St, int iteration, double lambda, hipStream_t st);
 hipError_t ba_launch_lm_energies(const BaPtrs &B, const BaDims &D, const ResSet &S, float calibPrior, bool hasPrior, hipStream_t st);
@@ -47,6 +47,7 @@ void ldso_set_error(const std::string &s) { g_err = s; }
 
 #define CHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { ldso_set_error(std::string(#call) + ": " + hipGetErrorString(e_)); return LDSO_E_HIP; } } while (0)
 #define REQ(cond, msg) do { if (!(cond)) { ldso_set_error(msg); return LDSO_E_INVALID; } } while (0)
+#define RUN(x) do { int r_ = (x); if (r_ != LDSO_OK) return r_; } while (0)
 
 struct Timer { hipEvent_t a, b; int which; };
 
@@ -84,6 +85,10 @@ struct ldso_ba {
     // the window's descriptors in device memory (one BatchItem): the plain linearisation of the GN iteration reads them from there - passed
     // as kernel arguments, the ~150 pointers outgrow the scalar registers (400 SGPR spill moves in the kernel)
     BatchItem *d_item = nullptr, *h_item = nullptr;
+    BatchBlock *d_blocks = nullptr;    // [maxChunks] the window's chunks as k_linearize_batch reads them (window index 0)
+    std::vector<BatchBlock> h_blocks;
+    bool appliedValid = false;         // the applied residual set holds a linearisation of the resident window (its per-chunk partials feed the next reduce)
+    int chunkPoints = 0;               // points per workgroup of k_linearize: 0 = as few as keep the grid within one wave of workgroups (one window alone on the chip)
     BatchItem itemShadow;
     bool itemValid = false;
     int *h_stop = nullptr, *d_stop = nullptr;      // host-mapped word (and its device address): which iteration ended an un-forced optimize() loop
@@ -249,6 +254,7 @@ static int create_body(ldso_ba *H, int device, int w, int h, int max_frames, int
     H->ownStream = true;
     CHK(hipHostMalloc((void **) &H->h_item, sizeof(BatchItem)));
     { void *q_ = nullptr; CHK(hipMalloc(&q_, sizeof(BatchItem))); H->d_item = (BatchItem *) q_; }
+    { void *q_ = nullptr; CHK(hipMalloc(&q_, (size_t) H->maxChunks * sizeof(BatchBlock))); H->d_blocks = (BatchBlock *) q_; }
     CHK(hipHostMalloc((void **) &H->h_stop, 4 * sizeof(int), hipHostMallocMapped));
     CHK(hipHostGetDevicePointer((void **) &H->d_stop, H->h_stop, 0));
     memset(&H->B, 0, sizeof(H->B));
@@ -289,6 +295,7 @@ int ldso_ba_destroy(ldso_ba_t *H) {
     if (H->d_color) hipFree(H->d_color);
     if (H->h_item) hipHostFree(H->h_item);
     if (H->d_item) hipFree(H->d_item);
+    if (H->d_blocks) hipFree(H->d_blocks);
     if (H->h_stop) hipHostFree(H->h_stop);
     if (H->h_stage) hipHostFree(H->h_stage);
     if (H->d_stage) hipFree(H->d_stage);
@@ -390,7 +397,8 @@ static int build_chunks(ldso_ba *H) {
     BaDims &D = H->D;
     // smallest multiple of 4 points per chunk that keeps the grid within one wave of workgroups (one per CU)
     int CH = 4;
-    for (;; CH += 4) {
+    if (H->chunkPoints > 0) CH = H->chunkPoints;      // ldso_ba_set_chunk_points / ldso_ba_batch_create: many windows share a launch, fewer and fatter workgroups
+    else for (;; CH += 4) {
         int cnt = 0, run = 0, prev = -1;
         for (int q = D.pBegin; q < D.pEnd; q++) { int hq = H->h_phost[q]; if (hq != prev) { cnt += (run + CH - 1) / CH; run = 0; prev = hq; } run++; }
         cnt += (run + CH - 1) / CH;
@@ -412,6 +420,9 @@ static int build_chunks(ldso_ba *H) {
     REQ((int) p0.size() <= H->maxChunks, "too many chunks");
     D.nChunks = (int) p0.size();
     H2D(H->B.chunk_p0, p0); H2D(H->B.chunk_n, cn); H2D(H->B.chunk_host, ch); H2D(H->d_chunkStart, cs);
+    H->h_blocks.resize(p0.size());
+    for (size_t i = 0; i < p0.size(); i++) H->h_blocks[i] = BatchBlock{0, p0[i], cn[i], ch[i] | ((int32_t) i << 8)};
+    CHK(hipMemcpyAsync(H->d_blocks, H->h_blocks.data(), p0.size() * sizeof(BatchBlock), hipMemcpyHostToDevice, H->stream));
     for (int i = 0; i <= LD_MAXF; i++) H->chunkStarts.v[i] = (i <= D.F) ? cs[i] : cs[D.F];
     CHK(hipStreamSynchronize(H->stream));
     return LDSO_OK;
@@ -497,7 +508,7 @@ int ldso_ba_set_window(ldso_ba_t *H, int F, const int32_t *image_slot, int P, co
     }
     D.nL = (int) nLin;
     H->hasL = D.nL > 0;
-    H->cur = 0; H->pendingApply = false;
+    H->cur = 0; H->pendingApply = false; H->appliedValid = false;
     bool okT = W.again(B.pidepth_backup, pid, P);
     okT = okT && W.again(H->sets[1].state, st, PS) && W.again(H->sets[1].active, act, PS) && W.again(H->sets[1].energy, en, PS) && W.again(H->sets[1].JpJdF, jp, PS * 8);
     for (int s_ = 0; s_ < 2; s_++) {
@@ -528,6 +539,34 @@ int ldso_ba_set_point_stats(ldso_ba_t *H, const float *maxRelBaseline, const int
         CHK(hipMemcpyAsync(H->sets[s_].numGood, numGoodResiduals, (size_t) H->D.P * 4, hipMemcpyHostToDevice, H->stream));
     }
     CHK(hipStreamSynchronize(H->stream));
+    return LDSO_OK;
+}
+
+// Points per workgroup of the fused linearisation.  0 (default): the smallest chunk that keeps ONE window's grid within one workgroup per CU
+// (latency of a single window).  n > 0 (multiple of 4): fixed chunks of n points - what ldso_ba_batch_create applies to its windows, where
+// the launch is filled by many windows and a workgroup's fixed costs (operand staging, block reduction) should be spread over more points.
+// The fp32 partial sums of the top Hessian are formed per chunk: two handles agree bit for bit only under the same chunking.
+static int launch_linearize(ldso_ba *H, bool fix, int stepMode = 0, int itCheck = -1);
+// New chunks for the resident window.  The applied residual set carries per-chunk partial sums (top Hessian, energies) that the next
+// reduce reads: under a new chunking they are re-formed by linearising the applied state once more (same states, energies and Jacobians -
+// linearize is a function of the state - only the partials are cut differently).
+static int rechunk(ldso_ba *H) {
+    H->itemValid = false;
+    RUN(build_chunks(H));
+    if (H->appliedValid && !H->pendingApply) { RUN(launch_linearize(H, false, 0, -1)); H->cur ^= 1; }
+    return LDSO_OK;
+}
+int ldso_ba_set_chunk_points(ldso_ba_t *H, int points_per_workgroup) {
+    REQ(H && points_per_workgroup >= 0 && points_per_workgroup % 4 == 0 && points_per_workgroup <= 1024, "ldso_ba_set_chunk_points: 0 or a multiple of 4 up to 1024");
+    REQ(!H->pendingApply, "ldso_ba_set_chunk_points: a linearisation is pending (ldso_ba_apply_res first)");
+    H->chunkPoints = points_per_workgroup;
+    if (H->D.P > 0) { CHK(hipSetDevice(H->device)); return rechunk(H); }
+    return LDSO_OK;
+}
+int ldso_ba_get_chunk_points(ldso_ba_t *H, int *points_per_workgroup, int *workgroups) {
+    REQ(H && points_per_workgroup, "ldso_ba_get_chunk_points: null argument");
+    *points_per_workgroup = H->chunkPoints;
+    if (workgroups) *workgroups = H->D.nChunks;
     return LDSO_OK;
 }
 
@@ -616,13 +655,13 @@ static int refresh_item(ldso_ba *H) {
     return LDSO_OK;
 }
 
-static int launch_linearize(ldso_ba *H, bool fix, int stepMode = 0, int itCheck = -1) {
+static int launch_linearize(ldso_ba *H, bool fix, int stepMode, int itCheck) {
     t_begin(H, 0);
     GnInit gi; gi.enable = (H->D.pBegin > 0) ? 2 : 1; gi.hasPrior = H->hasPrior ? 1 : 0; gi.calibPrior = H->settings.initialCalibHessian; gi.itCheck = itCheck;
     if (!fix && !H->hasL && gi.enable == 1 && H->D.FS == 8) {      // (two slot groups, F > 8: the argument-based kernel is the faster one, 43.0 against 45.6 us at C5)
         // the plain linearisation (GN iterations): descriptors from device memory (k_linearize_batch with one window)
         { const int r_ = refresh_item(H); if (r_ != LDSO_OK) return r_; }
-        CHK(ba_launch_linearize_batch(H->d_item, 1, H->D.nChunks, H->D.FS, H->cur, H->settings, stepMode, gi.calibPrior, H->stream, itCheck));
+        CHK(ba_launch_linearize_batch(H->d_item, H->d_blocks, H->D.nChunks, H->D.FS, H->cur, H->settings, stepMode, gi.calibPrior, H->stream, itCheck));
     } else
     CHK(ba_launch_linearize(H->B, H->D, H->sets[H->cur], H->sets[H->cur ^ 1], H->settings, H->hasL, fix, stepMode, gi, H->stream));
     t_end(H);
@@ -650,7 +689,6 @@ static int launch_pstep(ldso_ba *H, const ResSet &S, int mode) {
     t_end(H);
     return LDSO_OK;
 }
-#define RUN(x) do { int r_ = (x); if (r_ != LDSO_OK) return r_; } while (0)
 
 static int read_scalars(ldso_ba *H, double *sc) {
     CHK(hipMemcpyAsync(sc, H->B.scalars, 16 * sizeof(double), hipMemcpyDeviceToHost, H->stream));
@@ -721,7 +759,7 @@ int ldso_ba_linearize_all(ldso_ba_t *H, int fix, double *energy_out) {
     RUN(launch_linearize(H, fix != 0));
     RUN(launch_solve(H, H->sets[H->cur ^ 1], SK_POST | SK_THRESH));
     H->pendingApply = true;
-    if (fix) { H->cur ^= 1; H->pendingApply = false; }     // applyRes happens inside the reductor when fixing
+    if (fix) { H->cur ^= 1; H->pendingApply = false; H->appliedValid = true; }     // applyRes happens inside the reductor when fixing
     double sc[16];
     RUN(read_scalars(H, sc));
     if (energy_out) *energy_out = sc[0];
@@ -731,7 +769,7 @@ int ldso_ba_linearize_all(ldso_ba_t *H, int fix, double *energy_out) {
 
 int ldso_ba_apply_res(ldso_ba_t *H) {
     REQ(H, "null handle");
-    if (H->pendingApply) { H->cur ^= 1; H->pendingApply = false; }
+    if (H->pendingApply) { H->cur ^= 1; H->pendingApply = false; H->appliedValid = true; }
     return LDSO_OK;
 }
 
@@ -815,7 +853,7 @@ static int enqueue_iteration(ldso_ba *H, int iteration, double lambda, int logId
         t_end(H);
     }
     RUN(launch_linearize(H, false, 1, itCheck));
-    H->cur ^= 1;      // forceAcceptStep: applyRes
+    H->cur ^= 1; H->appliedValid = true;      // forceAcceptStep: applyRes
     return LDSO_OK;
 }
 
@@ -914,7 +952,7 @@ int ldso_ba_optimize(ldso_ba_t *H, int mnumOptIts, int force_all, float *rmse_ou
     CHK(hipMemsetAsync(H->B.energyLog, 0, 64 * 8, H->stream));
     H->pendingApply = false;
     RUN(launch_linearize(H, false, 2));            // stepMode bit 1: resetOOB of the optimize() preamble fused into the first linearizeAll
-    H->cur ^= 1;                                   // applyRes
+    H->cur ^= 1; H->appliedValid = true;           // applyRes
     int done = 0;
     double lambda = 1e-1;
     {   // no iteration has asked to stop yet
@@ -1052,6 +1090,10 @@ struct ldso_ba_batch {
     std::vector<ldso_ba *> h;
     BatchItem *d_items = nullptr;      // [n] numbered over the whole batch, then [n] numbered per half (see ldso_ba_batch_enqueue_gn)
     std::vector<BatchItem> items;
+    BatchBlock *d_blocks = nullptr;    // [totalChunks] workgroups of the whole batch, then [halfChunks[0]] + [halfChunks[1]] per half
+    std::vector<BatchBlock> blocks;
+    size_t blocksCap = 0;
+    int chunkPoints = 0;               // the chunking ldso_ba_batch_create gave its windows
     int totalChunks = 0, totalReduce = 0, FS = 0, cur = 0;
     int n0 = 0;                        // windows in the first half (= all of them for batches under 4 windows)
     int halfChunks[2] = {0, 0}, halfReduce[2] = {0, 0};
@@ -1081,6 +1123,20 @@ static int batch_refresh(ldso_ba_batch *Bt) {
         else { Bt->halfChunks[1] = lin; Bt->halfReduce[1] = red; }
     }
     CHK(hipMemcpyAsync(Bt->d_items, Bt->items.data(), Bt->items.size() * sizeof(BatchItem), hipMemcpyHostToDevice, H0->stream));
+    // the workgroup table: whole batch (window index into items[0..n)), then half A (index into items[n..n+n0)) and half B (items[n+n0..))
+    Bt->blocks.clear();
+    for (size_t i = 0; i < n; i++) for (const BatchBlock &b : Bt->h[i]->h_blocks) Bt->blocks.push_back(BatchBlock{(int32_t) i, b.p0, b.np, b.host_chunk});
+    for (size_t i = 0; i < n; i++) { const int32_t w = (int) i < Bt->n0 ? (int32_t) i : (int32_t) i - Bt->n0; for (const BatchBlock &b : Bt->h[i]->h_blocks) Bt->blocks.push_back(BatchBlock{w, b.p0, b.np, b.host_chunk}); }
+    if (Bt->blocks.size() > Bt->blocksCap) {
+        CHK(hipStreamSynchronize(H0->stream));
+        if (Bt->aux) CHK(hipStreamSynchronize(Bt->aux));
+        if (Bt->d_blocks) hipFree(Bt->d_blocks);
+        Bt->d_blocks = nullptr; Bt->blocksCap = 0;
+        void *q = nullptr;
+        CHK(hipMalloc(&q, Bt->blocks.size() * sizeof(BatchBlock)));
+        Bt->d_blocks = (BatchBlock *) q; Bt->blocksCap = Bt->blocks.size();
+    }
+    CHK(hipMemcpyAsync(Bt->d_blocks, Bt->blocks.data(), Bt->blocks.size() * sizeof(BatchBlock), hipMemcpyHostToDevice, H0->stream));
     return LDSO_OK;
 }
 
@@ -1099,7 +1155,29 @@ int ldso_ba_batch_create(ldso_ba_t *const *handles, int n, ldso_ba_batch_t **out
         REQ(memcmp(&H->settings, &H0->settings, sizeof(H0->settings)) == 0, "ldso_ba_batch_create: the batched kernels run with ONE ldso_settings_t: every handle of a batch must have been created with identical settings");
     }
     CHK(hipSetDevice(H0->device));
+    // Chunking of a batch: the launch is filled by all windows together, so a workgroup takes several points per wavefront (its fixed
+    // costs - operand staging, block reduction, ~4.5 us - are then a fraction of its life) while the grid still holds a few workgroups
+    // per CU for balance.  Handles with an explicit ldso_ba_set_chunk_points keep theirs.
+    int Bt_chunk = 0;
+    {
+        long total = 0;
+        for (int i = 0; i < n; i++) total += handles[i]->D.P;
+        int ppw = (int) (total / ((long) H0->numCU * LD_WAVES));               // points per wavefront slot of the chip, capped at 4 (measured: 336 / 201 / 139 / 142 / 136 us per
+                                                                                 // launch of 32 C3 windows at 1 / 2 / 4 / 6 / 8 points per wavefront; 84 / 52 / 37 / 48 / 48 us for 8 windows)
+        if (const char *e = getenv("LDSO_BATCH_PPW")) { if (*e) ppw = atoi(e); }             // kernel experiments
+        ppw = ppw < 1 ? 1 : ppw > 8 ? 8 : ppw;
+        if (!getenv("LDSO_BATCH_PPW") && ppw > 4) ppw = 4;
+        const int CH = ppw * LD_WAVES;
+        Bt_chunk = ppw > 1 ? CH : 0;
+        for (int i = 0; i < n; i++) if (handles[i]->chunkPoints == 0 && ppw > 1) {      // ppw == 1: the single-window chunking already is the right one
+            handles[i]->chunkPoints = CH;
+            const int r_ = rechunk(handles[i]);
+            handles[i]->chunkPoints = 0;                                         // the policy stays "automatic": the next ldso_ba_set_window re-chunks for a single window
+            if (r_ != LDSO_OK) return r_;
+        }
+    }
     ldso_ba_batch *Bt = new ldso_ba_batch();
+    Bt->chunkPoints = Bt_chunk;
     Bt->h.assign(handles, handles + n);
     Bt->items.resize(2 * (size_t) n);
     Bt->n0 = (n >= 4) ? n / 2 : n;
@@ -1119,6 +1197,13 @@ int ldso_ba_batch_create(ldso_ba_t *const *handles, int n, ldso_ba_batch_t **out
     return LDSO_OK;
 }
 
+// points per workgroup ldso_ba_batch_create chose for the windows of this batch (0: it left their single-window chunking alone)
+int ldso_ba_batch_chunk_points(ldso_ba_batch_t *Bt, int *points_per_workgroup) {
+    REQ(Bt && points_per_workgroup, "ldso_ba_batch_chunk_points: null argument");
+    *points_per_workgroup = Bt->chunkPoints;
+    return LDSO_OK;
+}
+
 int ldso_ba_batch_destroy(ldso_ba_batch_t *Bt) {
     if (!Bt) return LDSO_OK;
     hipSetDevice(Bt->h[0]->device);
@@ -1128,6 +1213,9 @@ int ldso_ba_batch_destroy(ldso_ba_batch_t *Bt) {
     if (Bt->ev1) hipEventDestroy(Bt->ev1);
     if (Bt->evEnd) hipEventDestroy(Bt->evEnd);
     if (Bt->d_items) hipFree(Bt->d_items);
+    if (Bt->d_blocks) hipFree(Bt->d_blocks);
+    // back to the single-window chunking (handles that were re-chunked by ldso_ba_batch_create)
+    if (Bt->chunkPoints > 0) for (ldso_ba *H : Bt->h) if (H->chunkPoints == 0 && H->D.P > 0) rechunk(H);
     delete Bt;
     return LDSO_OK;
 }
@@ -1155,11 +1243,11 @@ int ldso_ba_batch_enqueue_gn(ldso_ba_batch_t *Bt, int first_iteration, int iters
         CHK(ba_launch_reduce_batch(itA, n0, Bt->halfReduce[0], cur, H0->settings.initialCalibHessian, l1, il, H0->stream));
         CHK(ba_launch_gn_solve_batch(itA, n0, Bt->Dmax, cur, H0->settings, first_iteration + i, 1e-1, H0->stream));
         if (n1 > 0 && i == 0) { CHK(hipEventRecord(Bt->ev1, H0->stream)); CHK(hipStreamWaitEvent(Bt->aux, Bt->ev1, 0)); }
-        CHK(ba_launch_linearize_batch(itA, n0, Bt->halfChunks[0], Bt->FS, cur, H0->settings, 1, H0->settings.initialCalibHessian, H0->stream));
+        CHK(ba_launch_linearize_batch(itA, Bt->d_blocks + Bt->totalChunks, Bt->halfChunks[0], Bt->FS, cur, H0->settings, 1, H0->settings.initialCalibHessian, H0->stream));
         if (n1 > 0) {
             CHK(ba_launch_reduce_batch(itB, n1, Bt->halfReduce[1], cur, H0->settings.initialCalibHessian, l1, il, Bt->aux));
             CHK(ba_launch_gn_solve_batch(itB, n1, Bt->Dmax, cur, H0->settings, first_iteration + i, 1e-1, Bt->aux));
-            CHK(ba_launch_linearize_batch(itB, n1, Bt->halfChunks[1], Bt->FS, cur, H0->settings, 1, H0->settings.initialCalibHessian, Bt->aux));
+            CHK(ba_launch_linearize_batch(itB, Bt->d_blocks + Bt->totalChunks + Bt->halfChunks[0], Bt->halfChunks[1], Bt->FS, cur, H0->settings, 1, H0->settings.initialCalibHessian, Bt->aux));
         }
         cur ^= 1;
     }
@@ -1177,9 +1265,9 @@ int ldso_ba_batch_time_linearize(ldso_ba_batch_t *Bt, int reps, double *avg_us) 
     RUN(batch_refresh(Bt));
     hipEvent_t a, b;
     CHK(hipEventCreate(&a)); CHK(hipEventCreate(&b));
-    CHK(ba_launch_linearize_batch(Bt->d_items, (int) Bt->h.size(), Bt->totalChunks, Bt->FS, H0->cur, H0->settings, 0, H0->settings.initialCalibHessian, H0->stream));
+    CHK(ba_launch_linearize_batch(Bt->d_items, Bt->d_blocks, Bt->totalChunks, Bt->FS, H0->cur, H0->settings, 0, H0->settings.initialCalibHessian, H0->stream));
     CHK(hipEventRecord(a, H0->stream));
-    for (int i = 0; i < reps; i++) CHK(ba_launch_linearize_batch(Bt->d_items, (int) Bt->h.size(), Bt->totalChunks, Bt->FS, H0->cur, H0->settings, 0, H0->settings.initialCalibHessian, H0->stream));
+    for (int i = 0; i < reps; i++) CHK(ba_launch_linearize_batch(Bt->d_items, Bt->d_blocks, Bt->totalChunks, Bt->FS, H0->cur, H0->settings, 0, H0->settings.initialCalibHessian, H0->stream));
     CHK(hipEventRecord(b, H0->stream));
     CHK(hipEventSynchronize(b));
     float ms = 0;

@@ -118,6 +118,10 @@ struct ChunkStarts {
 
 // One window of a batch (ldso_ba_batch_*): everything the kernels of a GN iteration take as arguments for a single window, in
 // device memory.  linBlock0 / redBlock0 = first workgroup of this window in the batched k_linearize / k_reduce launches.
+// one workgroup of a batched k_linearize: its window (index into the launch's BatchItem table) and its chunk, resolved on the host - the
+// kernel reads ONE 16-byte record instead of searching the window table and then three chunk arrays (two dependent memory round trips)
+struct BatchBlock { int32_t win, p0, np, host_chunk; };      // host_chunk = host frame | chunk-in-window << 8
+
 struct BatchItem {
     BaPtrs B;
     BaDims D;

@@ -128,14 +128,14 @@ static __device__ __forceinline__ void load_point(PtIn<NSG> &q, const BaPtrs &B,
 // workgroup's chunk inside ITS window, gridBlocks = workgroups of that window (partition of the accumulator initialisation).
 template <int NSG, bool HAS_L, bool FIX, bool MARG>
 static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaDims &D, const ResSet &cur, const ResSet &nxt, const ldso_settings_t &S, const int stepMode,
-                                                      const GnInit &gi, const int32_t *__restrict__ margFlags, const int chunk, const int gridBlocks) {
+                                                      const GnInit &gi, const int32_t *__restrict__ margFlags, const int chunk, const int gridBlocks,
+                                                      const int p0, const int np, const int h) {
     if (LD_ITER_SKIPPED(B, gi.itCheck)) return;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int FS = D.FS, F = D.F;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, s = lane >> 3, k = lane & 7;
     const long long t0_ = wall_clock64();
 #define LSTAMP(i) do { if (LD_STAMP_ON && chunk == 0 && tid == 0) B.energyLog[8 + (i)] = (double) (wall_clock64() - t0_); } while (0)
-    const int p0 = B.chunk_p0[chunk], np = B.chunk_n[chunk], h = B.chunk_host[chunk];
 
     // ---- LDS carve: pair structs of this host, float adjoints of this host, reduction scratch --------
     DevPair *sPair = (DevPair *) smem;                                  // [FS]
@@ -573,7 +573,9 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
             HdiF = (float) (1.0 / (double) H);
             bdSumF = bdA + bdL;
             if (!MARG) bdSumF += priorF * deltaF;       // shiftPriorToZero = true in accumulateSCF_MT, false in marginalizePointsF
-        } else {
+        } else if (!FIX) {
+            // AccumulatedSCHessian.cc:14-21 zeroes maxRelBaseline in the SOLVE that finds the point without an active residual: this pass feeds
+            // the next solve.  The fixing pass (linearizeAll(true)) is followed by no solve inside optimize(): there the value survives
             maxRelBS = 0;
         }
         // ---- store G row: [8*FS frame entries | Hcd 4, bdSum, HdiF, 0, 0] --------------------------------
@@ -650,19 +652,20 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
 template <int NSG, bool HAS_L, bool FIX, bool MARG>
 __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D, ResSet cur, ResSet nxt, ldso_settings_t S, int stepMode, GnInit gi,
                                                              const int32_t *__restrict__ margFlags) {
-    linearize_body<NSG, HAS_L, FIX, MARG>(B, D, cur, nxt, S, stepMode, gi, margFlags, (int) blockIdx.x, (int) gridDim.x);
+    const int chunk = (int) blockIdx.x;
+    linearize_body<NSG, HAS_L, FIX, MARG>(B, D, cur, nxt, S, stepMode, gi, margFlags, chunk, (int) gridDim.x, B.chunk_p0[chunk], B.chunk_n[chunk], B.chunk_host[chunk]);
 }
 
 // Batched windows (one 7-keyframe window is tiny for the chip): the chunks of nWin independent windows in one
 // launch.  Workgroup -> window by the prefix of chunk counts (items[w].linBlock0); `cur` = which residual set is the applied one
 // (all windows of a batch iterate in lockstep).
 template <int NSG>
-__global__ __launch_bounds__(64 * LD_WAVES) void k_linearize_batch(const BatchItem *__restrict__ items, int nWin, int cur, ldso_settings_t S, int stepMode, float calibPrior, int itCheck) {
-    int w = 0;
-    for (int i = 1; i < nWin; i++) if ((int) blockIdx.x >= items[i].linBlock0) w = i;
-    const BatchItem &it = items[w];
+__global__ __launch_bounds__(64 * LD_WAVES) void k_linearize_batch(const BatchItem *__restrict__ items, const BatchBlock *__restrict__ blocks, int cur, ldso_settings_t S, int stepMode,
+                                                                   float calibPrior, int itCheck) {
+    const BatchBlock bb = blocks[blockIdx.x];                   // one scalar 16-byte load: window, first point, point count, host | chunk
+    const BatchItem &it = items[bb.win];
     GnInit gi; gi.enable = 1; gi.hasPrior = it.hasPrior; gi.calibPrior = calibPrior; gi.itCheck = itCheck;
-    linearize_body<NSG, false, false, false>(it.B, it.D, it.set[cur], it.set[cur ^ 1], S, stepMode, gi, nullptr, (int) blockIdx.x - it.linBlock0, it.D.nChunks);
+    linearize_body<NSG, false, false, false>(it.B, it.D, it.set[cur], it.set[cur ^ 1], S, stepMode, gi, nullptr, bb.host_chunk >> 8, it.D.nChunks, bb.p0, bb.np, bb.host_chunk & 0xFF);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -704,15 +707,15 @@ hipError_t ba_launch_linearize_marg(const BaPtrs &B, const BaDims &D, const ResS
     return launch_one<2, false, false, true>(B, D, cur, nxt, S, 0, gi, st, margFlags);
 }
 
-hipError_t ba_launch_linearize_batch(const BatchItem *d_items, int nWin, int totalChunks, int FS, int cur, const ldso_settings_t &S, int stepMode, float calibPrior, hipStream_t st, int itCheck) {
+hipError_t ba_launch_linearize_batch(const BatchItem *d_items, const BatchBlock *d_blocks, int totalChunks, int FS, int cur, const ldso_settings_t &S, int stepMode, float calibPrior, hipStream_t st, int itCheck) {
     if (totalChunks == 0) return hipSuccess;
     const size_t lds = ba_linearize_lds_bytes(FS, false);
     if (FS == 8) {
         if (lds > 48 * 1024) (void) hipFuncSetAttribute((const void *) k_linearize_batch<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-        hipLaunchKernelGGL(k_linearize_batch<1>, dim3(totalChunks), dim3(64 * LD_WAVES), lds, st, d_items, nWin, cur, S, stepMode, calibPrior, itCheck);
+        hipLaunchKernelGGL(k_linearize_batch<1>, dim3(totalChunks), dim3(64 * LD_WAVES), lds, st, d_items, d_blocks, cur, S, stepMode, calibPrior, itCheck);
     } else {
         if (lds > 48 * 1024) (void) hipFuncSetAttribute((const void *) k_linearize_batch<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-        hipLaunchKernelGGL(k_linearize_batch<2>, dim3(totalChunks), dim3(64 * LD_WAVES), lds, st, d_items, nWin, cur, S, stepMode, calibPrior, itCheck);
+        hipLaunchKernelGGL(k_linearize_batch<2>, dim3(totalChunks), dim3(64 * LD_WAVES), lds, st, d_items, d_blocks, cur, S, stepMode, calibPrior, itCheck);
     }
     return hipGetLastError();
 }

@@ -433,6 +433,46 @@ def test_prior_survives_set_frames(small):
     assert rc != ra                                                # the prior matters on this window
 
 
+def test_large_batch_is_rechunked_and_equals_solo_runs_under_the_same_chunking():
+    """A batch big enough to fill the chip several times over (12 windows x 1600 points): ldso_ba_batch_create gives its windows fatter
+    workgroups (several points per wavefront); a handle run alone with the SAME chunking (ldso_ba_set_chunk_points) ends in the same state
+    to the last bits the fp64 atomics allow - the chunking decides only where the fp32 partial sums of the top Hessian are cut."""
+    import torch
+    ts = torch.cuda.Stream(); torch.cuda.set_stream(ts)
+    st = ts.cuda_stream
+    wins = [synth.add_synthetic_prior(synth.make_window(F=7, P=1750, w=320, h=240, fx=200.0, seed=60 + i)) for i in range(12)]
+    batch = []
+    for w in wins:
+        g = binding.BA.from_window(w, stream=st); g.collect_active(); g.linearize_all(False); g.apply_res(); batch.append(g)
+    b = binding.BABatch(batch)
+    ch = b.chunk_points()
+    assert ch >= 16 and ch % 8 == 0, ch
+    b.enqueue_gn(0, 4); b.sync(); torch.cuda.synchronize()
+    for i in (0, 5, 11):
+        g = binding.BA.from_window(wins[i], stream=st); g.set_chunk_points(ch)
+        assert g.get_chunk_points()[0] == ch
+        g.collect_active(); g.linearize_all(False); g.apply_res()
+        g.set_debug_split_launch(True); g.enqueue_gn(0, 4); g.sync(); torch.cuda.synchronize()
+        fs, fb = g.get_frames(), batch[i].get_frames()
+        assert np.abs(fb["frames"]["state"] - fs["frames"]["state"]).max() <= 1e-9 * np.abs(fs["frames"]["state"]).max()
+        assert np.array_equal(fb["frames"]["frameEnergyTH"], fs["frames"]["frameEnergyTH"])
+        rs, rb = g.get_residuals(), batch[i].get_residuals()
+        assert np.array_equal(rs["state_state"], rb["state_state"]) and rel(rb["out"]["state_NewEnergy"], rs["out"]["state_NewEnergy"]) < 1e-5
+        # and against the oracle (default chunking is irrelevant there): energies 1e-4
+        if i == 0:
+            o = po.OracleWindow(wins[i]); o.collect_active(); o.linearize_all(False); o.apply_res()
+            for it in range(4):
+                o.backup_state(); o.solve_system(it); o.do_step(); o.linearize_all(False); o.apply_res()
+            Eo = o.get_residuals(False)["out"]["state_NewEnergy"].astype(np.float64).sum()
+            Eg = rb["out"]["state_NewEnergy"].astype(np.float64).sum()
+            assert abs(Eg - Eo) <= 1e-4 * Eo
+        g.close()
+    b.close()
+    assert batch[0].get_chunk_points() == (0, batch[0].get_chunk_points()[1])          # back to the single-window chunking
+    for g in batch:
+        g.close()
+
+
 def test_batched_windows_equal_individual_runs():
     """ldso_ba_batch_*: five independent windows (different scenes, point counts and frame counts <= 8, one with a prior) iterated by
     three launches per iteration for the whole batch; every window must end where its own ldso_ba_enqueue_gn (split schedule) ends."""
