@@ -548,12 +548,13 @@ int ldso_ba_set_point_stats(ldso_ba_t *H, const float *maxRelBaseline, const int
 // The fp32 partial sums of the top Hessian are formed per chunk: two handles agree bit for bit only under the same chunking.
 static int launch_linearize(ldso_ba *H, bool fix, int stepMode = 0, int itCheck = -1);
 // New chunks for the resident window.  The applied residual set carries per-chunk partial sums (top Hessian, energies) that the next
-// reduce reads: under a new chunking they are re-formed by linearising the applied state once more (same states, energies and Jacobians -
-// linearize is a function of the state - only the partials are cut differently).
+// reduce reads: under a new chunking they are re-formed by linearising the applied state once more with the decisions of the original pass
+// kept (stepMode bit 2: same residual states, energies and activity - the Jacobians are a function of the state - only the partials are cut
+// differently).
 static int rechunk(ldso_ba *H) {
     H->itemValid = false;
     RUN(build_chunks(H));
-    if (H->appliedValid && !H->pendingApply) { RUN(launch_linearize(H, false, 0, -1)); H->cur ^= 1; }
+    if (H->appliedValid && !H->pendingApply) { RUN(launch_linearize(H, false, 4, -1)); H->cur ^= 1; }
     return LDSO_OK;
 }
 int ldso_ba_set_chunk_points(ldso_ba_t *H, int points_per_workgroup) {
@@ -658,7 +659,8 @@ static int refresh_item(ldso_ba *H) {
 static int launch_linearize(ldso_ba *H, bool fix, int stepMode, int itCheck) {
     t_begin(H, 0);
     GnInit gi; gi.enable = (H->D.pBegin > 0) ? 2 : 1; gi.hasPrior = H->hasPrior ? 1 : 0; gi.calibPrior = H->settings.initialCalibHessian; gi.itCheck = itCheck;
-    if (!fix && !H->hasL && gi.enable == 1 && H->D.FS == 8) {      // (two slot groups, F > 8: the argument-based kernel is the faster one, 43.0 against 45.6 us at C5)
+    static const bool descAll = getenv("LDSO_LIN_DESC") != nullptr;      // kernel experiments: the descriptor-based kernel for two slot groups as well
+    if (!fix && !H->hasL && gi.enable == 1 && (H->D.FS == 8 || descAll)) {      // (two slot groups, F > 8: the argument-based kernel is the faster one, 43.0 against 45.6 us at C5)
         // the plain linearisation (GN iterations): descriptors from device memory (k_linearize_batch with one window)
         { const int r_ = refresh_item(H); if (r_ != LDSO_OK) return r_; }
         CHK(ba_launch_linearize_batch(H->d_item, H->d_blocks, H->D.nChunks, H->D.FS, H->cur, H->settings, stepMode, gi.calibPrior, H->stream, itCheck));
@@ -1162,8 +1164,8 @@ int ldso_ba_batch_create(ldso_ba_t *const *handles, int n, ldso_ba_batch_t **out
     {
         long total = 0;
         for (int i = 0; i < n; i++) total += handles[i]->D.P;
-        int ppw = (int) (total / ((long) H0->numCU * LD_WAVES));               // points per wavefront slot of the chip, capped at 4 (measured: 336 / 201 / 139 / 142 / 136 us per
-                                                                                 // launch of 32 C3 windows at 1 / 2 / 4 / 6 / 8 points per wavefront; 84 / 52 / 37 / 48 / 48 us for 8 windows)
+        int ppw = (int) (total / ((long) H0->numCU * LD_WAVES));               // points per wavefront slot of the chip, capped at 4 (measured: 338 / 259 / 216 / 221 / 217 us per
+                                                                                 // launch of 32 C3 windows at 1 / 2 / 4 / 6 / 8 points per wavefront; 84 / 65 / 54 / 70 / 70 us for 8 windows)
         if (const char *e = getenv("LDSO_BATCH_PPW")) { if (*e) ppw = atoi(e); }             // kernel experiments
         ppw = ppw < 1 ? 1 : ppw > 8 ? 8 : ppw;
         if (!getenv("LDSO_BATCH_PPW") && ppw > 4) ppw = 4;

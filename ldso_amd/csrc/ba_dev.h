@@ -15,8 +15,12 @@
 
 #define LD_MAXF LDSO_MAX_FRAMES
 #define LD_TOPN 91            // unique entries of the 13x13 symmetric relative Hessian block
+#ifndef LD_WAVES
 #define LD_WAVES 8            // waves per linearize block
+#endif
+#ifndef LD_PREFETCH
 #define LD_PREFETCH 0         // 1: load the point record one point ahead (pays when a SIMD holds a single wave)
+#endif
 #define LD_GEXTRA 8           // per-point extras appended to a G row: Hcd[4], bdSum, HdiF, pad, pad
 
 struct DevPair {
@@ -50,22 +54,30 @@ struct DevCalib {
 
 // One of the two ping-pong sets (see header comment).
 struct ResSet {
-    int32_t *state;        // [P*FS] ResState
-    int32_t *active;       // [P*FS] isActiveAndIsGoodNEW
-    float *energy;         // [P*FS] state_energy
+    // Field ORDER matters: the batched linearisation kernel fetches these pointers just in time, eight at a time, with one
+    // s_load_dwordx16 per group (ba_linearize.hip: LDG16) - a group is eight consecutive pointers, 64-byte blocks of this struct.
+    // ---- group S0: per residual slot [P*FS] ------------------------------------------------------------------------------
+    int32_t *state;        // ResState
+    int32_t *active;       // isActiveAndIsGoodNEW
+    float *energy;         // state_energy
     float *JpJdF;          // [P*FS*8]
-    float *newEnergyWO;    // [P*FS] state_NewEnergyWithOutlier of the linearize that produced this set (-1: none)
     float *center;         // [P*FS*3] centerProjectedTo
-    int32_t *toRemove;     // [P*FS] (fix mode) residual became inactive -> host drops it
-    // per point
-    float *HdiF, *bdSumF, *idH, *HddA, *bdA, *HcdA, *HddL, *bdL, *HcdL, *maxRelBS;
-    int32_t *numGood, *nActive;
+    float *newEnergyWO;    // state_NewEnergyWithOutlier of the linearize that produced this set (-1: none)
+    int32_t *toRemove;     // (fix mode) residual became inactive -> host drops it
     float *candE;          // [P] newest-frame candidate energy for setNewFrameEnergyTH (-1: none)
-    // accumulator outputs of the fused linearize
+    // ---- group S1: per point [P] -----------------------------------------------------------------------------------------
+    float *HdiF, *bdSumF, *idH;
+    int32_t *nActive;
+    float *HcdA, *HcdL;    // [P*4]
+    float *maxRelBS;
+    int32_t *numGood;
+    // ---- group S2: per point, accumulator outputs of the fused linearize -------------------------------------------------
+    float *HddA, *bdA, *HddL, *bdL;
     float *G;              // [P][GS]  lifted Schur rows  g_p (8*FS frame entries + LD_GEXTRA)
     float *topA;           // [nChunks][FS][91]
     float *topL;           // [nChunks][FS][91]
     double *chunkEnergy;   // [nChunks]
+    // ---- group S3 --------------------------------------------------------------------------------------------------------
     int32_t *chunkCnt;     // [nChunks*2]  nres A, nres L
     float *chunkNID;       // [nChunks*2]  sum |idepth|, count   (doStepFromBackup statistics)
 };
@@ -86,13 +98,14 @@ struct BaPtrs {
     float *adHostF, *adTargetF;
     double *nsProj;                  // n*n projector onto the gauge nullspaces (reference ordering)
     double *HM, *bM;
-    // points
-    float *pu, *pv, *pidepth, *pidepth_zero, *pidepth_backup, *pstep, *ppriorF, *pcolor, *pweights;
+    // points.  Two groups of eight consecutive pointers (see ResSet): B0 = what a wave reads of a point, B1 = what the fused point step writes
+    float *pu, *pv, *pidepth, *pidepth_zero, *ppriorF, *pcolor, *pweights, *pstep;                  // ---- group B0
+    float *pidepth_backup;                                                                          // ---- group B1 (with the next seven)
     float *pLastHdiF, *pLastBdSumF, *pLastIdH;    // PointHessian::{HdiF, bdSumF, idepth_hessian} as the LAST solveSystemF left them (AccumulatedSCHessian.cc:9-51): the
                                                   // ResSet copies belong to the NEXT solve (the fused linearize pass already holds the new linearisation's Schur scalars)
-    int32_t *phost;
     // residual slots
-    int32_t *rflat, *rlin, *rnew, *rlidx;
+    int32_t *rflat, *rlin, *rnew, *rlidx;                                                           // (end of group B1)
+    int32_t *phost;
     // linearised store
     ldso_rawjac_t *Jlin;
     float *rtz;

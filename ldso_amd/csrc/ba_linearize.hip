@@ -18,6 +18,7 @@
 // the reference's operation order so that energies and residual states are bit-identical to the
 // CPU path; fused multiply-adds are used only (explicitly) in the accumulators.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "ba_dev.h"
 
 #define RES_IN 0
@@ -48,11 +49,21 @@ __device__ __forceinline__ float sum8(float x) {
 template <int J> __device__ __forceinline__ float dpp_row_shr(float x) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x110 + J, 0xF, 0xF, true));
 }
+// lane j (0..3) of each quad broadcast to its quad
+template <int J> __device__ __forceinline__ float dpp_quad_bcast(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), J * 0x55, 0xF, 0xF, true));
+}
+// element J and element 4 + J of every 8-lane group, in all 8 lanes of the group (two DPP moves and two selects instead of two ds_bpermute)
+template <int J> __device__ __forceinline__ void group_bcast_pair(float x, int k, float &lo, float &hi) {
+    const float a = dpp_quad_bcast<J>(x);           // lanes 0-3: x[J], lanes 4-7: x[4 + J]
+    const float b = dpp_half_mirror(a);             // lanes 0-3: x[4 + J], lanes 4-7: x[J]
+    lo = (k < 4) ? a : b; hi = (k < 4) ? b : a;
+}
+
 // sum over the 8 lanes in the reference's sequential order ((((x0+x1)+x2)+...)+x7), result in all 8 lanes.
 // The running sum lives in lane 7 of each group (lanes 7 and 15 of a row): step j adds x_j fetched with row_shr:(7-j) - one
 // v_add_f32_dpp per step whose DPP operand (x) is old, so no hazard padding; other lanes compute values nobody reads.
 __device__ __forceinline__ float seq8(float x, int k, int lane) {
-    (void) k;
     float t = dpp_row_shr<7>(x);
     t = t + dpp_row_shr<6>(x);
     t = t + dpp_row_shr<5>(x);
@@ -61,17 +72,68 @@ __device__ __forceinline__ float seq8(float x, int k, int lane) {
     t = t + dpp_row_shr<2>(x);
     t = t + dpp_row_shr<1>(x);
     t = t + x;
-    return __shfl(t, lane | 7, 64);
+    (void) lane;
+    float lo, hi;
+    group_bcast_pair<3>(t, k, lo, hi);          // hi = element 7 of the group
+    return hi;
 }
 
-// sum over the 8 slots of a wave (lanes with equal k), result in every lane: slot pairs by row_ror:8, then the four rows by two
-// ds_bpermute butterflies (tree order; the sequential-order sums that decide residual states use seq8 above)
-__device__ __forceinline__ float sum_slots(float x, int a16, int a32) {
+// gfx950: v_permlane16_swap_b32 a, b exchanges the odd 16-lane rows of a with the even rows of b; v_permlane32_swap_b32 the upper half of a
+// with the lower half of b.  With a = b = x, a + b is the xor-16 / xor-32 butterfly sum - in the vector ALU, where ds_bpermute costs an LDS
+// round trip (~64+ cycles of dependent latency; the point loop had 45 of them, most in dependent pairs).  s_nop: the assembler does not
+// know the hazards of hand-placed instructions.
+__device__ __forceinline__ float bfly16(float x) {
+    float a = x, b = x;
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+__device__ __forceinline__ float bfly32(float x) {
+    float a = x, b = x;
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+// sum over the 8 slots of a wave (lanes with equal k), result in every lane: slot pairs by row_ror:8, then the four rows by the two
+// butterflies above (tree order; the sequential-order sums that decide residual states use seq8)
+__device__ __forceinline__ float sum_slots(float x, int, int) {
     x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128, 0xF, 0xF, true));
-    x += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(a16, __builtin_bit_cast(int, x)));
-    x += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(a32, __builtin_bit_cast(int, x)));
+    x = bfly16(x);
+    x = bfly32(x);
     return x;
 }
+// ---- just-in-time pointer groups ------------------------------------------------------------------------------------------------
+// The kernel touches ~55 device arrays per point.  Held in scalar registers for the whole kernel (what the compiler does with a
+// descriptor it may load once) they do not fit the 102 SGPRs of a wave: 105 of them were spilled into VGPR lanes, and every use paid
+// two v_readlane plus a 64-bit VGPR address (v_lshl_add_u64, flat_load / flat_store) - 260 of the 1234 vector instructions of the point
+// loop.  Where the descriptor lives in device memory (k_linearize_batch; DESC = true) a group of eight pointers (64 consecutive bytes of
+// BaPtrs / ResSet, see ba_dev.h) is fetched with ONE s_load_dwordx16 right where it is used (scalar cache hit, no vector instruction)
+// and is dead a few instructions later; `asm volatile` keeps the compiler from hoisting the load back to the top of the kernel.
+typedef int v16i_t __attribute__((ext_vector_type(16)));
+template <bool DESC, int OFF> static __device__ __forceinline__ v16i_t ldg16(const void *base) {
+    v16i_t t;
+    if (DESC) asm volatile("s_load_dwordx16 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : "s"(base), "n"(OFF) : "memory");
+    else __builtin_memcpy(&t, (const char *) base + OFF, 64);          // kernel arguments: the compiler's own scalar loads
+    return t;
+}
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+template <bool DESC, int OFF> static __device__ __forceinline__ v4i_t ldg4(const void *base) {          // two pointers
+    v4i_t t;
+    if (DESC) asm volatile("s_load_dwordx4 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : "s"(base), "n"(OFF) : "memory");
+    else __builtin_memcpy(&t, (const char *) base + OFF, 16);
+    return t;
+}
+// two groups with one wait
+template <bool DESC, int OFFA, int OFFB> static __device__ __forceinline__ void ldg16x2(v16i_t &a, const void *baseA, v16i_t &b, const void *baseB) {
+    if (DESC) asm volatile("s_load_dwordx16 %0, %2, %4\n\ts_load_dwordx16 %1, %3, %5\n\ts_waitcnt lgkmcnt(0)" : "=&s"(a), "=&s"(b) : "s"(baseA), "s"(baseB), "n"(OFFA), "n"(OFFB) : "memory");
+    else { __builtin_memcpy(&a, (const char *) baseA + OFFA, 64); __builtin_memcpy(&b, (const char *) baseB + OFFB, 64); }
+}
+#define GP(T, t16, i) ((T *) ((((unsigned long long) (unsigned) (t16)[2 * (i) + 1]) << 32) | (unsigned long long) (unsigned) (t16)[2 * (i)]))
+#define OFF_B0 ((int) offsetof(BaPtrs, pu))
+#define OFF_B1 ((int) offsetof(BaPtrs, pidepth_backup))
+#define OFF_S0 ((int) offsetof(ResSet, state))
+#define OFF_S1 ((int) offsetof(ResSet, HdiF))
+#define OFF_S2 ((int) offsetof(ResSet, HddA))
+static_assert(offsetof(BaPtrs, pstep) == offsetof(BaPtrs, pu) + 56 && offsetof(BaPtrs, rlidx) == offsetof(BaPtrs, pidepth_backup) + 56, "BaPtrs pointer groups (ba_dev.h)");
+static_assert(offsetof(ResSet, candE) == 56 && offsetof(ResSet, numGood) == offsetof(ResSet, HdiF) + 56 && offsetof(ResSet, chunkEnergy) == offsetof(ResSet, HddA) + 56, "ResSet pointer groups (ba_dev.h)");
 
 // flat index of entry (r,c), r<=c, in the packed upper triangle of a 13x13 matrix
 __host__ __device__ constexpr int tri13(int r, int c) { return r * 13 - (r * (r - 1)) / 2 + (c - r); }
@@ -86,31 +148,56 @@ struct PtIn {
     int rflat[NSG], rlin[NSG], rnew[NSG], rlidx[NSG], state[NSG], active[NSG];
     float energy[NSG], jp[NSG], cen[NSG];
     // inputs of the fused point step (resubstituteFPt)
-    float pstep, bdSumF, HdiF, hcd[4];
+    float pstep, bdSumF, HdiF, idH, hcd[4];
     int nAct;
 };
 
-template <int NSG, bool HAS_L, bool FIX>
-// element i of a device array with the BYTE offset computed in 32 bits: base pointer (kernel argument, SGPR pair) + zero-extended
+// element i of a device array with the BYTE offset computed in 32 bits: base pointer (SGPR pair) + zero-extended
 // lane offset is the addressing mode the hardware has (saddr + voffset); a 64-bit per-lane address costs two registers and a
 // 64-bit shift-add per access.  Every table of a window is far below 4 GB.
-#define AT(ptr, i) (*(decltype(ptr)) ((char *) (ptr) + (size_t) ((unsigned) (i) * (unsigned) sizeof(*(ptr)))))
+// The pointers of a window are generic (flat) pointers to the compiler: accessed as such they become flat_load / flat_store, which have no
+// scalar-base addressing mode (two v_mov + v_lshl_add_u64 per access to build a 64-bit VGPR address) and count against lgkmcnt as well as
+// vmcnt (every s_waitcnt lgkmcnt(0) of a scalar load then waits for all vector memory traffic in flight).  Every table of a window is
+// hipMalloc'ed device memory: the access is made through an address_space(1) (global) pointer -> global_load/store v, v_off, s[base].
+template <class T> using gptr_t = __attribute__((address_space(1))) T *;
+#define AT(ptr, i) (*(gptr_t<typename std::remove_pointer<decltype(ptr)>::type>) ((gptr_t<char>) (ptr) + (size_t) ((unsigned) (i) * (unsigned) sizeof(*(ptr)))))
 
+template <int NSG, bool HAS_L, bool FIX, bool DESC>
 static __device__ __forceinline__ void load_point(PtIn<NSG> &q, const BaPtrs &B, const ResSet &cur, unsigned FS, unsigned p, unsigned s, unsigned k, int stepMode) {
-    q.pu = AT(B.pu, p); q.pv = AT(B.pv, p); q.idp = AT(B.pidepth, p); q.idz = AT(B.pidepth_zero, p); q.priorF = AT(B.ppriorF, p);
-    q.color = AT(B.pcolor, p * 8 + k); q.wgt = AT(B.pweights, p * 8 + k);
-    q.maxRelBS = AT(cur.maxRelBS, p); q.numGood = AT(cur.numGood, p);
+    {
+        v16i_t b0, b1;
+        ldg16x2<DESC, OFF_B0, OFF_B1>(b0, &B, b1, &B);
+        const float *pu = GP(const float, b0, 0), *pv = GP(const float, b0, 1), *pid = GP(const float, b0, 2), *piz = GP(const float, b0, 3), *ppr = GP(const float, b0, 4);
+        const float *pco = GP(const float, b0, 5), *pwe = GP(const float, b0, 6), *pst = GP(const float, b0, 7);
+        const int32_t *rflat = GP(const int32_t, b1, 4), *rlin = GP(const int32_t, b1, 5), *rnew = GP(const int32_t, b1, 6), *rlidx = GP(const int32_t, b1, 7);
+        q.pu = AT(pu, p); q.pv = AT(pv, p); q.idp = AT(pid, p); q.idz = AT(piz, p); q.priorF = AT(ppr, p);
+        q.color = AT(pco, p * 8 + k); q.wgt = AT(pwe, p * 8 + k);
+        if (stepMode & 1) q.pstep = AT(pst, p);
 #pragma unroll
-    for (int g = 0; g < NSG; g++) {
-        const unsigned slot = p * FS + g * 8 + s;       // slot tables are dense [P][FS]: every index is readable
-        q.rflat[g] = AT(B.rflat, slot); q.rlin[g] = AT(B.rlin, slot); q.rnew[g] = FIX ? AT(B.rnew, slot) : 0; q.rlidx[g] = HAS_L ? AT(B.rlidx, slot) : 0;
-        q.state[g] = AT(cur.state, slot); q.active[g] = AT(cur.active, slot); q.energy[g] = AT(cur.energy, slot);
-        q.jp[g] = AT(cur.JpJdF, slot * 8 + k); q.cen[g] = AT(cur.center, slot * 3 + (k < 3 ? k : 2u));
+        for (int g = 0; g < NSG; g++) {
+            const unsigned slot = p * FS + g * 8 + s;       // slot tables are dense [P][FS]: every index is readable
+            q.rflat[g] = AT(rflat, slot); q.rlin[g] = AT(rlin, slot); q.rnew[g] = FIX ? AT(rnew, slot) : 0; q.rlidx[g] = HAS_L ? AT(rlidx, slot) : 0;
+        }
     }
-    if (stepMode & 1) {
-        q.pstep = AT(B.pstep, p); q.bdSumF = AT(cur.bdSumF, p); q.HdiF = AT(cur.HdiF, p); q.nAct = AT(cur.nActive, p);
+    {
+        v16i_t s0, s1;
+        ldg16x2<DESC, OFF_S0, OFF_S1>(s0, &cur, s1, &cur);
+        const int32_t *state = GP(const int32_t, s0, 0), *active = GP(const int32_t, s0, 1);
+        const float *energy = GP(const float, s0, 2), *jp = GP(const float, s0, 3), *center = GP(const float, s0, 4);
+        const float *HdiF = GP(const float, s1, 0), *bdSumF = GP(const float, s1, 1), *idH_ = GP(const float, s1, 2), *HcdA = GP(const float, s1, 4), *HcdL = GP(const float, s1, 5), *maxRelBS = GP(const float, s1, 6);
+        const int32_t *nActive = GP(const int32_t, s1, 3), *numGood = GP(const int32_t, s1, 7);
+        q.maxRelBS = AT(maxRelBS, p); q.numGood = AT(numGood, p);
 #pragma unroll
-        for (int i = 0; i < 4; i++) q.hcd[i] = AT(cur.HcdA, p * 4 + i) + AT(cur.HcdL, p * 4 + i);
+        for (int g = 0; g < NSG; g++) {
+            const unsigned slot = p * FS + g * 8 + s;
+            q.state[g] = AT(state, slot); q.active[g] = AT(active, slot); q.energy[g] = AT(energy, slot);
+            q.jp[g] = AT(jp, slot * 8 + k); q.cen[g] = AT(center, slot * 3 + (k < 3 ? k : 2u));
+        }
+        if (stepMode & 1) {
+            q.bdSumF = AT(bdSumF, p); q.HdiF = AT(HdiF, p); q.idH = AT(idH_, p); q.nAct = AT(nActive, p);
+#pragma unroll
+            for (int i = 0; i < 4; i++) q.hcd[i] = AT(HcdA, p * 4 + i) + AT(HcdL, p * 4 + i);
+        }
     }
 }
 
@@ -126,7 +213,7 @@ static __device__ __forceinline__ void load_point(PtIn<NSG> &q, const BaPtrs &B,
 // The body is shared by k_linearize (one window: everything arrives as kernel arguments, i.e. in scalar registers) and
 // k_linearize_batch (many independent windows per launch: the descriptors live in device memory).  chunk = index of the
 // workgroup's chunk inside ITS window, gridBlocks = workgroups of that window (partition of the accumulator initialisation).
-template <int NSG, bool HAS_L, bool FIX, bool MARG>
+template <int NSG, bool HAS_L, bool FIX, bool MARG, bool DESC>
 static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaDims &D, const ResSet &cur, const ResSet &nxt, const ldso_settings_t &S, const int stepMode,
                                                       const GnInit &gi, const int32_t *__restrict__ margFlags, const int chunk, const int gridBlocks,
                                                       const int p0, const int np, const int h) {
@@ -144,6 +231,9 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
     float *sRed = sAdT + FS * 64;                                       // [LD_WAVES][FS][91] (+ topL [FS][91] when HAS_L)
     float *sTopL = sRed + LD_WAVES * FS * LD_TOPN;                        // [LD_WAVES][FS][91] when HAS_L: each (wave, slot) cell has ONE writer lane
     float *sXa = sTopL + (HAS_L ? LD_WAVES * FS * LD_TOPN : 0);                      // [FS][8] xAd of this host (stepMode)
+    // [FS] level-0 image of every target frame: the per-lane pointer comes from LDS (64 cycles) instead of a dependent global load of the
+    // descriptor's img[] table in front of every tap gather
+    const float **sImg = (const float **) (sXa + FS * 8 + 16 + 4 * LD_WAVES + LD_WAVES);
 
     if (gi.enable) {
         // initialise the HFinal / bFinal accumulator of the k_reduce that follows (lower triangle) with H_M and the diagonal
@@ -170,7 +260,7 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
 
     PtIn<NSG> nx;
     int pi = wave;
-    if (pi < np) load_point<NSG, HAS_L, FIX>(nx, B, cur, FS, p0 + pi, s, k, stepMode);
+    if (pi < np) load_point<NSG, HAS_L, FIX, DESC>(nx, B, cur, FS, p0 + pi, s, k, stepMode);
 
     // ---- staging: all global loads first (one latency level), then the LDS stores --------------------------------
     {
@@ -201,6 +291,7 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
 #pragma unroll
         for (int u = 0; u < NAB; u++) { const int i = tid + u * 64 * LD_WAVES; if (i < FS * 64) { sAdH[i] = ahv[u]; sAdT[i] = atv[u]; } }
         if ((stepMode & 1) && tid < FS * 8) sXa[tid] = xav;
+        if (tid < FS) sImg[tid] = (tid < F) ? B.img[tid] : nullptr;
     }
     if (HAS_L) for (int i = tid; i < LD_WAVES * FS * LD_TOPN; i += blockDim.x) sTopL[i] = 0.0f;
     __syncthreads();
@@ -229,9 +320,9 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
         const unsigned p = (unsigned) (p0 + pi);
 #if LD_PREFETCH
         const PtIn<NSG> q = nx;
-        if (pi + LD_WAVES < np) load_point<NSG, HAS_L, FIX>(nx, B, cur, FS, p + LD_WAVES, s, k, stepMode);
+        if (pi + LD_WAVES < np) load_point<NSG, HAS_L, FIX, DESC>(nx, B, cur, FS, p + LD_WAVES, s, k, stepMode);
 #else
-        if (pi != wave) load_point<NSG, HAS_L, FIX>(nx, B, cur, FS, p, s, k, stepMode);       // the first record was loaded before the staging
+        if (pi != wave) load_point<NSG, HAS_L, FIX, DESC>(nx, B, cur, FS, p, s, k, stepMode);       // the first record was loaded before the staging
         const PtIn<NSG> &q = nx;
 #endif
         const float pu = q.pu, pv = q.pv, priorF = MARG ? q.priorF * S.idepthFixPriorMargFac : q.priorF;
@@ -257,9 +348,15 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
                 if (isfinite(b)) step = -b * q.HdiF; else { step = q.pstep; if (lane == 0) B.scalars[4] = 1.0; }
             }
             const float ni = idp + 1.0f * step;
-            if (lane == 0) { AT(B.pstep, p) = step; AT(B.pidepth_backup, p) = idp; AT(B.pidepth, p) = ni; AT(B.pidepth_zero, p) = ni; }
-            // PointHessian::{HdiF, bdSumF, idepth_hessian} as the solve that produced this step left them (lanes 1..3: fire-and-forget stores)
-            if (lane == 1) AT(B.pLastHdiF, p) = q.HdiF; else if (lane == 2) AT(B.pLastBdSumF, p) = q.bdSumF; else if (lane == 3) AT(B.pLastIdH, p) = AT(cur.idH, p);
+            {
+                v16i_t b0, b1;
+                ldg16x2<DESC, OFF_B0, OFF_B1>(b0, &B, b1, &B);
+                float *w_pstep = GP(float, b0, 7), *w_pid = GP(float, b0, 2), *w_piz = GP(float, b0, 3), *w_pbk = GP(float, b1, 0);
+                float *w_lH = GP(float, b1, 1), *w_lB = GP(float, b1, 2), *w_lI = GP(float, b1, 3);
+                if (lane == 0) { AT(w_pstep, p) = step; AT(w_pbk, p) = idp; AT(w_pid, p) = ni; AT(w_piz, p) = ni; }
+                // PointHessian::{HdiF, bdSumF, idepth_hessian} as the solve that produced this step left them (lanes 1..3: fire-and-forget stores)
+                if (lane == 1) AT(w_lH, p) = q.HdiF; else if (lane == 2) AT(w_lB, p) = q.bdSumF; else if (lane == 3) AT(w_lI, p) = q.idH;
+            }
             idp = ni; idz = ni;
         }
         const float deltaF = idp - idz;
@@ -319,7 +416,7 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
             if (compute && centerOK && pixOK) {
                 int ix = (int) Ku, iy = (int) Kv;
                 float dx = Ku - ix, dy = Kv - iy, dxdy = dx * dy;
-                const float *bp = B.img[t] + 3 * (ix + iy * W);
+                const float *bp = sImg[t] + 3 * (ix + iy * W);
                 float a0 = bp[0], a1 = bp[1], a2 = bp[2], b0_ = bp[3], b1 = bp[4], b2 = bp[5];
                 const float *bq = bp + 3 * W;
                 float c0_ = bq[0], c1_ = bq[1], c2_ = bq[2], d0 = bq[3], d1 = bq[4], d2 = bq[5];
@@ -391,6 +488,9 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
                 newEnergy = energyLeft;
                 ret = (double) energyLeft;
                 c0 = cKu; c1 = cKv; c2 = new_idepth;
+                // stepMode bit 2 (re-chunking, ba_api.hip rechunk()): the applied state is linearised again only to re-form the per-chunk
+                // partial sums - the decisions of the pass that produced it stand (its energy thresholds have moved on since)
+                if (stepMode & 4) { newState = st; newEnergy = q.energy[g]; ret = (double) newEnergy; }
             }
 
             // ================= applyRes(true) (Residuals.h:70-87) ======================================
@@ -520,8 +620,8 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
             {
                 // all 8 components of JpJdF of this slot, gathered from the 8 lanes
                 float vj[8];
-#pragma unroll
-                for (int j = 0; j < 8; j++) vj[j] = __shfl(jp, (lane & ~7) | j, 64);
+                group_bcast_pair<0>(jp, k, vj[0], vj[4]); group_bcast_pair<1>(jp, k, vj[1], vj[5]);
+                group_bcast_pair<2>(jp, k, vj[2], vj[6]); group_bcast_pair<3>(jp, k, vj[3], vj[7]);
                 if (exists && activeNew) {
                     const float *aT = sAdT + t * 64 + k * 8, *aH = sAdH + t * 64 + k * 8;
 #pragma unroll
@@ -536,17 +636,20 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
 
             // ---- per-slot outputs (slot leader) ----------------------------------------------------------
             if (t < F) {
-                AT(nxt.JpJdF, slot * 8 + (unsigned) k) = jp;
+                const v16i_t o0 = ldg16<DESC, OFF_S0>(&nxt);
+                int32_t *o_state = GP(int32_t, o0, 0), *o_active = GP(int32_t, o0, 1), *o_rem = GP(int32_t, o0, 6);
+                float *o_energy = GP(float, o0, 2), *o_jp = GP(float, o0, 3), *o_center = GP(float, o0, 4), *o_ewo = GP(float, o0, 5), *o_cand = GP(float, o0, 7);
+                AT(o_jp, slot * 8 + (unsigned) k) = jp;
                 if (k == 0) {
-                    AT(nxt.state, slot) = newState;
-                    AT(nxt.active, slot) = activeNew;
-                    AT(nxt.energy, slot) = newEnergy;
-                    AT(nxt.newEnergyWO, slot) = doLin ? newEnergyWO : -1.0f;
-                    if (t == F - 1) AT(nxt.candE, p) = doLin ? newEnergyWO : -1.0f;
-                    AT(nxt.toRemove, slot) = toRemove;
+                    AT(o_state, slot) = newState;
+                    AT(o_active, slot) = activeNew;
+                    AT(o_energy, slot) = newEnergy;
+                    AT(o_ewo, slot) = doLin ? newEnergyWO : -1.0f;
+                    if (t == F - 1) AT(o_cand, p) = doLin ? newEnergyWO : -1.0f;
+                    AT(o_rem, slot) = toRemove;
                     if (doLin) energySum += ret;
                 }
-                if (k < 3) AT(nxt.center, slot * 3 + (unsigned) k) = compute ? (k == 0 ? c0 : k == 1 ? c1 : c2) : q.cen[g];
+                if (k < 3) AT(o_center, slot * 3 + (unsigned) k) = compute ? (k == 0 ? c0 : k == 1 ? c1 : c2) : q.cen[g];
             }
             if (B.dumpJ != nullptr && compute) {
                 ldso_rawjac_t &o = B.dumpJ[q.rflat[g]];
@@ -579,26 +682,34 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
             maxRelBS = 0;
         }
         // ---- store G row: [8*FS frame entries | Hcd 4, bdSum, HdiF, 0, 0] --------------------------------
-        float *Grow = nxt.G + (size_t) p * D.GS;
+        {
+            v16i_t o1, o2;
+            ldg16x2<DESC, OFF_S1, OFF_S2>(o1, &nxt, o2, &nxt);
+            float *Grow = GP(float, o2, 4) + (size_t) p * D.GS;
 #pragma unroll
-        for (int g = 0; g < NSG; g++) {
-            const int t = g * 8 + s;
-            float val = (t == h) ? hostPart : gT[g];
-            if (nActive == 0) val = 0.0f;
-            Grow[8 * t + k] = val;
-        }
-        if (lane < LD_GEXTRA) {
-            float e = (lane == 0) ? Hc0 : (lane == 1) ? Hc1 : (lane == 2) ? Hc2 : (lane == 3) ? Hc3 : (lane == 4) ? bdSumF : (lane == 5) ? HdiF : 0.0f;
-            if (nActive == 0 && lane < 4) e = 0.0f;
-            Grow[8 * FS + lane] = e;
-        }
-        if (lane == 0) {
-            AT(nxt.HdiF, p) = HdiF; AT(nxt.bdSumF, p) = bdSumF; AT(nxt.idH, p) = idH;
-            AT(nxt.HddA, p) = HddA; AT(nxt.bdA, p) = bdA; AT(nxt.HddL, p) = HddL; AT(nxt.bdL, p) = bdL;
-            AT(nxt.HcdA, p * 4 + 0) = HcdA0; AT(nxt.HcdA, p * 4 + 1) = HcdA1; AT(nxt.HcdA, p * 4 + 2) = HcdA2; AT(nxt.HcdA, p * 4 + 3) = HcdA3;
-            AT(nxt.HcdL, p * 4 + 0) = HcdL0; AT(nxt.HcdL, p * 4 + 1) = HcdL1; AT(nxt.HcdL, p * 4 + 2) = HcdL2; AT(nxt.HcdL, p * 4 + 3) = HcdL3;
-            AT(nxt.maxRelBS, p) = maxRelBS; AT(nxt.numGood, p) = numGood; AT(nxt.nActive, p) = nActive;
-            nidSum += fabsf(idp); nidCnt++;
+            for (int g = 0; g < NSG; g++) {
+                const int t = g * 8 + s;
+                float val = (t == h) ? hostPart : gT[g];
+                if (nActive == 0) val = 0.0f;
+                Grow[8 * t + k] = val;
+            }
+            if (lane < LD_GEXTRA) {
+                float e = (lane == 0) ? Hc0 : (lane == 1) ? Hc1 : (lane == 2) ? Hc2 : (lane == 3) ? Hc3 : (lane == 4) ? bdSumF : (lane == 5) ? HdiF : 0.0f;
+                if (nActive == 0 && lane < 4) e = 0.0f;
+                Grow[8 * FS + lane] = e;
+            }
+            // the per-point scalars: one value per lane (lanes 0..19), one store instruction per destination array
+            float *o_HdiF = GP(float, o1, 0), *o_bd = GP(float, o1, 1), *o_idH = GP(float, o1, 2), *o_HcdA = GP(float, o1, 4), *o_HcdL = GP(float, o1, 5), *o_mrb = GP(float, o1, 6);
+            int32_t *o_nAct = GP(int32_t, o1, 3), *o_nGood = GP(int32_t, o1, 7);
+            float *o_HddA = GP(float, o2, 0), *o_bdA = GP(float, o2, 1), *o_HddL = GP(float, o2, 2), *o_bdL = GP(float, o2, 3);
+            if (lane == 0) {
+                AT(o_HdiF, p) = HdiF; AT(o_bd, p) = bdSumF; AT(o_idH, p) = idH;
+                AT(o_HddA, p) = HddA; AT(o_bdA, p) = bdA; AT(o_HddL, p) = HddL; AT(o_bdL, p) = bdL;
+                AT(o_HcdA, p * 4 + 0) = HcdA0; AT(o_HcdA, p * 4 + 1) = HcdA1; AT(o_HcdA, p * 4 + 2) = HcdA2; AT(o_HcdA, p * 4 + 3) = HcdA3;
+                AT(o_HcdL, p * 4 + 0) = HcdL0; AT(o_HcdL, p * 4 + 1) = HcdL1; AT(o_HcdL, p * 4 + 2) = HcdL2; AT(o_HcdL, p * 4 + 3) = HcdL3;
+                AT(o_mrb, p) = maxRelBS; AT(o_nGood, p) = numGood; AT(o_nAct, p) = nActive;
+                nidSum += fabsf(idp); nidCnt++;
+            }
         }
     }   // points of this wave
 
@@ -628,24 +739,29 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
     }
     __syncthreads();
     LSTAMP(7);
+    const v16i_t e2 = ldg16<DESC, OFF_S2>(&nxt);
+    float *o_topA = GP(float, e2, 5), *o_topL = GP(float, e2, 6);
+    double *o_chunkE = GP(double, e2, 7);
     for (int i = tid; i < FS * LD_TOPN; i += blockDim.x) {
         float a = 0;
 #pragma unroll
         for (int wv = 0; wv < LD_WAVES; wv++) a += sRed[wv * FS * LD_TOPN + i];
-        nxt.topA[(size_t) chunk * FS * LD_TOPN + i] = a;
+        o_topA[(size_t) chunk * FS * LD_TOPN + i] = a;
         if (HAS_L) {
             float l = 0;
 #pragma unroll
             for (int wv = 0; wv < LD_WAVES; wv++) l += sTopL[wv * FS * LD_TOPN + i];
-            nxt.topL[(size_t) chunk * FS * LD_TOPN + i] = l;
+            o_topL[(size_t) chunk * FS * LD_TOPN + i] = l;
         }
     }
     if (tid == 0) {
         double e = 0; int na = 0, nl = 0, nc = 0; float ns = 0;
         for (int wv = 0; wv < LD_WAVES; wv++) { e += sE[wv]; na += sC[wv * 4 + 0]; nl += sC[wv * 4 + 1]; nc += sC[wv * 4 + 2]; ns += sN[wv]; }
-        nxt.chunkEnergy[chunk] = e;
-        nxt.chunkCnt[chunk * 2 + 0] = na; nxt.chunkCnt[chunk * 2 + 1] = nl;
-        nxt.chunkNID[chunk * 2 + 0] = ns; nxt.chunkNID[chunk * 2 + 1] = (float) nc;
+        o_chunkE[chunk] = e;
+        const v4i_t e3 = ldg4<DESC, (int) offsetof(ResSet, chunkCnt)>(&nxt);
+        int32_t *o_cnt = GP(int32_t, e3, 0); float *o_nid = GP(float, e3, 1);
+        o_cnt[chunk * 2 + 0] = na; o_cnt[chunk * 2 + 1] = nl;
+        o_nid[chunk * 2 + 0] = ns; o_nid[chunk * 2 + 1] = (float) nc;
     }
 }
 
@@ -653,7 +769,7 @@ template <int NSG, bool HAS_L, bool FIX, bool MARG>
 __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D, ResSet cur, ResSet nxt, ldso_settings_t S, int stepMode, GnInit gi,
                                                              const int32_t *__restrict__ margFlags) {
     const int chunk = (int) blockIdx.x;
-    linearize_body<NSG, HAS_L, FIX, MARG>(B, D, cur, nxt, S, stepMode, gi, margFlags, chunk, (int) gridDim.x, B.chunk_p0[chunk], B.chunk_n[chunk], B.chunk_host[chunk]);
+    linearize_body<NSG, HAS_L, FIX, MARG, false>(B, D, cur, nxt, S, stepMode, gi, margFlags, chunk, (int) gridDim.x, B.chunk_p0[chunk], B.chunk_n[chunk], B.chunk_host[chunk]);
 }
 
 // Batched windows (one 7-keyframe window is tiny for the chip): the chunks of nWin independent windows in one
@@ -665,14 +781,14 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize_batch(const BatchIt
     const BatchBlock bb = blocks[blockIdx.x];                   // one scalar 16-byte load: window, first point, point count, host | chunk
     const BatchItem &it = items[bb.win];
     GnInit gi; gi.enable = 1; gi.hasPrior = it.hasPrior; gi.calibPrior = calibPrior; gi.itCheck = itCheck;
-    linearize_body<NSG, false, false, false>(it.B, it.D, it.set[cur], it.set[cur ^ 1], S, stepMode, gi, nullptr, bb.host_chunk >> 8, it.D.nChunks, bb.p0, bb.np, bb.host_chunk & 0xFF);
+    linearize_body<NSG, false, false, false, true>(it.B, it.D, it.set[cur], it.set[cur ^ 1], S, stepMode, gi, nullptr, bb.host_chunk >> 8, it.D.nChunks, bb.p0, bb.np, bb.host_chunk & 0xFF);
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // launcher
 // ---------------------------------------------------------------------------------------------------------
 size_t ba_linearize_lds_bytes(int FS, bool hasL) {
-    size_t fl = (size_t) FS * (sizeof(DevPair) / 4) + 2 * (size_t) FS * 64 + (size_t) LD_WAVES * FS * LD_TOPN + (hasL ? (size_t) LD_WAVES * FS * LD_TOPN : 0) + (size_t) FS * 8 + 64;
+    size_t fl = (size_t) FS * (sizeof(DevPair) / 4) + 2 * (size_t) FS * 64 + (size_t) LD_WAVES * FS * LD_TOPN + (hasL ? (size_t) LD_WAVES * FS * LD_TOPN : 0) + (size_t) FS * 8 + 64 + 2 * (size_t) FS;
     return fl * sizeof(float) + 256;
 }
 
