@@ -201,6 +201,20 @@ int ldso_ba_batch_time_linearize(ldso_ba_batch_t *b, int reps, double *avg_us);
  * synchronisation.  `nccl_comm` is an ncclComm_t created by the caller (one rank per GPU, ncclCommInitRank); ncclAllReduce is
  * resolved at run time from the RCCL already in the process, else from librccl.so.  Every rank calls it with the same arguments. */
 int ldso_ba_enqueue_gn_rccl(ldso_ba_t *h, void *nccl_comm, int first_iteration, int iters);
+/* The same sharded iteration with a ONE-SHOT PEER-WRITE all-reduce instead of RCCL's ring (the message is 29 KB + 8 P bytes,
+ * latency-bound): every rank owns a receive window (2 parities x n_ranks slots) that its peers address over xGMI; a rank writes its partial
+ * into its slot of EVERY window as self-validating 64-bit words (payload | exchange number: no fence across the fabric) and sums the slots
+ * of its own window in rank order (deterministic).  ldso_ba_p2p_window_alloc: this rank's window (uncached device memory) and, optionally,
+ * its hipIpcMemHandle_t (64 bytes) for a peer PROCESS, which maps it with ldso_ba_p2p_window_open; ranks inside one process (or with peer
+ * access enabled) pass the pointers themselves.  windows[q] = rank q's window as this process addresses it, windows[rank] = the own one.
+ * Every rank calls ldso_ba_enqueue_gn_p2p with the same (first_iteration, iters).  ldso_ba_p2p_check (after ldso_ba_sync): LDSO_E_HIP when
+ * a peer's words did not arrive within the kernel's 2 s poll limit. */
+size_t ldso_ba_p2p_window_bytes(ldso_ba_t *h, int n_ranks);
+int ldso_ba_p2p_window_alloc(ldso_ba_t *h, int n_ranks, void **window_out, void *ipc_handle_out_64_bytes);
+int ldso_ba_p2p_window_open(ldso_ba_t *h, const void *ipc_handle_64_bytes, void **window_out);
+int ldso_ba_p2p_window_close(ldso_ba_t *h, void *window, int opened_from_handle);
+int ldso_ba_enqueue_gn_p2p(ldso_ba_t *h, int rank, int n_ranks, void *const *windows, int first_iteration, int iters);
+int ldso_ba_p2p_check(ldso_ba_t *h);
 int ldso_ba_reduce_local(ldso_ba_t *h, void *reduce_buf_dev);
 int ldso_ba_solve_reduced(ldso_ba_t *h, const void *reduce_buf_dev, int iteration, double lambda, int do_step);
 

@@ -187,6 +187,27 @@ class BA:
     def set_shard(self, begin, end):
         _chk(self.L.ldso_ba_set_shard(self.h, C.c_int(begin), C.c_int(end)))
 
+    # ---- one-shot peer-write all-reduce (ldso_ba_enqueue_gn_p2p) ----
+    def p2p_window_alloc(self, n_ranks, with_ipc_handle=False):
+        w = C.c_void_p(); hnd = C.create_string_buffer(64) if with_ipc_handle else None
+        _chk(self.L.ldso_ba_p2p_window_alloc(self.h, C.c_int(n_ranks), C.byref(w), hnd))
+        return (w.value, hnd.raw) if with_ipc_handle else w.value
+
+    def p2p_window_open(self, ipc_handle: bytes):
+        w = C.c_void_p()
+        _chk(self.L.ldso_ba_p2p_window_open(self.h, C.c_char_p(ipc_handle), C.byref(w)))
+        return w.value
+
+    def p2p_window_close(self, window, opened_from_handle=False):
+        _chk(self.L.ldso_ba_p2p_window_close(self.h, C.c_void_p(window), C.c_int(1 if opened_from_handle else 0)))
+
+    def enqueue_gn_p2p(self, rank, n_ranks, windows, first_iteration, iters):
+        arr = (C.c_void_p * n_ranks)(*windows)
+        _chk(self.L.ldso_ba_enqueue_gn_p2p(self.h, C.c_int(rank), C.c_int(n_ranks), arr, C.c_int(first_iteration), C.c_int(iters)))
+
+    def p2p_check(self):
+        _chk(self.L.ldso_ba_p2p_check(self.h))
+
     def set_chunk_points(self, n):
         _chk(self.L.ldso_ba_set_chunk_points(self.h, C.c_int(n)))
 

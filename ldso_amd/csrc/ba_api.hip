@@ -101,7 +101,9 @@ struct ldso_ba {
     int tcnt[5] = {0, 0, 0, 0, 0};
     int lastIterations = 0;
     bool noFusedLaunch = false;        // debug: k_reduce and k_gn_solve as two launches even where the fused k_reduce_solve applies
-    double *distBuf = nullptr;         // ldso_ba_enqueue_gn_rccl: all-reduce buffer [HFinal | bFinal | scalars | candidates]
+    double *distBuf = nullptr;         // ldso_ba_enqueue_gn_rccl / _p2p: all-reduce buffer [HFinal | bFinal | scalars | candidates]
+    unsigned p2pSeq = 0;               // ldso_ba_enqueue_gn_p2p: exchanges done (the tag of the hand-over words)
+    int *d_p2pErr = nullptr;           // set by k_p2p_sum when a peer's words did not arrive in time
     double neverStop = 1e300;          // source of the LD_SC_STOP reset (outlives the asynchronous copy)
 };
 
@@ -301,6 +303,7 @@ int ldso_ba_destroy(ldso_ba_t *H) {
     if (H->d_stage) hipFree(H->d_stage);
     if (H->d_act) hipFree(H->d_act);
     if (H->distBuf) hipFree(H->distBuf);
+    if (H->d_p2pErr) hipFree(H->d_p2pErr);
     for (auto &t : H->timers) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
     if (H->ownStream && H->stream) hipStreamDestroy(H->stream);
     delete H;
@@ -1079,7 +1082,7 @@ int ldso_ba_gn_solve_reduced(ldso_ba_t *H, const void *buf, int iteration, doubl
     CHK(ba_launch_gn_solve(H->B, H->D, S, H->settings, A, H->stream));
     t_end(H);
     RUN(launch_linearize(H, false, 1));
-    H->cur ^= 1;
+    H->cur ^= 1; H->appliedValid = true;
     return LDSO_OK;
 }
 
@@ -1309,6 +1312,116 @@ int ldso_ba_enqueue_gn_rccl(ldso_ba_t *H, void *nccl_comm, int first_iteration, 
     return LDSO_OK;
 }
 
+
+// ---- one-shot peer-write all-reduce --------------------------------------------------------------------------------
+// The reduce buffer of a GN iteration is small (29 KB + 8 P bytes at F = 7): a ring all-reduce pays 2 (N - 1) latency-bound hops for it.
+// Here every rank owns a RECEIVE WINDOW of 2 x N slots (two parities x one slot per source rank) that its peers can address (xGMI peer
+// mapping / hipIpcOpenMemHandle).  Per iteration a rank (1) forms its partial (ldso_ba_gn_reduce_local), (2) k_p2p_push writes it into slot
+// `rank` of EVERY rank's window as self-validating 64-bit words (32 payload bits | 32-bit exchange number - the hand-over of the cooperative
+// tracker: a word is valid by itself, so no fence has to order data before a flag across the fabric), (3) k_p2p_sum polls the N slots of
+// its own window and adds them in RANK ORDER (deterministic, unlike a ring whose order depends on the chunk), (4) the replicated solve.
+// One fabric traversal per direction.  Parity: a rank can run at most one exchange ahead of a peer (it needs that peer's partial of the
+// exchange to finish it), so two slots per source suffice.  The polls are bounded (2 s): a missing peer turns into LDSO_E_HIP at
+// ldso_ba_p2p_check instead of a hung stream.
+struct P2PWindows { unsigned long long *w[16]; };
+__global__ __launch_bounds__(256) void k_p2p_push(const double *__restrict__ src, int nd, P2PWindows W, int rank, int nRanks, int parity, unsigned seq) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nd; i += gridDim.x * blockDim.x) {
+        const unsigned long long u = __builtin_bit_cast(unsigned long long, src[i]);
+        const unsigned long long w0 = (u << 32) | seq, w1 = (u & 0xFFFFFFFF00000000ull) | seq;
+        const size_t o = (((size_t) parity * nRanks + rank) * nd + i) * 2;
+        for (int q = 0; q < nRanks; q++) {
+            __hip_atomic_store(W.w[q] + o, w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(W.w[q] + o + 1, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_p2p_sum(const unsigned long long *__restrict__ own, int nd, int nRanks, int parity, unsigned seq, double *__restrict__ out, int *err) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nd; i += gridDim.x * blockDim.x) {
+        double acc = 0.0;
+        for (int q = 0; q < nRanks; q++) {
+            const unsigned long long *p = own + (((size_t) parity * nRanks + q) * nd + i) * 2;
+            unsigned long long w0, w1;
+            unsigned spins = 0; long long t0 = 0; bool dead = false;
+            for (;;) {
+                w0 = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                w1 = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if ((unsigned) w0 == seq && (unsigned) w1 == seq) break;
+                if ((++spins & 255u) == 0) { const long long now = wall_clock64(); if (t0 == 0) t0 = now; else if (now - t0 > 200000000ll) { dead = true; break; } }
+            }
+            if (dead) { *err = 1; acc = __builtin_nan(""); break; }
+            acc += __builtin_bit_cast(double, (w1 & 0xFFFFFFFF00000000ull) | (w0 >> 32));
+        }
+        out[i] = acc;
+    }
+}
+
+size_t ldso_ba_p2p_window_bytes(ldso_ba_t *H, int n_ranks) {
+    if (!H || n_ranks < 1 || n_ranks > 16) return 0;
+    const size_t n = 8 * (size_t) H->maxF + 4;
+    return 2 * (size_t) n_ranks * (n * n + n + 8 + (size_t) H->maxP) * 16;
+}
+// This rank's receive window: uncached device memory (remote writes must be seen by a polling kernel), zeroed; ipc_handle_out (64 bytes,
+// hipIpcMemHandle_t) lets another process map it with ldso_ba_p2p_window_open.  Ranks of ONE process pass the pointer itself.
+int ldso_ba_p2p_window_alloc(ldso_ba_t *H, int n_ranks, void **window_out, void *ipc_handle_out) {
+    REQ(H && window_out && n_ranks >= 1 && n_ranks <= 16, "ldso_ba_p2p_window_alloc: bad arguments (1..16 ranks)");
+    CHK(hipSetDevice(H->device));
+    void *p = nullptr;
+    const size_t bytes = ldso_ba_p2p_window_bytes(H, n_ranks);
+    if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached) != hipSuccess) { (void) hipGetLastError(); CHK(hipMalloc(&p, bytes)); }
+    CHK(hipMemset(p, 0, bytes));
+    if (ipc_handle_out) { hipIpcMemHandle_t hnd; CHK(hipIpcGetMemHandle(&hnd, p)); memcpy(ipc_handle_out, &hnd, sizeof(hnd)); }
+    *window_out = p;
+    return LDSO_OK;
+}
+int ldso_ba_p2p_window_open(ldso_ba_t *H, const void *ipc_handle, void **window_out) {
+    REQ(H && ipc_handle && window_out, "ldso_ba_p2p_window_open: null argument");
+    CHK(hipSetDevice(H->device));
+    hipIpcMemHandle_t hnd; memcpy(&hnd, ipc_handle, sizeof(hnd));
+    CHK(hipIpcOpenMemHandle(window_out, hnd, hipIpcMemLazyEnablePeerAccess));
+    return LDSO_OK;
+}
+int ldso_ba_p2p_window_close(ldso_ba_t *H, void *window, int opened_from_handle) {
+    REQ(H && window, "ldso_ba_p2p_window_close: null argument");
+    CHK(hipSetDevice(H->device));
+    if (opened_from_handle) CHK(hipIpcCloseMemHandle(window)); else CHK(hipFree(window));
+    return LDSO_OK;
+}
+// `iters` forced Gauss-Newton iterations of this rank's shard with the one-shot exchange above instead of ncclAllReduce (same contract as
+// ldso_ba_enqueue_gn_rccl: every rank calls it with the same iteration arguments; windows[q] = rank q's receive window as THIS process
+// addresses it, windows[rank] = the own one).  n_ranks == 1 degenerates to the single-GPU iteration through the same kernels.
+int ldso_ba_enqueue_gn_p2p(ldso_ba_t *H, int rank, int n_ranks, void *const *windows, int first_iteration, int iters) {
+    REQ(H && windows && n_ranks >= 1 && n_ranks <= 16 && rank >= 0 && rank < n_ranks && H->D.P > 0 && iters >= 0, "ldso_ba_enqueue_gn_p2p: bad arguments");
+    for (int q = 0; q < n_ranks; q++) REQ(windows[q] != nullptr, "ldso_ba_enqueue_gn_p2p: a window pointer is null");
+    CHK(hipSetDevice(H->device));
+    const size_t nd = ldso_ba_gn_reduce_doubles(H);
+    if (!H->distBuf) { void *q = nullptr; CHK(hipMalloc(&q, ((size_t) (8 * H->maxF + 4) * (8 * H->maxF + 5) + 8 + H->maxP) * sizeof(double))); H->distBuf = (double *) q; }
+    if (!H->d_p2pErr) { void *q = nullptr; CHK(hipMalloc(&q, sizeof(int))); H->d_p2pErr = (int *) q; CHK(hipMemsetAsync(H->d_p2pErr, 0, sizeof(int), H->stream)); }
+    P2PWindows W;
+    for (int q = 0; q < 16; q++) W.w[q] = (unsigned long long *) (q < n_ranks ? windows[q] : nullptr);
+    const int grid = (int) ((nd + 255) / 256);
+    for (int i = 0; i < iters; i++) {
+        RUN(ldso_ba_gn_reduce_local(H, H->distBuf, 1e-1));
+        const unsigned seq = ++H->p2pSeq;
+        if (seq == 0xFFFFFFFFu) { ldso_set_error("ldso_ba_enqueue_gn_p2p: exchange counter exhausted (re-create the windows)"); return LDSO_E_INVALID; }
+        hipLaunchKernelGGL(k_p2p_push, dim3(grid), dim3(256), 0, H->stream, (const double *) H->distBuf, (int) nd, W, rank, n_ranks, (int) (seq & 1), seq);
+        hipLaunchKernelGGL(k_p2p_sum, dim3(grid), dim3(256), 0, H->stream, (const unsigned long long *) windows[rank], (int) nd, n_ranks, (int) (seq & 1), seq, H->distBuf, H->d_p2pErr);
+        CHK(hipGetLastError());
+        RUN(ldso_ba_gn_solve_reduced(H, H->distBuf, first_iteration + i, 1e-1));
+    }
+    return LDSO_OK;
+}
+// after ldso_ba_sync: LDSO_E_HIP if a peer's words did not arrive within the poll limit of some exchange since the last check
+int ldso_ba_p2p_check(ldso_ba_t *H) {
+    REQ(H, "null handle");
+    if (!H->d_p2pErr) return LDSO_OK;
+    CHK(hipSetDevice(H->device));
+    int e = 0;
+    CHK(hipMemcpyAsync(&e, H->d_p2pErr, sizeof(int), hipMemcpyDeviceToHost, H->stream));
+    CHK(hipStreamSynchronize(H->stream));
+    if (e) { CHK(hipMemsetAsync(H->d_p2pErr, 0, sizeof(int), H->stream)); ldso_set_error("ldso_ba_enqueue_gn_p2p: a peer's partial did not arrive within 2 s (peer not running / window not mapped)"); return LDSO_E_HIP; }
+    return LDSO_OK;
+}
+
 // FullSystem::optimizeImmaturePoint (FullSystem.cc:892-1010) for n immature points against the key frames of the window that is
 // resident in the handle (ldso_ba_set_image*, ldso_ba_set_window, ldso_ba_set_frames: images, calibration, current poses).
 int ldso_ba_activate_points(ldso_ba_t *H, int n, const ldso_immature_t *pts, int min_obs, float min_idepth_hessian, int gn_iterations, ldso_activation_t *out) {
@@ -1351,7 +1464,7 @@ int ldso_ba_solve_reduced(ldso_ba_t *H, const void *buf, int iteration, double l
     RUN(launch_gather(H, S, lambda, 2, (double *) buf));
     RUN(launch_solve(H, S, fl, iteration, lambda, -1, nullptr, (const double *) buf));
     RUN(launch_pstep(H, S, do_step ? (PS_RESUB | PS_BACKUP | PS_STEP) : PS_RESUB));
-    if (do_step) { RUN(launch_linearize(H, false)); H->cur ^= 1; }
+    if (do_step) { RUN(launch_linearize(H, false)); H->cur ^= 1; H->appliedValid = true; }
     return LDSO_OK;
 }
 

@@ -363,7 +363,10 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
         float HddA = 0, bdA = 0, HcdA0 = 0, HcdA1 = 0, HcdA2 = 0, HcdA3 = 0;
         float HddL = 0, bdL = 0, HcdL0 = 0, HcdL1 = 0, HcdL2 = 0, HcdL3 = 0;
         float hostPart = 0.0f;       // this lane's partial of the host block of g_p (component k)
-        float maxRelBS = q.maxRelBS;
+        // AccumulatedSCHessian.cc:14-21: the SOLVE that finds a point without an active residual zeroes its maxRelBaseline - i.e. the solve whose
+        // point step is fused in front of this pass (q.nAct = active residuals of the linearisation that solve used).  A pass that is followed
+        // by no solve (the last linearizeAll(false) of optimize(), the fixing pass) zeroes nothing.
+        float maxRelBS = ((stepMode & 1) && q.nAct <= 0) ? 0.0f : q.maxRelBS;
         int numGood = q.numGood;
         int nActive = 0;
         float gT[NSG];
@@ -676,10 +679,6 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
             HdiF = (float) (1.0 / (double) H);
             bdSumF = bdA + bdL;
             if (!MARG) bdSumF += priorF * deltaF;       // shiftPriorToZero = true in accumulateSCF_MT, false in marginalizePointsF
-        } else if (!FIX) {
-            // AccumulatedSCHessian.cc:14-21 zeroes maxRelBaseline in the SOLVE that finds the point without an active residual: this pass feeds
-            // the next solve.  The fixing pass (linearizeAll(true)) is followed by no solve inside optimize(): there the value survives
-            maxRelBS = 0;
         }
         // ---- store G row: [8*FS frame entries | Hcd 4, bdSum, HdiF, 0, 0] --------------------------------
         {

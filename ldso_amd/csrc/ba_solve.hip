@@ -1154,7 +1154,7 @@ __global__ __launch_bounds__(256) void k_point_step(BaPtrs B, BaDims D, ResSet S
     const int F = D.F, FS = D.FS, h = B.phost[p];
     float step = B.pstep[p];
     if (mode & PS_RESUB) { B.pLastHdiF[p] = S.HdiF[p]; B.pLastBdSumF[p] = S.bdSumF[p]; B.pLastIdH[p] = S.idH[p]; }      // what this solve's accumulateSCF_MT left in the point
-    if ((mode & PS_RESUB) && S.nActive[p] <= 0) step = 0.0f;
+    if ((mode & PS_RESUB) && S.nActive[p] <= 0) { step = 0.0f; S.maxRelBS[p] = 0.0f; }      // AccumulatedSCHessian.cc:14-21 (zeroed by the solve)
     if ((mode & PS_RESUB) && S.nActive[p] > 0) {
         float b = S.bdSumF[p];
         float dot = 0;

@@ -1,0 +1,106 @@
+"""ldso_ba_enqueue_gn_p2p: the sharded Gauss-Newton iteration with the one-shot peer-write all-reduce instead of RCCL's ring.
+One GPU is enough to test the protocol: two handles of one process on two streams (the windows are plain device pointers), and two PROCESSES
+whose windows cross the process boundary as hipIpcMemHandle_t - what ranks on different GPUs of an xGMI node do.  Checked against the
+unsharded single-handle iteration (same band as the RCCL / two-handle tests: the shards cut the fp32 partial sums differently) and, exactly,
+against the sum the two-handle test forms by hand (rank order = the order of the hand-made sum)."""
+import copy
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+from ldso_amd import synth, binding
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def _reference(win):
+    ref = binding.BA.from_window(win)
+    ref.collect_active(); ref.linearize_all(False); ref.apply_res()
+    ref.enqueue_gn(0, 4); ref.sync()
+    return ref
+
+
+def test_two_ranks_in_one_process(small):
+    import torch
+    win = synth.add_synthetic_prior(copy.deepcopy(small))
+    ref = _reference(win)
+    half = win.P // 2
+    ranks = []
+    for (a, b) in ((0, half), (half, win.P)):
+        g = binding.BA.from_window(win)             # own stream per handle: the two ranks must run concurrently
+        g.set_shard(a, b)
+        g.collect_active(); g.linearize_all(False); g.apply_res()
+        ranks.append(g)
+    windows = [g.p2p_window_alloc(2) for g in ranks]
+    for r, g in enumerate(ranks):
+        g.enqueue_gn_p2p(r, 2, windows, 0, 2)
+    for r, g in enumerate(ranks):
+        g.enqueue_gn_p2p(r, 2, windows, 2, 2)       # a second call continues the exchange numbering
+    for g in ranks:
+        g.sync(); g.p2p_check()
+    fr = ref.get_frames()
+    f0, f1 = ranks[0].get_frames(), ranks[1].get_frames()
+    assert np.array_equal(f0["frames"]["state"], f1["frames"]["state"]), "both ranks sum the same words in the same order: identical replicated solves"
+    assert rel(f0["frames"]["state"], fr["frames"]["state"]) < 5e-3 and rel(f0["frames"]["frameEnergyTH"], fr["frames"]["frameEnergyTH"]) < 1e-3
+    idr = ref.get_points()["idepth"]
+    assert rel(ranks[0].get_points()["idepth"][:half], idr[:half]) < 5e-3 and rel(ranks[1].get_points()["idepth"][half:], idr[half:]) < 5e-3
+    # the same four iterations with the sum formed by hand in rank order (what tests/test_ba_gpu.py::test_two_rank_fast_path does): bit for bit
+    ts = torch.cuda.Stream(); torch.cuda.set_stream(ts)
+    hand, bufs = [], []
+    for (a, b) in ((0, half), (half, win.P)):
+        g = binding.BA.from_window(win, stream=ts.cuda_stream); g.set_shard(a, b); g.collect_active(); g.linearize_all(False); g.apply_res()
+        hand.append(g); bufs.append(torch.zeros(g.gn_reduce_doubles(), dtype=torch.float64, device="cuda"))
+    for it in range(4):
+        for g, b in zip(hand, bufs):
+            g.gn_reduce_local(b.data_ptr(), 1e-1)
+        tot = bufs[0] + bufs[1]
+        for g, b in zip(hand, bufs):
+            b.copy_(tot); g.gn_solve_reduced(b.data_ptr(), it, 1e-1)
+    torch.cuda.synchronize()
+    assert rel(hand[0].get_frames()["frames"]["state"], f0["frames"]["state"]) < 1e-12
+    for g, w in zip(ranks, windows):
+        g.p2p_window_close(w)
+
+
+def test_single_rank_degenerates_to_the_single_gpu_iteration(small):
+    win = synth.add_synthetic_prior(copy.deepcopy(small))
+    ref = _reference(win)
+    g = binding.BA.from_window(win); g.collect_active(); g.linearize_all(False); g.apply_res()
+    w = g.p2p_window_alloc(1)
+    g.enqueue_gn_p2p(0, 1, [w], 0, 4); g.sync(); g.p2p_check()
+    assert rel(g.get_frames()["frames"]["state"], ref.get_frames()["frames"]["state"]) < 5e-3
+    g.p2p_window_close(w)
+
+
+def test_missing_peer_is_reported_not_hung(small):
+    """rank 0 of a two-rank exchange whose peer never pushes: the bounded poll ends the kernel, ldso_ba_p2p_check reports it."""
+    win = copy.deepcopy(small)
+    g = binding.BA.from_window(win); g.set_shard(0, win.P // 2); g.collect_active(); g.linearize_all(False); g.apply_res()
+    w0, w1 = g.p2p_window_alloc(2), g.p2p_window_alloc(2)
+    g.enqueue_gn_p2p(0, 2, [w0, w1], 0, 1); g.sync()
+    with pytest.raises(binding.LdsoError):
+        g.p2p_check()
+    g.p2p_check()                                    # the flag is cleared once reported
+
+
+def test_two_processes_share_windows_through_ipc_handles(small):
+    win = synth.add_synthetic_prior(copy.deepcopy(small))
+    ref = _reference(win)
+    here = os.path.dirname(os.path.abspath(__file__))
+    with tempfile.TemporaryDirectory() as d:
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs = [subprocess.Popen([sys.executable, os.path.join(here, "p2p_worker.py"), str(r), d], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in (0, 1)]
+        outs = [p.communicate(timeout=240)[0].decode(errors="replace") for p in procs]
+        assert all(p.returncode == 0 for p in procs), outs
+        s0, s1 = np.load(os.path.join(d, "state0.npy")), np.load(os.path.join(d, "state1.npy"))
+    assert np.array_equal(s0, s1)
+    assert rel(s0, ref.get_frames()["frames"]["state"]) < 5e-3
