@@ -1399,6 +1399,15 @@ int ldso_ba_enqueue_gn_p2p(ldso_ba_t *H, int rank, int n_ranks, void *const *win
     P2PWindows W;
     for (int q = 0; q < 16; q++) W.w[q] = (unsigned long long *) (q < n_ranks ? windows[q] : nullptr);
     const int grid = (int) ((nd + 255) / 256);
+    // everything that may synchronise the stream from the host (the handle's descriptor follows the accumulator pointer: refresh_item) happens
+    // BEFORE the first polling kernel is enqueued - a single host thread driving several ranks of one process must not wait for a kernel
+    // that polls for a peer it has not launched yet
+    if (H->B.acc != H->distBuf) {
+        H->B.acc = H->distBuf;
+        GnInit gi; gi.enable = (H->D.pBegin > 0) ? 2 : 1; gi.hasPrior = H->hasPrior ? 1 : 0; gi.calibPrior = H->settings.initialCalibHessian; gi.itCheck = -1;
+        CHK(ba_launch_acc_init(H->B, H->D, gi, H->stream));
+    }
+    RUN(refresh_item(H));
     for (int i = 0; i < iters; i++) {
         RUN(ldso_ba_gn_reduce_local(H, H->distBuf, 1e-1));
         const unsigned seq = ++H->p2pSeq;
