@@ -112,10 +112,22 @@ def measure(args, config, rank, local_rank, world, dist, steps, warmup, min_time
     ba.apply_res()
     dist_path = world > 1 or args.force_dist_path
     rbuf = torch.zeros(ba.gn_reduce_doubles(), dtype=torch.float64, device="cuda") if dist_path else None
+    windows = None
+    if dist_path and args.allreduce == "p2p":
+        # every rank's receive window, exchanged as hipIpcMemHandle_t through the process group (control plane only: the data path is peer stores)
+        own, hnd = ba.p2p_window_alloc(world, with_ipc_handle=True)
+        if world > 1:
+            allh = [None] * world
+            dist.all_gather_object(allh, hnd)
+            windows = [own if q == rank else ba.p2p_window_open(allh[q]) for q in range(world)]
+        else:
+            windows = [own]
 
     def run(k, it0):
         if not dist_path:
             ba.enqueue_gn(it0, k)
+        elif windows is not None:
+            ba.enqueue_gn_p2p(rank, world, windows, it0, k)     # reduce_local -> peer-write exchange -> replicated solve, all enqueued by the library
         elif world == 1:
             for i in range(k):                      # the multi-GPU step without the collective (one rank owns everything)
                 ba.gn_reduce_local(rbuf.data_ptr(), 1e-1)
@@ -151,6 +163,8 @@ def measure(args, config, rank, local_rank, world, dist, steps, warmup, min_time
             d = float(t.item())
         blocks.append(d); total += d
     dt = float(np.median(blocks))
+    if windows is not None:
+        ba.p2p_check()
     ok = bool(np.all(np.isfinite(ba.get_frames()["frames"]["state"])))
     parity = parity_check(win, ba, stream) if (with_parity and world == 1 and not dist_path) else None
 
@@ -219,6 +233,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the informational C4 / C5 / tracker / tracer / initialiser lines")
     ap.add_argument("--no-prior", action="store_true", help="window without the (synthetic) marginalisation prior H_M / b_M")
     ap.add_argument("--min-timed-s", type=float, default=2.0, help="repeat the timed block of exactly --steps iterations until this much time has been measured (profiling runs pass a small value)")
+    ap.add_argument("--allreduce", choices=["rccl", "p2p"], default="rccl", help="N > 1 (or --force-dist-path): RCCL all-reduce through torch.distributed, or the library's one-shot peer-write exchange (ldso_ba_enqueue_gn_p2p, windows shared as IPC handles)")
     ap.add_argument("--force-dist-path", action="store_true", help="1 GPU only: run the multi-GPU step (reduce_local / solve_reduced) with a no-op all-reduce")
     args = ap.parse_args()
 
@@ -267,7 +282,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": m["workload"],
                        "arithmetic": "f32 residuals / Jacobians / accumulators as the reference, f64 stitch and solve",
-                       "parallelism": "1 GPU" if world == 1 else f"points sharded over {world} GPUs, RCCL all-reduce of the stitched system per iteration"},
+                       "parallelism": "1 GPU" if world == 1 else f"points sharded over {world} GPUs, " + ("RCCL all-reduce" if args.allreduce == "rccl" else "one-shot peer-write all-reduce (ldso_ba_enqueue_gn_p2p)") + " of the stitched system per iteration"},
             "roofline": m["roofline"],
             "timed_blocks": m["timed_blocks"], "timed_total_ms": m["timed_total_ms"], "ms_per_step_min_max": m["ms_per_step_min_max"],
             "kernels": m["kernels"],

@@ -278,6 +278,31 @@ def make_mixed_window(win: synth.Window, oldest=2, perturb_seed=7) -> synth.Wind
     return w2
 
 
+def make_convergent_mixed_window(win: synth.Window, oldest=2, perturb_seed=11) -> synth.Window:
+    """A window with linearised residuals that a forced-accept GN sequence converges on: the window is first optimised to convergence, the
+    active residuals into the `oldest` frames are fixed THERE (fixLinearizationF at a consistent state, as FullSystem::flagPointsForRemoval
+    does for points about to be marginalised), and only then the state is perturbed a little.  (make_mixed_window fixes at an unconverged,
+    perturbed state: its sequence overshoots from the second step on.)"""
+    import copy
+    o = OracleWindow(win)
+    o.optimize(8)
+    r = o.get_residuals(False)
+    ids = np.nonzero((win.residuals["target"] < oldest) & (r["alive"] != 0) & (r["is_active"] != 0))[0]
+    o.fix_linearization(ids)
+    ex, fo = o.export_window(), o.get_frames()
+    w2 = copy.deepcopy(win)
+    w2.points, w2.residuals, w2.lin_J, w2.lin_res_toZeroF = ex["points"], ex["residuals"], ex["lin_J"], ex["lin_res_toZeroF"]
+    w2.frames = fo["frames"].copy()
+    w2.calib = w2.calib.copy(); w2.calib["value"] = fo["calib_value"]
+    rng = np.random.default_rng(perturb_seed)
+    for k in range(1, win.F):
+        w2.frames["state"][k][0:3] += rng.normal(0, 1e-4, 3)
+        w2.frames["state"][k][3:6] += rng.normal(0, 1e-5, 3)
+    w2.points["idepth"] = (w2.points["idepth"] * (1 + rng.normal(0, 5e-4, w2.P))).astype(np.float32)
+    o.close()
+    return w2
+
+
 def _track_new_coarse(fn, h, sprelast, slast, lastF, aff_last, last_rmse, retrack_threshold, poses_valid, with_tries):
     P = [np.ascontiguousarray(np.asarray(m, np.float64)[:3, :4]) for m in (sprelast, slast, lastF)]
     aff = np.asarray(aff_last, np.float32); rmse = np.ascontiguousarray(last_rmse, np.float64).copy()

@@ -182,6 +182,19 @@ def test_optimize_mixed_linearized(small):
     assert a > 0 and l > 0
 
 
+def test_optimize_convergent_mixed_window_five_iterations(small):
+    """The H_L / b_L fast path over several iterations: a window whose linearised residuals were fixed at a CONVERGED state
+    (po.make_convergent_mixed_window) - the forced-accept sequence stays put, so the per-iteration energies, the residual states and
+    the frame states can be held to the same tolerances as a window without linearised residuals."""
+    w2 = po.make_convergent_mixed_window(small)
+    assert w2.residuals["is_linearized"].sum() > 100
+    o, g = _optimize_compare(w2, its=5)
+    a, l = g.get_counts()
+    assert a > 0 and l > 0 and (a, l) == o.counts()[:2]
+    eo = o.energy_log()
+    assert eo[1:].max() < 1.05 * eo[0], "the window is meant to be convergent"
+
+
 def test_optimize_with_marginalization_prior(small):
     """H_M / b_M present: bFinal picks up b_M + H_M delta every iteration (EnergyFunctional.cc:279).  The prior is a
     synthetic symmetric PSD matrix (both sides get the same one)."""
