@@ -4,7 +4,10 @@
 #include <exception>
 #include <memory>
 #include <vector>
+#include <cmath>
 #include "ldso_gpu_adapter.h"
+#include "internal/PointHessian.h"
+#include "internal/Residuals.h"
 
 using namespace ldso;
 using namespace ldso::internal;
@@ -47,6 +50,23 @@ int adp_track_newest_coarse(void *b, void *tracker, void *fhs, void *newfh, void
         for (int i = 0; i < 3; i++) for (int j = 0; j < 4; j++) T[i * 4 + j] = M(i, j);
         ab[0] = aff.a; ab[1] = aff.b;
         for (int i = 0; i < 5; i++) lastResiduals[i] = tr.lastResiduals[i])
+}
+
+// toOptimize = ref_fs_build_immature(window, ...) of libldso_ref.so.  out: per candidate the verdict, the new point's inverse depth, and per
+// window frame 0 where the new point got a PointFrameResidual (state IN) / -1 elsewhere; last[k][0..1] = state of lastResiduals[0..1] (-1: no residual)
+int adp_activate_points(void *b, void *fs_, void *toOptimize, int n, int F, int *ok, float *idepth, int *res_target /*n*F*/, int *last /*n*2*/) {
+    GUARD(
+        auto &cand = *(std::vector<std::shared_ptr<ImmaturePoint>> *) toOptimize;
+        std::vector<std::shared_ptr<PointHessian>> made;
+        ((GpuBackend *) b)->activatePoints(*(FullSystem *) fs_, cand, made);
+        for (int i = 0; i < n; i++) {
+            ok[i] = made[i] ? 1 : 0; idepth[i] = made[i] ? made[i]->idepth : NAN;
+            for (int t = 0; t < F; t++) res_target[i * F + t] = -1;
+            last[2 * i] = last[2 * i + 1] = -1;
+            if (!made[i]) continue;
+            for (auto &r : made[i]->residuals) res_target[i * F + r->target.lock()->idx] = (int) r->state_state;
+            for (int j = 0; j < 2; j++) last[2 * i + j] = made[i]->lastResiduals[j].first ? (int) made[i]->lastResiduals[j].second : -1;
+        })
 }
 
 }  // extern "C"

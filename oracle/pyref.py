@@ -349,6 +349,22 @@ class GpuAdapter:
         ref_window.L.ref_fs_sync_back(ref_window.h)
         return rmse.value, its.value, bool(lost.value)
 
+    def activate_points(self, ref_window: "RefWindow", points, min_idepth_hessian=100.0, gn_iterations=3):
+        """GpuBackend::activatePoints on ImmaturePoint objects built from the records on the window's reference frames -> ok, idepth, per-frame
+        residual state of the created points (-1: no residual), states of lastResiduals[0..1]"""
+        ref_window.fs_attach()
+        L = ref_window.L
+        L.ref_fs_build_immature.restype = C.c_void_p
+        pts = np.ascontiguousarray(points); n = len(pts); F = ref_window.num_frames()
+        vec = C.c_void_p(L.ref_fs_build_immature(ref_window.h, C.c_int(n), _p(pts), C.c_int(1), C.c_float(min_idepth_hessian), C.c_int(gn_iterations)))
+        fs = C.c_void_p(L.ref_fs_handle(ref_window.h))
+        ok = np.zeros(n, np.int32); idepth = np.zeros(n, np.float32); tgt = np.zeros((n, F), np.int32); last = np.zeros((n, 2), np.int32)
+        try:
+            self._chk(self.A.adp_activate_points(self.h, fs, vec, C.c_int(n), C.c_int(F), _p(ok), _p(idepth), _p(tgt), _p(last)))
+        finally:
+            L.ref_fs_free_immature(vec)
+        return dict(ok=ok, idepth=idepth, res_target=tgt, last=last)
+
     def track_new_coarse(self, ref_tracker: "RefTracker", sprelast, slast, lastF, aff_last, last_rmse, retrack_threshold=1.5, poses_valid=True):
         """GpuBackend::makeK + setCoarseTrackingRef + trackNewCoarse in place of FullSystem::trackNewCoarse"""
         L, h = ref_tracker.L, ref_tracker.h

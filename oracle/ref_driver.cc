@@ -594,30 +594,39 @@ void ref_get_pair_rt(void *h, float *out) {
         }
 }
 
+// an ImmaturePoint of the reference on the window's host frame from a flat record: the constructor's own sampling of the host image is
+// replaced by the record's values (colour, weights, gradH, energyTH, depth interval), so that every side of a comparison starts identically
+static shared_ptr<ImmaturePoint> make_immature(RefWindow *W, FullSystem *fs, const ldso_immature_t &q) {
+    const int w = wG[0], hh = hG[0];
+    shared_ptr<Frame> host = fs->frames[q.host];
+    shared_ptr<Feature> feat(new Feature(q.u, q.v, host));
+    float uc = std::min(std::max(q.u, 8.0f), (float) w - 9), vc = std::min(std::max(q.v, 8.0f), (float) hh - 9);
+    feat->uv = Vec2f(uc, vc);                                  // keep the constructor's own sampling inside the image; its results are replaced by the record's
+    shared_ptr<ImmaturePoint> ip(new ImmaturePoint(host, feat, 1, W->Hcalib));
+    feat->uv = Vec2f(q.u, q.v);
+    feat->ip = ip;
+    memcpy(ip->color, q.color, sizeof(q.color)); memcpy(ip->weights, q.weights, sizeof(q.weights));
+    ip->gradH(0, 0) = q.gradH[0]; ip->gradH(0, 1) = q.gradH[1]; ip->gradH(1, 0) = q.gradH[2]; ip->gradH(1, 1) = q.gradH[3];
+    ip->energyTH = q.energyTH; ip->idepth_min = q.idepth_min; ip->idepth_max = q.idepth_max; ip->quality = q.quality;
+    ip->lastTraceStatus = (ImmaturePointStatus) q.lastTraceStatus;
+    return ip;
+}
+
 // shared_ptr<PointHessian> FullSystem::optimizeImmaturePoint(point, minObs, residuals) (FullSystem.cc:892-1010) - the member itself - for n
 // immature-point records against the key frames of the window.  Observable results: the verdict (non-null return), the new point's
 // inverse depth, and the caller-owned temporary residuals' final states (the energy / Hdd / bd locals of the function are not).
 void ref_fs_activate_points(void *h, int n, const ldso_immature_t *pts, int min_obs, float min_idepth_hessian, int gn_iterations, ldso_activation_t *out) {
     FsCall c(h);
     setting_minIdepthH_act = min_idepth_hessian; setting_GNItsOnPointActivation = gn_iterations;
-    const int F = (int) c.fs->frames.size(), w = wG[0], hh = hG[0];
+    const int F = (int) c.fs->frames.size();
     for (int i = 0; i < n; i++) {
         const ldso_immature_t &q = pts[i];
         ldso_activation_t &o = out[i];
         memset(&o, 0, sizeof(o));
         for (int f = 0; f < LDSO_MAX_FRAMES; f++) o.res_state[f] = -1;
         o.energy = o.Hdd = o.bd = NAN; o.iterations = -1;
-        shared_ptr<Frame> host = c.fs->frames[q.host];
-        shared_ptr<Feature> feat(new Feature(q.u, q.v, host));
-        float uc = std::min(std::max(q.u, 8.0f), (float) w - 9), vc = std::min(std::max(q.v, 8.0f), (float) hh - 9);
-        feat->uv = Vec2f(uc, vc);                                  // keep the constructor's own sampling inside the image; its results are replaced by the record's
-        shared_ptr<ImmaturePoint> ip(new ImmaturePoint(host, feat, 1, c.W->Hcalib));
-        feat->uv = Vec2f(q.u, q.v);
-        feat->ip = ip;
-        memcpy(ip->color, q.color, sizeof(q.color)); memcpy(ip->weights, q.weights, sizeof(q.weights));
-        ip->gradH(0, 0) = q.gradH[0]; ip->gradH(0, 1) = q.gradH[1]; ip->gradH(1, 0) = q.gradH[2]; ip->gradH(1, 1) = q.gradH[3];
-        ip->energyTH = q.energyTH; ip->idepth_min = q.idepth_min; ip->idepth_max = q.idepth_max; ip->quality = q.quality;
-        ip->lastTraceStatus = (ImmaturePointStatus) q.lastTraceStatus;
+        shared_ptr<ImmaturePoint> ip = make_immature(c.W, c.fs, q);
+        shared_ptr<Feature> feat = ip->feature;
         std::vector<shared_ptr<ImmaturePointTemporaryResidual>> tr;
         for (int f = 0; f + 1 < F; f++) tr.push_back(shared_ptr<ImmaturePointTemporaryResidual>(new ImmaturePointTemporaryResidual()));
         shared_ptr<PointHessian> ph = c.fs->optimizeImmaturePoint(ip, min_obs, tr);
@@ -633,6 +642,22 @@ void ref_fs_activate_points(void *h, int n, const ldso_immature_t *pts, int min_
         o.numGoodRes = good;
         feat->ReleaseAll();
     }
+}
+
+// for the compiled adapter's activation test (adapter/adapter_capi.cc): the same ImmaturePoint objects as ref_fs_activate_points builds,
+// handed over as a heap-allocated std::vector<shared_ptr<ImmaturePoint>> (ref_fs_free_immature releases them and what they created)
+void *ref_fs_build_immature(void *h, int n, const ldso_immature_t *pts, int min_obs_unused, float min_idepth_hessian, int gn_iterations) {
+    FsCall c(h);
+    (void) min_obs_unused;
+    setting_minIdepthH_act = min_idepth_hessian; setting_GNItsOnPointActivation = gn_iterations;
+    auto *v = new std::vector<shared_ptr<ImmaturePoint>>();
+    for (int i = 0; i < n; i++) v->push_back(make_immature(c.W, c.fs, pts[i]));
+    return v;
+}
+void ref_fs_free_immature(void *vec) {
+    auto *v = (std::vector<shared_ptr<ImmaturePoint>> *) vec;
+    for (auto &ip : *v) if (ip && ip->feature) ip->feature->ReleaseAll();
+    delete v;
 }
 
 // ---- FrameHessian::makeImages (FrameHessian.cc:44-113) -----------------------------------------------------------------------

@@ -118,3 +118,31 @@ def test_adapter_track_new_coarse_equals_reference(lost):
     t3 = A.track_newest_coarse(r2, np.eye(4), sc["new_aff"][0], sc["new_aff"][1], sc["levels"] - 1, min_res=np.full(5, 1e-3))
     assert not t3["ok"] and np.array_equal(t3["T"], np.eye(4)[:3])
     A.close()
+
+
+def test_adapter_activate_points_equals_reference_optimize_immature_point():
+    """GpuBackend::activatePoints (one ldso_ba_activate_points call + the object construction of FullSystem.cc:977-1008) against the reference's
+    own FullSystem::optimizeImmaturePoint on identical ImmaturePoint objects: verdict exact, the residuals the new points get (targets with
+    state IN) exact, activated inverse depth bit for bit, lastResiduals pointing at the two newest frames."""
+    win = synth.make_config("small", extra_frames=2)
+    pts, _ = synth.make_immature_points(win, 80)
+    for fidx in (win.F, win.F + 1):
+        KRKi, Kt, aff = synth.trace_poses(win, fidx)
+        po.trace_on(pts, win.images[fidx][0], KRKi, Kt, aff)
+    pts = pts[np.isfinite(pts["idepth_max"]) & (pts["lastTraceStatus"] != 1)].copy()
+    pts["idepth_min"][0] = np.nan
+    r_ref, r_adp = pr.RefWindow(win), pr.RefWindow(win)
+    r_ref.fs_attach()
+    ref = r_ref.fs_activate_points(pts)
+    A = pr.GpuAdapter(max_frames=win.F + 1, max_points=win.P + 16)
+    out = A.activate_points(r_adp, pts)
+    assert np.array_equal(out["ok"], ref["ok"]) and 0.3 < out["ok"].mean() < 1.0 and out["ok"][0] == 0
+    ok = out["ok"] == 1
+    assert np.array_equal(out["idepth"][ok].view(np.uint32), ref["idepth"][ok].view(np.uint32))
+    F = win.F
+    in_ref = (ref["res_state"][:, :F] == 0)
+    assert np.array_equal(out["res_target"][ok] == 0, in_ref[ok]), "a PointFrameResidual for exactly the targets whose temporary residual ended IN"
+    assert (out["res_target"][~ok] == -1).all()
+    # lastResiduals[0] / [1]: IN where the newest / second-newest frame is such a target (FullSystem.cc:1000-1006)
+    assert np.array_equal(out["last"][ok, 0] == 0, in_ref[ok, F - 1]) and np.array_equal(out["last"][ok, 1] == 0, in_ref[ok, F - 2])
+    A.close()
