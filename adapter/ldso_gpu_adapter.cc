@@ -95,7 +95,7 @@ void fromRaw(const ldso_rawjac_t &j, RawResidualJacobian &J) {
 
 GpuBackend::GpuBackend(int device, int maxFrames, int maxPoints) : device_(device), maxFrames_(maxFrames), maxPoints_(maxPoints) {
     throwOn(ldso_ba_create(device, wG[0], hG[0], maxFrames, maxPoints, &ba_), "ldso_ba_create");
-    slotOwner_.assign(maxFrames, nullptr);
+    slotOwner_.assign(maxFrames, -1);
 }
 
 GpuBackend::~GpuBackend() {
@@ -110,20 +110,20 @@ const char *GpuBackend::lastError() const { return ldso_last_error(); }
 // recycled when the frame has left (FullSystem::marginalizeFrame).
 // ------------------------------------------------------------------------------------------------------------------------------------
 void GpuBackend::syncImageSlots(FullSystem &fs, std::vector<int32_t> &slots) {
-    std::set<FrameHessian *> live;
-    for (auto &fr : fs.frames) live.insert(fr->frameHessian.get());
+    std::set<unsigned long> live;
+    for (auto &fr : fs.frames) live.insert(fr->id);
     for (size_t s = 0; s < slotOwner_.size(); s++)
-        if (slotOwner_[s] && !live.count(slotOwner_[s])) { slotOf_.erase(slotOwner_[s]); slotOwner_[s] = nullptr; }
+        if (slotOwner_[s] >= 0 && !live.count((unsigned long) slotOwner_[s])) { slotOf_.erase((unsigned long) slotOwner_[s]); slotOwner_[s] = -1; }
     slots.clear();
     for (auto &fr : fs.frames) {
         FrameHessian *fh = fr->frameHessian.get();
-        auto it = slotOf_.find(fh);
+        auto it = slotOf_.find(fr->id);
         if (it == slotOf_.end()) {
             size_t s = 0;
-            while (s < slotOwner_.size() && slotOwner_[s]) s++;
+            while (s < slotOwner_.size() && slotOwner_[s] >= 0) s++;
             if (s == slotOwner_.size()) throw std::runtime_error("GpuBackend: more key frames than maxFrames");
             throwOn(ldso_ba_set_image(ba_, (int) s, (const float *) fh->dIp[0]), "ldso_ba_set_image");      // Vec3f AoS (I, dx, dy): a straight copy
-            slotOwner_[s] = fh; it = slotOf_.emplace(fh, (int) s).first;
+            slotOwner_[s] = (long) fr->id; it = slotOf_.emplace(fr->id, (int) s).first;
         }
         slots.push_back(it->second);
     }
@@ -359,6 +359,15 @@ ldso_tracker_t *GpuBackend::trackerOf(CoarseTracker &tr) {
     return t;
 }
 
+// true when handle t already holds this frame's pyramid as its new frame; otherwise records that it is about to
+bool GpuBackend::newFrameResident(ldso_tracker_t *t, const shared_ptr<FrameHessian> &fh) {
+    const unsigned long id = fh->frame ? fh->frame->id : ~0ul;
+    auto it = trackerNewFrameId_.find(t);
+    if (it != trackerNewFrameId_.end() && it->second == id && id != ~0ul) return true;
+    trackerNewFrameId_[t] = id;
+    return false;
+}
+
 // void CoarseTracker::makeK(shared_ptr<CalibHessian>)                                                            CoarseTracker.cc:219-246
 void GpuBackend::makeK(CoarseTracker &tr, shared_ptr<CalibHessian> HCalib) {
     tr.makeK(HCalib);                                  // the host copies (w[], h[], K[] ...) other LDSO code reads; 20 scalar operations
@@ -397,11 +406,10 @@ bool GpuBackend::trackNewestCoarse(CoarseTracker &tr, shared_ptr<FrameHessian> n
                                    Vec5 minResForAbort) {
     ldso_tracker_t *t = trackerOf(tr);
     tr.newFrame = newFrameHessian;
-    if (trackerNewFrame_ != newFrameHessian.get()) {          // the pyramid goes over once per frame, not once per hypothesis
+    if (!newFrameResident(t, newFrameHessian)) {              // the pyramid goes over once per frame, not once per hypothesis
         const float *pyr[PYR_LEVELS];
         for (int l = 0; l < pyrLevelsUsed; l++) pyr[l] = (const float *) newFrameHessian->dIp[l];
         throwOn(ldso_tr_set_new_frame(t, pyr, newFrameHessian->ab_exposure), "ldso_tr_set_new_frame");
-        trackerNewFrame_ = newFrameHessian.get();
     }
     double T[12], mr[5], lr[5], fl[3];
     float ab[2] = {(float) aff_g2l_out.a, (float) aff_g2l_out.b};
@@ -425,11 +433,10 @@ Vec4 GpuBackend::trackNewCoarse(FullSystem &fs, shared_ptr<FrameHessian> fh) {
     ldso_tracker_t *t = trackerOf(tr);
     shared_ptr<FrameHessian> lastF = tr.lastRef;
     tr.newFrame = fh;
-    if (trackerNewFrame_ != fh.get()) {
+    if (!newFrameResident(t, fh)) {
         const float *pyr[PYR_LEVELS];
         for (int l = 0; l < pyrLevelsUsed; l++) pyr[l] = (const float *) fh->dIp[l];
         throwOn(ldso_tr_set_new_frame(t, pyr, fh->ab_exposure), "ldso_tr_set_new_frame");
-        trackerNewFrame_ = fh.get();
     }
     double sprelast[12], slast[12], lastFw2c[12];
     float aff_last[2] = {0, 0};

@@ -58,10 +58,13 @@ public:
 private:
     ldso_ba_t *ba_ = nullptr;
     std::map<CoarseTracker *, ldso_tracker_t *> trackers_;          // the reference double-buffers two CoarseTrackers (FullSystem.h:296-297)
-    std::map<internal::FrameHessian *, int> slotOf_;                 // key frame -> image slot of the BA handle
-    std::vector<internal::FrameHessian *> slotOwner_;
+    std::map<unsigned long, int> slotOf_;                            // key frame (Frame::id: addresses get reused) -> image slot of the BA handle
+    std::vector<long> slotOwner_;                                    // slot -> Frame::id, -1 = free
     int device_, maxFrames_, maxPoints_;
-    FrameHessian *trackerNewFrame_ = nullptr;                       // whose pyramid the tracker handle currently holds as "new frame"
+    // whose pyramid a tracker handle currently holds as "new frame": keyed by Frame::id, not by address (LDSO releases the FrameHessian of a
+    // non-key frame after tracking, the allocator may hand the same address to the next frame)
+    std::map<ldso_tracker_t *, unsigned long> trackerNewFrameId_;
+    bool newFrameResident(ldso_tracker_t *t, const shared_ptr<FrameHessian> &fh);
     ldso_tracker_t *trackerOf(CoarseTracker &tr);
     int uploadWindow(FullSystem &fs, std::vector<shared_ptr<PointHessian>> &allPoints, std::vector<shared_ptr<PointFrameResidual>> &flat);
     void syncImageSlots(FullSystem &fs, std::vector<int32_t> &slots);

@@ -1369,7 +1369,12 @@ int ldso_ba_p2p_window_alloc(ldso_ba_t *H, int n_ranks, void **window_out, void 
     const size_t bytes = ldso_ba_p2p_window_bytes(H, n_ranks);
     if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached) != hipSuccess) { (void) hipGetLastError(); CHK(hipMalloc(&p, bytes)); }
     CHK(hipMemset(p, 0, bytes));
-    if (ipc_handle_out) { hipIpcMemHandle_t hnd; CHK(hipIpcGetMemHandle(&hnd, p)); memcpy(ipc_handle_out, &hnd, sizeof(hnd)); }
+    if (ipc_handle_out) {
+        hipIpcMemHandle_t hnd;
+        const hipError_t e_ = hipIpcGetMemHandle(&hnd, p);
+        if (e_ != hipSuccess) { hipFree(p); ldso_set_error(std::string("hipIpcGetMemHandle: ") + hipGetErrorString(e_)); return LDSO_E_HIP; }
+        memcpy(ipc_handle_out, &hnd, sizeof(hnd));
+    }
     *window_out = p;
     return LDSO_OK;
 }

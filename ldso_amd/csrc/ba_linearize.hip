@@ -591,22 +591,37 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
                     for (int i = 0; i < 4; i++) { lx[i] = J.Jpdc[0][i]; ly[i] = J.Jpdc[1][i]; }
 #pragma unroll
                     for (int i = 0; i < 6; i++) { lx[4 + i] = J.Jpdxi[0][i]; ly[4 + i] = J.Jpdxi[1][i]; }
-                    if (k == 0) {
-                        float *dst = sTopL + (wave * FS + t) * LD_TOPN;      // plain read-modify-write: deterministic, no atomics
+                    {
+                        // AccumulatorApprox::update / updateTopRight / updateBotRight of this residual into the wave's own cell of the slot: lane k
+                        // owns row k (columns k..12) and, for k < 5, row k + 8 - the distribution of the mode-0 register accumulators.  Plain
+                        // read-modify-write of LDS words with exactly one writer lane each: deterministic, no atomics.  (Until round 3 lane 0
+                        // performed all 91 updates while 7 lanes idled.)
+                        float *dst = sTopL + (wave * FS + t) * LD_TOPN;
+                        const float lxr = (k == 0) ? lx[0] : (k == 1) ? lx[1] : (k == 2) ? lx[2] : (k == 3) ? lx[3] : (k == 4) ? lx[4] : (k == 5) ? lx[5] : (k == 6) ? lx[6] : lx[7];
+                        const float lyr = (k == 0) ? ly[0] : (k == 1) ? ly[1] : (k == 2) ? ly[2] : (k == 3) ? ly[3] : (k == 4) ? ly[4] : (k == 5) ? ly[5] : (k == 6) ? ly[6] : ly[7];
+                        const int b1 = k * 13 - (k * (k - 1)) / 2 - k;                       // tri13(k, cc) = b1 + cc
 #pragma unroll
-                        for (int r = 0; r < 10; r++)
-#pragma unroll
-                            for (int cc = r; cc < 10; cc++)
-                                dst[tri13(r, cc)] += a * lx[cc] * lx[r] + c * ly[cc] * ly[r] + b * (lx[cc] * ly[r] + ly[cc] * lx[r]);
-#pragma unroll
-                        for (int r = 0; r < 10; r++) {
-                            dst[tri13(r, 10)] += lx[r] * J.JabJIdx[0] + ly[r] * J.JabJIdx[1];
-                            dst[tri13(r, 11)] += lx[r] * J.JabJIdx[2] + ly[r] * J.JabJIdx[3];
-                            dst[tri13(r, 12)] += lx[r] * lJI_r0 + ly[r] * lJI_r1;
+                        for (int cc = 0; cc < 10; cc++)
+                            if (cc >= k) dst[b1 + cc] += a * lx[cc] * lxr + c * ly[cc] * lyr + b * (lx[cc] * lyr + ly[cc] * lxr);
+                        dst[b1 + 10] += lxr * J.JabJIdx[0] + lyr * J.JabJIdx[1];
+                        dst[b1 + 11] += lxr * J.JabJIdx[2] + lyr * J.JabJIdx[3];
+                        dst[b1 + 12] += lxr * lJI_r0 + lyr * lJI_r1;
+                        if (k < 2) {             // rows 8, 9 (geometric)
+                            const int r2 = k + 8, b2 = r2 * 13 - (r2 * (r2 - 1)) / 2 - r2;
+                            const float lx2 = (k == 0) ? lx[8] : lx[9], ly2 = (k == 0) ? ly[8] : ly[9];
+                            if (k == 0) dst[b2 + 8] += a * lx[8] * lx2 + c * ly[8] * ly2 + b * (lx[8] * ly2 + ly[8] * lx2);
+                            dst[b2 + 9] += a * lx[9] * lx2 + c * ly[9] * ly2 + b * (lx[9] * ly2 + ly[9] * lx2);
+                            dst[b2 + 10] += lx2 * J.JabJIdx[0] + ly2 * J.JabJIdx[1];
+                            dst[b2 + 11] += lx2 * J.JabJIdx[2] + ly2 * J.JabJIdx[3];
+                            dst[b2 + 12] += lx2 * lJI_r0 + ly2 * lJI_r1;
+                        } else if (k == 2) {     // row 10
+                            dst[tri13(10, 10)] += J.Jab2[0]; dst[tri13(10, 11)] += J.Jab2[1]; dst[tri13(10, 12)] += lJab_r0;
+                        } else if (k == 3) {     // row 11
+                            dst[tri13(11, 11)] += J.Jab2[3]; dst[tri13(11, 12)] += lJab_r1;
+                        } else if (k == 4) {     // row 12
+                            dst[tri13(12, 12)] += lrr;
                         }
-                        dst[tri13(10, 10)] += J.Jab2[0]; dst[tri13(10, 11)] += J.Jab2[1]; dst[tri13(10, 12)] += lJab_r0;
-                        dst[tri13(11, 11)] += J.Jab2[3]; dst[tri13(11, 12)] += lJab_r1; dst[tri13(12, 12)] += lrr;
-                        nresL++;
+                        if (k == 0) nresL++;
                     }
                     float lJi0 = a * J.Jpdd[0] + b * J.Jpdd[1], lJi1 = b * J.Jpdd[0] + c * J.Jpdd[1];
                     lsbd = lJI_r0 * J.Jpdd[0] + lJI_r1 * J.Jpdd[1];
