@@ -123,7 +123,7 @@ def test_adapter_track_new_coarse_equals_reference(lost):
 def test_adapter_activate_points_equals_reference_optimize_immature_point():
     """GpuBackend::activatePoints (one ldso_ba_activate_points call + the object construction of FullSystem.cc:977-1008) against the reference's
     own FullSystem::optimizeImmaturePoint on identical ImmaturePoint objects: verdict exact, the residuals the new points get (targets with
-    state IN) exact, activated inverse depth bit for bit, lastResiduals pointing at the two newest frames."""
+    state IN) exact, activated inverse depth to 1e-5, lastResiduals pointing at the two newest frames."""
     win = synth.make_config("small", extra_frames=2)
     pts, _ = synth.make_immature_points(win, 80)
     for fidx in (win.F, win.F + 1):
@@ -138,7 +138,9 @@ def test_adapter_activate_points_equals_reference_optimize_immature_point():
     out = A.activate_points(r_adp, pts)
     assert np.array_equal(out["ok"], ref["ok"]) and 0.3 < out["ok"].mean() < 1.0 and out["ok"][0] == 0
     ok = out["ok"] == 1
-    assert np.array_equal(out["idepth"][ok].view(np.uint32), ref["idepth"][ok].view(np.uint32))
+    # not bit for bit here (it is, given identical pair transforms: tests/test_activate_gpu.py, test_ref_pin.py): the device forms the pair
+    # transforms from [R|t] matrices, the reference from unit quaternions - the last bit of a float R entry can differ
+    assert np.abs(out["idepth"][ok] - ref["idepth"][ok]).max() <= 1e-5 * np.abs(ref["idepth"][ok]).max()
     F = win.F
     in_ref = (ref["res_state"][:, :F] == 0)
     assert np.array_equal(out["res_target"][ok] == 0, in_ref[ok]), "a PointFrameResidual for exactly the targets whose temporary residual ended IN"
