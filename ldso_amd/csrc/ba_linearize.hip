@@ -80,8 +80,8 @@ __device__ __forceinline__ float seq8(float x, int k, int lane) {
 
 // gfx950: v_permlane16_swap_b32 a, b exchanges the odd 16-lane rows of a with the even rows of b; v_permlane32_swap_b32 the upper half of a
 // with the lower half of b.  With a = b = x, a + b is the xor-16 / xor-32 butterfly sum - in the vector ALU, where ds_bpermute costs an LDS
-// round trip (~64+ cycles of dependent latency; the point loop had 45 of them, most in dependent pairs).  s_nop: the assembler does not
-// know the hazards of hand-placed instructions.
+// round trip.  s_nop: the assembler does not know the hazards of hand-placed instructions.  Kept as an option (LD_PERM_DESC / LD_PERM_ARGS):
+// bit-identical results, measured 2 % SLOWER than the ds_bpermute form in every configuration (see the defaults below).
 __device__ __forceinline__ float bfly16(float x) {
     float a = x, b = x;
     asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
@@ -94,10 +94,15 @@ __device__ __forceinline__ float bfly32(float x) {
 }
 // sum over the 8 slots of a wave (lanes with equal k), result in every lane: slot pairs by row_ror:8, then the four rows by the two
 // butterflies above (tree order; the sequential-order sums that decide residual states use seq8)
-__device__ __forceinline__ float sum_slots(float x, int, int) {
+template <bool PERM> __device__ __forceinline__ float sum_slots(float x, int a16, int a32) {
     x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128, 0xF, 0xF, true));
-    x = bfly16(x);
-    x = bfly32(x);
+    if (PERM) {
+        x = bfly16(x);
+        x = bfly32(x);
+    } else {
+        x += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(a16, __builtin_bit_cast(int, x)));
+        x += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(a32, __builtin_bit_cast(int, x)));
+    }
     return x;
 }
 // ---- just-in-time pointer groups ------------------------------------------------------------------------------------------------
@@ -160,7 +165,27 @@ struct PtIn {
 // vmcnt (every s_waitcnt lgkmcnt(0) of a scalar load then waits for all vector memory traffic in flight).  Every table of a window is
 // hipMalloc'ed device memory: the access is made through an address_space(1) (global) pointer -> global_load/store v, v_off, s[base].
 template <class T> using gptr_t = __attribute__((address_space(1))) T *;
-#define AT(ptr, i) (*(gptr_t<typename std::remove_pointer<decltype(ptr)>::type>) ((gptr_t<char>) (ptr) + (size_t) ((unsigned) (i) * (unsigned) sizeof(*(ptr)))))
+// ... where the base pointers were fetched just in time (DESC).  The argument-based kernels keep the generic access: measured at C5
+// (k_linearize<2,...>, A/B on one box) 44.8 us with flat accesses and ds_bpermute slot sums against 47.0 us with the global accesses and
+// permlane butterflies that the descriptor-based kernel uses - there the pointers sit in SGPRs from the start and the compiler's own
+// flat addressing / waitcnt placement is the better schedule.
+template <bool GLOBAL> struct at_sel;
+template <> struct at_sel<true> {
+    template <class T> static __device__ __forceinline__ __attribute__((address_space(1))) T &ref(T *p, unsigned i) { return *(gptr_t<T>) ((gptr_t<char>) p + (size_t) (i * (unsigned) sizeof(T))); }
+};
+template <> struct at_sel<false> {
+    template <class T> static __device__ __forceinline__ T &ref(T *p, unsigned i) { return *(T *) ((char *) p + (size_t) (i * (unsigned) sizeof(T))); }
+};
+#ifndef LD_GLOBAL_ARGS
+#define LD_GLOBAL_ARGS 0
+#endif
+#ifndef LD_PERM_ARGS
+#define LD_PERM_ARGS 0
+#endif
+#ifndef LD_PERM_DESC
+#define LD_PERM_DESC 0      // measured (A/B, two rounds each on one box): 220.3 / 51.6 / 10.07 us (B = 32 / B = 8 / C3) with ds_bpermute against 225.2 / 52.7 / 10.17 us with the
+#endif                   // permlane butterflies below - their hand-placed s_nop pairs and the opaque asm cost more than the LDS round trips they save
+#define AT(ptr, i) (at_sel<DESC || LD_GLOBAL_ARGS>::ref((ptr), (unsigned) (i)))
 
 template <int NSG, bool HAS_L, bool FIX, bool DESC>
 static __device__ __forceinline__ void load_point(PtIn<NSG> &q, const BaPtrs &B, const ResSet &cur, unsigned FS, unsigned p, unsigned s, unsigned k, int stepMode) {
@@ -343,7 +368,7 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
                     const bool act = (t < F) && (q.rflat[g] >= 0) && (q.active[g] != 0);
                     float sres = seq8(sXa[t * 8 + k] * q.jp[g], k, lane);
                     sres = act ? sres : 0.0f;
-                    b -= sum_slots(sres, a16, a32);
+                    b -= sum_slots<DESC ? (LD_PERM_DESC != 0) : (LD_PERM_ARGS != 0)>(sres, a16, a32);
                 }
                 if (isfinite(b)) step = -b * q.HdiF; else { step = q.pstep; if (lane == 0) B.scalars[4] = 1.0; }
             }
@@ -419,7 +444,8 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
             if (compute && centerOK && pixOK) {
                 int ix = (int) Ku, iy = (int) Kv;
                 float dx = Ku - ix, dy = Kv - iy, dxdy = dx * dy;
-                const float *bp = sImg[t] + 3 * (ix + iy * W);
+                // descriptor in memory: the pointer from LDS; kernel arguments: the table sits in scalar registers, selected per lane
+                const float *bp = (DESC ? sImg[t] : B.img[t]) + 3 * (ix + iy * W);
                 float a0 = bp[0], a1 = bp[1], a2 = bp[2], b0_ = bp[3], b1 = bp[4], b2 = bp[5];
                 const float *bq = bp + 3 * W;
                 float c0_ = bq[0], c1_ = bq[1], c2_ = bq[2], d0 = bq[3], d1 = bq[4], d2 = bq[5];
@@ -561,9 +587,9 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
             float sHc0 = accHere ? (x[0] * Ji2_0 + y[0] * Ji2_1) : 0.0f, sHc1 = accHere ? (x[1] * Ji2_0 + y[1] * Ji2_1) : 0.0f;
             float sHc2 = accHere ? (x[2] * Ji2_0 + y[2] * Ji2_1) : 0.0f, sHc3 = accHere ? (x[3] * Ji2_0 + y[3] * Ji2_1) : 0.0f;
             // sum over the 8 slots of this pass
-            bdA += sum_slots(sbd, a16, a32); HddA += sum_slots(sHdd, a16, a32);
-            HcdA0 += sum_slots(sHc0, a16, a32); HcdA1 += sum_slots(sHc1, a16, a32);
-            HcdA2 += sum_slots(sHc2, a16, a32); HcdA3 += sum_slots(sHc3, a16, a32);
+            bdA += sum_slots<DESC ? (LD_PERM_DESC != 0) : (LD_PERM_ARGS != 0)>(sbd, a16, a32); HddA += sum_slots<DESC ? (LD_PERM_DESC != 0) : (LD_PERM_ARGS != 0)>(sHdd, a16, a32);
+            HcdA0 += sum_slots<DESC ? (LD_PERM_DESC != 0) : (LD_PERM_ARGS != 0)>(sHc0, a16, a32); HcdA1 += sum_slots<DESC ? (LD_PERM_DESC != 0) : (LD_PERM_ARGS != 0)>(sHc1, a16, a32);
+            HcdA2 += sum_slots<DESC ? (LD_PERM_DESC != 0) : (LD_PERM_ARGS != 0)>(sHc2, a16, a32); HcdA3 += sum_slots<DESC ? (LD_PERM_DESC != 0) : (LD_PERM_ARGS != 0)>(sHc3, a16, a32);
             if (accHere && k == 0) nresA++;
 
             // ================= linearised residual, mode 1 (AccumulatedTopHessian.cc:29-31,44-63) =======
@@ -628,9 +654,9 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
                     lsHdd = lJi0 * J.Jpdd[0] + lJi1 * J.Jpdd[1];
                     lH0 = lx[0] * lJi0 + ly[0] * lJi1; lH1 = lx[1] * lJi0 + ly[1] * lJi1; lH2 = lx[2] * lJi0 + ly[2] * lJi1; lH3 = lx[3] * lJi0 + ly[3] * lJi1;
                 }
-                bdL += sum_slots(lsbd, a16, a32); HddL += sum_slots(lsHdd, a16, a32);
-                HcdL0 += sum_slots(lH0, a16, a32); HcdL1 += sum_slots(lH1, a16, a32);
-                HcdL2 += sum_slots(lH2, a16, a32); HcdL3 += sum_slots(lH3, a16, a32);
+                bdL += sum_slots<DESC ? (LD_PERM_DESC != 0) : (LD_PERM_ARGS != 0)>(lsbd, a16, a32); HddL += sum_slots<DESC ? (LD_PERM_DESC != 0) : (LD_PERM_ARGS != 0)>(lsHdd, a16, a32);
+                HcdL0 += sum_slots<DESC ? (LD_PERM_DESC != 0) : (LD_PERM_ARGS != 0)>(lH0, a16, a32); HcdL1 += sum_slots<DESC ? (LD_PERM_DESC != 0) : (LD_PERM_ARGS != 0)>(lH1, a16, a32);
+                HcdL2 += sum_slots<DESC ? (LD_PERM_DESC != 0) : (LD_PERM_ARGS != 0)>(lH2, a16, a32); HcdL3 += sum_slots<DESC ? (LD_PERM_DESC != 0) : (LD_PERM_ARGS != 0)>(lH3, a16, a32);
             }
 
             // ================= lifted Schur row: target block and this slot's share of the host block ==
@@ -646,7 +672,7 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
                     for (int j = 0; j < 8; j++) { tgt = __builtin_fmaf(aT[j], vj[j], tgt); hpart = __builtin_fmaf(aH[j], vj[j], hpart); }
                 }
             }
-            hostPart += sum_slots(hpart, a16, a32);
+            hostPart += sum_slots<DESC ? (LD_PERM_DESC != 0) : (LD_PERM_ARGS != 0)>(hpart, a16, a32);
             gT[g] = tgt;
             nActive += __popcll(__ballot(exists && activeNew && k == 0));
             if (FIX) numGood += __popcll(newGoodMask);
