@@ -40,3 +40,16 @@ def test_bench_two_ranks_on_one_gpu():
     j = _last_json(r.stdout)
     assert j["n_gpus"] == 2 and j["value"] > 0 and j["state_finite"]
     assert "sharded over 2 GPUs" in j["config"]["parallelism"]
+
+
+def test_bench_two_ranks_on_one_gpu_with_the_peer_write_exchange():
+    """the same two ranks with --allreduce p2p: the receive windows cross the process boundary as hipIpcMemHandle_t (all_gather_object over the
+    process group = control plane only), the iteration is ldso_ba_enqueue_gn_p2p"""
+    env = dict(os.environ, LDSO_BENCH_ONE_GPU="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29519", "bench.py", "--gpus", "2", "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--allreduce", "p2p", "--min-timed-s", "0.2"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    j = _last_json(r.stdout)
+    assert j["n_gpus"] == 2 and j["value"] > 0 and j["state_finite"]
+    assert "peer-write" in j["config"]["parallelism"]
