@@ -69,4 +69,9 @@ int adp_activate_points(void *b, void *fs_, void *toOptimize, int n, int F, int 
         })
 }
 
+// fh = ref_fs_new_frame(window, ...): GpuBackend::traceNewCoarse in place of FullSystem::traceNewCoarse; counts = its six trace_* counters
+int adp_trace_new_coarse(void *b, void *fs, void *fh, int *counts) {
+    GUARD(((GpuBackend *) b)->traceNewCoarse(*(FullSystem *) fs, *(std::shared_ptr<FrameHessian> *) fh); for (int i = 0; i < 6; i++) counts[i] = ((GpuBackend *) b)->lastTraceCounts[i])
+}
+
 }  // extern "C"

@@ -100,6 +100,7 @@ GpuBackend::GpuBackend(int device, int maxFrames, int maxPoints) : device_(devic
 
 GpuBackend::~GpuBackend() {
     for (auto &kv : trackers_) ldso_tr_destroy(kv.second);
+    if (tracer_) ldso_trace_destroy(tracer_);
     if (ba_) ldso_ba_destroy(ba_);
 }
 
@@ -344,6 +345,70 @@ void GpuBackend::activatePoints(FullSystem &fs, std::vector<shared_ptr<ImmatureP
             else if (target == (fs.frames.size() < 2 ? nullptr : fs.frames[fs.frames.size() - 2]->frameHessian)) { p->lastResiduals[1].first = r; p->lastResiduals[1].second = ResState::IN; }
         }
         optimized[k] = p;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// void FullSystem::traceNewCoarse(shared_ptr<FrameHessian> fh)                                                   FullSystem.cc:1012-1050
+// Every immature point of the window's key frames is traced into the new frame by one ldso_trace_on call (one wavefront per point);
+// the per-host KRKi / Kt / affine transfer are formed here exactly as the reference forms them (its own Eigen / Sophus expressions).
+// ------------------------------------------------------------------------------------------------------------------------------------
+void GpuBackend::traceNewCoarse(FullSystem &fs, shared_ptr<FrameHessian> fh) {
+    unique_lock<mutex> lock(fs.mapMutex);
+    for (int i = 0; i < 6; i++) lastTraceCounts[i] = 0;
+    const int F = (int) fs.frames.size();
+    std::vector<ldso_immature_t> rec;
+    std::vector<ImmaturePoint *> who;
+    for (int f = 0; f < F; f++)
+        for (auto &feat : fs.frames[f]->features) {
+            if (!(feat->status == Feature::FeatureStatus::IMMATURE && feat->ip)) continue;
+            ImmaturePoint &ip = *feat->ip;
+            ldso_immature_t q;
+            memset(&q, 0, sizeof(q));
+            q.u = feat->uv[0]; q.v = feat->uv[1];
+            memcpy(q.color, ip.color, sizeof(q.color)); memcpy(q.weights, ip.weights, sizeof(q.weights));
+            q.gradH[0] = ip.gradH(0, 0); q.gradH[1] = ip.gradH(0, 1); q.gradH[2] = ip.gradH(1, 0); q.gradH[3] = ip.gradH(1, 1);
+            q.energyTH = ip.energyTH; q.idepth_min = ip.idepth_min; q.idepth_max = ip.idepth_max; q.quality = ip.quality;
+            q.lastTraceStatus = (int32_t) ip.lastTraceStatus; q.lastTraceUV[0] = ip.lastTraceUV[0]; q.lastTraceUV[1] = ip.lastTraceUV[1];
+            q.lastTracePixelInterval = ip.lastTracePixelInterval; q.host = f;
+            rec.push_back(q); who.push_back(&ip);
+        }
+    if (rec.empty()) return;
+    if (!tracer_ || (int) rec.size() > tracerCap_) {
+        if (tracer_) ldso_trace_destroy(tracer_);
+        tracer_ = nullptr;
+        tracerCap_ = std::max((int) rec.size() * 2, 16384);
+        throwOn(ldso_trace_create(device_, wG[0], hG[0], tracerCap_, &tracer_), "ldso_trace_create");
+    }
+    ldso_trace_settings_t ts;
+    ldso_trace_settings_default(&ts);
+    ts.maxPixSearch = setting_maxPixSearch; ts.trace_stepsize = setting_trace_stepsize; ts.trace_GNThreshold = setting_trace_GNThreshold;
+    ts.trace_extraSlackOnTH = setting_trace_extraSlackOnTH; ts.trace_slackInterval = setting_trace_slackInterval;
+    ts.trace_minImprovementFactor = setting_trace_minImprovementFactor; ts.huberTH = setting_huberTH;
+    ts.trace_GNIterations = setting_trace_GNIterations; ts.minTraceTestRadius = setting_minTraceTestRadius;
+    throwOn(ldso_trace_set_settings(tracer_, &ts), "ldso_trace_set_settings");
+    // :1018-1032, per host frame
+    Mat33f K = Mat33f::Identity();
+    K(0, 0) = fs.Hcalib->mpCH->fxl(); K(1, 1) = fs.Hcalib->mpCH->fyl(); K(0, 2) = fs.Hcalib->mpCH->cxl(); K(1, 2) = fs.Hcalib->mpCH->cyl();
+    std::vector<float> KRKi((size_t) F * 9), Kt((size_t) F * 3), aff((size_t) F * 2);
+    for (int f = 0; f < F; f++) {
+        shared_ptr<FrameHessian> host = fs.frames[f]->frameHessian;
+        SE3 hostToNew = fh->PRE_worldToCam * host->PRE_camToWorld;
+        Mat33f M = K * hostToNew.rotationMatrix().cast<float>() * K.inverse();
+        Vec3f t = K * hostToNew.translation().cast<float>();
+        Vec2f a = AffLight::fromToVecExposure(host->ab_exposure, fh->ab_exposure, host->aff_g2l(), fh->aff_g2l()).cast<float>();
+        for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) KRKi[(size_t) f * 9 + r * 3 + c] = M(r, c); Kt[(size_t) f * 3 + r] = t[r]; }
+        aff[(size_t) f * 2] = a[0]; aff[(size_t) f * 2 + 1] = a[1];
+    }
+    throwOn(ldso_trace_set_points(tracer_, (int) rec.size(), rec.data()), "ldso_trace_set_points");
+    throwOn(ldso_trace_set_frame(tracer_, (const float *) fh->dIp[0]), "ldso_trace_set_frame");
+    throwOn(ldso_trace_on(tracer_, F, KRKi.data(), Kt.data(), aff.data(), lastTraceCounts), "ldso_trace_on");
+    throwOn(ldso_trace_get_points(tracer_, rec.data()), "ldso_trace_get_points");
+    for (size_t i = 0; i < rec.size(); i++) {          // what ImmaturePoint::traceOn leaves in the object (ImmaturePoint.cc:47-310)
+        ImmaturePoint &ip = *who[i]; const ldso_immature_t &q = rec[i];
+        ip.idepth_min = q.idepth_min; ip.idepth_max = q.idepth_max; ip.quality = q.quality;
+        ip.lastTraceStatus = (ImmaturePointStatus) q.lastTraceStatus;
+        ip.lastTraceUV = Vec2f(q.lastTraceUV[0], q.lastTraceUV[1]); ip.lastTracePixelInterval = q.lastTracePixelInterval;
     }
 }
 

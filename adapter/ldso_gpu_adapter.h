@@ -10,6 +10,7 @@
 //   GpuBackend::trackNewestCoarse                   bool CoarseTracker::trackNewestCoarse(...)                      CoarseTracker.cc:61-217
 //   GpuBackend::trackNewCoarse(fs, fh)              Vec4 FullSystem::trackNewCoarse(shared_ptr<FrameHessian>)       FullSystem.cc:179-386
 //   GpuBackend::activatePoints(fs, ...)             the optimizeImmaturePoint loop of activatePointsMT              FullSystem.cc:892-1010,1196-1206
+//   GpuBackend::traceNewCoarse(fs, fh)              void FullSystem::traceNewCoarse(shared_ptr<FrameHessian>)       FullSystem.cc:1012-1050
 //
 // The functions reach into private members of FullSystem / CoarseTracker (frames, ef, activeResiduals, allFrameHistory, lastCoarseRMSE,
 // shellPoseMutex ...): a maintainer makes them member functions or adds `friend class ldso::GpuBackend;` to the two classes.  The reference tree
@@ -53,10 +54,16 @@ public:
     // optimized[k] = the new PointHessian of toOptimize[k] or nullptr, exactly what FullSystem::optimizeImmaturePoint returns
     void activatePoints(FullSystem &fs, std::vector<shared_ptr<internal::ImmaturePoint>> &toOptimize, std::vector<shared_ptr<PointHessian>> &optimized);
 
+    // ---- immature-point tracing: void FullSystem::traceNewCoarse(shared_ptr<FrameHessian> fh)                   FullSystem.cc:1012-1050
+    void traceNewCoarse(FullSystem &fs, shared_ptr<FrameHessian> fh);
+    int lastTraceCounts[6] = {0, 0, 0, 0, 0, 0};        // good, oob, outlier, skipped, bad condition, uninitialised (the function's trace_* counters)
+
     const char *lastError() const;
 
 private:
     ldso_ba_t *ba_ = nullptr;
+    ldso_tracer_t *tracer_ = nullptr;
+    int tracerCap_ = 0;
     std::map<CoarseTracker *, ldso_tracker_t *> trackers_;          // the reference double-buffers two CoarseTrackers (FullSystem.h:296-297)
     std::map<unsigned long, int> slotOf_;                            // key frame (Frame::id: addresses get reused) -> image slot of the BA handle
     std::vector<long> slotOwner_;                                    // slot -> Frame::id, -1 = free

@@ -173,6 +173,24 @@ class RefWindow:
     def fs_marginalize_frame(self, idx):
         self.L.ref_fs_marginalize_frame(self.h, C.c_int(idx))
 
+    # --- FullSystem::traceNewCoarse on this window: immature points on the key frames, a new frame with a pose ---
+    def fs_add_immature(self, points):
+        pts = np.ascontiguousarray(points)
+        self.L.ref_fs_add_immature(self.h, C.c_int(len(pts)), _p(pts))
+
+    def fs_new_frame(self, dI_level0, w2c, aff_a, aff_b, exposure=1.0):
+        self.L.ref_fs_new_frame.restype = C.c_void_p
+        img = np.ascontiguousarray(dI_level0, np.float32); T = np.ascontiguousarray(np.asarray(w2c, np.float64)[:3, :4])
+        return C.c_void_p(self.L.ref_fs_new_frame(self.h, _p(img), _p(T), C.c_float(aff_a), C.c_float(aff_b), C.c_float(exposure)))
+
+    def fs_trace_new_coarse(self, fh):
+        self.L.ref_fs_trace_new_coarse(self.h, fh)
+
+    def fs_get_immature(self, cap=100000):
+        out = np.zeros(cap, synth.IMMATURE_DTYPE)
+        n = self.L.ref_fs_get_immature(self.h, _p(out), C.c_int(cap))
+        return out[:n].copy()
+
     def get_pair_rt(self):
         out = np.zeros((self.num_frames() ** 2, 14), np.float32)
         self.L.ref_get_pair_rt(self.h, _p(out))
@@ -364,6 +382,14 @@ class GpuAdapter:
         finally:
             L.ref_fs_free_immature(vec)
         return dict(ok=ok, idepth=idepth, res_target=tgt, last=last)
+
+    def trace_new_coarse(self, ref_window: "RefWindow", fh):
+        """GpuBackend::traceNewCoarse(fs, fh) in place of FullSystem::traceNewCoarse -> the six status counters"""
+        ref_window.fs_attach()
+        fs = C.c_void_p(ref_window.L.ref_fs_handle(ref_window.h))
+        counts = np.zeros(6, np.int32)
+        self._chk(self.A.adp_trace_new_coarse(self.h, fs, fh, _p(counts)))
+        return counts
 
     def track_new_coarse(self, ref_tracker: "RefTracker", sprelast, slast, lastF, aff_last, last_rmse, retrack_threshold=1.5, poses_valid=True):
         """GpuBackend::makeK + setCoarseTrackingRef + trackNewCoarse in place of FullSystem::trackNewCoarse"""

@@ -644,6 +644,62 @@ void ref_fs_activate_points(void *h, int n, const ldso_immature_t *pts, int min_
     }
 }
 
+// ---- FullSystem::traceNewCoarse (FullSystem.cc:1012-1050), the member itself ---------------------------------------------------------------
+// ref_fs_add_immature hangs immature points (Feature::IMMATURE + ImmaturePoint) on the window's key frames, ref_fs_new_frame builds the frame to
+// trace into (level-0 image, pose through setEvalPT_scaled as makeKeyFrame / makeNonKeyFrame do, :596 / :430), ref_fs_trace_new_coarse calls
+// the member, ref_fs_get_immature reads the records back in traversal order (frames, then their features).
+void ref_fs_add_immature(void *h, int n, const ldso_immature_t *pts) {
+    FsCall c(h);
+    for (int i = 0; i < n; i++) {
+        shared_ptr<ImmaturePoint> ip = make_immature(c.W, c.fs, pts[i]);
+        ip->lastTraceUV = Vec2f(pts[i].lastTraceUV[0], pts[i].lastTraceUV[1]); ip->lastTracePixelInterval = pts[i].lastTracePixelInterval;
+        ip->feature->status = Feature::FeatureStatus::IMMATURE;
+        c.fs->frames[pts[i].host]->features.push_back(ip->feature);
+    }
+}
+static std::vector<shared_ptr<Frame>> g_newFrames;          // frames handed out by ref_fs_new_frame (kept alive for the adapter's borrowed pointers)
+static std::vector<std::vector<float>> g_newFrameImages;
+void *ref_fs_new_frame(void *h, const float *dI_level0, const double *w2c, float aff_a, float aff_b, float exposure) {
+    FsCall c(h);
+    const int w = wG[0], hh = hG[0];
+    shared_ptr<Frame> fr(new Frame());
+    fr->CreateFH(fr);
+    auto fh = fr->frameHessian;
+    for (int l = 0; l < PYR_LEVELS; l++) { fh->dIp[l] = nullptr; fh->absSquaredGrad[l] = nullptr; }
+    g_newFrameImages.emplace_back(dI_level0, dI_level0 + (size_t) w * hh * 3);
+    fh->dIp[0] = (Vec3f *) g_newFrameImages.back().data(); fh->dI = fh->dIp[0];
+    fh->ab_exposure = exposure;
+    fr->setPose(se3_from34(w2c)); fr->aff_g2l = AffLight(aff_a, aff_b);
+    fh->setEvalPT_scaled(fr->getPose(), fr->aff_g2l);
+    g_newFrames.push_back(fr);
+    return &g_newFrames.back()->frameHessian;               // shared_ptr<FrameHessian> *
+}
+void ref_fs_release_new_frames() {
+    for (auto &fr : g_newFrames) if (fr->frameHessian) for (int l = 0; l < PYR_LEVELS; l++) { fr->frameHessian->dIp[l] = nullptr; fr->frameHessian->absSquaredGrad[l] = nullptr; }
+    g_newFrames.clear(); g_newFrameImages.clear();
+}
+void ref_fs_trace_new_coarse(void *h, void *fh_shared_ptr) { FsCall c(h); c.fs->traceNewCoarse(*(shared_ptr<FrameHessian> *) fh_shared_ptr); }
+int ref_fs_get_immature(void *h, ldso_immature_t *out, int cap) {
+    FsCall c(h);
+    int n = 0;
+    for (size_t f = 0; f < c.fs->frames.size(); f++)
+        for (auto &feat : c.fs->frames[f]->features) {
+            if (!(feat->status == Feature::FeatureStatus::IMMATURE && feat->ip)) continue;
+            if (n < cap) {
+                ldso_immature_t &q = out[n]; ImmaturePoint &ip = *feat->ip;
+                memset(&q, 0, sizeof(q));
+                q.u = feat->uv[0]; q.v = feat->uv[1];
+                memcpy(q.color, ip.color, sizeof(q.color)); memcpy(q.weights, ip.weights, sizeof(q.weights));
+                q.gradH[0] = ip.gradH(0, 0); q.gradH[1] = ip.gradH(0, 1); q.gradH[2] = ip.gradH(1, 0); q.gradH[3] = ip.gradH(1, 1);
+                q.energyTH = ip.energyTH; q.idepth_min = ip.idepth_min; q.idepth_max = ip.idepth_max; q.quality = ip.quality;
+                q.lastTraceStatus = (int32_t) ip.lastTraceStatus; q.lastTraceUV[0] = ip.lastTraceUV[0]; q.lastTraceUV[1] = ip.lastTraceUV[1];
+                q.lastTracePixelInterval = ip.lastTracePixelInterval; q.host = (int32_t) f;
+            }
+            n++;
+        }
+    return n;
+}
+
 // for the compiled adapter's activation test (adapter/adapter_capi.cc): the same ImmaturePoint objects as ref_fs_activate_points builds,
 // handed over as a heap-allocated std::vector<shared_ptr<ImmaturePoint>> (ref_fs_free_immature releases them and what they created)
 void *ref_fs_build_immature(void *h, int n, const ldso_immature_t *pts, int min_obs_unused, float min_idepth_hessian, int gn_iterations) {

@@ -148,3 +148,29 @@ def test_adapter_activate_points_equals_reference_optimize_immature_point():
     # lastResiduals[0] / [1]: IN where the newest / second-newest frame is such a target (FullSystem.cc:1000-1006)
     assert np.array_equal(out["last"][ok, 0] == 0, in_ref[ok, F - 1]) and np.array_equal(out["last"][ok, 1] == 0, in_ref[ok, F - 2])
     A.close()
+
+
+def test_adapter_trace_new_coarse_equals_reference_member():
+    """GpuBackend::traceNewCoarse (one ldso_trace_on call over every immature point of the window's key frames, per-host KRKi / Kt / affine
+    transfer formed by the reference's own expressions) against void FullSystem::traceNewCoarse(fh) itself (FullSystem.cc:1012-1050) on a second
+    copy of the same objects: the records ImmaturePoint::traceOn leaves behind byte for byte, twice in a row (the second round starts from
+    the intervals of the first)."""
+    win = synth.make_config("small", extra_frames=2)
+    pts, _ = synth.make_immature_points(win, 60)
+    r_ref, r_adp = pr.RefWindow(win), pr.RefWindow(win)
+    A = pr.GpuAdapter(max_frames=win.F + 1, max_points=win.P + 16)
+    for r in (r_ref, r_adp):
+        r.fs_attach(); r.fs_add_immature(pts)
+    assert r_ref.fs_get_immature().tobytes() == r_adp.fs_get_immature().tobytes()
+    for fidx in (win.F, win.F + 1):
+        T = win.truth["w2c"][fidx]; a, b = float(win.truth["aff_a"][fidx]), float(win.truth["aff_b"][fidx])
+        r_ref.fs_trace_new_coarse(r_ref.fs_new_frame(win.images[fidx][0], T, a, b))
+        counts = A.trace_new_coarse(r_adp, r_adp.fs_new_frame(win.images[fidx][0], T, a, b))
+        ra, rb = r_ref.fs_get_immature(), r_adp.fs_get_immature()
+        assert len(ra) == len(rb) == len(pts)
+        for k in ("idepth_min", "idepth_max", "quality", "lastTraceStatus", "lastTraceUV", "lastTracePixelInterval"):
+            assert ra[k].tobytes() == rb[k].tobytes(), (fidx, k, int((ra[k] != rb[k]).sum()))
+        st = ra["lastTraceStatus"]
+        assert counts[0] == (st == 0).sum() > len(pts) // 3 and counts.sum() == len(pts)
+    A.close()
+    r_ref.L.ref_fs_release_new_frames()
