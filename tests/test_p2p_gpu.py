@@ -81,6 +81,27 @@ def test_single_rank_degenerates_to_the_single_gpu_iteration(small):
     g.p2p_window_close(w)
 
 
+def test_exchange_buffer_survives_growing_activation_batches(small):
+    """the per-key-frame sequence of a sharded host: exchange iteration, point activation with a batch larger than any before (the handle
+    grows its activation buffers), exchange iteration again.  The exchange buffer is sized from maxFrames / maxPoints once and must be
+    untouched by the growth (round-2 review: a stray free in the growth branch left it dangling)."""
+    win = synth.add_synthetic_prior(copy.deepcopy(small))
+    twin = binding.BA.from_window(win); twin.collect_active(); twin.linearize_all(False); twin.apply_res()
+    wt = twin.p2p_window_alloc(1)
+    twin.enqueue_gn_p2p(0, 1, [wt], 0, 2); twin.enqueue_gn_p2p(0, 1, [wt], 2, 2); twin.sync(); twin.p2p_check()
+    g = binding.BA.from_window(win); g.collect_active(); g.linearize_all(False); g.apply_res()
+    w = g.p2p_window_alloc(1)
+    g.enqueue_gn_p2p(0, 1, [w], 0, 2); g.sync()
+    pts, _ = synth.make_immature_points(win, 40)
+    for n in (16, 64, len(pts)):                       # every call larger than the capacity the previous one left
+        out = g.activate_points(pts[:n])
+        assert len(out) == n
+    g.enqueue_gn_p2p(0, 1, [w], 2, 2); g.sync(); g.p2p_check()
+    assert np.array_equal(g.get_frames()["frames"]["state"], twin.get_frames()["frames"]["state"])
+    assert np.array_equal(g.get_points()["idepth"], twin.get_points()["idepth"])
+    g.p2p_window_close(w); twin.p2p_window_close(wt)
+
+
 def test_missing_peer_is_reported_not_hung(small):
     """rank 0 of a two-rank exchange whose peer never pushes: the bounded poll ends the kernel, ldso_ba_p2p_check reports it."""
     win = copy.deepcopy(small)
