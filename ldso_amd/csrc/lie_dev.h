@@ -10,6 +10,10 @@
 #define LD_HD inline
 #endif
 
+#ifndef LD_EXP_SERIES_TH2
+#define LD_EXP_SERIES_TH2 0.25      // se3_exp: |omega|^2 below which the coefficient series replace the closed forms (0: always the closed forms)
+#endif
+
 namespace ld {
 
 LD_HD void mat3_mul(const double *A, const double *B, double *C) {   // C = A*B (3x3 row-major)
@@ -27,15 +31,21 @@ LD_HD void hat3(const double *w, double *W) {
 LD_HD void se3_exp(const double *xi, double *T) {
     const double *ups = xi, *om = xi + 3;
     double th2 = om[0] * om[0] + om[1] * om[1] + om[2] * om[2];
-    double th = sqrt(th2);
     double W[9], W2[9];
     hat3(om, W);
     mat3_mul(W, W, W2);
     double a, b, c;   // R = I + a W + b W^2 ; V = I + b W + c W^2
-    if (th < 1e-10) {
-        a = 1.0 - th2 / 6.0; b = 0.5 - th2 / 24.0; c = 1.0 / 6.0 - th2 / 120.0;
+    if (th2 < LD_EXP_SERIES_TH2) {
+        // a = sin(th)/th, b = (1 - cos th)/th^2, c = (th - sin th)/th^3 are power series in th^2: for |th| < 0.5 nine terms reach 1e-19, with
+        // no square root, no division, no trigonometric call (every one of them a dependent chain of 30..140 ns on one lane of the control
+        // step / the tracker's leader, which call this on their critical path) and without the cancellation of the closed forms at small th
+        const double x = th2;
+        a = 1.0 + x * (-1.0 / 6 + x * (1.0 / 120 + x * (-1.0 / 5040 + x * (1.0 / 362880 + x * (-1.0 / 39916800 + x * (1.0 / 6227020800.0 + x * (-1.0 / 1307674368000.0 + x * (1.0 / 355687428096000.0))))))));
+        b = 0.5 + x * (-1.0 / 24 + x * (1.0 / 720 + x * (-1.0 / 40320 + x * (1.0 / 3628800 + x * (-1.0 / 479001600 + x * (1.0 / 87178291200.0 + x * (-1.0 / 20922789888000.0 + x * (1.0 / 6402373705728000.0))))))));
+        c = 1.0 / 6 + x * (-1.0 / 120 + x * (1.0 / 5040 + x * (-1.0 / 362880 + x * (1.0 / 39916800 + x * (-1.0 / 6227020800.0 + x * (1.0 / 1307674368000.0 + x * (-1.0 / 355687428096000.0 + x * (1.0 / 121645100408832000.0))))))));
     } else {
-        a = sin(th) / th; b = (1.0 - cos(th)) / th2; c = (th - sin(th)) / (th2 * th);
+        const double th = sqrt(th2), sn = sin(th), cs = cos(th);
+        a = sn / th; b = (1.0 - cs) / th2; c = (th - sn) / (th2 * th);
     }
     double V[9];
     for (int i = 0; i < 9; i++) {

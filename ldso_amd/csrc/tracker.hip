@@ -484,12 +484,12 @@ template <int CTRL> __device__ __forceinline__ double tr_dpp64(double v) {
 //   - the back substitution's L entries are fetched in one batch before its dependent chain, the permutation is undone by the
 //     indexed store of the result.
 // Must be called by all 64 lanes of a wave; x (8 entries) is written by lanes 0..7.
-__device__ void ldlt8_wave(const double *H /*LDS 64, row major*/, const double *rhs /*LDS 8*/, double diagScale, double *x /*LDS 8*/) {
+__device__ void ldlt8_wave(const double *H /*LDS 64, row major*/, const double *rhs /*LDS 8*/, double rhsSign, double diagScale, double *x /*LDS 8*/) {
     const int lane = threadIdx.x & 63, i = lane >> 3, j = lane & 7;
     double a = H[lane];
     if (i == j) a *= diagScale;
     double dg = H[j * 9] * diagScale;         // the same product as lane (j,j)'s a: the two stay bit-identical
-    double y = rhs[j];
+    double y = rhsSign * rhs[j];
     int pidx = j;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
@@ -740,10 +740,9 @@ __global__ __launch_bounds__(TR_NT) void k_tr_track(const TrParams *__restrict__
 #if LD_STAMP_ON_TR
             tQ = wall_clock64();
 #endif
-            if (tid < 8) sNb[tid] = -sB[tid];
-            __syncthreads();
-            if (tid < 64) ldlt8_wave(sH, sNb, (double) (1 + sLambda), sInc);
-            __syncthreads();
+            // wave 0 alone: the solve (right-hand side -b), then its lane 0 takes the step from the increment the wave has just stored -
+            // LDS operations of one wavefront execute in order, so neither hand-over needs a workgroup barrier
+            if (tid < 64) ldlt8_wave(sH, sB, -1.0, (double) (1 + sLambda), sInc);
 #if LD_STAMP_ON_TR
             tS1 += wall_clock64() - tQ; tQ = wall_clock64();
 #endif
@@ -752,7 +751,7 @@ __global__ __launch_bounds__(TR_NT) void k_tr_track(const TrParams *__restrict__
                 const float lambda = sLambda;
                 double inc[8];
                 const bool fixA = P.affineOptModeA < 0, fixB = P.affineOptModeB < 0;
-                if (fixA || fixB) tr_solve_fixed_affine(sH, sB, sNb, lambda, fixA, fixB, sInc);
+                if (fixA || fixB) { for (int i = 0; i < 8; i++) sNb[i] = -sB[i]; tr_solve_fixed_affine(sH, sB, sNb, lambda, fixA, fixB, sInc); }
                 for (int i = 0; i < 8; i++) inc[i] = sInc[i];
                 float extrapFac = 1;
                 if (lambda < lambdaExtrapolationLimit) extrapFac = sqrtf((float) sqrt((double) (lambdaExtrapolationLimit / lambda)));
@@ -776,15 +775,13 @@ __global__ __launch_bounds__(TR_NT) void k_tr_track(const TrParams *__restrict__
             tQ = wall_clock64();
 #endif
             if (sCtl[4]) break;
+            // accept? (CoarseTracker.cc:168-170) - every thread takes the decision itself from the sums the evaluation left in LDS
+            // (the two operands of tr_vec6's entries 0 and 1), instead of one thread publishing it behind a barrier
+            const bool accept = (((double) (float) sAcc[0]) / ((double) (int) sAcc[1])) < (sResOld[0] / sResOld[1]);
+            if (accept) tr_hb(sAcc, sH, sB);
             if (tid == 0) {
-                tr_vec6(sAcc, sResNew);
-                sCtl[1] = ((sResNew[0] / sResNew[1]) < (sResOld[0] / sResOld[1])) ? 1 : 0;
-            }
-            __syncthreads();
-            if (sCtl[1]) tr_hb(sAcc, sH, sB);
-            if (tid == 0) {
-                const bool accept = sCtl[1] != 0;
                 if (accept) {
+                    tr_vec6(sAcc, sResNew);
                     for (int i = 0; i < 6; i++) sResOld[i] = sResNew[i];
                     sAff[0] = sAffNew[0]; sAff[1] = sAffNew[1];
                     for (int i = 0; i < 12; i++) sT[i] = sTnew[i];
