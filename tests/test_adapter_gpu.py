@@ -87,6 +87,52 @@ def test_adapter_optimize_with_linearized_residuals_and_a_second_call(small):
     A.close()
 
 
+def test_reference_marginalisation_runs_on_what_the_adapter_wrote_back(small):
+    """The rest of makeKeyFrame after optimize() (FullSystem.cc:568-640) stays host code in a first integration: flagPointsForRemoval (its
+    r->linearize / applyRes / fixLinearizationF need state_state, the Jacobians r->J and the efResidual fields), ef->dropPointsF,
+    ef->marginalizePointsF (HdiF / bdSumF / Hcd_accAF / JpJdF of the last linearisation) and marginalizeFrame.  Run those REFERENCE members on
+    the objects GpuBackend::optimize left behind and on the objects the reference's own optimize() left behind: same point flags, same prior
+    H_M / b_M - i.e. the adapter's write-back is complete for what the host does next."""
+    win = synth.add_synthetic_prior(copy.deepcopy(small))
+    r_ref, r_adp = pr.RefWindow(win), pr.RefWindow(win)
+    r_ref.fs_attach()
+    rv_ref, _ = r_ref.fs_optimize(4)
+    A = pr.GpuAdapter(max_frames=win.F + 1, max_points=win.P + 16)
+    rv, its, lost = A.optimize(r_adp, 4)
+    assert not lost and abs(rv - rv_ref) <= 1e-4 * rv_ref
+    for r in (r_ref, r_adp):
+        r.fs_flag_frame(0)
+        r.fs_flag_points_for_removal()
+    (_, s_ref), (_, s_adp) = r_ref.get_points(), r_adp.get_points()
+    same = (s_ref % 100) == (s_adp % 100)
+    assert same.mean() > 0.995, (~same).sum()                 # a point sitting on the inlier / outlier threshold may flip with 1e-6 differences
+    assert ((s_ref % 100) == 3).sum() > 10, "points of the flagged frame get marginalised"
+    rr, ra = r_ref.get_residuals(), r_adp.get_residuals()
+    marg = np.isin(win.residuals["point"], np.nonzero(same & (s_ref % 100 == 3))[0]) & (rr["alive"] != 0) & (ra["alive"] != 0)
+    act = marg & (rr["is_active"] != 0) & (ra["is_active"] != 0)
+    assert act.sum() > 10
+    e = np.abs(ra["res_toZeroF"][act] - rr["res_toZeroF"][act]).max(axis=1) / np.maximum(np.abs(rr["res_toZeroF"][act]).max(axis=1), 1.0)
+    # residuals re-evaluated by the HOST at states that agree to ~2e-4 (see _compare_written_back): image gradients amplify that to ~1e-3 of a residual
+    assert np.median(e) < 1e-3 and np.percentile(e, 99) < 5e-2
+    for r in (r_ref, r_adp):
+        r.drop_points(); r.marginalize_points()
+    (HMr, bMr), (HMa, bMa) = r_ref.get_prior(), r_adp.get_prior()
+    # sums over ~100 marginalised points whose states agree to 1e-4 (and up to a handful of points flagged differently)
+    assert _rel(HMa, HMr) < 2e-2 and _rel(bMa, bMr) < 2e-2
+    assert _rel(np.diag(HMa), np.diag(HMr)) < 2e-2
+    for r in (r_ref, r_adp):
+        r.fs_marginalize_frame(0)
+    (HMr, bMr), (HMa, bMa) = r_ref.get_prior(), r_adp.get_prior()
+    assert HMa.shape == HMr.shape == (8 * (win.F - 1) + 4,) * 2
+    assert _rel(HMa, HMr) < 2e-2 and _rel(bMa, bMr) < 2e-2
+    assert r_adp.num_frames() == r_ref.num_frames() == win.F - 1
+    # ... and the next optimize() through the adapter on the shrunken window (image slots re-keyed by Frame::id, prior re-uploaded) against the reference's
+    rv_ref, _ = r_ref.fs_optimize(2)
+    rv, its, lost = A.optimize(r_adp, 2)
+    assert not lost and abs(rv - rv_ref) <= 2e-3 * rv_ref
+    A.close()
+
+
 @pytest.mark.parametrize("lost", [False, True])
 def test_adapter_track_new_coarse_equals_reference(lost):
     from tracker_common import tracker_scenario
