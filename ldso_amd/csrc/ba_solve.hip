@@ -1083,7 +1083,13 @@ __global__ __launch_bounds__(NT) void k_reduce_solve(BaPtrs B, BaDims D, ResSet 
 // Batched windows: k_reduce and the control step of nWin independent windows, one launch each (the fused k_reduce_solve needs
 // every workgroup of a window resident at once - with many windows per launch a kernel boundary orders the two instead).
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NT) void k_reduce_batch(const BatchItem *__restrict__ items, int nWin, int cur, float calibPrior, double l1, double il) {
+#ifndef LD_REDB_BLOCKS
+// workgroups of k_reduce_batch per CU the register allocation leaves room for.  The 4160 workgroups of a B = 32 batch are latency-bound (each
+// lives ~10 us whatever the load), so residency is throughput: measured at B = 32, 3 per CU (132 VGPRs, the unconstrained allocation) and 4 (126)
+// 101.4 k window-iterations/s, 5 (96 VGPRs, 30 spilled) 104.8 k, 6 (80 VGPRs, 48 spilled) 83.0 k
+#define LD_REDB_BLOCKS 5
+#endif
+__global__ __launch_bounds__(NT, LD_REDB_BLOCKS) void k_reduce_batch(const BatchItem *__restrict__ items, int nWin, int cur, float calibPrior, double l1, double il) {
     int w = 0;
     for (int i = 1; i < nWin; i++) if ((int) blockIdx.x >= items[i].redBlock0) w = i;
     const BatchItem &it = items[w];
