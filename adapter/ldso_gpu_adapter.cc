@@ -416,6 +416,7 @@ void GpuBackend::traceNewCoarse(FullSystem &fs, shared_ptr<FrameHessian> fh) {
 // CoarseTracker
 // ------------------------------------------------------------------------------------------------------------------------------------
 ldso_tracker_t *GpuBackend::trackerOf(CoarseTracker &tr) {
+    std::lock_guard<std::mutex> lk(handlesMutex_);
     auto it = trackers_.find(&tr);
     if (it != trackers_.end()) return it->second;
     ldso_tracker_t *t = nullptr;
@@ -427,6 +428,7 @@ ldso_tracker_t *GpuBackend::trackerOf(CoarseTracker &tr) {
 // true when handle t already holds this frame's pyramid as its new frame; otherwise records that it is about to
 bool GpuBackend::newFrameResident(ldso_tracker_t *t, const shared_ptr<FrameHessian> &fh) {
     const unsigned long id = fh->frame ? fh->frame->id : ~0ul;
+    std::lock_guard<std::mutex> lk(handlesMutex_);
     auto it = trackerNewFrameId_.find(t);
     if (it != trackerNewFrameId_.end() && it->second == id && id != ~0ul) return true;
     trackerNewFrameId_[t] = id;

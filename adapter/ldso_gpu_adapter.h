@@ -19,6 +19,7 @@
 #pragma once
 #include <map>
 #include <memory>
+#include <mutex>
 #include <vector>
 
 #include "frontend/CoarseTracker.h"
@@ -71,6 +72,9 @@ private:
     // whose pyramid a tracker handle currently holds as "new frame": keyed by Frame::id, not by address (LDSO releases the FrameHessian of a
     // non-key frame after tracking, the allocator may hand the same address to the next frame)
     std::map<ldso_tracker_t *, unsigned long> trackerNewFrameId_;
+    // trackerOf / newFrameResident run on the tracking thread (coarseTracker) AND on the mapping thread (coarseTracker_forNewKF under
+    // coarseTrackerSwapMutex, FullSystem.cc makeKeyFrame): the two maps above are shared between them
+    std::mutex handlesMutex_;
     bool newFrameResident(ldso_tracker_t *t, const shared_ptr<FrameHessian> &fh);
     ldso_tracker_t *trackerOf(CoarseTracker &tr);
     int uploadWindow(FullSystem &fs, std::vector<shared_ptr<PointHessian>> &allPoints, std::vector<shared_ptr<PointFrameResidual>> &flat);

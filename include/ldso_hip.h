@@ -208,7 +208,11 @@ int ldso_ba_enqueue_gn_rccl(ldso_ba_t *h, void *nccl_comm, int first_iteration, 
  * its hipIpcMemHandle_t (64 bytes) for a peer PROCESS, which maps it with ldso_ba_p2p_window_open; ranks inside one process (or with peer
  * access enabled) pass the pointers themselves.  windows[q] = rank q's window as this process addresses it, windows[rank] = the own one.
  * Every rank calls ldso_ba_enqueue_gn_p2p with the same (first_iteration, iters).  ldso_ba_p2p_check (after ldso_ba_sync): LDSO_E_HIP when
- * a peer's words did not arrive within the kernel's 2 s poll limit. */
+ * a peer's words did not arrive within the kernel's 2 s poll limit.
+ * The exchange number lives in the HANDLE (1, 2, 3 ... over all ldso_ba_enqueue_gn_p2p calls of its lifetime) and must advance in lock-step
+ * on all ranks: the handles and windows of the n_ranks ranks form ONE generation.  When any rank re-creates its handle, every rank re-creates
+ * its handle and re-allocates its window (alloc zeroes it) - words of an older generation carrying the same number would otherwise be taken
+ * for the new partial, numbers that never meet end in the 2 s timeout. */
 size_t ldso_ba_p2p_window_bytes(ldso_ba_t *h, int n_ranks);
 int ldso_ba_p2p_window_alloc(ldso_ba_t *h, int n_ranks, void **window_out, void *ipc_handle_out_64_bytes);
 int ldso_ba_p2p_window_open(ldso_ba_t *h, const void *ipc_handle_64_bytes, void **window_out);
