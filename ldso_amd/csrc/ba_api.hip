@@ -1158,6 +1158,8 @@ int ldso_ba_batch_create(ldso_ba_t *const *handles, int n, ldso_ba_batch_t **out
         REQ(H->D.pBegin == 0 && H->D.pEnd == H->D.P, "ldso_ba_batch_create: sharded handles cannot be batched");
         REQ(H->settings.forceAcceptStep && !H->pendingApply, "ldso_ba_batch_create: forced-accept schedule, no pending linearisation");
         REQ(memcmp(&H->settings, &H0->settings, sizeof(H0->settings)) == 0, "ldso_ba_batch_create: the batched kernels run with ONE ldso_settings_t: every handle of a batch must have been created with identical settings");
+        // re-chunking re-forms a window's partial sums into its OTHER ping-pong set: the windows stay at one parity only if all of them are re-cut or none
+        REQ(H->chunkPoints == H0->chunkPoints, "ldso_ba_batch_create: the handles of a batch share one chunking policy (ldso_ba_set_chunk_points: all automatic or all the same value)");
     }
     CHK(hipSetDevice(H0->device));
     // Chunking of a batch: the launch is filled by all windows together, so a workgroup takes several points per wavefront (its fixed
@@ -1178,7 +1180,7 @@ int ldso_ba_batch_create(ldso_ba_t *const *handles, int n, ldso_ba_batch_t **out
             handles[i]->chunkPoints = CH;
             const int r_ = rechunk(handles[i]);
             handles[i]->chunkPoints = 0;                                         // the policy stays "automatic": the next ldso_ba_set_window re-chunks for a single window
-            if (r_ != LDSO_OK) return r_;
+            if (r_ != LDSO_OK) { for (int k = 0; k <= i; k++) rechunk(handles[k]); return r_; }      // leave nobody with the batch's chunks
         }
     }
     ldso_ba_batch *Bt = new ldso_ba_batch();
