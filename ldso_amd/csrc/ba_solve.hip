@@ -1083,17 +1083,29 @@ __global__ __launch_bounds__(NT) void k_reduce_solve(BaPtrs B, BaDims D, ResSet 
 // Batched windows: k_reduce and the control step of nWin independent windows, one launch each (the fused k_reduce_solve needs
 // every workgroup of a window resident at once - with many windows per launch a kernel boundary orders the two instead).
 // ---------------------------------------------------------------------------------------------------------
+// Two register allocations of the same kernel.  Its workgroups are latency-bound (each lives ~10 us whatever the load), so for a launch
+// that queues many of them per CU residency is throughput, while a launch that fits the chip in one go only sees the spill code.  Measured,
+// B = 32 (2080 workgroups per half-batch launch, 8 per CU): 3 per CU (132 VGPRs, the unconstrained allocation) and 4 (126) 101.4 k
+// window-iterations/s, 5 (96 VGPRs, 30 spilled; also fits beside the two resident k_linearize_batch wavefronts of a SIMD, 2 x 205 + 96 <= 512, so
+// the reduce of one half-batch overlaps the linearisation of the other) 104.8 k, 6 (80 VGPRs, 48 spilled) 83.0 k; B = 8 (520 workgroups per
+// launch, 2 per CU): 82 k unconstrained, 75.7 k with the 96-register allocation (different boxes, same day).
 #ifndef LD_REDB_BLOCKS
-// workgroups of k_reduce_batch per CU the register allocation leaves room for.  The 4160 workgroups of a B = 32 batch are latency-bound (each
-// lives ~10 us whatever the load), so residency is throughput: measured at B = 32, 3 per CU (132 VGPRs, the unconstrained allocation) and 4 (126)
-// 101.4 k window-iterations/s, 5 (96 VGPRs, 30 spilled) 104.8 k, 6 (80 VGPRs, 48 spilled) 83.0 k
-#define LD_REDB_BLOCKS 5
+#define LD_REDB_BLOCKS 5             // the dense variant: workgroups per CU its register allocation leaves room for
 #endif
-__global__ __launch_bounds__(NT, LD_REDB_BLOCKS) void k_reduce_batch(const BatchItem *__restrict__ items, int nWin, int cur, float calibPrior, double l1, double il) {
+#ifndef LD_REDB_DENSE_PER_CU
+#define LD_REDB_DENSE_PER_CU 6       // launches with at least this many workgroups per CU take the dense variant
+#endif
+static __device__ __forceinline__ void reduce_batch_body(const BatchItem *__restrict__ items, int nWin, int cur, float calibPrior, double l1, double il) {
     int w = 0;
     for (int i = 1; i < nWin; i++) if ((int) blockIdx.x >= items[i].redBlock0) w = i;
     const BatchItem &it = items[w];
     reduce_body(it.B, it.D, it.set[cur], it.cs, 0, it.GSP, 1, it.hasPrior, calibPrior, l1, il, -1, (int) blockIdx.x - it.redBlock0);
+}
+__global__ __launch_bounds__(NT) void k_reduce_batch(const BatchItem *__restrict__ items, int nWin, int cur, float calibPrior, double l1, double il) {
+    reduce_batch_body(items, nWin, cur, calibPrior, l1, il);
+}
+__global__ __launch_bounds__(NT, LD_REDB_BLOCKS) void k_reduce_batch_dense(const BatchItem *__restrict__ items, int nWin, int cur, float calibPrior, double l1, double il) {
+    reduce_batch_body(items, nWin, cur, calibPrior, l1, il);
 }
 
 __global__ __launch_bounds__(NT) void k_gn_solve_batch(const BatchItem *__restrict__ items, int cur, ldso_settings_t St, int iteration, double lambda) {
@@ -1106,8 +1118,16 @@ __global__ __launch_bounds__(NT) void k_gn_solve_batch(const BatchItem *__restri
 
 hipError_t ba_launch_reduce_batch(const BatchItem *d_items, int nWin, int totalBlocks, int cur, float calibPrior, double l1, double il, hipStream_t st) {
     const size_t lds = (size_t) (2 * SCT_SLAB * 16 + SCT_SLAB) * sizeof(float);
-    if (lds > 48 * 1024) (void) hipFuncSetAttribute((const void *) k_reduce_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-    hipLaunchKernelGGL(k_reduce_batch, dim3(totalBlocks), dim3(NT), lds, st, d_items, nWin, cur, calibPrior, l1, il);
+    static int numCU[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (numCU[dev] == 0) { int cu = 0; if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0) cu = 256; numCU[dev] = cu; }
+    if (lds > 48 * 1024) {
+        (void) hipFuncSetAttribute((const void *) k_reduce_batch, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+        (void) hipFuncSetAttribute((const void *) k_reduce_batch_dense, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+    }
+    if (totalBlocks >= LD_REDB_DENSE_PER_CU * numCU[dev]) hipLaunchKernelGGL(k_reduce_batch_dense, dim3(totalBlocks), dim3(NT), lds, st, d_items, nWin, cur, calibPrior, l1, il);
+    else hipLaunchKernelGGL(k_reduce_batch, dim3(totalBlocks), dim3(NT), lds, st, d_items, nWin, cur, calibPrior, l1, il);
     return hipGetLastError();
 }
 
