@@ -186,6 +186,33 @@ template <> struct at_sel<false> {
 #define LD_PERM_DESC 0      // measured (A/B, two rounds each on one box): 220.3 / 51.6 / 10.07 us (B = 32 / B = 8 / C3) with ds_bpermute against 225.2 / 52.7 / 10.17 us with the
 #endif                   // permlane butterflies below - their hand-placed s_nop pairs and the opaque asm cost more than the LDS round trips they save
 #define AT(ptr, i) (at_sel<DESC || LD_GLOBAL_ARGS>::ref((ptr), (unsigned) (i)))
+// a per-point entry (index wave-uniform): scalar load when LD_SCALAR_POINT and the descriptor-based kernel, else as AT
+#define PT(ptr, i) (pt_get<DESC && (LD_SCALAR_POINT != 0), DESC>((ptr), (unsigned) (i)))
+
+// LD_SCALAR_POINT (experiment, descriptor-based kernel only): the per-POINT entries of the record (22 of its 31 loads in a GN pass) have a
+// wave-uniform address - a wavefront works on one point at a time.  Read through a constant-address-space pointer with the index in an SGPR
+// they become scalar loads (s_load_dword, scalar cache): no vector memory instruction, no VGPR address, nothing on vmcnt.  Legal because no
+// wavefront reads an entry again after anybody has written it inside one launch (a point belongs to one wavefront; what it stores -
+// pidepth, pidepth_zero, pstep, the backup - depends on what it loaded), and the scalar cache is invalidated at the launch boundary.
+#ifndef LD_SCALAR_POINT
+#define LD_SCALAR_POINT 0
+#endif
+#ifndef LD_GLOBAL_TAPS
+#define LD_GLOBAL_TAPS 0
+#endif
+template <class T> using cptr_t = const __attribute__((address_space(4))) T *;
+template <bool SC> struct pt_sel;
+template <> struct pt_sel<true> {
+    template <class T> static __device__ __forceinline__ T get(const T *p, unsigned i) { return *(cptr_t<T>) ((unsigned long long) p + (unsigned long long) (i * (unsigned) sizeof(T))); }
+};
+template <> struct pt_sel<false> {
+    template <class T> static __device__ __forceinline__ T get(const T *p, unsigned i) { return *(const T *) ((const char *) p + (size_t) (i * (unsigned) sizeof(T))); }
+};
+
+template <bool SC, bool DESC_, class T> static __device__ __forceinline__ T pt_get(const T *p, unsigned i) {
+    if constexpr (SC) return pt_sel<true>::get(p, (unsigned) __builtin_amdgcn_readfirstlane((int) i));
+    else return at_sel<DESC_ || LD_GLOBAL_ARGS>::ref(p, i);
+}
 
 template <int NSG, bool HAS_L, bool FIX, bool DESC>
 static __device__ __forceinline__ void load_point(PtIn<NSG> &q, const BaPtrs &B, const ResSet &cur, unsigned FS, unsigned p, unsigned s, unsigned k, int stepMode) {
@@ -195,9 +222,9 @@ static __device__ __forceinline__ void load_point(PtIn<NSG> &q, const BaPtrs &B,
         const float *pu = GP(const float, b0, 0), *pv = GP(const float, b0, 1), *pid = GP(const float, b0, 2), *piz = GP(const float, b0, 3), *ppr = GP(const float, b0, 4);
         const float *pco = GP(const float, b0, 5), *pwe = GP(const float, b0, 6), *pst = GP(const float, b0, 7);
         const int32_t *rflat = GP(const int32_t, b1, 4), *rlin = GP(const int32_t, b1, 5), *rnew = GP(const int32_t, b1, 6), *rlidx = GP(const int32_t, b1, 7);
-        q.pu = AT(pu, p); q.pv = AT(pv, p); q.idp = AT(pid, p); q.idz = AT(piz, p); q.priorF = AT(ppr, p);
+        q.pu = PT(pu, p); q.pv = PT(pv, p); q.idp = PT(pid, p); q.idz = PT(piz, p); q.priorF = PT(ppr, p);
         q.color = AT(pco, p * 8 + k); q.wgt = AT(pwe, p * 8 + k);
-        if (stepMode & 1) q.pstep = AT(pst, p);
+        if (stepMode & 1) q.pstep = PT(pst, p);
 #pragma unroll
         for (int g = 0; g < NSG; g++) {
             const unsigned slot = p * FS + g * 8 + s;       // slot tables are dense [P][FS]: every index is readable
@@ -211,7 +238,7 @@ static __device__ __forceinline__ void load_point(PtIn<NSG> &q, const BaPtrs &B,
         const float *energy = GP(const float, s0, 2), *jp = GP(const float, s0, 3), *center = GP(const float, s0, 4);
         const float *HdiF = GP(const float, s1, 0), *bdSumF = GP(const float, s1, 1), *idH_ = GP(const float, s1, 2), *HcdA = GP(const float, s1, 4), *HcdL = GP(const float, s1, 5), *maxRelBS = GP(const float, s1, 6);
         const int32_t *nActive = GP(const int32_t, s1, 3), *numGood = GP(const int32_t, s1, 7);
-        q.maxRelBS = AT(maxRelBS, p); q.numGood = AT(numGood, p);
+        q.maxRelBS = PT(maxRelBS, p); q.numGood = PT(numGood, p);
 #pragma unroll
         for (int g = 0; g < NSG; g++) {
             const unsigned slot = p * FS + g * 8 + s;
@@ -219,9 +246,9 @@ static __device__ __forceinline__ void load_point(PtIn<NSG> &q, const BaPtrs &B,
             q.jp[g] = AT(jp, slot * 8 + k); q.cen[g] = AT(center, slot * 3 + (k < 3 ? k : 2u));
         }
         if (stepMode & 1) {
-            q.bdSumF = AT(bdSumF, p); q.HdiF = AT(HdiF, p); q.idH = AT(idH_, p); q.nAct = AT(nActive, p);
+            q.bdSumF = PT(bdSumF, p); q.HdiF = PT(HdiF, p); q.idH = PT(idH_, p); q.nAct = PT(nActive, p);
 #pragma unroll
-            for (int i = 0; i < 4; i++) q.hcd[i] = AT(HcdA, p * 4 + i) + AT(HcdL, p * 4 + i);
+            for (int i = 0; i < 4; i++) q.hcd[i] = PT(HcdA, p * 4 + i) + PT(HcdL, p * 4 + i);
         }
     }
 }
@@ -445,10 +472,20 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
                 int ix = (int) Ku, iy = (int) Kv;
                 float dx = Ku - ix, dy = Kv - iy, dxdy = dx * dy;
                 // descriptor in memory: the pointer from LDS; kernel arguments: the table sits in scalar registers, selected per lane
-                const float *bp = (DESC ? sImg[t] : B.img[t]) + 3 * (ix + iy * W);
-                float a0 = bp[0], a1 = bp[1], a2 = bp[2], b0_ = bp[3], b1 = bp[4], b2 = bp[5];
-                const float *bq = bp + 3 * W;
-                float c0_ = bq[0], c1_ = bq[1], c2_ = bq[2], d0 = bq[3], d1 = bq[4], d2 = bq[5];
+                float a0, a1, a2, b0_, b1, b2, c0_, c1_, c2_, d0, d1, d2;
+                if constexpr (DESC && (LD_GLOBAL_TAPS != 0)) {
+                    // experiment: the image pointer is a per-lane value from LDS, i.e. generic to the compiler -> FLAT loads, which tick lgkmcnt as
+                    // well as vmcnt (every LDS wait then also waits for the taps).  Images are hipMalloc'ed: address them as global memory.
+                    const gptr_t<const float> bp = (gptr_t<const float>) (unsigned long long) sImg[t] + 3 * (ix + iy * W);
+                    a0 = bp[0]; a1 = bp[1]; a2 = bp[2]; b0_ = bp[3]; b1 = bp[4]; b2 = bp[5];
+                    const gptr_t<const float> bq = bp + 3 * W;
+                    c0_ = bq[0]; c1_ = bq[1]; c2_ = bq[2]; d0 = bq[3]; d1 = bq[4]; d2 = bq[5];
+                } else {
+                    const float *bp = (DESC ? sImg[t] : B.img[t]) + 3 * (ix + iy * W);
+                    a0 = bp[0]; a1 = bp[1]; a2 = bp[2]; b0_ = bp[3]; b1 = bp[4]; b2 = bp[5];
+                    const float *bq = bp + 3 * W;
+                    c0_ = bq[0]; c1_ = bq[1]; c2_ = bq[2]; d0 = bq[3]; d1 = bq[4]; d2 = bq[5];
+                }
                 float w11 = dxdy, w01 = dy - dxdy, w10 = dx - dxdy, w00 = 1 - dx - dy + dxdy;
                 hit0 = ((w11 * d0 + w01 * c0_) + w10 * b0_) + w00 * a0;
                 hit1 = ((w11 * d1 + w01 * c1_) + w10 * b1) + w00 * a1;
