@@ -11,10 +11,12 @@ if [ "${1:-run}" = build ]; then
   bash scripts/build_variant.sh sp ba_linearize.hip "-DLD_SCALAR_POINT=1" | tail -1
   bash scripts/build_variant.sh gt ba_linearize.hip "-DLD_GLOBAL_TAPS=1" | tail -1
   bash scripts/build_variant.sh spgt ba_linearize.hip "-DLD_SCALAR_POINT=1 -DLD_GLOBAL_TAPS=1" | tail -1
+  # with 22 loads off vmcnt the one-point-ahead record prefetch (LD_PREFETCH, no gain in round 3) may start to pay
+  bash scripts/build_variant.sh spgtpf ba_linearize.hip "-DLD_SCALAR_POINT=1 -DLD_GLOBAL_TAPS=1 -DLD_PREFETCH=1" | tail -1
   exit 0
 fi
 mkdir -p gpurun_out
-for L in base sp gt spgt base; do
+for L in base sp gt spgt spgtpf base; do
   if [ "$L" = base ]; then unset LDSO_HIP_LIB; else export LDSO_HIP_LIB=$PWD/ldso_amd/libldso_hip_$L.so; fi
   echo "== $L: C3 (value, ms per step, live k_linearize us, parity) then B = 32"
   timeout 200 python bench.py --no-cpu-baseline --no-extras --min-timed-s 0.5 2>&1 | grep '^{' | python -c "import sys,json; j=json.loads(sys.stdin.read()); print(j['value'], j['ms_per_step'], j['roofline']['avg_launch_us_live'], j['parity_vs_oracle']['ok'], j['parity_vs_oracle']['energy_log_10_iterations_max_rel'])"
