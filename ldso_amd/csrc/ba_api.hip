@@ -438,6 +438,9 @@ int ldso_ba_set_window(ldso_ba_t *H, int F, const int32_t *image_slot, int P, co
     CHK(hipSetDevice(H->device));
     BaDims &D = H->D;
     BaPtrs &B = H->B;
+    // a call that fails half way (bad indices, allocation) must not leave the dimensions of the NEW window over the data of the old one:
+    // the handle then holds no window (every entry point that needs one says so)
+    struct WinGuard { ldso_ba *H; bool ok; ~WinGuard() { if (!ok) { H->D.P = 0; H->D.R = 0; H->R = 0; H->appliedValid = false; H->itemValid = false; } } } guard{H, false};
     D.F = F; D.FS = (F + 7) / 8 * 8; D.P = P; D.R = R; D.n = 8 * F + 4; D.GS = 8 * D.FS + LD_GEXTRA; D.w = H->w; D.h = H->h; D.nsg = D.FS / 8;
     D.pBegin = 0; D.pEnd = P; D.wM3G = (float) (H->w - 3); D.hM3G = (float) (H->h - 3);
     H->GSP = (D.GS + 15) / 16 * 16;
@@ -528,7 +531,9 @@ int ldso_ba_set_window(ldso_ba_t *H, int F, const int32_t *image_slot, int P, co
     hipLaunchKernelGGL(k_win_scatter, dim3(256), dim3(256), 0, H->stream, (const char *) H->d_stage, W.n);
     CHK(hipGetLastError());
     CHK(hipStreamSynchronize(H->stream));
-    return build_chunks(H);
+    const int rc_ = build_chunks(H);
+    guard.ok = (rc_ == LDSO_OK);
+    return rc_;
 }
 
 // PointHessian::maxRelBaseline / numGoodResiduals live across optimize() calls in the reference (FullSystem.cc:1521-1536 updates them in the
