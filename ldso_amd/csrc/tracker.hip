@@ -736,6 +736,10 @@ __global__ __launch_bounds__(TR_NT) void k_tr_track(const TrParams *__restrict__
         __syncthreads();
 
         for (int iteration = 0; iteration < maxIterations[lvl]; iteration++) {
+            // the accepted energy ratio, read HERE: thread 0 overwrites sResOld in the accept block below while other wavefronts may still
+            // be deciding; the closing barrier of the previous iteration orders this read behind that write, the barrier after the step
+            // orders it in front of the next one
+            const double oldRatio = sResOld[0] / sResOld[1];
             // H (1 + lambda on the diagonal) x = -b: wave 0 solves the 8x8 system lane-parallel (CoarseTracker.cc:120-128)
 #if LD_STAMP_ON_TR
             tQ = wall_clock64();
@@ -777,7 +781,7 @@ __global__ __launch_bounds__(TR_NT) void k_tr_track(const TrParams *__restrict__
             if (sCtl[4]) break;
             // accept? (CoarseTracker.cc:168-170) - every thread takes the decision itself from the sums the evaluation left in LDS
             // (the two operands of tr_vec6's entries 0 and 1), instead of one thread publishing it behind a barrier
-            const bool accept = (((double) (float) sAcc[0]) / ((double) (int) sAcc[1])) < (sResOld[0] / sResOld[1]);
+            const bool accept = (((double) (float) sAcc[0]) / ((double) (int) sAcc[1])) < oldRatio;
             if (accept) tr_hb(sAcc, sH, sB);
             if (tid == 0) {
                 if (accept) {
