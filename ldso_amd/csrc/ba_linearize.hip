@@ -134,11 +134,11 @@ template <bool DESC, int OFFA, int OFFB> static __device__ __forceinline__ void 
 #define GP(T, t16, i) ((T *) ((((unsigned long long) (unsigned) (t16)[2 * (i) + 1]) << 32) | (unsigned long long) (unsigned) (t16)[2 * (i)]))
 #define OFF_B0 ((int) offsetof(BaPtrs, pu))
 #define OFF_B1 ((int) offsetof(BaPtrs, pidepth_backup))
-#define OFF_S0 ((int) offsetof(ResSet, state))
-#define OFF_S1 ((int) offsetof(ResSet, HdiF))
-#define OFF_S2 ((int) offsetof(ResSet, HddA))
-static_assert(offsetof(BaPtrs, pstep) == offsetof(BaPtrs, pu) + 56 && offsetof(BaPtrs, rlidx) == offsetof(BaPtrs, pidepth_backup) + 56, "BaPtrs pointer groups (ba_dev.h)");
-static_assert(offsetof(ResSet, candE) == 56 && offsetof(ResSet, numGood) == offsetof(ResSet, HdiF) + 56 && offsetof(ResSet, chunkEnergy) == offsetof(ResSet, HddA) + 56, "ResSet pointer groups (ba_dev.h)");
+#define OFF_S0 ((int) offsetof(ResSet, slot))
+static_assert(offsetof(BaPtrs, pstep) == offsetof(BaPtrs, pu) + 56 && offsetof(BaPtrs, rtz) == offsetof(BaPtrs, pidepth_backup) + 56, "BaPtrs pointer groups (ba_dev.h)");
+static_assert(offsetof(ResSet, slot) == 0 && offsetof(ResSet, chunkEnergy) == 56 && offsetof(ResSet, chunkCnt) == 64, "ResSet pointer group (ba_dev.h)");
+// indices of the ResSet pointers inside their group
+enum { RS_SLOT = 0, RS_PT = 1, RS_ACC = 2, RS_CAND = 3, RS_G = 4, RS_TOPA = 5, RS_TOPL = 6, RS_CHUNKE = 7 };
 
 // flat index of entry (r,c), r<=c, in the packed upper triangle of a 13x13 matrix
 __host__ __device__ constexpr int tri13(int r, int c) { return r * 13 - (r * (r - 1)) / 2 + (c - r); }
@@ -148,13 +148,11 @@ __host__ __device__ constexpr int tri13(int r, int c) { return r * 13 - (r * (r 
 // the LDS staging of the block, so a wave sees two dependent memory levels (this record, then the taps).
 template <int NSG>
 struct PtIn {
-    float pu, pv, idp, idz, priorF, color, wgt, maxRelBS;
-    int numGood;
-    int rflat[NSG], rlin[NSG], rnew[NSG], rlidx[NSG], state[NSG], active[NSG];
-    float energy[NSG], jp[NSG], cen[NSG];
-    // inputs of the fused point step (resubstituteFPt)
-    float pstep, bdSumF, HdiF, idH, hcd[4];
-    int nAct;
+    float pu, pv, idp, idz, priorF, color, wgt;
+    float pstep;                  // input of the fused point step (resubstituteFPt)
+    PtRec rec;                    // the point's Schur scalars of the applied set (one scalar load: scalar registers)
+    int rflat[NSG], rlin[NSG], rnew[NSG], rlidx[NSG];     // SlotTab of this lane's slot(s)
+    float jp[NSG], m[NSG];        // this lane's pair of the slot record: JpJdF[k] and scalar k (LD_SM_*; integers as raw bits)
 };
 
 // element i of a device array with the BYTE offset computed in 32 bits: base pointer (SGPR pair) + zero-extended
@@ -214,6 +212,14 @@ template <bool SC, bool DESC_, class T> static __device__ __forceinline__ T pt_g
     else return at_sel<DESC_ || LD_GLOBAL_ARGS>::ref(p, i);
 }
 
+typedef int v4i32_t __attribute__((ext_vector_type(4)));
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+
+// The record of one point as a wavefront needs it: 5 + 1 per-point scalars of the geometry arrays (scalar loads under LD_SCALAR_POINT),
+// the point's PtRec (ONE scalar load - the index is wave-uniform), this lane's colour / weight, and per slot group one dwordx4 (SlotTab,
+// the same 16 bytes for the 8 lanes of a slot) and one dwordx2 (this lane's pair of the 64-byte SlotRec): 4 + 2 NSG vector loads
+// (round 3: 9 + 9 NSG + 13).
 template <int NSG, bool HAS_L, bool FIX, bool DESC>
 static __device__ __forceinline__ void load_point(PtIn<NSG> &q, const BaPtrs &B, const ResSet &cur, unsigned FS, unsigned p, unsigned s, unsigned k, int stepMode) {
     {
@@ -221,34 +227,28 @@ static __device__ __forceinline__ void load_point(PtIn<NSG> &q, const BaPtrs &B,
         ldg16x2<DESC, OFF_B0, OFF_B1>(b0, &B, b1, &B);
         const float *pu = GP(const float, b0, 0), *pv = GP(const float, b0, 1), *pid = GP(const float, b0, 2), *piz = GP(const float, b0, 3), *ppr = GP(const float, b0, 4);
         const float *pco = GP(const float, b0, 5), *pwe = GP(const float, b0, 6), *pst = GP(const float, b0, 7);
-        const int32_t *rflat = GP(const int32_t, b1, 4), *rlin = GP(const int32_t, b1, 5), *rnew = GP(const int32_t, b1, 6), *rlidx = GP(const int32_t, b1, 7);
+        const v4i32_t *rtab = GP(const v4i32_t, b1, 4);
         q.pu = PT(pu, p); q.pv = PT(pv, p); q.idp = PT(pid, p); q.idz = PT(piz, p); q.priorF = PT(ppr, p);
         q.color = AT(pco, p * 8 + k); q.wgt = AT(pwe, p * 8 + k);
-        if (stepMode & 1) q.pstep = PT(pst, p);
+        q.pstep = (stepMode & 1) ? PT(pst, p) : 0.0f;
 #pragma unroll
         for (int g = 0; g < NSG; g++) {
             const unsigned slot = p * FS + g * 8 + s;       // slot tables are dense [P][FS]: every index is readable
-            q.rflat[g] = AT(rflat, slot); q.rlin[g] = AT(rlin, slot); q.rnew[g] = FIX ? AT(rnew, slot) : 0; q.rlidx[g] = HAS_L ? AT(rlidx, slot) : 0;
+            const v4i32_t t4 = AT(rtab, slot);
+            q.rflat[g] = t4.x; q.rlin[g] = t4.y; q.rnew[g] = FIX ? t4.z : 0; q.rlidx[g] = HAS_L ? t4.w : 0;
         }
     }
     {
-        v16i_t s0, s1;
-        ldg16x2<DESC, OFF_S0, OFF_S1>(s0, &cur, s1, &cur);
-        const int32_t *state = GP(const int32_t, s0, 0), *active = GP(const int32_t, s0, 1);
-        const float *energy = GP(const float, s0, 2), *jp = GP(const float, s0, 3), *center = GP(const float, s0, 4);
-        const float *HdiF = GP(const float, s1, 0), *bdSumF = GP(const float, s1, 1), *idH_ = GP(const float, s1, 2), *HcdA = GP(const float, s1, 4), *HcdL = GP(const float, s1, 5), *maxRelBS = GP(const float, s1, 6);
-        const int32_t *nActive = GP(const int32_t, s1, 3), *numGood = GP(const int32_t, s1, 7);
-        q.maxRelBS = PT(maxRelBS, p); q.numGood = PT(numGood, p);
+        const v16i_t s0 = ldg16<DESC, OFF_S0>(&cur);
+        const v2f_t *slots = GP(const v2f_t, s0, RS_SLOT);
+        const PtRec *pts = GP(const PtRec, s0, RS_PT);
+        // wave-uniform 64-byte record: through the constant address space with the index in a scalar register -> s_load_dwordx16 (see PT())
+        q.rec = __builtin_bit_cast(PtRec, *(cptr_t<v16i_t>) ((unsigned long long) pts + (unsigned long long) ((unsigned) __builtin_amdgcn_readfirstlane((int) p) * (unsigned) sizeof(PtRec))));
 #pragma unroll
         for (int g = 0; g < NSG; g++) {
             const unsigned slot = p * FS + g * 8 + s;
-            q.state[g] = AT(state, slot); q.active[g] = AT(active, slot); q.energy[g] = AT(energy, slot);
-            q.jp[g] = AT(jp, slot * 8 + k); q.cen[g] = AT(center, slot * 3 + (k < 3 ? k : 2u));
-        }
-        if (stepMode & 1) {
-            q.bdSumF = PT(bdSumF, p); q.HdiF = PT(HdiF, p); q.idH = PT(idH_, p); q.nAct = PT(nActive, p);
-#pragma unroll
-            for (int i = 0; i < 4; i++) q.hcd[i] = PT(HcdA, p * 4 + i) + PT(HcdL, p * 4 + i);
+            const v2f_t e = AT(slots, slot * 8 + k);
+            q.jp[g] = e.x; q.m[g] = e.y;
         }
     }
 }
@@ -377,6 +377,16 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
         if (pi != wave) load_point<NSG, HAS_L, FIX, DESC>(nx, B, cur, FS, p, s, k, stepMode);       // the first record was loaded before the staging
         const PtIn<NSG> &q = nx;
 #endif
+        // the uniform scalars of each slot record sit in the m of lanes 3 (energy), 5 (state), 6 (activity) of its 8-lane group
+        int qState[NSG], qActive[NSG];
+        float qEnergy[NSG];
+#pragma unroll
+        for (int g = 0; g < NSG; g++) {
+            float l1, h1, l2, h2, l3, h3;
+            group_bcast_pair<1>(q.m[g], k, l1, h1); group_bcast_pair<2>(q.m[g], k, l2, h2); group_bcast_pair<3>(q.m[g], k, l3, h3);
+            qState[g] = __builtin_bit_cast(int, h1); qActive[g] = __builtin_bit_cast(int, h2); qEnergy[g] = l3;
+            (void) l1; (void) l2; (void) h3;
+        }
         const float pu = q.pu, pv = q.pv, priorF = MARG ? q.priorF * S.idepthFixPriorMargFac : q.priorF;
         const bool flagged = MARG ? (margFlags[p] != 0) : true;
         const float color = q.color, wgt = q.wgt;
@@ -384,20 +394,20 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
         if (stepMode & 1) {
             // ---- resubstituteFPt for this point, then backupState + doStepFromBackup (stepfacD = 1) ------------
             float step = 0.0f;
-            if (q.nAct > 0) {
-                float b = q.bdSumF;
+            if (q.rec.nActive > 0) {
+                float b = q.rec.bdSumF;
                 float dot = 0;
-                dot += xc0 * q.hcd[0]; dot += xc1 * q.hcd[1]; dot += xc2 * q.hcd[2]; dot += xc3 * q.hcd[3];
+                dot += xc0 * (q.rec.HcdA[0] + q.rec.HcdL[0]); dot += xc1 * (q.rec.HcdA[1] + q.rec.HcdL[1]); dot += xc2 * (q.rec.HcdA[2] + q.rec.HcdL[2]); dot += xc3 * (q.rec.HcdA[3] + q.rec.HcdL[3]);
                 b -= dot;
 #pragma unroll
                 for (int g = 0; g < NSG; g++) {
                     const int t = g * 8 + s;
-                    const bool act = (t < F) && (q.rflat[g] >= 0) && (q.active[g] != 0);
+                    const bool act = (t < F) && (q.rflat[g] >= 0) && (qActive[g] != 0);
                     float sres = seq8(sXa[t * 8 + k] * q.jp[g], k, lane);
                     sres = act ? sres : 0.0f;
                     b -= sum_slots<DESC ? (LD_PERM_DESC != 0) : (LD_PERM_ARGS != 0)>(sres, a16, a32);
                 }
-                if (isfinite(b)) step = -b * q.HdiF; else { step = q.pstep; if (lane == 0) B.scalars[4] = 1.0; }
+                if (isfinite(b)) step = -b * q.rec.HdiF; else { step = q.pstep; if (lane == 0) B.scalars[4] = 1.0; }
             }
             const float ni = idp + 1.0f * step;
             {
@@ -407,7 +417,7 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
                 float *w_lH = GP(float, b1, 1), *w_lB = GP(float, b1, 2), *w_lI = GP(float, b1, 3);
                 if (lane == 0) { AT(w_pstep, p) = step; AT(w_pbk, p) = idp; AT(w_pid, p) = ni; AT(w_piz, p) = ni; }
                 // PointHessian::{HdiF, bdSumF, idepth_hessian} as the solve that produced this step left them (lanes 1..3: fire-and-forget stores)
-                if (lane == 1) AT(w_lH, p) = q.HdiF; else if (lane == 2) AT(w_lB, p) = q.bdSumF; else if (lane == 3) AT(w_lI, p) = q.idH;
+                if (lane == 1) AT(w_lH, p) = q.rec.HdiF; else if (lane == 2) AT(w_lB, p) = q.rec.bdSumF; else if (lane == 3) AT(w_lI, p) = q.rec.idH;
             }
             idp = ni; idz = ni;
         }
@@ -416,10 +426,10 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
         float HddL = 0, bdL = 0, HcdL0 = 0, HcdL1 = 0, HcdL2 = 0, HcdL3 = 0;
         float hostPart = 0.0f;       // this lane's partial of the host block of g_p (component k)
         // AccumulatedSCHessian.cc:14-21: the SOLVE that finds a point without an active residual zeroes its maxRelBaseline - i.e. the solve whose
-        // point step is fused in front of this pass (q.nAct = active residuals of the linearisation that solve used).  A pass that is followed
+        // point step is fused in front of this pass (q.rec.nActive = active residuals of the linearisation that solve used).  A pass that is followed
         // by no solve (the last linearizeAll(false) of optimize(), the fixing pass) zeroes nothing.
-        float maxRelBS = ((stepMode & 1) && q.nAct <= 0) ? 0.0f : q.maxRelBS;
-        int numGood = q.numGood;
+        float maxRelBS = ((stepMode & 1) && q.rec.nActive <= 0) ? 0.0f : q.rec.maxRelBS;
+        int numGood = q.rec.numGood;
         int nActive = 0;
         float gT[NSG];
 
@@ -431,13 +441,13 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
             const bool isLin = MARG ? false : (exists && (q.rlin[g] != 0));
             // resetOOB (Residuals.h): MARG always; stepMode bit 1 = the optimize() preamble on every non-linearised residual (FullSystem.cc:744-748)
             const bool reset = MARG || ((stepMode & 2) && !isLin);
-            const int st = exists ? (reset ? RES_IN : q.state[g]) : RES_OOB;
+            const int st = exists ? (reset ? RES_IN : qState[g]) : RES_OOB;
             const DevPair &pr = sPair[t];
 
             int newState = st;
-            float newEnergy = (exists && !reset) ? q.energy[g] : 0.0f;
+            float newEnergy = (exists && !reset) ? qEnergy[g] : 0.0f;
             float newEnergyWO = -1.0f;
-            int activeNew = exists ? q.active[g] : 0;
+            int activeNew = exists ? qActive[g] : 0;
             float jp = exists ? q.jp[g] : 0.0f;     // this lane's component k of JpJdF
             float c0 = 0, c1 = 0, c2 = 0;
             int toRemove = 0;
@@ -556,7 +566,7 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
                 c0 = cKu; c1 = cKv; c2 = new_idepth;
                 // stepMode bit 2 (re-chunking, ba_api.hip rechunk()): the applied state is linearised again only to re-form the per-chunk
                 // partial sums - the decisions of the pass that produced it stand (its energy thresholds have moved on since)
-                if (stepMode & 4) { newState = st; newEnergy = q.energy[g]; ret = (double) newEnergy; }
+                if (stepMode & 4) { newState = st; newEnergy = qEnergy[g]; ret = (double) newEnergy; }
             }
 
             // ================= applyRes(true) (Residuals.h:70-87) ======================================
@@ -715,22 +725,21 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
             if (FIX) numGood += __popcll(newGoodMask);
             if (FIX) { float m = maxRelBS; m = fmaxf(m, __shfl_xor(m, 8, 64)); m = fmaxf(m, __shfl_xor(m, 16, 64)); m = fmaxf(m, __shfl_xor(m, 32, 64)); maxRelBS = m; }
 
-            // ---- per-slot outputs (slot leader) ----------------------------------------------------------
+            // ---- per-slot outputs: the slot's SlotRec of the next set, lane k stores its own pair (one dwordx2 store per lane) ------------
             if (t < F) {
                 const v16i_t o0 = ldg16<DESC, OFF_S0>(&nxt);
-                int32_t *o_state = GP(int32_t, o0, 0), *o_active = GP(int32_t, o0, 1), *o_rem = GP(int32_t, o0, 6);
-                float *o_energy = GP(float, o0, 2), *o_jp = GP(float, o0, 3), *o_center = GP(float, o0, 4), *o_ewo = GP(float, o0, 5), *o_cand = GP(float, o0, 7);
-                AT(o_jp, slot * 8 + (unsigned) k) = jp;
+                v2f_t *o_slot = GP(v2f_t, o0, RS_SLOT);
+                float *o_cand = GP(float, o0, RS_CAND);
+                const float ewo_ = doLin ? newEnergyWO : -1.0f;
+                const float cenK = compute ? (k == 0 ? c0 : k == 1 ? c1 : c2) : q.m[g];      // k < 3 only: lanes 0..2 hold the old centre in their m
+                float mOut = (k < 3) ? cenK : (k == LD_SM_ENERGY) ? newEnergy : (k == LD_SM_EWO) ? ewo_
+                           : __builtin_bit_cast(float, (k == LD_SM_STATE) ? newState : (k == LD_SM_ACTIVE) ? activeNew : toRemove);
+                v2f_t e; e.x = jp; e.y = mOut;
+                AT(o_slot, slot * 8 + (unsigned) k) = e;
                 if (k == 0) {
-                    AT(o_state, slot) = newState;
-                    AT(o_active, slot) = activeNew;
-                    AT(o_energy, slot) = newEnergy;
-                    AT(o_ewo, slot) = doLin ? newEnergyWO : -1.0f;
-                    if (t == F - 1) AT(o_cand, p) = doLin ? newEnergyWO : -1.0f;
-                    AT(o_rem, slot) = toRemove;
+                    if (t == F - 1) AT(o_cand, p) = ewo_;
                     if (doLin) energySum += ret;
                 }
-                if (k < 3) AT(o_center, slot * 3 + (unsigned) k) = compute ? (k == 0 ? c0 : k == 1 ? c1 : c2) : q.cen[g];
             }
             if (B.dumpJ != nullptr && compute) {
                 ldso_rawjac_t &o = B.dumpJ[q.rflat[g]];
@@ -760,9 +769,8 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
         }
         // ---- store G row: [8*FS frame entries | Hcd 4, bdSum, HdiF, 0, 0] --------------------------------
         {
-            v16i_t o1, o2;
-            ldg16x2<DESC, OFF_S1, OFF_S2>(o1, &nxt, o2, &nxt);
-            float *Grow = GP(float, o2, 4) + (size_t) p * D.GS;
+            const v16i_t o0 = ldg16<DESC, OFF_S0>(&nxt);
+            float *Grow = GP(float, o0, RS_G) + (size_t) p * D.GS;
 #pragma unroll
             for (int g = 0; g < NSG; g++) {
                 const int t = g * 8 + s;
@@ -775,18 +783,21 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
                 if (nActive == 0 && lane < 4) e = 0.0f;
                 Grow[8 * FS + lane] = e;
             }
-            // the per-point scalars: one value per lane (lanes 0..19), one store instruction per destination array
-            float *o_HdiF = GP(float, o1, 0), *o_bd = GP(float, o1, 1), *o_idH = GP(float, o1, 2), *o_HcdA = GP(float, o1, 4), *o_HcdL = GP(float, o1, 5), *o_mrb = GP(float, o1, 6);
-            int32_t *o_nAct = GP(int32_t, o1, 3), *o_nGood = GP(int32_t, o1, 7);
-            float *o_HddA = GP(float, o2, 0), *o_bdA = GP(float, o2, 1), *o_HddL = GP(float, o2, 2), *o_bdL = GP(float, o2, 3);
-            if (lane == 0) {
-                AT(o_HdiF, p) = HdiF; AT(o_bd, p) = bdSumF; AT(o_idH, p) = idH;
-                AT(o_HddA, p) = HddA; AT(o_bdA, p) = bdA; AT(o_HddL, p) = HddL; AT(o_bdL, p) = bdL;
-                AT(o_HcdA, p * 4 + 0) = HcdA0; AT(o_HcdA, p * 4 + 1) = HcdA1; AT(o_HcdA, p * 4 + 2) = HcdA2; AT(o_HcdA, p * 4 + 3) = HcdA3;
-                AT(o_HcdL, p * 4 + 0) = HcdL0; AT(o_HcdL, p * 4 + 1) = HcdL1; AT(o_HcdL, p * 4 + 2) = HcdL2; AT(o_HcdL, p * 4 + 3) = HcdL3;
-                AT(o_mrb, p) = maxRelBS; AT(o_nGood, p) = numGood; AT(o_nAct, p) = nActive;
-                nidSum += fabsf(idp); nidCnt++;
+            // the point's PtRec of the next set: lanes 0..3 store one dwordx4 each (ONE store instruction, 64 contiguous bytes); lane 4 the
+            // accumulator scalars only the fetch functions read
+            v4f_t *o_pt = GP(v4f_t, o0, RS_PT), *o_acc = GP(v4f_t, o0, RS_ACC);
+            if (lane < 4) {
+                v4f_t v;
+                v.x = (lane == 0) ? HdiF : (lane == 1) ? HcdA0 : (lane == 2) ? HcdL0 : maxRelBS;
+                v.y = (lane == 0) ? bdSumF : (lane == 1) ? HcdA1 : (lane == 2) ? HcdL1 : __builtin_bit_cast(float, numGood);
+                v.z = (lane == 0) ? idH : (lane == 1) ? HcdA2 : (lane == 2) ? HcdL2 : 0.0f;
+                v.w = (lane == 0) ? __builtin_bit_cast(float, nActive) : (lane == 1) ? HcdA3 : (lane == 2) ? HcdL3 : 0.0f;
+                AT(o_pt, p * 4 + (unsigned) lane) = v;
+            } else if (lane == 4) {
+                v4f_t v; v.x = HddA; v.y = bdA; v.z = HddL; v.w = bdL;
+                AT(o_acc, p) = v;
             }
+            if (lane == 0) { nidSum += fabsf(idp); nidCnt++; }
         }
     }   // points of this wave
 
@@ -816,9 +827,9 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
     }
     __syncthreads();
     LSTAMP(7);
-    const v16i_t e2 = ldg16<DESC, OFF_S2>(&nxt);
-    float *o_topA = GP(float, e2, 5), *o_topL = GP(float, e2, 6);
-    double *o_chunkE = GP(double, e2, 7);
+    const v16i_t e2 = ldg16<DESC, OFF_S0>(&nxt);
+    float *o_topA = GP(float, e2, RS_TOPA), *o_topL = GP(float, e2, RS_TOPL);
+    double *o_chunkE = GP(double, e2, RS_CHUNKE);
     for (int i = tid; i < FS * LD_TOPN; i += blockDim.x) {
         float a = 0;
 #pragma unroll
