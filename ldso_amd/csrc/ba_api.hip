@@ -264,8 +264,7 @@ static int create_body(ldso_ba *H, int device, int w, int h, int max_frames, int
     DA(B.frames, F); DA(B.calib, 1); DA(B.pairs, F * F); DA(B.pairRt, F * F * 12);
     DA(B.adHost, F * F * 64); DA(B.adTarget, F * F * 64); DA(B.adHostF, F * F * 64); DA(B.adTargetF, F * F * 64);
     DA(B.nsProj, nmax * 7); DA(B.HM, nmax * nmax); DA(B.bM, nmax);
-    DA(B.pu, P); DA(B.pv, P); DA(B.pidepth, P); DA(B.pidepth_zero, P); DA(B.pidepth_backup, P); DA(B.pstep, P); DA(B.ppriorF, P); DA(B.pLastHdiF, P); DA(B.pLastBdSumF, P); DA(B.pLastIdH, P);
-    DA(B.pcolor, P * 8); DA(B.pweights, P * 8); DA(B.phost, P);
+    DA(B.pgeo, P); DA(B.pcw, P * 8); DA(B.phost, P);
     DA(B.rtab, P * FS);
     DA(B.Jlin, P * FS); DA(B.rtz, P * FS * 8);
     DA(B.chunk_p0, H->maxChunks); DA(B.chunk_n, H->maxChunks); DA(B.chunk_host, H->maxChunks);
@@ -456,7 +455,7 @@ int ldso_ba_set_window(ldso_ba_t *H, int F, const int32_t *image_slot, int P, co
     REQ(nLin == 0 || (linJ && lin_rtz), "ldso_ba_set_window: linearised residual without linJ / lin_res_toZeroF");
     auto A16 = [](size_t b) { return (b + 15) & ~(size_t) 15; };
     const size_t tabBytes = A16(LD_XFER_MAX * sizeof(WinXfer));
-    const size_t need = tabBytes + 5 * A16((size_t) P * 4) + 2 * A16((size_t) P * 32) + A16((size_t) P * 4) + A16(PS * sizeof(SlotTab)) + A16(nLin * sizeof(ldso_rawjac_t)) + A16(nLin * 32)
+    const size_t need = tabBytes + A16((size_t) P * sizeof(PtGeo)) + A16((size_t) P * 8 * sizeof(PtCw)) + A16((size_t) P * 4) + A16(PS * sizeof(SlotTab)) + A16(nLin * sizeof(ldso_rawjac_t)) + A16(nLin * 32)
                       + A16(PS * sizeof(SlotRec)) + 64;
     if (need > H->stageCap) {
         CHK(hipStreamSynchronize(H->stream));
@@ -469,20 +468,23 @@ int ldso_ba_set_window(ldso_ba_t *H, int F, const int32_t *image_slot, int P, co
         H->stageCap = cap;
     }
     WinStage W{H->h_stage, H->stageCap, tabBytes, reinterpret_cast<WinXfer *>(H->h_stage), 0};
-    float *pu = W.put(B.pu, P), *pv = W.put(B.pv, P), *pid = W.put(B.pidepth, P), *pidz = W.put(B.pidepth_zero, P), *ppr = W.put(B.ppriorF, P);
-    float *pcol = W.put(B.pcolor, (size_t) P * 8), *pwt = W.put(B.pweights, (size_t) P * 8);
+    PtGeo *geo = W.put(B.pgeo, P);
+    PtCw *pcw = W.put(B.pcw, (size_t) P * 8);
     int32_t *phost = W.put(B.phost, P);
     SlotTab *tab = W.put(B.rtab, PS);
     ldso_rawjac_t *Jl = W.put(B.Jlin, nLin);
     float *rtz = W.put(B.rtz, nLin * 8);
     SlotRec *sr = W.put(H->sets[0].slot, PS);
-    REQ(pu && pv && pid && pidz && ppr && pcol && pwt && phost && tab && Jl && rtz && sr, "ldso_ba_set_window: staging arena too small (internal)");
+    REQ(geo && pcw && phost && tab && Jl && rtz && sr, "ldso_ba_set_window: staging arena too small (internal)");
     H->h_phost.resize(P);
     for (int i = 0; i < P; i++) {
-        pu[i] = pts[i].u; pv[i] = pts[i].v; pid[i] = pts[i].idepth; pidz[i] = pts[i].idepth_zero; ppr[i] = pts[i].priorF;
+        PtGeo g_;
+        memset(&g_, 0, sizeof(g_));           // step, the scalars of the last solve: zero
+        g_.u = pts[i].u; g_.v = pts[i].v; g_.priorF = pts[i].priorF; g_.idepth = pts[i].idepth; g_.idepth_zero = pts[i].idepth_zero; g_.idepth_backup = pts[i].idepth;
+        geo[i] = g_;
         REQ(pts[i].host >= 0 && pts[i].host < F, "ldso_ba_set_window: point host out of range");
         H->h_phost[i] = pts[i].host; phost[i] = pts[i].host;
-        memcpy(&pcol[(size_t) i * 8], pts[i].color, 32); memcpy(&pwt[(size_t) i * 8], pts[i].weights, 32);
+        for (int k = 0; k < 8; k++) pcw[(size_t) i * 8 + k] = PtCw{pts[i].color[k], pts[i].weights[k]};
     }
     memset(sr, 0, PS * sizeof(SlotRec));          // JpJdF, centre, energies, activity, removal flag: zero
     for (size_t q = 0; q < PS; q++) { tab[q] = SlotTab{-1, 0, 0, -1}; sr[q].e[LD_SM_STATE].m.i = LDSO_RES_OOB; }
@@ -512,14 +514,13 @@ int ldso_ba_set_window(ldso_ba_t *H, int F, const int32_t *image_slot, int P, co
     D.nL = (int) nLin;
     H->hasL = D.nL > 0;
     H->cur = 0; H->pendingApply = false; H->appliedValid = false;
-    bool okT = W.again(B.pidepth_backup, pid, P);
-    okT = okT && W.again(H->sets[1].slot, sr, PS);
+    bool okT = W.again(H->sets[1].slot, sr, PS);
     for (int s_ = 0; s_ < 2; s_++) {
         ResSet &S = H->sets[s_];
         okT = okT && W.zero(S.pt, (size_t) P) && W.zero(S.acc, (size_t) P) && W.zero(S.G, (size_t) P * D.GS);
     }
     // a new window has a new dimension 8F+4: the marginalisation prior starts at zero (ldso_ba_set_prior follows when there is one)
-    okT = okT && W.zero(B.pstep, (size_t) P) && W.zero(B.pLastHdiF, (size_t) P) && W.zero(B.pLastBdSumF, (size_t) P) && W.zero(B.pLastIdH, (size_t) P) && W.zero(B.HM, (size_t) D.n * D.n) && W.zero(B.bM, (size_t) D.n) && W.zero(B.scalars, (size_t) 16)
+    okT = okT && W.zero(B.HM, (size_t) D.n * D.n) && W.zero(B.bM, (size_t) D.n) && W.zero(B.scalars, (size_t) 16)
               && W.zero(B.scPart, (size_t) LD_SC_SPLITS * H->GSP * H->GSP);
     REQ(okT, "ldso_ba_set_window: upload table overflow (internal)");
     H->hasPrior = false;
@@ -1524,18 +1525,17 @@ int ldso_ba_get_points(ldso_ba_t *H, ldso_point_out_t *out) {
     CHK(hipSetDevice(H->device));
     const size_t P = H->D.P;
     const ResSet &S = H->sets[H->cur];
-    std::vector<float> step, HdiF, bd, idH, idp;
+    std::vector<PtGeo> geo;
     std::vector<PtRec> pt;
     std::vector<PtAcc> acc;
-    D2H(step, H->B.pstep, P); D2H(HdiF, H->B.pLastHdiF, P); D2H(bd, H->B.pLastBdSumF, P); D2H(idH, H->B.pLastIdH, P); D2H(idp, H->B.pidepth, P);
-    D2H(pt, S.pt, P); D2H(acc, S.acc, P);
+    D2H(geo, H->B.pgeo, P); D2H(pt, S.pt, P); D2H(acc, S.acc, P);
     CHK(hipStreamSynchronize(H->stream));
     for (size_t i = 0; i < P; i++) {
         ldso_point_out_t &o = out[i];
-        o.step = step[i]; o.HdiF = HdiF[i]; o.bdSumF = bd[i]; o.idepth_hessian = idH[i]; o.Hdd_accAF = acc[i].HddA; o.bd_accAF = acc[i].bdA;
+        o.step = geo[i].step; o.HdiF = geo[i].lastHdiF; o.bdSumF = geo[i].lastBdSumF; o.idepth_hessian = geo[i].lastIdH; o.Hdd_accAF = acc[i].HddA; o.bd_accAF = acc[i].bdA;
         o.Hdd_accLF = acc[i].HddL; o.bd_accLF = acc[i].bdL;
         for (int k = 0; k < 4; k++) { o.Hcd_accAF[k] = pt[i].HcdA[k]; o.Hcd_accLF[k] = pt[i].HcdL[k]; }
-        o.idepth = idp[i]; o.maxRelBaseline = pt[i].maxRelBS; o.numGoodResiduals = pt[i].numGood;
+        o.idepth = geo[i].idepth; o.maxRelBaseline = pt[i].maxRelBS; o.numGoodResiduals = pt[i].numGood;
     }
     return LDSO_OK;
 }

@@ -78,6 +78,17 @@ struct alignas(64) PtRec {
 };
 static_assert(sizeof(PtRec) == 64, "PtRec is one 64-byte line");
 struct PtAcc { float HddA, bdA, HddL, bdL; };        // accumulator scalars only the fetch functions read
+// Geometry and inverse depth of a point, 64 bytes.  Read with one scalar load (dwords 0..7); the fused point step rewrites dwords 4..11 with
+// two dwordx4 of one store instruction (lanes 1, 2).
+struct alignas(64) PtGeo {
+    float u, v, priorF, pad0_;                               // static (ldso_ba_set_window)
+    float idepth, idepth_zero, step, idepth_backup;          // PointHessian::{idepth, idepth_zero, step, idepth_backup}
+    float lastHdiF, lastBdSumF, lastIdH, pad1_;              // PointHessian::{HdiF, bdSumF, idepth_hessian} as the LAST solveSystemF left them (AccumulatedSCHessian.cc:9-51):
+                                                             // the PtRec copies belong to the NEXT solve (the fused linearize pass already holds the new linearisation's scalars)
+    float pad2_[4];
+};
+static_assert(sizeof(PtGeo) == 64, "PtGeo is one 64-byte line");
+struct PtCw { float color, weight; };
 
 // One of the two ping-pong sets (see header comment).
 struct ResSet {
@@ -112,18 +123,15 @@ struct BaPtrs {
     float *adHostF, *adTargetF;
     double *nsProj;                  // n*n projector onto the gauge nullspaces (reference ordering)
     double *HM, *bM;
-    // points.  Two groups of eight consecutive pointers (see ResSet): B0 = what a wave reads of a point, B1 = what the fused point step writes
-    float *pu, *pv, *pidepth, *pidepth_zero, *ppriorF, *pcolor, *pweights, *pstep;                  // ---- group B0
-    float *pidepth_backup;                                                                          // ---- group B1 (with the next seven)
-    float *pLastHdiF, *pLastBdSumF, *pLastIdH;    // PointHessian::{HdiF, bdSumF, idepth_hessian} as the LAST solveSystemF left them (AccumulatedSCHessian.cc:9-51): the
-                                                  // ResSet copies belong to the NEXT solve (the fused linearize pass already holds the new linearisation's Schur scalars)
-    SlotTab *rtab;                   // [P*FS] residual slots: flat residual index (-1: none), linearised?, new?, index into Jlin / rtz
-    int32_t *phost;
-    // linearised store
-    ldso_rawjac_t *Jlin;
-    float *rtz;                                                                                     // (end of group B1)
-    // chunks
-    int32_t *chunk_p0, *chunk_n, *chunk_host;
+    // points and residual slots: ONE group of eight consecutive pointers (ba_linearize.hip: LDG16) - everything a wave reads / writes of a point
+    PtGeo *pgeo;                     // [P]     geometry + inverse depth + the scalars of the last solve, 64 bytes per point          ---- group B0
+    PtCw *pcw;                       // [P*8]   (colour, weight) of the 8 pattern pixels
+    SlotTab *rtab;                   // [P*FS]  residual slots: flat residual index (-1: none), linearised?, new?, index into Jlin / rtz
+    int32_t *phost;                  // [P]
+    ldso_rawjac_t *Jlin;             // linearised store
+    float *rtz;
+    int32_t *chunk_p0, *chunk_n;                                                                    // (end of group B0)
+    int32_t *chunk_host;
     // solve-side buffers
     double *pairC;      // [F*F][PAIRC] lifted top contributions (A then L)
     float *scPart;      // [SC_SPLITS][n*(n+1)] Schur partials

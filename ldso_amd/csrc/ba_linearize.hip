@@ -132,10 +132,10 @@ template <bool DESC, int OFFA, int OFFB> static __device__ __forceinline__ void 
     else { __builtin_memcpy(&a, (const char *) baseA + OFFA, 64); __builtin_memcpy(&b, (const char *) baseB + OFFB, 64); }
 }
 #define GP(T, t16, i) ((T *) ((((unsigned long long) (unsigned) (t16)[2 * (i) + 1]) << 32) | (unsigned long long) (unsigned) (t16)[2 * (i)]))
-#define OFF_B0 ((int) offsetof(BaPtrs, pu))
-#define OFF_B1 ((int) offsetof(BaPtrs, pidepth_backup))
+#define OFF_B0 ((int) offsetof(BaPtrs, pgeo))
+enum { BP_GEO = 0, BP_CW = 1, BP_RTAB = 2, BP_PHOST = 3, BP_JLIN = 4, BP_RTZ = 5 };      // indices of the BaPtrs pointers inside their group
 #define OFF_S0 ((int) offsetof(ResSet, slot))
-static_assert(offsetof(BaPtrs, pstep) == offsetof(BaPtrs, pu) + 56 && offsetof(BaPtrs, rtz) == offsetof(BaPtrs, pidepth_backup) + 56, "BaPtrs pointer groups (ba_dev.h)");
+static_assert(offsetof(BaPtrs, chunk_n) == offsetof(BaPtrs, pgeo) + 56, "BaPtrs pointer group (ba_dev.h)");
 static_assert(offsetof(ResSet, slot) == 0 && offsetof(ResSet, chunkEnergy) == 56 && offsetof(ResSet, chunkCnt) == 64, "ResSet pointer group (ba_dev.h)");
 // indices of the ResSet pointers inside their group
 enum { RS_SLOT = 0, RS_PT = 1, RS_ACC = 2, RS_CAND = 3, RS_G = 4, RS_TOPA = 5, RS_TOPL = 6, RS_CHUNKE = 7 };
@@ -184,59 +184,43 @@ template <> struct at_sel<false> {
 #define LD_PERM_DESC 0      // measured (A/B, two rounds each on one box): 220.3 / 51.6 / 10.07 us (B = 32 / B = 8 / C3) with ds_bpermute against 225.2 / 52.7 / 10.17 us with the
 #endif                   // permlane butterflies below - their hand-placed s_nop pairs and the opaque asm cost more than the LDS round trips they save
 #define AT(ptr, i) (at_sel<DESC || LD_GLOBAL_ARGS>::ref((ptr), (unsigned) (i)))
-// a per-point entry (index wave-uniform): scalar load when LD_SCALAR_POINT and the descriptor-based kernel, else as AT
-#define PT(ptr, i) (pt_get<DESC && (LD_SCALAR_POINT != 0), DESC>((ptr), (unsigned) (i)))
-
-// LD_SCALAR_POINT (experiment, descriptor-based kernel only): the per-POINT entries of the record (22 of its 31 loads in a GN pass) have a
-// wave-uniform address - a wavefront works on one point at a time.  Read through a constant-address-space pointer with the index in an SGPR
-// they become scalar loads (s_load_dword, scalar cache): no vector memory instruction, no VGPR address, nothing on vmcnt.  Legal because no
-// wavefront reads an entry again after anybody has written it inside one launch (a point belongs to one wavefront; what it stores -
-// pidepth, pidepth_zero, pstep, the backup - depends on what it loaded), and the scalar cache is invalidated at the launch boundary.
-#ifndef LD_SCALAR_POINT
-#define LD_SCALAR_POINT 0
-#endif
+// Per-POINT data have a wave-uniform address - a wavefront works on one point at a time.  Read through a constant-address-space pointer with
+// the index in an SGPR they become scalar loads (s_load_dwordxN, scalar cache): no vector memory instruction, no VGPR address, nothing on
+// vmcnt.  Legal because no wavefront reads an entry again after anybody has written it inside one launch (a point belongs to one wavefront;
+// what it stores depends on what it loaded), and the scalar cache is invalidated at the launch boundary.
 #ifndef LD_GLOBAL_TAPS
 #define LD_GLOBAL_TAPS 0
 #endif
 template <class T> using cptr_t = const __attribute__((address_space(4))) T *;
-template <bool SC> struct pt_sel;
-template <> struct pt_sel<true> {
-    template <class T> static __device__ __forceinline__ T get(const T *p, unsigned i) { return *(cptr_t<T>) ((unsigned long long) p + (unsigned long long) (i * (unsigned) sizeof(T))); }
-};
-template <> struct pt_sel<false> {
-    template <class T> static __device__ __forceinline__ T get(const T *p, unsigned i) { return *(const T *) ((const char *) p + (size_t) (i * (unsigned) sizeof(T))); }
-};
-
-template <bool SC, bool DESC_, class T> static __device__ __forceinline__ T pt_get(const T *p, unsigned i) {
-    if constexpr (SC) return pt_sel<true>::get(p, (unsigned) __builtin_amdgcn_readfirstlane((int) i));
-    else return at_sel<DESC_ || LD_GLOBAL_ARGS>::ref(p, i);
-}
 
 typedef int v4i32_t __attribute__((ext_vector_type(4)));
+typedef int v8i_t __attribute__((ext_vector_type(8)));
 typedef float v2f_t __attribute__((ext_vector_type(2)));
 typedef float v4f_t __attribute__((ext_vector_type(4)));
 
-// The record of one point as a wavefront needs it: 5 + 1 per-point scalars of the geometry arrays (scalar loads under LD_SCALAR_POINT),
-// the point's PtRec (ONE scalar load - the index is wave-uniform), this lane's colour / weight, and per slot group one dwordx4 (SlotTab,
-// the same 16 bytes for the 8 lanes of a slot) and one dwordx2 (this lane's pair of the 64-byte SlotRec): 4 + 2 NSG vector loads
-// (round 3: 9 + 9 NSG + 13).
+// The record of one point as a wavefront needs it: the first half of its PtGeo and its PtRec (two scalar loads - the index is wave-uniform),
+// this lane's (colour, weight) pair (one dwordx2), and per slot group one dwordx4 (SlotTab, the same 16 bytes for the 8 lanes of a slot) and
+// one dwordx2 (this lane's pair of the 64-byte SlotRec): 1 + 2 NSG vector loads (round 3: 9 + 9 NSG + 13).
 template <int NSG, bool HAS_L, bool FIX, bool DESC>
 static __device__ __forceinline__ void load_point(PtIn<NSG> &q, const BaPtrs &B, const ResSet &cur, unsigned FS, unsigned p, unsigned s, unsigned k, int stepMode) {
     {
-        v16i_t b0, b1;
-        ldg16x2<DESC, OFF_B0, OFF_B1>(b0, &B, b1, &B);
-        const float *pu = GP(const float, b0, 0), *pv = GP(const float, b0, 1), *pid = GP(const float, b0, 2), *piz = GP(const float, b0, 3), *ppr = GP(const float, b0, 4);
-        const float *pco = GP(const float, b0, 5), *pwe = GP(const float, b0, 6), *pst = GP(const float, b0, 7);
-        const v4i32_t *rtab = GP(const v4i32_t, b1, 4);
-        q.pu = PT(pu, p); q.pv = PT(pv, p); q.idp = PT(pid, p); q.idz = PT(piz, p); q.priorF = PT(ppr, p);
-        q.color = AT(pco, p * 8 + k); q.wgt = AT(pwe, p * 8 + k);
-        q.pstep = (stepMode & 1) ? PT(pst, p) : 0.0f;
+        const v16i_t b0 = ldg16<DESC, OFF_B0>(&B);
+        const PtGeo *geo = GP(const PtGeo, b0, BP_GEO);
+        const v2f_t *pcw = GP(const v2f_t, b0, BP_CW);
+        const v4i32_t *rtab = GP(const v4i32_t, b0, BP_RTAB);
+        // dwords 0..7 of the point's PtGeo (u, v, prior | idepth, idepth_zero, step): wave-uniform address -> ONE scalar load
+        const v8i_t g8 = *(cptr_t<v8i_t>) ((unsigned long long) geo + (unsigned long long) ((unsigned) __builtin_amdgcn_readfirstlane((int) p) * (unsigned) sizeof(PtGeo)));
+        q.pu = __builtin_bit_cast(float, g8[0]); q.pv = __builtin_bit_cast(float, g8[1]); q.priorF = __builtin_bit_cast(float, g8[2]);
+        q.idp = __builtin_bit_cast(float, g8[4]); q.idz = __builtin_bit_cast(float, g8[5]); q.pstep = __builtin_bit_cast(float, g8[6]);
+        const v2f_t cw = AT(pcw, p * 8 + k);
+        q.color = cw.x; q.wgt = cw.y;
 #pragma unroll
         for (int g = 0; g < NSG; g++) {
             const unsigned slot = p * FS + g * 8 + s;       // slot tables are dense [P][FS]: every index is readable
             const v4i32_t t4 = AT(rtab, slot);
             q.rflat[g] = t4.x; q.rlin[g] = t4.y; q.rnew[g] = FIX ? t4.z : 0; q.rlidx[g] = HAS_L ? t4.w : 0;
         }
+        (void) stepMode;
     }
     {
         const v16i_t s0 = ldg16<DESC, OFF_S0>(&cur);
@@ -367,6 +351,7 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
     float nidSum = 0.0f;
     int nidCnt = 0;
 
+#pragma clang loop unroll(disable)
     for (; pi < np; pi += LD_WAVES) {
         if (pi == wave) LSTAMP(2);
         const unsigned p = (unsigned) (p0 + pi);
@@ -411,13 +396,15 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
             }
             const float ni = idp + 1.0f * step;
             {
-                v16i_t b0, b1;
-                ldg16x2<DESC, OFF_B0, OFF_B1>(b0, &B, b1, &B);
-                float *w_pstep = GP(float, b0, 7), *w_pid = GP(float, b0, 2), *w_piz = GP(float, b0, 3), *w_pbk = GP(float, b1, 0);
-                float *w_lH = GP(float, b1, 1), *w_lB = GP(float, b1, 2), *w_lI = GP(float, b1, 3);
-                if (lane == 0) { AT(w_pstep, p) = step; AT(w_pbk, p) = idp; AT(w_pid, p) = ni; AT(w_piz, p) = ni; }
-                // PointHessian::{HdiF, bdSumF, idepth_hessian} as the solve that produced this step left them (lanes 1..3: fire-and-forget stores)
-                if (lane == 1) AT(w_lH, p) = q.rec.HdiF; else if (lane == 2) AT(w_lB, p) = q.rec.bdSumF; else if (lane == 3) AT(w_lI, p) = q.rec.idH;
+                // dwords 4..11 of the point's PtGeo: lane 1 {idepth, idepth_zero, step, idepth_backup}, lane 2 PointHessian::{HdiF, bdSumF,
+                // idepth_hessian} as the solve that produced this step left them - two dwordx4 of ONE store instruction (round 3: seven stores)
+                const v16i_t b0 = ldg16<DESC, OFF_B0>(&B);
+                v4f_t *w_geo = GP(v4f_t, b0, BP_GEO);
+                if (lane == 1 || lane == 2) {
+                    v4f_t v;
+                    v.x = (lane == 1) ? ni : q.rec.HdiF; v.y = (lane == 1) ? ni : q.rec.bdSumF; v.z = (lane == 1) ? step : q.rec.idH; v.w = (lane == 1) ? idp : 0.0f;
+                    AT(w_geo, p * 4 + (unsigned) lane) = v;
+                }
             }
             idp = ni; idz = ni;
         }
@@ -770,18 +757,19 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
         // ---- store G row: [8*FS frame entries | Hcd 4, bdSum, HdiF, 0, 0] --------------------------------
         {
             const v16i_t o0 = ldg16<DESC, OFF_S0>(&nxt);
-            float *Grow = GP(float, o0, RS_G) + (size_t) p * D.GS;
+            float *Gall = GP(float, o0, RS_G);
+            const unsigned g0 = p * (unsigned) D.GS;              // P * GS floats stay far below 2^32 bytes
 #pragma unroll
             for (int g = 0; g < NSG; g++) {
                 const int t = g * 8 + s;
                 float val = (t == h) ? hostPart : gT[g];
                 if (nActive == 0) val = 0.0f;
-                Grow[8 * t + k] = val;
+                AT(Gall, g0 + 8u * (unsigned) t + (unsigned) k) = val;
             }
             if (lane < LD_GEXTRA) {
                 float e = (lane == 0) ? Hc0 : (lane == 1) ? Hc1 : (lane == 2) ? Hc2 : (lane == 3) ? Hc3 : (lane == 4) ? bdSumF : (lane == 5) ? HdiF : 0.0f;
                 if (nActive == 0 && lane < 4) e = 0.0f;
-                Grow[8 * FS + lane] = e;
+                AT(Gall, g0 + 8u * (unsigned) FS + (unsigned) lane) = e;
             }
             // the point's PtRec of the next set: lanes 0..3 store one dwordx4 each (ONE store instruction, 64 contiguous bytes); lane 4 the
             // accumulator scalars only the fetch functions read

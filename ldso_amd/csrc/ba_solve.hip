@@ -1176,11 +1176,12 @@ hipError_t ba_launch_gn_export(const BaPtrs &B, const BaDims &D, const ResSet &S
 __global__ __launch_bounds__(256) void k_point_step(BaPtrs B, BaDims D, ResSet S, int mode) {
     const int p = D.pBegin + blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= D.pEnd) return;
-    if (mode & PS_LOAD) { float b = B.pidepth_backup[p]; B.pidepth[p] = b; B.pidepth_zero[p] = b; return; }   // loadSateBackup
+    PtGeo &Gp = B.pgeo[p];
+    if (mode & PS_LOAD) { float b = Gp.idepth_backup; Gp.idepth = b; Gp.idepth_zero = b; return; }   // loadSateBackup
     const int F = D.F, FS = D.FS, h = B.phost[p];
-    float step = B.pstep[p];
+    float step = Gp.step;
     PtRec &R = S.pt[p];
-    if (mode & PS_RESUB) { B.pLastHdiF[p] = R.HdiF; B.pLastBdSumF[p] = R.bdSumF; B.pLastIdH[p] = R.idH; }      // what this solve's accumulateSCF_MT left in the point
+    if (mode & PS_RESUB) { Gp.lastHdiF = R.HdiF; Gp.lastBdSumF = R.bdSumF; Gp.lastIdH = R.idH; }      // what this solve's accumulateSCF_MT left in the point
     if ((mode & PS_RESUB) && R.nActive <= 0) { step = 0.0f; R.maxRelBS = 0.0f; }      // AccumulatedSCHessian.cc:14-21 (zeroed by the solve)
     if ((mode & PS_RESUB) && R.nActive > 0) {
         float b = R.bdSumF;
@@ -1198,14 +1199,14 @@ __global__ __launch_bounds__(256) void k_point_step(BaPtrs B, BaDims D, ResSet S
             b -= s;
         }
         if (!isfinite(b)) finite = false;
-        if (finite) step = -b * R.HdiF; else { step = B.pstep[p]; B.scalars[4] = 1.0; }
+        if (finite) step = -b * R.HdiF; else { step = Gp.step; B.scalars[4] = 1.0; }
     }
-    B.pstep[p] = step;
-    if (mode & PS_BACKUP) B.pidepth_backup[p] = B.pidepth[p];
+    Gp.step = step;
+    if (mode & PS_BACKUP) Gp.idepth_backup = Gp.idepth;
     if (mode & PS_STEP) {     // doStepFromBackup (stepfacD = 1)
-        float ni = B.pidepth_backup[p] + 1.0f * step;
-        B.pidepth[p] = ni;
-        B.pidepth_zero[p] = ni;
+        float ni = Gp.idepth_backup + 1.0f * step;
+        Gp.idepth = ni;
+        Gp.idepth_zero = ni;
     }
 }
 
@@ -1236,7 +1237,7 @@ __global__ __launch_bounds__(256) void k_lm_energies(BaPtrs B, BaDims D, ResSet 
     // ---- L energy: points ----
     const float cD0 = B.calib->cDeltaF[0], cD1 = B.calib->cDeltaF[1], cD2 = B.calib->cDeltaF[2], cD3 = B.calib->cDeltaF[3];
     for (int p = D.pBegin + tid; p < D.pEnd; p += 256) {
-        const float dd = B.pidepth[p] - B.pidepth_zero[p];
+        const float dd = B.pgeo[p].idepth - B.pgeo[p].idepth_zero;
         const int h = B.phost[p];
         double e = 0.0;
         for (int t = 0; t < F; t++) {
@@ -1255,7 +1256,7 @@ __global__ __launch_bounds__(256) void k_lm_energies(BaPtrs B, BaDims D, ResSet 
                 e += (double) (Jd * ((rtz[i] + rtz[i]) + Jd));
             }
         }
-        e += (double) (dd * dd * B.ppriorF[p]);
+        e += (double) (dd * dd * B.pgeo[p].priorF);
         el += e;
     }
     em = wave_sum(em); el = wave_sum(el);
