@@ -195,6 +195,7 @@ template <class T> using cptr_t = const __attribute__((address_space(4))) T *;
 
 typedef int v4i32_t __attribute__((ext_vector_type(4)));
 typedef int v8i_t __attribute__((ext_vector_type(8)));
+typedef int v2i32_t __attribute__((ext_vector_type(2)));
 typedef float v2f_t __attribute__((ext_vector_type(2)));
 typedef float v4f_t __attribute__((ext_vector_type(4)));
 
@@ -212,13 +213,23 @@ static __device__ __forceinline__ void load_point(PtIn<NSG> &q, const BaPtrs &B,
         const v8i_t g8 = *(cptr_t<v8i_t>) ((unsigned long long) geo + (unsigned long long) ((unsigned) __builtin_amdgcn_readfirstlane((int) p) * (unsigned) sizeof(PtGeo)));
         q.pu = __builtin_bit_cast(float, g8[0]); q.pv = __builtin_bit_cast(float, g8[1]); q.priorF = __builtin_bit_cast(float, g8[2]);
         q.idp = __builtin_bit_cast(float, g8[4]); q.idz = __builtin_bit_cast(float, g8[5]); q.pstep = __builtin_bit_cast(float, g8[6]);
-        const v2f_t cw = AT(pcw, p * 8 + k);
+        // addresses = (uniform base advanced to the point, on the scalar side) + (a lane offset that never changes): no per-point VGPR address
+        // arithmetic, and no VGPR shared between one load's address and another load's destination (the allocator had put the slot-record
+        // address into a register of the SlotTab destination: a vmcnt(0) between the two loads, i.e. two serialised latencies)
+        const unsigned pU = (unsigned) __builtin_amdgcn_readfirstlane((int) p);
+        const v2f_t cw = AT(pcw + (size_t) pU * 8, k);
         q.color = cw.x; q.wgt = cw.y;
 #pragma unroll
         for (int g = 0; g < NSG; g++) {
-            const unsigned slot = p * FS + g * 8 + s;       // slot tables are dense [P][FS]: every index is readable
-            const v4i32_t t4 = AT(rtab, slot);
-            q.rflat[g] = t4.x; q.rlin[g] = t4.y; q.rnew[g] = FIX ? t4.z : 0; q.rlidx[g] = HAS_L ? t4.w : 0;
+            // slot tables are dense [P][FS]: every index is readable.  Only the half of the entry this variant uses is loaded: dead lanes of a
+            // wider destination get re-used by the allocator for the next load's address, which costs a vmcnt(0) between the two loads
+            if constexpr (FIX || HAS_L) {
+                const v4i32_t t4 = AT(rtab + (size_t) pU * FS, g * 8 + s);
+                q.rflat[g] = t4.x; q.rlin[g] = t4.y; q.rnew[g] = FIX ? t4.z : 0; q.rlidx[g] = HAS_L ? t4.w : 0;
+            } else {
+                const v2i32_t t2 = AT((const v2i32_t *) (rtab + (size_t) pU * FS), (g * 8 + s) * 2);
+                q.rflat[g] = t2.x; q.rlin[g] = t2.y; q.rnew[g] = 0; q.rlidx[g] = 0;
+            }
         }
         (void) stepMode;
     }
@@ -227,11 +238,11 @@ static __device__ __forceinline__ void load_point(PtIn<NSG> &q, const BaPtrs &B,
         const v2f_t *slots = GP(const v2f_t, s0, RS_SLOT);
         const PtRec *pts = GP(const PtRec, s0, RS_PT);
         // wave-uniform 64-byte record: through the constant address space with the index in a scalar register -> s_load_dwordx16 (see PT())
-        q.rec = __builtin_bit_cast(PtRec, *(cptr_t<v16i_t>) ((unsigned long long) pts + (unsigned long long) ((unsigned) __builtin_amdgcn_readfirstlane((int) p) * (unsigned) sizeof(PtRec))));
+        const unsigned pU = (unsigned) __builtin_amdgcn_readfirstlane((int) p);
+        q.rec = __builtin_bit_cast(PtRec, *(cptr_t<v16i_t>) ((unsigned long long) pts + (unsigned long long) (pU * (unsigned) sizeof(PtRec))));
 #pragma unroll
         for (int g = 0; g < NSG; g++) {
-            const unsigned slot = p * FS + g * 8 + s;
-            const v2f_t e = AT(slots, slot * 8 + k);
+            const v2f_t e = AT(slots + (size_t) pU * FS * 8, (g * 8 + s) * 8 + k);
             q.jp[g] = e.x; q.m[g] = e.y;
         }
     }
