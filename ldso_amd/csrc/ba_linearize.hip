@@ -191,6 +191,9 @@ template <> struct at_sel<false> {
 #ifndef LD_GLOBAL_TAPS
 #define LD_GLOBAL_TAPS 0
 #endif
+#ifndef LD_PIPE
+#define LD_PIPE 0          // 1: software-pipelined point loop of the descriptor-based one-slot-group kernel (see linearize_body)
+#endif
 template <class T> using cptr_t = const __attribute__((address_space(4))) T *;
 
 typedef int v4i32_t __attribute__((ext_vector_type(4)));
@@ -347,6 +350,10 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
     const int ox = (k == 1 || k == 6) ? -1 : (k == 2) ? 1 : (k == 3) ? -2 : (k == 5) ? 2 : 0;     // staticPattern[8], Setting.cc:221
     const int oy = (k == 0) ? -2 : (k == 1 || k == 2) ? -1 : (k == 6) ? 1 : (k == 7) ? 2 : 0;
     const int W = D.w;
+    // loop invariants of the descriptor as values: a store through a pointer the compiler cannot tell apart would otherwise force re-loads
+    const float wM3G = D.wM3G, hM3G = D.hM3G;
+    const unsigned GSu = (unsigned) D.GS;
+    ldso_rawjac_t *const dumpJ = B.dumpJ;
     const int a16 = (lane ^ 16) << 2, a32 = (lane ^ 32) << 2;      // ds_bpermute addresses of sum_slots
 
     // top accumulators (13x13 symmetric block per slot), distributed over the 8 pattern lanes of the slot: lane k owns row k
@@ -362,17 +369,84 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
     float nidSum = 0.0f;
     int nidCnt = 0;
 
-#pragma clang loop unroll(disable)
-    for (; pi < np; pi += LD_WAVES) {
+    // ---- LD_PIPE: software pipeline over the points of a wavefront (one slot group, plain GN pass) ----------------------------------------
+    // front(i + 1) - record, fused point step, projection, TAP LOADS - is issued before the arithmetic of point i, so the tap latency of a
+    // point overlaps the arithmetic and the stores of its predecessor and the record latency overlaps the predecessor's tap latency.  What
+    // crosses from the front to the back half is small: the record, the stepped inverse depth and the 12 tap values (the back half redoes the
+    // projection - same inputs, same bits - instead of carrying ~25 registers of it).  Needs the record layout (13 vector memory operations per
+    // point: two points in flight stay far below the 63 the counter tracks) and taps through GLOBAL addresses (a flat load also ticks
+    // lgkmcnt, and every LDS permute of the next front half would wait for the taps in flight).
+    constexpr bool PIPE = (LD_PIPE != 0) && DESC && NSG == 1 && !HAS_L && !FIX && !MARG;
+    struct FrontT { PtIn<NSG> q; float idp, idz; float tap[NSG][12]; };
+    auto front = [&](FrontT &f, const unsigned p, const bool load) {
+        if (load) load_point<NSG, HAS_L, FIX, DESC>(f.q, B, cur, FS, p, s, k, stepMode);
+        const PtIn<NSG> &q = f.q;
+        float idp = q.idp, idz = q.idz;
+        float lo_, hiState, hiActive;
+        group_bcast_pair<1>(q.m[0], k, lo_, hiState); group_bcast_pair<2>(q.m[0], k, lo_, hiActive);
+        const int qState0 = __builtin_bit_cast(int, hiState), qActive0 = __builtin_bit_cast(int, hiActive);
+        const int t = s;
+        if (stepMode & 1) {          // the fused point step, exactly as in the body below
+            float step = 0.0f;
+            if (q.rec.nActive > 0) {
+                float b = q.rec.bdSumF;
+                float dot = 0;
+                dot += xc0 * (q.rec.HcdA[0] + q.rec.HcdL[0]); dot += xc1 * (q.rec.HcdA[1] + q.rec.HcdL[1]); dot += xc2 * (q.rec.HcdA[2] + q.rec.HcdL[2]); dot += xc3 * (q.rec.HcdA[3] + q.rec.HcdL[3]);
+                b -= dot;
+                const bool act = (t < F) && (q.rflat[0] >= 0) && (qActive0 != 0);
+                float sres = seq8(sXa[t * 8 + k] * q.jp[0], k, lane);
+                sres = act ? sres : 0.0f;
+                b -= sum_slots<(LD_PERM_DESC != 0)>(sres, a16, a32);
+                if (isfinite(b)) step = -b * q.rec.HdiF; else { step = q.pstep; if (lane == 0) *(gptr_t<double>) (unsigned long long) (B.scalars + 4) = 1.0; }
+            }
+            const float ni = idp + 1.0f * step;
+            const v16i_t b0 = ldg16<DESC, OFF_B0>(&B);
+            v4f_t *w_geo = GP(v4f_t, b0, BP_GEO);
+            if (lane == 1 || lane == 2) {
+                v4f_t v;
+                v.x = (lane == 1) ? ni : q.rec.HdiF; v.y = (lane == 1) ? ni : q.rec.bdSumF; v.z = (lane == 1) ? step : q.rec.idH; v.w = (lane == 1) ? idp : 0.0f;
+                AT(w_geo, p * 4 + (unsigned) lane) = v;
+            }
+            idp = ni; idz = ni;
+        }
+        f.idp = idp; f.idz = idz;
+        // the projection of the body below, only as far as the tap addresses need it
+        const bool exists = (t < F) && (q.rflat[0] >= 0);
+        const bool isLin = exists && (q.rlin[0] != 0);
+        const bool reset = (stepMode & 2) && !isLin;
+        const int st = exists ? (reset ? RES_IN : qState0) : RES_OOB;
+        const bool compute = exists && !isLin && st != RES_OOB;
+        const DevPair &pr = sPair[t];
+        const float pu = q.pu, pv = q.pv;
+        float KliP0 = (pu + 0 - cx) * fxi, KliP1 = (pv + 0 - cy) * fyi;
+        float ptp0 = ((pr.R0[0] * KliP0 + pr.R0[1] * KliP1) + pr.R0[2] * 1.0f) + pr.t0[0] * idz;
+        float ptp1 = ((pr.R0[3] * KliP0 + pr.R0[4] * KliP1) + pr.R0[5] * 1.0f) + pr.t0[1] * idz;
+        float ptp2 = ((pr.R0[6] * KliP0 + pr.R0[7] * KliP1) + pr.R0[8] * 1.0f) + pr.t0[2] * idz;
+        float drescale = 1.0f / ptp2;
+        float uu = ptp0 * drescale, vv = ptp1 * drescale;
+        float cKu = uu * fx + cx, cKv = vv * fy + cy;
+        const bool centerOK = (drescale > 0) && cKu > 1.1f && cKv > 1.1f && cKu < wM3G && cKv < hM3G;
+        float px_ = pu + (float) ox, py_ = pv + (float) oy;
+        float q0 = ((pr.KRKi[0] * px_ + pr.KRKi[1] * py_) + pr.KRKi[2] * 1.0f) + pr.Kt[0] * idp;
+        float q1 = ((pr.KRKi[3] * px_ + pr.KRKi[4] * py_) + pr.KRKi[5] * 1.0f) + pr.Kt[1] * idp;
+        float q2 = ((pr.KRKi[6] * px_ + pr.KRKi[7] * py_) + pr.KRKi[8] * 1.0f) + pr.Kt[2] * idp;
+        float Ku = q0 / q2, Kv = q1 / q2;
+        const bool pixOK = Ku > 1.1f && Kv > 1.1f && Ku < wM3G && Kv < hM3G;
+        {
+            // UNCONDITIONAL loads (a lane without a valid projection reads pixel (0, 0) of frame 0 and ignores it): loads under a divergent branch
+            // make the compiler's wait for the PREVIOUS point's taps a vmcnt(0), which would also drain these
+            const bool ok = compute && centerOK && pixOK;
+            const int ix = ok ? (int) Ku : 0, iy = ok ? (int) Kv : 0;
+            const gptr_t<const float> bp = (gptr_t<const float>) (unsigned long long) sImg[ok ? t : 0] + 3 * (ix + iy * W);
+            const gptr_t<const float> bq = bp + 3 * W;
+#pragma unroll
+            for (int i = 0; i < 6; i++) { f.tap[0][i] = bp[i]; f.tap[0][6 + i] = bq[i]; }
+        }
+    };
+
+    // one point: `fr` = its front half when pipelined (nullptr otherwise)
+    auto point_body = [&](const unsigned p, const PtIn<NSG> &q, const FrontT *fr) {
         if (pi == wave) LSTAMP(2);
-        const unsigned p = (unsigned) (p0 + pi);
-#if LD_PREFETCH
-        const PtIn<NSG> q = nx;
-        if (pi + LD_WAVES < np) load_point<NSG, HAS_L, FIX, DESC>(nx, B, cur, FS, p + LD_WAVES, s, k, stepMode);
-#else
-        if (pi != wave) load_point<NSG, HAS_L, FIX, DESC>(nx, B, cur, FS, p, s, k, stepMode);       // the first record was loaded before the staging
-        const PtIn<NSG> &q = nx;
-#endif
         // the uniform scalars of each slot record sit in the m of lanes 3 (energy), 5 (state), 6 (activity) of its 8-lane group
         int qState[NSG], qActive[NSG];
         float qEnergy[NSG];
@@ -387,7 +461,8 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
         const bool flagged = MARG ? (margFlags[p] != 0) : true;
         const float color = q.color, wgt = q.wgt;
         float idp = q.idp, idz = q.idz;
-        if (stepMode & 1) {
+        if (PIPE) { idp = fr->idp; idz = fr->idz; }
+        else if (stepMode & 1) {
             // ---- resubstituteFPt for this point, then backupState + doStepFromBackup (stepfacD = 1) ------------
             float step = 0.0f;
             if (q.rec.nActive > 0) {
@@ -403,7 +478,7 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
                     sres = act ? sres : 0.0f;
                     b -= sum_slots<DESC ? (LD_PERM_DESC != 0) : (LD_PERM_ARGS != 0)>(sres, a16, a32);
                 }
-                if (isfinite(b)) step = -b * q.rec.HdiF; else { step = q.pstep; if (lane == 0) B.scalars[4] = 1.0; }
+                if (isfinite(b)) step = -b * q.rec.HdiF; else { step = q.pstep; if (lane == 0) *(gptr_t<double>) (unsigned long long) (B.scalars + 4) = 1.0; }
             }
             const float ni = idp + 1.0f * step;
             {
@@ -465,14 +540,14 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
             float new_idepth = idz * drescale;
             float uu = ptp0 * drescale, vv = ptp1 * drescale;
             float cKu = uu * fx + cx, cKv = vv * fy + cy;
-            bool centerOK = (drescale > 0) && cKu > 1.1f && cKv > 1.1f && cKu < D.wM3G && cKv < D.hM3G;
+            bool centerOK = (drescale > 0) && cKu > 1.1f && cKv > 1.1f && cKu < wM3G && cKv < hM3G;
             // ---- pattern pixel projection at the current state (ResidualProjections.h:24-33) ---------
             float px_ = pu + (float) ox, py_ = pv + (float) oy;
             float q0 = ((pr.KRKi[0] * px_ + pr.KRKi[1] * py_) + pr.KRKi[2] * 1.0f) + pr.Kt[0] * idp;
             float q1 = ((pr.KRKi[3] * px_ + pr.KRKi[4] * py_) + pr.KRKi[5] * 1.0f) + pr.Kt[1] * idp;
             float q2 = ((pr.KRKi[6] * px_ + pr.KRKi[7] * py_) + pr.KRKi[8] * 1.0f) + pr.Kt[2] * idp;
             float Ku = q0 / q2, Kv = q1 / q2;
-            bool pixOK = Ku > 1.1f && Kv > 1.1f && Ku < D.wM3G && Kv < D.hM3G;
+            bool pixOK = Ku > 1.1f && Kv > 1.1f && Ku < wM3G && Kv < hM3G;
             if (pi == wave && g == 0) LSTAMP(3);
             // ---- bilinear Vec3f sample of the target image (GlobalFuncs.h:89-103) ---------------------
             float hit0 = 0, hit1 = 0, hit2 = 0;
@@ -481,7 +556,14 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
                 float dx = Ku - ix, dy = Kv - iy, dxdy = dx * dy;
                 // descriptor in memory: the pointer from LDS; kernel arguments: the table sits in scalar registers, selected per lane
                 float a0, a1, a2, b0_, b1, b2, c0_, c1_, c2_, d0, d1, d2;
-                if constexpr (DESC && (LD_GLOBAL_TAPS != 0)) {
+                if constexpr (PIPE) {          // loaded by the front half
+                    const float *tp = fr->tap[g];
+                    a0 = tp[0]; a1 = tp[1]; a2 = tp[2]; b0_ = tp[3]; b1 = tp[4]; b2 = tp[5]; c0_ = tp[6]; c1_ = tp[7]; c2_ = tp[8]; d0 = tp[9]; d1 = tp[10]; d2 = tp[11];
+                    // opaque to the compiler up to here: it must not start re-packing the freshly loaded values for packed arithmetic right
+                    // behind the loads (that re-packing is a use, and a use is a wait)
+                    asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(b0_), "+v"(b1), "+v"(b2));
+                    asm volatile("" : "+v"(c0_), "+v"(c1_), "+v"(c2_), "+v"(d0), "+v"(d1), "+v"(d2));
+                } else if constexpr (DESC && (LD_GLOBAL_TAPS != 0)) {
                     // experiment: the image pointer is a per-lane value from LDS, i.e. generic to the compiler -> FLAT loads, which tick lgkmcnt as
                     // well as vmcnt (every LDS wait then also waits for the taps).  Images are hipMalloc'ed: address them as global memory.
                     const gptr_t<const float> bp = (gptr_t<const float>) (unsigned long long) sImg[t] + 3 * (ix + iy * W);
@@ -739,8 +821,8 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
                     if (doLin) energySum += ret;
                 }
             }
-            if (B.dumpJ != nullptr && compute) {
-                ldso_rawjac_t &o = B.dumpJ[q.rflat[g]];
+            if (dumpJ != nullptr && compute) {
+                auto &o = *(gptr_t<ldso_rawjac_t>) (unsigned long long) (dumpJ + q.rflat[g]);          // global, not flat: a pending flat access makes every later wait a vmcnt(0)
                 o.resF[k] = resF; o.JIdx[0][k] = gx; o.JIdx[1][k] = gy; o.JabF[0][k] = jab0; o.JabF[1][k] = jab1;
                 if (k == 0) {
                     for (int i = 0; i < 6; i++) { o.Jpdxi[0][i] = x[4 + i]; o.Jpdxi[1][i] = y[4 + i]; }
@@ -769,7 +851,7 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
         {
             const v16i_t o0 = ldg16<DESC, OFF_S0>(&nxt);
             float *Gall = GP(float, o0, RS_G);
-            const unsigned g0 = p * (unsigned) D.GS;              // P * GS floats stay far below 2^32 bytes
+            const unsigned g0 = p * GSu;              // P * GS floats stay far below 2^32 bytes
 #pragma unroll
             for (int g = 0; g < NSG; g++) {
                 const int t = g * 8 + s;
@@ -797,6 +879,30 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
                 AT(o_acc, p) = v;
             }
             if (lane == 0) { nidSum += fabsf(idp); nidCnt++; }
+        }
+    };   // point_body
+
+    if constexpr (PIPE) {
+        FrontT fa, fb;
+        fa.q = nx;                                   // the first record was loaded before the staging
+        if (pi < np) front(fa, (unsigned) (p0 + pi), false);
+        while (pi < np) {                            // two points per trip: the two front buffers alternate without register copies
+            const bool more = pi + LD_WAVES < np;    // wave-uniform
+            if (more) front(fb, (unsigned) (p0 + pi + LD_WAVES), true);
+            point_body((unsigned) (p0 + pi), fa.q, &fa);
+            pi += LD_WAVES;
+            if (!more) break;
+            const bool more2 = pi + LD_WAVES < np;
+            if (more2) front(fa, (unsigned) (p0 + pi + LD_WAVES), true);
+            point_body((unsigned) (p0 + pi), fb.q, &fb);
+            pi += LD_WAVES;
+        }
+    } else {
+#pragma clang loop unroll(disable)
+        for (; pi < np; pi += LD_WAVES) {
+            const unsigned p = (unsigned) (p0 + pi);
+            if (pi != wave) load_point<NSG, HAS_L, FIX, DESC>(nx, B, cur, FS, p, s, k, stepMode);       // the first record was loaded before the staging
+            point_body(p, nx, nullptr);
         }
     }   // points of this wave
 
