@@ -883,20 +883,22 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
     };   // point_body
 
     if constexpr (PIPE) {
+        // Steady state and tail are SEPARATE copies of the arithmetic: the compiler's wait for a point's taps is the minimum over all paths that
+        // reach it, and on the path without a successor (single point, last point) those taps are the most recent loads - sharing the code
+        // would make the steady-state wait drain the successor's taps as well.
         FrontT fa, fb;
         fa.q = nx;                                   // the first record was loaded before the staging
         if (pi < np) front(fa, (unsigned) (p0 + pi), false);
-        while (pi < np) {                            // two points per trip: the two front buffers alternate without register copies
-            const bool more = pi + LD_WAVES < np;    // wave-uniform
-            if (more) front(fb, (unsigned) (p0 + pi + LD_WAVES), true);
+        while (pi + LD_WAVES < np) {                 // a successor exists (wave-uniform); two points per trip: the buffers alternate without copies
+            front(fb, (unsigned) (p0 + pi + LD_WAVES), true);
             point_body((unsigned) (p0 + pi), fa.q, &fa);
             pi += LD_WAVES;
-            if (!more) break;
-            const bool more2 = pi + LD_WAVES < np;
-            if (more2) front(fa, (unsigned) (p0 + pi + LD_WAVES), true);
+            if (!(pi + LD_WAVES < np)) { fa = fb; break; }
+            front(fa, (unsigned) (p0 + pi + LD_WAVES), true);
             point_body((unsigned) (p0 + pi), fb.q, &fb);
             pi += LD_WAVES;
         }
+        if (pi < np) { point_body((unsigned) (p0 + pi), fa.q, &fa); pi += LD_WAVES; }
     } else {
 #pragma clang loop unroll(disable)
         for (; pi < np; pi += LD_WAVES) {
