@@ -887,14 +887,20 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
         // reach it, and on the path without a successor (single point, last point) those taps are the most recent loads - sharing the code
         // would make the steady-state wait drain the successor's taps as well.
         FrontT fa, fb;
+        PtIn<NSG> qn;                                // the record one point further ahead: in flight during a whole back half
         fa.q = nx;                                   // the first record was loaded before the staging
         if (pi < np) front(fa, (unsigned) (p0 + pi), false);
+        if (pi + LD_WAVES < np) load_point<NSG, HAS_L, FIX, DESC>(qn, B, cur, FS, (unsigned) (p0 + pi + LD_WAVES), s, k, stepMode);
         while (pi + LD_WAVES < np) {                 // a successor exists (wave-uniform); two points per trip: the buffers alternate without copies
-            front(fb, (unsigned) (p0 + pi + LD_WAVES), true);
+            // the record after the successor's - UNCONDITIONALLY (the successor's once more when there is none: a branch around the loads would
+            // again make the wait below the minimum over two paths)
+            fb.q = qn; front(fb, (unsigned) (p0 + pi + LD_WAVES), false);
+            { const int nn = (pi + 2 * LD_WAVES < np) ? pi + 2 * LD_WAVES : pi + LD_WAVES; load_point<NSG, HAS_L, FIX, DESC>(qn, B, cur, FS, (unsigned) (p0 + nn), s, k, stepMode); }
             point_body((unsigned) (p0 + pi), fa.q, &fa);
             pi += LD_WAVES;
             if (!(pi + LD_WAVES < np)) { fa = fb; break; }
-            front(fa, (unsigned) (p0 + pi + LD_WAVES), true);
+            fa.q = qn; front(fa, (unsigned) (p0 + pi + LD_WAVES), false);
+            { const int nn = (pi + 2 * LD_WAVES < np) ? pi + 2 * LD_WAVES : pi + LD_WAVES; load_point<NSG, HAS_L, FIX, DESC>(qn, B, cur, FS, (unsigned) (p0 + nn), s, k, stepMode); }
             point_body((unsigned) (p0 + pi), fb.q, &fb);
             pi += LD_WAVES;
         }
