@@ -666,7 +666,7 @@ static int launch_linearize(ldso_ba *H, bool fix, int stepMode, int itCheck) {
     t_begin(H, 0);
     GnInit gi; gi.enable = (H->D.pBegin > 0) ? 2 : 1; gi.hasPrior = H->hasPrior ? 1 : 0; gi.calibPrior = H->settings.initialCalibHessian; gi.itCheck = itCheck;
     static const bool descAll = getenv("LDSO_LIN_DESC") != nullptr;      // kernel experiments: the descriptor-based kernel for two slot groups as well
-    if (!fix && !H->hasL && gi.enable == 1 && (H->D.FS == 8 || descAll)) {      // (two slot groups, F > 8: the argument-based kernel is the faster one, 43.0 against 45.6 us at C5)
+    if (!fix && !H->hasL && gi.enable == 1 && (H->D.FS == 8 || descAll) && H->B.dumpJ == nullptr) {      // (two slot groups, F > 8: the argument-based kernel is the faster one, 43.0 against 45.6 us at C5)
         // the plain linearisation (GN iterations): descriptors from device memory (k_linearize_batch with one window)
         { const int r_ = refresh_item(H); if (r_ != LDSO_OK) return r_; }
         CHK(ba_launch_linearize_batch(H->d_item, H->d_blocks, H->D.nChunks, H->D.FS, H->cur, H->settings, stepMode, gi.calibPrior, H->stream, itCheck));

@@ -806,7 +806,7 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
             if (FIX) { float m = maxRelBS; m = fmaxf(m, __shfl_xor(m, 8, 64)); m = fmaxf(m, __shfl_xor(m, 16, 64)); m = fmaxf(m, __shfl_xor(m, 32, 64)); maxRelBS = m; }
 
             // ---- per-slot outputs: the slot's SlotRec of the next set, lane k stores its own pair (one dwordx2 store per lane) ------------
-            if (t < F) {
+            if (PIPE || t < F) {          // pipelined: also the padding slots (t >= F) store their (constant: no residual) record - one branch less in front of the stores
                 const v16i_t o0 = ldg16<DESC, OFF_S0>(&nxt);
                 v2f_t *o_slot = GP(v2f_t, o0, RS_SLOT);
                 float *o_cand = GP(float, o0, RS_CAND);
@@ -821,7 +821,7 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
                     if (doLin) energySum += ret;
                 }
             }
-            if (dumpJ != nullptr && compute) {
+            if (!PIPE && dumpJ != nullptr && compute) {          // (the pipelined kernel keeps its store count static: no dump - the host launches the plain kernel for it)
                 auto &o = *(gptr_t<ldso_rawjac_t>) (unsigned long long) (dumpJ + q.rflat[g]);          // global, not flat: a pending flat access makes every later wait a vmcnt(0)
                 o.resF[k] = resF; o.JIdx[0][k] = gx; o.JIdx[1][k] = gy; o.JabF[0][k] = jab0; o.JabF[1][k] = jab1;
                 if (k == 0) {
