@@ -89,6 +89,17 @@ struct alignas(64) PtGeo {
 };
 static_assert(sizeof(PtGeo) == 64, "PtGeo is one 64-byte line");
 struct PtCw { float color, weight; };
+// the lane <-> dword maps the kernels rely on (ba_linearize.hip: load_point, the slot / point stores)
+#include <stddef.h>
+static_assert(offsetof(SlotRec, e[3].m) == 8 * 3 + 4 && offsetof(SlotRec, e[7].jp) == 56, "SlotRec: lane k owns dwords 2k (JpJdF[k]) and 2k+1 (scalar k)");
+static_assert(sizeof(SlotTab) == 16 && offsetof(SlotTab, rlin) == 4 && offsetof(SlotTab, rnew) == 8 && offsetof(SlotTab, rlidx) == 12, "SlotTab: x = rflat, y = rlin, z = rnew, w = rlidx");
+static_assert(offsetof(PtRec, HdiF) == 0 && offsetof(PtRec, bdSumF) == 4 && offsetof(PtRec, idH) == 8 && offsetof(PtRec, nActive) == 12, "PtRec: lane 0's dwordx4");
+static_assert(offsetof(PtRec, HcdA) == 16 && offsetof(PtRec, HcdL) == 32 && offsetof(PtRec, maxRelBS) == 48 && offsetof(PtRec, numGood) == 52, "PtRec: lanes 1..3");
+static_assert(sizeof(PtAcc) == 16, "PtAcc: one dwordx4");
+static_assert(offsetof(PtGeo, u) == 0 && offsetof(PtGeo, v) == 4 && offsetof(PtGeo, priorF) == 8 && offsetof(PtGeo, idepth) == 16 && offsetof(PtGeo, idepth_zero) == 20
+              && offsetof(PtGeo, step) == 24 && offsetof(PtGeo, idepth_backup) == 28 && offsetof(PtGeo, lastHdiF) == 32 && offsetof(PtGeo, lastBdSumF) == 36 && offsetof(PtGeo, lastIdH) == 40,
+              "PtGeo: dwords 0..7 are the scalar load, lane 1 stores dwords 4..7, lane 2 dwords 8..11");
+static_assert(sizeof(PtCw) == 8, "PtCw: one dwordx2");
 
 // One of the two ping-pong sets (see header comment).
 struct ResSet {
