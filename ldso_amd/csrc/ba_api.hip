@@ -222,9 +222,7 @@ extern "C" {
 
 static int alloc_set(ldso_ba *H, ResSet &S) {
     const size_t P = H->maxP, FS = H->FSmax, PS = P * FS, C = H->maxChunks;
-    DA(S.state, PS); DA(S.active, PS); DA(S.energy, PS); DA(S.JpJdF, PS * 8); DA(S.newEnergyWO, PS); DA(S.center, PS * 3); DA(S.toRemove, PS);
-    DA(S.HdiF, P); DA(S.bdSumF, P); DA(S.idH, P); DA(S.HddA, P); DA(S.bdA, P); DA(S.HcdA, P * 4); DA(S.HddL, P); DA(S.bdL, P); DA(S.HcdL, P * 4);
-    DA(S.maxRelBS, P); DA(S.numGood, P); DA(S.nActive, P); DA(S.candE, P);
+    DA(S.slot, PS); DA(S.pt, P); DA(S.acc, P); DA(S.candE, P);
     DA(S.G, P * (8 * FS + LD_GEXTRA)); DA(S.topA, C * FS * LD_TOPN); DA(S.topL, C * FS * LD_TOPN);
     DA(S.chunkEnergy, C); DA(S.chunkCnt, C * 2); DA(S.chunkNID, C * 2);
     return LDSO_OK;
@@ -266,9 +264,8 @@ static int create_body(ldso_ba *H, int device, int w, int h, int max_frames, int
     DA(B.frames, F); DA(B.calib, 1); DA(B.pairs, F * F); DA(B.pairRt, F * F * 12);
     DA(B.adHost, F * F * 64); DA(B.adTarget, F * F * 64); DA(B.adHostF, F * F * 64); DA(B.adTargetF, F * F * 64);
     DA(B.nsProj, nmax * 7); DA(B.HM, nmax * nmax); DA(B.bM, nmax);
-    DA(B.pu, P); DA(B.pv, P); DA(B.pidepth, P); DA(B.pidepth_zero, P); DA(B.pidepth_backup, P); DA(B.pstep, P); DA(B.ppriorF, P); DA(B.pLastHdiF, P); DA(B.pLastBdSumF, P); DA(B.pLastIdH, P);
-    DA(B.pcolor, P * 8); DA(B.pweights, P * 8); DA(B.phost, P);
-    DA(B.rflat, P * FS); DA(B.rlin, P * FS); DA(B.rnew, P * FS); DA(B.rlidx, P * FS);
+    DA(B.pgeo, P); DA(B.pcw, P * 8); DA(B.phost, P);
+    DA(B.rtab, P * FS);
     DA(B.Jlin, P * FS); DA(B.rtz, P * FS * 8);
     DA(B.chunk_p0, H->maxChunks); DA(B.chunk_n, H->maxChunks); DA(B.chunk_host, H->maxChunks);
     DA(H->d_chunkStart, F + 2);
@@ -458,8 +455,8 @@ int ldso_ba_set_window(ldso_ba_t *H, int F, const int32_t *image_slot, int P, co
     REQ(nLin == 0 || (linJ && lin_rtz), "ldso_ba_set_window: linearised residual without linJ / lin_res_toZeroF");
     auto A16 = [](size_t b) { return (b + 15) & ~(size_t) 15; };
     const size_t tabBytes = A16(LD_XFER_MAX * sizeof(WinXfer));
-    const size_t need = tabBytes + 5 * A16((size_t) P * 4) + 2 * A16((size_t) P * 32) + A16((size_t) P * 4) + 4 * A16(PS * 4) + A16(nLin * sizeof(ldso_rawjac_t)) + A16(nLin * 32)
-                      + 3 * A16(PS * 4) + A16(PS * 32) + 64;
+    const size_t need = tabBytes + A16((size_t) P * sizeof(PtGeo)) + A16((size_t) P * 8 * sizeof(PtCw)) + A16((size_t) P * 4) + A16(PS * sizeof(SlotTab)) + A16(nLin * sizeof(ldso_rawjac_t)) + A16(nLin * 32)
+                      + A16(PS * sizeof(SlotRec)) + 64;
     if (need > H->stageCap) {
         CHK(hipStreamSynchronize(H->stream));
         if (H->h_stage) hipHostFree(H->h_stage);
@@ -471,59 +468,59 @@ int ldso_ba_set_window(ldso_ba_t *H, int F, const int32_t *image_slot, int P, co
         H->stageCap = cap;
     }
     WinStage W{H->h_stage, H->stageCap, tabBytes, reinterpret_cast<WinXfer *>(H->h_stage), 0};
-    float *pu = W.put(B.pu, P), *pv = W.put(B.pv, P), *pid = W.put(B.pidepth, P), *pidz = W.put(B.pidepth_zero, P), *ppr = W.put(B.ppriorF, P);
-    float *pcol = W.put(B.pcolor, (size_t) P * 8), *pwt = W.put(B.pweights, (size_t) P * 8);
+    PtGeo *geo = W.put(B.pgeo, P);
+    PtCw *pcw = W.put(B.pcw, (size_t) P * 8);
     int32_t *phost = W.put(B.phost, P);
-    int32_t *rflat = W.put(B.rflat, PS), *rlin = W.put(B.rlin, PS), *rnew = W.put(B.rnew, PS), *rlidx = W.put(B.rlidx, PS);
+    SlotTab *tab = W.put(B.rtab, PS);
     ldso_rawjac_t *Jl = W.put(B.Jlin, nLin);
     float *rtz = W.put(B.rtz, nLin * 8);
-    int32_t *st = W.put(H->sets[0].state, PS), *act = W.put(H->sets[0].active, PS);
-    float *en = W.put(H->sets[0].energy, PS), *jp = W.put(H->sets[0].JpJdF, PS * 8);
-    REQ(pu && pv && pid && pidz && ppr && pcol && pwt && phost && rflat && rlin && rnew && rlidx && Jl && rtz && st && act && en && jp, "ldso_ba_set_window: staging arena too small (internal)");
+    SlotRec *sr = W.put(H->sets[0].slot, PS);
+    REQ(geo && pcw && phost && tab && Jl && rtz && sr, "ldso_ba_set_window: staging arena too small (internal)");
     H->h_phost.resize(P);
     for (int i = 0; i < P; i++) {
-        pu[i] = pts[i].u; pv[i] = pts[i].v; pid[i] = pts[i].idepth; pidz[i] = pts[i].idepth_zero; ppr[i] = pts[i].priorF;
+        PtGeo g_;
+        memset(&g_, 0, sizeof(g_));           // step, the scalars of the last solve: zero
+        g_.u = pts[i].u; g_.v = pts[i].v; g_.priorF = pts[i].priorF; g_.idepth = pts[i].idepth; g_.idepth_zero = pts[i].idepth_zero; g_.idepth_backup = pts[i].idepth;
+        geo[i] = g_;
         REQ(pts[i].host >= 0 && pts[i].host < F, "ldso_ba_set_window: point host out of range");
         H->h_phost[i] = pts[i].host; phost[i] = pts[i].host;
-        memcpy(&pcol[(size_t) i * 8], pts[i].color, 32); memcpy(&pwt[(size_t) i * 8], pts[i].weights, 32);
+        for (int k = 0; k < 8; k++) pcw[(size_t) i * 8 + k] = PtCw{pts[i].color[k], pts[i].weights[k]};
     }
-    for (size_t q = 0; q < PS; q++) { rflat[q] = -1; rlin[q] = 0; rnew[q] = 0; rlidx[q] = -1; st[q] = LDSO_RES_OOB; act[q] = 0; en[q] = 0.f; }
-    memset(jp, 0, PS * 8 * sizeof(float));
+    memset(sr, 0, PS * sizeof(SlotRec));          // JpJdF, centre, energies, activity, removal flag: zero
+    for (size_t q = 0; q < PS; q++) { tab[q] = SlotTab{-1, 0, 0, -1}; sr[q].e[LD_SM_STATE].m.i = LDSO_RES_OOB; }
     H->flat2slot.assign(R, -1);
     size_t nl = 0;
     for (int i = 0; i < R; i++) {
         const ldso_residual_t &r = res[i];
         REQ(r.point >= 0 && r.point < P && r.target >= 0 && r.target < F && r.host == pts[r.point].host && r.target != r.host, "ldso_ba_set_window: bad residual indices");
         size_t slot = (size_t) r.point * FS + r.target;
-        REQ(rflat[slot] < 0, "ldso_ba_set_window: two residuals of one point target the same frame");
-        rflat[slot] = i; rlin[slot] = r.is_linearized ? 1 : 0; rnew[slot] = r.is_new ? 1 : 0;
-        st[slot] = r.state_state; act[slot] = r.is_active ? 1 : 0; en[slot] = r.state_energy;
+        REQ(tab[slot].rflat < 0, "ldso_ba_set_window: two residuals of one point target the same frame");
+        tab[slot].rflat = i; tab[slot].rlin = r.is_linearized ? 1 : 0; tab[slot].rnew = r.is_new ? 1 : 0;
+        sr[slot].e[LD_SM_STATE].m.i = r.state_state; sr[slot].e[LD_SM_ACTIVE].m.i = r.is_active ? 1 : 0; sr[slot].e[LD_SM_ENERGY].m.f = r.state_energy;
         H->flat2slot[i] = (int32_t) slot;
         if (r.is_linearized) {
-            rlidx[slot] = (int32_t) nl;
+            tab[slot].rlidx = (int32_t) nl;
             Jl[nl] = linJ[i];
             for (int k = 0; k < 8; k++) rtz[nl * 8 + k] = lin_rtz[(size_t) i * 8 + k];
             nl++;
             // takeData (Residuals.h:123-128)
             const ldso_rawjac_t &J = linJ[i];
             float v0 = J.JIdx2[0] * J.Jpdd[0] + J.JIdx2[1] * J.Jpdd[1], v1 = J.JIdx2[2] * J.Jpdd[0] + J.JIdx2[3] * J.Jpdd[1];
-            for (int k = 0; k < 6; k++) jp[slot * 8 + k] = J.Jpdxi[0][k] * v0 + J.Jpdxi[1][k] * v1;
-            jp[slot * 8 + 6] = J.JabJIdx[0] * J.Jpdd[0] + J.JabJIdx[1] * J.Jpdd[1];
-            jp[slot * 8 + 7] = J.JabJIdx[2] * J.Jpdd[0] + J.JabJIdx[3] * J.Jpdd[1];
+            for (int k = 0; k < 6; k++) sr[slot].e[k].jp = J.Jpdxi[0][k] * v0 + J.Jpdxi[1][k] * v1;
+            sr[slot].e[6].jp = J.JabJIdx[0] * J.Jpdd[0] + J.JabJIdx[1] * J.Jpdd[1];
+            sr[slot].e[7].jp = J.JabJIdx[2] * J.Jpdd[0] + J.JabJIdx[3] * J.Jpdd[1];
         }
     }
     D.nL = (int) nLin;
     H->hasL = D.nL > 0;
     H->cur = 0; H->pendingApply = false; H->appliedValid = false;
-    bool okT = W.again(B.pidepth_backup, pid, P);
-    okT = okT && W.again(H->sets[1].state, st, PS) && W.again(H->sets[1].active, act, PS) && W.again(H->sets[1].energy, en, PS) && W.again(H->sets[1].JpJdF, jp, PS * 8);
+    bool okT = W.again(H->sets[1].slot, sr, PS);
     for (int s_ = 0; s_ < 2; s_++) {
         ResSet &S = H->sets[s_];
-        okT = okT && W.zero(S.newEnergyWO, PS) && W.zero(S.center, PS * 3) && W.zero(S.toRemove, PS) && W.zero(S.maxRelBS, (size_t) P) && W.zero(S.numGood, (size_t) P)
-                  && W.zero(S.nActive, (size_t) P) && W.zero(S.G, (size_t) P * D.GS);
+        okT = okT && W.zero(S.pt, (size_t) P) && W.zero(S.acc, (size_t) P) && W.zero(S.G, (size_t) P * D.GS);
     }
     // a new window has a new dimension 8F+4: the marginalisation prior starts at zero (ldso_ba_set_prior follows when there is one)
-    okT = okT && W.zero(B.pstep, (size_t) P) && W.zero(B.pLastHdiF, (size_t) P) && W.zero(B.pLastBdSumF, (size_t) P) && W.zero(B.pLastIdH, (size_t) P) && W.zero(B.HM, (size_t) D.n * D.n) && W.zero(B.bM, (size_t) D.n) && W.zero(B.scalars, (size_t) 16)
+    okT = okT && W.zero(B.HM, (size_t) D.n * D.n) && W.zero(B.bM, (size_t) D.n) && W.zero(B.scalars, (size_t) 16)
               && W.zero(B.scPart, (size_t) LD_SC_SPLITS * H->GSP * H->GSP);
     REQ(okT, "ldso_ba_set_window: upload table overflow (internal)");
     H->hasPrior = false;
@@ -543,8 +540,9 @@ int ldso_ba_set_point_stats(ldso_ba_t *H, const float *maxRelBaseline, const int
     REQ(H && H->D.P > 0 && maxRelBaseline && numGoodResiduals, "ldso_ba_set_point_stats: bad arguments / no window");
     CHK(hipSetDevice(H->device));
     for (int s_ = 0; s_ < 2; s_++) {
-        CHK(hipMemcpyAsync(H->sets[s_].maxRelBS, maxRelBaseline, (size_t) H->D.P * 4, hipMemcpyHostToDevice, H->stream));
-        CHK(hipMemcpyAsync(H->sets[s_].numGood, numGoodResiduals, (size_t) H->D.P * 4, hipMemcpyHostToDevice, H->stream));
+        // one 4-byte field of every 64-byte PtRec: a strided copy
+        CHK(hipMemcpy2DAsync(&H->sets[s_].pt[0].maxRelBS, sizeof(PtRec), maxRelBaseline, 4, 4, (size_t) H->D.P, hipMemcpyHostToDevice, H->stream));
+        CHK(hipMemcpy2DAsync(&H->sets[s_].pt[0].numGood, sizeof(PtRec), numGoodResiduals, 4, 4, (size_t) H->D.P, hipMemcpyHostToDevice, H->stream));
     }
     CHK(hipStreamSynchronize(H->stream));
     return LDSO_OK;
@@ -668,7 +666,7 @@ static int launch_linearize(ldso_ba *H, bool fix, int stepMode, int itCheck) {
     t_begin(H, 0);
     GnInit gi; gi.enable = (H->D.pBegin > 0) ? 2 : 1; gi.hasPrior = H->hasPrior ? 1 : 0; gi.calibPrior = H->settings.initialCalibHessian; gi.itCheck = itCheck;
     static const bool descAll = getenv("LDSO_LIN_DESC") != nullptr;      // kernel experiments: the descriptor-based kernel for two slot groups as well
-    if (!fix && !H->hasL && gi.enable == 1 && (H->D.FS == 8 || descAll)) {      // (two slot groups, F > 8: the argument-based kernel is the faster one, 43.0 against 45.6 us at C5)
+    if (!fix && !H->hasL && gi.enable == 1 && (H->D.FS == 8 || descAll) && H->B.dumpJ == nullptr) {      // (two slot groups, F > 8: the argument-based kernel is the faster one, 43.0 against 45.6 us at C5)
         // the plain linearisation (GN iterations): descriptors from device memory (k_linearize_batch with one window)
         { const int r_ = refresh_item(H); if (r_ != LDSO_OK) return r_; }
         CHK(ba_launch_linearize_batch(H->d_item, H->d_blocks, H->D.nChunks, H->D.FS, H->cur, H->settings, stepMode, gi.calibPrior, H->stream, itCheck));
@@ -1501,22 +1499,23 @@ int ldso_ba_get_residuals(ldso_ba_t *H, ldso_res_out_t *out, int32_t *state_stat
     // "new" values come from the set written by the last linearize, applied values from the current set
     const ResSet &Sn = H->pendingApply ? H->sets[H->cur ^ 1] : H->sets[H->cur];
     const ResSet &Sc = H->sets[H->cur];
-    std::vector<int32_t> nst, cst, cact, trm;
-    std::vector<float> nen, nwo, cen, jp;
-    D2H(nst, Sn.state, PS); D2H(nen, Sn.energy, PS); D2H(nwo, Sn.newEnergyWO, PS); D2H(cen, Sn.center, PS * 3); D2H(jp, Sn.JpJdF, PS * 8);
-    D2H(cst, Sc.state, PS); D2H(cact, Sc.active, PS); D2H(trm, Sn.toRemove, PS);
+    std::vector<SlotRec> rn, rc;
+    D2H(rn, Sn.slot, PS);
+    if (&Sn != &Sc) D2H(rc, Sc.slot, PS);
     CHK(hipStreamSynchronize(H->stream));
+    const std::vector<SlotRec> &rcur = (&Sn != &Sc) ? rc : rn;
     for (int i = 0; i < H->R; i++) {
         size_t s = H->flat2slot[i];
+        const SlotRec &n_ = rn[s], &c_ = rcur[s];
         if (out) {
             ldso_res_out_t &o = out[i];
-            o.state_NewEnergy = nen[s]; o.state_NewEnergyWithOutlier = nwo[s]; o.state_NewState = nst[s];
-            for (int k = 0; k < 3; k++) o.centerProjectedTo[k] = cen[s * 3 + k];
-            for (int k = 0; k < 8; k++) o.JpJdF[k] = jp[s * 8 + k];
+            o.state_NewEnergy = n_.e[LD_SM_ENERGY].m.f; o.state_NewEnergyWithOutlier = n_.e[LD_SM_EWO].m.f; o.state_NewState = n_.e[LD_SM_STATE].m.i;
+            for (int k = 0; k < 3; k++) o.centerProjectedTo[k] = n_.e[LD_SM_CEN0 + k].m.f;
+            for (int k = 0; k < 8; k++) o.JpJdF[k] = n_.e[k].jp;
         }
-        if (state_state) state_state[i] = cst[s];
-        if (is_active) is_active[i] = cact[s];
-        if (to_remove) to_remove[i] = trm[s];
+        if (state_state) state_state[i] = c_.e[LD_SM_STATE].m.i;
+        if (is_active) is_active[i] = c_.e[LD_SM_ACTIVE].m.i;
+        if (to_remove) to_remove[i] = n_.e[LD_SM_REMOVE].m.i;
     }
     return LDSO_OK;
 }
@@ -1526,18 +1525,17 @@ int ldso_ba_get_points(ldso_ba_t *H, ldso_point_out_t *out) {
     CHK(hipSetDevice(H->device));
     const size_t P = H->D.P;
     const ResSet &S = H->sets[H->cur];
-    std::vector<float> step, HdiF, bd, idH, HddA, bdA, HcdA, HddL, bdL, HcdL, idp, mrb;
-    std::vector<int32_t> ng;
-    D2H(step, H->B.pstep, P); D2H(HdiF, H->B.pLastHdiF, P); D2H(bd, H->B.pLastBdSumF, P); D2H(idH, H->B.pLastIdH, P); D2H(HddA, S.HddA, P); D2H(bdA, S.bdA, P);
-    D2H(HcdA, S.HcdA, P * 4); D2H(HddL, S.HddL, P); D2H(bdL, S.bdL, P); D2H(HcdL, S.HcdL, P * 4); D2H(idp, H->B.pidepth, P);
-    D2H(mrb, S.maxRelBS, P); D2H(ng, S.numGood, P);
+    std::vector<PtGeo> geo;
+    std::vector<PtRec> pt;
+    std::vector<PtAcc> acc;
+    D2H(geo, H->B.pgeo, P); D2H(pt, S.pt, P); D2H(acc, S.acc, P);
     CHK(hipStreamSynchronize(H->stream));
     for (size_t i = 0; i < P; i++) {
         ldso_point_out_t &o = out[i];
-        o.step = step[i]; o.HdiF = HdiF[i]; o.bdSumF = bd[i]; o.idepth_hessian = idH[i]; o.Hdd_accAF = HddA[i]; o.bd_accAF = bdA[i];
-        o.Hdd_accLF = HddL[i]; o.bd_accLF = bdL[i];
-        for (int k = 0; k < 4; k++) { o.Hcd_accAF[k] = HcdA[i * 4 + k]; o.Hcd_accLF[k] = HcdL[i * 4 + k]; }
-        o.idepth = idp[i]; o.maxRelBaseline = mrb[i]; o.numGoodResiduals = ng[i];
+        o.step = geo[i].step; o.HdiF = geo[i].lastHdiF; o.bdSumF = geo[i].lastBdSumF; o.idepth_hessian = geo[i].lastIdH; o.Hdd_accAF = acc[i].HddA; o.bd_accAF = acc[i].bdA;
+        o.Hdd_accLF = acc[i].HddL; o.bd_accLF = acc[i].bdL;
+        for (int k = 0; k < 4; k++) { o.Hcd_accAF[k] = pt[i].HcdA[k]; o.Hcd_accLF[k] = pt[i].HcdL[k]; }
+        o.idepth = geo[i].idepth; o.maxRelBaseline = pt[i].maxRelBS; o.numGoodResiduals = pt[i].numGood;
     }
     return LDSO_OK;
 }

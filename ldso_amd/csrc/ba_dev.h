@@ -5,8 +5,9 @@
 //   frames[F]   DevFrame: eval point, state, backup, step, priors (double)                                  (<1 KB each)
 //   pairs[F*F]  DevPair at [host*F + target]: FrameFramePrecalc floats + adHTdeltaF + max frameEnergyTH    (144 B each)
 //   ad*[F*F]    adjoints at [host + target*F] (reference slot order), double and float copies
-//   points      SoA arrays of P entries
-//   residuals   dense slot table [P][FS], slot index == target frame idx, FS = F rounded up to 8
+//   points      SoA arrays of P entries (geometry, inverse depth) + one 64-byte PtRec per point and set (Schur scalars)
+//   residuals   dense slot table [P][FS], slot index == target frame idx, FS = F rounded up to 8: SlotTab (static, 16 B) and
+//               one 64-byte SlotRec per slot and set
 //   ResSet x2   ping-pong "applied" residual state + accumulator partials (linearize writes the other
 //               set; applyRes is a pointer swap, so a rejected LM step costs nothing)
 #pragma once
@@ -52,32 +53,67 @@ struct DevCalib {
     float pad_[4];
 };
 
+// ---- records (round 4): what a wavefront reads of a point / a residual slot arrives in FEW WIDE loads instead of ~30 four-byte arrays ----
+// One residual slot of a set, 64 bytes.  Interleaved so that lane k of the slot's 8-lane group loads (and stores) ONE dwordx2 holding
+// exactly its own pair: e[k].jp = component k of JpJdF, e[k].m = the k-th of the slot's eight scalars below.
+#define LD_SM_CEN0 0       // centerProjectedTo[0..2] in m of lanes 0..2 (the lanes that use them)
+#define LD_SM_ENERGY 3     // state_energy
+#define LD_SM_EWO 4        // state_NewEnergyWithOutlier of the pass that produced this set (-1: none)
+#define LD_SM_STATE 5      // ResState (int)
+#define LD_SM_ACTIVE 6     // isActiveAndIsGoodNEW (int)
+#define LD_SM_REMOVE 7     // (fix mode) residual became inactive -> host drops it (int)
+struct SlotRec {
+    struct { float jp; union { float f; int32_t i; } m; } e[8];
+};
+static_assert(sizeof(SlotRec) == 64, "SlotRec is one 64-byte line");
+// static part of a slot (set by ldso_ba_set_window), 16 bytes: one dwordx4 per 8-lane group
+struct SlotTab { int32_t rflat, rlin, rnew, rlidx; };
+// Per-point scalars of a set, 64 bytes: read with ONE scalar load (a wavefront works on one point: the address is wave-uniform), written by
+// lanes 0..3 as four dwordx4 of one store instruction.
+struct alignas(64) PtRec {
+    float HdiF, bdSumF, idH; int32_t nActive;        // lane 0
+    float HcdA[4];                                   // lane 1
+    float HcdL[4];                                   // lane 2
+    float maxRelBS; int32_t numGood; float pad_[2];  // lane 3
+};
+static_assert(sizeof(PtRec) == 64, "PtRec is one 64-byte line");
+struct PtAcc { float HddA, bdA, HddL, bdL; };        // accumulator scalars only the fetch functions read
+// Geometry and inverse depth of a point, 64 bytes.  Read with one scalar load (dwords 0..7); the fused point step rewrites dwords 4..11 with
+// two dwordx4 of one store instruction (lanes 1, 2).
+struct alignas(64) PtGeo {
+    float u, v, priorF, pad0_;                               // static (ldso_ba_set_window)
+    float idepth, idepth_zero, step, idepth_backup;          // PointHessian::{idepth, idepth_zero, step, idepth_backup}
+    float lastHdiF, lastBdSumF, lastIdH, pad1_;              // PointHessian::{HdiF, bdSumF, idepth_hessian} as the LAST solveSystemF left them (AccumulatedSCHessian.cc:9-51):
+                                                             // the PtRec copies belong to the NEXT solve (the fused linearize pass already holds the new linearisation's scalars)
+    float pad2_[4];
+};
+static_assert(sizeof(PtGeo) == 64, "PtGeo is one 64-byte line");
+struct PtCw { float color, weight; };
+// the lane <-> dword maps the kernels rely on (ba_linearize.hip: load_point, the slot / point stores)
+#include <stddef.h>
+static_assert(offsetof(SlotRec, e[3].m) == 8 * 3 + 4 && offsetof(SlotRec, e[7].jp) == 56, "SlotRec: lane k owns dwords 2k (JpJdF[k]) and 2k+1 (scalar k)");
+static_assert(sizeof(SlotTab) == 16 && offsetof(SlotTab, rlin) == 4 && offsetof(SlotTab, rnew) == 8 && offsetof(SlotTab, rlidx) == 12, "SlotTab: x = rflat, y = rlin, z = rnew, w = rlidx");
+static_assert(offsetof(PtRec, HdiF) == 0 && offsetof(PtRec, bdSumF) == 4 && offsetof(PtRec, idH) == 8 && offsetof(PtRec, nActive) == 12, "PtRec: lane 0's dwordx4");
+static_assert(offsetof(PtRec, HcdA) == 16 && offsetof(PtRec, HcdL) == 32 && offsetof(PtRec, maxRelBS) == 48 && offsetof(PtRec, numGood) == 52, "PtRec: lanes 1..3");
+static_assert(sizeof(PtAcc) == 16, "PtAcc: one dwordx4");
+static_assert(offsetof(PtGeo, u) == 0 && offsetof(PtGeo, v) == 4 && offsetof(PtGeo, priorF) == 8 && offsetof(PtGeo, idepth) == 16 && offsetof(PtGeo, idepth_zero) == 20
+              && offsetof(PtGeo, step) == 24 && offsetof(PtGeo, idepth_backup) == 28 && offsetof(PtGeo, lastHdiF) == 32 && offsetof(PtGeo, lastBdSumF) == 36 && offsetof(PtGeo, lastIdH) == 40,
+              "PtGeo: dwords 0..7 are the scalar load, lane 1 stores dwords 4..7, lane 2 dwords 8..11");
+static_assert(sizeof(PtCw) == 8, "PtCw: one dwordx2");
+
 // One of the two ping-pong sets (see header comment).
 struct ResSet {
-    // Field ORDER matters: the batched linearisation kernel fetches these pointers just in time, eight at a time, with one
-    // s_load_dwordx16 per group (ba_linearize.hip: LDG16) - a group is eight consecutive pointers, 64-byte blocks of this struct.
-    // ---- group S0: per residual slot [P*FS] ------------------------------------------------------------------------------
-    int32_t *state;        // ResState
-    int32_t *active;       // isActiveAndIsGoodNEW
-    float *energy;         // state_energy
-    float *JpJdF;          // [P*FS*8]
-    float *center;         // [P*FS*3] centerProjectedTo
-    float *newEnergyWO;    // state_NewEnergyWithOutlier of the linearize that produced this set (-1: none)
-    int32_t *toRemove;     // (fix mode) residual became inactive -> host drops it
+    // Field ORDER matters: the batched linearisation kernel fetches these pointers just in time with one s_load_dwordx16 (ba_linearize.hip:
+    // LDG16): the first eight pointers are one group (64 bytes).
+    SlotRec *slot;         // [P*FS]
+    PtRec *pt;             // [P]
+    PtAcc *acc;            // [P]
     float *candE;          // [P] newest-frame candidate energy for setNewFrameEnergyTH (-1: none)
-    // ---- group S1: per point [P] -----------------------------------------------------------------------------------------
-    float *HdiF, *bdSumF, *idH;
-    int32_t *nActive;
-    float *HcdA, *HcdL;    // [P*4]
-    float *maxRelBS;
-    int32_t *numGood;
-    // ---- group S2: per point, accumulator outputs of the fused linearize -------------------------------------------------
-    float *HddA, *bdA, *HddL, *bdL;
     float *G;              // [P][GS]  lifted Schur rows  g_p (8*FS frame entries + LD_GEXTRA)
     float *topA;           // [nChunks][FS][91]
     float *topL;           // [nChunks][FS][91]
     double *chunkEnergy;   // [nChunks]
-    // ---- group S3 --------------------------------------------------------------------------------------------------------
+    // ---- behind the group ------------------------------------------------------------------------------------------------
     int32_t *chunkCnt;     // [nChunks*2]  nres A, nres L
     float *chunkNID;       // [nChunks*2]  sum |idepth|, count   (doStepFromBackup statistics)
 };
@@ -98,19 +134,15 @@ struct BaPtrs {
     float *adHostF, *adTargetF;
     double *nsProj;                  // n*n projector onto the gauge nullspaces (reference ordering)
     double *HM, *bM;
-    // points.  Two groups of eight consecutive pointers (see ResSet): B0 = what a wave reads of a point, B1 = what the fused point step writes
-    float *pu, *pv, *pidepth, *pidepth_zero, *ppriorF, *pcolor, *pweights, *pstep;                  // ---- group B0
-    float *pidepth_backup;                                                                          // ---- group B1 (with the next seven)
-    float *pLastHdiF, *pLastBdSumF, *pLastIdH;    // PointHessian::{HdiF, bdSumF, idepth_hessian} as the LAST solveSystemF left them (AccumulatedSCHessian.cc:9-51): the
-                                                  // ResSet copies belong to the NEXT solve (the fused linearize pass already holds the new linearisation's Schur scalars)
-    // residual slots
-    int32_t *rflat, *rlin, *rnew, *rlidx;                                                           // (end of group B1)
-    int32_t *phost;
-    // linearised store
-    ldso_rawjac_t *Jlin;
+    // points and residual slots: ONE group of eight consecutive pointers (ba_linearize.hip: LDG16) - everything a wave reads / writes of a point
+    PtGeo *pgeo;                     // [P]     geometry + inverse depth + the scalars of the last solve, 64 bytes per point          ---- group B0
+    PtCw *pcw;                       // [P*8]   (colour, weight) of the 8 pattern pixels
+    SlotTab *rtab;                   // [P*FS]  residual slots: flat residual index (-1: none), linearised?, new?, index into Jlin / rtz
+    int32_t *phost;                  // [P]
+    ldso_rawjac_t *Jlin;             // linearised store
     float *rtz;
-    // chunks
-    int32_t *chunk_p0, *chunk_n, *chunk_host;
+    int32_t *chunk_p0, *chunk_n;                                                                    // (end of group B0)
+    int32_t *chunk_host;
     // solve-side buffers
     double *pairC;      // [F*F][PAIRC] lifted top contributions (A then L)
     float *scPart;      // [SC_SPLITS][n*(n+1)] Schur partials

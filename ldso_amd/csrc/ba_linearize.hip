@@ -132,13 +132,13 @@ template <bool DESC, int OFFA, int OFFB> static __device__ __forceinline__ void 
     else { __builtin_memcpy(&a, (const char *) baseA + OFFA, 64); __builtin_memcpy(&b, (const char *) baseB + OFFB, 64); }
 }
 #define GP(T, t16, i) ((T *) ((((unsigned long long) (unsigned) (t16)[2 * (i) + 1]) << 32) | (unsigned long long) (unsigned) (t16)[2 * (i)]))
-#define OFF_B0 ((int) offsetof(BaPtrs, pu))
-#define OFF_B1 ((int) offsetof(BaPtrs, pidepth_backup))
-#define OFF_S0 ((int) offsetof(ResSet, state))
-#define OFF_S1 ((int) offsetof(ResSet, HdiF))
-#define OFF_S2 ((int) offsetof(ResSet, HddA))
-static_assert(offsetof(BaPtrs, pstep) == offsetof(BaPtrs, pu) + 56 && offsetof(BaPtrs, rlidx) == offsetof(BaPtrs, pidepth_backup) + 56, "BaPtrs pointer groups (ba_dev.h)");
-static_assert(offsetof(ResSet, candE) == 56 && offsetof(ResSet, numGood) == offsetof(ResSet, HdiF) + 56 && offsetof(ResSet, chunkEnergy) == offsetof(ResSet, HddA) + 56, "ResSet pointer groups (ba_dev.h)");
+#define OFF_B0 ((int) offsetof(BaPtrs, pgeo))
+enum { BP_GEO = 0, BP_CW = 1, BP_RTAB = 2, BP_PHOST = 3, BP_JLIN = 4, BP_RTZ = 5 };      // indices of the BaPtrs pointers inside their group
+#define OFF_S0 ((int) offsetof(ResSet, slot))
+static_assert(offsetof(BaPtrs, chunk_n) == offsetof(BaPtrs, pgeo) + 56, "BaPtrs pointer group (ba_dev.h)");
+static_assert(offsetof(ResSet, slot) == 0 && offsetof(ResSet, chunkEnergy) == 56 && offsetof(ResSet, chunkCnt) == 64, "ResSet pointer group (ba_dev.h)");
+// indices of the ResSet pointers inside their group
+enum { RS_SLOT = 0, RS_PT = 1, RS_ACC = 2, RS_CAND = 3, RS_G = 4, RS_TOPA = 5, RS_TOPL = 6, RS_CHUNKE = 7 };
 
 // flat index of entry (r,c), r<=c, in the packed upper triangle of a 13x13 matrix
 __host__ __device__ constexpr int tri13(int r, int c) { return r * 13 - (r * (r - 1)) / 2 + (c - r); }
@@ -148,13 +148,11 @@ __host__ __device__ constexpr int tri13(int r, int c) { return r * 13 - (r * (r 
 // the LDS staging of the block, so a wave sees two dependent memory levels (this record, then the taps).
 template <int NSG>
 struct PtIn {
-    float pu, pv, idp, idz, priorF, color, wgt, maxRelBS;
-    int numGood;
-    int rflat[NSG], rlin[NSG], rnew[NSG], rlidx[NSG], state[NSG], active[NSG];
-    float energy[NSG], jp[NSG], cen[NSG];
-    // inputs of the fused point step (resubstituteFPt)
-    float pstep, bdSumF, HdiF, idH, hcd[4];
-    int nAct;
+    float pu, pv, idp, idz, priorF, color, wgt;
+    float pstep;                  // input of the fused point step (resubstituteFPt)
+    PtRec rec;                    // the point's Schur scalars of the applied set (one scalar load: scalar registers)
+    int rflat[NSG], rlin[NSG], rnew[NSG], rlidx[NSG];     // SlotTab of this lane's slot(s)
+    float jp[NSG], m[NSG];        // this lane's pair of the slot record: JpJdF[k] and scalar k (LD_SM_*; integers as raw bits)
 };
 
 // element i of a device array with the BYTE offset computed in 32 bits: base pointer (SGPR pair) + zero-extended
@@ -186,69 +184,69 @@ template <> struct at_sel<false> {
 #define LD_PERM_DESC 0      // measured (A/B, two rounds each on one box): 220.3 / 51.6 / 10.07 us (B = 32 / B = 8 / C3) with ds_bpermute against 225.2 / 52.7 / 10.17 us with the
 #endif                   // permlane butterflies below - their hand-placed s_nop pairs and the opaque asm cost more than the LDS round trips they save
 #define AT(ptr, i) (at_sel<DESC || LD_GLOBAL_ARGS>::ref((ptr), (unsigned) (i)))
-// a per-point entry (index wave-uniform): scalar load when LD_SCALAR_POINT and the descriptor-based kernel, else as AT
-#define PT(ptr, i) (pt_get<DESC && (LD_SCALAR_POINT != 0), DESC>((ptr), (unsigned) (i)))
-
-// LD_SCALAR_POINT (experiment, descriptor-based kernel only): the per-POINT entries of the record (22 of its 31 loads in a GN pass) have a
-// wave-uniform address - a wavefront works on one point at a time.  Read through a constant-address-space pointer with the index in an SGPR
-// they become scalar loads (s_load_dword, scalar cache): no vector memory instruction, no VGPR address, nothing on vmcnt.  Legal because no
-// wavefront reads an entry again after anybody has written it inside one launch (a point belongs to one wavefront; what it stores -
-// pidepth, pidepth_zero, pstep, the backup - depends on what it loaded), and the scalar cache is invalidated at the launch boundary.
-#ifndef LD_SCALAR_POINT
-#define LD_SCALAR_POINT 0
-#endif
+// Per-POINT data have a wave-uniform address - a wavefront works on one point at a time.  Read through a constant-address-space pointer with
+// the index in an SGPR they become scalar loads (s_load_dwordxN, scalar cache): no vector memory instruction, no VGPR address, nothing on
+// vmcnt.  Legal because no wavefront reads an entry again after anybody has written it inside one launch (a point belongs to one wavefront;
+// what it stores depends on what it loaded), and the scalar cache is invalidated at the launch boundary.
 #ifndef LD_GLOBAL_TAPS
 #define LD_GLOBAL_TAPS 0
 #endif
+#ifndef LD_PIPE
+#define LD_PIPE 0          // 1: software-pipelined point loop of the descriptor-based one-slot-group kernel (see linearize_body)
+#endif
 template <class T> using cptr_t = const __attribute__((address_space(4))) T *;
-template <bool SC> struct pt_sel;
-template <> struct pt_sel<true> {
-    template <class T> static __device__ __forceinline__ T get(const T *p, unsigned i) { return *(cptr_t<T>) ((unsigned long long) p + (unsigned long long) (i * (unsigned) sizeof(T))); }
-};
-template <> struct pt_sel<false> {
-    template <class T> static __device__ __forceinline__ T get(const T *p, unsigned i) { return *(const T *) ((const char *) p + (size_t) (i * (unsigned) sizeof(T))); }
-};
 
-template <bool SC, bool DESC_, class T> static __device__ __forceinline__ T pt_get(const T *p, unsigned i) {
-    if constexpr (SC) return pt_sel<true>::get(p, (unsigned) __builtin_amdgcn_readfirstlane((int) i));
-    else return at_sel<DESC_ || LD_GLOBAL_ARGS>::ref(p, i);
-}
+typedef int v4i32_t __attribute__((ext_vector_type(4)));
+typedef int v8i_t __attribute__((ext_vector_type(8)));
+typedef int v2i32_t __attribute__((ext_vector_type(2)));
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+typedef float v4f_t __attribute__((ext_vector_type(4)));
 
+// The record of one point as a wavefront needs it: the first half of its PtGeo and its PtRec (two scalar loads - the index is wave-uniform),
+// this lane's (colour, weight) pair (one dwordx2), and per slot group one dwordx4 (SlotTab, the same 16 bytes for the 8 lanes of a slot) and
+// one dwordx2 (this lane's pair of the 64-byte SlotRec): 1 + 2 NSG vector loads (round 3: 9 + 9 NSG + 13).
 template <int NSG, bool HAS_L, bool FIX, bool DESC>
 static __device__ __forceinline__ void load_point(PtIn<NSG> &q, const BaPtrs &B, const ResSet &cur, unsigned FS, unsigned p, unsigned s, unsigned k, int stepMode) {
     {
-        v16i_t b0, b1;
-        ldg16x2<DESC, OFF_B0, OFF_B1>(b0, &B, b1, &B);
-        const float *pu = GP(const float, b0, 0), *pv = GP(const float, b0, 1), *pid = GP(const float, b0, 2), *piz = GP(const float, b0, 3), *ppr = GP(const float, b0, 4);
-        const float *pco = GP(const float, b0, 5), *pwe = GP(const float, b0, 6), *pst = GP(const float, b0, 7);
-        const int32_t *rflat = GP(const int32_t, b1, 4), *rlin = GP(const int32_t, b1, 5), *rnew = GP(const int32_t, b1, 6), *rlidx = GP(const int32_t, b1, 7);
-        q.pu = PT(pu, p); q.pv = PT(pv, p); q.idp = PT(pid, p); q.idz = PT(piz, p); q.priorF = PT(ppr, p);
-        q.color = AT(pco, p * 8 + k); q.wgt = AT(pwe, p * 8 + k);
-        if (stepMode & 1) q.pstep = PT(pst, p);
+        const v16i_t b0 = ldg16<DESC, OFF_B0>(&B);
+        const PtGeo *geo = GP(const PtGeo, b0, BP_GEO);
+        const v2f_t *pcw = GP(const v2f_t, b0, BP_CW);
+        const v4i32_t *rtab = GP(const v4i32_t, b0, BP_RTAB);
+        // dwords 0..7 of the point's PtGeo (u, v, prior | idepth, idepth_zero, step): wave-uniform address -> ONE scalar load
+        const v8i_t g8 = *(cptr_t<v8i_t>) ((unsigned long long) geo + (unsigned long long) ((unsigned) __builtin_amdgcn_readfirstlane((int) p) * (unsigned) sizeof(PtGeo)));
+        q.pu = __builtin_bit_cast(float, g8[0]); q.pv = __builtin_bit_cast(float, g8[1]); q.priorF = __builtin_bit_cast(float, g8[2]);
+        q.idp = __builtin_bit_cast(float, g8[4]); q.idz = __builtin_bit_cast(float, g8[5]); q.pstep = __builtin_bit_cast(float, g8[6]);
+        // addresses = (uniform base advanced to the point, on the scalar side) + (a lane offset that never changes): no per-point VGPR address
+        // arithmetic, and no VGPR shared between one load's address and another load's destination (the allocator had put the slot-record
+        // address into a register of the SlotTab destination: a vmcnt(0) between the two loads, i.e. two serialised latencies)
+        const unsigned pU = (unsigned) __builtin_amdgcn_readfirstlane((int) p);
+        const v2f_t cw = AT(pcw + (size_t) pU * 8, k);
+        q.color = cw.x; q.wgt = cw.y;
 #pragma unroll
         for (int g = 0; g < NSG; g++) {
-            const unsigned slot = p * FS + g * 8 + s;       // slot tables are dense [P][FS]: every index is readable
-            q.rflat[g] = AT(rflat, slot); q.rlin[g] = AT(rlin, slot); q.rnew[g] = FIX ? AT(rnew, slot) : 0; q.rlidx[g] = HAS_L ? AT(rlidx, slot) : 0;
+            // slot tables are dense [P][FS]: every index is readable.  Only the half of the entry this variant uses is loaded: dead lanes of a
+            // wider destination get re-used by the allocator for the next load's address, which costs a vmcnt(0) between the two loads
+            if constexpr (FIX || HAS_L) {
+                const v4i32_t t4 = AT(rtab + (size_t) pU * FS, g * 8 + s);
+                q.rflat[g] = t4.x; q.rlin[g] = t4.y; q.rnew[g] = FIX ? t4.z : 0; q.rlidx[g] = HAS_L ? t4.w : 0;
+            } else {
+                const v2i32_t t2 = AT((const v2i32_t *) (rtab + (size_t) pU * FS), (g * 8 + s) * 2);
+                q.rflat[g] = t2.x; q.rlin[g] = t2.y; q.rnew[g] = 0; q.rlidx[g] = 0;
+            }
         }
+        (void) stepMode;
     }
     {
-        v16i_t s0, s1;
-        ldg16x2<DESC, OFF_S0, OFF_S1>(s0, &cur, s1, &cur);
-        const int32_t *state = GP(const int32_t, s0, 0), *active = GP(const int32_t, s0, 1);
-        const float *energy = GP(const float, s0, 2), *jp = GP(const float, s0, 3), *center = GP(const float, s0, 4);
-        const float *HdiF = GP(const float, s1, 0), *bdSumF = GP(const float, s1, 1), *idH_ = GP(const float, s1, 2), *HcdA = GP(const float, s1, 4), *HcdL = GP(const float, s1, 5), *maxRelBS = GP(const float, s1, 6);
-        const int32_t *nActive = GP(const int32_t, s1, 3), *numGood = GP(const int32_t, s1, 7);
-        q.maxRelBS = PT(maxRelBS, p); q.numGood = PT(numGood, p);
+        const v16i_t s0 = ldg16<DESC, OFF_S0>(&cur);
+        const v2f_t *slots = GP(const v2f_t, s0, RS_SLOT);
+        const PtRec *pts = GP(const PtRec, s0, RS_PT);
+        // wave-uniform 64-byte record: through the constant address space with the index in a scalar register -> s_load_dwordx16 (see PT())
+        const unsigned pU = (unsigned) __builtin_amdgcn_readfirstlane((int) p);
+        q.rec = __builtin_bit_cast(PtRec, *(cptr_t<v16i_t>) ((unsigned long long) pts + (unsigned long long) (pU * (unsigned) sizeof(PtRec))));
 #pragma unroll
         for (int g = 0; g < NSG; g++) {
-            const unsigned slot = p * FS + g * 8 + s;
-            q.state[g] = AT(state, slot); q.active[g] = AT(active, slot); q.energy[g] = AT(energy, slot);
-            q.jp[g] = AT(jp, slot * 8 + k); q.cen[g] = AT(center, slot * 3 + (k < 3 ? k : 2u));
-        }
-        if (stepMode & 1) {
-            q.bdSumF = PT(bdSumF, p); q.HdiF = PT(HdiF, p); q.idH = PT(idH_, p); q.nAct = PT(nActive, p);
-#pragma unroll
-            for (int i = 0; i < 4; i++) q.hcd[i] = PT(HcdA, p * 4 + i) + PT(HcdL, p * 4 + i);
+            const v2f_t e = AT(slots + (size_t) pU * FS * 8, (g * 8 + s) * 8 + k);
+            q.jp[g] = e.x; q.m[g] = e.y;
         }
     }
 }
@@ -352,6 +350,10 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
     const int ox = (k == 1 || k == 6) ? -1 : (k == 2) ? 1 : (k == 3) ? -2 : (k == 5) ? 2 : 0;     // staticPattern[8], Setting.cc:221
     const int oy = (k == 0) ? -2 : (k == 1 || k == 2) ? -1 : (k == 6) ? 1 : (k == 7) ? 2 : 0;
     const int W = D.w;
+    // loop invariants of the descriptor as values: a store through a pointer the compiler cannot tell apart would otherwise force re-loads
+    const float wM3G = D.wM3G, hM3G = D.hM3G;
+    const unsigned GSu = (unsigned) D.GS;
+    ldso_rawjac_t *const dumpJ = B.dumpJ;
     const int a16 = (lane ^ 16) << 2, a32 = (lane ^ 32) << 2;      // ds_bpermute addresses of sum_slots
 
     // top accumulators (13x13 symmetric block per slot), distributed over the 8 pattern lanes of the slot: lane k owns row k
@@ -367,47 +369,128 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
     float nidSum = 0.0f;
     int nidCnt = 0;
 
-    for (; pi < np; pi += LD_WAVES) {
+    // ---- LD_PIPE: software pipeline over the points of a wavefront (one slot group, plain GN pass) ----------------------------------------
+    // front(i + 1) - record, fused point step, projection, TAP LOADS - is issued before the arithmetic of point i, so the tap latency of a
+    // point overlaps the arithmetic and the stores of its predecessor and the record latency overlaps the predecessor's tap latency.  What
+    // crosses from the front to the back half is small: the record, the stepped inverse depth and the 12 tap values (the back half redoes the
+    // projection - same inputs, same bits - instead of carrying ~25 registers of it).  Needs the record layout (13 vector memory operations per
+    // point: two points in flight stay far below the 63 the counter tracks) and taps through GLOBAL addresses (a flat load also ticks
+    // lgkmcnt, and every LDS permute of the next front half would wait for the taps in flight).
+    constexpr bool PIPE = (LD_PIPE != 0) && DESC && NSG == 1 && !HAS_L && !FIX && !MARG;
+    struct FrontT { PtIn<NSG> q; float idp, idz; float tap[NSG][12]; };
+    auto front = [&](FrontT &f, const unsigned p, const bool load) {
+        if (load) load_point<NSG, HAS_L, FIX, DESC>(f.q, B, cur, FS, p, s, k, stepMode);
+        const PtIn<NSG> &q = f.q;
+        float idp = q.idp, idz = q.idz;
+        float lo_, hiState, hiActive;
+        group_bcast_pair<1>(q.m[0], k, lo_, hiState); group_bcast_pair<2>(q.m[0], k, lo_, hiActive);
+        const int qState0 = __builtin_bit_cast(int, hiState), qActive0 = __builtin_bit_cast(int, hiActive);
+        const int t = s;
+        if (stepMode & 1) {          // the fused point step, exactly as in the body below
+            float step = 0.0f;
+            if (q.rec.nActive > 0) {
+                float b = q.rec.bdSumF;
+                float dot = 0;
+                dot += xc0 * (q.rec.HcdA[0] + q.rec.HcdL[0]); dot += xc1 * (q.rec.HcdA[1] + q.rec.HcdL[1]); dot += xc2 * (q.rec.HcdA[2] + q.rec.HcdL[2]); dot += xc3 * (q.rec.HcdA[3] + q.rec.HcdL[3]);
+                b -= dot;
+                const bool act = (t < F) && (q.rflat[0] >= 0) && (qActive0 != 0);
+                float sres = seq8(sXa[t * 8 + k] * q.jp[0], k, lane);
+                sres = act ? sres : 0.0f;
+                b -= sum_slots<(LD_PERM_DESC != 0)>(sres, a16, a32);
+                if (isfinite(b)) step = -b * q.rec.HdiF; else { step = q.pstep; if (lane == 0) *(gptr_t<double>) (unsigned long long) (B.scalars + 4) = 1.0; }
+            }
+            const float ni = idp + 1.0f * step;
+            const v16i_t b0 = ldg16<DESC, OFF_B0>(&B);
+            v4f_t *w_geo = GP(v4f_t, b0, BP_GEO);
+            if (lane == 1 || lane == 2) {
+                v4f_t v;
+                v.x = (lane == 1) ? ni : q.rec.HdiF; v.y = (lane == 1) ? ni : q.rec.bdSumF; v.z = (lane == 1) ? step : q.rec.idH; v.w = (lane == 1) ? idp : 0.0f;
+                AT(w_geo, p * 4 + (unsigned) lane) = v;
+            }
+            idp = ni; idz = ni;
+        }
+        f.idp = idp; f.idz = idz;
+        // the projection of the body below, only as far as the tap addresses need it
+        const bool exists = (t < F) && (q.rflat[0] >= 0);
+        const bool isLin = exists && (q.rlin[0] != 0);
+        const bool reset = (stepMode & 2) && !isLin;
+        const int st = exists ? (reset ? RES_IN : qState0) : RES_OOB;
+        const bool compute = exists && !isLin && st != RES_OOB;
+        const DevPair &pr = sPair[t];
+        const float pu = q.pu, pv = q.pv;
+        float KliP0 = (pu + 0 - cx) * fxi, KliP1 = (pv + 0 - cy) * fyi;
+        float ptp0 = ((pr.R0[0] * KliP0 + pr.R0[1] * KliP1) + pr.R0[2] * 1.0f) + pr.t0[0] * idz;
+        float ptp1 = ((pr.R0[3] * KliP0 + pr.R0[4] * KliP1) + pr.R0[5] * 1.0f) + pr.t0[1] * idz;
+        float ptp2 = ((pr.R0[6] * KliP0 + pr.R0[7] * KliP1) + pr.R0[8] * 1.0f) + pr.t0[2] * idz;
+        float drescale = 1.0f / ptp2;
+        float uu = ptp0 * drescale, vv = ptp1 * drescale;
+        float cKu = uu * fx + cx, cKv = vv * fy + cy;
+        const bool centerOK = (drescale > 0) && cKu > 1.1f && cKv > 1.1f && cKu < wM3G && cKv < hM3G;
+        float px_ = pu + (float) ox, py_ = pv + (float) oy;
+        float q0 = ((pr.KRKi[0] * px_ + pr.KRKi[1] * py_) + pr.KRKi[2] * 1.0f) + pr.Kt[0] * idp;
+        float q1 = ((pr.KRKi[3] * px_ + pr.KRKi[4] * py_) + pr.KRKi[5] * 1.0f) + pr.Kt[1] * idp;
+        float q2 = ((pr.KRKi[6] * px_ + pr.KRKi[7] * py_) + pr.KRKi[8] * 1.0f) + pr.Kt[2] * idp;
+        float Ku = q0 / q2, Kv = q1 / q2;
+        const bool pixOK = Ku > 1.1f && Kv > 1.1f && Ku < wM3G && Kv < hM3G;
+        {
+            // UNCONDITIONAL loads (a lane without a valid projection reads pixel (0, 0) of frame 0 and ignores it): loads under a divergent branch
+            // make the compiler's wait for the PREVIOUS point's taps a vmcnt(0), which would also drain these
+            const bool ok = compute && centerOK && pixOK;
+            const int ix = ok ? (int) Ku : 0, iy = ok ? (int) Kv : 0;
+            const gptr_t<const float> bp = (gptr_t<const float>) (unsigned long long) sImg[ok ? t : 0] + 3 * (ix + iy * W);
+            const gptr_t<const float> bq = bp + 3 * W;
+#pragma unroll
+            for (int i = 0; i < 6; i++) { f.tap[0][i] = bp[i]; f.tap[0][6 + i] = bq[i]; }
+        }
+    };
+
+    // one point: `fr` = its front half when pipelined (nullptr otherwise)
+    auto point_body = [&](const unsigned p, const PtIn<NSG> &q, const FrontT *fr) {
         if (pi == wave) LSTAMP(2);
-        const unsigned p = (unsigned) (p0 + pi);
-#if LD_PREFETCH
-        const PtIn<NSG> q = nx;
-        if (pi + LD_WAVES < np) load_point<NSG, HAS_L, FIX, DESC>(nx, B, cur, FS, p + LD_WAVES, s, k, stepMode);
-#else
-        if (pi != wave) load_point<NSG, HAS_L, FIX, DESC>(nx, B, cur, FS, p, s, k, stepMode);       // the first record was loaded before the staging
-        const PtIn<NSG> &q = nx;
-#endif
+        // the uniform scalars of each slot record sit in the m of lanes 3 (energy), 5 (state), 6 (activity) of its 8-lane group
+        int qState[NSG], qActive[NSG];
+        float qEnergy[NSG];
+#pragma unroll
+        for (int g = 0; g < NSG; g++) {
+            float l1, h1, l2, h2, l3, h3;
+            group_bcast_pair<1>(q.m[g], k, l1, h1); group_bcast_pair<2>(q.m[g], k, l2, h2); group_bcast_pair<3>(q.m[g], k, l3, h3);
+            qState[g] = __builtin_bit_cast(int, h1); qActive[g] = __builtin_bit_cast(int, h2); qEnergy[g] = l3;
+            (void) l1; (void) l2; (void) h3;
+        }
         const float pu = q.pu, pv = q.pv, priorF = MARG ? q.priorF * S.idepthFixPriorMargFac : q.priorF;
         const bool flagged = MARG ? (margFlags[p] != 0) : true;
         const float color = q.color, wgt = q.wgt;
         float idp = q.idp, idz = q.idz;
-        if (stepMode & 1) {
+        if (PIPE) { idp = fr->idp; idz = fr->idz; }
+        else if (stepMode & 1) {
             // ---- resubstituteFPt for this point, then backupState + doStepFromBackup (stepfacD = 1) ------------
             float step = 0.0f;
-            if (q.nAct > 0) {
-                float b = q.bdSumF;
+            if (q.rec.nActive > 0) {
+                float b = q.rec.bdSumF;
                 float dot = 0;
-                dot += xc0 * q.hcd[0]; dot += xc1 * q.hcd[1]; dot += xc2 * q.hcd[2]; dot += xc3 * q.hcd[3];
+                dot += xc0 * (q.rec.HcdA[0] + q.rec.HcdL[0]); dot += xc1 * (q.rec.HcdA[1] + q.rec.HcdL[1]); dot += xc2 * (q.rec.HcdA[2] + q.rec.HcdL[2]); dot += xc3 * (q.rec.HcdA[3] + q.rec.HcdL[3]);
                 b -= dot;
 #pragma unroll
                 for (int g = 0; g < NSG; g++) {
                     const int t = g * 8 + s;
-                    const bool act = (t < F) && (q.rflat[g] >= 0) && (q.active[g] != 0);
+                    const bool act = (t < F) && (q.rflat[g] >= 0) && (qActive[g] != 0);
                     float sres = seq8(sXa[t * 8 + k] * q.jp[g], k, lane);
                     sres = act ? sres : 0.0f;
                     b -= sum_slots<DESC ? (LD_PERM_DESC != 0) : (LD_PERM_ARGS != 0)>(sres, a16, a32);
                 }
-                if (isfinite(b)) step = -b * q.HdiF; else { step = q.pstep; if (lane == 0) B.scalars[4] = 1.0; }
+                if (isfinite(b)) step = -b * q.rec.HdiF; else { step = q.pstep; if (lane == 0) *(gptr_t<double>) (unsigned long long) (B.scalars + 4) = 1.0; }
             }
             const float ni = idp + 1.0f * step;
             {
-                v16i_t b0, b1;
-                ldg16x2<DESC, OFF_B0, OFF_B1>(b0, &B, b1, &B);
-                float *w_pstep = GP(float, b0, 7), *w_pid = GP(float, b0, 2), *w_piz = GP(float, b0, 3), *w_pbk = GP(float, b1, 0);
-                float *w_lH = GP(float, b1, 1), *w_lB = GP(float, b1, 2), *w_lI = GP(float, b1, 3);
-                if (lane == 0) { AT(w_pstep, p) = step; AT(w_pbk, p) = idp; AT(w_pid, p) = ni; AT(w_piz, p) = ni; }
-                // PointHessian::{HdiF, bdSumF, idepth_hessian} as the solve that produced this step left them (lanes 1..3: fire-and-forget stores)
-                if (lane == 1) AT(w_lH, p) = q.HdiF; else if (lane == 2) AT(w_lB, p) = q.bdSumF; else if (lane == 3) AT(w_lI, p) = q.idH;
+                // dwords 4..11 of the point's PtGeo: lane 1 {idepth, idepth_zero, step, idepth_backup}, lane 2 PointHessian::{HdiF, bdSumF,
+                // idepth_hessian} as the solve that produced this step left them - two dwordx4 of ONE store instruction (round 3: seven stores)
+                const v16i_t b0 = ldg16<DESC, OFF_B0>(&B);
+                v4f_t *w_geo = GP(v4f_t, b0, BP_GEO);
+                if (lane == 1 || lane == 2) {
+                    v4f_t v;
+                    v.x = (lane == 1) ? ni : q.rec.HdiF; v.y = (lane == 1) ? ni : q.rec.bdSumF; v.z = (lane == 1) ? step : q.rec.idH; v.w = (lane == 1) ? idp : 0.0f;
+                    AT(w_geo, p * 4 + (unsigned) lane) = v;
+                }
             }
             idp = ni; idz = ni;
         }
@@ -416,10 +499,10 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
         float HddL = 0, bdL = 0, HcdL0 = 0, HcdL1 = 0, HcdL2 = 0, HcdL3 = 0;
         float hostPart = 0.0f;       // this lane's partial of the host block of g_p (component k)
         // AccumulatedSCHessian.cc:14-21: the SOLVE that finds a point without an active residual zeroes its maxRelBaseline - i.e. the solve whose
-        // point step is fused in front of this pass (q.nAct = active residuals of the linearisation that solve used).  A pass that is followed
+        // point step is fused in front of this pass (q.rec.nActive = active residuals of the linearisation that solve used).  A pass that is followed
         // by no solve (the last linearizeAll(false) of optimize(), the fixing pass) zeroes nothing.
-        float maxRelBS = ((stepMode & 1) && q.nAct <= 0) ? 0.0f : q.maxRelBS;
-        int numGood = q.numGood;
+        float maxRelBS = ((stepMode & 1) && q.rec.nActive <= 0) ? 0.0f : q.rec.maxRelBS;
+        int numGood = q.rec.numGood;
         int nActive = 0;
         float gT[NSG];
 
@@ -431,13 +514,13 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
             const bool isLin = MARG ? false : (exists && (q.rlin[g] != 0));
             // resetOOB (Residuals.h): MARG always; stepMode bit 1 = the optimize() preamble on every non-linearised residual (FullSystem.cc:744-748)
             const bool reset = MARG || ((stepMode & 2) && !isLin);
-            const int st = exists ? (reset ? RES_IN : q.state[g]) : RES_OOB;
+            const int st = exists ? (reset ? RES_IN : qState[g]) : RES_OOB;
             const DevPair &pr = sPair[t];
 
             int newState = st;
-            float newEnergy = (exists && !reset) ? q.energy[g] : 0.0f;
+            float newEnergy = (exists && !reset) ? qEnergy[g] : 0.0f;
             float newEnergyWO = -1.0f;
-            int activeNew = exists ? q.active[g] : 0;
+            int activeNew = exists ? qActive[g] : 0;
             float jp = exists ? q.jp[g] : 0.0f;     // this lane's component k of JpJdF
             float c0 = 0, c1 = 0, c2 = 0;
             int toRemove = 0;
@@ -457,14 +540,14 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
             float new_idepth = idz * drescale;
             float uu = ptp0 * drescale, vv = ptp1 * drescale;
             float cKu = uu * fx + cx, cKv = vv * fy + cy;
-            bool centerOK = (drescale > 0) && cKu > 1.1f && cKv > 1.1f && cKu < D.wM3G && cKv < D.hM3G;
+            bool centerOK = (drescale > 0) && cKu > 1.1f && cKv > 1.1f && cKu < wM3G && cKv < hM3G;
             // ---- pattern pixel projection at the current state (ResidualProjections.h:24-33) ---------
             float px_ = pu + (float) ox, py_ = pv + (float) oy;
             float q0 = ((pr.KRKi[0] * px_ + pr.KRKi[1] * py_) + pr.KRKi[2] * 1.0f) + pr.Kt[0] * idp;
             float q1 = ((pr.KRKi[3] * px_ + pr.KRKi[4] * py_) + pr.KRKi[5] * 1.0f) + pr.Kt[1] * idp;
             float q2 = ((pr.KRKi[6] * px_ + pr.KRKi[7] * py_) + pr.KRKi[8] * 1.0f) + pr.Kt[2] * idp;
             float Ku = q0 / q2, Kv = q1 / q2;
-            bool pixOK = Ku > 1.1f && Kv > 1.1f && Ku < D.wM3G && Kv < D.hM3G;
+            bool pixOK = Ku > 1.1f && Kv > 1.1f && Ku < wM3G && Kv < hM3G;
             if (pi == wave && g == 0) LSTAMP(3);
             // ---- bilinear Vec3f sample of the target image (GlobalFuncs.h:89-103) ---------------------
             float hit0 = 0, hit1 = 0, hit2 = 0;
@@ -473,7 +556,14 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
                 float dx = Ku - ix, dy = Kv - iy, dxdy = dx * dy;
                 // descriptor in memory: the pointer from LDS; kernel arguments: the table sits in scalar registers, selected per lane
                 float a0, a1, a2, b0_, b1, b2, c0_, c1_, c2_, d0, d1, d2;
-                if constexpr (DESC && (LD_GLOBAL_TAPS != 0)) {
+                if constexpr (PIPE) {          // loaded by the front half
+                    const float *tp = fr->tap[g];
+                    a0 = tp[0]; a1 = tp[1]; a2 = tp[2]; b0_ = tp[3]; b1 = tp[4]; b2 = tp[5]; c0_ = tp[6]; c1_ = tp[7]; c2_ = tp[8]; d0 = tp[9]; d1 = tp[10]; d2 = tp[11];
+                    // opaque to the compiler up to here: it must not start re-packing the freshly loaded values for packed arithmetic right
+                    // behind the loads (that re-packing is a use, and a use is a wait)
+                    asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(b0_), "+v"(b1), "+v"(b2));
+                    asm volatile("" : "+v"(c0_), "+v"(c1_), "+v"(c2_), "+v"(d0), "+v"(d1), "+v"(d2));
+                } else if constexpr (DESC && (LD_GLOBAL_TAPS != 0)) {
                     // experiment: the image pointer is a per-lane value from LDS, i.e. generic to the compiler -> FLAT loads, which tick lgkmcnt as
                     // well as vmcnt (every LDS wait then also waits for the taps).  Images are hipMalloc'ed: address them as global memory.
                     const gptr_t<const float> bp = (gptr_t<const float>) (unsigned long long) sImg[t] + 3 * (ix + iy * W);
@@ -556,7 +646,7 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
                 c0 = cKu; c1 = cKv; c2 = new_idepth;
                 // stepMode bit 2 (re-chunking, ba_api.hip rechunk()): the applied state is linearised again only to re-form the per-chunk
                 // partial sums - the decisions of the pass that produced it stand (its energy thresholds have moved on since)
-                if (stepMode & 4) { newState = st; newEnergy = q.energy[g]; ret = (double) newEnergy; }
+                if (stepMode & 4) { newState = st; newEnergy = qEnergy[g]; ret = (double) newEnergy; }
             }
 
             // ================= applyRes(true) (Residuals.h:70-87) ======================================
@@ -715,25 +805,24 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
             if (FIX) numGood += __popcll(newGoodMask);
             if (FIX) { float m = maxRelBS; m = fmaxf(m, __shfl_xor(m, 8, 64)); m = fmaxf(m, __shfl_xor(m, 16, 64)); m = fmaxf(m, __shfl_xor(m, 32, 64)); maxRelBS = m; }
 
-            // ---- per-slot outputs (slot leader) ----------------------------------------------------------
-            if (t < F) {
+            // ---- per-slot outputs: the slot's SlotRec of the next set, lane k stores its own pair (one dwordx2 store per lane) ------------
+            if (PIPE || t < F) {          // pipelined: also the padding slots (t >= F) store their (constant: no residual) record - one branch less in front of the stores
                 const v16i_t o0 = ldg16<DESC, OFF_S0>(&nxt);
-                int32_t *o_state = GP(int32_t, o0, 0), *o_active = GP(int32_t, o0, 1), *o_rem = GP(int32_t, o0, 6);
-                float *o_energy = GP(float, o0, 2), *o_jp = GP(float, o0, 3), *o_center = GP(float, o0, 4), *o_ewo = GP(float, o0, 5), *o_cand = GP(float, o0, 7);
-                AT(o_jp, slot * 8 + (unsigned) k) = jp;
+                v2f_t *o_slot = GP(v2f_t, o0, RS_SLOT);
+                float *o_cand = GP(float, o0, RS_CAND);
+                const float ewo_ = doLin ? newEnergyWO : -1.0f;
+                const float cenK = compute ? (k == 0 ? c0 : k == 1 ? c1 : c2) : q.m[g];      // k < 3 only: lanes 0..2 hold the old centre in their m
+                float mOut = (k < 3) ? cenK : (k == LD_SM_ENERGY) ? newEnergy : (k == LD_SM_EWO) ? ewo_
+                           : __builtin_bit_cast(float, (k == LD_SM_STATE) ? newState : (k == LD_SM_ACTIVE) ? activeNew : toRemove);
+                v2f_t e; e.x = jp; e.y = mOut;
+                AT(o_slot, slot * 8 + (unsigned) k) = e;
                 if (k == 0) {
-                    AT(o_state, slot) = newState;
-                    AT(o_active, slot) = activeNew;
-                    AT(o_energy, slot) = newEnergy;
-                    AT(o_ewo, slot) = doLin ? newEnergyWO : -1.0f;
-                    if (t == F - 1) AT(o_cand, p) = doLin ? newEnergyWO : -1.0f;
-                    AT(o_rem, slot) = toRemove;
+                    if (t == F - 1) AT(o_cand, p) = ewo_;
                     if (doLin) energySum += ret;
                 }
-                if (k < 3) AT(o_center, slot * 3 + (unsigned) k) = compute ? (k == 0 ? c0 : k == 1 ? c1 : c2) : q.cen[g];
             }
-            if (B.dumpJ != nullptr && compute) {
-                ldso_rawjac_t &o = B.dumpJ[q.rflat[g]];
+            if (!PIPE && dumpJ != nullptr && compute) {          // (the pipelined kernel keeps its store count static: no dump - the host launches the plain kernel for it)
+                auto &o = *(gptr_t<ldso_rawjac_t>) (unsigned long long) (dumpJ + q.rflat[g]);          // global, not flat: a pending flat access makes every later wait a vmcnt(0)
                 o.resF[k] = resF; o.JIdx[0][k] = gx; o.JIdx[1][k] = gy; o.JabF[0][k] = jab0; o.JabF[1][k] = jab1;
                 if (k == 0) {
                     for (int i = 0; i < 6; i++) { o.Jpdxi[0][i] = x[4 + i]; o.Jpdxi[1][i] = y[4 + i]; }
@@ -760,33 +849,68 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
         }
         // ---- store G row: [8*FS frame entries | Hcd 4, bdSum, HdiF, 0, 0] --------------------------------
         {
-            v16i_t o1, o2;
-            ldg16x2<DESC, OFF_S1, OFF_S2>(o1, &nxt, o2, &nxt);
-            float *Grow = GP(float, o2, 4) + (size_t) p * D.GS;
+            const v16i_t o0 = ldg16<DESC, OFF_S0>(&nxt);
+            float *Gall = GP(float, o0, RS_G);
+            const unsigned g0 = p * GSu;              // P * GS floats stay far below 2^32 bytes
 #pragma unroll
             for (int g = 0; g < NSG; g++) {
                 const int t = g * 8 + s;
                 float val = (t == h) ? hostPart : gT[g];
                 if (nActive == 0) val = 0.0f;
-                Grow[8 * t + k] = val;
+                AT(Gall, g0 + 8u * (unsigned) t + (unsigned) k) = val;
             }
             if (lane < LD_GEXTRA) {
                 float e = (lane == 0) ? Hc0 : (lane == 1) ? Hc1 : (lane == 2) ? Hc2 : (lane == 3) ? Hc3 : (lane == 4) ? bdSumF : (lane == 5) ? HdiF : 0.0f;
                 if (nActive == 0 && lane < 4) e = 0.0f;
-                Grow[8 * FS + lane] = e;
+                AT(Gall, g0 + 8u * (unsigned) FS + (unsigned) lane) = e;
             }
-            // the per-point scalars: one value per lane (lanes 0..19), one store instruction per destination array
-            float *o_HdiF = GP(float, o1, 0), *o_bd = GP(float, o1, 1), *o_idH = GP(float, o1, 2), *o_HcdA = GP(float, o1, 4), *o_HcdL = GP(float, o1, 5), *o_mrb = GP(float, o1, 6);
-            int32_t *o_nAct = GP(int32_t, o1, 3), *o_nGood = GP(int32_t, o1, 7);
-            float *o_HddA = GP(float, o2, 0), *o_bdA = GP(float, o2, 1), *o_HddL = GP(float, o2, 2), *o_bdL = GP(float, o2, 3);
-            if (lane == 0) {
-                AT(o_HdiF, p) = HdiF; AT(o_bd, p) = bdSumF; AT(o_idH, p) = idH;
-                AT(o_HddA, p) = HddA; AT(o_bdA, p) = bdA; AT(o_HddL, p) = HddL; AT(o_bdL, p) = bdL;
-                AT(o_HcdA, p * 4 + 0) = HcdA0; AT(o_HcdA, p * 4 + 1) = HcdA1; AT(o_HcdA, p * 4 + 2) = HcdA2; AT(o_HcdA, p * 4 + 3) = HcdA3;
-                AT(o_HcdL, p * 4 + 0) = HcdL0; AT(o_HcdL, p * 4 + 1) = HcdL1; AT(o_HcdL, p * 4 + 2) = HcdL2; AT(o_HcdL, p * 4 + 3) = HcdL3;
-                AT(o_mrb, p) = maxRelBS; AT(o_nGood, p) = numGood; AT(o_nAct, p) = nActive;
-                nidSum += fabsf(idp); nidCnt++;
+            // the point's PtRec of the next set: lanes 0..3 store one dwordx4 each (ONE store instruction, 64 contiguous bytes); lane 4 the
+            // accumulator scalars only the fetch functions read
+            v4f_t *o_pt = GP(v4f_t, o0, RS_PT), *o_acc = GP(v4f_t, o0, RS_ACC);
+            if (lane < 4) {
+                v4f_t v;
+                v.x = (lane == 0) ? HdiF : (lane == 1) ? HcdA0 : (lane == 2) ? HcdL0 : maxRelBS;
+                v.y = (lane == 0) ? bdSumF : (lane == 1) ? HcdA1 : (lane == 2) ? HcdL1 : __builtin_bit_cast(float, numGood);
+                v.z = (lane == 0) ? idH : (lane == 1) ? HcdA2 : (lane == 2) ? HcdL2 : 0.0f;
+                v.w = (lane == 0) ? __builtin_bit_cast(float, nActive) : (lane == 1) ? HcdA3 : (lane == 2) ? HcdL3 : 0.0f;
+                AT(o_pt, p * 4 + (unsigned) lane) = v;
+            } else if (lane == 4) {
+                v4f_t v; v.x = HddA; v.y = bdA; v.z = HddL; v.w = bdL;
+                AT(o_acc, p) = v;
             }
+            if (lane == 0) { nidSum += fabsf(idp); nidCnt++; }
+        }
+    };   // point_body
+
+    if constexpr (PIPE) {
+        // Steady state and tail are SEPARATE copies of the arithmetic: the compiler's wait for a point's taps is the minimum over all paths that
+        // reach it, and on the path without a successor (single point, last point) those taps are the most recent loads - sharing the code
+        // would make the steady-state wait drain the successor's taps as well.
+        FrontT fa, fb;
+        PtIn<NSG> qn;                                // the record one point further ahead: in flight during a whole back half
+        fa.q = nx;                                   // the first record was loaded before the staging
+        if (pi < np) front(fa, (unsigned) (p0 + pi), false);
+        if (pi + LD_WAVES < np) load_point<NSG, HAS_L, FIX, DESC>(qn, B, cur, FS, (unsigned) (p0 + pi + LD_WAVES), s, k, stepMode);
+        while (pi + LD_WAVES < np) {                 // a successor exists (wave-uniform); two points per trip: the buffers alternate without copies
+            // the record after the successor's - UNCONDITIONALLY (the successor's once more when there is none: a branch around the loads would
+            // again make the wait below the minimum over two paths)
+            fb.q = qn; front(fb, (unsigned) (p0 + pi + LD_WAVES), false);
+            { const int nn = (pi + 2 * LD_WAVES < np) ? pi + 2 * LD_WAVES : pi + LD_WAVES; load_point<NSG, HAS_L, FIX, DESC>(qn, B, cur, FS, (unsigned) (p0 + nn), s, k, stepMode); }
+            point_body((unsigned) (p0 + pi), fa.q, &fa);
+            pi += LD_WAVES;
+            if (!(pi + LD_WAVES < np)) { fa = fb; break; }
+            fa.q = qn; front(fa, (unsigned) (p0 + pi + LD_WAVES), false);
+            { const int nn = (pi + 2 * LD_WAVES < np) ? pi + 2 * LD_WAVES : pi + LD_WAVES; load_point<NSG, HAS_L, FIX, DESC>(qn, B, cur, FS, (unsigned) (p0 + nn), s, k, stepMode); }
+            point_body((unsigned) (p0 + pi), fb.q, &fb);
+            pi += LD_WAVES;
+        }
+        if (pi < np) { point_body((unsigned) (p0 + pi), fa.q, &fa); pi += LD_WAVES; }
+    } else {
+#pragma clang loop unroll(disable)
+        for (; pi < np; pi += LD_WAVES) {
+            const unsigned p = (unsigned) (p0 + pi);
+            if (pi != wave) load_point<NSG, HAS_L, FIX, DESC>(nx, B, cur, FS, p, s, k, stepMode);       // the first record was loaded before the staging
+            point_body(p, nx, nullptr);
         }
     }   // points of this wave
 
@@ -816,9 +940,9 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
     }
     __syncthreads();
     LSTAMP(7);
-    const v16i_t e2 = ldg16<DESC, OFF_S2>(&nxt);
-    float *o_topA = GP(float, e2, 5), *o_topL = GP(float, e2, 6);
-    double *o_chunkE = GP(double, e2, 7);
+    const v16i_t e2 = ldg16<DESC, OFF_S0>(&nxt);
+    float *o_topA = GP(float, e2, RS_TOPA), *o_topL = GP(float, e2, RS_TOPL);
+    double *o_chunkE = GP(double, e2, RS_CHUNKE);
     for (int i = tid; i < FS * LD_TOPN; i += blockDim.x) {
         float a = 0;
 #pragma unroll

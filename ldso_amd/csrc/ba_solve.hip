@@ -898,7 +898,7 @@ __global__ __launch_bounds__(NT) void k_solve(BaPtrs B, BaDims D, ResSet S, ldso
     if (fl & SK_COLLECT) {
         // FullSystem::optimize preamble: resetOOB on every non-linearised residual (FullSystem.cc:744-748)
         for (int i = tid; i < D.P * D.FS; i += NT)
-            if (B.rflat[i] >= 0 && !B.rlin[i]) { S.state[i] = 0; S.energy[i] = 0.0f; }
+            if (B.rtab[i].rflat >= 0 && !B.rtab[i].rlin) { S.slot[i].e[LD_SM_STATE].m.i = 0; S.slot[i].e[LD_SM_ENERGY].m.f = 0.0f; }
         __syncthreads();
     }
     if (fl & SK_POST) post_sums(B, D, S, sW);
@@ -1176,34 +1176,37 @@ hipError_t ba_launch_gn_export(const BaPtrs &B, const BaDims &D, const ResSet &S
 __global__ __launch_bounds__(256) void k_point_step(BaPtrs B, BaDims D, ResSet S, int mode) {
     const int p = D.pBegin + blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= D.pEnd) return;
-    if (mode & PS_LOAD) { float b = B.pidepth_backup[p]; B.pidepth[p] = b; B.pidepth_zero[p] = b; return; }   // loadSateBackup
+    PtGeo &Gp = B.pgeo[p];
+    if (mode & PS_LOAD) { float b = Gp.idepth_backup; Gp.idepth = b; Gp.idepth_zero = b; return; }   // loadSateBackup
     const int F = D.F, FS = D.FS, h = B.phost[p];
-    float step = B.pstep[p];
-    if (mode & PS_RESUB) { B.pLastHdiF[p] = S.HdiF[p]; B.pLastBdSumF[p] = S.bdSumF[p]; B.pLastIdH[p] = S.idH[p]; }      // what this solve's accumulateSCF_MT left in the point
-    if ((mode & PS_RESUB) && S.nActive[p] <= 0) { step = 0.0f; S.maxRelBS[p] = 0.0f; }      // AccumulatedSCHessian.cc:14-21 (zeroed by the solve)
-    if ((mode & PS_RESUB) && S.nActive[p] > 0) {
-        float b = S.bdSumF[p];
+    float step = Gp.step;
+    PtRec &R = S.pt[p];
+    if (mode & PS_RESUB) { Gp.lastHdiF = R.HdiF; Gp.lastBdSumF = R.bdSumF; Gp.lastIdH = R.idH; }      // what this solve's accumulateSCF_MT left in the point
+    if ((mode & PS_RESUB) && R.nActive <= 0) { step = 0.0f; R.maxRelBS = 0.0f; }      // AccumulatedSCHessian.cc:14-21 (zeroed by the solve)
+    if ((mode & PS_RESUB) && R.nActive > 0) {
+        float b = R.bdSumF;
         float dot = 0;
-        for (int i = 0; i < 4; i++) dot += B.xc[i] * (S.HcdA[p * 4 + i] + S.HcdL[p * 4 + i]);
+        for (int i = 0; i < 4; i++) dot += B.xc[i] * (R.HcdA[i] + R.HcdL[i]);
         b -= dot;
         bool finite = true;
         for (int t = 0; t < F; t++) {
             int slot = p * FS + t;
-            if (B.rflat[slot] < 0 || !S.active[slot]) continue;
-            const float *xa = B.xAd + (size_t) (h * F + t) * 8, *jp = S.JpJdF + (size_t) slot * 8;
+            const SlotRec &sr = S.slot[slot];
+            if (B.rtab[slot].rflat < 0 || !sr.e[LD_SM_ACTIVE].m.i) continue;
+            const float *xa = B.xAd + (size_t) (h * F + t) * 8;
             float s = 0;
-            for (int i = 0; i < 8; i++) s += xa[i] * jp[i];
+            for (int i = 0; i < 8; i++) s += xa[i] * sr.e[i].jp;
             b -= s;
         }
         if (!isfinite(b)) finite = false;
-        if (finite) step = -b * S.HdiF[p]; else { step = B.pstep[p]; B.scalars[4] = 1.0; }
+        if (finite) step = -b * R.HdiF; else { step = Gp.step; B.scalars[4] = 1.0; }
     }
-    B.pstep[p] = step;
-    if (mode & PS_BACKUP) B.pidepth_backup[p] = B.pidepth[p];
+    Gp.step = step;
+    if (mode & PS_BACKUP) Gp.idepth_backup = Gp.idepth;
     if (mode & PS_STEP) {     // doStepFromBackup (stepfacD = 1)
-        float ni = B.pidepth_backup[p] + 1.0f * step;
-        B.pidepth[p] = ni;
-        B.pidepth_zero[p] = ni;
+        float ni = Gp.idepth_backup + 1.0f * step;
+        Gp.idepth = ni;
+        Gp.idepth_zero = ni;
     }
 }
 
@@ -1234,14 +1237,15 @@ __global__ __launch_bounds__(256) void k_lm_energies(BaPtrs B, BaDims D, ResSet 
     // ---- L energy: points ----
     const float cD0 = B.calib->cDeltaF[0], cD1 = B.calib->cDeltaF[1], cD2 = B.calib->cDeltaF[2], cD3 = B.calib->cDeltaF[3];
     for (int p = D.pBegin + tid; p < D.pEnd; p += 256) {
-        const float dd = B.pidepth[p] - B.pidepth_zero[p];
+        const float dd = B.pgeo[p].idepth - B.pgeo[p].idepth_zero;
         const int h = B.phost[p];
         double e = 0.0;
         for (int t = 0; t < F; t++) {
             const int slot = p * D.FS + t;
-            if (B.rflat[slot] < 0 || !B.rlin[slot] || !S.active[slot]) continue;
-            const ldso_rawjac_t &J = B.Jlin[B.rlidx[slot]];
-            const float *rtz = B.rtz + (size_t) B.rlidx[slot] * 8;
+            const SlotTab tb = B.rtab[slot];
+            if (tb.rflat < 0 || !tb.rlin || !S.slot[slot].e[LD_SM_ACTIVE].m.i) continue;
+            const ldso_rawjac_t &J = B.Jlin[tb.rlidx];
+            const float *rtz = B.rtz + (size_t) tb.rlidx * 8;
             const float *dp = B.pairs[h * F + t].dp;
             float jx = 0, jy = 0;
             for (int i = 0; i < 6; i++) { jx += J.Jpdxi[0][i] * dp[i]; jy += J.Jpdxi[1][i] * dp[i]; }
@@ -1252,7 +1256,7 @@ __global__ __launch_bounds__(256) void k_lm_energies(BaPtrs B, BaDims D, ResSet 
                 e += (double) (Jd * ((rtz[i] + rtz[i]) + Jd));
             }
         }
-        e += (double) (dd * dd * B.ppriorF[p]);
+        e += (double) (dd * dd * B.pgeo[p].priorF);
         el += e;
     }
     em = wave_sum(em); el = wave_sum(el);
