@@ -92,6 +92,75 @@ def parity_check(win, ba, stream):
     return res
 
 
+def parity_check_dist(win, ba, rank, world, dist, pb, pe, stream, device):
+    """The N > 1 (or --force-dist-path) counterpart of parity_check, OUTSIDE the timed region: (i) every rank's frame states must be
+    bit-identical (replicated solve on the all-reduced system); the shards' points / residual states are gathered on rank 0, the oracle
+    re-evaluates that state and its energy must be the sum of the ranks' energies; (ii) a fresh sharded 10-iteration run (reduce_local ->
+    all-reduce -> solve_reduced) against the oracle's FullSystem::optimize loop, total energy before every iteration and after the last.
+    Tolerance 1e-4 relative (north_star).  Rank 0 raises on violation (the other ranks return None)."""
+    from ldso_amd import binding
+    from oracle import pyoracle as po
+    n = 8 * win.F + 4
+
+    def allsum(t):
+        if world > 1:
+            dist.all_reduce(t)
+        return t
+
+    def gathered(x):
+        if world == 1:
+            return [x]
+        out = [None] * world
+        dist.all_gather_object(out, x)
+        return out
+
+    buf = torch.zeros(ba.gn_reduce_doubles(), dtype=torch.float64, device="cuda")
+    ba.gn_reduce_local(buf.data_ptr(), 1e-1); ba.sync(); torch.cuda.synchronize()
+    e_gpu = float(allsum(buf[n * n + n:n * n + n + 1].clone()).item())
+    fr, pts, res = ba.get_frames(), ba.get_points(), ba.get_residuals()
+    mine = (win.residuals["point"] >= pb) & (win.residuals["point"] < pe)
+    parts = gathered({"pb": pb, "pe": pe, "state": fr["frames"]["state"].copy(), "calib": np.asarray(fr["calib_value"]).copy(), "idepth": pts["idepth"][pb:pe].copy(),
+                      "rows": np.nonzero(mine)[0], "state_state": res["state_state"][mine].copy(), "is_active": res["is_active"][mine].copy(),
+                      "energy": res["out"]["state_NewEnergy"][mine].copy()})
+    # (ii) fresh sharded run, energies of the all-reduced scalar block
+    g2 = binding.BA.from_window(win, device=device, stream=stream)
+    if world > 1:
+        g2.set_shard(pb, pe)
+    g2.collect_active(); g2.linearize_all(False); g2.apply_res()
+    b2 = torch.zeros(g2.gn_reduce_doubles(), dtype=torch.float64, device="cuda")
+    es = []
+    for i in range(11):
+        g2.gn_reduce_local(b2.data_ptr(), 1e-1)
+        allsum(b2)
+        torch.cuda.synchronize()
+        es.append(float(b2[n * n + n].item()))
+        if i < 10:
+            g2.gn_solve_reduced(b2.data_ptr(), i, 1e-1)
+    g2.sync(); g2.close()
+    if rank != 0:
+        return None
+    ranks_diff = max(float(np.max(np.abs(q["state"] - parts[0]["state"]))) for q in parts)
+    ranks_diff = max(ranks_diff, max(float(np.max(np.abs(q["calib"] - parts[0]["calib"]))) for q in parts))
+    idepth = pts["idepth"].copy(); ss = res["state_state"].copy(); act = res["is_active"].copy(); en = res["out"]["state_NewEnergy"].copy()
+    for q in parts:
+        idepth[q["pb"]:q["pe"]] = q["idepth"]; ss[q["rows"]] = q["state_state"]; act[q["rows"]] = q["is_active"]; en[q["rows"]] = q["energy"]
+    covered = int(sum(len(q["rows"]) for q in parts))
+    w2 = transplant(win, fr, {"idepth": idepth}, {"state_state": ss, "is_active": act, "out": {"state_NewEnergy": en}})
+    o = po.OracleWindow(w2); o.collect_active(reset_oob=False)
+    e_orc = o.linearize_all(False); o.close()
+    o2 = po.OracleWindow(win); o2.set_force_all_iterations(True); o2.optimize(10)
+    eo = np.asarray(o2.energy_log())[:11]; o2.close()
+    eg = np.asarray(es)
+    r1 = abs(e_gpu - e_orc) / abs(e_orc)
+    r2 = float(np.max(np.abs(eg - eo) / np.abs(eo))) if len(eo) == len(eg) else float("inf")
+    out = {"ranks": world, "energy_after_timed_run_sum_over_ranks": e_gpu, "energy_oracle_at_that_state": e_orc, "rel": r1,
+           "energy_log_10_iterations_max_rel": r2, "frame_states_max_abs_diff_between_ranks": ranks_diff, "residuals_covered_by_shards": covered,
+           "tolerance": 1e-4, "ok": bool(r1 <= 1e-4 and r2 <= 1e-4 and ranks_diff == 0.0 and covered == win.R)}
+    if not out["ok"]:
+        raise SystemExit(f"bench.py: sharded parity check against the oracle failed: {out}")
+    return out
+
+
 def measure(args, config, rank, local_rank, world, dist, steps, warmup, min_timed_s=2.0, with_parity=True):
     """One BASELINE window: median time of blocks of EXACTLY `steps` forced GN iterations + the live roofline of k_linearize."""
     from ldso_amd import synth, binding, dist as ldist
@@ -201,6 +270,10 @@ def measure(args, config, rank, local_rank, world, dist, steps, warmup, min_time
     # HBM traffic per launch: rocprofv3 PMC counters cannot be read from inside this process; the value is the committed
     # measurement of the same command (profiles/rNN_pmc_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE, the guide's gfx950 correction)
     traffic, traffic_src = committed_profile(config, "traffic") if single else (None, None)
+    if with_parity and dist_path:
+        if windows is not None:
+            ba.sync(); fence()
+        parity = parity_check_dist(win, ba, rank, world, dist, pb, pe, stream, local_rank)
     ba.close()
     return {
         "win": win,
@@ -272,6 +345,7 @@ def main():
             "unit": "GN iters/s",
             "mresiduals_per_s": m["mresiduals_per_s"],
             "n_gpus": world,
+            "rccl_ranks": (world if (dist is not None and dist.get_backend() == "nccl") else 0),      # ranks of the RCCL communicator this line ran on (0: single process, or the gloo debug mode)
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": m["ms_per_step"],

@@ -197,7 +197,7 @@ template <> struct at_sel<false> {
 template <class T> using cptr_t = const __attribute__((address_space(4))) T *;
 
 typedef int v4i32_t __attribute__((ext_vector_type(4)));
-typedef int v8i_t __attribute__((ext_vector_type(8)));
+typedef float v8f_t __attribute__((ext_vector_type(8)));
 typedef int v2i32_t __attribute__((ext_vector_type(2)));
 typedef float v2f_t __attribute__((ext_vector_type(2)));
 typedef float v4f_t __attribute__((ext_vector_type(4)));
@@ -213,9 +213,11 @@ static __device__ __forceinline__ void load_point(PtIn<NSG> &q, const BaPtrs &B,
         const v2f_t *pcw = GP(const v2f_t, b0, BP_CW);
         const v4i32_t *rtab = GP(const v4i32_t, b0, BP_RTAB);
         // dwords 0..7 of the point's PtGeo (u, v, prior | idepth, idepth_zero, step): wave-uniform address -> ONE scalar load
-        const v8i_t g8 = *(cptr_t<v8i_t>) ((unsigned long long) geo + (unsigned long long) ((unsigned) __builtin_amdgcn_readfirstlane((int) p) * (unsigned) sizeof(PtGeo)));
-        q.pu = __builtin_bit_cast(float, g8[0]); q.pv = __builtin_bit_cast(float, g8[1]); q.priorF = __builtin_bit_cast(float, g8[2]);
-        q.idp = __builtin_bit_cast(float, g8[4]); q.idz = __builtin_bit_cast(float, g8[5]); q.pstep = __builtin_bit_cast(float, g8[6]);
+        // (a float vector, indexed directly: __builtin_bit_cast(float, v[i]) of an integer ext-vector ELEMENT is miscompiled by this clang - every
+        // element became element 0, found on the first GPU run of the record layout)
+        const v8f_t g8 = *(cptr_t<v8f_t>) ((unsigned long long) geo + (unsigned long long) ((unsigned) __builtin_amdgcn_readfirstlane((int) p) * (unsigned) sizeof(PtGeo)));
+        q.pu = g8[0]; q.pv = g8[1]; q.priorF = g8[2];
+        q.idp = g8[4]; q.idz = g8[5]; q.pstep = g8[6];
         // addresses = (uniform base advanced to the point, on the scalar side) + (a lane offset that never changes): no per-point VGPR address
         // arithmetic, and no VGPR shared between one load's address and another load's destination (the allocator had put the slot-record
         // address into a register of the SlotTab destination: a vmcnt(0) between the two loads, i.e. two serialised latencies)

@@ -40,6 +40,9 @@ def test_bench_two_ranks_on_one_gpu():
     j = _last_json(r.stdout)
     assert j["n_gpus"] == 2 and j["value"] > 0 and j["state_finite"]
     assert "sharded over 2 GPUs" in j["config"]["parallelism"]
+    pv = j["parity_vs_oracle"]          # rank 0 gathered the shards, the oracle re-evaluated the state and the 10-iteration log
+    assert pv["ok"] and pv["ranks"] == 2 and pv["rel"] <= 1e-4 and pv["energy_log_10_iterations_max_rel"] <= 1e-4 and pv["frame_states_max_abs_diff_between_ranks"] == 0.0
+    assert j["rccl_ranks"] == 0          # gloo debug mode
 
 
 def test_bench_two_ranks_on_one_gpu_with_the_peer_write_exchange():
@@ -53,3 +56,4 @@ def test_bench_two_ranks_on_one_gpu_with_the_peer_write_exchange():
     j = _last_json(r.stdout)
     assert j["n_gpus"] == 2 and j["value"] > 0 and j["state_finite"]
     assert "peer-write" in j["config"]["parallelism"]
+    assert j["parity_vs_oracle"]["ok"] and j["parity_vs_oracle"]["ranks"] == 2

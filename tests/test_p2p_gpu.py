@@ -128,3 +128,62 @@ def test_two_processes_share_windows_through_ipc_handles(small):
         s0, s1 = np.load(os.path.join(d, "state0.npy")), np.load(os.path.join(d, "state1.npy"))
     assert np.array_equal(s0, s1)
     assert rel(s0, ref.get_frames()["frames"]["state"]) < 5e-3
+
+
+def _check_against_unsharded(win, states, idepth, energy, sizes):
+    """all ranks bit-identical; against the unsharded iteration: total energy 1e-4 (north_star), states off the gauge directions 2e-4 (the measure
+    of tests/test_fullsize_gpu.py - the shards cut the fp32 partial sums differently and the solve amplifies that along the gauge), inverse depths 2e-4"""
+    import torch
+    from test_fullsize_gpu import gauge_basis
+    ref = _reference(win)
+    n = 8 * win.F + 4
+    b = torch.zeros(ref.gn_reduce_doubles(), dtype=torch.float64, device="cuda")
+    ref.gn_reduce_local(b.data_ptr(), 1e-1); ref.sync(); torch.cuda.synchronize()
+    e_ref = float(b[n * n + n].item())
+    assert all(np.array_equal(states[0], s_) for s_ in states[1:]), "replicated solves must be bit-identical"
+    assert sum(sizes) == win.P and max(sizes) - min(sizes) <= 1
+    assert abs(energy - e_ref) <= 1e-4 * e_ref, (energy, e_ref)
+    fr = ref.get_frames()["frames"]
+    Q, _ = np.linalg.qr(gauge_basis(fr))
+    xs, xr = states[0][:, :8].reshape(-1), fr["state"][:, :8].reshape(-1)
+    dd = xs - xr
+    assert np.abs(dd - Q @ (Q.T @ dd)).max() < 2e-4 * np.abs(xr).max()
+    assert rel(idepth, ref.get_points()["idepth"]) < 2e-4
+
+
+@pytest.mark.parametrize("cfg,nranks", [("C4", 8), ("C5", 8), ("C4", 7)])
+def test_many_processes_at_full_size(cfg, nranks):
+    """BASELINE configs 4 / 5 as an 8-GPU node will run them: 8 (and 7: uneven shards of 429 / 428 points) PROCESSES, one rank each, on one GPU; the
+    receive windows cross the process boundaries as IPC handles, four iterations through ldso_ba_enqueue_gn_p2p."""
+    from conftest import get_window
+    win = synth.add_synthetic_prior(copy.deepcopy(get_window(cfg)))
+    here = os.path.dirname(os.path.abspath(__file__))
+    with tempfile.TemporaryDirectory() as d:
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs = [subprocess.Popen([sys.executable, os.path.join(here, "p2p_worker.py"), str(r), d, str(nranks), cfg], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+                 for r in range(nranks)]
+        outs = [p.communicate(timeout=600)[0].decode(errors="replace") for p in procs]
+        assert all(p.returncode == 0 for p in procs), [o[-800:] for o in outs]
+        states = [np.load(os.path.join(d, f"state{r}.npy")) for r in range(nranks)]
+        shards = [np.load(os.path.join(d, f"shard{r}.npy")) for r in range(nranks)]
+        idepth = np.zeros(win.P, np.float32)
+        for r in range(nranks):
+            a, b = int(shards[r][0]), int(shards[r][1])
+            idepth[a:b] = np.load(os.path.join(d, f"idepth{r}.npy"))[a:b]
+    _check_against_unsharded(win, states, idepth, float(sum(s_[2] for s_ in shards)), [int(s_[1] - s_[0]) for s_ in shards])
+
+
+@pytest.mark.parametrize("cfg,nranks", [("C5", 8), ("C4", 7), ("C3", 3)])
+def test_many_ranks_in_one_process_with_the_hand_made_all_reduce(cfg, nranks):
+    """the same shards as ranks of ONE process: each rank its own handle, four iterations of gn_reduce_local -> all-reduce formed by hand in rank
+    order -> gn_solve_reduced (= bench.py's RCCL iteration with the collective replaced by a sum)."""
+    from conftest import get_window
+    win = synth.add_synthetic_prior(copy.deepcopy(get_window(cfg)))
+    here = os.path.dirname(os.path.abspath(__file__))
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "r.npz")
+        r = subprocess.run([sys.executable, os.path.join(here, "p2p_nranks_worker.py"), cfg, str(nranks), out, "--hand"], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+        z = dict(np.load(out))
+    sizes = [int(b - a) for a, b in z["shards"]]
+    _check_against_unsharded(win, list(z["states"]), z["idepth"], float(z["energy"]), sizes)
