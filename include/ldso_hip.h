@@ -209,6 +209,9 @@ int ldso_ba_enqueue_gn_rccl(ldso_ba_t *h, void *nccl_comm, int first_iteration, 
  * access enabled) pass the pointers themselves.  windows[q] = rank q's window as this process addresses it, windows[rank] = the own one.
  * Every rank calls ldso_ba_enqueue_gn_p2p with the same (first_iteration, iters).  ldso_ba_p2p_check (after ldso_ba_sync): LDSO_E_HIP when
  * a peer's words did not arrive within the kernel's 2 s poll limit.
+ * The slots of a window are laid out by the CAPACITY of the handle (ldso_ba_create's max_frames / max_points), not by the current window: all ranks
+ * create their handles with the same capacities, and a window change (ldso_ba_set_window) between two exchanges moves nothing.  Where uncached
+ * device memory cannot be had ldso_ba_p2p_window_alloc fails with LDSO_E_UNSUPPORTED (cached memory would never show a polling kernel its peers' stores).
  * The exchange number lives in the HANDLE (1, 2, 3 ... over all ldso_ba_enqueue_gn_p2p calls of its lifetime) and must advance in lock-step
  * on all ranks: the handles and windows of the n_ranks ranks form ONE generation.  When any rank re-creates its handle, every rank re-creates
  * its handle and re-allocates its window (alloc zeroes it) - words of an older generation carrying the same number would otherwise be taken

@@ -88,6 +88,7 @@ struct ldso_ba {
     BatchBlock *d_blocks = nullptr;    // [maxChunks] the window's chunks as k_linearize_batch reads them (window index 0)
     std::vector<BatchBlock> h_blocks;
     bool appliedValid = false;         // the applied residual set holds a linearisation of the resident window (its per-chunk partials feed the next reduce)
+    const void *inBatch = nullptr;     // the ldso_ba_batch this handle belongs to (at most one; it must outlive the batch: ldso_ba_destroy refuses while set)
     int chunkPoints = 0;               // points per workgroup of k_linearize: 0 = as few as keep the grid within one wave of workgroups (one window alone on the chip)
     BatchItem itemShadow;
     bool itemValid = false;
@@ -287,6 +288,7 @@ static int create_body(ldso_ba *H, int device, int w, int h, int max_frames, int
 
 int ldso_ba_destroy(ldso_ba_t *H) {
     if (!H) return LDSO_OK;
+    REQ(H->inBatch == nullptr, "ldso_ba_destroy: the handle is part of a live batch (ldso_ba_batch_destroy first: the batch dereferences its handles)");
     hipSetDevice(H->device);
     hipDeviceSynchronize();
     for (void *p : H->allocs) hipFree(p);
@@ -1157,6 +1159,8 @@ int ldso_ba_batch_create(ldso_ba_t *const *handles, int n, ldso_ba_batch_t **out
         REQ(H && H->D.P > 0, "ldso_ba_batch_create: every handle needs a resident window");
         REQ(H->device == H0->device && H->stream == H0->stream, "ldso_ba_batch_create: the handles of a batch share one device and one stream (ldso_ba_set_stream)");
         REQ(H->D.FS == H0->D.FS, "ldso_ba_batch_create: the windows of a batch use the same slot-table width (all F <= 8 or all 9 <= F <= 16)");
+        REQ(H->inBatch == nullptr, "ldso_ba_batch_create: a handle belongs to at most one batch at a time");
+        for (int k = 0; k < i; k++) REQ(handles[k] != H, "ldso_ba_batch_create: the same handle twice");
         REQ(!H->hasL, "ldso_ba_batch_create: windows with linearised residuals run on their own handle");
         REQ(H->D.pBegin == 0 && H->D.pEnd == H->D.P, "ldso_ba_batch_create: sharded handles cannot be batched");
         REQ(H->settings.forceAcceptStep && !H->pendingApply, "ldso_ba_batch_create: forced-accept schedule, no pending linearisation");
@@ -1195,7 +1199,9 @@ int ldso_ba_batch_create(ldso_ba_t *const *handles, int n, ldso_ba_batch_t **out
     Bt->Dmax = H0->D;
     for (int i = 0; i < n; i++) if (handles[i]->D.F > Bt->Dmax.F) Bt->Dmax = handles[i]->D;
     void *q = nullptr;
-    if (hipMalloc(&q, 2 * (size_t) n * sizeof(BatchItem)) != hipSuccess) { delete Bt; ldso_set_error("ldso_ba_batch_create: hipMalloc failed"); return LDSO_E_HIP; }
+    for (int i = 0; i < n; i++) handles[i]->inBatch = Bt;
+    // every failure from here on goes through ldso_ba_batch_destroy: it restores the single-window chunking and releases the handles
+    if (hipMalloc(&q, 2 * (size_t) n * sizeof(BatchItem)) != hipSuccess) { (void) hipGetLastError(); ldso_ba_batch_destroy(Bt); ldso_set_error("ldso_ba_batch_create: hipMalloc failed"); return LDSO_E_HIP; }
     Bt->d_items = (BatchItem *) q;
     if (Bt->n0 < n) {
         if (hipStreamCreateWithFlags(&Bt->aux, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&Bt->ev0, hipEventDisableTiming) != hipSuccess
@@ -1226,6 +1232,7 @@ int ldso_ba_batch_destroy(ldso_ba_batch_t *Bt) {
     if (Bt->d_blocks) hipFree(Bt->d_blocks);
     // back to the single-window chunking (handles that were re-chunked by ldso_ba_batch_create)
     if (Bt->chunkPoints > 0) for (ldso_ba *H : Bt->h) if (H->chunkPoints == 0 && H->D.P > 0) rechunk(H);
+    for (ldso_ba *H : Bt->h) if (H->inBatch == Bt) H->inBatch = nullptr;
     delete Bt;
     return LDSO_OK;
 }
@@ -1329,22 +1336,25 @@ int ldso_ba_enqueue_gn_rccl(ldso_ba_t *H, void *nccl_comm, int first_iteration, 
 // exchange to finish it), so two slots per source suffice.  The polls are bounded (2 s): a missing peer turns into LDSO_E_HIP at
 // ldso_ba_p2p_check instead of a hung stream.
 struct P2PWindows { unsigned long long *w[16]; };
-__global__ __launch_bounds__(256) void k_p2p_push(const double *__restrict__ src, int nd, P2PWindows W, int rank, int nRanks, int parity, unsigned seq) {
+// `cap` = slot stride in doubles = the CAPACITY of the handles (maxF / maxP: ldso_ba_p2p_window_bytes), not the current window's size: the
+// parity regions then stay where they are when ldso_ba_set_window changes the window dimension between two exchanges (a rank that has
+// moved on to the next window must not write over words a slower peer has not summed yet)
+__global__ __launch_bounds__(256) void k_p2p_push(const double *__restrict__ src, int nd, size_t cap, P2PWindows W, int rank, int nRanks, int parity, unsigned seq) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nd; i += gridDim.x * blockDim.x) {
         const unsigned long long u = __builtin_bit_cast(unsigned long long, src[i]);
         const unsigned long long w0 = (u << 32) | seq, w1 = (u & 0xFFFFFFFF00000000ull) | seq;
-        const size_t o = (((size_t) parity * nRanks + rank) * nd + i) * 2;
+        const size_t o = (((size_t) parity * nRanks + rank) * cap + i) * 2;
         for (int q = 0; q < nRanks; q++) {
             __hip_atomic_store(W.w[q] + o, w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(W.w[q] + o + 1, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
-__global__ __launch_bounds__(256) void k_p2p_sum(const unsigned long long *__restrict__ own, int nd, int nRanks, int parity, unsigned seq, double *__restrict__ out, int *err) {
+__global__ __launch_bounds__(256) void k_p2p_sum(const unsigned long long *__restrict__ own, int nd, size_t cap, int nRanks, int parity, unsigned seq, double *__restrict__ out, int *err) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nd; i += gridDim.x * blockDim.x) {
         double acc = 0.0;
         for (int q = 0; q < nRanks; q++) {
-            const unsigned long long *p = own + (((size_t) parity * nRanks + q) * nd + i) * 2;
+            const unsigned long long *p = own + (((size_t) parity * nRanks + q) * cap + i) * 2;
             unsigned long long w0, w1;
             unsigned spins = 0; long long t0 = 0; bool dead = false;
             for (;;) {
@@ -1360,10 +1370,13 @@ __global__ __launch_bounds__(256) void k_p2p_sum(const unsigned long long *__res
     }
 }
 
+static size_t p2p_slot_doubles(const ldso_ba *H) {          // one slot: the largest reduce buffer the handle can produce
+    const size_t n = 8 * (size_t) H->maxF + 4;
+    return n * n + n + 8 + (size_t) H->maxP;
+}
 size_t ldso_ba_p2p_window_bytes(ldso_ba_t *H, int n_ranks) {
     if (!H || n_ranks < 1 || n_ranks > 16) return 0;
-    const size_t n = 8 * (size_t) H->maxF + 4;
-    return 2 * (size_t) n_ranks * (n * n + n + 8 + (size_t) H->maxP) * 16;
+    return 2 * (size_t) n_ranks * p2p_slot_doubles(H) * 16;
 }
 // This rank's receive window: uncached device memory (remote writes must be seen by a polling kernel), zeroed; ipc_handle_out (64 bytes,
 // hipIpcMemHandle_t) lets another process map it with ldso_ba_p2p_window_open.  Ranks of ONE process pass the pointer itself.
@@ -1372,7 +1385,12 @@ int ldso_ba_p2p_window_alloc(ldso_ba_t *H, int n_ranks, void **window_out, void 
     CHK(hipSetDevice(H->device));
     void *p = nullptr;
     const size_t bytes = ldso_ba_p2p_window_bytes(H, n_ranks);
-    if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached) != hipSuccess) { (void) hipGetLastError(); CHK(hipMalloc(&p, bytes)); }
+    // no fallback to cached memory: a polling k_p2p_sum may never see peer stores that sit in another L2, and every exchange would end in the
+    // 2 s timeout without a hint of the cause
+    {
+        const hipError_t e_ = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached);
+        if (e_ != hipSuccess) { (void) hipGetLastError(); ldso_set_error(std::string("ldso_ba_p2p_window_alloc: uncached device memory unavailable (hipExtMallocWithFlags: ") + hipGetErrorString(e_) + ")"); return LDSO_E_UNSUPPORTED; }
+    }
     CHK(hipMemset(p, 0, bytes));
     if (ipc_handle_out) {
         hipIpcMemHandle_t hnd;
@@ -1422,8 +1440,8 @@ int ldso_ba_enqueue_gn_p2p(ldso_ba_t *H, int rank, int n_ranks, void *const *win
         RUN(ldso_ba_gn_reduce_local(H, H->distBuf, 1e-1));
         const unsigned seq = ++H->p2pSeq;
         if (seq == 0xFFFFFFFFu) { ldso_set_error("ldso_ba_enqueue_gn_p2p: exchange counter exhausted (re-create the windows)"); return LDSO_E_INVALID; }
-        hipLaunchKernelGGL(k_p2p_push, dim3(grid), dim3(256), 0, H->stream, (const double *) H->distBuf, (int) nd, W, rank, n_ranks, (int) (seq & 1), seq);
-        hipLaunchKernelGGL(k_p2p_sum, dim3(grid), dim3(256), 0, H->stream, (const unsigned long long *) windows[rank], (int) nd, n_ranks, (int) (seq & 1), seq, H->distBuf, H->d_p2pErr);
+        hipLaunchKernelGGL(k_p2p_push, dim3(grid), dim3(256), 0, H->stream, (const double *) H->distBuf, (int) nd, p2p_slot_doubles(H), W, rank, n_ranks, (int) (seq & 1), seq);
+        hipLaunchKernelGGL(k_p2p_sum, dim3(grid), dim3(256), 0, H->stream, (const unsigned long long *) windows[rank], (int) nd, p2p_slot_doubles(H), n_ranks, (int) (seq & 1), seq, H->distBuf, H->d_p2pErr);
         CHK(hipGetLastError());
         RUN(ldso_ba_gn_solve_reduced(H, H->distBuf, first_iteration + i, 1e-1));
     }

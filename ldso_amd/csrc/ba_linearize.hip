@@ -140,6 +140,8 @@ static_assert(offsetof(ResSet, slot) == 0 && offsetof(ResSet, chunkEnergy) == 56
 // indices of the ResSet pointers inside their group
 enum { RS_SLOT = 0, RS_PT = 1, RS_ACC = 2, RS_CAND = 3, RS_G = 4, RS_TOPA = 5, RS_TOPL = 6, RS_CHUNKE = 7 };
 
+// floats of LDS behind sXa: sE [LD_WAVES] doubles | sC [4 LD_WAVES] ints | sN [LD_WAVES] floats, rounded to 16 bytes; the image pointers follow
+#define LD_TAIL_FLOATS ((2 * LD_WAVES + 4 * LD_WAVES + LD_WAVES + 3) & ~3)
 // flat index of entry (r,c), r<=c, in the packed upper triangle of a 13x13 matrix
 __host__ __device__ constexpr int tri13(int r, int c) { return r * 13 - (r * (r - 1)) / 2 + (c - r); }
 
@@ -285,7 +287,7 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
     float *sXa = sTopL + (HAS_L ? LD_WAVES * FS * LD_TOPN : 0);                      // [FS][8] xAd of this host (stepMode)
     // [FS] level-0 image of every target frame: the per-lane pointer comes from LDS (64 cycles) instead of a dependent global load of the
     // descriptor's img[] table in front of every tap gather
-    const float **sImg = (const float **) (sXa + FS * 8 + 16 + 4 * LD_WAVES + LD_WAVES);
+    const float **sImg = (const float **) (sXa + FS * 8 + LD_TAIL_FLOATS);      // behind sE | sC | sN of the block reduction (see below)
 
     if (gi.enable) {
         // initialise the HFinal / bFinal accumulator of the k_reduce that follows (lower triangle) with H_M and the diagonal
@@ -991,7 +993,7 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize_batch(const BatchIt
 // launcher
 // ---------------------------------------------------------------------------------------------------------
 size_t ba_linearize_lds_bytes(int FS, bool hasL) {
-    size_t fl = (size_t) FS * (sizeof(DevPair) / 4) + 2 * (size_t) FS * 64 + (size_t) LD_WAVES * FS * LD_TOPN + (hasL ? (size_t) LD_WAVES * FS * LD_TOPN : 0) + (size_t) FS * 8 + 64 + 2 * (size_t) FS;
+    size_t fl = (size_t) FS * (sizeof(DevPair) / 4) + 2 * (size_t) FS * 64 + (size_t) LD_WAVES * FS * LD_TOPN + (hasL ? (size_t) LD_WAVES * FS * LD_TOPN : 0) + (size_t) FS * 8 + LD_TAIL_FLOATS + 2 * (size_t) FS;
     return fl * sizeof(float) + 256;
 }
 
@@ -1000,7 +1002,7 @@ static hipError_t launch_one(const BaPtrs &B, const BaDims &D, const ResSet &cur
                             const int32_t *margFlags = nullptr) {
     size_t lds = ba_linearize_lds_bytes(D.FS, HAS_L);
     auto kfn = k_linearize<NSG, HAS_L, FIX, MARG>;
-    if (lds > 48 * 1024) hipFuncSetAttribute((const void *) kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+    if (lds > 48 * 1024) (void) hipFuncSetAttribute((const void *) kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
     hipLaunchKernelGGL(kfn, dim3(D.nChunks), dim3(64 * LD_WAVES), lds, st, B, D, cur, nxt, S, stepMode, gi, margFlags);
     return hipGetLastError();
 }
