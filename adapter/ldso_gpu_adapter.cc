@@ -1,6 +1,7 @@
 // ldso_gpu_adapter.cc — see ldso_gpu_adapter.h.  Compiles against the reference's headers (LDSO include/ + its Eigen / Sophus) and links
 // libldso_hip.so; every function is the replacement body of the reference member function it cites.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -206,7 +207,11 @@ float GpuBackend::optimize(FullSystem &fs, int mnumOptIts) {
 
     std::vector<shared_ptr<PointHessian>> allPoints;
     std::vector<shared_ptr<PointFrameResidual>> flat;
+    const auto tWall0 = std::chrono::steady_clock::now();
+    auto lap = [&](int i, std::chrono::steady_clock::time_point &t) { const auto n_ = std::chrono::steady_clock::now(); lastOptimizeSeconds[i] = std::chrono::duration<double>(n_ - t).count(); t = n_; };
+    auto tLap = tWall0;
     if (uploadWindow(fs, allPoints, flat) == 0) return 0;
+    lap(0, tLap);
     const int F = (int) fs.frames.size(), P = (int) allPoints.size(), R = (int) flat.size();
 
     // activeResiduals (:735-755) stays what the reference's later stages expect: the non-linearised residuals in traversal order
@@ -218,6 +223,7 @@ float GpuBackend::optimize(FullSystem &fs, int mnumOptIts) {
     const int rc = ldso_ba_optimize(ba_, mnumOptIts, /*force_all_iterations*/ 0, &rmse, &lastIterations);
     throwOn(rc, "ldso_ba_optimize");
     if (rc == LDSO_E_NONFINITE) { LOG(WARNING) << "KF Tracking failed: LOST!"; fs.isLost = true; }         // :853-857
+    lap(1, tLap);
 
     // ---- write back ----------------------------------------------------------------------------------------------------------------
     std::vector<ldso_res_out_t> ro((size_t) R); std::vector<int32_t> st((size_t) R), act((size_t) R), rem((size_t) R);
@@ -234,6 +240,7 @@ float GpuBackend::optimize(FullSystem &fs, int mnumOptIts) {
         throwOn(ldso_ba_get_jacobians(ba_, ids.data(), R, Jv.data()), "ldso_ba_get_jacobians");
     }
 
+    lap(2, tLap);
     // calibration and frames: the states through the reference's own setters (they rebuild state_scaled, PRE_worldToCam / PRE_camToWorld);
     // the newest frame was re-anchored (:845-848: setEvalPT(PRE_worldToCam, [0..0, a, b, 0, 0]))
     VecC v, vs;
@@ -298,6 +305,7 @@ float GpuBackend::optimize(FullSystem &fs, int mnumOptIts) {
             fr->aff_g2l = fr->frameHessian->aff_g2l();
         }
     }
+    lap(3, tLap);
     return rmse;
 }
 

@@ -41,8 +41,12 @@ public:
 
     // ---- windowed bundle adjustment -------------------------------------------------------------------------------------------------
     float optimize(FullSystem &fs, int mnumOptIts);
-    bool writeBackJacobians = true;      // also store RawResidualJacobian (296 B per residual) back into r->J (host code that still reads J)
+    // also store RawResidualJacobian (296 B per residual: 3.5 MB at C3) back into r->J.  Off by default: nothing of makeKeyFrame reads the J that
+    // optimize() leaves behind - flagPointsForRemoval re-linearises the residuals it marginalises (FullSystem.cc:1241-1250: r->linearize writes
+    // r->J itself) and the next optimize() re-linearises everything.  On for host code that still accumulates from r->J.
+    bool writeBackJacobians = false;
     int lastIterations = 0;              // GN iterations the device executed in the last optimize()
+    double lastOptimizeSeconds[4] = {0, 0, 0, 0};      // wall clock of the last optimize(): flatten + upload | device | fetch | write-back into the objects
 
     // ---- coarse tracker -------------------------------------------------------------------------------------------------------------
     void makeK(CoarseTracker &tr, shared_ptr<CalibHessian> HCalib);

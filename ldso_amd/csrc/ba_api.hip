@@ -161,7 +161,11 @@ int ldso_frame_set_prior(ldso_frame_t *f, const ldso_settings_t *s) {
 template <class T> static int dalloc(ldso_ba *H, T **p, size_t n) {
     void *q = nullptr;
     CHK(hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T)));
+    // hipMemset on device memory is asynchronous (legacy null stream) and the handles work on NON-BLOCKING streams, which do not order themselves
+    // behind it: without the wait a zero-fill that is still queued (the null stream busy with another library's work, e.g. torch's) could land on top
+    // of data the handle's first uploads / kernels have already written
     CHK(hipMemset(q, 0, std::max<size_t>(n, 1) * sizeof(T)));
+    CHK(hipStreamSynchronize(nullptr));
     H->allocs.push_back(q);
     *p = (T *) q;
     return LDSO_OK;
@@ -1392,6 +1396,7 @@ int ldso_ba_p2p_window_alloc(ldso_ba_t *H, int n_ranks, void **window_out, void 
         if (e_ != hipSuccess) { (void) hipGetLastError(); ldso_set_error(std::string("ldso_ba_p2p_window_alloc: uncached device memory unavailable (hipExtMallocWithFlags: ") + hipGetErrorString(e_) + ")"); return LDSO_E_UNSUPPORTED; }
     }
     CHK(hipMemset(p, 0, bytes));
+    CHK(hipStreamSynchronize(nullptr));          // (asynchronous zero-fill, see dalloc)
     if (ipc_handle_out) {
         hipIpcMemHandle_t hnd;
         const hipError_t e_ = hipIpcGetMemHandle(&hnd, p);

@@ -881,7 +881,11 @@ struct ldso_tracker {
 template <class T> static int tr_alloc(ldso_tracker *H, T **p, size_t n) {
     void *q = nullptr;
     CHK(hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T)));
+    // hipMemset on device memory is asynchronous (legacy null stream) and the handles work on NON-BLOCKING streams, which do not order themselves
+    // behind it: without the wait a zero-fill that is still queued (the null stream busy with another library's work, e.g. torch's) could land on top
+    // of data the handle's first uploads / kernels have already written
     CHK(hipMemset(q, 0, std::max<size_t>(n, 1) * sizeof(T)));
+    CHK(hipStreamSynchronize(nullptr));
     H->allocs.push_back(q);
     *p = (T *) q;
     return LDSO_OK;

@@ -517,15 +517,19 @@ def default_trace_settings():
     return s
 
 
-def make_immature_points(win: "Window", per_frame: int, seed: int = 7):
+def make_immature_points(win: "Window", per_frame: int, seed: int = 7, frames=None, hosts=None):
     """Fresh immature points on the key frames of a window, as the ImmaturePoint constructor makes them
-    (ImmaturePoint.cc:14-38): pattern colours / weights / gradH at gradient-rich pixels; idepth interval [0, NaN)."""
+    (ImmaturePoint.cc:14-38): pattern colours / weights / gradH at gradient-rich pixels; idepth interval [0, NaN).
+    frames: indices into win.images (default: the window's F key frames; the extra frames of make_window(extra_frames=...) are F, F+1, ...),
+    hosts: the `host` index each of them gets (default: the image index)."""
     rng = np.random.default_rng(seed)
-    F = win.F
+    frames = list(range(win.F)) if frames is None else list(frames)
+    hosts = frames if hosts is None else list(hosts)
+    F = len(frames)
     out = np.zeros(F * per_frame, IMMATURE_DTYPE)
     true_id = np.zeros(F * per_frame, np.float32)
     n = 0
-    for k in range(F):
+    for k, hostIdx in zip(frames, hosts):
         dI = win.images[k][0]
         us, vs = [], []
         while len(us) < per_frame:
@@ -536,7 +540,7 @@ def make_immature_points(win: "Window", per_frame: int, seed: int = 7):
             us += list(cu[ok]); vs += list(cv[ok])
         us = np.asarray(us[:per_frame], np.float32); vs = np.asarray(vs[:per_frame], np.float32)
         sl = slice(n, n + per_frame)
-        out["u"][sl] = us; out["v"][sl] = vs; out["host"][sl] = k
+        out["u"][sl] = us; out["v"][sl] = vs; out["host"][sl] = hostIdx
         gh = np.zeros((per_frame, 4), np.float32)
         for j in range(8):
             c, gx, gy = interp_bilin33(dI, us + PATTERN[j, 0], vs + PATTERN[j, 1])

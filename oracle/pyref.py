@@ -183,6 +183,14 @@ class RefWindow:
         img = np.ascontiguousarray(dI_level0, np.float32); T = np.ascontiguousarray(np.asarray(w2c, np.float64)[:3, :4])
         return C.c_void_p(self.L.ref_fs_new_frame(self.h, _p(img), _p(T), C.c_float(aff_a), C.c_float(aff_b), C.c_float(exposure)))
 
+    def fs_set_frame_id(self, fh, frame_id):
+        self.L.ref_fs_set_frame_id(fh, C.c_long(frame_id))
+
+    def fs_handle(self):
+        self.fs_attach()
+        self.L.ref_fs_handle.restype = C.c_void_p
+        return C.c_void_p(self.L.ref_fs_handle(self.h))
+
     def fs_trace_new_coarse(self, fh):
         self.L.ref_fs_trace_new_coarse(self.h, fh)
 
@@ -383,6 +391,15 @@ class GpuAdapter:
             L.ref_fs_free_immature(vec)
         return dict(ok=ok, idepth=idepth, res_target=tgt, last=last)
 
+    def set_write_back_jacobians(self, on: bool):
+        self.A.adp_set_write_back_jacobians(self.h, C.c_int(1 if on else 0))
+
+    def last_optimize_times(self):
+        """wall-clock split of the last GpuBackend::optimize (s): flatten + upload, device, fetch, write-back"""
+        t = np.zeros(4, np.float64)
+        self.A.adp_last_optimize_times(self.h, _p(t))
+        return t
+
     def trace_new_coarse(self, ref_window: "RefWindow", fh):
         """GpuBackend::traceNewCoarse(fs, fh) in place of FullSystem::traceNewCoarse -> the six status counters"""
         ref_window.fs_attach()
@@ -549,3 +566,33 @@ class RefInitializer:
         out = np.zeros(self.n[lvl], synth.INIT_POINT_DTYPE)
         self.L.ref_init_get_points(self.h, C.c_int(lvl), _p(out))
         return out
+
+
+def make_keyframe(ref_window: "RefWindow", adapter, fh, marg_idx: int, kf_id: int, iterations: int = 6):
+    """one key frame in FullSystem::makeKeyFrame's order (adapter/adapter_capi.cc: adp_make_keyframe) on the window's reference objects: adapter = None
+    runs the reference's own members, a GpuAdapter puts GpuBackend::traceNewCoarse / activatePoints / optimize in their place
+    -> (rmse, dict(candidates, activated, new_residuals, points, lost))"""
+    A = adapter_lib()
+    fs = ref_window.fs_handle()
+    rmse = C.c_float()
+    st = np.zeros(8, np.int32)
+    rc = A.adp_make_keyframe(adapter.h if adapter is not None else None, fs, fh, C.c_int(marg_idx), C.c_int(kf_id), C.c_int(iterations), C.byref(rmse), _p(st))
+    if rc != 0:
+        raise RuntimeError(A.adp_last_error().decode())
+    ref_window.L.ref_fs_sync_back(ref_window.h)
+    return rmse.value, dict(candidates=int(st[0]), activated=int(st[1]), new_residuals=int(st[2]), points=int(st[3]), lost=bool(st[4]))
+
+
+def graph_summary(ref_window: "RefWindow", cap_frames=16):
+    """frames: [F] rows of (id, camToWorld 3x4, a, b, active points, residuals, immature points), the prior HM / bM, the calibration, inverse depths + hosts"""
+    A = adapter_lib()
+    fs = ref_window.fs_handle()
+    fr = np.zeros((cap_frames, 18), np.float64)
+    n = 8 * cap_frames + 4
+    HM = np.zeros(n * n, np.float64); bM = np.zeros(n, np.float64); cal = np.zeros(4, np.float64)
+    F = A.adp_graph_summary(fs, C.c_int(cap_frames), _p(fr), _p(HM), _p(bM), _p(cal))
+    n = 8 * F + 4
+    idp = np.zeros(200000, np.float32); host = np.zeros(200000, np.int32)
+    P = A.adp_graph_idepths(fs, C.c_int(len(idp)), _p(idp), _p(host))
+    return dict(F=F, ids=fr[:F, 0].astype(int), c2w=fr[:F, 1:13].reshape(F, 3, 4), aff=fr[:F, 13:15], points=fr[:F, 15].astype(int), residuals=fr[:F, 16].astype(int),
+                immature=fr[:F, 17].astype(int), HM=HM[:n * n].reshape(n, n).copy(), bM=bM[:n].copy(), calib=cal, idepth=idp[:P].copy(), host=host[:P].copy())

@@ -674,6 +674,12 @@ void *ref_fs_new_frame(void *h, const float *dI_level0, const double *w2c, float
     g_newFrames.push_back(fr);
     return &g_newFrames.back()->frameHessian;               // shared_ptr<FrameHessian> *
 }
+// Frame::id comes from a process-wide counter (Frame.cc:13-20): two object graphs built side by side get different ids, and FrameHessian::getPrior
+// / the adapter's image slots key on it - a comparison run gives the frames of both graphs the same ids
+void ref_fs_set_frame_id(void *fh_shared_ptr, long id) {
+    shared_ptr<FrameHessian> &fh = *(shared_ptr<FrameHessian> *) fh_shared_ptr;
+    fh->frame->id = (unsigned long) id;
+}
 void ref_fs_release_new_frames() {
     for (auto &fr : g_newFrames) if (fr->frameHessian) for (int l = 0; l < PYR_LEVELS; l++) { fr->frameHessian->dIp[l] = nullptr; fr->frameHessian->absSquaredGrad[l] = nullptr; }
     g_newFrames.clear(); g_newFrameImages.clear();
