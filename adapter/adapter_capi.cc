@@ -238,14 +238,15 @@ int adp_graph_summary(void *fs_, int capFrames, double *frames18, double *HM, do
     if (calib4) for (int i = 0; i < 4; i++) calib4[i] = fs.Hcalib->mpCH->value[i];
     return F;
 }
-// inverse depths of the active points in traversal order (frames, then their features) - up to cap; returns the count
-int adp_graph_idepths(void *fs_, int cap, float *idepth, int *host) {
+// inverse depths of the active points in traversal order (frames, then their features) - up to cap; returns the count.  host = Frame::id of the host
+// key frame, uv = the point's pixel: (host, u, v) identifies a point across two object graphs whose point sets differ by a few threshold cases
+int adp_graph_idepths(void *fs_, int cap, float *idepth, int *host, float *uv) {
     FullSystem &fs = *(FullSystem *) fs_;
     int n = 0;
     for (size_t f = 0; f < fs.frames.size(); f++)
         for (auto &feat : fs.frames[f]->features)
             if (feat->status == Feature::FeatureStatus::VALID && feat->point && feat->point->status == Point::PointStatus::ACTIVE) {
-                if (n < cap) { idepth[n] = feat->point->mpPH->idepth; host[n] = (int) f; }
+                if (n < cap) { idepth[n] = feat->point->mpPH->idepth; host[n] = (int) fs.frames[f]->id; uv[2 * n] = feat->uv[0]; uv[2 * n + 1] = feat->uv[1]; }
                 n++;
             }
     return n;

@@ -382,7 +382,7 @@ def main():
                 out["batched"] = batched_line(args, local_rank)
             except Exception as ex:
                 out["batched"] = {"error": repr(ex)}
-            for key, fn in (("tracker", tracker_line), ("tracer", tracer_line), ("initializer", initializer_line)):
+            for key, fn in (("adapter", adapter_line), ("tracker", tracker_line), ("tracer", tracer_line), ("initializer", initializer_line)):
                 try:
                     out[key] = fn()          # informational lines; never fail the BA metric on them
                 except Exception as ex:
@@ -430,6 +430,47 @@ def batched_line(args, local_rank, Bs=(8, 32), min_timed_s=0.2):
         bt.close()
     for g in handles:
         g.close()
+    return out
+
+
+def adapter_line(name="C3"):
+    """What a maintainer sees after the switch (informational): wall time of ldso::GpuBackend::optimize(6) - the compiled drop-in of
+    adapter/ldso_gpu_adapter.cc - against the reference's own FullSystem::optimize(6) ON THE SAME REFERENCE OBJECT GRAPH (Frame / FrameHessian /
+    PointHessian / PointFrameResidual objects built by oracle/ref_driver.cc from the reference's translation units: they are the boundary's
+    types here, and the reference leg is a cpu_baseline), with the adapter's time split into flatten + upload | device | fetch | write-back.
+    None where the prebuilt libraries are absent."""
+    from ldso_amd import synth
+    try:
+        from oracle import pyref as pr
+        if not (pr.available() and pr.adapter_available()):
+            return None
+    except Exception:
+        return None
+    win = synth.add_synthetic_prior(synth.make_config(name))
+    out = {"workload": f"{name}: {win.F} KF x {win.P} pt, R = {win.R}; one optimize(6) call on the reference's object graph (canbreak decides the iterations executed)"}
+    with _QuietCStdout():
+        keep = pr.RefWindow(win)          # the reference's globals (image size, calibration: internal/GlobalCalib.h) are set by the first object graph
+        A = pr.GpuAdapter(max_frames=win.F + 1, max_points=win.P + 16)
+        for wb in (False, True):
+            A.set_write_back_jacobians(wb)
+            ts, splits, its = [], [], 0
+            for rep in range(6):
+                r = pr.RefWindow(win)
+                t0 = time.perf_counter(); rv, its, lost = A.optimize(r, 6); ts.append(time.perf_counter() - t0); splits.append(A.last_optimize_times().copy())
+                r.close()
+            sp = np.median(np.array(splits[1:]), axis=0)
+            out["gpu_backend_optimize_ms" if not wb else "gpu_backend_optimize_ms_with_jacobian_write_back"] = round(float(np.median(ts[1:])) * 1e3, 3)
+            out["split_ms" if not wb else "split_ms_with_jacobian_write_back"] = {"flatten_upload": round(sp[0] * 1e3, 3), "device": round(sp[1] * 1e3, 3), "fetch": round(sp[2] * 1e3, 3),
+                                                                                  "write_back": round(sp[3] * 1e3, 3)}
+            out["iterations_executed"] = its
+        tr = []
+        for rep in range(3):
+            r = pr.RefWindow(win); r.fs_attach()
+            t0 = time.perf_counter(); r.fs_optimize(6); tr.append(time.perf_counter() - t0)
+            r.close()
+        A.close(); keep.close()
+    out["reference_FullSystem_optimize_ms"] = round(float(np.median(tr)) * 1e3, 3)
+    out["reference_build"] = "reference translation units, g++ -O2, single thread, Eigen = oracle/ref_shim (eager evaluation): a floor for the reference's speed"
     return out
 
 

@@ -19,9 +19,6 @@
 #ifndef LD_WAVES
 #define LD_WAVES 8            // waves per linearize block
 #endif
-#ifndef LD_PREFETCH
-#define LD_PREFETCH 0         // 1: load the point record one point ahead (pays when a SIMD holds a single wave)
-#endif
 #define LD_GEXTRA 8           // per-point extras appended to a G row: Hcd[4], bdSum, HdiF, pad, pad
 
 struct DevPair {

@@ -78,31 +78,13 @@ __device__ __forceinline__ float seq8(float x, int k, int lane) {
     return hi;
 }
 
-// gfx950: v_permlane16_swap_b32 a, b exchanges the odd 16-lane rows of a with the even rows of b; v_permlane32_swap_b32 the upper half of a
-// with the lower half of b.  With a = b = x, a + b is the xor-16 / xor-32 butterfly sum - in the vector ALU, where ds_bpermute costs an LDS
-// round trip.  s_nop: the assembler does not know the hazards of hand-placed instructions.  Kept as an option (LD_PERM_DESC / LD_PERM_ARGS):
-// bit-identical results, measured 2 % SLOWER than the ds_bpermute form in every configuration (see the defaults below).
-__device__ __forceinline__ float bfly16(float x) {
-    float a = x, b = x;
-    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
-    return a + b;
-}
-__device__ __forceinline__ float bfly32(float x) {
-    float a = x, b = x;
-    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
-    return a + b;
-}
-// sum over the 8 slots of a wave (lanes with equal k), result in every lane: slot pairs by row_ror:8, then the four rows by the two
-// butterflies above (tree order; the sequential-order sums that decide residual states use seq8)
-template <bool PERM> __device__ __forceinline__ float sum_slots(float x, int a16, int a32) {
+// sum over the 8 slots of a wave (lanes with equal k), result in every lane: slot pairs by row_ror:8, then the four rows by two ds_bpermute
+// butterflies (tree order; the sequential-order sums that decide residual states use seq8).  gfx950's v_permlane16_swap / v_permlane32_swap
+// butterflies were measured against this in rounds 3 and 4: bit-identical, 2 % slower in every configuration - removed.
+__device__ __forceinline__ float sum_slots(float x, int a16, int a32) {
     x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128, 0xF, 0xF, true));
-    if (PERM) {
-        x = bfly16(x);
-        x = bfly32(x);
-    } else {
-        x += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(a16, __builtin_bit_cast(int, x)));
-        x += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(a32, __builtin_bit_cast(int, x)));
-    }
+    x += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(a16, __builtin_bit_cast(int, x)));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(a32, __builtin_bit_cast(int, x)));
     return x;
 }
 // ---- just-in-time pointer groups ------------------------------------------------------------------------------------------------
@@ -145,9 +127,8 @@ enum { RS_SLOT = 0, RS_PT = 1, RS_ACC = 2, RS_CAND = 3, RS_G = 4, RS_TOPA = 5, R
 // flat index of entry (r,c), r<=c, in the packed upper triangle of a 13x13 matrix
 __host__ __device__ constexpr int tri13(int r, int c) { return r * 13 - (r * (r - 1)) / 2 + (c - r); }
 
-// Everything a wave reads from HBM for one point besides the image taps.  With LD_PREFETCH: loaded one point ahead (software
-// pipeline): the loads of point i+1 are in flight while point i is computed, and the first point's loads overlap
-// the LDS staging of the block, so a wave sees two dependent memory levels (this record, then the taps).
+// Everything a wave reads from HBM for one point besides the image taps.  The first point's record is loaded before the LDS staging of the block
+// (its latency overlaps the staging); later points load theirs at the top of their pass.
 template <int NSG>
 struct PtIn {
     float pu, pv, idp, idz, priorF, color, wgt;
@@ -176,26 +157,11 @@ template <> struct at_sel<true> {
 template <> struct at_sel<false> {
     template <class T> static __device__ __forceinline__ T &ref(T *p, unsigned i) { return *(T *) ((char *) p + (size_t) (i * (unsigned) sizeof(T))); }
 };
-#ifndef LD_GLOBAL_ARGS
-#define LD_GLOBAL_ARGS 0
-#endif
-#ifndef LD_PERM_ARGS
-#define LD_PERM_ARGS 0
-#endif
-#ifndef LD_PERM_DESC
-#define LD_PERM_DESC 0      // measured (A/B, two rounds each on one box): 220.3 / 51.6 / 10.07 us (B = 32 / B = 8 / C3) with ds_bpermute against 225.2 / 52.7 / 10.17 us with the
-#endif                   // permlane butterflies below - their hand-placed s_nop pairs and the opaque asm cost more than the LDS round trips they save
-#define AT(ptr, i) (at_sel<DESC || LD_GLOBAL_ARGS>::ref((ptr), (unsigned) (i)))
+#define AT(ptr, i) (at_sel<DESC>::ref((ptr), (unsigned) (i)))
 // Per-POINT data have a wave-uniform address - a wavefront works on one point at a time.  Read through a constant-address-space pointer with
 // the index in an SGPR they become scalar loads (s_load_dwordxN, scalar cache): no vector memory instruction, no VGPR address, nothing on
 // vmcnt.  Legal because no wavefront reads an entry again after anybody has written it inside one launch (a point belongs to one wavefront;
 // what it stores depends on what it loaded), and the scalar cache is invalidated at the launch boundary.
-#ifndef LD_GLOBAL_TAPS
-#define LD_GLOBAL_TAPS 0
-#endif
-#ifndef LD_PIPE
-#define LD_PIPE 0          // 1: software-pipelined point loop of the descriptor-based one-slot-group kernel (see linearize_body)
-#endif
 template <class T> using cptr_t = const __attribute__((address_space(4))) T *;
 
 typedef int v4i32_t __attribute__((ext_vector_type(4)));
@@ -373,83 +339,7 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
     float nidSum = 0.0f;
     int nidCnt = 0;
 
-    // ---- LD_PIPE: software pipeline over the points of a wavefront (one slot group, plain GN pass) ----------------------------------------
-    // front(i + 1) - record, fused point step, projection, TAP LOADS - is issued before the arithmetic of point i, so the tap latency of a
-    // point overlaps the arithmetic and the stores of its predecessor and the record latency overlaps the predecessor's tap latency.  What
-    // crosses from the front to the back half is small: the record, the stepped inverse depth and the 12 tap values (the back half redoes the
-    // projection - same inputs, same bits - instead of carrying ~25 registers of it).  Needs the record layout (13 vector memory operations per
-    // point: two points in flight stay far below the 63 the counter tracks) and taps through GLOBAL addresses (a flat load also ticks
-    // lgkmcnt, and every LDS permute of the next front half would wait for the taps in flight).
-    constexpr bool PIPE = (LD_PIPE != 0) && DESC && NSG == 1 && !HAS_L && !FIX && !MARG;
-    struct FrontT { PtIn<NSG> q; float idp, idz; float tap[NSG][12]; };
-    auto front = [&](FrontT &f, const unsigned p, const bool load) {
-        if (load) load_point<NSG, HAS_L, FIX, DESC>(f.q, B, cur, FS, p, s, k, stepMode);
-        const PtIn<NSG> &q = f.q;
-        float idp = q.idp, idz = q.idz;
-        float lo_, hiState, hiActive;
-        group_bcast_pair<1>(q.m[0], k, lo_, hiState); group_bcast_pair<2>(q.m[0], k, lo_, hiActive);
-        const int qState0 = __builtin_bit_cast(int, hiState), qActive0 = __builtin_bit_cast(int, hiActive);
-        const int t = s;
-        if (stepMode & 1) {          // the fused point step, exactly as in the body below
-            float step = 0.0f;
-            if (q.rec.nActive > 0) {
-                float b = q.rec.bdSumF;
-                float dot = 0;
-                dot += xc0 * (q.rec.HcdA[0] + q.rec.HcdL[0]); dot += xc1 * (q.rec.HcdA[1] + q.rec.HcdL[1]); dot += xc2 * (q.rec.HcdA[2] + q.rec.HcdL[2]); dot += xc3 * (q.rec.HcdA[3] + q.rec.HcdL[3]);
-                b -= dot;
-                const bool act = (t < F) && (q.rflat[0] >= 0) && (qActive0 != 0);
-                float sres = seq8(sXa[t * 8 + k] * q.jp[0], k, lane);
-                sres = act ? sres : 0.0f;
-                b -= sum_slots<(LD_PERM_DESC != 0)>(sres, a16, a32);
-                if (isfinite(b)) step = -b * q.rec.HdiF; else { step = q.pstep; if (lane == 0) *(gptr_t<double>) (unsigned long long) (B.scalars + 4) = 1.0; }
-            }
-            const float ni = idp + 1.0f * step;
-            const v16i_t b0 = ldg16<DESC, OFF_B0>(&B);
-            v4f_t *w_geo = GP(v4f_t, b0, BP_GEO);
-            if (lane == 1 || lane == 2) {
-                v4f_t v;
-                v.x = (lane == 1) ? ni : q.rec.HdiF; v.y = (lane == 1) ? ni : q.rec.bdSumF; v.z = (lane == 1) ? step : q.rec.idH; v.w = (lane == 1) ? idp : 0.0f;
-                AT(w_geo, p * 4 + (unsigned) lane) = v;
-            }
-            idp = ni; idz = ni;
-        }
-        f.idp = idp; f.idz = idz;
-        // the projection of the body below, only as far as the tap addresses need it
-        const bool exists = (t < F) && (q.rflat[0] >= 0);
-        const bool isLin = exists && (q.rlin[0] != 0);
-        const bool reset = (stepMode & 2) && !isLin;
-        const int st = exists ? (reset ? RES_IN : qState0) : RES_OOB;
-        const bool compute = exists && !isLin && st != RES_OOB;
-        const DevPair &pr = sPair[t];
-        const float pu = q.pu, pv = q.pv;
-        float KliP0 = (pu + 0 - cx) * fxi, KliP1 = (pv + 0 - cy) * fyi;
-        float ptp0 = ((pr.R0[0] * KliP0 + pr.R0[1] * KliP1) + pr.R0[2] * 1.0f) + pr.t0[0] * idz;
-        float ptp1 = ((pr.R0[3] * KliP0 + pr.R0[4] * KliP1) + pr.R0[5] * 1.0f) + pr.t0[1] * idz;
-        float ptp2 = ((pr.R0[6] * KliP0 + pr.R0[7] * KliP1) + pr.R0[8] * 1.0f) + pr.t0[2] * idz;
-        float drescale = 1.0f / ptp2;
-        float uu = ptp0 * drescale, vv = ptp1 * drescale;
-        float cKu = uu * fx + cx, cKv = vv * fy + cy;
-        const bool centerOK = (drescale > 0) && cKu > 1.1f && cKv > 1.1f && cKu < wM3G && cKv < hM3G;
-        float px_ = pu + (float) ox, py_ = pv + (float) oy;
-        float q0 = ((pr.KRKi[0] * px_ + pr.KRKi[1] * py_) + pr.KRKi[2] * 1.0f) + pr.Kt[0] * idp;
-        float q1 = ((pr.KRKi[3] * px_ + pr.KRKi[4] * py_) + pr.KRKi[5] * 1.0f) + pr.Kt[1] * idp;
-        float q2 = ((pr.KRKi[6] * px_ + pr.KRKi[7] * py_) + pr.KRKi[8] * 1.0f) + pr.Kt[2] * idp;
-        float Ku = q0 / q2, Kv = q1 / q2;
-        const bool pixOK = Ku > 1.1f && Kv > 1.1f && Ku < wM3G && Kv < hM3G;
-        {
-            // UNCONDITIONAL loads (a lane without a valid projection reads pixel (0, 0) of frame 0 and ignores it): loads under a divergent branch
-            // make the compiler's wait for the PREVIOUS point's taps a vmcnt(0), which would also drain these
-            const bool ok = compute && centerOK && pixOK;
-            const int ix = ok ? (int) Ku : 0, iy = ok ? (int) Kv : 0;
-            const gptr_t<const float> bp = (gptr_t<const float>) (unsigned long long) sImg[ok ? t : 0] + 3 * (ix + iy * W);
-            const gptr_t<const float> bq = bp + 3 * W;
-#pragma unroll
-            for (int i = 0; i < 6; i++) { f.tap[0][i] = bp[i]; f.tap[0][6 + i] = bq[i]; }
-        }
-    };
-
-    // one point: `fr` = its front half when pipelined (nullptr otherwise)
-    auto point_body = [&](const unsigned p, const PtIn<NSG> &q, const FrontT *fr) {
+    auto point_body = [&](const unsigned p, const PtIn<NSG> &q) {
         if (pi == wave) LSTAMP(2);
         // the uniform scalars of each slot record sit in the m of lanes 3 (energy), 5 (state), 6 (activity) of its 8-lane group
         int qState[NSG], qActive[NSG];
@@ -465,8 +355,7 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
         const bool flagged = MARG ? (margFlags[p] != 0) : true;
         const float color = q.color, wgt = q.wgt;
         float idp = q.idp, idz = q.idz;
-        if (PIPE) { idp = fr->idp; idz = fr->idz; }
-        else if (stepMode & 1) {
+        if (stepMode & 1) {
             // ---- resubstituteFPt for this point, then backupState + doStepFromBackup (stepfacD = 1) ------------
             float step = 0.0f;
             if (q.rec.nActive > 0) {
@@ -480,7 +369,7 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
                     const bool act = (t < F) && (q.rflat[g] >= 0) && (qActive[g] != 0);
                     float sres = seq8(sXa[t * 8 + k] * q.jp[g], k, lane);
                     sres = act ? sres : 0.0f;
-                    b -= sum_slots<DESC ? (LD_PERM_DESC != 0) : (LD_PERM_ARGS != 0)>(sres, a16, a32);
+                    b -= sum_slots(sres, a16, a32);
                 }
                 if (isfinite(b)) step = -b * q.rec.HdiF; else { step = q.pstep; if (lane == 0) *(gptr_t<double>) (unsigned long long) (B.scalars + 4) = 1.0; }
             }
@@ -560,21 +449,7 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
                 float dx = Ku - ix, dy = Kv - iy, dxdy = dx * dy;
                 // descriptor in memory: the pointer from LDS; kernel arguments: the table sits in scalar registers, selected per lane
                 float a0, a1, a2, b0_, b1, b2, c0_, c1_, c2_, d0, d1, d2;
-                if constexpr (PIPE) {          // loaded by the front half
-                    const float *tp = fr->tap[g];
-                    a0 = tp[0]; a1 = tp[1]; a2 = tp[2]; b0_ = tp[3]; b1 = tp[4]; b2 = tp[5]; c0_ = tp[6]; c1_ = tp[7]; c2_ = tp[8]; d0 = tp[9]; d1 = tp[10]; d2 = tp[11];
-                    // opaque to the compiler up to here: it must not start re-packing the freshly loaded values for packed arithmetic right
-                    // behind the loads (that re-packing is a use, and a use is a wait)
-                    asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(b0_), "+v"(b1), "+v"(b2));
-                    asm volatile("" : "+v"(c0_), "+v"(c1_), "+v"(c2_), "+v"(d0), "+v"(d1), "+v"(d2));
-                } else if constexpr (DESC && (LD_GLOBAL_TAPS != 0)) {
-                    // experiment: the image pointer is a per-lane value from LDS, i.e. generic to the compiler -> FLAT loads, which tick lgkmcnt as
-                    // well as vmcnt (every LDS wait then also waits for the taps).  Images are hipMalloc'ed: address them as global memory.
-                    const gptr_t<const float> bp = (gptr_t<const float>) (unsigned long long) sImg[t] + 3 * (ix + iy * W);
-                    a0 = bp[0]; a1 = bp[1]; a2 = bp[2]; b0_ = bp[3]; b1 = bp[4]; b2 = bp[5];
-                    const gptr_t<const float> bq = bp + 3 * W;
-                    c0_ = bq[0]; c1_ = bq[1]; c2_ = bq[2]; d0 = bq[3]; d1 = bq[4]; d2 = bq[5];
-                } else {
+                {
                     const float *bp = (DESC ? sImg[t] : B.img[t]) + 3 * (ix + iy * W);
                     a0 = bp[0]; a1 = bp[1]; a2 = bp[2]; b0_ = bp[3]; b1 = bp[4]; b2 = bp[5];
                     const float *bq = bp + 3 * W;
@@ -718,9 +593,9 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
             float sHc0 = accHere ? (x[0] * Ji2_0 + y[0] * Ji2_1) : 0.0f, sHc1 = accHere ? (x[1] * Ji2_0 + y[1] * Ji2_1) : 0.0f;
             float sHc2 = accHere ? (x[2] * Ji2_0 + y[2] * Ji2_1) : 0.0f, sHc3 = accHere ? (x[3] * Ji2_0 + y[3] * Ji2_1) : 0.0f;
             // sum over the 8 slots of this pass
-            bdA += sum_slots<DESC ? (LD_PERM_DESC != 0) : (LD_PERM_ARGS != 0)>(sbd, a16, a32); HddA += sum_slots<DESC ? (LD_PERM_DESC != 0) : (LD_PERM_ARGS != 0)>(sHdd, a16, a32);
-            HcdA0 += sum_slots<DESC ? (LD_PERM_DESC != 0) : (LD_PERM_ARGS != 0)>(sHc0, a16, a32); HcdA1 += sum_slots<DESC ? (LD_PERM_DESC != 0) : (LD_PERM_ARGS != 0)>(sHc1, a16, a32);
-            HcdA2 += sum_slots<DESC ? (LD_PERM_DESC != 0) : (LD_PERM_ARGS != 0)>(sHc2, a16, a32); HcdA3 += sum_slots<DESC ? (LD_PERM_DESC != 0) : (LD_PERM_ARGS != 0)>(sHc3, a16, a32);
+            bdA += sum_slots(sbd, a16, a32); HddA += sum_slots(sHdd, a16, a32);
+            HcdA0 += sum_slots(sHc0, a16, a32); HcdA1 += sum_slots(sHc1, a16, a32);
+            HcdA2 += sum_slots(sHc2, a16, a32); HcdA3 += sum_slots(sHc3, a16, a32);
             if (accHere && k == 0) nresA++;
 
             // ================= linearised residual, mode 1 (AccumulatedTopHessian.cc:29-31,44-63) =======
@@ -785,9 +660,9 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
                     lsHdd = lJi0 * J.Jpdd[0] + lJi1 * J.Jpdd[1];
                     lH0 = lx[0] * lJi0 + ly[0] * lJi1; lH1 = lx[1] * lJi0 + ly[1] * lJi1; lH2 = lx[2] * lJi0 + ly[2] * lJi1; lH3 = lx[3] * lJi0 + ly[3] * lJi1;
                 }
-                bdL += sum_slots<DESC ? (LD_PERM_DESC != 0) : (LD_PERM_ARGS != 0)>(lsbd, a16, a32); HddL += sum_slots<DESC ? (LD_PERM_DESC != 0) : (LD_PERM_ARGS != 0)>(lsHdd, a16, a32);
-                HcdL0 += sum_slots<DESC ? (LD_PERM_DESC != 0) : (LD_PERM_ARGS != 0)>(lH0, a16, a32); HcdL1 += sum_slots<DESC ? (LD_PERM_DESC != 0) : (LD_PERM_ARGS != 0)>(lH1, a16, a32);
-                HcdL2 += sum_slots<DESC ? (LD_PERM_DESC != 0) : (LD_PERM_ARGS != 0)>(lH2, a16, a32); HcdL3 += sum_slots<DESC ? (LD_PERM_DESC != 0) : (LD_PERM_ARGS != 0)>(lH3, a16, a32);
+                bdL += sum_slots(lsbd, a16, a32); HddL += sum_slots(lsHdd, a16, a32);
+                HcdL0 += sum_slots(lH0, a16, a32); HcdL1 += sum_slots(lH1, a16, a32);
+                HcdL2 += sum_slots(lH2, a16, a32); HcdL3 += sum_slots(lH3, a16, a32);
             }
 
             // ================= lifted Schur row: target block and this slot's share of the host block ==
@@ -803,14 +678,14 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
                     for (int j = 0; j < 8; j++) { tgt = __builtin_fmaf(aT[j], vj[j], tgt); hpart = __builtin_fmaf(aH[j], vj[j], hpart); }
                 }
             }
-            hostPart += sum_slots<DESC ? (LD_PERM_DESC != 0) : (LD_PERM_ARGS != 0)>(hpart, a16, a32);
+            hostPart += sum_slots(hpart, a16, a32);
             gT[g] = tgt;
             nActive += __popcll(__ballot(exists && activeNew && k == 0));
             if (FIX) numGood += __popcll(newGoodMask);
             if (FIX) { float m = maxRelBS; m = fmaxf(m, __shfl_xor(m, 8, 64)); m = fmaxf(m, __shfl_xor(m, 16, 64)); m = fmaxf(m, __shfl_xor(m, 32, 64)); maxRelBS = m; }
 
             // ---- per-slot outputs: the slot's SlotRec of the next set, lane k stores its own pair (one dwordx2 store per lane) ------------
-            if (PIPE || t < F) {          // pipelined: also the padding slots (t >= F) store their (constant: no residual) record - one branch less in front of the stores
+            if (t < F) {
                 const v16i_t o0 = ldg16<DESC, OFF_S0>(&nxt);
                 v2f_t *o_slot = GP(v2f_t, o0, RS_SLOT);
                 float *o_cand = GP(float, o0, RS_CAND);
@@ -825,7 +700,7 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
                     if (doLin) energySum += ret;
                 }
             }
-            if (!PIPE && dumpJ != nullptr && compute) {          // (the pipelined kernel keeps its store count static: no dump - the host launches the plain kernel for it)
+            if (dumpJ != nullptr && compute) {
                 auto &o = *(gptr_t<ldso_rawjac_t>) (unsigned long long) (dumpJ + q.rflat[g]);          // global, not flat: a pending flat access makes every later wait a vmcnt(0)
                 o.resF[k] = resF; o.JIdx[0][k] = gx; o.JIdx[1][k] = gy; o.JabF[0][k] = jab0; o.JabF[1][k] = jab1;
                 if (k == 0) {
@@ -886,35 +761,12 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
         }
     };   // point_body
 
-    if constexpr (PIPE) {
-        // Steady state and tail are SEPARATE copies of the arithmetic: the compiler's wait for a point's taps is the minimum over all paths that
-        // reach it, and on the path without a successor (single point, last point) those taps are the most recent loads - sharing the code
-        // would make the steady-state wait drain the successor's taps as well.
-        FrontT fa, fb;
-        PtIn<NSG> qn;                                // the record one point further ahead: in flight during a whole back half
-        fa.q = nx;                                   // the first record was loaded before the staging
-        if (pi < np) front(fa, (unsigned) (p0 + pi), false);
-        if (pi + LD_WAVES < np) load_point<NSG, HAS_L, FIX, DESC>(qn, B, cur, FS, (unsigned) (p0 + pi + LD_WAVES), s, k, stepMode);
-        while (pi + LD_WAVES < np) {                 // a successor exists (wave-uniform); two points per trip: the buffers alternate without copies
-            // the record after the successor's - UNCONDITIONALLY (the successor's once more when there is none: a branch around the loads would
-            // again make the wait below the minimum over two paths)
-            fb.q = qn; front(fb, (unsigned) (p0 + pi + LD_WAVES), false);
-            { const int nn = (pi + 2 * LD_WAVES < np) ? pi + 2 * LD_WAVES : pi + LD_WAVES; load_point<NSG, HAS_L, FIX, DESC>(qn, B, cur, FS, (unsigned) (p0 + nn), s, k, stepMode); }
-            point_body((unsigned) (p0 + pi), fa.q, &fa);
-            pi += LD_WAVES;
-            if (!(pi + LD_WAVES < np)) { fa = fb; break; }
-            fa.q = qn; front(fa, (unsigned) (p0 + pi + LD_WAVES), false);
-            { const int nn = (pi + 2 * LD_WAVES < np) ? pi + 2 * LD_WAVES : pi + LD_WAVES; load_point<NSG, HAS_L, FIX, DESC>(qn, B, cur, FS, (unsigned) (p0 + nn), s, k, stepMode); }
-            point_body((unsigned) (p0 + pi), fb.q, &fb);
-            pi += LD_WAVES;
-        }
-        if (pi < np) { point_body((unsigned) (p0 + pi), fa.q, &fa); pi += LD_WAVES; }
-    } else {
+    {
 #pragma clang loop unroll(disable)
         for (; pi < np; pi += LD_WAVES) {
             const unsigned p = (unsigned) (p0 + pi);
             if (pi != wave) load_point<NSG, HAS_L, FIX, DESC>(nx, B, cur, FS, p, s, k, stepMode);       // the first record was loaded before the staging
-            point_body(p, nx, nullptr);
+            point_body(p, nx);
         }
     }   // points of this wave
 

@@ -1090,7 +1090,9 @@ __global__ __launch_bounds__(NT) void k_reduce_solve(BaPtrs B, BaDims D, ResSet 
 // the reduce of one half-batch overlaps the linearisation of the other) 104.8 k, 6 (80 VGPRs, 48 spilled) 83.0 k; B = 8 (520 workgroups per
 // launch, 2 per CU): 82 k unconstrained, 75.7 k with the 96-register allocation (different boxes, same day).
 #ifndef LD_REDB_BLOCKS
-#define LD_REDB_BLOCKS 5             // the dense variant: workgroups per CU its register allocation leaves room for
+#define LD_REDB_BLOCKS 4             // the dense variant: workgroups per CU its register allocation leaves room for (round 4, against the record-layout
+                                     // k_linearize_batch of 187 VGPRs, B = 32 different windows: 3 -> 122.4 k, 4 -> 122.4 k, 5 -> 96.8 k, 6 -> 87.5 k window-iterations/s,
+                                     // unconstrained 107.8 k; with round 3's 205-VGPR kernel 5 had been the best: 104.8 k)
 #endif
 #ifndef LD_REDB_DENSE_PER_CU
 #define LD_REDB_DENSE_PER_CU 6       // launches with at least this many workgroups per CU take the dense variant

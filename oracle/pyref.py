@@ -592,7 +592,7 @@ def graph_summary(ref_window: "RefWindow", cap_frames=16):
     HM = np.zeros(n * n, np.float64); bM = np.zeros(n, np.float64); cal = np.zeros(4, np.float64)
     F = A.adp_graph_summary(fs, C.c_int(cap_frames), _p(fr), _p(HM), _p(bM), _p(cal))
     n = 8 * F + 4
-    idp = np.zeros(200000, np.float32); host = np.zeros(200000, np.int32)
-    P = A.adp_graph_idepths(fs, C.c_int(len(idp)), _p(idp), _p(host))
+    idp = np.zeros(200000, np.float32); host = np.zeros(200000, np.int32); uv = np.zeros((200000, 2), np.float32)
+    P = A.adp_graph_idepths(fs, C.c_int(len(idp)), _p(idp), _p(host), _p(uv))
     return dict(F=F, ids=fr[:F, 0].astype(int), c2w=fr[:F, 1:13].reshape(F, 3, 4), aff=fr[:F, 13:15], points=fr[:F, 15].astype(int), residuals=fr[:F, 16].astype(int),
-                immature=fr[:F, 17].astype(int), HM=HM[:n * n].reshape(n, n).copy(), bM=bM[:n].copy(), calib=cal, idepth=idp[:P].copy(), host=host[:P].copy())
+                immature=fr[:F, 17].astype(int), HM=HM[:n * n].reshape(n, n).copy(), bM=bM[:n].copy(), calib=cal, idepth=idp[:P].copy(), host=host[:P].copy(), uv=uv[:P].copy())

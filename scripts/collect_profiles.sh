@@ -8,7 +8,7 @@
 # gpurun_out/profiles_<tag>/ (copy them into profiles/).  The timed region of bench.py is cut to 50 ms here (--min-timed-s): the default 2 s
 # would put 100 000 kernel records into every trace.
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 WHAT=${2:-all}
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/prof
@@ -26,9 +26,15 @@ if [ "$WHAT" = all ] || [ "$WHAT" = stats ]; then
   done
   ( cd "$ROOT" && timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/stats_bench_B32" -o stats --output-format csv -- $BB > "$OUT/stats_B32.log" 2>&1 )
   ( cd "$ROOT" && timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/stats_tracker" -o stats --output-format csv -- python scripts/bench_tracker.py > "$OUT/stats_tracker.log" 2>&1 )
+  # the sharded iteration on one GPU (the multi-GPU step with one rank owning every point): k_reduce + k_gn_export -> exchange -> k_gn_solve -> k_linearize,
+  # once with the no-op all-reduce (= what RCCL brackets) and once through the peer-write exchange (k_p2p_push / k_p2p_sum)
+  for CFG in C3 C4; do
+    timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/stats_dist_$CFG" -o stats --output-format csv -- $B --steps 300 --warmup 30 --no-extras --config $CFG --force-dist-path > "$OUT/stats_dist_$CFG.log" 2>&1
+    timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/stats_dist_p2p_$CFG" -o stats --output-format csv -- $B --steps 300 --warmup 30 --no-extras --config $CFG --force-dist-path --allreduce p2p > "$OUT/stats_dist_p2p_$CFG.log" 2>&1
+  done
 fi
 if [ "$WHAT" = all ] || [ "$WHAT" = pmc ]; then
-  for CFG in C3 C5; do
+  for CFG in C3 C4 C5; do
     for C in FETCH_SIZE WRITE_SIZE; do
       timeout 300 rocprofv3 --kernel-trace --pmc $C -d "$OUT/pmc_${CFG}_$C" -o pmc --output-format csv -- $B --steps 40 --warmup 5 --no-extras --config $CFG > "$OUT/pmc_${CFG}_$C.log" 2>&1
     done

@@ -27,6 +27,28 @@ for d in sorted(glob.glob(os.path.join(out, "stats_*"))):
     for r in rows[1:7]:
         print("  ", r[0][:70], "calls", r[1], "avg ns", r[3])
 
+# B = 32: the stats file averages whole-batch, half-batch (the pipelined iteration runs the batch as two halves) and single-window launches of
+# k_linearize_batch under one name; the per-launch trace tells them apart by their grid size -> {tag}_bench_B32_linearize_by_grid.json
+# (the bench line's k_linearize figure = the whole-batch launches: ldso_ba_batch_time_linearize)
+kt = find("stats_bench_B32/**/*kernel_trace.csv")
+if kt:
+    by = defaultdict(list)
+    for r in csv.DictReader(open(kt)):
+        if "k_linearize_batch" not in r.get("Kernel_Name", ""):
+            continue
+        try:
+            wg = int(r["Grid_Size_X"]) // max(int(r["Workgroup_Size_X"]), 1)
+            by[wg].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+        except (KeyError, ValueError):
+            continue
+    if by:
+        res = {"note": "k_linearize_batch launches of `python scripts/bench_batched.py --B 32` by workgroup count (rocprofv3 --kernel-trace): the largest grid = all 32 windows "
+                       "in one launch (the timing loop of ldso_ba_batch_time_linearize and the bench line's roofline figure), about half of it = one half-batch of the "
+                       "pipelined iteration (overlapped with the other half's k_reduce_batch / k_gn_solve_batch), ~250 = a single window (set-up)",
+               "by_workgroups": {str(k): {"launches": len(v), "avg_us": round(sum(v) / len(v), 3), "min_us": round(min(v), 3), "max_us": round(max(v), 3)} for k, v in sorted(by.items())}}
+        json.dump(res, open(os.path.join(dst, f"{tag}_bench_B32_linearize_by_grid.json"), "w"), indent=1)
+        print("== B32 k_linearize_batch by grid", {k: v["avg_us"] for k, v in res["by_workgroups"].items()})
+
 # calibration of the gfx950 FETCH_SIZE unit: scripts/micro/pmc_calib.hip (see profiles/r01_pmc_traffic.json "calibration")
 for cfg in ("C3", "C4", "C5", "B32"):
     res = {"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, with --kernel-trace only) around `python bench.py --steps 40 --warmup 5 "

@@ -88,3 +88,35 @@ def blockrel(A, B, bs=4):
             elif d > 0:
                 worst = max(worst, np.inf)
     return worst
+
+
+def observe(name, value, limit):
+    """assert value <= limit, and leave the OBSERVED value behind (gpurun_out/observed_tolerances.jsonl): the limits of the multi-iteration / sharded
+    comparisons are set from what the hardware actually produces (x 2), not from a guess"""
+    import json
+    v = float(value)
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "observed_tolerances.jsonl"), "a") as f:
+            f.write(json.dumps({"name": name, "observed": v, "limit": float(limit)}) + "\n")
+    except OSError:
+        pass
+    assert v <= limit, (name, v, limit)
+
+
+def gauge_projected_rel(frames, state_a, state_b):
+    """max |d - Q Q^T d| / max |state_b| with d = state_a - state_b over the 8 optimised parameters per frame and Q an orthonormal basis of the 7 gauge
+    directions (6 pose + scale, FullSystem::getNullspaces, FullSystem.cc:1711-1760): the reduced system is ill-conditioned along the gauge, two
+    correct solvers (or two shardings of the fp32 partial sums) drift apart along it and agree off it"""
+    F = len(frames)
+    N = np.zeros((8 * F, 7))
+    for f in range(F):
+        P = np.asarray(frames["nullspaces_pose"][f]).reshape(6, 6)
+        for i in range(6):
+            N[8 * f:8 * f + 6, i] = P[:, i]
+        N[8 * f:8 * f + 6, 6] = frames["nullspaces_scale"][f]
+        N[8 * f:8 * f + 3, :] *= 2.0                                                     # SCALE_XI_TRANS_INVERSE
+    Q, _ = np.linalg.qr(N)
+    xa, xb = np.asarray(state_a)[:, :8].reshape(-1), np.asarray(state_b)[:, :8].reshape(-1)
+    d = xa - xb
+    return float(np.abs(d - Q @ (Q.T @ d)).max() / max(np.abs(xb).max(), 1e-300))

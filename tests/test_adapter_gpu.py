@@ -9,7 +9,7 @@ import copy
 import numpy as np
 import pytest
 
-from conftest import get_window
+from conftest import get_window, observe
 from ldso_amd import synth
 from oracle import pyoracle as po, pyref as pr
 
@@ -21,7 +21,7 @@ def _rel(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
 
 
-def _compare_written_back(r_ref, r_adp, win, state_tol=2e-4, idepth_tol=1e-4):
+def _compare_written_back(r_ref, r_adp, win, state_tol=2e-4, idepth_tol=1e-4, with_J=True):
     fr, fa = r_ref.get_frames(), r_adp.get_frames()
     assert _rel(fa["frames"]["frameEnergyTH"], fr["frames"]["frameEnergyTH"]) < 1e-4
     # frame states: the reduced system is ill-conditioned along the gauge, compare the poses the states produce
@@ -36,7 +36,9 @@ def _compare_written_back(r_ref, r_adp, win, state_tol=2e-4, idepth_tol=1e-4):
     assert _rel(pa["idepth"], pr_["idepth"]) < 10 * idepth_tol and np.median(np.abs(pa["idepth"] - pr_["idepth"]) / np.abs(pr_["idepth"])) < idepth_tol
     assert _rel(pa["maxRelBaseline"], pr_["maxRelBaseline"]) < 1e-3
     ok = pr_["HdiF"] > 0
-    assert np.median(np.abs(pa["HdiF"][ok] - pr_["HdiF"][ok]) / pr_["HdiF"][ok]) < 1e-4
+    hd = np.abs(pa["HdiF"][ok] - pr_["HdiF"][ok]) / pr_["HdiF"][ok]
+    assert np.median(hd) < 1e-4
+    observe("adapter_HdiF_max", hd.max(), 0.5)
     rr, ra = r_ref.get_residuals(), r_adp.get_residuals()
     for k in ("state_state", "is_active", "alive", "is_linearized"):
         same = (ra[k] == rr[k])
@@ -44,12 +46,19 @@ def _compare_written_back(r_ref, r_adp, win, state_tol=2e-4, idepth_tol=1e-4):
     live = (rr["alive"] != 0) & (ra["alive"] != 0) & (rr["is_active"] != 0) & (ra["is_active"] != 0)
     assert live.sum() > 0.5 * win.R
     e = np.abs(ra["out"]["state_NewEnergy"][live] - rr["out"]["state_NewEnergy"][live]) / np.maximum(rr["out"]["state_NewEnergy"][live], 1.0)
+    # medians AND maxima (a regression must not hide under a median): the two graphs evaluate the residuals at states that agree to ~1e-4 (gauge
+    # drift of the fp64 solvers), which image gradients amplify for individual residuals - the maximum is bounded by the state difference times
+    # the largest gradient, the count of residuals beyond 10 x the median tolerance stays a small fraction
     assert np.median(e) < 1e-4
+    observe("adapter_energy_max", e.max(), 0.5); observe("adapter_energy_frac_above_1e-3", float((e > 1e-3).mean()), 0.05)
     j = np.abs(ra["out"]["JpJdF"][live] - rr["out"]["JpJdF"][live]).max(axis=1) / np.maximum(np.abs(rr["out"]["JpJdF"][live]).max(axis=1), 1e-3)
     assert np.median(j) < 1e-4
+    observe("adapter_JpJdF_max", j.max(), 0.5); observe("adapter_JpJdF_frac_above_1e-3", float((j > 1e-3).mean()), 0.05)
+    flipped = {k: int((ra[k] != rr[k]).sum()) for k in ("state_state", "is_active", "alive")}
+    observe("adapter_flipped_residual_states", max(flipped.values()), 1e-3 * len(rr["alive"]))
     assert np.abs(ra["out"]["centerProjectedTo"][live] - rr["out"]["centerProjectedTo"][live]).max() < 0.05       # pixels
-    # the Jacobians stored back into r->J
-    for k in ("Jpdxi", "Jpdc", "Jpdd", "JIdx2"):
+    # the Jacobians stored back into r->J (GpuBackend::writeBackJacobians, off by default: nothing of makeKeyFrame reads them)
+    for k in (("Jpdxi", "Jpdc", "Jpdd", "JIdx2") if with_J else ()):
         a, b = ra["J"][k][live].reshape(live.sum(), -1), rr["J"][k][live].reshape(live.sum(), -1)
         assert np.median(np.abs(a - b).max(axis=1) / np.maximum(np.abs(b).max(axis=1), 1e-6)) < 1e-4, k
     assert r_adp.counts()[:2] == r_ref.counts()[:2] or abs(r_adp.counts()[0] - r_ref.counts()[0]) <= 2
@@ -62,6 +71,7 @@ def test_adapter_optimize_equals_reference_optimize(name, iters):
     r_ref.fs_attach()
     rv_ref, log_ref = r_ref.fs_optimize(iters)
     A = pr.GpuAdapter(max_frames=win.F + 1, max_points=win.P + 16)
+    A.set_write_back_jacobians(True)
     rv, its, lost = A.optimize(r_adp, iters)
     assert not lost and not r_ref.fs_is_lost()
     assert its == len(log_ref) - 1, "same number of GN iterations executed (canbreak at the same iteration)"
@@ -83,7 +93,7 @@ def test_adapter_optimize_with_linearized_residuals_and_a_second_call(small):
         assert not lost and abs(rv - rv_ref) <= 2e-4 * rv_ref, rnd
         # the synthetic mixed window is poorly constrained along the scale gauge (tests/test_ba_gpu.py::test_optimize_mixed_linearized): the two
         # fp64 solvers drift apart by a common factor of ~1e-4 in all inverse depths per call
-        _compare_written_back(r_ref, r_adp, win, state_tol=5e-4 * (rnd + 1), idepth_tol=3e-4 * (rnd + 1))
+        _compare_written_back(r_ref, r_adp, win, state_tol=5e-4 * (rnd + 1), idepth_tol=3e-4 * (rnd + 1), with_J=False)
     A.close()
 
 

@@ -6,7 +6,7 @@ import copy
 import numpy as np
 import pytest
 
-from conftest import rel, blockrel, get_window
+from conftest import rel, blockrel, observe, get_window
 from ldso_amd import synth, binding
 from oracle import pyoracle as po
 
@@ -72,7 +72,7 @@ def stage_compare(win, check_J=True):
     fo, fg = o.get_frames(), g.get_frames()
     assert rel(fg["step"], fo["step"]) < 5e-2                       # the frame part of -x: gauge-limited like x
     Eo, Eg = o.linearize_all(False), g.linearize_all(False)
-    assert abs(Eo - Eg) <= 5 * TOL * abs(Eo)
+    observe("stage_relinearise_energy", abs(Eo - Eg) / abs(Eo), 5 * TOL)
     return o, g
 
 
@@ -110,7 +110,8 @@ def test_optimize_small(small):
     rmg, its = g.optimize(6, force_all=True)
     assert its == 6 and abs(rmo - rmg) <= TOL * rmo
     eo, eg = o.energy_log(), g.get_energy_log()
-    assert len(eo) == len(eg) == 8 and rel(eg, eo) < 5 * TOL
+    assert len(eo) == len(eg) == 8
+    observe("optimize6_energy_log", rel(eg, eo), 5 * TOL)
     ro, rg = o.get_residuals(), g.get_residuals()
     assert np.array_equal(ro["state_state"], rg["state_state"]) and np.array_equal(ro["is_active"], rg["is_active"])
     assert np.array_equal(rg["to_remove"].astype(bool), ro["alive"] == 0)
@@ -130,7 +131,7 @@ def test_optimize_canbreak_path(small):
     rmo = o.optimize(6)
     rmg, its = g.optimize(6, force_all=False)
     assert its == len(o.energy_log()) - 2
-    assert abs(rmo - rmg) <= 5 * TOL * rmo
+    observe("optimize_rmse", abs(rmo - rmg) / rmo, 5 * TOL)
 
 
 @pytest.mark.parametrize("F,P", [(12, 500), (3, 300), (2, 200)])
@@ -143,8 +144,8 @@ def test_optimize_canbreak_other_window_shapes(F, P):
     rmo = o.optimize(6)
     rmg, its = g.optimize(6, force_all=False)
     assert its == len(o.energy_log()) - 2
-    assert abs(rmo - rmg) <= 5 * TOL * rmo
-    assert rel(g.get_energy_log(), o.energy_log()) < 5 * TOL
+    observe("optimize_rmse", abs(rmo - rmg) / rmo, 5 * TOL)
+    observe("optimize_energy_log_b", rel(g.get_energy_log(), o.energy_log()), 5 * TOL)
     # and once more on the same handle: the stop word is re-armed per call
     rmg2, its2 = g.optimize(6, force_all=False)
     assert its2 >= 1 and np.isfinite(rmg2)
@@ -155,9 +156,11 @@ def _optimize_compare(win, its=5, tol_e=5 * TOL):
     g = binding.BA.from_window(win)
     rmo = o.optimize(its)
     rmg, n_its = g.optimize(its, force_all=True)
-    assert n_its == its and abs(rmo - rmg) <= tol_e * rmo
+    assert n_its == its
+    observe(f"optimize_compare_rmse_F{win.F}_P{win.P}", abs(rmo - rmg) / rmo, tol_e)
     eo, eg = o.energy_log(), g.get_energy_log()
-    assert len(eo) == len(eg) == its + 2 and rel(eg, eo) < tol_e
+    assert len(eo) == len(eg) == its + 2
+    observe(f"optimize_compare_energy_log_F{win.F}_P{win.P}", rel(eg, eo), tol_e)
     ro, rg = o.get_residuals(), g.get_residuals()
     mism = (ro["state_state"] != rg["state_state"]).sum()
     assert mism <= 2e-3 * len(ro["state_state"])          # a few threshold-borderline residuals may flip after several GN steps
