@@ -158,7 +158,22 @@ int GpuBackend::uploadWindow(FullSystem &fs, std::vector<shared_ptr<PointHessian
     }
     allPoints.clear(); flat.clear();
     std::vector<ldso_point_t> P; std::vector<ldso_residual_t> R; std::vector<ldso_rawjac_t> LJ; std::vector<float> RTZ, mrb; std::vector<int32_t> ngr;
+    // linearised residuals (none in LDSO's own flow: flagPointsForRemoval clears isLinearized, FullSystem.cc:1243) carry their Jacobian and
+    // res_toZeroF across; the 296-byte records are only built when there is one
     bool anyLin = false;
+    for (int f = 0; f < F && !anyLin; f++)
+        for (shared_ptr<Feature> &feat : fs.frames[f]->features) {
+            if (!(feat->status == Feature::FeatureStatus::VALID && feat->point && feat->point->status == Point::PointStatus::ACTIVE)) continue;
+            for (shared_ptr<PointFrameResidual> &r : feat->point->mpPH->residuals) if (r->isLinearized) { anyLin = true; break; }
+            if (anyLin) break;
+        }
+    {
+        size_t np = 0, nr = 0;
+        for (int f = 0; f < F; f++) for (shared_ptr<Feature> &feat : fs.frames[f]->features)
+            if (feat->status == Feature::FeatureStatus::VALID && feat->point && feat->point->status == Point::PointStatus::ACTIVE) { np++; nr += feat->point->mpPH->residuals.size(); }
+        P.reserve(np); allPoints.reserve(np); mrb.reserve(np); ngr.reserve(np); R.reserve(nr); flat.reserve(nr);
+        if (anyLin) { LJ.reserve(nr); RTZ.reserve(nr * 8); }
+    }
     for (int f = 0; f < F; f++)
         for (shared_ptr<Feature> &feat : fs.frames[f]->features) {
             if (!(feat->status == Feature::FeatureStatus::VALID && feat->point && feat->point->status == Point::PointStatus::ACTIVE)) continue;
@@ -174,11 +189,13 @@ int GpuBackend::uploadWindow(FullSystem &fs, std::vector<shared_ptr<PointHessian
                 q.point = (int32_t) P.size(); q.host = r->hostIDX; q.target = r->targetIDX; q.state_state = (int32_t) r->state_state;
                 q.is_linearized = r->isLinearized ? 1 : 0; q.is_active = r->isActive() ? 1 : 0; q.is_new = r->isNew ? 1 : 0; q.state_energy = (float) r->state_energy;
                 R.push_back(q); flat.push_back(r);
-                ldso_rawjac_t j;
-                memset(&j, 0, sizeof(j));
-                if (r->isLinearized) { toRaw(*r->J, j); anyLin = true; }
-                LJ.push_back(j);
-                for (int k = 0; k < 8; k++) RTZ.push_back(r->isLinearized ? r->res_toZeroF[k] : 0.0f);
+                if (anyLin) {
+                    ldso_rawjac_t j;
+                    memset(&j, 0, sizeof(j));
+                    if (r->isLinearized) toRaw(*r->J, j);
+                    LJ.push_back(j);
+                    for (int k = 0; k < 8; k++) RTZ.push_back(r->isLinearized ? r->res_toZeroF[k] : 0.0f);
+                }
             }
             P.push_back(p); allPoints.push_back(ph);
             mrb.push_back(ph->maxRelBaseline); ngr.push_back(ph->numGoodResiduals);

@@ -455,7 +455,7 @@ def adapter_line(name="C3"):
             A.set_write_back_jacobians(wb)
             ts, splits, its = [], [], 0
             for rep in range(6):
-                r = pr.RefWindow(win)
+                r = pr.RefWindow(win); r.fs_attach()          # (the FullSystem object of the graph exists before the clock starts, as for the reference leg)
                 t0 = time.perf_counter(); rv, its, lost = A.optimize(r, 6); ts.append(time.perf_counter() - t0); splits.append(A.last_optimize_times().copy())
                 r.close()
             sp = np.median(np.array(splits[1:]), axis=0)

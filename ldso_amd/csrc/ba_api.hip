@@ -27,13 +27,16 @@ hipError_t ba_launch_gather(const BaPtrs &B, const BaDims &D, const ResSet &S, b
                             const ldso_settings_t &St, int mode, double *rbuf, hipStream_t st);
 hipError_t ba_launch_solve(const BaPtrs &B, const BaDims &D, const ResSet &S, const ldso_settings_t &St, const SolveArgs &A, hipStream_t st);
 hipError_t ba_launch_point_step(const BaPtrs &B, const BaDims &D, const ResSet &S, int mode, hipStream_t st);
+hipError_t ba_launch_linearize_one(const BaPtrs &B, const BaDims &D, const ResSet &cur, const ResSet &nxt, const ldso_settings_t &S, int stepMode, const GnInit &gi, const LinHead &hd,
+                                   hipStream_t st);
 hipError_t ba_launch_linearize_marg(const BaPtrs &B, const BaDims &D, const ResSet &cur, const ResSet &nxt, const ldso_settings_t &S, const int32_t *margFlags, hipStream_t st);
 hipError_t ba_launch_marg_frame(const BaPtrs &B, const BaDims &D, int idx, double *work, double *outH, double *outb, hipStream_t st);
 hipError_t ba_launch_acc_init(const BaPtrs &B, const BaDims &D, const GnInit &gi, hipStream_t st);
 hipError_t ba_launch_gn_export(const BaPtrs &B, const BaDims &D, const ResSet &S, double *tail, hipStream_t st);
 hipError_t ba_launch_activate(const BaPtrs &B, const BaDims &D, const ldso_settings_t &S, const ldso_immature_t *d_pts, ldso_activation_t *d_out, int n, int minObs,
                               float minIdepthH_act, int GNIts, hipStream_t st);
-hipError_t ba_launch_linearize_batch(const BatchItem *d_items, const BatchBlock *d_blocks, int totalChunks, int FS, int cur, const ldso_settings_t &S, int stepMode, float calibPrior, hipStream_t st, int itCheck = -1);
+hipError_t ba_launch_linearize_batch(const BatchItem *d_items, const BatchBlock *d_blocks, int totalChunks, int FS, int cur, const ldso_settings_t &S, int stepMode, float calibPrior, hipStream_t st, int itCheck = -1,
+                                     bool singleWindow = false);
 hipError_t ba_launch_reduce_batch(const BatchItem *d_items, int nWin, int totalBlocks, int cur, float calibPrior, double l1, double il, hipStream_t st);
 hipError_t ba_launch_gn_solve_batch(const BatchItem *d_items, int nWin, const BaDims &Dmax, int cur, const ldso_settings_t &St, int iteration, double lambda, hipStream_t st);
 hipError_t ba_launch_lm_energies(const BaPtrs &B, const BaDims &D, const ResSet &S, float calibPrior, bool hasPrior, hipStream_t st);
@@ -88,6 +91,8 @@ struct ldso_ba {
     BatchBlock *d_blocks = nullptr;    // [maxChunks] the window's chunks as k_linearize_batch reads them (window index 0)
     std::vector<BatchBlock> h_blocks;
     bool appliedValid = false;         // the applied residual set holds a linearisation of the resident window (its per-chunk partials feed the next reduce)
+    LinHead linHead;                   // chunk geometry of the current window by value (k_linearize_one)
+    bool linHeadOk = false;            // the chunks are regular (every host cut into CH-point pieces): true for everything build_chunks produces
     const void *inBatch = nullptr;     // the ldso_ba_batch this handle belongs to (at most one; it must outlive the batch: ldso_ba_destroy refuses while set)
     int chunkPoints = 0;               // points per workgroup of k_linearize: 0 = as few as keep the grid within one wave of workgroups (one window alone on the chip)
     BatchItem itemShadow;
@@ -430,6 +435,24 @@ static int build_chunks(ldso_ba *H) {
     for (size_t i = 0; i < p0.size(); i++) H->h_blocks[i] = BatchBlock{0, p0[i], cn[i], ch[i] | ((int32_t) i << 8)};
     CHK(hipMemcpyAsync(H->d_blocks, H->h_blocks.data(), p0.size() * sizeof(BatchBlock), hipMemcpyHostToDevice, H->stream));
     for (int i = 0; i <= LD_MAXF; i++) H->chunkStarts.v[i] = (i <= D.F) ? cs[i] : cs[D.F];
+    {
+        LinHead &L = H->linHead;
+        memset(&L, 0, sizeof(L));
+        L.CH = CH; L.F = D.F;
+        int q = D.pBegin;
+        for (int hst = 0; hst <= LD_MAXF; hst++) {
+            L.cs[hst] = (hst <= D.F) ? cs[hst] : cs[D.F];
+            L.hostP0[hst] = q;
+            while (hst < D.F && q < D.pEnd && H->h_phost[q] == hst) q++;
+        }
+        // the closed form must reproduce the table (it does for every chunking build_chunks makes; checked, not assumed)
+        bool ok = true;
+        for (size_t i = 0; i < p0.size() && ok; i++) {
+            const int hst = ch[i];
+            ok = p0[i] == L.hostP0[hst] + ((int) i - L.cs[hst]) * CH && cn[i] == std::min(CH, L.hostP0[hst + 1] - p0[i]);
+        }
+        H->linHeadOk = ok;
+    }
     CHK(hipStreamSynchronize(H->stream));
     return LDSO_OK;
 }
@@ -672,10 +695,15 @@ static int launch_linearize(ldso_ba *H, bool fix, int stepMode, int itCheck) {
     t_begin(H, 0);
     GnInit gi; gi.enable = (H->D.pBegin > 0) ? 2 : 1; gi.hasPrior = H->hasPrior ? 1 : 0; gi.calibPrior = H->settings.initialCalibHessian; gi.itCheck = itCheck;
     static const bool descAll = getenv("LDSO_LIN_DESC") != nullptr;      // kernel experiments: the descriptor-based kernel for two slot groups as well
+    static const bool noOne = getenv("LDSO_LIN_NO_ONE") != nullptr;      // kernel experiments: the table-driven kernels instead of k_linearize_one
+    if (!fix && !H->hasL && gi.enable == 1 && H->linHeadOk && !noOne) {
+        // the plain linearisation (GN iterations) of one window, one or two slot groups: descriptor and chunk geometry in the kernel arguments
+        CHK(ba_launch_linearize_one(H->B, H->D, H->sets[H->cur], H->sets[H->cur ^ 1], H->settings, stepMode, gi, H->linHead, H->stream));
+    } else
     if (!fix && !H->hasL && gi.enable == 1 && (H->D.FS == 8 || descAll) && H->B.dumpJ == nullptr) {      // (two slot groups, F > 8: the argument-based kernel is the faster one, 43.0 against 45.6 us at C5)
         // the plain linearisation (GN iterations): descriptors from device memory (k_linearize_batch with one window)
         { const int r_ = refresh_item(H); if (r_ != LDSO_OK) return r_; }
-        CHK(ba_launch_linearize_batch(H->d_item, H->d_blocks, H->D.nChunks, H->D.FS, H->cur, H->settings, stepMode, gi.calibPrior, H->stream, itCheck));
+        CHK(ba_launch_linearize_batch(H->d_item, H->d_blocks, H->D.nChunks, H->D.FS, H->cur, H->settings, stepMode, gi.calibPrior, H->stream, itCheck, true));
     } else
     CHK(ba_launch_linearize(H->B, H->D, H->sets[H->cur], H->sets[H->cur ^ 1], H->settings, H->hasL, fix, stepMode, gi, H->stream));
     t_end(H);
@@ -1180,11 +1208,11 @@ int ldso_ba_batch_create(ldso_ba_t *const *handles, int n, ldso_ba_batch_t **out
     {
         long total = 0;
         for (int i = 0; i < n; i++) total += handles[i]->D.P;
-        int ppw = (int) (total / ((long) H0->numCU * LD_WAVES));               // points per wavefront slot of the chip, capped at 4 (measured: 338 / 259 / 216 / 221 / 217 us per
+        int ppw = (int) (total / ((long) H0->numCU * LD_WAVES));               // points per wavefront slot of the chip, capped at 6 (round 3, capped at 4: 338 / 259 / 216 / 221 / 217 us per
                                                                                  // launch of 32 C3 windows at 1 / 2 / 4 / 6 / 8 points per wavefront; 84 / 65 / 54 / 70 / 70 us for 8 windows)
         if (const char *e = getenv("LDSO_BATCH_PPW")) { if (*e) ppw = atoi(e); }             // kernel experiments
         ppw = ppw < 1 ? 1 : ppw > 8 ? 8 : ppw;
-        if (!getenv("LDSO_BATCH_PPW") && ppw > 4) ppw = 4;
+        if (!getenv("LDSO_BATCH_PPW") && ppw > 6) ppw = 6;          // round 4 (record-layout kernel, k_reduce_batch_dense at 4 workgroups per CU), B = 32: 122.0 / 139.3 / 128.6 k window-iterations/s at 4 / 6 / 8
         const int CH = ppw * LD_WAVES;
         Bt_chunk = ppw > 1 ? CH : 0;
         for (int i = 0; i < n; i++) if (handles[i]->chunkPoints == 0 && ppw > 1) {      // ppw == 1: the single-window chunking already is the right one

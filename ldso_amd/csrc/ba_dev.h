@@ -158,6 +158,14 @@ struct ChunkStarts {
     int32_t v[LD_MAXF + 1];
 };
 
+// What a workgroup of the single-window GN linearisation (k_linearize_one) needs to find its chunk WITHOUT a table in memory: the chunks of a window
+// are host-major, every host's points cut into pieces of `CH` points (build_chunks), so chunk c of host h starts at hostP0[h] + (c - cs[h]) CH.
+struct LinHead {
+    int32_t cs[LD_MAXF + 1];         // first chunk of every host (cs[F] = number of chunks)
+    int32_t hostP0[LD_MAXF + 1];     // first point of every host inside the shard (hostP0[F] = one past the last point)
+    int32_t CH, F;
+};
+
 // One window of a batch (ldso_ba_batch_*): everything the kernels of a GN iteration take as arguments for a single window, in
 // device memory.  linBlock0 / redBlock0 = first workgroup of this window in the batched k_linearize / k_reduce launches.
 // one workgroup of a batched k_linearize: its window (index into the launch's BatchItem table) and its chunk, resolved on the host - the

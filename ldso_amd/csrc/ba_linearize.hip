@@ -832,13 +832,58 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D,
 // Batched windows (one 7-keyframe window is tiny for the chip): the chunks of nWin independent windows in one
 // launch.  Workgroup -> window by the prefix of chunk counts (items[w].linBlock0); `cur` = which residual set is the applied one
 // (all windows of a batch iterate in lockstep).
-template <int NSG>
+// SINGLE: the launch holds ONE window (the GN iteration of a single handle): its descriptor sits at items[0] whatever the workgroup table says, so the
+// scalar loads of its pointers are issued together with the workgroup's table entry instead of behind it - one dependent memory level less in a
+// prologue that is nothing but dependent levels (kernel arguments -> table entry -> descriptor -> operands -> LDS).
+template <int NSG, bool SINGLE = false>
 __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize_batch(const BatchItem *__restrict__ items, const BatchBlock *__restrict__ blocks, int cur, ldso_settings_t S, int stepMode,
                                                                    float calibPrior, int itCheck) {
     const BatchBlock bb = blocks[blockIdx.x];                   // one scalar 16-byte load: window, first point, point count, host | chunk
-    const BatchItem &it = items[bb.win];
+    const BatchItem &it = items[SINGLE ? 0 : bb.win];
     GnInit gi; gi.enable = 1; gi.hasPrior = it.hasPrior; gi.calibPrior = calibPrior; gi.itCheck = itCheck;
     linearize_body<NSG, false, false, false, true>(it.B, it.D, it.set[cur], it.set[cur ^ 1], S, stepMode, gi, nullptr, bb.host_chunk >> 8, it.D.nChunks, bb.p0, bb.np, bb.host_chunk & 0xFF);
+}
+
+// The GN-iteration linearisation of ONE window with everything a workgroup needs before its first operand load in the KERNEL ARGUMENTS: the whole
+// descriptor (BaPtrs / BaDims / the two residual sets) by value - it stays in the kernarg segment, the body fetches its pointer groups from there just
+// in time exactly as from a BatchItem in device memory (DESC = true: `&B` is an address in the constant kernarg segment) - and the chunk of the
+// workgroup computed from the by-value host tables of LinHead instead of a table entry in memory.  The prologue of this kernel is a chain of dependent
+// memory levels and nothing else (window of 5 MB on a chip that moves that in 0.7 us): kernel arguments -> workgroup table entry -> descriptor ->
+// operands -> LDS was four levels (k_linearize_batch<NSG, false>), this is two.
+struct OneArgs { BaPtrs B; BaDims D; ResSet cur, nxt; ldso_settings_t S; int stepMode; GnInit gi; LinHead hd; };
+template <int NSG>
+__global__ __launch_bounds__(64 * LD_WAVES) void k_linearize_one(OneArgs a) {
+    // The descriptor is addressed IN the kernarg segment (the only parameter starts at its offset 0): taking the address of the by-value parameter
+    // itself would make the compiler copy it to scratch memory (536 bytes per lane, and a scalar load from a private address is meaningless).
+    const OneArgs &A = *(const OneArgs *) __builtin_amdgcn_kernarg_segment_ptr();
+#ifndef LD_NO_KTOUCH
+    {
+        // The compiler fetches kernel arguments lazily, a few at a time, each fetch a fresh scalar-cache line of a kernarg buffer that nobody has
+        // touched on this CU yet: five to ten DEPENDENT-LOOKING round trips in front of the first operand load.  One dword of every 64-byte line of
+        // the argument block is requested here, back to back, with one wait: the block is in the scalar cache before the first real use.
+        static_assert(sizeof(OneArgs) <= 16 * 64, "k_linearize_one: one touch per 64-byte line of the arguments");
+        const unsigned long long ka = (unsigned long long) __builtin_amdgcn_kernarg_segment_ptr();
+        int t0, t1, t2, t3, t4, t5, t6, t7, t8, t9, t10, t11, t12, t13, t14, t15;
+        asm volatile("s_load_dword %0, %16, 0x0\n\ts_load_dword %1, %16, 0x40\n\ts_load_dword %2, %16, 0x80\n\ts_load_dword %3, %16, 0xc0\n\t"
+                     "s_load_dword %4, %16, 0x100\n\ts_load_dword %5, %16, 0x140\n\ts_load_dword %6, %16, 0x180\n\ts_load_dword %7, %16, 0x1c0\n\t"
+                     "s_load_dword %8, %16, 0x200\n\ts_load_dword %9, %16, 0x240\n\ts_load_dword %10, %16, 0x280\n\ts_load_dword %11, %16, 0x2c0\n\t"
+                     "s_load_dword %12, %16, 0x300\n\ts_load_dword %13, %16, 0x340\n\ts_load_dword %14, %16, 0x380\n\ts_load_dword %15, %16, 0x3c0\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3), "=&s"(t4), "=&s"(t5), "=&s"(t6), "=&s"(t7), "=&s"(t8), "=&s"(t9), "=&s"(t10), "=&s"(t11), "=&s"(t12), "=&s"(t13),
+                       "=&s"(t14), "=&s"(t15)
+                     : "s"(ka) : "memory");
+    }
+#endif
+    const LinHead &hd = a.hd;
+    const int chunk = (int) blockIdx.x;
+    int h = 0;
+#pragma unroll
+    for (int i = 1; i < LD_MAXF; i++) h += (i < hd.F && chunk >= hd.cs[i]) ? 1 : 0;          // hosts without points have cs[i] == cs[i + 1]: they are skipped
+    int c0 = 0, q0 = 0, q1 = 0;
+#pragma unroll
+    for (int i = 0; i < LD_MAXF; i++) { const bool m = (i == h); c0 = m ? hd.cs[i] : c0; q0 = m ? hd.hostP0[i] : q0; q1 = m ? hd.hostP0[i + 1] : q1; }
+    const int p0 = q0 + (chunk - c0) * hd.CH, np = min(hd.CH, q1 - p0);
+    linearize_body<NSG, false, false, false, true>(A.B, A.D, A.cur, A.nxt, a.S, a.stepMode, a.gi, nullptr, chunk, (int) gridDim.x, p0, np, h);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -871,6 +916,22 @@ hipError_t ba_launch_linearize(const BaPtrs &B, const BaDims &D, const ResSet &c
     }
 }
 
+hipError_t ba_launch_linearize_one(const BaPtrs &B, const BaDims &D, const ResSet &cur, const ResSet &nxt, const ldso_settings_t &S, int stepMode, const GnInit &gi, const LinHead &hd,
+                                   hipStream_t st) {
+    if (D.nChunks == 0) return hipSuccess;
+    const size_t lds = ba_linearize_lds_bytes(D.FS, false);
+    OneArgs a;
+    a.B = B; a.D = D; a.cur = cur; a.nxt = nxt; a.S = S; a.stepMode = stepMode; a.gi = gi; a.hd = hd;
+    if (D.nsg == 1) {
+        if (lds > 48 * 1024) (void) hipFuncSetAttribute((const void *) k_linearize_one<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+        hipLaunchKernelGGL(k_linearize_one<1>, dim3(D.nChunks), dim3(64 * LD_WAVES), lds, st, a);
+    } else {
+        if (lds > 48 * 1024) (void) hipFuncSetAttribute((const void *) k_linearize_one<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+        hipLaunchKernelGGL(k_linearize_one<2>, dim3(D.nChunks), dim3(64 * LD_WAVES), lds, st, a);
+    }
+    return hipGetLastError();
+}
+
 // marginalizePointsF accumulate for the flagged points (see the MARG note at k_linearize); `nxt` is scratch
 hipError_t ba_launch_linearize_marg(const BaPtrs &B, const BaDims &D, const ResSet &cur, const ResSet &nxt, const ldso_settings_t &S, const int32_t *margFlags,
                                     hipStream_t st) {
@@ -880,9 +941,23 @@ hipError_t ba_launch_linearize_marg(const BaPtrs &B, const BaDims &D, const ResS
     return launch_one<2, false, false, true>(B, D, cur, nxt, S, 0, gi, st, margFlags);
 }
 
-hipError_t ba_launch_linearize_batch(const BatchItem *d_items, const BatchBlock *d_blocks, int totalChunks, int FS, int cur, const ldso_settings_t &S, int stepMode, float calibPrior, hipStream_t st, int itCheck) {
+template <int NSG, bool SINGLE> static void launch_batch(const BatchItem *d_items, const BatchBlock *d_blocks, int totalChunks, size_t lds, int cur, const ldso_settings_t &S, int stepMode, float calibPrior, hipStream_t st, int itCheck) {
+    auto kfn = k_linearize_batch<NSG, SINGLE>;
+    if (lds > 48 * 1024) (void) hipFuncSetAttribute((const void *) kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+    hipLaunchKernelGGL(kfn, dim3(totalChunks), dim3(64 * LD_WAVES), lds, st, d_items, d_blocks, cur, S, stepMode, calibPrior, itCheck);
+}
+hipError_t ba_launch_linearize_batch(const BatchItem *d_items, const BatchBlock *d_blocks, int totalChunks, int FS, int cur, const ldso_settings_t &S, int stepMode, float calibPrior, hipStream_t st, int itCheck,
+                                     bool singleWindow) {
     if (totalChunks == 0) return hipSuccess;
     const size_t lds = ba_linearize_lds_bytes(FS, false);
+#ifdef LD_NO_SINGLE      // A/B builds (scripts/build_variant.sh)
+    singleWindow = false;
+#endif
+    if (singleWindow) {
+        if (FS == 8) launch_batch<1, true>(d_items, d_blocks, totalChunks, lds, cur, S, stepMode, calibPrior, st, itCheck);
+        else launch_batch<2, true>(d_items, d_blocks, totalChunks, lds, cur, S, stepMode, calibPrior, st, itCheck);
+        return hipGetLastError();
+    }
     if (FS == 8) {
         if (lds > 48 * 1024) (void) hipFuncSetAttribute((const void *) k_linearize_batch<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
         hipLaunchKernelGGL(k_linearize_batch<1>, dim3(totalChunks), dim3(64 * LD_WAVES), lds, st, d_items, d_blocks, cur, S, stepMode, calibPrior, itCheck);

@@ -72,7 +72,7 @@ def stage_compare(win, check_J=True):
     fo, fg = o.get_frames(), g.get_frames()
     assert rel(fg["step"], fo["step"]) < 5e-2                       # the frame part of -x: gauge-limited like x
     Eo, Eg = o.linearize_all(False), g.linearize_all(False)
-    observe("stage_relinearise_energy", abs(Eo - Eg) / abs(Eo), 5 * TOL)
+    observe("stage_relinearise_energy", abs(Eo - Eg) / abs(Eo), 2 * TOL)      # observed 9.5e-5 (round 4)
     return o, g
 
 
@@ -111,7 +111,7 @@ def test_optimize_small(small):
     assert its == 6 and abs(rmo - rmg) <= TOL * rmo
     eo, eg = o.energy_log(), g.get_energy_log()
     assert len(eo) == len(eg) == 8
-    observe("optimize6_energy_log", rel(eg, eo), 5 * TOL)
+    observe("optimize6_energy_log", rel(eg, eo), TOL)      # observed 2.6e-5
     ro, rg = o.get_residuals(), g.get_residuals()
     assert np.array_equal(ro["state_state"], rg["state_state"]) and np.array_equal(ro["is_active"], rg["is_active"])
     assert np.array_equal(rg["to_remove"].astype(bool), ro["alive"] == 0)
@@ -131,7 +131,7 @@ def test_optimize_canbreak_path(small):
     rmo = o.optimize(6)
     rmg, its = g.optimize(6, force_all=False)
     assert its == len(o.energy_log()) - 2
-    observe("optimize_rmse", abs(rmo - rmg) / rmo, 5 * TOL)
+    observe("optimize_rmse", abs(rmo - rmg) / rmo, TOL)      # observed 7.5e-6
 
 
 @pytest.mark.parametrize("F,P", [(12, 500), (3, 300), (2, 200)])
@@ -144,14 +144,14 @@ def test_optimize_canbreak_other_window_shapes(F, P):
     rmo = o.optimize(6)
     rmg, its = g.optimize(6, force_all=False)
     assert its == len(o.energy_log()) - 2
-    observe("optimize_rmse", abs(rmo - rmg) / rmo, 5 * TOL)
-    observe("optimize_energy_log_b", rel(g.get_energy_log(), o.energy_log()), 5 * TOL)
+    observe("optimize_rmse", abs(rmo - rmg) / rmo, TOL)      # observed 7.5e-6
+    observe("optimize_energy_log_b", rel(g.get_energy_log(), o.energy_log()), TOL)      # observed 4.3e-5
     # and once more on the same handle: the stop word is re-armed per call
     rmg2, its2 = g.optimize(6, force_all=False)
     assert its2 >= 1 and np.isfinite(rmg2)
 
 
-def _optimize_compare(win, its=5, tol_e=5 * TOL):
+def _optimize_compare(win, its=5, tol_e=TOL):          # observed <= 1.2e-5 (round 4)
     o = po.OracleWindow(win); o.set_force_all_iterations(True)
     g = binding.BA.from_window(win)
     rmo = o.optimize(its)
