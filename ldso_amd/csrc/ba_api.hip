@@ -35,8 +35,7 @@ hipError_t ba_launch_acc_init(const BaPtrs &B, const BaDims &D, const GnInit &gi
 hipError_t ba_launch_gn_export(const BaPtrs &B, const BaDims &D, const ResSet &S, double *tail, hipStream_t st);
 hipError_t ba_launch_activate(const BaPtrs &B, const BaDims &D, const ldso_settings_t &S, const ldso_immature_t *d_pts, ldso_activation_t *d_out, int n, int minObs,
                               float minIdepthH_act, int GNIts, hipStream_t st);
-hipError_t ba_launch_linearize_batch(const BatchItem *d_items, const BatchBlock *d_blocks, int totalChunks, int FS, int cur, const ldso_settings_t &S, int stepMode, float calibPrior, hipStream_t st, int itCheck = -1,
-                                     bool singleWindow = false);
+hipError_t ba_launch_linearize_batch(const BatchItem *d_items, const BatchBlock *d_blocks, int totalChunks, int FS, int cur, const ldso_settings_t &S, int stepMode, float calibPrior, hipStream_t st, int itCheck = -1);
 hipError_t ba_launch_reduce_batch(const BatchItem *d_items, int nWin, int totalBlocks, int cur, float calibPrior, double l1, double il, hipStream_t st);
 hipError_t ba_launch_gn_solve_batch(const BatchItem *d_items, int nWin, const BaDims &Dmax, int cur, const ldso_settings_t &St, int iteration, double lambda, hipStream_t st);
 hipError_t ba_launch_lm_energies(const BaPtrs &B, const BaDims &D, const ResSet &S, float calibPrior, bool hasPrior, hipStream_t st);
@@ -703,7 +702,7 @@ static int launch_linearize(ldso_ba *H, bool fix, int stepMode, int itCheck) {
     if (!fix && !H->hasL && gi.enable == 1 && (H->D.FS == 8 || descAll) && H->B.dumpJ == nullptr) {      // (two slot groups, F > 8: the argument-based kernel is the faster one, 43.0 against 45.6 us at C5)
         // the plain linearisation (GN iterations): descriptors from device memory (k_linearize_batch with one window)
         { const int r_ = refresh_item(H); if (r_ != LDSO_OK) return r_; }
-        CHK(ba_launch_linearize_batch(H->d_item, H->d_blocks, H->D.nChunks, H->D.FS, H->cur, H->settings, stepMode, gi.calibPrior, H->stream, itCheck, true));
+        CHK(ba_launch_linearize_batch(H->d_item, H->d_blocks, H->D.nChunks, H->D.FS, H->cur, H->settings, stepMode, gi.calibPrior, H->stream, itCheck));
     } else
     CHK(ba_launch_linearize(H->B, H->D, H->sets[H->cur], H->sets[H->cur ^ 1], H->settings, H->hasL, fix, stepMode, gi, H->stream));
     t_end(H);

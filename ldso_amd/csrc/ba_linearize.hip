@@ -825,6 +825,7 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
 template <int NSG, bool HAS_L, bool FIX, bool MARG>
 __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D, ResSet cur, ResSet nxt, ldso_settings_t S, int stepMode, GnInit gi,
                                                              const int32_t *__restrict__ margFlags) {
+    ld_touch_kernarg<14>();          // 952 bytes of arguments into the scalar cache with one wait (ba_dev.h)
     const int chunk = (int) blockIdx.x;
     linearize_body<NSG, HAS_L, FIX, MARG, false>(B, D, cur, nxt, S, stepMode, gi, margFlags, chunk, (int) gridDim.x, B.chunk_p0[chunk], B.chunk_n[chunk], B.chunk_host[chunk]);
 }
@@ -832,14 +833,11 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D,
 // Batched windows (one 7-keyframe window is tiny for the chip): the chunks of nWin independent windows in one
 // launch.  Workgroup -> window by the prefix of chunk counts (items[w].linBlock0); `cur` = which residual set is the applied one
 // (all windows of a batch iterate in lockstep).
-// SINGLE: the launch holds ONE window (the GN iteration of a single handle): its descriptor sits at items[0] whatever the workgroup table says, so the
-// scalar loads of its pointers are issued together with the workgroup's table entry instead of behind it - one dependent memory level less in a
-// prologue that is nothing but dependent levels (kernel arguments -> table entry -> descriptor -> operands -> LDS).
-template <int NSG, bool SINGLE = false>
+template <int NSG>
 __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize_batch(const BatchItem *__restrict__ items, const BatchBlock *__restrict__ blocks, int cur, ldso_settings_t S, int stepMode,
                                                                    float calibPrior, int itCheck) {
     const BatchBlock bb = blocks[blockIdx.x];                   // one scalar 16-byte load: window, first point, point count, host | chunk
-    const BatchItem &it = items[SINGLE ? 0 : bb.win];
+    const BatchItem &it = items[bb.win];
     GnInit gi; gi.enable = 1; gi.hasPrior = it.hasPrior; gi.calibPrior = calibPrior; gi.itCheck = itCheck;
     linearize_body<NSG, false, false, false, true>(it.B, it.D, it.set[cur], it.set[cur ^ 1], S, stepMode, gi, nullptr, bb.host_chunk >> 8, it.D.nChunks, bb.p0, bb.np, bb.host_chunk & 0xFF);
 }
@@ -856,24 +854,8 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize_one(OneArgs a) {
     // The descriptor is addressed IN the kernarg segment (the only parameter starts at its offset 0): taking the address of the by-value parameter
     // itself would make the compiler copy it to scratch memory (536 bytes per lane, and a scalar load from a private address is meaningless).
     const OneArgs &A = *(const OneArgs *) __builtin_amdgcn_kernarg_segment_ptr();
-#ifndef LD_NO_KTOUCH
-    {
-        // The compiler fetches kernel arguments lazily, a few at a time, each fetch a fresh scalar-cache line of a kernarg buffer that nobody has
-        // touched on this CU yet: five to ten DEPENDENT-LOOKING round trips in front of the first operand load.  One dword of every 64-byte line of
-        // the argument block is requested here, back to back, with one wait: the block is in the scalar cache before the first real use.
-        static_assert(sizeof(OneArgs) <= 16 * 64, "k_linearize_one: one touch per 64-byte line of the arguments");
-        const unsigned long long ka = (unsigned long long) __builtin_amdgcn_kernarg_segment_ptr();
-        int t0, t1, t2, t3, t4, t5, t6, t7, t8, t9, t10, t11, t12, t13, t14, t15;
-        asm volatile("s_load_dword %0, %16, 0x0\n\ts_load_dword %1, %16, 0x40\n\ts_load_dword %2, %16, 0x80\n\ts_load_dword %3, %16, 0xc0\n\t"
-                     "s_load_dword %4, %16, 0x100\n\ts_load_dword %5, %16, 0x140\n\ts_load_dword %6, %16, 0x180\n\ts_load_dword %7, %16, 0x1c0\n\t"
-                     "s_load_dword %8, %16, 0x200\n\ts_load_dword %9, %16, 0x240\n\ts_load_dword %10, %16, 0x280\n\ts_load_dword %11, %16, 0x2c0\n\t"
-                     "s_load_dword %12, %16, 0x300\n\ts_load_dword %13, %16, 0x340\n\ts_load_dword %14, %16, 0x380\n\ts_load_dword %15, %16, 0x3c0\n\t"
-                     "s_waitcnt lgkmcnt(0)"
-                     : "=&s"(t0), "=&s"(t1), "=&s"(t2), "=&s"(t3), "=&s"(t4), "=&s"(t5), "=&s"(t6), "=&s"(t7), "=&s"(t8), "=&s"(t9), "=&s"(t10), "=&s"(t11), "=&s"(t12), "=&s"(t13),
-                       "=&s"(t14), "=&s"(t15)
-                     : "s"(ka) : "memory");
-    }
-#endif
+    static_assert(sizeof(OneArgs) >= 12 * 64 && sizeof(OneArgs) <= 16 * 64, "k_linearize_one: 16 lines = the explicit arguments (>= 768 bytes) + the 256 bytes of hidden arguments behind them");
+    ld_touch_kernarg<16>();          // the whole argument block into the scalar cache with one wait (ba_dev.h): 10.6 -> 9.9 us at C3, 43.0 -> 42.3 us at C5
     const LinHead &hd = a.hd;
     const int chunk = (int) blockIdx.x;
     int h = 0;
@@ -941,23 +923,9 @@ hipError_t ba_launch_linearize_marg(const BaPtrs &B, const BaDims &D, const ResS
     return launch_one<2, false, false, true>(B, D, cur, nxt, S, 0, gi, st, margFlags);
 }
 
-template <int NSG, bool SINGLE> static void launch_batch(const BatchItem *d_items, const BatchBlock *d_blocks, int totalChunks, size_t lds, int cur, const ldso_settings_t &S, int stepMode, float calibPrior, hipStream_t st, int itCheck) {
-    auto kfn = k_linearize_batch<NSG, SINGLE>;
-    if (lds > 48 * 1024) (void) hipFuncSetAttribute((const void *) kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-    hipLaunchKernelGGL(kfn, dim3(totalChunks), dim3(64 * LD_WAVES), lds, st, d_items, d_blocks, cur, S, stepMode, calibPrior, itCheck);
-}
-hipError_t ba_launch_linearize_batch(const BatchItem *d_items, const BatchBlock *d_blocks, int totalChunks, int FS, int cur, const ldso_settings_t &S, int stepMode, float calibPrior, hipStream_t st, int itCheck,
-                                     bool singleWindow) {
+hipError_t ba_launch_linearize_batch(const BatchItem *d_items, const BatchBlock *d_blocks, int totalChunks, int FS, int cur, const ldso_settings_t &S, int stepMode, float calibPrior, hipStream_t st, int itCheck) {
     if (totalChunks == 0) return hipSuccess;
     const size_t lds = ba_linearize_lds_bytes(FS, false);
-#ifdef LD_NO_SINGLE      // A/B builds (scripts/build_variant.sh)
-    singleWindow = false;
-#endif
-    if (singleWindow) {
-        if (FS == 8) launch_batch<1, true>(d_items, d_blocks, totalChunks, lds, cur, S, stepMode, calibPrior, st, itCheck);
-        else launch_batch<2, true>(d_items, d_blocks, totalChunks, lds, cur, S, stepMode, calibPrior, st, itCheck);
-        return hipGetLastError();
-    }
     if (FS == 8) {
         if (lds > 48 * 1024) (void) hipFuncSetAttribute((const void *) k_linearize_batch<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
         hipLaunchKernelGGL(k_linearize_batch<1>, dim3(totalChunks), dim3(64 * LD_WAVES), lds, st, d_items, d_blocks, cur, S, stepMode, calibPrior, itCheck);

