@@ -98,6 +98,7 @@ int adp_trace_new_coarse(void *b, void *fs, void *fh, int *counts) {
 int adp_set_write_back_jacobians(void *b, int on) { ((GpuBackend *) b)->writeBackJacobians = on != 0; return 0; }
 // wall-clock split of the last GpuBackend::optimize (seconds): flatten + upload, device (ldso_ba_optimize incl. its read-back of the energies), fetch, write-back into the objects
 int adp_last_optimize_times(void *b, double *out4) { for (int i = 0; i < 4; i++) out4[i] = ((GpuBackend *) b)->lastOptimizeSeconds[i]; return 0; }
+int adp_last_upload_times(void *b, double *out6) { for (int i = 0; i < 6; i++) out6[i] = ((GpuBackend *) b)->lastUploadSeconds[i]; return 0; }
 
 // ---- one key frame in the order of FullSystem::makeKeyFrame (FullSystem.cc:410-640) on a reference object graph -----------------------------
 // b == nullptr: the reference's own members everywhere.  b != nullptr: GpuBackend::traceNewCoarse / activatePoints / optimize in place of

@@ -137,10 +137,13 @@ void GpuBackend::syncImageSlots(FullSystem &fs, std::vector<int32_t> &slots) {
 // PointHessian::residuals order; a residual's slot is (hostIDX, targetIDX).  allPoints / flat give the write-back its objects.
 // ------------------------------------------------------------------------------------------------------------------------------------
 int GpuBackend::uploadWindow(FullSystem &fs, std::vector<shared_ptr<PointHessian>> &allPoints, std::vector<shared_ptr<PointFrameResidual>> &flat) {
+    auto tU = std::chrono::steady_clock::now();
+    auto lapU = [&](int i) { const auto n_ = std::chrono::steady_clock::now(); lastUploadSeconds[i] = std::chrono::duration<double>(n_ - tU).count(); tU = n_; };
     const ldso_settings_t st = flatSettings();
     throwOn(ldso_ba_set_settings(ba_, &st), "ldso_ba_set_settings");
     std::vector<int32_t> slots;
     syncImageSlots(fs, slots);
+    lapU(0);
     const int F = (int) fs.frames.size();
     std::vector<ldso_frame_t> Fv((size_t) F);
     for (int f = 0; f < F; f++) {
@@ -201,16 +204,21 @@ int GpuBackend::uploadWindow(FullSystem &fs, std::vector<shared_ptr<PointHessian
             mrb.push_back(ph->maxRelBaseline); ngr.push_back(ph->numGoodResiduals);
         }
     if (P.empty()) return 0;
+    lapU(1);
     throwOn(ldso_ba_set_window(ba_, F, slots.data(), (int) P.size(), P.data(), (int) R.size(), R.data(), anyLin ? LJ.data() : nullptr, anyLin ? RTZ.data() : nullptr), "ldso_ba_set_window");
+    lapU(2);
     throwOn(ldso_ba_set_point_stats(ba_, mrb.data(), ngr.data()), "ldso_ba_set_point_stats");
+    lapU(3);
     const ldso_calib_t c = flatCalib(*fs.Hcalib->mpCH);
     throwOn(ldso_ba_set_frames(ba_, Fv.data(), &c), "ldso_ba_set_frames");                      // setAdjointsF + setPrecalcValues on the device
+    lapU(4);
     const int n = CPARS + 8 * F;
     if ((int) fs.ef->HM.rows() == n) {
         std::vector<double> HM((size_t) n * n), bM((size_t) n);
         for (int i = 0; i < n; i++) { for (int j = 0; j < n; j++) HM[(size_t) i * n + j] = fs.ef->HM(i, j); bM[i] = fs.ef->bM[i]; }
         throwOn(ldso_ba_set_prior(ba_, HM.data(), bM.data()), "ldso_ba_set_prior");
     }
+    lapU(5);
     return (int) P.size();
 }
 

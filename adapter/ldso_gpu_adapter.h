@@ -46,6 +46,7 @@ public:
     // r->J itself) and the next optimize() re-linearises everything.  On for host code that still accumulates from r->J.
     bool writeBackJacobians = false;
     int lastIterations = 0;              // GN iterations the device executed in the last optimize()
+    double lastUploadSeconds[6] = {0, 0, 0, 0, 0, 0};  // of that: settings + image slots | flatten (host walk) | ldso_ba_set_window | set_point_stats | set_frames | set_prior
     double lastOptimizeSeconds[4] = {0, 0, 0, 0};      // wall clock of the last optimize(): flatten + upload | device | fetch | write-back into the objects
 
     // ---- coarse tracker -------------------------------------------------------------------------------------------------------------

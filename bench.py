@@ -453,12 +453,15 @@ def adapter_line(name="C3"):
         A = pr.GpuAdapter(max_frames=win.F + 1, max_points=win.P + 16)
         for wb in (False, True):
             A.set_write_back_jacobians(wb)
-            ts, splits, its = [], [], 0
+            ts, splits, ups, its = [], [], [], 0
             for rep in range(6):
                 r = pr.RefWindow(win); r.fs_attach()          # (the FullSystem object of the graph exists before the clock starts, as for the reference leg)
-                t0 = time.perf_counter(); rv, its, lost = A.optimize(r, 6); ts.append(time.perf_counter() - t0); splits.append(A.last_optimize_times().copy())
+                t0 = time.perf_counter(); rv, its, lost = A.optimize(r, 6); ts.append(time.perf_counter() - t0); splits.append(A.last_optimize_times().copy()); ups.append(A.last_upload_times().copy())
                 r.close()
             sp = np.median(np.array(splits[1:]), axis=0)
+            up = np.median(np.array(ups[1:]), axis=0)
+            if not wb:
+                out["flatten_upload_split_ms"] = dict(zip(("settings_images", "host_walk", "set_window", "set_point_stats", "set_frames", "set_prior"), [round(float(v) * 1e3, 3) for v in up]))
             out["gpu_backend_optimize_ms" if not wb else "gpu_backend_optimize_ms_with_jacobian_write_back"] = round(float(np.median(ts[1:])) * 1e3, 3)
             out["split_ms" if not wb else "split_ms_with_jacobian_write_back"] = {"flatten_upload": round(sp[0] * 1e3, 3), "device": round(sp[1] * 1e3, 3), "fetch": round(sp[2] * 1e3, 3),
                                                                                   "write_back": round(sp[3] * 1e3, 3)}

@@ -97,6 +97,8 @@ struct ldso_ba {
     BatchItem itemShadow;
     bool itemValid = false;
     int *h_stop = nullptr, *d_stop = nullptr;      // host-mapped word (and its device address): which iteration ended an un-forced optimize() loop
+    char *h_down = nullptr;             // pinned arena of the fetch functions (ldso_ba_get_residuals / _points / _frames): device -> pinned host at link speed, one wait
+    size_t downCap = 0;
     char *h_stage = nullptr, *d_stage = nullptr;
     size_t stageCap = 0;
     // profiling
@@ -193,6 +195,12 @@ __global__ __launch_bounds__(256) void k_win_scatter(const char *__restrict__ ar
         }
     }
 }
+__global__ __launch_bounds__(256) void k_point_stats(PtRec *__restrict__ a, PtRec *__restrict__ b, const float *__restrict__ mrb, const int32_t *__restrict__ ngr, int P) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    const float m = mrb[i]; const int32_t g = ngr[i];
+    a[i].maxRelBS = m; a[i].numGood = g; b[i].maxRelBS = m; b[i].numGood = g;
+}
 // host side of the arena: reserve (16-byte aligned) room, remember where it goes
 struct WinStage {
     char *base; size_t cap, used; WinXfer *tab; int n;
@@ -221,6 +229,27 @@ template <class T> static int h2d(ldso_ba *H, T *dst, const std::vector<T> &src)
     CHK(hipMemcpyAsync(dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, H->stream));
     return LDSO_OK;
 }
+// the fetch functions read the device tables through ONE pinned arena: reserve what the call needs (growth invalidates nothing: it happens before
+// the first copy is enqueued), enqueue the copies back to back, wait once, read in place.  (std::vector destinations are pageable memory: the
+// runtime stages them in small pieces - ldso_ba_get_residuals of a C3 window took 0.35 ms for 1 MB.)
+static int down_reserve(ldso_ba *H, size_t bytes) {
+    if (bytes <= H->downCap) return LDSO_OK;
+    CHK(hipStreamSynchronize(H->stream));
+    if (H->h_down) (void) hipHostFree(H->h_down);
+    H->h_down = nullptr; H->downCap = 0;
+    const size_t cap = bytes + bytes / 2 + 4096;
+    CHK(hipHostMalloc((void **) &H->h_down, cap));
+    H->downCap = cap;
+    return LDSO_OK;
+}
+template <class T> static const T *down_put(ldso_ba *H, size_t &used, const T *src, size_t n, int &rc) {
+    const size_t bytes = (n * sizeof(T) + 63) & ~(size_t) 63;
+    const T *p = reinterpret_cast<const T *>(H->h_down + used);
+    if (rc == LDSO_OK && n) { if (hipMemcpyAsync(H->h_down + used, src, n * sizeof(T), hipMemcpyDeviceToHost, H->stream) != hipSuccess) { ldso_set_error("hipMemcpyAsync (fetch) failed"); rc = LDSO_E_HIP; } }
+    used += bytes;
+    return p;
+}
+
 template <class T> static int d2h(ldso_ba *H, std::vector<T> &dst, const T *src, size_t n) {
     dst.resize(n);
     if (n == 0) return LDSO_OK;
@@ -306,6 +335,7 @@ int ldso_ba_destroy(ldso_ba_t *H) {
     if (H->d_item) hipFree(H->d_item);
     if (H->d_blocks) hipFree(H->d_blocks);
     if (H->h_stop) hipHostFree(H->h_stop);
+    if (H->h_down) hipHostFree(H->h_down);
     if (H->h_stage) hipHostFree(H->h_stage);
     if (H->d_stage) hipFree(H->d_stage);
     if (H->d_act) hipFree(H->d_act);
@@ -567,12 +597,15 @@ int ldso_ba_set_window(ldso_ba_t *H, int F, const int32_t *image_slot, int P, co
 int ldso_ba_set_point_stats(ldso_ba_t *H, const float *maxRelBaseline, const int32_t *numGoodResiduals) {
     REQ(H && H->D.P > 0 && maxRelBaseline && numGoodResiduals, "ldso_ba_set_point_stats: bad arguments / no window");
     CHK(hipSetDevice(H->device));
-    for (int s_ = 0; s_ < 2; s_++) {
-        // one 4-byte field of every 64-byte PtRec: a strided copy
-        CHK(hipMemcpy2DAsync(&H->sets[s_].pt[0].maxRelBS, sizeof(PtRec), maxRelBaseline, 4, 4, (size_t) H->D.P, hipMemcpyHostToDevice, H->stream));
-        CHK(hipMemcpy2DAsync(&H->sets[s_].pt[0].numGood, sizeof(PtRec), numGoodResiduals, 4, 4, (size_t) H->D.P, hipMemcpyHostToDevice, H->stream));
-    }
-    CHK(hipStreamSynchronize(H->stream));
+    // one 4-byte field of every 64-byte PtRec of both sets: through the pinned staging arena of ldso_ba_set_window (free again: that call ends
+    // synchronised) and one scatter kernel - four strided 2-D copies took 0.25 ms for 2000 points
+    const size_t P = (size_t) H->D.P;
+    REQ(H->h_stage && H->stageCap >= 8 * P, "ldso_ba_set_point_stats: staging arena missing (internal)");
+    memcpy(H->h_stage, maxRelBaseline, 4 * P); memcpy(H->h_stage + 4 * P, numGoodResiduals, 4 * P);
+    CHK(hipMemcpyAsync(H->d_stage, H->h_stage, 8 * P, hipMemcpyHostToDevice, H->stream));
+    hipLaunchKernelGGL(k_point_stats, dim3((unsigned) ((P + 255) / 256)), dim3(256), 0, H->stream, H->sets[0].pt, H->sets[1].pt, (const float *) H->d_stage, (const int32_t *) (H->d_stage + 4 * P), (int) P);
+    CHK(hipGetLastError());
+    CHK(hipStreamSynchronize(H->stream));          // the arena is handed back to the next ldso_ba_set_window
     return LDSO_OK;
 }
 
@@ -1541,7 +1574,6 @@ int ldso_ba_solve_reduced(ldso_ba_t *H, const void *buf, int iteration, double l
 // fetchers
 // ---------------------------------------------------------------------------------------------------------
 #define D2H(vec, src, n) do { int r_ = d2h(H, (vec), (src), (n)); if (r_ != LDSO_OK) return r_; } while (0)
-
 int ldso_ba_get_residuals(ldso_ba_t *H, ldso_res_out_t *out, int32_t *state_state, int32_t *is_active, int32_t *to_remove) {
     REQ(H && H->D.P > 0, "no window");
     CHK(hipSetDevice(H->device));
@@ -1549,11 +1581,13 @@ int ldso_ba_get_residuals(ldso_ba_t *H, ldso_res_out_t *out, int32_t *state_stat
     // "new" values come from the set written by the last linearize, applied values from the current set
     const ResSet &Sn = H->pendingApply ? H->sets[H->cur ^ 1] : H->sets[H->cur];
     const ResSet &Sc = H->sets[H->cur];
-    std::vector<SlotRec> rn, rc;
-    D2H(rn, Sn.slot, PS);
-    if (&Sn != &Sc) D2H(rc, Sc.slot, PS);
+    RUN(down_reserve(H, 2 * (PS * sizeof(SlotRec) + 64)));
+    size_t used = 0; int rcD = LDSO_OK;
+    const SlotRec *rn = down_put(H, used, Sn.slot, PS, rcD);
+    const SlotRec *rc = (&Sn != &Sc) ? down_put(H, used, Sc.slot, PS, rcD) : rn;
+    if (rcD != LDSO_OK) return rcD;
     CHK(hipStreamSynchronize(H->stream));
-    const std::vector<SlotRec> &rcur = (&Sn != &Sc) ? rc : rn;
+    const SlotRec *rcur = rc;
     for (int i = 0; i < H->R; i++) {
         size_t s = H->flat2slot[i];
         const SlotRec &n_ = rn[s], &c_ = rcur[s];
@@ -1575,10 +1609,12 @@ int ldso_ba_get_points(ldso_ba_t *H, ldso_point_out_t *out) {
     CHK(hipSetDevice(H->device));
     const size_t P = H->D.P;
     const ResSet &S = H->sets[H->cur];
-    std::vector<PtGeo> geo;
-    std::vector<PtRec> pt;
-    std::vector<PtAcc> acc;
-    D2H(geo, H->B.pgeo, P); D2H(pt, S.pt, P); D2H(acc, S.acc, P);
+    RUN(down_reserve(H, P * (sizeof(PtGeo) + sizeof(PtRec) + sizeof(PtAcc)) + 3 * 64));
+    size_t used = 0; int rcD = LDSO_OK;
+    const PtGeo *geo = down_put(H, used, H->B.pgeo, P, rcD);
+    const PtRec *pt = down_put(H, used, S.pt, P, rcD);
+    const PtAcc *acc = down_put(H, used, S.acc, P, rcD);
+    if (rcD != LDSO_OK) return rcD;
     CHK(hipStreamSynchronize(H->stream));
     for (size_t i = 0; i < P; i++) {
         ldso_point_out_t &o = out[i];
@@ -1594,11 +1630,13 @@ int ldso_ba_get_frames(ldso_ba_t *H, ldso_frame_t *fr, double *step, double *cv,
     REQ(H && H->D.F > 0, "no window");
     CHK(hipSetDevice(H->device));
     const int F = H->D.F;
-    std::vector<DevFrame> df;
-    D2H(df, H->B.frames, (size_t) F);
-    DevCalib dc;
-    CHK(hipMemcpyAsync(&dc, H->B.calib, sizeof(dc), hipMemcpyDeviceToHost, H->stream));
+    RUN(down_reserve(H, (size_t) F * sizeof(DevFrame) + sizeof(DevCalib) + 2 * 64));
+    size_t used = 0; int rcD = LDSO_OK;
+    const DevFrame *df = down_put(H, used, H->B.frames, (size_t) F, rcD);
+    const DevCalib *dcp = down_put(H, used, H->B.calib, (size_t) 1, rcD);
+    if (rcD != LDSO_OK) return rcD;
     CHK(hipStreamSynchronize(H->stream));
+    const DevCalib &dc = *dcp;
     for (int f = 0; f < F; f++) {
         if (fr) {
             ldso_frame_t &o = fr[f];

@@ -400,6 +400,12 @@ class GpuAdapter:
         self.A.adp_last_optimize_times(self.h, _p(t))
         return t
 
+    def last_upload_times(self):
+        """split of the flatten + upload part (s): settings + image slots, host walk, set_window, set_point_stats, set_frames, set_prior"""
+        t = np.zeros(6, np.float64)
+        self.A.adp_last_upload_times(self.h, _p(t))
+        return t
+
     def trace_new_coarse(self, ref_window: "RefWindow", fh):
         """GpuBackend::traceNewCoarse(fs, fh) in place of FullSystem::traceNewCoarse -> the six status counters"""
         ref_window.fs_attach()
