@@ -164,16 +164,13 @@ int GpuBackend::uploadWindow(FullSystem &fs, std::vector<shared_ptr<PointHessian
     // linearised residuals (none in LDSO's own flow: flagPointsForRemoval clears isLinearized, FullSystem.cc:1243) carry their Jacobian and
     // res_toZeroF across; the 296-byte records are only built when there is one
     bool anyLin = false;
-    for (int f = 0; f < F && !anyLin; f++)
-        for (shared_ptr<Feature> &feat : fs.frames[f]->features) {
-            if (!(feat->status == Feature::FeatureStatus::VALID && feat->point && feat->point->status == Point::PointStatus::ACTIVE)) continue;
-            for (shared_ptr<PointFrameResidual> &r : feat->point->mpPH->residuals) if (r->isLinearized) { anyLin = true; break; }
-            if (anyLin) break;
-        }
     {
         size_t np = 0, nr = 0;
         for (int f = 0; f < F; f++) for (shared_ptr<Feature> &feat : fs.frames[f]->features)
-            if (feat->status == Feature::FeatureStatus::VALID && feat->point && feat->point->status == Point::PointStatus::ACTIVE) { np++; nr += feat->point->mpPH->residuals.size(); }
+            if (feat->status == Feature::FeatureStatus::VALID && feat->point && feat->point->status == Point::PointStatus::ACTIVE) {
+                np++; nr += feat->point->mpPH->residuals.size();
+                if (!anyLin) for (shared_ptr<PointFrameResidual> &r : feat->point->mpPH->residuals) if (r->isLinearized) { anyLin = true; break; }
+            }
         P.reserve(np); allPoints.reserve(np); mrb.reserve(np); ngr.reserve(np); R.reserve(nr); flat.reserve(nr);
         if (anyLin) { LJ.reserve(nr); RTZ.reserve(nr * 8); }
     }

@@ -99,6 +99,7 @@ struct ldso_ba {
     int *h_stop = nullptr, *d_stop = nullptr;      // host-mapped word (and its device address): which iteration ended an un-forced optimize() loop
     char *h_down = nullptr;             // pinned arena of the fetch functions (ldso_ba_get_residuals / _points / _frames): device -> pinned host at link speed, one wait
     size_t downCap = 0;
+    bool stageBusy = false;            // an asynchronous copy out of h_stage may still be in flight (ldso_ba_set_prior): the next user of the arena waits first
     char *h_stage = nullptr, *d_stage = nullptr;
     size_t stageCap = 0;
     // profiling
@@ -525,6 +526,7 @@ int ldso_ba_set_window(ldso_ba_t *H, int F, const int32_t *image_slot, int P, co
         CHK(hipMalloc((void **) &H->d_stage, cap));
         H->stageCap = cap;
     }
+    if (H->stageBusy) { CHK(hipStreamSynchronize(H->stream)); H->stageBusy = false; }
     WinStage W{H->h_stage, H->stageCap, tabBytes, reinterpret_cast<WinXfer *>(H->h_stage), 0};
     PtGeo *geo = W.put(B.pgeo, P);
     PtCw *pcw = W.put(B.pcw, (size_t) P * 8);
@@ -601,6 +603,7 @@ int ldso_ba_set_point_stats(ldso_ba_t *H, const float *maxRelBaseline, const int
     // synchronised) and one scatter kernel - four strided 2-D copies took 0.25 ms for 2000 points
     const size_t P = (size_t) H->D.P;
     REQ(H->h_stage && H->stageCap >= 8 * P, "ldso_ba_set_point_stats: staging arena missing (internal)");
+    if (H->stageBusy) { CHK(hipStreamSynchronize(H->stream)); H->stageBusy = false; }
     memcpy(H->h_stage, maxRelBaseline, 4 * P); memcpy(H->h_stage + 4 * P, numGoodResiduals, 4 * P);
     CHK(hipMemcpyAsync(H->d_stage, H->h_stage, 8 * P, hipMemcpyHostToDevice, H->stream));
     hipLaunchKernelGGL(k_point_stats, dim3((unsigned) ((P + 255) / 256)), dim3(256), 0, H->stream, H->sets[0].pt, H->sets[1].pt, (const float *) H->d_stage, (const int32_t *) (H->d_stage + 4 * P), (int) P);
@@ -683,8 +686,18 @@ int ldso_ba_set_prior(ldso_ba_t *H, const double *HM, const double *bM) {
     CHK(hipSetDevice(H->device));
     size_t n = H->D.n;
     H->hasPrior = (HM != nullptr) || (bM != nullptr);
-    if (HM) CHK(hipMemcpyAsync(H->B.HM, HM, n * n * 8, hipMemcpyHostToDevice, H->stream)); else CHK(hipMemsetAsync(H->B.HM, 0, n * n * 8, H->stream));
-    if (bM) CHK(hipMemcpyAsync(H->B.bM, bM, n * 8, hipMemcpyHostToDevice, H->stream)); else CHK(hipMemsetAsync(H->B.bM, 0, n * 8, H->stream));
+    // through the pinned staging arena of ldso_ba_set_window (free: that call ends synchronised) when it is there - two copies from pageable memory + a wait
+    // took 0.13 ms for 29 KB; no wait at the end: the arena is not reused before the next ldso_ba_set_window / set_point_stats, which synchronise first
+    const size_t bytesH = n * n * 8, bytesB = n * 8;
+    if (H->h_stage && H->stageCap >= bytesH + bytesB + 64) {
+        if (H->stageBusy) { CHK(hipStreamSynchronize(H->stream)); H->stageBusy = false; }          // a previous ldso_ba_set_prior's copy
+        if (HM) { memcpy(H->h_stage, HM, bytesH); CHK(hipMemcpyAsync(H->B.HM, H->h_stage, bytesH, hipMemcpyHostToDevice, H->stream)); } else CHK(hipMemsetAsync(H->B.HM, 0, bytesH, H->stream));
+        if (bM) { memcpy(H->h_stage + bytesH, bM, bytesB); CHK(hipMemcpyAsync(H->B.bM, H->h_stage + bytesH, bytesB, hipMemcpyHostToDevice, H->stream)); } else CHK(hipMemsetAsync(H->B.bM, 0, bytesB, H->stream));
+        H->stageBusy = true;
+        return LDSO_OK;
+    }
+    if (HM) CHK(hipMemcpyAsync(H->B.HM, HM, bytesH, hipMemcpyHostToDevice, H->stream)); else CHK(hipMemsetAsync(H->B.HM, 0, bytesH, H->stream));
+    if (bM) CHK(hipMemcpyAsync(H->B.bM, bM, bytesB, hipMemcpyHostToDevice, H->stream)); else CHK(hipMemsetAsync(H->B.bM, 0, bytesB, H->stream));
     CHK(hipStreamSynchronize(H->stream));
     return LDSO_OK;
 }
