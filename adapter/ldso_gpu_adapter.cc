@@ -136,7 +136,7 @@ void GpuBackend::syncImageSlots(FullSystem &fs, std::vector<int32_t> &slots) {
 // the order of EnergyFunctional::makeIDX (EnergyFunctional.cc:380-401: frames, then the host frame's features), residuals in
 // PointHessian::residuals order; a residual's slot is (hostIDX, targetIDX).  allPoints / flat give the write-back its objects.
 // ------------------------------------------------------------------------------------------------------------------------------------
-int GpuBackend::uploadWindow(FullSystem &fs, std::vector<shared_ptr<PointHessian>> &allPoints, std::vector<shared_ptr<PointFrameResidual>> &flat) {
+int GpuBackend::uploadWindow(FullSystem &fs, std::vector<shared_ptr<PointHessian>> &allPoints, std::vector<shared_ptr<PointFrameResidual>> &flat, bool trustIndices) {
     auto tU = std::chrono::steady_clock::now();
     auto lapU = [&](int i) { const auto n_ = std::chrono::steady_clock::now(); lastUploadSeconds[i] = std::chrono::duration<double>(n_ - tU).count(); tU = n_; };
     const ldso_settings_t st = flatSettings();
@@ -160,6 +160,7 @@ int GpuBackend::uploadWindow(FullSystem &fs, std::vector<shared_ptr<PointHessian
         o.ab_exposure = fh.ab_exposure; o.frameEnergyTH = fh.frameEnergyTH; o.frameID = (int32_t) fh.frame->id;   // getPrior keys on frame->id == 0
     }
     allPoints.clear(); flat.clear();
+    resBegin_.assign(1, 0);
     std::vector<ldso_point_t> P; std::vector<ldso_residual_t> R; std::vector<ldso_rawjac_t> LJ; std::vector<float> RTZ, mrb; std::vector<int32_t> ngr;
     // linearised residuals (none in LDSO's own flow: flagPointsForRemoval clears isLinearized, FullSystem.cc:1243) carry their Jacobian and
     // res_toZeroF across; the 296-byte records are only built when there is one
@@ -184,7 +185,13 @@ int GpuBackend::uploadWindow(FullSystem &fs, std::vector<shared_ptr<PointHessian
             memcpy(p.color, ph->color, sizeof(p.color)); memcpy(p.weights, ph->weights, sizeof(p.weights));
             p.host = f; p.res_begin = (int32_t) R.size(); p.res_count = (int32_t) ph->residuals.size();
             for (shared_ptr<PointFrameResidual> &r : ph->residuals) {
-                r->hostIDX = r->host.lock()->idx; r->targetIDX = r->target.lock()->idx;           // makeIDX
+                // makeIDX (EnergyFunctional.cc:380-401).  LDSO's own flow reaches optimize() with valid indices (makeKeyFrame calls ef->makeIDX() right before it,
+                // solveSystemF asserts EFIndicesValid): then r->hostIDX / targetIDX are taken as they are - two weak_ptr::lock() per residual are two atomic
+                // read-modify-write pairs, 24 000 of them a quarter of the flatten at C3
+                // - and only there (trustIndices): insertResidual does not invalidate the flag, so between insertFrame's makeIDX and the explicit one in front
+                // of optimize() (FullSystem.cc:474) fresh residuals carry no indices yet - the activation upload derives them.  The host needs no lock at all.
+                r->hostIDX = f;
+                if (!(trustIndices && EFIndicesValid)) r->targetIDX = r->target.lock()->idx;
                 ldso_residual_t q;
                 q.point = (int32_t) P.size(); q.host = r->hostIDX; q.target = r->targetIDX; q.state_state = (int32_t) r->state_state;
                 q.is_linearized = r->isLinearized ? 1 : 0; q.is_active = r->isActive() ? 1 : 0; q.is_new = r->isNew ? 1 : 0; q.state_energy = (float) r->state_energy;
@@ -199,6 +206,7 @@ int GpuBackend::uploadWindow(FullSystem &fs, std::vector<shared_ptr<PointHessian
             }
             P.push_back(p); allPoints.push_back(ph);
             mrb.push_back(ph->maxRelBaseline); ngr.push_back(ph->numGoodResiduals);
+            resBegin_.push_back((int32_t) R.size());
         }
     if (P.empty()) return 0;
     lapU(1);
@@ -232,7 +240,7 @@ float GpuBackend::optimize(FullSystem &fs, int mnumOptIts) {
     const auto tWall0 = std::chrono::steady_clock::now();
     auto lap = [&](int i, std::chrono::steady_clock::time_point &t) { const auto n_ = std::chrono::steady_clock::now(); lastOptimizeSeconds[i] = std::chrono::duration<double>(n_ - t).count(); t = n_; };
     auto tLap = tWall0;
-    if (uploadWindow(fs, allPoints, flat) == 0) return 0;
+    if (uploadWindow(fs, allPoints, flat, /*trustIndices*/ true) == 0) return 0;
     lap(0, tLap);
     const int F = (int) fs.frames.size(), P = (int) allPoints.size(), R = (int) flat.size();
 
@@ -294,20 +302,25 @@ float GpuBackend::optimize(FullSystem &fs, int mnumOptIts) {
         for (int k = 0; k < 8; k++) r.JpJdF[k] = ro[i].JpJdF[k];
         if (writeBackJacobians && r.state_NewState != ResState::OOB) fromRaw(Jv[i], *r.J);
     }
-    for (int i = 0; i < R; i++) {
-        shared_ptr<PointFrameResidual> &r = flat[i];
-        if (r->isLinearized) continue;
-        shared_ptr<PointHessian> ph = r->point.lock();
-        if (ph->lastResiduals[0].first == r) ph->lastResiduals[0].second = r->state_state;
-        else if (ph->lastResiduals[1].first == r) ph->lastResiduals[1].second = r->state_state;
+    // (the residuals of point k are flat[resBegin[k] .. resBegin[k + 1]): no weak_ptr::lock() per residual to find the point)
+    for (int k = 0; k < P; k++) {
+        PointHessian &ph = *allPoints[k];
+        for (int i = resBegin_[k]; i < resBegin_[k + 1]; i++) {
+            shared_ptr<PointFrameResidual> &r = flat[i];
+            if (r->isLinearized) continue;
+            if (ph.lastResiduals[0].first == r) ph.lastResiduals[0].second = r->state_state;
+            else if (ph.lastResiduals[1].first == r) ph.lastResiduals[1].second = r->state_state;
+        }
     }
-    for (int i = 0; i < R; i++) {
-        if (!rem[i]) continue;
-        shared_ptr<PointFrameResidual> r = flat[i];
-        shared_ptr<PointHessian> ph = r->point.lock();
-        if (ph->lastResiduals[0].first == r) ph->lastResiduals[0].first = 0;
-        else if (ph->lastResiduals[1].first == r) ph->lastResiduals[1].first = 0;
-        fs.ef->dropResidual(r);                                                                   // EnergyFunctional.cc:44-56
+    for (int k = 0; k < P; k++) {
+        PointHessian &ph = *allPoints[k];
+        for (int i = resBegin_[k]; i < resBegin_[k + 1]; i++) {
+            if (!rem[i]) continue;
+            shared_ptr<PointFrameResidual> r = flat[i];
+            if (ph.lastResiduals[0].first == r) ph.lastResiduals[0].first = 0;
+            else if (ph.lastResiduals[1].first == r) ph.lastResiduals[1].first = 0;
+            fs.ef->dropResidual(r);                                                               // EnergyFunctional.cc:44-56
+        }
     }
     int resInA = 0, resInL = 0;
     throwOn(ldso_ba_get_counts(ba_, &resInA, &resInL), "ldso_ba_get_counts");

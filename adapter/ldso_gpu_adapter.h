@@ -73,6 +73,7 @@ private:
     std::map<CoarseTracker *, ldso_tracker_t *> trackers_;          // the reference double-buffers two CoarseTrackers (FullSystem.h:296-297)
     std::map<unsigned long, int> slotOf_;                            // key frame (Frame::id: addresses get reused) -> image slot of the BA handle
     std::vector<long> slotOwner_;                                    // slot -> Frame::id, -1 = free
+    std::vector<int32_t> resBegin_;                                  // last upload: the residuals of point k are flat[resBegin_[k] .. resBegin_[k + 1])
     int device_, maxFrames_, maxPoints_;
     // whose pyramid a tracker handle currently holds as "new frame": keyed by Frame::id, not by address (LDSO releases the FrameHessian of a
     // non-key frame after tracking, the allocator may hand the same address to the next frame)
@@ -82,7 +83,7 @@ private:
     std::mutex handlesMutex_;
     bool newFrameResident(ldso_tracker_t *t, const shared_ptr<FrameHessian> &fh);
     ldso_tracker_t *trackerOf(CoarseTracker &tr);
-    int uploadWindow(FullSystem &fs, std::vector<shared_ptr<PointHessian>> &allPoints, std::vector<shared_ptr<PointFrameResidual>> &flat);
+    int uploadWindow(FullSystem &fs, std::vector<shared_ptr<PointHessian>> &allPoints, std::vector<shared_ptr<PointFrameResidual>> &flat, bool trustIndices = false);
     void syncImageSlots(FullSystem &fs, std::vector<int32_t> &slots);
 };
 
