@@ -19,6 +19,7 @@
 
 __global__ __launch_bounds__(256) void k_reduce(BaPtrs B, BaDims D, ResSet S, ChunkStarts chunkStart, int hasL, int GSP, int atomicMode,
                                                 int hasPrior, float calibPrior, double l1, double il, int itCheck) {
+    static_assert(sizeof(BaPtrs) + sizeof(BaDims) + sizeof(ResSet) + sizeof(ChunkStarts) >= 8 * 64 - 60, "k_reduce: ld_touch_kernarg<8> must stay inside the arguments");
     ld_touch_kernarg<8>();           // 620 bytes of arguments: the first 512 into the scalar cache with one wait (ba_dev.h): 9.24 -> 9.03 us at C3
     reduce_body(B, D, S, chunkStart, hasL, GSP, atomicMode, hasPrior, calibPrior, l1, il, itCheck, (int) blockIdx.x);
 }

@@ -1044,6 +1044,7 @@ static __device__ __forceinline__ void gn_solve_body(const BaPtrs &B, const BaDi
 __global__ __launch_bounds__(NT) void k_gn_solve(BaPtrs B, BaDims D, ResSet S, ldso_settings_t St, SolveArgs A) {
     // the 672 bytes of arguments into the scalar cache with one wait (ba_dev.h) - for the systems up to 64 x 64 only: measured (round 4, A/B on one box)
     // 27.2 -> 26.5 us at C3 (n = 60), but 62.1 -> 63.6 us at C5 (n = 100, the generic factorisation)
+    static_assert(sizeof(BaPtrs) + sizeof(BaDims) + sizeof(ResSet) + sizeof(ldso_settings_t) + sizeof(SolveArgs) >= 10 * 64 - 60, "k_gn_solve: ld_touch_kernarg<10> must stay inside the arguments");
     if (D.n + 1 <= 64) ld_touch_kernarg<10>();
     gn_solve_body<false>(B, D, S, St, A, (int) blockIdx.x);
 }
@@ -1059,6 +1060,7 @@ __global__ __launch_bounds__(NT) void k_gn_solve(BaPtrs B, BaDims D, ResSet S, l
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(NT) void k_reduce_solve(BaPtrs B, BaDims D, ResSet S, ldso_settings_t St, SolveArgs A, ChunkStarts chunkStart, int atomicMode,
                                                      float calibPrior, double l1, double il) {
+    static_assert(sizeof(BaPtrs) + sizeof(BaDims) + sizeof(ResSet) + sizeof(ldso_settings_t) + sizeof(SolveArgs) + sizeof(ChunkStarts) + 24 >= 12 * 64 - 60, "k_reduce_solve: ld_touch_kernarg<12> must stay inside the arguments");
     ld_touch_kernarg<12>();          // 768 bytes of arguments into the scalar cache with one wait (ba_dev.h): 31.8 -> 31.25 us at C3
     if (blockIdx.x >= 2) {
         const long long tStart_ = LD_STAMP_ON ? wall_clock64() : 0;
