@@ -825,7 +825,7 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
 template <int NSG, bool HAS_L, bool FIX, bool MARG>
 __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D, ResSet cur, ResSet nxt, ldso_settings_t S, int stepMode, GnInit gi,
                                                              const int32_t *__restrict__ margFlags) {
-    static_assert(sizeof(BaPtrs) + sizeof(BaDims) + 2 * sizeof(ResSet) + sizeof(ldso_settings_t) + sizeof(GnInit) + 12 >= 14 * 64 - 60, "k_linearize: ld_touch_kernarg<14> must stay inside the arguments");
+    static_assert(sizeof(BaPtrs) + sizeof(BaDims) + 2 * sizeof(ResSet) + sizeof(ldso_settings_t) + sizeof(GnInit) + 256 >= 14 * 64 - 60, "k_linearize: ld_touch_kernarg<14> must stay inside the explicit arguments + the 256 bytes of hidden arguments behind them (the kernel uses dynamic LDS: the whole hidden block is part of its kernarg segment)");
     ld_touch_kernarg<14>();          // 952 bytes of arguments into the scalar cache with one wait (ba_dev.h)
     const int chunk = (int) blockIdx.x;
     linearize_body<NSG, HAS_L, FIX, MARG, false>(B, D, cur, nxt, S, stepMode, gi, margFlags, chunk, (int) gridDim.x, B.chunk_p0[chunk], B.chunk_n[chunk], B.chunk_host[chunk]);
