@@ -110,6 +110,8 @@ int adp_last_upload_times(void *b, double *out6) { for (int i = 0; i < 6; i++) o
 // activatePointsMT, which is restated below WITHOUT the distance map (every immature point that passes the canActivate rule and projects into
 // the newest frame is a candidate).  The coarse-tracker swap (:515-522) and makeNewTraces (:539: pixel selection) are the caller's business.
 // newfh = shared_ptr<FrameHessian>* of ref_fs_new_frame.  stats: [candidates, activated, residuals added for old points, points after, lost]
+static bool deviceMarginalisation = false;
+int adp_set_device_marginalisation(int on) { deviceMarginalisation = on != 0; return 0; }
 int adp_make_keyframe(void *b, void *fs_, void *newfh, int margIdx, int kfId, int iterations, float *rmse, int *stats) {
     GUARD(
         GpuBackend *B = (GpuBackend *) b; FullSystem &fs = *(FullSystem *) fs_;
@@ -199,10 +201,18 @@ int adp_make_keyframe(void *b, void *fs_, void *newfh, int margIdx, int kfId, in
         if (fs.isLost) { stats[4] = 1; return 0; }
         // :511 remove outliers; :526-536 flag / drop / marginalise points
         fs.removeOutliers();
-        fs.flagPointsForRemoval();
-        fs.ef->dropPointsF();
-        fs.getNullspaces(fs.ef->lastNullspaces_pose, fs.ef->lastNullspaces_scale, fs.ef->lastNullspaces_affA, fs.ef->lastNullspaces_affB);
-        fs.ef->marginalizePointsF();
+        if (B && deviceMarginalisation) {
+            // the device keeps the window of optimize(): the policy on the host, the re-linearise / fix / accumulate of the marginalised points on the device
+            B->flagPointsForRemoval(fs);
+            fs.ef->dropPointsF();
+            fs.getNullspaces(fs.ef->lastNullspaces_pose, fs.ef->lastNullspaces_scale, fs.ef->lastNullspaces_affA, fs.ef->lastNullspaces_affB);
+            B->marginalizePoints(fs);
+        } else {
+            fs.flagPointsForRemoval();
+            fs.ef->dropPointsF();
+            fs.getNullspaces(fs.ef->lastNullspaces_pose, fs.ef->lastNullspaces_scale, fs.ef->lastNullspaces_affA, fs.ef->lastNullspaces_affB);
+            fs.ef->marginalizePointsF();
+        }
         // :594-603 marginalise the flagged frames (their pyramids live in the driver's image store: ~FrameHessian must not delete[] them)
         for (unsigned int i = 0; i < fs.frames.size(); i++)
             if (fs.frames[i]->frameHessian->flaggedForMarginalization) {

@@ -340,8 +340,71 @@ float GpuBackend::optimize(FullSystem &fs, int mnumOptIts) {
             fr->aff_g2l = fr->frameHessian->aff_g2l();
         }
     }
+    lastPoints_ = allPoints;
     lap(3, tLap);
     return rmse;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// void FullSystem::flagPointsForRemoval()                                                                       FullSystem.cc:1208-1270
+// The policy, line for line; the inner loop of :1241-1250 (re-linearise and fix the residuals of a point that is marginalised) is what
+// ldso_ba_marginalize_points runs on the device for the points flagged here.
+// ------------------------------------------------------------------------------------------------------------------------------------
+void GpuBackend::flagPointsForRemoval(FullSystem &fs) {
+    std::vector<shared_ptr<FrameHessian>> fhsToMargPoints;
+    for (int i = 0; i < (int) fs.frames.size(); i++)
+        if (fs.frames[i]->frameHessian->flaggedForMarginalization) fhsToMargPoints.push_back(fs.frames[i]->frameHessian);
+    for (auto &fr : fs.frames) {
+        shared_ptr<FrameHessian> host = fr->frameHessian;
+        for (auto &feat : fr->features) {
+            if (!(feat->status == Feature::FeatureStatus::VALID && feat->point->status == Point::PointStatus::ACTIVE)) continue;
+            shared_ptr<PointHessian> ph = feat->point->mpPH;
+            if (ph->idepth_scaled < 0 || ph->residuals.size() == 0) {
+                ph->point->status = Point::PointStatus::OUTLIER;
+                feat->status = Feature::FeatureStatus::OUTLIER;
+            } else if (ph->isOOB(fhsToMargPoints) || host->flaggedForMarginalization) {
+                if (ph->isInlierNew()) {
+                    // (:1241-1250 happens on the device, see marginalizePoints)
+                    if (ph->idepth_hessian > setting_minIdepthH_marg) ph->point->status = Point::PointStatus::MARGINALIZED;
+                    else ph->point->status = Point::PointStatus::OUT;
+                } else ph->point->status = Point::PointStatus::OUT;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// void EnergyFunctional::marginalizePointsF()                                                          EnergyFunctional.cc:165-222
+// ------------------------------------------------------------------------------------------------------------------------------------
+void GpuBackend::marginalizePoints(FullSystem &fs) {
+    EnergyFunctional &ef = *fs.ef;
+    const int P = (int) lastPoints_.size();
+    if (P == 0) throw std::runtime_error("GpuBackend::marginalizePoints: no window resident (call optimize first)");
+    std::vector<int32_t> flags((size_t) P, 0);
+    int nMarg = 0;
+    for (int k = 0; k < P; k++)
+        if (lastPoints_[k]->point && lastPoints_[k]->point->status == Point::PointStatus::MARGINALIZED) { flags[k] = 1; nMarg++; }
+    const int n = CPARS + 8 * (int) fs.frames.size();
+    if ((int) ef.HM.rows() != n) throw std::runtime_error("GpuBackend::marginalizePoints: the prior does not have the window's dimension");
+    if (nMarg > 0) {
+        // (the settings the device pass reads - margWeightFac, idepthFixPriorMargFac - went up with optimize(); so did ef.HM / ef.bM)
+        std::vector<double> HM((size_t) n * n), bM((size_t) n);
+        throwOn(ldso_ba_marginalize_points(ba_, flags.data(), HM.data(), bM.data()), "ldso_ba_marginalize_points");
+        for (int i = 0; i < n; i++) { for (int j = 0; j < n; j++) ef.HM(i, j) = HM[(size_t) i * n + j]; ef.bM[i] = bM[i]; }
+    }
+    // the reference's bookkeeping around the accumulation (:169-184, :193, :199, :219-220)
+    ef.allPointsToMarg.clear();
+    for (int k = 0; k < P; k++) {
+        if (!flags[k]) continue;
+        shared_ptr<PointHessian> p = lastPoints_[k];
+        p->priorF *= setting_idepthFixPriorMargFac;
+        for (auto r : p->residuals)
+            if (r->isActive()) { ef.connectivityMap[(((uint64_t) r->host.lock()->frameID) << 32) + ((uint64_t) r->target.lock()->frameID)][1]++; ef.resInM++; }
+        ef.allPointsToMarg.push_back(p);
+    }
+    for (auto p : ef.allPointsToMarg) ef.removePoint(p);
+    EFIndicesValid = false;
+    ef.makeIDX();
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------------

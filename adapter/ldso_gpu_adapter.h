@@ -11,6 +11,8 @@
 //   GpuBackend::trackNewCoarse(fs, fh)              Vec4 FullSystem::trackNewCoarse(shared_ptr<FrameHessian>)       FullSystem.cc:179-386
 //   GpuBackend::activatePoints(fs, ...)             the optimizeImmaturePoint loop of activatePointsMT              FullSystem.cc:892-1010,1196-1206
 //   GpuBackend::traceNewCoarse(fs, fh)              void FullSystem::traceNewCoarse(shared_ptr<FrameHessian>)       FullSystem.cc:1012-1050
+//   GpuBackend::flagPointsForRemoval(fs)            the policy of void FullSystem::flagPointsForRemoval()           FullSystem.cc:1208-1270
+//   GpuBackend::marginalizePoints(fs)               void EnergyFunctional::marginalizePointsF() + FullSystem.cc:1241-1250   EnergyFunctional.cc:165-222
 //
 // The functions reach into private members of FullSystem / CoarseTracker (frames, ef, activeResiduals, allFrameHistory, lastCoarseRMSE,
 // shellPoseMutex ...): a maintainer makes them member functions or adds `friend class ldso::GpuBackend;` to the two classes.  The reference tree
@@ -49,6 +51,16 @@ public:
     double lastUploadSeconds[6] = {0, 0, 0, 0, 0, 0};  // of that: settings + image slots | flatten (host walk) | ldso_ba_set_window | set_point_stats | set_frames | set_prior
     double lastOptimizeSeconds[4] = {0, 0, 0, 0};      // wall clock of the last optimize(): flatten + upload | device | fetch | write-back into the objects
 
+    // ---- point marginalisation on the device (what follows optimize() in makeKeyFrame, FullSystem.cc:526-536) ----------------------------
+    // flagPointsForRemoval: the POLICY of FullSystem::flagPointsForRemoval (FullSystem.cc:1208-1270: which points go OUT / OUTLIER / MARGINALIZED) without its inner
+    // loop (:1241-1250: resetOOB + linearize + applyRes + fixLinearizationF of every residual of a point that gets marginalised) - the device pass of
+    // marginalizePoints does exactly that to exactly those points.  marginalizePoints: EnergyFunctional::marginalizePointsF (EnergyFunctional.cc:165-222) through
+    // ldso_ba_marginalize_points on the window GpuBackend::optimize left resident (same frames, same point order), H_M / b_M written back into ef, the
+    // reference's bookkeeping (priorF, connectivity counts, removePoint, makeIDX) on the host.  Call order as the reference: flagPointsForRemoval,
+    // ef->dropPointsF(), marginalizePoints.
+    void flagPointsForRemoval(FullSystem &fs);
+    void marginalizePoints(FullSystem &fs);
+
     // ---- coarse tracker -------------------------------------------------------------------------------------------------------------
     void makeK(CoarseTracker &tr, shared_ptr<CalibHessian> HCalib);
     void setCoarseTrackingRef(CoarseTracker &tr, std::vector<shared_ptr<FrameHessian>> &frameHessians);
@@ -73,6 +85,7 @@ private:
     std::map<CoarseTracker *, ldso_tracker_t *> trackers_;          // the reference double-buffers two CoarseTrackers (FullSystem.h:296-297)
     std::map<unsigned long, int> slotOf_;                            // key frame (Frame::id: addresses get reused) -> image slot of the BA handle
     std::vector<long> slotOwner_;                                    // slot -> Frame::id, -1 = free
+    std::vector<shared_ptr<PointHessian>> lastPoints_;               // the points of the window optimize() left on the device, in its order
     std::vector<int32_t> resBegin_;                                  // last upload: the residuals of point k are flat[resBegin_[k] .. resBegin_[k + 1])
     int device_, maxFrames_, maxPoints_;
     // whose pyramid a tracker handle currently holds as "new frame": keyed by Frame::id, not by address (LDSO releases the FrameHessian of a

@@ -574,6 +574,12 @@ class RefInitializer:
         return out
 
 
+def set_device_marginalisation(on: bool):
+    """adp_make_keyframe with a GpuAdapter: GpuBackend::flagPointsForRemoval + marginalizePoints (ldso_ba_marginalize_points on the window optimize() left
+    resident) instead of the reference's flagPointsForRemoval / ef->marginalizePointsF on the host"""
+    adapter_lib().adp_set_device_marginalisation(C.c_int(1 if on else 0))
+
+
 def make_keyframe(ref_window: "RefWindow", adapter, fh, marg_idx: int, kf_id: int, iterations: int = 6):
     """one key frame in FullSystem::makeKeyFrame's order (adapter/adapter_capi.cc: adp_make_keyframe) on the window's reference objects: adapter = None
     runs the reference's own members, a GpuAdapter puts GpuBackend::traceNewCoarse / activatePoints / optimize in their place

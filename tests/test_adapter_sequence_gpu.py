@@ -22,12 +22,20 @@ def _rel(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
 
 
-def test_eight_key_frames_through_the_adapter_follow_the_reference():
+@pytest.mark.parametrize("device_marg", [False, True])
+def test_eight_key_frames_through_the_adapter_follow_the_reference(device_marg):
+    """device_marg: the point marginalisation after optimize() through GpuBackend::flagPointsForRemoval + marginalizePoints (the policy on the host, the
+    re-linearise / fix / accumulate pass of FullSystem.cc:1241-1250 + EnergyFunctional.cc:165-222 as ldso_ba_marginalize_points on the resident window)
+    instead of the reference's host members on what the adapter wrote back"""
     from adapter_sequence_common import run_sequence
     win = synth.make_config("small", extra_frames=K)
     r_ref, log_ref = run_sequence(win, K)
     A = pr.GpuAdapter(max_frames=8, max_points=4000)
-    r_adp, log_adp = run_sequence(win, K, adapter=A)
+    pr.set_device_marginalisation(device_marg)
+    try:
+        r_adp, log_adp = run_sequence(win, K, adapter=A)
+    finally:
+        pr.set_device_marginalisation(False)
     assert len(log_ref) == len(log_adp) == K
     worst = dict(pose=0.0, aff=0.0, HM=0.0, bM=0.0, idepth_max=0.0, idepth_med=0.0, rmse=0.0, counts=0, unmatched_points=0)
     for a, b in zip(log_ref, log_adp):
@@ -56,12 +64,12 @@ def test_eight_key_frames_through_the_adapter_follow_the_reference():
         assert len(both) > 0.97 * max(len(ka), len(kb))
         e = np.array([abs(ka[q] - kb[q]) / max(abs(ka[q]), 1e-3) for q in both])
         worst["idepth_max"] = max(worst["idepth_max"], float(e.max())); worst["idepth_med"] = max(worst["idepth_med"], float(np.median(e)))
-    print("adapter sequence, worst over", K, "key frames:", {k: (round(v, 7) if isinstance(v, float) else v) for k, v in worst.items()})
+    print("adapter sequence (device marginalisation: %s), worst over" % device_marg, K, "key frames:", {k: (round(v, 7) if isinstance(v, float) else v) for k, v in worst.items()})
     # observed on MI355X (round 4): rmse 1.9e-3, pose 2.0e-4 of the scene scale, affine 0.02 (b is in intensity units, 0..255), H_M 1.3e-3, b_M 2.3e-2,
     # inverse depths 1e-4 median / 8e-4 maximum, <= 1 object per count, 5 points held by one graph only - limits = 2..3 x observed
-    observe("sequence_rmse", worst["rmse"], 5e-3)
-    observe("sequence_pose", worst["pose"], 6e-4); observe("sequence_affine", worst["aff"], 6e-2)
-    observe("sequence_HM", worst["HM"], 4e-3); observe("sequence_bM", worst["bM"], 6e-2)
-    observe("sequence_idepth_median", worst["idepth_med"], 3e-4); observe("sequence_idepth_max", worst["idepth_max"], 3e-3)
-    observe("sequence_unmatched_points", worst["unmatched_points"], 20)
+    observe(("sequence_dm_" if device_marg else "sequence_") + "rmse", worst["rmse"], 5e-3)
+    observe(("sequence_dm_" if device_marg else "sequence_") + "pose", worst["pose"], 6e-4); observe(("sequence_dm_" if device_marg else "sequence_") + "affine", worst["aff"], 6e-2)
+    observe(("sequence_dm_" if device_marg else "sequence_") + "HM", worst["HM"], 4e-3); observe(("sequence_dm_" if device_marg else "sequence_") + "bM", worst["bM"], 6e-2)
+    observe(("sequence_dm_" if device_marg else "sequence_") + "idepth_median", worst["idepth_med"], 3e-4); observe(("sequence_dm_" if device_marg else "sequence_") + "idepth_max", worst["idepth_max"], 3e-3)
+    observe(("sequence_dm_" if device_marg else "sequence_") + "unmatched_points", worst["unmatched_points"], 20)
     A.close()
