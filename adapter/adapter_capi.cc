@@ -95,6 +95,8 @@ int adp_trace_new_coarse(void *b, void *fs, void *fh, int *counts) {
     GUARD(((GpuBackend *) b)->traceNewCoarse(*(FullSystem *) fs, *(std::shared_ptr<FrameHessian> *) fh); for (int i = 0; i < 6; i++) counts[i] = ((GpuBackend *) b)->lastTraceCounts[i])
 }
 
+int adp_set_device_pyramids(void *b, int on) { ((GpuBackend *) b)->useDevicePyramids = on != 0; return 0; }
+int adp_pyramids_built(void *b) { return ((GpuBackend *) b)->pyramidsBuilt; }
 int adp_set_write_back_jacobians(void *b, int on) { ((GpuBackend *) b)->writeBackJacobians = on != 0; return 0; }
 // wall-clock split of the last GpuBackend::optimize (seconds): flatten + upload, device (ldso_ba_optimize incl. its read-back of the energies), fetch, write-back into the objects
 int adp_last_optimize_times(void *b, double *out4) { for (int i = 0; i < 4; i++) out4[i] = ((GpuBackend *) b)->lastOptimizeSeconds[i]; return 0; }

@@ -103,6 +103,41 @@ GpuBackend::~GpuBackend() {
     for (auto &kv : trackers_) ldso_tr_destroy(kv.second);
     if (tracer_) ldso_trace_destroy(tracer_);
     if (ba_) ldso_ba_destroy(ba_);
+    for (auto &kv : pyr_) if (kv.second.p) ldso_pyr_destroy(kv.second.p);          // after their consumers
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// FrameHessian::dIp on the device (FrameHessian.cc:44-113): built once per frame from channel 0 of dIp[0] (= the irradiance makeImages started from;
+// the device build is bit-identical to the host arrays, tests/test_pyramid_gpu.py), keyed by Frame::id
+// ------------------------------------------------------------------------------------------------------------------------------------
+ldso_pyramid_t *GpuBackend::pyramidOf(const shared_ptr<FrameHessian> &fh) {
+    const unsigned long id = fh->frame->id;
+    std::lock_guard<std::mutex> lk(pyrMutex_);
+    auto it = pyr_.find(id);
+    if (it != pyr_.end()) { it->second.stamp = ++pyrClock_; return it->second.p; }
+    PyrEntry &e = pyr_[id];
+    e.stamp = ++pyrClock_;
+    const size_t n = (size_t) wG[0] * hG[0];
+    e.irradiance.resize(n);
+    const Vec3f *src = fh->dIp[0];
+    for (size_t i = 0; i < n; i++) e.irradiance[i] = src[i][0];
+    int rc = ldso_pyr_create(device_, wG[0], hG[0], pyrLevelsUsed, &e.p);
+    if (rc == LDSO_OK) rc = ldso_pyr_make_images(e.p, e.irradiance.data(), nullptr);
+    if (rc != LDSO_OK) { if (e.p) ldso_pyr_destroy(e.p); pyr_.erase(id); throwOn(rc, "ldso_pyr_create / ldso_pyr_make_images"); }
+    pyramidsBuilt++;
+    return e.p;
+}
+
+void GpuBackend::releasePyramids(FullSystem &fs) {
+    std::lock_guard<std::mutex> lk(pyrMutex_);
+    std::set<unsigned long> keep;
+    for (auto &fr : fs.frames) keep.insert(fr->id);
+    for (CoarseTracker *tr : {fs.coarseTracker.get(), fs.coarseTracker_forNewKF.get()}) if (tr && tr->lastRef && tr->lastRef->frame) keep.insert(tr->lastRef->frame->id);
+    for (auto &kv : trackers_) { auto it = trackerNewFrameId_.find(kv.second); if (it != trackerNewFrameId_.end()) keep.insert(it->second); }
+    for (auto it = pyr_.begin(); it != pyr_.end();) {
+        const bool recent = it->second.stamp + 4 > pyrClock_;          // the last few frames asked for: a tracker / the tracer may still name them
+        if (!keep.count(it->first) && !recent) { ldso_pyr_destroy(it->second.p); it = pyr_.erase(it); } else ++it;
+    }
 }
 
 const char *GpuBackend::lastError() const { return ldso_last_error(); }
@@ -124,7 +159,8 @@ void GpuBackend::syncImageSlots(FullSystem &fs, std::vector<int32_t> &slots) {
             size_t s = 0;
             while (s < slotOwner_.size() && slotOwner_[s] >= 0) s++;
             if (s == slotOwner_.size()) throw std::runtime_error("GpuBackend: more key frames than maxFrames");
-            throwOn(ldso_ba_set_image(ba_, (int) s, (const float *) fh->dIp[0]), "ldso_ba_set_image");      // Vec3f AoS (I, dx, dy): a straight copy
+            if (useDevicePyramids && fr->frameHessian->frame) throwOn(ldso_ba_set_image_pyramid(ba_, (int) s, pyramidOf(fr->frameHessian)), "ldso_ba_set_image_pyramid");   // zero-copy: level 0 of the frame's pyramid
+            else throwOn(ldso_ba_set_image(ba_, (int) s, (const float *) fh->dIp[0]), "ldso_ba_set_image");      // Vec3f AoS (I, dx, dy): a straight copy
             slotOwner_[s] = (long) fr->id; it = slotOf_.emplace(fr->id, (int) s).first;
         }
         slots.push_back(it->second);
@@ -237,6 +273,7 @@ float GpuBackend::optimize(FullSystem &fs, int mnumOptIts) {
 
     std::vector<shared_ptr<PointHessian>> allPoints;
     std::vector<shared_ptr<PointFrameResidual>> flat;
+    if (useDevicePyramids) releasePyramids(fs);
     const auto tWall0 = std::chrono::steady_clock::now();
     auto lap = [&](int i, std::chrono::steady_clock::time_point &t) { const auto n_ = std::chrono::steady_clock::now(); lastOptimizeSeconds[i] = std::chrono::duration<double>(n_ - t).count(); t = n_; };
     auto tLap = tWall0;
@@ -507,7 +544,8 @@ void GpuBackend::traceNewCoarse(FullSystem &fs, shared_ptr<FrameHessian> fh) {
         aff[(size_t) f * 2] = a[0]; aff[(size_t) f * 2 + 1] = a[1];
     }
     throwOn(ldso_trace_set_points(tracer_, (int) rec.size(), rec.data()), "ldso_trace_set_points");
-    throwOn(ldso_trace_set_frame(tracer_, (const float *) fh->dIp[0]), "ldso_trace_set_frame");
+    if (useDevicePyramids && fh->frame) throwOn(ldso_trace_set_frame_pyramid(tracer_, pyramidOf(fh)), "ldso_trace_set_frame_pyramid");
+    else throwOn(ldso_trace_set_frame(tracer_, (const float *) fh->dIp[0]), "ldso_trace_set_frame");
     throwOn(ldso_trace_on(tracer_, F, KRKi.data(), Kt.data(), aff.data(), lastTraceCounts), "ldso_trace_on");
     throwOn(ldso_trace_get_points(tracer_, rec.data()), "ldso_trace_get_points");
     for (size_t i = 0; i < rec.size(); i++) {          // what ImmaturePoint::traceOn leaves in the object (ImmaturePoint.cc:47-310)
@@ -569,6 +607,11 @@ void GpuBackend::setCoarseTrackingRef(CoarseTracker &tr, std::vector<shared_ptr<
     tr.refFrameID = tr.lastRef->frame->id;
     tr.lastRef_aff_g2l = tr.lastRef->aff_g2l();
     tr.firstCoarseRMSE = -1;
+    if (useDevicePyramids && tr.lastRef->frame) {
+        throwOn(ldso_tr_set_ref_pyramid(trackerOf(tr), pyramidOf(tr.lastRef), tr.lastRef_aff_g2l.a, tr.lastRef_aff_g2l.b, tr.lastRef->ab_exposure, pts.data(), (int) (pts.size() / 4)),
+                "ldso_tr_set_ref_pyramid");
+        return;
+    }
     const float *pyr[PYR_LEVELS];
     for (int l = 0; l < pyrLevelsUsed; l++) pyr[l] = (const float *) tr.lastRef->dIp[l];
     throwOn(ldso_tr_set_ref(trackerOf(tr), pyr, tr.lastRef_aff_g2l.a, tr.lastRef_aff_g2l.b, tr.lastRef->ab_exposure, pts.data(), (int) (pts.size() / 4)), "ldso_tr_set_ref");
@@ -580,9 +623,12 @@ bool GpuBackend::trackNewestCoarse(CoarseTracker &tr, shared_ptr<FrameHessian> n
     ldso_tracker_t *t = trackerOf(tr);
     tr.newFrame = newFrameHessian;
     if (!newFrameResident(t, newFrameHessian)) {              // the pyramid goes over once per frame, not once per hypothesis
-        const float *pyr[PYR_LEVELS];
-        for (int l = 0; l < pyrLevelsUsed; l++) pyr[l] = (const float *) newFrameHessian->dIp[l];
-        throwOn(ldso_tr_set_new_frame(t, pyr, newFrameHessian->ab_exposure), "ldso_tr_set_new_frame");
+        if (useDevicePyramids && newFrameHessian->frame) throwOn(ldso_tr_set_new_frame_pyramid(t, pyramidOf(newFrameHessian), newFrameHessian->ab_exposure), "ldso_tr_set_new_frame_pyramid");
+        else {
+            const float *pyr[PYR_LEVELS];
+            for (int l = 0; l < pyrLevelsUsed; l++) pyr[l] = (const float *) newFrameHessian->dIp[l];
+            throwOn(ldso_tr_set_new_frame(t, pyr, newFrameHessian->ab_exposure), "ldso_tr_set_new_frame");
+        }
     }
     double T[12], mr[5], lr[5], fl[3];
     float ab[2] = {(float) aff_g2l_out.a, (float) aff_g2l_out.b};
@@ -607,9 +653,12 @@ Vec4 GpuBackend::trackNewCoarse(FullSystem &fs, shared_ptr<FrameHessian> fh) {
     shared_ptr<FrameHessian> lastF = tr.lastRef;
     tr.newFrame = fh;
     if (!newFrameResident(t, fh)) {
-        const float *pyr[PYR_LEVELS];
-        for (int l = 0; l < pyrLevelsUsed; l++) pyr[l] = (const float *) fh->dIp[l];
-        throwOn(ldso_tr_set_new_frame(t, pyr, fh->ab_exposure), "ldso_tr_set_new_frame");
+        if (useDevicePyramids && fh->frame) throwOn(ldso_tr_set_new_frame_pyramid(t, pyramidOf(fh), fh->ab_exposure), "ldso_tr_set_new_frame_pyramid");
+        else {
+            const float *pyr[PYR_LEVELS];
+            for (int l = 0; l < pyrLevelsUsed; l++) pyr[l] = (const float *) fh->dIp[l];
+            throwOn(ldso_tr_set_new_frame(t, pyr, fh->ab_exposure), "ldso_tr_set_new_frame");
+        }
     }
     double sprelast[12], slast[12], lastFw2c[12];
     float aff_last[2] = {0, 0};

@@ -76,6 +76,13 @@ public:
     void traceNewCoarse(FullSystem &fs, shared_ptr<FrameHessian> fh);
     int lastTraceCounts[6] = {0, 0, 0, 0, 0, 0};        // good, oob, outlier, skipped, bad condition, uninitialised (the function's trace_* counters)
 
+    // ---- FrameHessian::dIp on the device: one ldso_pyramid_t per frame (FrameHessian.cc:44-113 on the device from the frame's irradiance, 4 bytes per pixel
+    // over PCIe once per frame), shared zero-copy by the BA image slot, the tracer and both roles of the coarse trackers - as the reference shares fh->dIp by
+    // pointer.  Off: every consumer uploads the host arrays it needs (12 bytes per pixel and consumer).  Pyramids of frames that left the window and are neither
+    // a tracker's reference nor among the most recent frames are released at the next optimize().
+    bool useDevicePyramids = true;
+    int pyramidsBuilt = 0;               // statistics: pyramids built so far (one per frame seen)
+
     const char *lastError() const;
 
 private:
@@ -86,6 +93,12 @@ private:
     std::map<unsigned long, int> slotOf_;                            // key frame (Frame::id: addresses get reused) -> image slot of the BA handle
     std::vector<long> slotOwner_;                                    // slot -> Frame::id, -1 = free
     std::vector<shared_ptr<PointHessian>> lastPoints_;               // the points of the window optimize() left on the device, in its order
+    struct PyrEntry { ldso_pyramid_t *p = nullptr; std::vector<float> irradiance; unsigned long stamp = 0; };
+    std::map<unsigned long, PyrEntry> pyr_;                          // Frame::id -> pyramid (+ the host copy of channel 0 the build read from)
+    unsigned long pyrClock_ = 0;
+    std::mutex pyrMutex_;                                            // tracking thread (new frame / reference) and mapping thread (window, tracer) share the map
+    ldso_pyramid_t *pyramidOf(const shared_ptr<FrameHessian> &fh);
+    void releasePyramids(FullSystem &fs);
     std::vector<int32_t> resBegin_;                                  // last upload: the residuals of point k are flat[resBegin_[k] .. resBegin_[k + 1])
     int device_, maxFrames_, maxPoints_;
     // whose pyramid a tracker handle currently holds as "new frame": keyed by Frame::id, not by address (LDSO releases the FrameHessian of a

@@ -391,6 +391,12 @@ class GpuAdapter:
             L.ref_fs_free_immature(vec)
         return dict(ok=ok, idepth=idepth, res_target=tgt, last=last)
 
+    def set_device_pyramids(self, on: bool):
+        self.A.adp_set_device_pyramids(self.h, C.c_int(1 if on else 0))
+
+    def pyramids_built(self) -> int:
+        return int(self.A.adp_pyramids_built(self.h))
+
     def set_write_back_jacobians(self, on: bool):
         self.A.adp_set_write_back_jacobians(self.h, C.c_int(1 if on else 0))
 

@@ -37,6 +37,9 @@ def test_eight_key_frames_through_the_adapter_follow_the_reference(device_marg):
     finally:
         pr.set_device_marginalisation(False)
     assert len(log_ref) == len(log_adp) == K
+    # FrameHessian::dIp on the device: ONE pyramid per frame seen (the 5 frames of the initial window + the 8 new key frames), shared by the tracer, the
+    # BA image slot and - in a full system - the coarse trackers; built from 4 bytes per pixel
+    assert A.pyramids_built() == win.F + K, A.pyramids_built()
     worst = dict(pose=0.0, aff=0.0, HM=0.0, bM=0.0, idepth_max=0.0, idepth_med=0.0, rmse=0.0, counts=0, unmatched_points=0)
     for a, b in zip(log_ref, log_adp):
         sa, sb = a["summary"], b["summary"]
