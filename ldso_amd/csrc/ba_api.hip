@@ -739,17 +739,11 @@ static int refresh_item(ldso_ba *H) {
 static int launch_linearize(ldso_ba *H, bool fix, int stepMode, int itCheck) {
     t_begin(H, 0);
     GnInit gi; gi.enable = (H->D.pBegin > 0) ? 2 : 1; gi.hasPrior = H->hasPrior ? 1 : 0; gi.calibPrior = H->settings.initialCalibHessian; gi.itCheck = itCheck;
-    static const bool descAll = getenv("LDSO_LIN_DESC") != nullptr;      // kernel experiments: the descriptor-based kernel for two slot groups as well
-    static const bool noOne = getenv("LDSO_LIN_NO_ONE") != nullptr;      // kernel experiments: the table-driven kernels instead of k_linearize_one
-    if (!fix && !H->hasL && gi.enable == 1 && H->linHeadOk && !noOne) {
-        // the plain linearisation (GN iterations) of one window, one or two slot groups: descriptor and chunk geometry in the kernel arguments
+    if (!fix && !H->hasL && gi.enable == 1 && H->linHeadOk) {
+        // the plain linearisation (GN iterations) of one window, one or two slot groups: descriptor and chunk geometry in the kernel arguments (k_linearize_one;
+        // until round 3 k_linearize_batch with one window for F <= 8 and the argument-based kernel for F > 8)
         CHK(ba_launch_linearize_one(H->B, H->D, H->sets[H->cur], H->sets[H->cur ^ 1], H->settings, stepMode, gi, H->linHead, H->stream));
-    } else
-    if (!fix && !H->hasL && gi.enable == 1 && (H->D.FS == 8 || descAll) && H->B.dumpJ == nullptr) {      // (two slot groups, F > 8: the argument-based kernel is the faster one, 43.0 against 45.6 us at C5)
-        // the plain linearisation (GN iterations): descriptors from device memory (k_linearize_batch with one window)
-        { const int r_ = refresh_item(H); if (r_ != LDSO_OK) return r_; }
-        CHK(ba_launch_linearize_batch(H->d_item, H->d_blocks, H->D.nChunks, H->D.FS, H->cur, H->settings, stepMode, gi.calibPrior, H->stream, itCheck));
-    } else
+    } else          // fixing pass, linearised residuals, shards of a multi-GPU window: the argument-based kernels
     CHK(ba_launch_linearize(H->B, H->D, H->sets[H->cur], H->sets[H->cur ^ 1], H->settings, H->hasL, fix, stepMode, gi, H->stream));
     t_end(H);
     if (H->profile) { t_begin(H, 4); t_end(H); }      // empty event pair: calibrates the event overhead (which = 4)
