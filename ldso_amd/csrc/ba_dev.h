@@ -203,7 +203,9 @@ struct GnInit {
 
 #define LD_PAIRC 296        // doubles per pair contribution: hh 64, tt 64, ht 64, hc 32, tc 32, cc 16, bh 8, bt 8, bc 4 (=292, padded)
 #define LD_SC_SPLITS 16
+#ifndef LD_SCT_KS
 #define LD_SCT_KS 8          // GN fast path: K-splits (workgroups) per 16x16 Schur tile
+#endif
 #define LD_SYS_MATS 4       // HA, HL, Hsc, HFinal
 
 #ifdef __HIPCC__

@@ -1,0 +1,13 @@
+#!/bin/bash
+# Round 4, GPU call 19: K-splits per Schur tile in the fused reduce (6 / 8 / 12 workgroups per 16 x 16 tile)
+set -u
+cd "$(dirname "$0")/../.."
+ROOT=$PWD
+mkdir -p gpurun_out
+{
+for rep in 1 2; do
+for L in base ks6 ks12; do
+  if [ "$L" = base ]; then unset LDSO_HIP_LIB; else export LDSO_HIP_LIB=$ROOT/ldso_amd/libldso_hip_$L.so; fi
+  echo -n "$L C3: "; timeout 200 python bench.py --no-cpu-baseline --no-extras --min-timed-s 0.5 2>&1 | grep -E '^\{' | python -c "import sys,json; j=json.loads(sys.stdin.read()); print(j['value'], j['ms_per_step'], j['parity_vs_oracle']['ok'], j['kernels']['k_reduce_solve'])"
+done; done
+} 2>&1 | tee gpurun_out/r4_call19.log
