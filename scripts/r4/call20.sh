@@ -1,0 +1,12 @@
+#!/bin/bash
+set -u
+cd "$(dirname "$0")/../.."
+ROOT=$PWD
+mkdir -p gpurun_out
+{
+for rep in 1 2 3; do
+for L in prev base; do
+  if [ "$L" = base ]; then unset LDSO_HIP_LIB; else export LDSO_HIP_LIB=$ROOT/ldso_amd/libldso_hip_$L.so; fi
+  echo -n "$L C3: "; timeout 200 python bench.py --no-cpu-baseline --no-extras --min-timed-s 0.5 2>&1 | grep -E '^\{' | python -c "import sys,json; j=json.loads(sys.stdin.read()); print(j['value'], j['ms_per_step'], j['parity_vs_oracle']['ok'], j['parity_vs_oracle']['energy_log_10_iterations_max_rel'], j['kernels']['k_reduce_solve'])"
+done; done
+} 2>&1 | tee gpurun_out/r4_call20.log
