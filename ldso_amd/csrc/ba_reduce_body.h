@@ -222,17 +222,35 @@ static __device__ __forceinline__ void reduce_body(const BaPtrs &B, const BaDims
             else { const DevFrame &f = B.frames[(tid - 4) >> 3]; prH = f.prior[(tid - 4) & 7]; prb = prH * f.delta_prior[(tid - 4) & 7]; }
             if (hasPrior) bm = B.bM[tid];
         }
+        // H_M delta with the whole workgroup: 4 threads per row, a quarter of the row each, ALL loads of a thread issued at once (one memory latency; a thread
+        // per row walked its row in four dependent batches - this workgroup signalled last in four iterations of five, 6.6 us after the launch), the four
+        // partial sums of a row combined in the quad
+        const int rowT = tid >> 2, quarter = tid & 3;
+        constexpr int QW = 16;          // columns per quarter: n <= 64
+        double hq[QW];
+        const int per = (n + 3) >> 2, j0 = quarter * per;
+        const bool rowOn = hasPrior && rowT < n && 4 * n <= 256;          // 4 threads per row: systems up to 64 x 64; larger ones take the loop below
+#pragma unroll
+        for (int u = 0; u < QW; u++) hq[u] = (rowOn && u < per && j0 + u < n) ? B.HM[(size_t) rowT * n + j0 + u] : 0.0;
+        __syncthreads();
+        double part = 0;
+#pragma unroll
+        for (int u = 0; u < QW; u++) if (u < per && j0 + u < n) part += hq[u] * sDelta[j0 + u];
+        part += __shfl_xor(part, 1, 64); part += __shfl_xor(part, 2, 64);
+        __shared__ double sHd[8 * LD_MAXF + 4];
+        if (quarter == 0 && rowT < n) sHd[rowT] = part;
         __syncthreads();
         if (tid < n) {
             double s_ = 0;
             if (hasPrior) {
                 s_ = bm;
-                for (int j0 = 0; j0 < n; j0 += 16) {
+                if (4 * n <= 256) s_ += sHd[tid];
+                else for (int j0_ = 0; j0_ < n; j0_ += 16) {
                     double q[16];
 #pragma unroll
-                    for (int u = 0; u < 16; u++) q[u] = (j0 + u < n) ? B.HM[(size_t) tid * n + j0 + u] : 0.0;
+                    for (int u = 0; u < 16; u++) q[u] = (j0_ + u < n) ? B.HM[(size_t) tid * n + j0_ + u] : 0.0;
 #pragma unroll
-                    for (int u = 0; u < 16; u++) if (j0 + u < n) s_ += q[u] * sDelta[j0 + u];
+                    for (int u = 0; u < 16; u++) if (j0_ + u < n) s_ += q[u] * sDelta[j0_ + u];
                 }
             }
             acc_add(&B.acc[(size_t) n * n + tid], prb + s_);
