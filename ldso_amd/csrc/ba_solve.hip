@@ -306,6 +306,26 @@ static __device__ __forceinline__ void canbreak_partial(const DevFrame *fr, int 
     acc /= F;
     sF[which] = acc;
 }
+// the same four sums from the solution vector x (step = -x: the squares are the same numbers), by lanes 0..3 of the calling wavefront.  No branch on
+// `which` around the loads: four lanes taking four different branches, each with its own LDS round trips inside the loop over the frames, took 2.8 us
+static __device__ __forceinline__ void canbreak_partial_x(const double *x, int F, float *sF, int which) {
+    const int base = (which == 0) ? 6 : (which == 1) ? 7 : (which == 2) ? 0 : 3;
+    const bool three = which >= 2;
+    const int o1 = three ? base + 1 : base, o2 = three ? base + 2 : base;
+    float acc = 0;
+    for (int f0 = 0; f0 < F; f0 += 8) {
+        double a[8], b[8], c[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const double *s = x + 4 + 8 * min(f0 + u, F - 1); a[u] = s[base]; b[u] = s[o1]; c[u] = s[o2]; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const double v1 = a[u] * a[u], v3 = a[u] * a[u] + b[u] * b[u] + c[u] * c[u];
+            if (f0 + u < F) acc += three ? v3 : v1;
+        }
+    }
+    acc /= F;
+    sF[which] = acc;
+}
 static __device__ __forceinline__ void canbreak_final(const BaPtrs &B, const ldso_settings_t &St, const float *sF, float sumNID) {
     const float sumA = sF[0], sumB = sF[1], sumT = sF[2], sumR = sF[3];
     bool cb = sqrtf(sumA) < 0.0005 * St.thOptIterations && sqrtf(sumB) < 0.00005 * St.thOptIterations &&
@@ -313,92 +333,114 @@ static __device__ __forceinline__ void canbreak_final(const BaPtrs &B, const lds
     B.scalars[3] = cb ? 1.0 : 0.0;
 }
 
-// setPrecalcValues: frames' PRE poses, pair precalc, deltas
-// fr / cal: working copies of the frames and the calibration (global memory, or the LDS mirror of k_gn_solve)
-// FULL = false (inside a GN iteration): the linearisation-point part of a pair (R0, t0, b0: functions of evalPT and
-// state_zero only) is left untouched.
+// ---- pieces of setPrecalcValues shared by the step-wise path (set_precalc) and the GN tail (gn_tail) ----
+// one frame: PRE_worldToCam = exp(state) evalPT, its inverse, the deltas, from the state st[8] the caller holds in registers.  Everything is computed in
+// registers and stored afterwards - written straight into the frame, every store would force the loads that follow it to wait for it
+static __device__ __forceinline__ void frame_pose(DevFrame &f, const double *st) {
+    double sz[8], ev[12];
+#pragma unroll
+    for (int i = 0; i < 8; i++) sz[i] = f.state_zero[i];
+#pragma unroll
+    for (int i = 0; i < 12; i++) ev[i] = f.evalPT[i];
+    const double ss[6] = {0.5 * st[0], 0.5 * st[1], 0.5 * st[2], 1.0 * st[3], 1.0 * st[4], 1.0 * st[5]};
+    double E[12], P[12], Pi[12];
+    ld::se3_exp(ss, E);
+    ld::se3_mul(E, ev, P);
+    ld::se3_inv(P, Pi);
+#pragma unroll
+    for (int i = 0; i < 12; i++) { f.PRE_w2c[i] = P[i]; f.PRE_c2w[i] = Pi[i]; }
+#pragma unroll
+    for (int i = 0; i < 8; i++) { f.delta[i] = st[i] - sz[i]; f.delta_prior[i] = st[i]; }
+}
+// CalibHessian::setValue derived floats (CalibHessian.h:71-85) from the calibration value v[4]
+static __device__ __forceinline__ void calib_derived(DevCalib &C, const double *v) {
+    float sf[4], dl[4];
+    for (int i = 0; i < 4; i++) { sf[i] = (float) (50.0 * v[i]); dl[i] = (float) (v[i] - C.value_zero[i]); }
+    for (int i = 0; i < 4; i++) { C.sf[i] = sf[i]; C.cDeltaF[i] = dl[i]; }
+    C.si[0] = 1.0f / sf[0]; C.si[1] = 1.0f / sf[1]; C.si[2] = -sf[2] / sf[0]; C.si[3] = -sf[3] / sf[1];
+}
+// one pair record.  The affine parameters come from delta_prior (= state, written by frame_pose): inside gn_tail the states themselves are being
+// stored by other wavefronts while this runs.  FULL = false (inside a GN iteration): the linearisation-point part of a pair (R0, t0, b0: functions of
+// evalPT and state_zero only) is left untouched.
+// K^-1 by Eigen's 3x3 cofactor inverse (float)
+static __device__ __forceinline__ void k_inverse(float fx, float fy, float cx, float cy, float *Ki) {
+    const float K[9] = {fx, 0, cx, 0, fy, cy, 0, 0, 1};
+    auto cof = [&](int a, int b) { int a1 = (a + 1) % 3, a2 = (a + 2) % 3, b1 = (b + 1) % 3, b2 = (b + 2) % 3; return K[a1 * 3 + b1] * K[a2 * 3 + b2] - K[a1 * 3 + b2] * K[a2 * 3 + b1]; };
+    float k0 = cof(0, 0), k1 = cof(1, 0), k2 = cof(2, 0);
+    float det = (k0 * K[0] + k1 * K[3]) + k2 * K[6];
+    float invdet = 1.0f / det;
+    Ki[0] = k0 * invdet; Ki[1] = k1 * invdet; Ki[2] = k2 * invdet;
+    Ki[3] = cof(0, 1) * invdet; Ki[4] = cof(1, 1) * invdet; Ki[5] = cof(2, 1) * invdet;
+    Ki[6] = cof(0, 2) * invdet; Ki[7] = cof(1, 2) * invdet; Ki[8] = cof(2, 2) * invdet;
+}
+// KiShared: K^-1 of the current calibration where the caller has it (gn_tail: computed once beside the frame poses), or nullptr
 template <bool FULL>
-static __device__ __forceinline__ void set_precalc(const BaPtrs &B, const BaDims &D, DevFrame *fr, DevCalib *cal, const float *adH, const float *adT,
-                                   const ldso_settings_t *cbSt = nullptr, float *cbF = nullptr, float cbNID = 0.0f, int cbIter = -1, int *hostStop = nullptr, int lastIt = -1) {
+static __device__ __forceinline__ void pair_record(const BaPtrs &B, const DevFrame *fr, const DevCalib &C, int F, int i, const float *KiShared = nullptr) {
+    const int h = i / F, t = i % F;
+    const DevFrame &fh = fr[h], &ft = fr[t];
+    DevPair &o = B.pairs[i];
+    // every operand into registers before the first store of the record
+    double Tw[12], Hc[12], T[12];
+#pragma unroll
+    for (int q = 0; q < 12; q++) { Tw[q] = ft.PRE_w2c[q]; Hc[q] = fh.PRE_c2w[q]; }
+    const float expH = fh.ab_exposure, expT = ft.ab_exposure;
+    const float aH = (float) (10.0f * fh.delta_prior[6]), bH = (float) (1000.0f * fh.delta_prior[7]), aT = (float) (10.0f * ft.delta_prior[6]), bT = (float) (1000.0f * ft.delta_prior[7]);
+    const float fx = C.sf[0], fy = C.sf[1], cx = C.sf[2], cy = C.sf[3];
+    ld::se3_mul(Tw, Hc, T);
+    float R[9], tt[3];
+    for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) R[r * 3 + c] = (float) T[r * 4 + c]; tt[r] = (float) T[r * 4 + 3]; }
+    // PRE_RTll / PRE_tTll for point activation: only where the host can call it (after set_frames / optimize), not inside GN iterations
+    if (FULL) { float *rt = B.pairRt + (size_t) i * 12; for (int q = 0; q < 9; q++) rt[q] = R[q]; for (int q = 0; q < 3; q++) rt[9 + q] = tt[q]; }
+    if (FULL) {
+        double Ti[12], T0[12];
+        ld::se3_inv(fh.evalPT, Ti);
+        ld::se3_mul(ft.evalPT, Ti, T0);
+        for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) o.R0[r * 3 + c] = (float) T0[r * 4 + c]; o.t0[r] = (float) T0[r * 4 + 3]; }
+        o.b0 = (float) (fh.state_zero[7] * 1000.0);
+        o.thMax = fmaxf(fh.frameEnergyTH, ft.frameEnergyTH);
+    }
+    const float K[9] = {fx, 0, cx, 0, fy, cy, 0, 0, 1};
+    float Ki[9];
+    if (KiShared != nullptr) { for (int q = 0; q < 9; q++) Ki[q] = KiShared[q]; }
+    else k_inverse(fx, fy, cx, cy, Ki);
+    float KR[9], KRKi[9], Kt[3];
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) KR[r * 3 + c] = (K[r * 3 + 0] * R[0 * 3 + c] + K[r * 3 + 1] * R[1 * 3 + c]) + K[r * 3 + 2] * R[2 * 3 + c];
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) KRKi[r * 3 + c] = (KR[r * 3 + 0] * Ki[0 * 3 + c] + KR[r * 3 + 1] * Ki[1 * 3 + c]) + KR[r * 3 + 2] * Ki[2 * 3 + c];
+    for (int r = 0; r < 3; r++) Kt[r] = (K[r * 3 + 0] * tt[0] + K[r * 3 + 1] * tt[1]) + K[r * 3 + 2] * tt[2];
+    float a0_, b0_;
+    aff_from_to(expH, expT, aH, bH, aT, bT, a0_, b0_);
+    for (int q = 0; q < 9; q++) o.KRKi[q] = KRKi[q];
+    for (int q = 0; q < 3; q++) o.Kt[q] = Kt[q];
+    o.aff[0] = a0_; o.aff[1] = b0_;
+}
+
+// setPrecalcValues of the step-wise path and of the host entry points: frames' PRE poses, pair precalc (with the linearisation-point part), deltas
+static __device__ __forceinline__ void set_precalc(const BaPtrs &B, const BaDims &D, DevFrame *fr, DevCalib *cal, const float *adH, const float *adT) {
     const int tid = threadIdx.x, F = D.F;
     DevCalib &C = *cal;
-    if (cbF != nullptr) canbreak_partial(fr, F, cbF);
     if (tid < F) {
-        DevFrame &f = fr[tid];
-        double ss[6] = {0.5 * f.state[0], 0.5 * f.state[1], 0.5 * f.state[2], 1.0 * f.state[3], 1.0 * f.state[4], 1.0 * f.state[5]};
-        double E[12];
-        ld::se3_exp(ss, E);
-        ld::se3_mul(E, f.evalPT, f.PRE_w2c);
-        ld::se3_inv(f.PRE_w2c, f.PRE_c2w);
-        for (int i = 0; i < 8; i++) { f.delta[i] = f.state[i] - f.state_zero[i]; f.delta_prior[i] = f.state[i]; }
+        double st[8];
+        for (int i = 0; i < 8; i++) st[i] = fr[tid].state[i];
+        frame_pose(fr[tid], st);
     }
     if (tid == 64) {
-        // CalibHessian::setValue derived floats (CalibHessian.h:71-85)
-        double vs[4] = {50.0 * C.value[0], 50.0 * C.value[1], 50.0 * C.value[2], 50.0 * C.value[3]};
-        for (int i = 0; i < 4; i++) C.sf[i] = (float) vs[i];
-        C.si[0] = 1.0f / C.sf[0]; C.si[1] = 1.0f / C.sf[1]; C.si[2] = -C.sf[2] / C.sf[0]; C.si[3] = -C.sf[3] / C.sf[1];
-        for (int i = 0; i < 4; i++) C.cDeltaF[i] = (float) (C.value[i] - C.value_zero[i]);
+        double v[4];
+        for (int i = 0; i < 4; i++) v[i] = C.value[i];
+        calib_derived(C, v);
     }
     __syncthreads();
-    if (cbF != nullptr && tid == 192) {
-        canbreak_final(B, *cbSt, cbF, cbNID);
-        // un-forced optimize(): end the loop after this iteration (FullSystem.cc:829)
-        if (cbIter >= 0 && B.scalars[3] != 0.0 && cbIter >= cbSt->minOptIterations && (double) cbIter < B.scalars[LD_SC_STOP]) B.scalars[LD_SC_STOP] = (double) cbIter;
-        // tell the host at once which iteration ended the loop (it then enqueues the tail behind the iterations that turn into no-ops
-        // instead of synchronising with the stream first); iterations after the stop return at their first instruction and never get here
-        if (hostStop != nullptr && cbIter >= 0 && (B.scalars[LD_SC_STOP] == (double) cbIter || cbIter == lastIt))
-            __hip_atomic_store(hostStop, cbIter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    for (int i = tid; i < F * F; i += NT) {
-        const int h = i / F, t = i % F;
-        const DevFrame &fh = fr[h], &ft = fr[t];
-        DevPair &o = B.pairs[i];
-        double T[12];
-        ld::se3_mul(ft.PRE_w2c, fh.PRE_c2w, T);
-        float R[9], tt[3];
-        for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) R[r * 3 + c] = (float) T[r * 4 + c]; tt[r] = (float) T[r * 4 + 3]; }
-        // PRE_RTll / PRE_tTll for point activation: only where the host can call it (after set_frames / optimize), not inside GN iterations
-        if (FULL) { float *rt = B.pairRt + (size_t) i * 12; for (int q = 0; q < 9; q++) rt[q] = R[q]; for (int q = 0; q < 3; q++) rt[9 + q] = tt[q]; }
-        if (FULL) {
-            double Ti[12], T0[12];
-            ld::se3_inv(fh.evalPT, Ti);
-            ld::se3_mul(ft.evalPT, Ti, T0);
-            for (int r = 0; r < 3; r++) { for (int c = 0; c < 3; c++) o.R0[r * 3 + c] = (float) T0[r * 4 + c]; o.t0[r] = (float) T0[r * 4 + 3]; }
-            o.b0 = (float) (fh.state_zero[7] * 1000.0);
-            o.thMax = fmaxf(fh.frameEnergyTH, ft.frameEnergyTH);
-        }
-        const float fx = C.sf[0], fy = C.sf[1], cx = C.sf[2], cy = C.sf[3];
-        // K^-1 by Eigen's 3x3 cofactor inverse (float)
-        float K[9] = {fx, 0, cx, 0, fy, cy, 0, 0, 1};
-        float Ki[9];
-        {
-            auto cof = [&](int a, int b) { int a1 = (a + 1) % 3, a2 = (a + 2) % 3, b1 = (b + 1) % 3, b2 = (b + 2) % 3; return K[a1 * 3 + b1] * K[a2 * 3 + b2] - K[a1 * 3 + b2] * K[a2 * 3 + b1]; };
-            float k0 = cof(0, 0), k1 = cof(1, 0), k2 = cof(2, 0);
-            float det = (k0 * K[0] + k1 * K[3]) + k2 * K[6];
-            float invdet = 1.0f / det;
-            Ki[0] = k0 * invdet; Ki[1] = k1 * invdet; Ki[2] = k2 * invdet;
-            Ki[3] = cof(0, 1) * invdet; Ki[4] = cof(1, 1) * invdet; Ki[5] = cof(2, 1) * invdet;
-            Ki[6] = cof(0, 2) * invdet; Ki[7] = cof(1, 2) * invdet; Ki[8] = cof(2, 2) * invdet;
-        }
-        float KR[9];
-        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) KR[r * 3 + c] = (K[r * 3 + 0] * R[0 * 3 + c] + K[r * 3 + 1] * R[1 * 3 + c]) + K[r * 3 + 2] * R[2 * 3 + c];
-        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) o.KRKi[r * 3 + c] = (KR[r * 3 + 0] * Ki[0 * 3 + c] + KR[r * 3 + 1] * Ki[1 * 3 + c]) + KR[r * 3 + 2] * Ki[2 * 3 + c];
-        for (int r = 0; r < 3; r++) o.Kt[r] = (K[r * 3 + 0] * tt[0] + K[r * 3 + 1] * tt[1]) + K[r * 3 + 2] * tt[2];
-        float a0_, b0_;
-        aff_from_to(fh.ab_exposure, ft.ab_exposure, (float) (10.0f * fh.state[6]), (float) (1000.0f * fh.state[7]),
-                    (float) (10.0f * ft.state[6]), (float) (1000.0f * ft.state[7]), a0_, b0_);
-        o.aff[0] = a0_; o.aff[1] = b0_;
-    }
-    // adHTdeltaF[h + t*F] = delta_h^T adHostF + delta_t^T adTargetF  (EnergyFunctional.cc:403-414), one thread per component
+    for (int i = tid; i < F * F; i += NT) pair_record<true>(B, fr, C, F, i);
+    // adHTdeltaF[h + t*F] = delta_h^T adHostF + delta_t^T adTargetF  (EnergyFunctional.cc:403-414), one thread per component; the frames' delta is
+    // state - state_zero in double, stored exactly: converting it is converting the difference
     for (int i = tid; i < F * F * 8; i += NT) {
         const int c = i & 7, pr = i >> 3, h = pr / F, t = pr % F;
         const DevFrame &fh = fr[h], &ft = fr[t];
         const float *AH = adH + (size_t) (h + t * F) * 64, *AT = adT + (size_t) (h + t * F) * 64;
         float s1 = 0, s2 = 0;
 #pragma unroll
-        for (int k = 0; k < 8; k++) s1 += (float) (fh.state[k] - fh.state_zero[k]) * AH[k * 8 + c];
+        for (int k = 0; k < 8; k++) s1 += (float) fh.delta[k] * AH[k * 8 + c];
 #pragma unroll
-        for (int k = 0; k < 8; k++) s2 += (float) (ft.state[k] - ft.state_zero[k]) * AT[k * 8 + c];
+        for (int k = 0; k < 8; k++) s2 += (float) ft.delta[k] * AT[k * 8 + c];
         B.pairs[pr].dp[c] = s1 + s2;
     }
     __syncthreads();
@@ -463,16 +505,23 @@ static __host__ __device__ inline size_t solve_core_lds_doubles(int NB, int n) {
 // GN = true (k_gn_solve): the prologue also mirrors the frames / calibration (and, when they fit, the float
 // adjoints) into LDS and reduces sumNID, so that the whole control step has ONE global-load latency level; the
 // frame / calibration part of backupState + doStepFromBackup is fused into the output pass.
+// LDS copies of the float adjoints: 72 floats per 8 x 8 matrix.  At 64 the column reads of xAd / adHTdeltaF (lane = (pair, column), one row per instruction) put the
+// eight pairs of a wavefront on the same eight banks - an 8-way conflict on each of the 32 reads of an item.  The copies are ordered by pr = h F + t (the order the
+// items walk them in; the global tables are indexed h + F t), so that eight consecutive items always read eight different bank groups
+#define LD_AD_LDS_PITCH 72
 struct SolveIO {
     DevFrame *fr;          // working copy of the frames (global, or the LDS mirror)
     DevCalib *cal;
-    const float *adH, *adT;  // float adjoints [F*F][64] (global, or LDS)
+    const float *adH, *adT;  // float adjoints [F*F][adPitch] (global: 64, or the LDS copies: LD_AD_LDS_PITCH)
+    int adPitch;
     float *ldsAd;          // LDS room for both adjoint tables (GN, may be null)
     double *sRed;          // 16 doubles of LDS scratch
     float sumNID;          // out (GN)
     double lambda;         // GN: LM lambda as passed to solveSystem
     int hasPrior;          // GN: HM / bM present
     const double *redScalars;  // GN, multi-GPU: all-reduced scalar sums (see k_gn_export), nullptr on one GPU
+    const double *sx;          // out (GN): the solution in LDS (steps are its negative)
+    float *sTail;              // out (GN): LDS scratch for gn_tail, 3 x 2 x LD_XFP floats (the panel buffers, free after the factorisation)
     int *waitCtr;              // GN, fused kernel: HFinal / bFinal are complete when *waitCtr reaches waitTarget (nullptr: already complete)
     int waitTarget;
 };
@@ -577,10 +626,10 @@ _Pragma("unroll") \
         for (int u = 0; u < MW; u++) { const int i = tid + u * NT; if (i < F * FW) lF[i] = mw[u]; }
         if (tid < CW) ((unsigned *) io.cal)[tid] = cw;
         if (io.ldsAd != nullptr) {
-            float4 *lh = (float4 *) io.ldsAd, *lt = (float4 *) (io.ldsAd + F * F * 64);
+            float4 *lh = (float4 *) io.ldsAd, *lt = (float4 *) (io.ldsAd + F * F * LD_AD_LDS_PITCH);
 #pragma unroll
-            for (int u = 0; u < 4; u++) { const int i = tid + u * NT; if (i < F * F * 16) { lh[i] = ah[u]; lt[i] = at[u]; } }
-            io.adH = io.ldsAd; io.adT = io.ldsAd + F * F * 64;
+            for (int u = 0; u < 4; u++) { const int i = tid + u * NT, sl = i >> 4, j = ((sl % F) * F + sl / F) * (LD_AD_LDS_PITCH / 4) + (i & 15); if (i < F * F * 16) { lh[j] = ah[u]; lt[j] = at[u]; } }
+            io.adH = io.ldsAd; io.adT = io.ldsAd + F * F * LD_AD_LDS_PITCH; io.adPitch = LD_AD_LDS_PITCH;
         }
         for (int o = 32; o > 0; o >>= 1) { double a_ = __shfl_xor(ns, o, 64), b_ = __shfl_xor(nc, o, 64); ns += a_; nc += b_; }
         if ((tid & 63) == 0) { io.sRed[tid >> 6] = ns; io.sRed[4 + (tid >> 6)] = nc; }
@@ -640,6 +689,14 @@ _Pragma("unroll") \
     if (GN) io.sumNID = (io.redScalars != nullptr) ? (float) io.redScalars[3] / (float) io.redScalars[4]
                                                    : (float) (io.sRed[0] + io.sRed[1] + io.sRed[2] + io.sRed[3]) / (float) (io.sRed[4] + io.sRed[5] + io.sRed[6] + io.sRed[7]);
 
+#if LD_STAMP_ON
+    long long rc_[6] = {0, 0, 0, 0, 0, 0}, rt_ = 0;
+#define RCYC(i, WAITLDS) do { if (WAITLDS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const long long now_ = (long long) __builtin_readcyclecounter(); \
+        rc_[i] += now_ - rt_; rt_ = now_; } while (0)
+    rt_ = (long long) __builtin_readcyclecounter();
+#else
+#define RCYC(i, WAITLDS) do { } while (0)
+#endif
 #pragma nounroll
     for (int k = 0; k < n; k += C) {
         // ---------------- phase 1: LDL^T of the CxC pivot block (replicated in every lane) + this row's multipliers -------
@@ -661,25 +718,30 @@ _Pragma("unroll") \
                 }
 #pragma unroll
             for (int q2 = 0; q2 < C; q2 += 2) { const double2 w = ld2(&sPr[i * CP + q2]); g[q2] = w.x; g[q2 + 1] = w.y; }
+            RCYC(0, true);          // panel in registers
+            // l_r = c[r][q] / d_q once per pivot, every update ONE fma on it, this row's g decoupled from f: 38 fp64 instructions per round.  (Until round 4
+            // every update was written as x -= (product of known values) * inv_q, which puts pivot d_{q+1} one fma behind the reciprocal of d_q but takes
+            // 48 instructions: 25.4 -> 25.7 k GN iterations/s at C3 for the short form, same box - the round is bound by issue, not by the pivot chain.)
 #pragma unroll
             for (int q = 0; q < C; q++) {
                 const double d = c[q][q];
-                double w_[C][C], wg[C];
-#pragma unroll
-                for (int r = q + 1; r < C; r++) {
-#pragma unroll
-                    for (int s_ = q + 1; s_ <= r; s_++) w_[r][s_] = c[r][q] * c[s_][q];
-                    wg[r] = g[q] * c[r][q];
-                }
                 inv[q] = (fabs(d) > TINY) ? fast_rcp(d) : 0.0;
+                double l_[C];
+#pragma unroll
+                for (int r = q + 1; r < C; r++) l_[r] = c[r][q] * inv[q];
 #pragma unroll
                 for (int r = q + 1; r < C; r++) {
 #pragma unroll
-                    for (int s_ = q + 1; s_ <= r; s_++) c[r][s_] = __builtin_fma(-w_[r][s_], inv[q], c[r][s_]);
-                    g[r] = __builtin_fma(-wg[r], inv[q], g[r]);
+                    for (int s_ = q + 1; s_ <= r; s_++) c[r][s_] = __builtin_fma(-l_[r], c[s_][q], c[r][s_]);
+                    g[r] = __builtin_fma(-g[q], l_[r], g[r]);
                 }
-                f[q] = g[q] * inv[q];
             }
+#pragma unroll
+            for (int q = 0; q < C; q++) f[q] = g[q] * inv[q];
+#if LD_STAMP_ON
+            asm volatile("" :: "v"(f[C - 1]), "v"(g[C - 1]));
+#endif
+            RCYC(1, false);         // 4 x 4 block and this row's multipliers issued
             const bool below = (i >= k + C);
             const bool rowOn = below && (i <= n), colOn = below && (i < n);
             if constexpr (MF) {
@@ -714,6 +776,7 @@ _Pragma("unroll") \
             // ---------------- phase 2 on the matrix cores: one v_mfma_f64_16x16x4_f64 per live tile (D -= F_rows G_cols^T) -------------
             // A operand: lane l supplies F[16 ta + (l & 15)][l >> 4], B operand: G[16 tb + (l & 15)][l >> 4] - read back from this
             // wave's own LDS copies (same wave wrote them: no barrier).  Tile columns left of the next panel are finished.
+            RCYC(2, true);          // F, G, L, y, D stored
             const int bDone = (k + C) >> 4, c0 = (k + C) & 15;
             const double *Fw = sPn + wv * 256, *Gw = sPn + 1024 + wv * 256;
             double *sPw = ((k >> 2) & 1) ? sFp : sGp;
@@ -729,7 +792,9 @@ _Pragma("unroll") \
                     for (int r = 0; r < 4; r++) sPw[(16 * mta[s_] + (lane >> 4) + 4 * r) * CP + (lane & 15) - c0] = Dv[s_][r];
                 }
             }
+            RCYC(3, true);          // operands read back, matrix cores, next panel published
             __syncthreads();
+            RCYC(4, false);         // barrier
             continue;
         }
         __syncthreads();
@@ -764,6 +829,9 @@ _Pragma("unroll") \
         __syncthreads();
     }
     if (LD_STAMP_ON && GN && tid == 0) B.energyLog[42] = (double) wall_clock64();
+#if LD_STAMP_ON
+    if (GN && MF && tid == 0) for (int u = 0; u < 5; u++) B.energyLog[53 + u] = (double) rc_[u];
+#endif
 
     // ---------------- back substitution by wave 0: x = L^-T D^+ y ----------------
     if (tid < 64) {
@@ -776,6 +844,9 @@ _Pragma("unroll") \
             for (int kk = 0; kk < 64; kk += 2) { const double2 q = ld2(&sL[lane * (M + 2) + kk]); row[kk] = q.x; row[kk + 1] = q.y; }
             const double d = sD[lane], z = sY[lane];
             double xi = (lane < n && fabs(d) > TINY) ? z * fast_rcp(d) : 0.0;
+            // (tried, round 4: 16-lane blocks, x_k to the lanes of its row by DPP row_newbcast - 2 moves + 1 fma per column, no v_readlane - and the 16
+            // finished values of a block to the lanes below through LDS: bitwise the same x, 2.04 against 1.78 us.  A column is one broadcast + one fp64 fma
+            // on the dependent chain either way, ~50 cycles; the DPP moves wait for the fma like the readlanes do, and the LDS hand-overs come on top.)
 #pragma unroll
             for (int kk = 63; kk >= 1; kk--) { double xk = readlane_f64(xi, kk); xi = __builtin_fma(-row[kk], xk, xi); }
             if (lane < n) sx[lane] = xi * sSc[lane];
@@ -827,23 +898,11 @@ _Pragma("unroll") \
     if (LD_STAMP_ON && GN && tid == 0) B.energyLog[43] = (double) wall_clock64();
     // ---------------- outputs: x, steps, xAd ----------------
     DevFrame *fr = io.fr;
-    bool bad = false;
-    for (int i = tid; i < n; i += NT) { B.x[i] = sx[i]; if (!isfinite(sx[i])) bad = true; }
-    if (bad) B.scalars[4] = 1.0;
-    if (tid < 4) {
-        const double st = -sx[tid];
-        io.cal->step[tid] = st; B.xc[tid] = (float) sx[tid];
-        if (GN) { const double bk = io.cal->value[tid]; io.cal->value_backup[tid] = bk; io.cal->value[tid] = bk + st * (double) 1.0f; }
-    }
-    for (int i = tid; i < F * 10; i += NT) {
-        int f = i / 10, a = i % 10;
-        const double st = (a < 8) ? -sx[4 + 8 * f + a] : 0.0;
-        fr[f].step[a] = st;
-        if (GN) { const double bk = fr[f].state[a]; fr[f].state_backup[a] = bk; fr[f].state[a] = bk + st; }     // backupState + doStepFromBackup
-    }
-    for (int i = tid; i < F * F * 8; i += NT) {
+    io.sx = sx;
+    auto x_ad = [&](int i) {
         int c = i & 7, pr = i >> 3, h = pr / F, t = pr % F;
-        const float *AH = io.adH + (size_t) (h + F * t) * 64, *AT = io.adT + (size_t) (h + F * t) * 64;
+        const int sl = (io.adPitch == 64) ? h + F * t : pr;          // the LDS copies are ordered by pr = h F + t
+        const float *AH = io.adH + (size_t) sl * io.adPitch, *AT = io.adT + (size_t) sl * io.adPitch;
         float ah[8], at[8];
 #pragma unroll
         for (int kk = 0; kk < 8; kk++) { ah[kk] = AH[kk * 8 + c]; at[kk] = AT[kk * 8 + c]; }
@@ -853,7 +912,21 @@ _Pragma("unroll") \
 #pragma unroll
         for (int kk = 0; kk < 8; kk++) s2 += (float) sx[4 + 8 * t + kk] * at[kk];
         B.xAd[i] = s1 + s2;
+    };
+    if constexpr (GN) { io.sTail = (float *) sFp; return; }          // the panel buffers are free now; gn_tail does the rest
+    bool bad = false;
+    for (int i = tid; i < n; i += NT) { B.x[i] = sx[i]; if (!isfinite(sx[i])) bad = true; }
+    if (bad) B.scalars[4] = 1.0;
+    if (tid < 4) {
+        const double st = -sx[tid];
+        io.cal->step[tid] = st; B.xc[tid] = (float) sx[tid];
     }
+    for (int i = tid; i < F * 10; i += NT) {
+        int f = i / 10, a = i % 10;
+        const double st = (a < 8) ? -sx[4 + 8 * f + a] : 0.0;
+        fr[f].step[a] = st;
+    }
+    for (int i = tid; i < F * F * 8; i += NT) x_ad(i);
     __syncthreads();
 }
 
@@ -969,7 +1042,7 @@ __global__ __launch_bounds__(NT) void k_solve(BaPtrs B, BaDims D, ResSet S, ldso
         // HFinal / bFinal were assembled by k_gather (ba_reduce.hip)
         if (!(fl & SK_FROMREDUCED)) res_counts(B, D, S, sW);
         SolveIO io;
-        io.fr = B.frames; io.cal = B.calib; io.adH = B.adHostF; io.adT = B.adTargetF; io.ldsAd = nullptr; io.sRed = sW; io.sumNID = 0; io.lambda = A.lambda; io.hasPrior = A.hasPrior; io.redScalars = nullptr;
+        io.fr = B.frames; io.cal = B.calib; io.adH = B.adHostF; io.adT = B.adTargetF; io.adPitch = 64; io.ldsAd = nullptr; io.sRed = sW; io.sumNID = 0; io.lambda = A.lambda; io.hasPrior = A.hasPrior; io.redScalars = nullptr;
         solve_core_dispatch<false>(B, D, S, St, A.iteration, sm, io);
     }
     if (fl & SK_BACKUP) frames_backup(B.frames, B.calib, F);
@@ -979,7 +1052,7 @@ __global__ __launch_bounds__(NT) void k_solve(BaPtrs B, BaDims D, ResSet S, ldso
         if (tid == 0) for (int i = 0; i < 4; i++) B.calib->value[i] = B.calib->value_backup[i];
         __syncthreads();
     }
-    if (fl & SK_PRECALC) set_precalc<true>(B, D, B.frames, B.calib, B.adHostF, B.adTargetF);
+    if (fl & SK_PRECALC) set_precalc(B, D, B.frames, B.calib, B.adHostF, B.adTargetF);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -990,6 +1063,122 @@ __global__ __launch_bounds__(NT) void k_solve(BaPtrs B, BaDims D, ResSet S, ldso
 // The two blocks touch disjoint data: block 0 never reads frameEnergyTH (the linearize kernel takes the pair
 // maximum itself) and skips that word in its write-back; canbreak's sumNID is recomputed from the chunk sums.
 // ---------------------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------------------
+// gn_tail - everything of the control step behind the back substitution: x, xAd, backupState + doStepFromBackup (frames, calibration), canbreak,
+// setPrecalcValues (frame poses, pair records, adHTdeltaF).  One workgroup on the critical path of the iteration, so it is laid out by WAVEFRONT around the
+// one chain that is long:  new states -> frame poses (a lane per frame, a few hundred dependent fp64 instructions) -> pair records (a lane per pair).
+// Wave 0 runs that chain and nothing else: it forms the new states in registers, touches no memory another wave writes, and (windows of up to 8 frames:
+// all pairs fit its lanes) needs no workgroup barrier between the poses and the pair records.  Waves 1..3 do the wide work beside it: float copies of x
+// and of the new deltas (private to each wave), per item (pair, column) xAd AND adHTdeltaF in one pass over the adjoint columns (the same loads; waves 1
+// and 2), the remainder of the items and canbreak (wave 3), the frames' step / state_backup (wave 2).  The OLD states stay in the working copies - every
+// wave reads them - and the new ones reach memory through delta_prior (see the end).  One workgroup barrier, at the end.
+// Device stamps, C3, us after the back substitution - before: outputs 1.2, poses 2.0 - 2.8, pair records 1.0, adHTdeltaF 0.85 = 5.6 (the poses stored through
+// LDS between dependent products, canbreak walked four divergent branches with LDS round trips inside, and every wave walked every phase); now: see DESIGN 5.
+// ---------------------------------------------------------------------------------------------------------
+#define LD_XFP (8 * LD_MAXF + 8)
+static __device__ __forceinline__ void gn_tail(const BaPtrs &B, const BaDims &D, DevFrame *fr, DevCalib *cal, const SolveIO &io, const ldso_settings_t &St, float *cbF,
+                                               int cbIter, int *hostStop, int lastIt) {
+    const int tid = threadIdx.x, F = D.F, n = D.n, wave = tid >> 6, lane = tid & 63;
+    constexpr int W2 = 128;          // waves 1 and 2 walk the items; wave 3 takes what is left of them, and canbreak
+    const double *sx = io.sx;
+    DevCalib &C = *cal;
+    float *sKi = cbF + 8;          // 9 floats of the scratch behind the canbreak sums
+    const bool split = F * F <= 64;          // one wavefront holds all pairs
+    const int items = F * F * 8, nMain = (items / W2) * W2;
+    float *xf = io.sTail + (wave > 0 ? wave - 1 : 0) * 2 * LD_XFP, *df = xf + LD_XFP;
+    const float *adH = io.adH, *adT = io.adT;
+    const int adPitch = io.adPitch;
+    // xAd[i] = x_h^T adHostF[:, c] + x_t^T adTargetF[:, c] (EnergyFunctional.cc:491-516), adHTdeltaF likewise from the deltas (:403-414)
+    auto item = [&](int i) {
+        const int c = i & 7, pr = i >> 3, h = pr / F, t = pr % F;
+        const int sl = (adPitch == 64) ? h + F * t : pr;          // the LDS copies are ordered by pr = h F + t
+        const float *AH = adH + (size_t) sl * adPitch, *AT = adT + (size_t) sl * adPitch;
+        float ah[8], at[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { ah[k] = AH[k * 8 + c]; at[k] = AT[k * 8 + c]; }
+        const float4 xh0 = *(const float4 *) (xf + 4 + 8 * h), xh1 = *(const float4 *) (xf + 8 + 8 * h), xt0 = *(const float4 *) (xf + 4 + 8 * t), xt1 = *(const float4 *) (xf + 8 + 8 * t);
+        const float4 dh0 = *(const float4 *) (df + 4 + 8 * h), dh1 = *(const float4 *) (df + 8 + 8 * h), dt0 = *(const float4 *) (df + 4 + 8 * t), dt1 = *(const float4 *) (df + 8 + 8 * t);
+        const float xh[8] = {xh0.x, xh0.y, xh0.z, xh0.w, xh1.x, xh1.y, xh1.z, xh1.w}, xt[8] = {xt0.x, xt0.y, xt0.z, xt0.w, xt1.x, xt1.y, xt1.z, xt1.w};
+        const float dh[8] = {dh0.x, dh0.y, dh0.z, dh0.w, dh1.x, dh1.y, dh1.z, dh1.w}, dt[8] = {dt0.x, dt0.y, dt0.z, dt0.w, dt1.x, dt1.y, dt1.z, dt1.w};
+        float s1 = 0, s2 = 0, d1 = 0, d2 = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) { s1 += xh[k] * ah[k]; d1 += dh[k] * ah[k]; }
+#pragma unroll
+        for (int k = 0; k < 8; k++) { s2 += xt[k] * at[k]; d2 += dt[k] * at[k]; }
+        B.xAd[i] = s1 + s2;
+        B.pairs[pr].dp[c] = d1 + d2;
+    };
+    if (wave == 0) {
+        if (lane < F) {
+            double st[8];
+#pragma unroll
+            for (int a = 0; a < 8; a++) st[a] = fr[lane].state[a] + (-sx[4 + 8 * lane + a]);          // doStepFromBackup: state = backup + step, step = -x
+            frame_pose(fr[lane], st);
+        } else if (lane == 32) {
+            double v[4];
+#pragma unroll
+            for (int a = 0; a < 4; a++) {          // backupState + doStepFromBackup of the calibration: nobody else touches it
+                const double stp = -sx[a], bk = C.value[a];
+                v[a] = bk + stp * (double) 1.0f;
+                C.step[a] = stp; C.value_backup[a] = bk; C.value[a] = v[a]; B.xc[a] = (float) sx[a];
+            }
+            calib_derived(C, v);
+            float Ki[9];
+            k_inverse((float) (50.0 * v[0]), (float) (50.0 * v[1]), (float) (50.0 * v[2]), (float) (50.0 * v[3]), Ki);          // = C.sf
+            for (int q = 0; q < 9; q++) sKi[q] = Ki[q];
+        }
+        if (LD_STAMP_ON && tid == 0) B.energyLog[59] = (double) wall_clock64();          // frame poses done
+        if (split) {
+            // poses, calibration floats and pair records all belong to this wave: no workgroup barrier between them
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (lane < F * F) pair_record<false>(B, fr, C, F, lane, sKi);
+        }
+        if (LD_STAMP_ON && tid == 0) B.energyLog[62] = (double) wall_clock64();          // wave 0 at the barrier
+    } else {
+        bool bad = false;
+        for (int i = lane; i < n; i += 64) {
+            const double x = sx[i];
+            double d = 0.0;
+            if (i >= 4) {
+                const int f = (i - 4) >> 3, a = (i - 4) & 7;
+                const double bk = fr[f].state[a];
+                d = (bk + (-x)) - fr[f].state_zero[a];
+                if (wave == 2) { fr[f].step[a] = -x; fr[f].state_backup[a] = bk; }          // backupState, the step: written only, by nobody else
+            }
+            xf[i] = (float) x; df[i] = (float) d;
+            if (wave == 1) { B.x[i] = x; if (!isfinite(x)) bad = true; }
+        }
+        if (wave == 2 && lane < 2 * F) { const int f = lane >> 1, a = 8 + (lane & 1); fr[f].step[a] = 0.0; fr[f].state_backup[a] = fr[f].state[a]; }
+        if (bad) B.scalars[4] = 1.0;
+        // the copies are private to the wave; LDS executes a wavefront's accesses in order
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (wave < 3) for (int i = tid - 64; i < nMain; i += W2) item(i);
+        if (wave == 3) {
+            for (int i = nMain + lane; i < items; i += 64) item(i);
+            if (lane < 4) canbreak_partial_x(sx, F, cbF, lane);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (lane == 0) {
+                canbreak_final(B, St, cbF, io.sumNID);
+                // un-forced optimize(): end the loop after this iteration (FullSystem.cc:829)
+                if (cbIter >= 0 && B.scalars[3] != 0.0 && cbIter >= St.minOptIterations && (double) cbIter < B.scalars[LD_SC_STOP]) B.scalars[LD_SC_STOP] = (double) cbIter;
+                // tell the host at once which iteration ended the loop (it then enqueues the tail behind the iterations that turn into no-ops
+                // instead of synchronising with the stream first); iterations after the stop return at their first instruction and never get here
+                if (hostStop != nullptr && cbIter >= 0 && (B.scalars[LD_SC_STOP] == (double) cbIter || cbIter == lastIt))
+                    __hip_atomic_store(hostStop, cbIter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            if (LD_STAMP_ON && lane == 0) B.energyLog[63] = (double) wall_clock64();          // wave 3 at the barrier
+        }
+        if (LD_STAMP_ON && tid == 64) B.energyLog[58] = (double) wall_clock64();          // wave 1 at the barrier
+    }
+    if (!split) {
+        __syncthreads();
+        for (int i = tid; i < F * F; i += NT) pair_record<false>(B, fr, C, F, i, sKi);
+    }
+    // The frames' NEW states are in delta_prior (= state, setPrecalcValues); the state fields of the working copies still hold the old ones - they were
+    // read by every wave up to here.  The caller's write-back of the copies takes state[0..7] from delta_prior (gn_solve_body).
+    __syncthreads();
+}
+
 template <bool WAIT>
 static __device__ __forceinline__ void gn_solve_body(const BaPtrs &B, const BaDims &D, const ResSet &S, const ldso_settings_t &St, const SolveArgs &A, const int role) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -1024,18 +1213,22 @@ static __device__ __forceinline__ void gn_solve_body(const BaPtrs &B, const BaDi
     DevCalib *sCal = (DevCalib *) (sFr + F);
     if (LD_STAMP_ON && tid == 0) B.energyLog[39] = (double) t0_;
     SolveIO io;
-    io.fr = sFr; io.cal = sCal; io.adH = B.adHostF; io.adT = B.adTargetF; io.sRed = sW; io.sumNID = 0; io.lambda = A.lambda; io.hasPrior = A.hasPrior; io.redScalars = A.reduceIn; io.waitCtr = A.waitCtr; io.waitTarget = A.waitTarget;
+    io.fr = sFr; io.cal = sCal; io.adH = B.adHostF; io.adT = B.adTargetF; io.adPitch = 64; io.sRed = sW; io.sumNID = 0; io.lambda = A.lambda; io.hasPrior = A.hasPrior; io.redScalars = A.reduceIn; io.waitCtr = A.waitCtr; io.waitTarget = A.waitTarget;
     io.ldsAd = (F <= 8) ? (float *) (sCal + 1) : nullptr;
     solve_core_dispatch<true, WAIT>(B, D, S, St, A.iteration, sm, io);      // + mirrors, backupState, doStepFromBackup
     GSTAMP(4);
     GSTAMP(5);
-    set_precalc<false>(B, D, sFr, sCal, io.adH, io.adT, &St, (float *) (sW + 8), io.sumNID, A.itCheck, A.hostStop, A.lastIt);      // + canbreak of doStepFromBackup
+    gn_tail(B, D, sFr, sCal, io, St, (float *) (sW + 8), A.itCheck, A.hostStop, A.lastIt);      // x, xAd, backupState + doStepFromBackup + canbreak, setPrecalcValues
     GSTAMP(6);
     // write the mirrors back (all but frameEnergyTH, which block 1 owns)
     {
         unsigned *gF = (unsigned *) B.frames; const unsigned *lF = (const unsigned *) sFr;
         const int W = (int) (sizeof(DevFrame) / 4), skip = (int) (offsetof(DevFrame, frameEnergyTH) / 4);
-        for (int i = tid; i < F * W; i += NT) if (i % W != skip) gF[i] = lF[i];
+        const int s0 = (int) (offsetof(DevFrame, state) / 4), dp0 = (int) (offsetof(DevFrame, delta_prior) / 4);
+        for (int i = tid; i < F * W; i += NT) {
+            const int w = i % W;
+            if (w != skip) gF[i] = lF[(w >= s0 && w < s0 + 16) ? i - s0 + dp0 : i];          // doStepFromBackup: state[0..7] = the new states (gn_tail)
+        }
         unsigned *gC = (unsigned *) B.calib; const unsigned *lC = (const unsigned *) sCal;
         for (int i = tid; i < (int) (sizeof(DevCalib) / 4); i += NT) gC[i] = lC[i];
     }
@@ -1141,7 +1334,7 @@ hipError_t ba_launch_reduce_batch(const BatchItem *d_items, int nWin, int totalB
 
 // Dmax: the window of the batch with the most frames (LDS of the control step)
 hipError_t ba_launch_gn_solve_batch(const BatchItem *d_items, int nWin, const BaDims &Dmax, int cur, const ldso_settings_t &St, int iteration, double lambda, hipStream_t st) {
-    size_t mirror = (size_t) Dmax.F * sizeof(DevFrame) + sizeof(DevCalib) + (Dmax.F <= 8 ? (size_t) Dmax.F * Dmax.F * 128 * sizeof(float) : 0), stats = 64 * sizeof(double) + (256 + 8) * sizeof(int) + TH_CAP * sizeof(float);
+    size_t mirror = (size_t) Dmax.F * sizeof(DevFrame) + sizeof(DevCalib) + (Dmax.F <= 8 ? (size_t) Dmax.F * Dmax.F * 2 * LD_AD_LDS_PITCH * sizeof(float) : 0), stats = 64 * sizeof(double) + (256 + 8) * sizeof(int) + TH_CAP * sizeof(float);
     const int n = Dmax.n, NBsel = (n + 1 <= 64) ? 4 : (n + 1 <= 112) ? 7 : 9;
     size_t lds0 = solve_core_lds_doubles(NBsel, n) * sizeof(double) + 64 * sizeof(double) + mirror + 64;
     size_t lds = lds0 > stats + 64 ? lds0 : stats + 64;
@@ -1295,7 +1488,7 @@ hipError_t ba_launch_solve(const BaPtrs &B, const BaDims &D, const ResSet &S, co
 }
 
 hipError_t ba_launch_gn_solve(const BaPtrs &B, const BaDims &D, const ResSet &S, const ldso_settings_t &St, const SolveArgs &A, hipStream_t st) {
-    size_t mirror = (size_t) D.F * sizeof(DevFrame) + sizeof(DevCalib) + (D.F <= 8 ? (size_t) D.F * D.F * 128 * sizeof(float) : 0), stats = 64 * sizeof(double) + (256 + 8) * sizeof(int) + TH_CAP * sizeof(float);
+    size_t mirror = (size_t) D.F * sizeof(DevFrame) + sizeof(DevCalib) + (D.F <= 8 ? (size_t) D.F * D.F * 2 * LD_AD_LDS_PITCH * sizeof(float) : 0), stats = 64 * sizeof(double) + (256 + 8) * sizeof(int) + TH_CAP * sizeof(float);
     size_t lds0 = solve_lds_common(D) + 64 * sizeof(double) + mirror + 64;      // block 0
     size_t lds = lds0 > stats + 64 ? lds0 : stats + 64;                         // block 1 aliases the base
     if (lds > 48 * 1024) hipFuncSetAttribute((const void *) k_gn_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
@@ -1308,7 +1501,7 @@ hipError_t ba_launch_reduce_solve(const BaPtrs &B, const BaDims &D, const ResSet
                                   int atomicMode, float calibPrior, double l1, double il, hipStream_t st) {
     const int nT = A.GSP / 16;
     const int nReduce = D.F * D.F * (A.hasL ? 2 : 1) + SCT_KS * nT * (nT + 1) / 2 + 1;
-    size_t mirror = (size_t) D.F * sizeof(DevFrame) + sizeof(DevCalib) + (D.F <= 8 ? (size_t) D.F * D.F * 128 * sizeof(float) : 0), stats = 64 * sizeof(double) + (256 + 8) * sizeof(int) + TH_CAP * sizeof(float);
+    size_t mirror = (size_t) D.F * sizeof(DevFrame) + sizeof(DevCalib) + (D.F <= 8 ? (size_t) D.F * D.F * 2 * LD_AD_LDS_PITCH * sizeof(float) : 0), stats = 64 * sizeof(double) + (256 + 8) * sizeof(int) + TH_CAP * sizeof(float);
     size_t lds0 = solve_lds_common(D) + 64 * sizeof(double) + mirror + 64;
     size_t lds = lds0 > stats + 64 ? lds0 : stats + 64;
     const size_t ldsR = (size_t) (2 * SCT_SLAB * 16 + SCT_SLAB) * sizeof(float);

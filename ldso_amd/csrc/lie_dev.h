@@ -31,9 +31,12 @@ LD_HD void hat3(const double *w, double *W) {
 LD_HD void se3_exp(const double *xi, double *T) {
     const double *ups = xi, *om = xi + 3;
     double th2 = om[0] * om[0] + om[1] * om[1] + om[2] * om[2];
-    double W[9], W2[9];
-    hat3(om, W);
-    mat3_mul(W, W, W2);
+    // W = hat(omega) and W^2 written out: the terms the 3 x 3 product forms minus its products with the zeros of W (bitwise the same values for finite
+    // input - a compiler may not drop x * 0 - at 9 instead of 45 instructions; this runs on one lane of a latency-bound control step)
+    const double w0 = om[0], w1 = om[1], w2 = om[2];
+    const double W[9] = {0, -w2, w1, w2, 0, -w0, -w1, w0, 0};
+    const double q01 = w1 * w0, q02 = w2 * w0, q12 = w2 * w1;
+    const double W2[9] = {-(w2 * w2 + w1 * w1), q01, q02, q01, -(w2 * w2 + w0 * w0), q12, q02, q12, -(w1 * w1 + w0 * w0)};
     double a, b, c;   // R = I + a W + b W^2 ; V = I + b W + c W^2
     if (th2 < LD_EXP_SERIES_TH2) {
         // a = sin(th)/th, b = (1 - cos th)/th^2, c = (th - sin th)/th^3 are power series in th^2: for |th| < 0.5 nine terms reach 1e-19, with
@@ -49,9 +52,9 @@ LD_HD void se3_exp(const double *xi, double *T) {
     }
     double V[9];
     for (int i = 0; i < 9; i++) {
-        double I = (i == 0 || i == 4 || i == 8) ? 1.0 : 0.0;
-        T[(i / 3) * 4 + (i % 3)] = I + a * W[i] + b * W2[i];
-        V[i] = I + b * W[i] + c * W2[i];
+        const bool diag = (i == 0 || i == 4 || i == 8);          // W is zero there: (1 + a 0) + b W2 = 1 + b W2; elsewhere (0 + a W) + b W2 = a W + b W2
+        T[(i / 3) * 4 + (i % 3)] = diag ? 1.0 + b * W2[i] : a * W[i] + b * W2[i];
+        V[i] = diag ? 1.0 + c * W2[i] : b * W[i] + c * W2[i];
     }
     for (int i = 0; i < 3; i++) T[i * 4 + 3] = V[i * 3 + 0] * ups[0] + V[i * 3 + 1] * ups[1] + V[i * 3 + 2] * ups[2];
 }
