@@ -308,7 +308,7 @@ static __device__ __forceinline__ void canbreak_partial(const DevFrame *fr, int 
 }
 // the same four sums from the solution vector x (step = -x: the squares are the same numbers), by lanes 0..3 of the calling wavefront.  No branch on
 // `which` around the loads: four lanes taking four different branches, each with its own LDS round trips inside the loop over the frames, took 2.8 us
-static __device__ __forceinline__ void canbreak_partial_x(const double *x, int F, float *sF, int which) {
+static __device__ __forceinline__ float canbreak_partial_x(const double *x, int F, int which) {
     const int base = (which == 0) ? 6 : (which == 1) ? 7 : (which == 2) ? 0 : 3;
     const bool three = which >= 2;
     const int o1 = three ? base + 1 : base, o2 = three ? base + 2 : base;
@@ -324,7 +324,7 @@ static __device__ __forceinline__ void canbreak_partial_x(const double *x, int F
         }
     }
     acc /= F;
-    sF[which] = acc;
+    return acc;
 }
 static __device__ __forceinline__ void canbreak_final(const BaPtrs &B, const ldso_settings_t &St, const float *sF, float sumNID) {
     const float sumA = sF[0], sumB = sF[1], sumT = sF[2], sumR = sF[3];
@@ -1070,12 +1070,14 @@ __global__ __launch_bounds__(NT) void k_solve(BaPtrs B, BaDims D, ResSet S, ldso
 // Wave 0 runs that chain and nothing else: it forms the new states in registers, touches no memory another wave writes, and (windows of up to 8 frames:
 // all pairs fit its lanes) needs no workgroup barrier between the poses and the pair records.  Waves 1..3 do the wide work beside it: float copies of x
 // and of the new deltas (private to each wave), per item (pair, column) xAd AND adHTdeltaF in one pass over the adjoint columns (the same loads; waves 1
-// and 2), the remainder of the items and canbreak (wave 3), the frames' step / state_backup (wave 2).  The OLD states stay in the working copies - every
+// and 2), the calibration (its step, the derived floats, K^-1: one lane, handed to wave 0 through a flag), the remainder of the items and canbreak (wave 3),
+// the frames' step / state_backup (wave 2).  The OLD states stay in the working copies - every
 // wave reads them - and the new ones reach memory through delta_prior (see the end).  One workgroup barrier, at the end.
 // Device stamps, C3, us after the back substitution - before: outputs 1.2, poses 2.0 - 2.8, pair records 1.0, adHTdeltaF 0.85 = 5.6 (the poses stored through
 // LDS between dependent products, canbreak walked four divergent branches with LDS round trips inside, and every wave walked every phase); now: see DESIGN 5.
 // ---------------------------------------------------------------------------------------------------------
 #define LD_XFP (8 * LD_MAXF + 8)
+#define LD_TAIL_FLAG 20          // float index behind cbF of the calibration hand-over flag
 static __device__ __forceinline__ void gn_tail(const BaPtrs &B, const BaDims &D, DevFrame *fr, DevCalib *cal, const SolveIO &io, const ldso_settings_t &St, float *cbF,
                                                int cbIter, int *hostStop, int lastIt) {
     const int tid = threadIdx.x, F = D.F, n = D.n, wave = tid >> 6, lane = tid & 63;
@@ -1083,6 +1085,7 @@ static __device__ __forceinline__ void gn_tail(const BaPtrs &B, const BaDims &D,
     const double *sx = io.sx;
     DevCalib &C = *cal;
     float *sKi = cbF + 8;          // 9 floats of the scratch behind the canbreak sums
+    int *sFlag = (int *) (cbF + LD_TAIL_FLAG);          // cleared by the caller before the solve
     const bool split = F * F <= 64;          // one wavefront holds all pairs
     const int items = F * F * 8, nMain = (items / W2) * W2;
     float *xf = io.sTail + (wave > 0 ? wave - 1 : 0) * 2 * LD_XFP, *df = xf + LD_XFP;
@@ -1114,23 +1117,12 @@ static __device__ __forceinline__ void gn_tail(const BaPtrs &B, const BaDims &D,
 #pragma unroll
             for (int a = 0; a < 8; a++) st[a] = fr[lane].state[a] + (-sx[4 + 8 * lane + a]);          // doStepFromBackup: state = backup + step, step = -x
             frame_pose(fr[lane], st);
-        } else if (lane == 32) {
-            double v[4];
-#pragma unroll
-            for (int a = 0; a < 4; a++) {          // backupState + doStepFromBackup of the calibration: nobody else touches it
-                const double stp = -sx[a], bk = C.value[a];
-                v[a] = bk + stp * (double) 1.0f;
-                C.step[a] = stp; C.value_backup[a] = bk; C.value[a] = v[a]; B.xc[a] = (float) sx[a];
-            }
-            calib_derived(C, v);
-            float Ki[9];
-            k_inverse((float) (50.0 * v[0]), (float) (50.0 * v[1]), (float) (50.0 * v[2]), (float) (50.0 * v[3]), Ki);          // = C.sf
-            for (int q = 0; q < 9; q++) sKi[q] = Ki[q];
         }
         if (LD_STAMP_ON && tid == 0) B.energyLog[59] = (double) wall_clock64();          // frame poses done
         if (split) {
             // poses, calibration floats and pair records all belong to this wave: no workgroup barrier between them
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            while (__hip_atomic_load(sFlag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(1);          // wave 3: calibration floats, K^-1 (long done)
             if (lane < F * F) pair_record<false>(B, fr, C, F, lane, sKi);
         }
         if (LD_STAMP_ON && tid == 0) B.energyLog[62] = (double) wall_clock64();          // wave 0 at the barrier
@@ -1154,13 +1146,36 @@ static __device__ __forceinline__ void gn_tail(const BaPtrs &B, const BaDims &D,
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (wave < 3) for (int i = tid - 64; i < nMain; i += W2) item(i);
         if (wave == 3) {
+            // the calibration: backupState + doStepFromBackup, the derived floats, K^-1 for the pair records - one lane, off wave 0's chain (a branch of
+            // its own there ran behind the poses: +0.25 us); handed to wave 0 through a flag in LDS (a wavefront's LDS accesses complete in order)
+            if (lane == 63) {
+                double v[4];
+#pragma unroll
+                for (int a = 0; a < 4; a++) {
+                    const double stp = -sx[a], bk = C.value[a];
+                    v[a] = bk + stp * (double) 1.0f;
+                    C.step[a] = stp; C.value_backup[a] = bk; C.value[a] = v[a]; B.xc[a] = (float) sx[a];
+                }
+                calib_derived(C, v);
+                float Ki[9];
+                k_inverse((float) (50.0 * v[0]), (float) (50.0 * v[1]), (float) (50.0 * v[2]), (float) (50.0 * v[3]), Ki);          // = C.sf
+                for (int q = 0; q < 9; q++) sKi[q] = Ki[q];
+                __hip_atomic_store(sFlag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
             for (int i = nMain + lane; i < items; i += 64) item(i);
-            if (lane < 4) canbreak_partial_x(sx, F, cbF, lane);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // canbreak (FullSystem.cc:1604-1622): the four sums, their square roots and comparisons on four lanes side by side, the conjunction by ballot
+            // (one lane walking sqrt -> compare -> branch four times in a row, behind a round trip through LDS, took as long as the sums)
+            bool ok = true;
+            if (lane < 4) {
+                float v = sqrtf(canbreak_partial_x(sx, F, lane));
+                if (lane == 2) v = v * io.sumNID;
+                ok = v < ((lane == 0) ? 0.0005 : 0.00005) * St.thOptIterations;
+            }
+            const bool cb = (__ballot(ok) & 0xFull) == 0xFull;
             if (lane == 0) {
-                canbreak_final(B, St, cbF, io.sumNID);
+                B.scalars[3] = cb ? 1.0 : 0.0;
                 // un-forced optimize(): end the loop after this iteration (FullSystem.cc:829)
-                if (cbIter >= 0 && B.scalars[3] != 0.0 && cbIter >= St.minOptIterations && (double) cbIter < B.scalars[LD_SC_STOP]) B.scalars[LD_SC_STOP] = (double) cbIter;
+                if (cbIter >= 0 && cb && cbIter >= St.minOptIterations && (double) cbIter < B.scalars[LD_SC_STOP]) B.scalars[LD_SC_STOP] = (double) cbIter;
                 // tell the host at once which iteration ended the loop (it then enqueues the tail behind the iterations that turn into no-ops
                 // instead of synchronising with the stream first); iterations after the stop return at their first instruction and never get here
                 if (hostStop != nullptr && cbIter >= 0 && (B.scalars[LD_SC_STOP] == (double) cbIter || cbIter == lastIt))
@@ -1215,7 +1230,8 @@ static __device__ __forceinline__ void gn_solve_body(const BaPtrs &B, const BaDi
     SolveIO io;
     io.fr = sFr; io.cal = sCal; io.adH = B.adHostF; io.adT = B.adTargetF; io.adPitch = 64; io.sRed = sW; io.sumNID = 0; io.lambda = A.lambda; io.hasPrior = A.hasPrior; io.redScalars = A.reduceIn; io.waitCtr = A.waitCtr; io.waitTarget = A.waitTarget;
     io.ldsAd = (F <= 8) ? (float *) (sCal + 1) : nullptr;
-    solve_core_dispatch<true, WAIT>(B, D, S, St, A.iteration, sm, io);      // + mirrors, backupState, doStepFromBackup
+    if (tid == 0) *(int *) ((float *) (sW + 8) + LD_TAIL_FLAG) = 0;          // gn_tail's hand-over flag (the solve's barriers publish it)
+    solve_core_dispatch<true, WAIT>(B, D, S, St, A.iteration, sm, io);      // + mirrors
     GSTAMP(4);
     GSTAMP(5);
     gn_tail(B, D, sFr, sCal, io, St, (float *) (sW + 8), A.itCheck, A.hostStop, A.lastIt);      // x, xAd, backupState + doStepFromBackup + canbreak, setPrecalcValues
