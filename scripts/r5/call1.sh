@@ -14,3 +14,5 @@ done
 echo "stamps, main:";   LDSO_HIP_LIB=$ROOT/ldso_amd/libldso_hip_trstamps.so timeout 120 python scripts/bench_tracker.py 2>&1 | grep "tr stamps" | tail -3
 echo "stamps, trlead:"; LDSO_HIP_LIB=$ROOT/ldso_amd/libldso_hip_trlead_stamps.so timeout 120 python scripts/bench_tracker.py 2>&1 | grep "tr stamps" | tail -3
 } 2>&1 | tee gpurun_out/r5_call1.log
+# HIP graph of 300 GN iterations against the same launches enqueued one by one (C3)
+timeout 200 python scripts/r5/graph_gn.py C3 300 2>&1 | tail -4 | tee -a gpurun_out/r5_call1.log
