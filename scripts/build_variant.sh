@@ -7,7 +7,7 @@ set -e
 cd "$(dirname "$0")/.."
 python -m ldso_amd.build > /dev/null
 NAME=$1; SRC=$2; EXTRA=$3; FROM=${4:-ldso_amd/csrc/$SRC}
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-result -Ildso_amd/csrc -Iinclude $EXTRA -c "$FROM" -o /tmp/variant_$NAME.o
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-result -Wno-unused-value -Ildso_amd/csrc -Iinclude $EXTRA -c "$FROM" -o /tmp/variant_$NAME.o
 OBJS=$(ls ldso_amd/_obj/*.o | grep -v "/$SRC.o")
 hipcc --offload-arch=gfx950 -shared -fPIC $OBJS /tmp/variant_$NAME.o -o ldso_amd/libldso_hip_$NAME.so
 echo ldso_amd/libldso_hip_$NAME.so

@@ -9,3 +9,10 @@ git show next/tracker-leader:ldso_amd/csrc/tracker.hip > /tmp/tracker_lead.hip
 bash scripts/build_variant.sh trlead tracker.hip "" /tmp/tracker_lead.hip
 bash scripts/build_variant.sh trstamps tracker.hip "-DLDSO_STAMPS"
 bash scripts/build_variant.sh trlead_stamps tracker.hip "-DLDSO_STAMPS" /tmp/tracker_lead.hip
+# the factorisation switches of branch next/solve-variants (ba_solve.hip): base = the branch with both switches off (= main's code, scheduled slightly differently)
+git show next/solve-variants:ldso_amd/csrc/ba_solve.hip > /tmp/ba_solve_sv.hip
+bash scripts/build_variant.sh sv_base ba_solve.hip "" /tmp/ba_solve_sv.hip
+bash scripts/build_variant.sh sv_keeper3 ba_solve.hip "-DLD_KEEPER_WAVE=3" /tmp/ba_solve_sv.hip
+bash scripts/build_variant.sh sv_skip ba_solve.hip "-DLD_P1_SKIP=1" /tmp/ba_solve_sv.hip
+bash scripts/build_variant.sh sv_keeper3skip ba_solve.hip "-DLD_KEEPER_WAVE=3 -DLD_P1_SKIP=1" /tmp/ba_solve_sv.hip
+bash scripts/build_variant.sh sv_keeper2skip ba_solve.hip "-DLD_KEEPER_WAVE=2 -DLD_P1_SKIP=1" /tmp/ba_solve_sv.hip
