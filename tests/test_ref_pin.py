@@ -104,6 +104,21 @@ def test_full_size_c3_bit_exact():
     _stage(synth.add_synthetic_prior(copy.deepcopy(get_window("C3"))))
 
 
+@pytest.mark.parametrize("F,P,iteration", [(9, 500, 0), (12, 600, 0), (12, 600, 2)])
+def test_stage_bit_exact_two_slot_groups(F, P, iteration):
+    """F > 8: two slot groups, 144-column Schur rows, the (8F+4)-wide system the 100 x 100 factorisation serves (C5's code path)
+    - AccumulatedTopHessian.cc:193-255 / AccumulatedSCHessian.cc:53-119 stitched over nframes^2 > 64 pairs, EF.cc:240-351 at n = 76 / 100;
+    with the marginalisation prior, at iteration 0 and at an orthogonalised iteration."""
+    w = synth.add_synthetic_prior(synth.make_config("small", F=F, P=P))
+    assert w.F == F
+    _stage(w, iteration=iteration, x_tol=1e-10 if iteration >= 2 else 0.0)
+
+
+def test_full_size_c4_bit_exact():
+    """BASELINE configs[3]'s window (7 KF x 3000 pt, 1232 x 368, KITTI intrinsics) with the prior."""
+    _stage(synth.add_synthetic_prior(copy.deepcopy(get_window("C4"))))
+
+
 def test_marginalization_bit_exact(small):
     """flagPointsForRemoval's relinearise + fixLinearizationF (Residuals.cc:216-242), marginalizePointsF (EF.cc:165-222, addPoint<2>)
     and marginalizeFrame (EF.cc:72-151) after three GN iterations of the oracle; the reference graph is rebuilt from the oracle's
