@@ -52,6 +52,31 @@ def committed_profile(config, what):
     return None, None
 
 
+def committed_per_kernel(config):
+    """{short kernel name: {"rocprofv3_us", "hbm_bytes_pmc"}} of the GN iteration's kernels from the latest committed profiles of this config."""
+    import csv, glob
+    out = {}
+    try:
+        cand = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_bench_{config}_kernel_stats*.csv")))
+        if cand:
+            for row in csv.DictReader(open(cand[-1])):
+                nm = row["Name"].replace("void ", "").split("(")[0]
+                if nm.startswith(("k_linearize_one", "k_reduce_solve", "k_gn_solve", "k_reduce")) and int(row["Calls"]) > 100:
+                    out.setdefault(nm, {})["rocprofv3_us"] = round(float(row["AverageNs"]) / 1e3, 3)
+                    out[nm]["rocprofv3_profile"] = os.path.relpath(cand[-1], ROOT)
+        cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json")), key=lambda f: os.path.basename(f)[:3])
+        for fn in reversed(cand):
+            pj = json.load(open(fn))
+            if pj.get("config", "C3") == config:
+                for kname, kv in pj["kernels"].items():
+                    if kname in out and "hbm_bytes_per_launch_corrected" in kv:
+                        out[kname]["hbm_bytes_pmc"] = kv["hbm_bytes_per_launch_corrected"]; out[kname]["pmc_profile"] = os.path.relpath(fn, ROOT)
+                break
+    except Exception:
+        pass
+    return out
+
+
 def transplant(win, frames, points, residuals):
     """The window with the evaluation state a GPU handle holds (frames, calibration, inverse depths, residual states)."""
     import copy
@@ -275,6 +300,23 @@ def measure(args, config, rank, local_rank, world, dist, steps, warmup, min_time
             ba.sync(); fence()
         parity = parity_check_dist(win, ba, rank, world, dist, pb, pe, stream, local_rank)
     ba.close()
+    # the WHOLE step against the roofline (436 R + 112 P + 8 n^2 algorithmic bytes per GN iteration over the driver-timed ms_per_step), and every
+    # kernel of the iteration with its own bytes and time: k_linearize is the HBM-side kernel `frac` grades, the control kernel is where the time goes
+    n_sys = 8 * F + 4
+    step_bytes = alg_bytes + 8 * n_sys * n_sys
+    step_GBps = step_bytes / (dt / steps) / 1e9
+    comm = committed_per_kernel(config) if single else {}
+    per_kernel = []
+    for nm, kt in ktimes.items():
+        if kt["launches"] == 0:
+            continue
+        live = max(kt["avg_us"] - ev_ms * 1e3, 0.0)
+        kb = alg_bytes if nm == "k_linearize" else (8 * n_sys * n_sys if nm in ("k_reduce_solve", "k_gn_solve") else 0)
+        cm = next((v for k_, v in comm.items() if (k_.startswith("k_linearize_one") if nm == "k_linearize" else k_ == nm)), {})
+        per_kernel.append({"name": nm, "live_us_in_pipeline": round(live, 3), "rocprofv3_us_committed": cm.get("rocprofv3_us"),
+                           "algorithmic_bytes": kb, "hbm_bytes_pmc_committed": cm.get("hbm_bytes_pmc"),
+                           "share_of_step": round(live / (dt / steps * 1e6), 3),
+                           "frac_of_8TBps": round(kb / (max(live, cm.get("rocprofv3_us") or 0.0) * 1e-6) / 8e12, 5) if live > 0 else None})
     return {
         "win": win,
         "value": round(steps / dt, 2),                       # median of the timed blocks of exactly `steps` iterations
@@ -289,7 +331,8 @@ def measure(args, config, rank, local_rank, world, dist, steps, warmup, min_time
                      "achieved_live": round(achieved_live, 2), "frac_live": round(achieved_live / 8000.0, 5), "avg_launch_us_live": round(lin_live_us, 3),
                      "avg_launch_us_back_to_back_100": round(lin_b2b, 3), "avg_launch_us_in_pipeline_events_minus_empty_pair": round(lin_insitu, 3),
                      "rocprofv3_avg_us_committed_profile": rocprof_us, "rocprofv3_profile": rocprof_src,
-                     "step_achieved_GBps": round((alg_bytes + 8 * (8 * F + 4) ** 2) / (dt / steps) / 1e9, 2)},
+                     "step_algorithmic_bytes": step_bytes, "step_achieved_GBps": round(step_GBps, 2), "step_frac": round(step_GBps / 8000.0, 5),
+                     "per_kernel": per_kernel},
         "timed_blocks": len(blocks), "timed_total_ms": round(total * 1e3, 2),
         "ms_per_step_min_max": [round(min(blocks) / steps * 1e3, 5), round(max(blocks) / steps * 1e3, 5)],
         "kernels": ktimes, "state_finite": ok, "parity_vs_oracle": parity,

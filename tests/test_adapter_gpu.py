@@ -21,6 +21,34 @@ def _rel(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
 
 
+def _compare_at_common_state(r_adp, win, tol=1e-5):
+    """Per-residual quantities without the drift between two solvers: a THIRD reference graph is built AT the state the adapter wrote back (frames,
+    calibration, inverse depths, residual states) and the reference's own PointFrameResidual::linearize / applyRes run on it (Residuals.cc:13-214,
+    Residuals.h:70-87).  Whatever GpuBackend::optimize left in the objects for its last linearisation (FullSystem.cc:843: linearizeAll(true) at the
+    final state) must be what the reference computes there - maxima, not medians: a regression of a single residual shows."""
+    fa = r_adp.get_frames(); pa, _ = r_adp.get_points(); ra = r_adp.get_residuals()
+    w2 = copy.deepcopy(win)
+    w2.frames = fa["frames"].copy()
+    w2.calib = w2.calib.copy(); w2.calib["value"] = fa["calib_value"]
+    w2.points = w2.points.copy(); w2.points["idepth"] = pa["idepth"]; w2.points["idepth_zero"] = pa["idepth"]
+    w2.residuals = w2.residuals.copy()
+    w2.residuals["state_state"] = ra["state_state"]; w2.residuals["is_active"] = ra["is_active"]; w2.residuals["state_energy"] = ra["out"]["state_NewEnergy"]
+    r_t = pr.RefWindow(w2)
+    r_t.collect_active(reset_oob=False); r_t.linearize_all(); r_t.apply_res()
+    rt = r_t.get_residuals()
+    live = (ra["alive"] != 0) & (ra["is_active"] != 0) & (ra["is_linearized"] == 0) & (ra["state_state"] == 0) & (rt["state_state"] == 0)
+    assert live.sum() > 0.25 * (win.residuals["is_linearized"] == 0).sum()
+    flipped = int(((ra["state_state"] != rt["state_state"]) & (ra["alive"] != 0) & (ra["is_linearized"] == 0)).sum())
+    observe("adapter_common_state_flipped", flipped, 1e-3 * win.R)
+    e = np.abs(ra["out"]["state_NewEnergy"][live] - rt["out"]["state_NewEnergy"][live]) / np.maximum(rt["out"]["state_NewEnergy"][live], 1.0)
+    observe("adapter_common_state_energy_max", e.max(), tol)
+    j = np.abs(ra["out"]["JpJdF"][live] - rt["out"]["JpJdF"][live]).max(axis=1) / np.maximum(np.abs(rt["out"]["JpJdF"][live]).max(axis=1), 1e-3)
+    observe("adapter_common_state_JpJdF_max", j.max(), tol)
+    c = np.abs(ra["out"]["centerProjectedTo"][live] - rt["out"]["centerProjectedTo"][live]).max()
+    observe("adapter_common_state_centerProjectedTo_px", c, 1e-3)
+    r_t.close()
+
+
 def _compare_written_back(r_ref, r_adp, win, state_tol=2e-4, idepth_tol=1e-4, with_J=True):
     fr, fa = r_ref.get_frames(), r_adp.get_frames()
     assert _rel(fa["frames"]["frameEnergyTH"], fr["frames"]["frameEnergyTH"]) < 1e-4
@@ -64,9 +92,12 @@ def _compare_written_back(r_ref, r_adp, win, state_tol=2e-4, idepth_tol=1e-4, wi
     assert r_adp.counts()[:2] == r_ref.counts()[:2] or abs(r_adp.counts()[0] - r_ref.counts()[0]) <= 2
 
 
-@pytest.mark.parametrize("name,iters", [("small", 6), ("C3", 6)])
-def test_adapter_optimize_equals_reference_optimize(name, iters):
-    win = synth.add_synthetic_prior(copy.deepcopy(get_window(name)))
+@pytest.mark.parametrize("name,iters,over", [("small", 6, {}), ("C3", 6, {}), ("small", 6, dict(F=12, P=600))], ids=["small", "C3", "F12"])
+def test_adapter_optimize_equals_reference_optimize(name, iters, over):
+    """F12: two slot groups, the 100 x 100 factorisation, the separate k_reduce launch - GpuBackend::optimize against the reference's own
+    FullSystem::optimize at F > 8 (EnergyFunctional.cc:240-351, AccumulatedSCHessian.cc:9-119 with nframes^2 = 144 pairs)."""
+    win = synth.add_synthetic_prior(copy.deepcopy(get_window(name, **over)))
+    assert win.F == over.get("F", win.F)
     r_ref, r_adp = pr.RefWindow(win), pr.RefWindow(win)
     r_ref.fs_attach()
     rv_ref, log_ref = r_ref.fs_optimize(iters)
@@ -77,6 +108,7 @@ def test_adapter_optimize_equals_reference_optimize(name, iters):
     assert its == len(log_ref) - 1, "same number of GN iterations executed (canbreak at the same iteration)"
     assert abs(rv - rv_ref) <= 1e-4 * rv_ref
     _compare_written_back(r_ref, r_adp, win)
+    _compare_at_common_state(r_adp, win)
     A.close()
 
 
@@ -94,6 +126,7 @@ def test_adapter_optimize_with_linearized_residuals_and_a_second_call(small):
         # the synthetic mixed window is poorly constrained along the scale gauge (tests/test_ba_gpu.py::test_optimize_mixed_linearized): the two
         # fp64 solvers drift apart by a common factor of ~1e-4 in all inverse depths per call
         _compare_written_back(r_ref, r_adp, win, state_tol=5e-4 * (rnd + 1), idepth_tol=3e-4 * (rnd + 1), with_J=False)
+        _compare_at_common_state(r_adp, win)
     A.close()
 
 
