@@ -532,12 +532,13 @@ __device__ void ldlt8_wave(const double *H /*LDS 64, row major*/, const double *
 }
 
 __device__ __forceinline__ void tr_vec6(const double *acc, double *rs) {
-    rs[0] = (double) (float) acc[0];
-    rs[1] = (double) (int) acc[1];
-    rs[2] = (double) ((float) acc[2] / ((float) acc[4] + 0.1f));
+    const double a0 = acc[0], a1 = acc[1], a2 = acc[2], a3 = acc[3], a4 = acc[4], a5 = acc[5];          // all loads in front of the first store (both may be LDS)
+    rs[0] = (double) (float) a0;
+    rs[1] = (double) (int) a1;
+    rs[2] = (double) ((float) a2 / ((float) a4 + 0.1f));
     rs[3] = 0;
-    rs[4] = (double) ((float) acc[3] / ((float) acc[4] + 0.1f));
-    rs[5] = (double) ((float) (int) acc[5] / (float) (int) acc[1]);
+    rs[4] = (double) ((float) a3 / ((float) a4 + 0.1f));
+    rs[5] = (double) ((float) (int) a5 / (float) (int) a1);
 }
 
 // The step when an affine parameter is fixed (setting_affineOptModeA/B < 0; CoarseTracker.cc:129-166): rare, single thread, kept out
@@ -694,7 +695,7 @@ __global__ __launch_bounds__(TR_NT) void k_tr_track(const TrParams *__restrict__
     __shared__ float sRt[12];
     __shared__ double sT[12], sTnew[12];
     __shared__ float sAff[2], sAffNew[2];
-    __shared__ double sH[64], sB[8], sNb[8], sInc[8], sResOld[6], sResNew[6];
+    __shared__ double sH[64], sB[8], sNb[8], sInc[8], sResOld[6];
     __shared__ int sCtl[5];          // 0: continue LM loop, 1: accept, 2: abort (return false), 3: iterations, 4: hand-over timed out (error)
 #if LD_STAMP_ON_TR
     // debug builds: device timing of tr_eval per level (dynamically indexed -> scratch memory: never in a product build)
@@ -763,11 +764,19 @@ __global__ __launch_bounds__(TR_NT) void k_tr_track(const TrParams *__restrict__
                 const double sc[8] = {1.0, 1.0, 1.0, 0.5, 0.5, 0.5, 10.0, 1000.0};
                 for (int i = 0; i < 8; i++) { inc[i] *= extrapFac; nrm += inc[i] * inc[i]; incScaled[i] = inc[i] * sc[i]; sum += incScaled[i]; }
                 if (!isfinite(sum)) for (int i = 0; i < 8; i++) incScaled[i] = 0;
-                double E[12];
+                // operands into registers first, results stored at the end: a product written straight into LDS orders every load behind each of its
+                // stores (same type, possibly the same memory) - twelve dependent LDS round trips for one 3 x 4 product on the LM loop's critical lane
+                double E[12], Told[12], Tn[12];
+#pragma unroll
+                for (int i = 0; i < 12; i++) Told[i] = sT[i];
+                const float a0 = sAff[0], b0 = sAff[1];
                 ld::se3_exp(incScaled, E);
-                ld::se3_mul(E, sT, sTnew);
-                sAffNew[0] = sAff[0]; sAffNew[1] = sAff[1];
-                sAffNew[0] += incScaled[6]; sAffNew[1] += incScaled[7];
+                ld::se3_mul(E, Told, Tn);
+                float an = a0, bn = b0;
+                an += incScaled[6]; bn += incScaled[7];
+#pragma unroll
+                for (int i = 0; i < 12; i++) sTnew[i] = Tn[i];
+                sAffNew[0] = an; sAffNew[1] = bn;
                 sCtl[0] = (sqrt(nrm) > 1e-3) ? 1 : 0;          // continue after this iteration?
             }
             __syncthreads();
@@ -785,14 +794,24 @@ __global__ __launch_bounds__(TR_NT) void k_tr_track(const TrParams *__restrict__
             if (accept) tr_hb(sAcc, sH, sB);
             if (tid == 0) {
                 if (accept) {
-                    tr_vec6(sAcc, sResNew);
-                    for (int i = 0; i < 6; i++) sResOld[i] = sResNew[i];
-                    sAff[0] = sAffNew[0]; sAff[1] = sAffNew[1];
-                    for (int i = 0; i < 12; i++) sT[i] = sTnew[i];
-                    sLambda *= 0.5f;
+                    // every load in front of the first store (see the step above)
+                    double acc6[6], rn[6], Tn[12];
+#pragma unroll
+                    for (int i = 0; i < 6; i++) acc6[i] = sAcc[i];
+#pragma unroll
+                    for (int i = 0; i < 12; i++) Tn[i] = sTnew[i];
+                    const float an = sAffNew[0], bn = sAffNew[1], lam = sLambda;
+                    tr_vec6(acc6, rn);
+#pragma unroll
+                    for (int i = 0; i < 6; i++) sResOld[i] = rn[i];
+                    sAff[0] = an; sAff[1] = bn;
+#pragma unroll
+                    for (int i = 0; i < 12; i++) sT[i] = Tn[i];
+                    sLambda = lam * 0.5f;
                 } else {
-                    sLambda *= 4;
-                    if (sLambda < lambdaExtrapolationLimit) sLambda = lambdaExtrapolationLimit;
+                    float lam = sLambda * 4;
+                    if (lam < lambdaExtrapolationLimit) lam = lambdaExtrapolationLimit;
+                    sLambda = lam;
                 }
             }
             __syncthreads();
