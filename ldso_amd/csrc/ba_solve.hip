@@ -758,7 +758,9 @@ _Pragma("unroll") \
                     st2(&sGp[i * CP + q2], colOn ? g[q2] : 0.0, colOn ? g[q2 + 1] : 0.0);
                 }
             }
-            const bool keeper = !MF || wv == 0;          // L, y, D are stored once (MF: by wave 0)
+            // L, y, D are stored once (MF: by wave 3 - it holds ONE tile, wave 0 holds three for the longest and is the wave the round's barrier waits for:
+            // 36.9 -> 35.6 us per iteration at C3, A/B x 3 on one box, profiles/r05_call0_solve_variants.log; skipping phase 1 in waves without a live tile was slower)
+            const bool keeper = !MF || wv == 3;
             if (keeper && i > k && i < n) {       // L[i][k+q] for the rows of the pivot block (q < i-k) and all rows below it
 #pragma unroll
                 for (int q = 0; q < C; q++) if (i > k + q) sL[LIX(i, k + q)] = f[q];
