@@ -103,40 +103,44 @@ GpuBackend::~GpuBackend() {
     for (auto &kv : trackers_) ldso_tr_destroy(kv.second);
     if (tracer_) ldso_trace_destroy(tracer_);
     if (ba_) ldso_ba_destroy(ba_);
-    for (auto &kv : pyr_) if (kv.second.p) ldso_pyr_destroy(kv.second.p);          // after their consumers
+    slotPyr_.clear(); tracerPyr_.reset(); trackerPyr_.clear(); pyr_.clear();          // the pyramids, after their consumers
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------------
 // FrameHessian::dIp on the device (FrameHessian.cc:44-113): built once per frame from channel 0 of dIp[0] (= the irradiance makeImages started from;
 // the device build is bit-identical to the host arrays, tests/test_pyramid_gpu.py), keyed by Frame::id
 // ------------------------------------------------------------------------------------------------------------------------------------
-ldso_pyramid_t *GpuBackend::pyramidOf(const shared_ptr<FrameHessian> &fh) {
+GpuBackend::PyrHolder::~PyrHolder() { if (p) ldso_pyr_destroy(p); }
+
+GpuBackend::PyrRef GpuBackend::pyramidOf(const shared_ptr<FrameHessian> &fh) {
     const unsigned long id = fh->frame->id;
     std::lock_guard<std::mutex> lk(pyrMutex_);
     auto it = pyr_.find(id);
-    if (it != pyr_.end()) { it->second.stamp = ++pyrClock_; return it->second.p; }
-    PyrEntry &e = pyr_[id];
-    e.stamp = ++pyrClock_;
+    if (it != pyr_.end()) return it->second;
+    PyrRef e = std::make_shared<PyrHolder>();
     const size_t n = (size_t) wG[0] * hG[0];
-    e.irradiance.resize(n);
+    e->irradiance.resize(n);
     const Vec3f *src = fh->dIp[0];
-    for (size_t i = 0; i < n; i++) e.irradiance[i] = src[i][0];
-    int rc = ldso_pyr_create(device_, wG[0], hG[0], pyrLevelsUsed, &e.p);
-    if (rc == LDSO_OK) rc = ldso_pyr_make_images(e.p, e.irradiance.data(), nullptr);
-    if (rc != LDSO_OK) { if (e.p) ldso_pyr_destroy(e.p); pyr_.erase(id); throwOn(rc, "ldso_pyr_create / ldso_pyr_make_images"); }
+    for (size_t i = 0; i < n; i++) e->irradiance[i] = src[i][0];
+    int rc = ldso_pyr_create(device_, wG[0], hG[0], pyrLevelsUsed, &e->p);
+    if (rc == LDSO_OK) rc = ldso_pyr_make_images(e->p, e->irradiance.data(), nullptr);
+    throwOn(rc, "ldso_pyr_create / ldso_pyr_make_images");          // e (and its half-built pyramid) goes with the exception
+    pyr_[id] = e;
     pyramidsBuilt++;
-    return e.p;
+    return e;
 }
 
+// Frames that left the window AND that no consumer holds any more (use_count 1 = the map alone).  A consumer can only gain a reference through pyramidOf,
+// i.e. under pyrMutex_: a count of 1 seen here cannot grow behind our back; a consumer letting go concurrently only delays the release by one call.
 void GpuBackend::releasePyramids(FullSystem &fs) {
-    std::lock_guard<std::mutex> lk(pyrMutex_);
     std::set<unsigned long> keep;
     for (auto &fr : fs.frames) keep.insert(fr->id);
-    for (CoarseTracker *tr : {fs.coarseTracker.get(), fs.coarseTracker_forNewKF.get()}) if (tr && tr->lastRef && tr->lastRef->frame) keep.insert(tr->lastRef->frame->id);
-    for (auto &kv : trackers_) { auto it = trackerNewFrameId_.find(kv.second); if (it != trackerNewFrameId_.end()) keep.insert(it->second); }
-    for (auto it = pyr_.begin(); it != pyr_.end();) {
-        const bool recent = it->second.stamp + 4 > pyrClock_;          // the last few frames asked for: a tracker / the tracer may still name them
-        if (!keep.count(it->first) && !recent) { ldso_pyr_destroy(it->second.p); it = pyr_.erase(it); } else ++it;
+    std::vector<PyrRef> dying;                                       // destroyed outside the lock
+    {
+        std::lock_guard<std::mutex> lk(pyrMutex_);
+        for (auto it = pyr_.begin(); it != pyr_.end();) {
+            if (!keep.count(it->first) && it->second.use_count() == 1) { dying.push_back(std::move(it->second)); it = pyr_.erase(it); } else ++it;
+        }
     }
 }
 
@@ -150,7 +154,7 @@ void GpuBackend::syncImageSlots(FullSystem &fs, std::vector<int32_t> &slots) {
     std::set<unsigned long> live;
     for (auto &fr : fs.frames) live.insert(fr->id);
     for (size_t s = 0; s < slotOwner_.size(); s++)
-        if (slotOwner_[s] >= 0 && !live.count((unsigned long) slotOwner_[s])) { slotOf_.erase((unsigned long) slotOwner_[s]); slotOwner_[s] = -1; }
+        if (slotOwner_[s] >= 0 && !live.count((unsigned long) slotOwner_[s])) { slotOf_.erase((unsigned long) slotOwner_[s]); slotOwner_[s] = -1; if (s < slotPyr_.size()) slotPyr_[s].reset(); }
     slots.clear();
     for (auto &fr : fs.frames) {
         FrameHessian *fh = fr->frameHessian.get();
@@ -159,8 +163,12 @@ void GpuBackend::syncImageSlots(FullSystem &fs, std::vector<int32_t> &slots) {
             size_t s = 0;
             while (s < slotOwner_.size() && slotOwner_[s] >= 0) s++;
             if (s == slotOwner_.size()) throw std::runtime_error("GpuBackend: more key frames than maxFrames");
-            if (useDevicePyramids && fr->frameHessian->frame) throwOn(ldso_ba_set_image_pyramid(ba_, (int) s, pyramidOf(fr->frameHessian)), "ldso_ba_set_image_pyramid");   // zero-copy: level 0 of the frame's pyramid
-            else throwOn(ldso_ba_set_image(ba_, (int) s, (const float *) fh->dIp[0]), "ldso_ba_set_image");      // Vec3f AoS (I, dx, dy): a straight copy
+            if (useDevicePyramids && fr->frameHessian->frame) {      // zero-copy: level 0 of the frame's pyramid, held for as long as the slot names it
+                PyrRef pr = pyramidOf(fr->frameHessian);
+                throwOn(ldso_ba_set_image_pyramid(ba_, (int) s, pr->p), "ldso_ba_set_image_pyramid");
+                if (slotPyr_.size() < slotOwner_.size()) slotPyr_.resize(slotOwner_.size());
+                slotPyr_[s] = pr;
+            } else throwOn(ldso_ba_set_image(ba_, (int) s, (const float *) fh->dIp[0]), "ldso_ba_set_image");      // Vec3f AoS (I, dx, dy): a straight copy
             slotOwner_[s] = (long) fr->id; it = slotOf_.emplace(fr->id, (int) s).first;
         }
         slots.push_back(it->second);
@@ -220,6 +228,15 @@ int GpuBackend::uploadWindow(FullSystem &fs, std::vector<shared_ptr<PointHessian
             p.u = ph->u; p.v = ph->v; p.idepth = ph->idepth; p.idepth_zero = ph->idepth_zero; p.priorF = ph->priorF;
             memcpy(p.color, ph->color, sizeof(p.color)); memcpy(p.weights, ph->weights, sizeof(p.weights));
             p.host = f; p.res_begin = (int32_t) R.size(); p.res_count = (int32_t) ph->residuals.size();
+            // PRECONDITION of trustIndices: ef->makeIDX() ran after the last insertResidual (makeKeyFrame does, FullSystem.cc:474) - insertResidual does not
+            // clear EFIndicesValid, so a caller that adds residuals and skips makeIDX would hand over stale / zero target indices.  Fresh residuals are appended:
+            // the NEWEST residual of the point is checked against the frame it names (one weak_ptr::lock per point, not per residual); a mismatch derives the
+            // indices of this point the slow way
+            bool trust = trustIndices && EFIndicesValid;
+            if (trust && !ph->residuals.empty()) {
+                const PointFrameResidual &rl = *ph->residuals.back();
+                trust = rl.targetIDX >= 0 && rl.targetIDX < F && fs.frames[rl.targetIDX]->frameHessian.get() == rl.target.lock().get();
+            }
             for (shared_ptr<PointFrameResidual> &r : ph->residuals) {
                 // makeIDX (EnergyFunctional.cc:380-401).  LDSO's own flow reaches optimize() with valid indices (makeKeyFrame calls ef->makeIDX() right before it,
                 // solveSystemF asserts EFIndicesValid): then r->hostIDX / targetIDX are taken as they are - two weak_ptr::lock() per residual are two atomic
@@ -227,7 +244,7 @@ int GpuBackend::uploadWindow(FullSystem &fs, std::vector<shared_ptr<PointHessian
                 // - and only there (trustIndices): insertResidual does not invalidate the flag, so between insertFrame's makeIDX and the explicit one in front
                 // of optimize() (FullSystem.cc:474) fresh residuals carry no indices yet - the activation upload derives them.  The host needs no lock at all.
                 r->hostIDX = f;
-                if (!(trustIndices && EFIndicesValid)) r->targetIDX = r->target.lock()->idx;
+                if (!trust) r->targetIDX = r->target.lock()->idx;
                 ldso_residual_t q;
                 q.point = (int32_t) P.size(); q.host = r->hostIDX; q.target = r->targetIDX; q.state_state = (int32_t) r->state_state;
                 q.is_linearized = r->isLinearized ? 1 : 0; q.is_active = r->isActive() ? 1 : 0; q.is_new = r->isNew ? 1 : 0; q.state_energy = (float) r->state_energy;
@@ -544,7 +561,7 @@ void GpuBackend::traceNewCoarse(FullSystem &fs, shared_ptr<FrameHessian> fh) {
         aff[(size_t) f * 2] = a[0]; aff[(size_t) f * 2 + 1] = a[1];
     }
     throwOn(ldso_trace_set_points(tracer_, (int) rec.size(), rec.data()), "ldso_trace_set_points");
-    if (useDevicePyramids && fh->frame) throwOn(ldso_trace_set_frame_pyramid(tracer_, pyramidOf(fh)), "ldso_trace_set_frame_pyramid");
+    if (useDevicePyramids && fh->frame) { tracerPyr_ = pyramidOf(fh); throwOn(ldso_trace_set_frame_pyramid(tracer_, tracerPyr_->p), "ldso_trace_set_frame_pyramid"); }
     else throwOn(ldso_trace_set_frame(tracer_, (const float *) fh->dIp[0]), "ldso_trace_set_frame");
     throwOn(ldso_trace_on(tracer_, F, KRKi.data(), Kt.data(), aff.data(), lastTraceCounts), "ldso_trace_on");
     throwOn(ldso_trace_get_points(tracer_, rec.data()), "ldso_trace_get_points");
@@ -608,7 +625,10 @@ void GpuBackend::setCoarseTrackingRef(CoarseTracker &tr, std::vector<shared_ptr<
     tr.lastRef_aff_g2l = tr.lastRef->aff_g2l();
     tr.firstCoarseRMSE = -1;
     if (useDevicePyramids && tr.lastRef->frame) {
-        throwOn(ldso_tr_set_ref_pyramid(trackerOf(tr), pyramidOf(tr.lastRef), tr.lastRef_aff_g2l.a, tr.lastRef_aff_g2l.b, tr.lastRef->ab_exposure, pts.data(), (int) (pts.size() / 4)),
+        ldso_tracker_t *t = trackerOf(tr);
+        PyrRef pr = pyramidOf(tr.lastRef);
+        { std::lock_guard<std::mutex> lk(handlesMutex_); trackerPyr_[t].ref = pr; }
+        throwOn(ldso_tr_set_ref_pyramid(t, pr->p, tr.lastRef_aff_g2l.a, tr.lastRef_aff_g2l.b, tr.lastRef->ab_exposure, pts.data(), (int) (pts.size() / 4)),
                 "ldso_tr_set_ref_pyramid");
         return;
     }
@@ -623,7 +643,11 @@ bool GpuBackend::trackNewestCoarse(CoarseTracker &tr, shared_ptr<FrameHessian> n
     ldso_tracker_t *t = trackerOf(tr);
     tr.newFrame = newFrameHessian;
     if (!newFrameResident(t, newFrameHessian)) {              // the pyramid goes over once per frame, not once per hypothesis
-        if (useDevicePyramids && newFrameHessian->frame) throwOn(ldso_tr_set_new_frame_pyramid(t, pyramidOf(newFrameHessian), newFrameHessian->ab_exposure), "ldso_tr_set_new_frame_pyramid");
+        if (useDevicePyramids && newFrameHessian->frame) {
+            PyrRef pr = pyramidOf(newFrameHessian);
+            { std::lock_guard<std::mutex> lk(handlesMutex_); trackerPyr_[t].newFrame = pr; }
+            throwOn(ldso_tr_set_new_frame_pyramid(t, pr->p, newFrameHessian->ab_exposure), "ldso_tr_set_new_frame_pyramid");
+        }
         else {
             const float *pyr[PYR_LEVELS];
             for (int l = 0; l < pyrLevelsUsed; l++) pyr[l] = (const float *) newFrameHessian->dIp[l];
@@ -653,7 +677,11 @@ Vec4 GpuBackend::trackNewCoarse(FullSystem &fs, shared_ptr<FrameHessian> fh) {
     shared_ptr<FrameHessian> lastF = tr.lastRef;
     tr.newFrame = fh;
     if (!newFrameResident(t, fh)) {
-        if (useDevicePyramids && fh->frame) throwOn(ldso_tr_set_new_frame_pyramid(t, pyramidOf(fh), fh->ab_exposure), "ldso_tr_set_new_frame_pyramid");
+        if (useDevicePyramids && fh->frame) {
+            PyrRef pr = pyramidOf(fh);
+            { std::lock_guard<std::mutex> lk(handlesMutex_); trackerPyr_[t].newFrame = pr; }
+            throwOn(ldso_tr_set_new_frame_pyramid(t, pr->p, fh->ab_exposure), "ldso_tr_set_new_frame_pyramid");
+        }
         else {
             const float *pyr[PYR_LEVELS];
             for (int l = 0; l < pyrLevelsUsed; l++) pyr[l] = (const float *) fh->dIp[l];

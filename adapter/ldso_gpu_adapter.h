@@ -93,11 +93,23 @@ private:
     std::map<unsigned long, int> slotOf_;                            // key frame (Frame::id: addresses get reused) -> image slot of the BA handle
     std::vector<long> slotOwner_;                                    // slot -> Frame::id, -1 = free
     std::vector<shared_ptr<PointHessian>> lastPoints_;               // the points of the window optimize() left on the device, in its order
-    struct PyrEntry { ldso_pyramid_t *p = nullptr; std::vector<float> irradiance; unsigned long stamp = 0; };
-    std::map<unsigned long, PyrEntry> pyr_;                          // Frame::id -> pyramid (+ the host copy of channel 0 the build read from)
-    unsigned long pyrClock_ = 0;
+    // One device pyramid per frame (Frame::id), REFERENCE-COUNTED: the map below holds one reference, every consumer that names the pyramid on the device
+    // holds another (the BA image slot, the tracer, a tracker's reference frame / new frame).  releasePyramids() only drops the MAP's reference of frames that
+    // left the window and that nobody else holds; the device memory goes when the last holder lets go - no guessing which tracker may still read it, no
+    // reading of another thread's state (the keep-set was built from an unsynchronised read of the trackers' maps and of lastRef).
+    struct PyrHolder {
+        ldso_pyramid_t *p = nullptr;
+        std::vector<float> irradiance;                               // the host copy of channel 0 the build read from
+        ~PyrHolder();
+    };
+    typedef std::shared_ptr<PyrHolder> PyrRef;
+    std::map<unsigned long, PyrRef> pyr_;                            // Frame::id -> pyramid
     std::mutex pyrMutex_;                                            // tracking thread (new frame / reference) and mapping thread (window, tracer) share the map
-    ldso_pyramid_t *pyramidOf(const shared_ptr<FrameHessian> &fh);
+    std::vector<PyrRef> slotPyr_;                                    // BA image slot -> the pyramid it aliases (mapping thread only)
+    PyrRef tracerPyr_;                                               // the frame the tracer currently reads (mapping thread only)
+    struct TrackerPyr { PyrRef ref, newFrame; };
+    std::map<ldso_tracker_t *, TrackerPyr> trackerPyr_;              // guarded by handlesMutex_
+    PyrRef pyramidOf(const shared_ptr<FrameHessian> &fh);
     void releasePyramids(FullSystem &fs);
     std::vector<int32_t> resBegin_;                                  // last upload: the residuals of point k are flat[resBegin_[k] .. resBegin_[k + 1])
     int device_, maxFrames_, maxPoints_;

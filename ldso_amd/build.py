@@ -35,6 +35,48 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+# ld_touch_kernarg<LINES>() (csrc/ba_dev.h) requests one dword of each of the first LINES 64-byte lines of a kernel's argument block at kernel entry.  The
+# static_asserts beside the calls bound the EXPLICIT arguments only; two kernels (k_linearize_one: 16 lines, the argument-based k_linearize: 14) also reach into
+# the hidden arguments behind them.  What actually bounds the loads is .kernarg_segment_size of the code object: checked here, from the objects that get linked,
+# so that another code-object version / compiler that trims the hidden block fails the BUILD instead of reading past the segment.
+KERNARG_TOUCH = {"k_linearize_one": 16, "k_linearize": 14, "k_reduce_solve": 12, "k_gn_solve": 10, "k_reduce": 8}
+
+
+def check_kernarg_segments() -> None:
+    import re
+    import tempfile
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not os.path.exists(os.path.join(llvm, "llvm-readelf")):
+        return
+    seen = set()
+    with tempfile.TemporaryDirectory() as tmp:
+        for s in ("ba_linearize.hip", "ba_reduce.hip", "ba_solve.hip"):
+            o, fat, co = os.path.join(HERE, "_obj", s + ".o"), os.path.join(tmp, "k.fat"), os.path.join(tmp, "k.co")
+            if subprocess.run([f"{llvm}/llvm-objcopy", f"--dump-section=.hip_fatbin={fat}", o], capture_output=True).returncode != 0:
+                raise RuntimeError(f"kernarg check: no .hip_fatbin in {o}")
+            subprocess.run([f"{llvm}/clang-offload-bundler", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--input={fat}", f"--output={co}", "--unbundle"],
+                           check=True, capture_output=True)
+            notes = subprocess.run([f"{llvm}/llvm-readelf", "--notes", co], check=True, capture_output=True, text=True).stdout
+            size = None
+            for line in notes.splitlines():
+                m = re.search(r"\.kernarg_segment_size:\s*(\d+)", line)
+                if m:
+                    size = int(m.group(1))
+                m = re.search(r"\.name:\s*(\S+)", line)          # .name follows .kernarg_segment_size inside a kernel's record (keys are sorted)
+                if m and size is not None:
+                    mangled = m.group(1)
+                    for kn, lines in KERNARG_TOUCH.items():
+                        if mangled.startswith(f"_Z{len(kn)}{kn}"):          # _Z<len><name>...: the length prefix makes this the exact kernel name (plain or template)
+                            need = (lines - 1) * 64 + 4
+                            if size < need:
+                                raise RuntimeError(f"{mangled}: kernarg segment of {size} bytes, ld_touch_kernarg<{lines}> reads up to byte {need}")
+                            seen.add(kn)
+                    size = None
+    missing = set(KERNARG_TOUCH) - seen
+    if missing:
+        raise RuntimeError(f"kernarg check: kernels not found in the code objects: {sorted(missing)}")
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return OUT
@@ -63,6 +105,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             raise RuntimeError(f"hipcc failed on {s}")
         if verbose and out.strip():
             print(out)
+    check_kernarg_segments()
     cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", OUT]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:

@@ -351,7 +351,10 @@ int ldso_ba_destroy(ldso_ba_t *H) {
 int ldso_ba_set_stream(ldso_ba_t *H, void *s) {
     REQ(H, "null handle");
     CHK(hipSetDevice(H->device));
-    if (H->ownStream && H->stream) { hipStreamSynchronize(H->stream); if (s) { hipStreamDestroy(H->stream); H->ownStream = false; } }
+    // work of this handle that is still in flight on the OLD stream is not ordered against the new one: wait for it here - in particular a staged copy out of the
+    // pinned arena (stageBusy, ldso_ba_set_prior), whose later "wait for H->stream" would otherwise wait on the wrong stream
+    if (H->stream && (H->ownStream || H->stageBusy)) { CHK(hipStreamSynchronize(H->stream)); H->stageBusy = false; }
+    if (H->ownStream && H->stream && s) { hipStreamDestroy(H->stream); H->ownStream = false; }
     if (s) { H->stream = (hipStream_t) s; H->ownStream = false; }
     else if (!H->ownStream) { CHK(hipStreamCreateWithFlags(&H->stream, hipStreamNonBlocking)); H->ownStream = true; }
     return LDSO_OK;

@@ -1079,14 +1079,21 @@ __global__ __launch_bounds__(NT) void k_solve(BaPtrs B, BaDims D, ResSet S, ldso
 // LDS between dependent products, canbreak walked four divergent branches with LDS round trips inside, and every wave walked every phase); now: see DESIGN 5.
 // ---------------------------------------------------------------------------------------------------------
 #define LD_XFP (8 * LD_MAXF + 8)
+// LDS scratch of the control workgroup (gn_solve_body: sW, LD_SW_DOUBLES doubles): doubles [0, LD_SW_RED) are io.sRed (solve_core's partial sums of sumNID - the
+// only part of it the solve may touch), the floats behind them belong to gn_tail: canbreak sums 0..3, K^-1 8..16, the calibration hand-over flag LD_TAIL_FLAG
+#define LD_SW_DOUBLES 64
+#define LD_SW_RED 8
+#define LD_TAIL_KI 8
 #define LD_TAIL_FLAG 20          // float index behind cbF of the calibration hand-over flag
+static_assert(NT == 256, "gn_tail is laid out for exactly four wavefronts: wave 0 waits for a flag that wave 3 sets");
+static_assert(LD_TAIL_KI + 9 <= LD_TAIL_FLAG && (LD_TAIL_FLAG + 1) * 4 <= (LD_SW_DOUBLES - LD_SW_RED) * 8, "gn_tail's floats must fit the scratch behind io.sRed");
 static __device__ __forceinline__ void gn_tail(const BaPtrs &B, const BaDims &D, DevFrame *fr, DevCalib *cal, const SolveIO &io, const ldso_settings_t &St, float *cbF,
                                                int cbIter, int *hostStop, int lastIt) {
     const int tid = threadIdx.x, F = D.F, n = D.n, wave = tid >> 6, lane = tid & 63;
     constexpr int W2 = 128;          // waves 1 and 2 walk the items; wave 3 takes what is left of them, and canbreak
     const double *sx = io.sx;
     DevCalib &C = *cal;
-    float *sKi = cbF + 8;          // 9 floats of the scratch behind the canbreak sums
+    float *sKi = cbF + LD_TAIL_KI;          // 9 floats of the scratch behind the canbreak sums
     int *sFlag = (int *) (cbF + LD_TAIL_FLAG);          // cleared by the caller before the solve
     const bool split = F * F <= 64;          // one wavefront holds all pairs
     const int items = F * F * 8, nMain = (items / W2) * W2;
@@ -1124,7 +1131,11 @@ static __device__ __forceinline__ void gn_tail(const BaPtrs &B, const BaDims &D,
         if (split) {
             // poses, calibration floats and pair records all belong to this wave: no workgroup barrier between them
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            while (__hip_atomic_load(sFlag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) __builtin_amdgcn_s_sleep(1);          // wave 3: calibration floats, K^-1 (long done)
+            // wave 3: calibration floats, K^-1 (long done).  Bounded like the p2p polls: a flag that never comes (a launch shape this was not written for) ends
+            // in the non-finite status of the iteration (scalars[4]) instead of a hung kernel
+            int spins = 0;
+            while (__hip_atomic_load(sFlag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0 && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(1);
+            if (spins >= (1 << 22) && lane == 0) B.scalars[4] = 1.0;
             if (lane < F * F) pair_record<false>(B, fr, C, F, lane, sKi);
         }
         if (LD_STAMP_ON && tid == 0) B.energyLog[62] = (double) wall_clock64();          // wave 0 at the barrier
@@ -1201,7 +1212,7 @@ static __device__ __forceinline__ void gn_solve_body(const BaPtrs &B, const BaDi
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int tid = threadIdx.x, F = D.F, n = D.n;
     const int NBsel = (n + 1 <= 64) ? 4 : (n + 1 <= 112) ? 7 : 9;
-    double *sW = sm + solve_core_lds_doubles(NBsel, n);      // 64 doubles of scratch
+    double *sW = sm + solve_core_lds_doubles(NBsel, n);      // LD_SW_DOUBLES doubles of scratch (layout: above gn_tail)
     if (LD_ITER_SKIPPED(B, A.itCheck)) return;
     const long long t0_ = wall_clock64();
 #define GSTAMP(i) do { if (LD_STAMP_ON && tid == 0) B.energyLog[40 + (i)] = (double) (wall_clock64() - t0_); } while (0)
@@ -1226,17 +1237,17 @@ static __device__ __forceinline__ void gn_solve_body(const BaPtrs &B, const BaDi
         if (tid == 0 && A.logIdx >= 0 && A.logIdx < 64) B.energyLog[A.logIdx] = B.scalars[0];
         return;
     }
-    DevFrame *sFr = (DevFrame *) (sW + 64);
+    DevFrame *sFr = (DevFrame *) (sW + LD_SW_DOUBLES);
     DevCalib *sCal = (DevCalib *) (sFr + F);
     if (LD_STAMP_ON && tid == 0) B.energyLog[39] = (double) t0_;
     SolveIO io;
     io.fr = sFr; io.cal = sCal; io.adH = B.adHostF; io.adT = B.adTargetF; io.adPitch = 64; io.sRed = sW; io.sumNID = 0; io.lambda = A.lambda; io.hasPrior = A.hasPrior; io.redScalars = A.reduceIn; io.waitCtr = A.waitCtr; io.waitTarget = A.waitTarget;
     io.ldsAd = (F <= 8) ? (float *) (sCal + 1) : nullptr;
-    if (tid == 0) *(int *) ((float *) (sW + 8) + LD_TAIL_FLAG) = 0;          // gn_tail's hand-over flag (the solve's barriers publish it)
+    if (tid == 0) *(int *) ((float *) (sW + LD_SW_RED) + LD_TAIL_FLAG) = 0;          // gn_tail's hand-over flag (the solve's barriers publish it)
     solve_core_dispatch<true, WAIT>(B, D, S, St, A.iteration, sm, io);      // + mirrors
     GSTAMP(4);
     GSTAMP(5);
-    gn_tail(B, D, sFr, sCal, io, St, (float *) (sW + 8), A.itCheck, A.hostStop, A.lastIt);      // x, xAd, backupState + doStepFromBackup + canbreak, setPrecalcValues
+    gn_tail(B, D, sFr, sCal, io, St, (float *) (sW + LD_SW_RED), A.itCheck, A.hostStop, A.lastIt);      // x, xAd, backupState + doStepFromBackup + canbreak, setPrecalcValues
     GSTAMP(6);
     // write the mirrors back (all but frameEnergyTH, which block 1 owns)
     {

@@ -306,12 +306,13 @@ class RefWindow:
         self.L.ref_marginalize_frame(self.h, C.c_int(idx))
 
 
-# ---- the compiled drop-in adapter (adapter/ldso_gpu_adapter.cc -> oracle/_ref/libldso_adapter.so) on reference object graphs ----------------
+# ---- the compiled drop-in adapter (adapter/ldso_gpu_adapter.cc -> adapter/_build/libldso_gpu_adapter.so) on reference object graphs, driven through the
+# ---- test-only C face adapter/adapter_capi.cc -> adapter/_build/libldso_adapter_test.so -------------------------------------------------------
 _ADP = None
 
 
 def adapter_path() -> str:
-    return os.path.join(_HERE, "_ref", "libldso_adapter.so")
+    return os.path.join(_HERE, "..", "adapter", "_build", "libldso_adapter_test.so")
 
 
 def adapter_available() -> bool:

@@ -20,7 +20,7 @@ g.enqueue_gn(0, 20); g.sync()
 def timed(fn, reps=7):
     out = []
     for _ in range(reps):
-        s.synchronize(); t0 = time.perf_counter(); fn(); s.synchronize(); out.append((time.perf_counter() - t0) / N * 1e6)
+        torch.cuda.synchronize(); t0 = time.perf_counter(); fn(); torch.cuda.synchronize(); out.append((time.perf_counter() - t0) / N * 1e6)
     return sorted(out)
 
 plain = timed(lambda: g.enqueue_gn(2, N))
@@ -29,7 +29,10 @@ try:
     cg = torch.cuda.CUDAGraph()
     with torch.cuda.graph(cg, stream=s):
         g.enqueue_gn(2, N)
-    graph = timed(cg.replay)
+    def replay():
+        with torch.cuda.stream(s):          # replay() launches on torch's CURRENT stream (the first version of this script timed an unsynchronised launch)
+            cg.replay()
+    graph = timed(replay)
     print("graph replay:     us per iteration (sorted)", [round(x, 2) for x in graph])
     st = g.get_frames()["frames"]["state"]
     print("state finite after the replays:", bool(np.isfinite(st).all()))

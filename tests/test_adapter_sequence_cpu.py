@@ -1,14 +1,14 @@
 """The key-frame driver of tests/test_adapter_sequence_gpu.py (adapter/adapter_capi.cc: adp_make_keyframe, FullSystem::makeKeyFrame's order,
 FullSystem.cc:410-640) with the reference's OWN members at every stage - no GPU involved: the reference leg of the end-to-end comparison must itself behave
 like a sliding-window system (the window grows to `max_frames` and slides, points get activated and marginalised, the prior builds up, the poses stay near
-the truth).  Needs the libraries built where /root/reference exists (oracle/_ref/libldso_ref.so, libldso_adapter.so)."""
+the truth).  Needs the libraries built where /root/reference exists (oracle/_ref/libldso_ref.so, adapter/_build/*.so)."""
 import numpy as np
 import pytest
 
 from ldso_amd import synth
 from oracle import pyref as pr
 
-pytestmark = pytest.mark.skipif(not (pr.available() and pr.adapter_available()), reason="oracle/_ref/libldso_ref.so / libldso_adapter.so not built")
+pytestmark = pytest.mark.skipif(not (pr.available() and pr.adapter_available()), reason="oracle/_ref/libldso_ref.so / adapter/_build/libldso_adapter_test.so not built")
 
 
 def test_reference_leg_of_the_key_frame_sequence_slides_a_window():

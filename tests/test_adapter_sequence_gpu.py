@@ -12,7 +12,7 @@ from conftest import observe
 from ldso_amd import synth
 from oracle import pyref as pr
 
-pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not (pr.available() and pr.adapter_available()), reason="oracle/_ref/libldso_ref.so / libldso_adapter.so not built")]
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not (pr.available() and pr.adapter_available()), reason="oracle/_ref/libldso_ref.so / adapter/_build/libldso_adapter_test.so not built")]
 
 K = 8
 
