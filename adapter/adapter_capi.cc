@@ -98,6 +98,9 @@ int adp_trace_new_coarse(void *b, void *fs, void *fh, int *counts) {
 int adp_set_device_pyramids(void *b, int on) { ((GpuBackend *) b)->useDevicePyramids = on != 0; return 0; }
 int adp_pyramids_built(void *b) { return ((GpuBackend *) b)->pyramidsBuilt; }
 int adp_set_write_back_jacobians(void *b, int on) { ((GpuBackend *) b)->writeBackJacobians = on != 0; return 0; }
+// the window resident across optimize() calls (ldso_ba_update_window) or flattened and uploaded every time; how many uploads of each kind so far
+int adp_set_resident_window(void *b, int on) { ((GpuBackend *) b)->residentWindow = on != 0; return 0; }
+int adp_upload_counts(void *b, int *delta, int *fresh) { *delta = ((GpuBackend *) b)->uploadsDelta; *fresh = ((GpuBackend *) b)->uploadsFresh; return 0; }
 // wall-clock split of the last GpuBackend::optimize (seconds): flatten + upload, device (ldso_ba_optimize incl. its read-back of the energies), fetch, write-back into the objects
 int adp_last_optimize_times(void *b, double *out4) { for (int i = 0; i < 4; i++) out4[i] = ((GpuBackend *) b)->lastOptimizeSeconds[i]; return 0; }
 int adp_last_upload_times(void *b, double *out6) { for (int i = 0; i < 6; i++) out6[i] = ((GpuBackend *) b)->lastUploadSeconds[i]; return 0; }
@@ -220,7 +223,7 @@ int adp_make_keyframe(void *b, void *fs_, void *newfh, int margIdx, int kfId, in
             if (fs.frames[i]->frameHessian->flaggedForMarginalization) {
                 shared_ptr<Frame> fr = fs.frames[i];
                 for (int l = 0; l < PYR_LEVELS; l++) { fr->frameHessian->dIp[l] = nullptr; fr->frameHessian->absSquaredGrad[l] = nullptr; }
-                fs.marginalizeFrame(fr);
+                if (B && deviceMarginalisation) B->marginalizeFrame(fs, fr); else fs.marginalizeFrame(fr);
                 i = 0;
             }
         for (auto &fr : fs.frames) for (auto &feat : fr->features) if (feat->status == Feature::FeatureStatus::VALID && feat->point && feat->point->status == Point::PointStatus::ACTIVE) stats[3]++;

@@ -37,6 +37,7 @@
 #include "internal/CalibHessian.h"
 #include "internal/FrameHessian.h"
 #include "internal/GlobalCalib.h"
+#include "internal/GlobalFuncs.h"
 #include "internal/OptimizationBackend/EnergyFunctional.h"
 #include "internal/PointHessian.h"
 #include "internal/Residuals.h"
@@ -180,14 +181,185 @@ void GpuBackend::syncImageSlots(FullSystem &fs, std::vector<int32_t> &slots) {
 // the order of EnergyFunctional::makeIDX (EnergyFunctional.cc:380-401: frames, then the host frame's features), residuals in
 // PointHessian::residuals order; a residual's slot is (hostIDX, targetIDX).  allPoints / flat give the write-back its objects.
 // ------------------------------------------------------------------------------------------------------------------------------------
-int GpuBackend::uploadWindow(FullSystem &fs, std::vector<shared_ptr<PointHessian>> &allPoints, std::vector<shared_ptr<PointFrameResidual>> &flat, bool trustIndices) {
-    auto tU = std::chrono::steady_clock::now();
-    auto lapU = [&](int i) { const auto n_ = std::chrono::steady_clock::now(); lastUploadSeconds[i] = std::chrono::duration<double>(n_ - tU).count(); tU = n_; };
+// one point of the window as ldso_ba_set_window / ldso_ba_update_window take it
+static void flatPoint(const PointHessian &ph, int host, ldso_point_t &p) {
+    memset(&p, 0, sizeof(p));
+    p.u = ph.u; p.v = ph.v; p.idepth = ph.idepth; p.idepth_zero = ph.idepth_zero; p.priorF = ph.priorF;
+    memcpy(p.color, ph.color, sizeof(p.color)); memcpy(p.weights, ph.weights, sizeof(p.weights));
+    p.host = host;
+}
+static void flatResidual(const PointFrameResidual &r, int point, int host, int target, ldso_residual_t &q) {
+    q.point = point; q.host = host; q.target = target; q.state_state = (int32_t) r.state_state;
+    q.is_linearized = r.isLinearized ? 1 : 0; q.is_active = r.isActive() ? 1 : 0; q.is_new = r.isNew ? 1 : 0; q.state_energy = (float) r.state_energy;
+}
+
+// The whole window from the objects (the first optimize() of a handle, windows with linearised residuals, after invalidateWindow(), or when the delta path below
+// gave up).  Residuals of a point go over target-ascending: the flat order ldso_ba_update_window keeps, so that both paths describe the same window.
+void GpuBackend::uploadFresh(FullSystem &fs, const std::vector<int32_t> &slots, std::vector<shared_ptr<PointHessian>> &allPoints, bool trustIndices) {
+    const int F = (int) fs.frames.size();
+    allPoints.clear(); flat_.clear(); rows_.clear();
+    resBegin_.assign(1, 0);
+    std::vector<ldso_point_t> P; std::vector<ldso_residual_t> R; std::vector<ldso_rawjac_t> LJ; std::vector<float> RTZ, mrb; std::vector<int32_t> ngr;
+    P.reserve(4096); R.reserve(32768); flat_.reserve(32768); rows_.reserve(4096);
+    // linearised residuals (none in LDSO's own flow: flagPointsForRemoval clears isLinearized, FullSystem.cc:1243) carry their Jacobian and
+    // res_toZeroF across; the 296-byte records are only built from the first one on (the residuals in front of it get empty ones then)
+    bool anyLin = false;
+    for (int f = 0; f < F; f++)
+        for (shared_ptr<Feature> &feat : fs.frames[f]->features) {
+            if (!(feat->status == Feature::FeatureStatus::VALID && feat->point && feat->point->status == Point::PointStatus::ACTIVE)) continue;
+            shared_ptr<PointHessian> ph = feat->point->mpPH;
+            ldso_point_t p;
+            flatPoint(*ph, f, p);
+            p.res_begin = (int32_t) R.size(); p.res_count = (int32_t) ph->residuals.size();
+            // PRECONDITION of trustIndices: ef->makeIDX() ran after the last insertResidual (makeKeyFrame does, FullSystem.cc:474) - insertResidual does not
+            // clear EFIndicesValid, so a caller that adds residuals and skips makeIDX would hand over stale / zero target indices.  Fresh residuals are appended:
+            // the NEWEST residual of the point is checked against the frame it names (one weak_ptr::lock per point, not per residual); a mismatch derives the
+            // indices of this point the slow way (ADVICE round 4)
+            bool trust = trustIndices && EFIndicesValid;
+            if (trust && !ph->residuals.empty()) {
+                const PointFrameResidual &rl = *ph->residuals.back();
+                trust = rl.targetIDX >= 0 && rl.targetIDX < F && fs.frames[rl.targetIDX]->frameHessian.get() == rl.target.lock().get();
+            }
+            Row row; row.ph = ph.get(); row.feat = feat.get(); row.mask = 0; row.host = f;
+            for (int c = 0; c < kMaxCols; c++) row.res[c] = nullptr;
+            for (shared_ptr<PointFrameResidual> &r : ph->residuals) {
+                // makeIDX (EnergyFunctional.cc:380-401): LDSO's own flow reaches optimize() with valid indices (two weak_ptr::lock() per residual are two
+                // atomic read-modify-write pairs, 24 000 of them a quarter of the flatten at C3)
+                r->hostIDX = f;
+                if (!trust) r->targetIDX = r->target.lock()->idx;
+                const int t = r->targetIDX;
+                if (t < 0 || t >= F || t == f || ((row.mask >> t) & 1u)) throw std::runtime_error("GpuBackend: a residual names a frame outside the window, its host, or a target twice");
+                row.mask |= 1u << t; row.res[t] = r.get();
+            }
+            for (int t = 0; t < F; t++) {
+                if (!((row.mask >> t) & 1u)) continue;
+                PointFrameResidual &r = *row.res[t];
+                ldso_residual_t q;
+                flatResidual(r, (int32_t) P.size(), f, t, q);
+                if (r.isLinearized && !anyLin) { anyLin = true; LJ.resize(R.size()); RTZ.resize(R.size() * 8, 0.0f); for (auto &j : LJ) memset(&j, 0, sizeof(j)); }
+                R.push_back(q); flat_.push_back(&r);
+                if (anyLin) {
+                    ldso_rawjac_t j;
+                    memset(&j, 0, sizeof(j));
+                    if (r.isLinearized) toRaw(*r.J, j);
+                    LJ.push_back(j);
+                    for (int k = 0; k < 8; k++) RTZ.push_back(r.isLinearized ? r.res_toZeroF[k] : 0.0f);
+                }
+            }
+            P.push_back(p); allPoints.push_back(ph); rows_.push_back(row);
+            mrb.push_back(ph->maxRelBaseline); ngr.push_back(ph->numGoodResiduals);
+            resBegin_.push_back((int32_t) R.size());
+        }
+    if (P.empty()) return;
+    lastUploadSeconds[1] += lapSince();
+    throwOn(ldso_ba_set_window(ba_, F, slots.data(), (int) P.size(), P.data(), (int) R.size(), R.data(), anyLin ? LJ.data() : nullptr, anyLin ? RTZ.data() : nullptr), "ldso_ba_set_window");
+    lastUploadSeconds[2] += lapSince();
+    throwOn(ldso_ba_set_point_stats(ba_, mrb.data(), ngr.data()), "ldso_ba_set_point_stats");
+    lastUploadSeconds[3] += lapSince();
+    residentValid_ = !anyLin;                                        // ldso_ba_update_window does not carry linearised residuals
+}
+
+// The window as a delta against the one the last optimize() left on the device (ldso_ba_update_window).  Surviving points are recognised by walking the new
+// window (frames, then the host frame's features: makeIDX order) against the rows of the resident one - both in the same stable order, so one pass with two
+// cursors; a row is skipped when its point is gone (host frame left, point no longer ACTIVE).  Returns false when the resident window cannot express the new
+// one (linearised residuals, an inconsistency): the caller uploads everything.
+bool GpuBackend::uploadDelta(FullSystem &fs, const std::vector<int32_t> &slots, std::vector<shared_ptr<PointHessian>> &allPoints) {
+    const int F = (int) fs.frames.size(), oF = (int) rowFrames_.size();
+    if (F > kMaxCols || oF > kMaxCols || rows_.empty()) return false;
+    int32_t frameFrom[kMaxCols], oldToNew[kMaxCols];
+    for (int c = 0; c < kMaxCols; c++) { frameFrom[c] = -1; oldToNew[c] = -1; }
+    int lastOld = -1, nInserted = 0;
+    for (int f = 0; f < F; f++) {
+        for (int o = 0; o < oF; o++) if (rowFrames_[o].get() == fs.frames[f].get()) frameFrom[f] = o;          // identity, not Frame::id: another object graph may reuse the ids
+        if (frameFrom[f] >= 0) { if (frameFrom[f] <= lastOld) return false; lastOld = frameFrom[f]; oldToNew[frameFrom[f]] = f; } else nInserted++;
+    }
+    if (nInserted == F) return false;          // nothing of the resident window is left
+    const size_t oP = rows_.size();
+    auto alive = [&](const Row &r) {          // the frame first: features of a frame that left the window may be gone with it
+        return oldToNew[r.host] >= 0 && r.feat->status == Feature::FeatureStatus::VALID && r.feat->point && r.feat->point->status == Point::PointStatus::ACTIVE
+               && r.feat->point->mpPH.get() == r.ph;
+    };
+    std::vector<Row> rows; rows.reserve(oP + 512);
+    std::vector<int32_t> pointFrom; pointFrom.reserve(oP + 512);
+    std::vector<uint32_t> mask; mask.reserve(oP + 512);
+    std::vector<shared_ptr<PointHessian>> pts; pts.reserve(oP + 512);
+    std::vector<ldso_point_t> fresh; std::vector<ldso_residual_t> freshRes; std::vector<float> fmrb; std::vector<int32_t> fngr;
+    size_t j = 0;
+    auto columnOf = [&](const PointFrameResidual &r) { const shared_ptr<FrameHessian> t = r.target.lock(); return t ? t->idx : -1; };      // FrameHessian::idx = window position (set above)
+    for (int f = 0; f < F; f++)
+        for (shared_ptr<Feature> &feat : fs.frames[f]->features) {
+            if (!(feat->status == Feature::FeatureStatus::VALID && feat->point && feat->point->status == Point::PointStatus::ACTIVE)) continue;
+            PointHessian *ph = feat->point->mpPH.get();
+            while (j < oP && rows_[j].ph != ph && !alive(rows_[j])) j++;
+            Row n; n.ph = ph; n.feat = feat.get(); n.mask = 0; n.host = f;
+            for (int c = 0; c < kMaxCols; c++) n.res[c] = nullptr;
+            const int have = (int) ph->residuals.size();
+            auto reread = [&]() -> bool {          // the point's residual list from the objects
+                n.mask = 0;
+                for (int c = 0; c < kMaxCols; c++) n.res[c] = nullptr;
+                for (shared_ptr<PointFrameResidual> &r : ph->residuals) {
+                    const int t = columnOf(*r);
+                    if (r->isLinearized || t < 0 || t >= F || t == f || ((n.mask >> t) & 1u)) return false;
+                    n.mask |= 1u << t; n.res[t] = r.get();
+                }
+                return true;
+            };
+            if (j < oP && rows_[j].ph == ph) {
+                // ---- a point of the resident window: its residuals by column, minus the frames that left, plus what was appended since ----
+                const Row &o = rows_[j];
+                if (oldToNew[o.host] != f) return false;
+                for (int c = 0; c < oF; c++)
+                    if (((o.mask >> c) & 1u) && oldToNew[c] >= 0) { n.mask |= 1u << oldToNew[c]; n.res[oldToNew[c]] = o.res[c]; }
+                int cnt = __builtin_popcount(n.mask);
+                bool ok = have >= cnt && have - cnt <= nInserted;
+                for (int k = cnt; ok && k < have; k++) {          // insertResidual appends (FullSystem.cc:447-470): the new ones are the last
+                    PointFrameResidual &r = *ph->residuals[k];
+                    const int t = columnOf(r);
+                    ok = !r.isLinearized && t >= 0 && t < F && t != f && frameFrom[t] < 0 && !((n.mask >> t) & 1u);
+                    if (ok) { n.mask |= 1u << t; n.res[t] = &r; }
+                }
+                if (!ok && !reread()) return false;
+                pointFrom.push_back((int32_t) j);
+                pts.push_back(lastPoints_[j]);
+                j++;
+            } else {
+                // ---- a fresh point (activated since the last optimize()): its records cross PCIe ----
+                if (!reread()) return false;
+                const int k = (int) fresh.size();
+                ldso_point_t p;
+                flatPoint(*ph, f, p);
+                p.res_begin = (int32_t) freshRes.size(); p.res_count = have;
+                fresh.push_back(p); fmrb.push_back(ph->maxRelBaseline); fngr.push_back(ph->numGoodResiduals);
+                for (int t = 0; t < F; t++) if ((n.mask >> t) & 1u) { ldso_residual_t q; flatResidual(*n.res[t], k, f, t, q); freshRes.push_back(q); }
+                pointFrom.push_back(-1 - k);
+                pts.push_back(feat->point->mpPH);
+            }
+            rows.push_back(n); mask.push_back(n.mask);
+        }
+    for (; j < oP; j++) if (alive(rows_[j])) return false;          // a point of the resident window that the walk did not meet
+    if (rows.empty()) return false;
+    lastUploadSeconds[1] += lapSince();
+    const int rc = ldso_ba_update_window(ba_, F, slots.data(), frameFrom, (int) rows.size(), pointFrom.data(), mask.data(), (int) fresh.size(), fresh.data(), (int) freshRes.size(),
+                                         freshRes.data(), fmrb.data(), fngr.data());
+    lastUploadSeconds[2] += lapSince();
+    if (rc != LDSO_OK) { LOG(WARNING) << "GpuBackend: ldso_ba_update_window refused the delta (" << ldso_last_error() << "), uploading the whole window"; return false; }
+    rows_.swap(rows); allPoints.swap(pts);
+    flat_.clear(); resBegin_.assign(1, 0);
+    for (const Row &r : rows_) {
+        for (int t = 0; t < F; t++) if ((r.mask >> t) & 1u) flat_.push_back(r.res[t]);
+        resBegin_.push_back((int32_t) flat_.size());
+    }
+    return true;
+}
+
+int GpuBackend::uploadWindow(FullSystem &fs, std::vector<shared_ptr<PointHessian>> &allPoints, bool trustIndices) {
+    lapSince();
+    for (double &t : lastUploadSeconds) t = 0;
     const ldso_settings_t st = flatSettings();
     throwOn(ldso_ba_set_settings(ba_, &st), "ldso_ba_set_settings");
     std::vector<int32_t> slots;
     syncImageSlots(fs, slots);
-    lapU(0);
+    lastUploadSeconds[0] += lapSince();
     const int F = (int) fs.frames.size();
     std::vector<ldso_frame_t> Fv((size_t) F);
     for (int f = 0; f < F; f++) {
@@ -203,81 +375,24 @@ int GpuBackend::uploadWindow(FullSystem &fs, std::vector<shared_ptr<PointHessian
         for (int r = 0; r < 4; r++) for (int c = 0; c < 2; c++) o.nullspaces_affine[r * 2 + c] = fh.nullspaces_affine(r, c);
         o.ab_exposure = fh.ab_exposure; o.frameEnergyTH = fh.frameEnergyTH; o.frameID = (int32_t) fh.frame->id;   // getPrior keys on frame->id == 0
     }
-    allPoints.clear(); flat.clear();
-    resBegin_.assign(1, 0);
-    std::vector<ldso_point_t> P; std::vector<ldso_residual_t> R; std::vector<ldso_rawjac_t> LJ; std::vector<float> RTZ, mrb; std::vector<int32_t> ngr;
-    // linearised residuals (none in LDSO's own flow: flagPointsForRemoval clears isLinearized, FullSystem.cc:1243) carry their Jacobian and
-    // res_toZeroF across; the 296-byte records are only built when there is one
-    bool anyLin = false;
-    {
-        size_t np = 0, nr = 0;
-        for (int f = 0; f < F; f++) for (shared_ptr<Feature> &feat : fs.frames[f]->features)
-            if (feat->status == Feature::FeatureStatus::VALID && feat->point && feat->point->status == Point::PointStatus::ACTIVE) {
-                np++; nr += feat->point->mpPH->residuals.size();
-                if (!anyLin) for (shared_ptr<PointFrameResidual> &r : feat->point->mpPH->residuals) if (r->isLinearized) { anyLin = true; break; }
-            }
-        P.reserve(np); allPoints.reserve(np); mrb.reserve(np); ngr.reserve(np); R.reserve(nr); flat.reserve(nr);
-        if (anyLin) { LJ.reserve(nr); RTZ.reserve(nr * 8); }
-    }
-    for (int f = 0; f < F; f++)
-        for (shared_ptr<Feature> &feat : fs.frames[f]->features) {
-            if (!(feat->status == Feature::FeatureStatus::VALID && feat->point && feat->point->status == Point::PointStatus::ACTIVE)) continue;
-            shared_ptr<PointHessian> ph = feat->point->mpPH;
-            ldso_point_t p;
-            memset(&p, 0, sizeof(p));
-            p.u = ph->u; p.v = ph->v; p.idepth = ph->idepth; p.idepth_zero = ph->idepth_zero; p.priorF = ph->priorF;
-            memcpy(p.color, ph->color, sizeof(p.color)); memcpy(p.weights, ph->weights, sizeof(p.weights));
-            p.host = f; p.res_begin = (int32_t) R.size(); p.res_count = (int32_t) ph->residuals.size();
-            // PRECONDITION of trustIndices: ef->makeIDX() ran after the last insertResidual (makeKeyFrame does, FullSystem.cc:474) - insertResidual does not
-            // clear EFIndicesValid, so a caller that adds residuals and skips makeIDX would hand over stale / zero target indices.  Fresh residuals are appended:
-            // the NEWEST residual of the point is checked against the frame it names (one weak_ptr::lock per point, not per residual); a mismatch derives the
-            // indices of this point the slow way (ADVICE round 4)
-            bool trust = trustIndices && EFIndicesValid;
-            if (trust && !ph->residuals.empty()) {
-                const PointFrameResidual &rl = *ph->residuals.back();
-                trust = rl.targetIDX >= 0 && rl.targetIDX < F && fs.frames[rl.targetIDX]->frameHessian.get() == rl.target.lock().get();
-            }
-            for (shared_ptr<PointFrameResidual> &r : ph->residuals) {
-                // makeIDX (EnergyFunctional.cc:380-401).  LDSO's own flow reaches optimize() with valid indices (makeKeyFrame calls ef->makeIDX() right before it,
-                // solveSystemF asserts EFIndicesValid): then r->hostIDX / targetIDX are taken as they are - two weak_ptr::lock() per residual are two atomic
-                // read-modify-write pairs, 24 000 of them a quarter of the flatten at C3
-                // - and only there (trustIndices): insertResidual does not invalidate the flag, so between insertFrame's makeIDX and the explicit one in front
-                // of optimize() (FullSystem.cc:474) fresh residuals carry no indices yet - the activation upload derives them.  The host needs no lock at all.
-                r->hostIDX = f;
-                if (!trust) r->targetIDX = r->target.lock()->idx;
-                ldso_residual_t q;
-                q.point = (int32_t) P.size(); q.host = r->hostIDX; q.target = r->targetIDX; q.state_state = (int32_t) r->state_state;
-                q.is_linearized = r->isLinearized ? 1 : 0; q.is_active = r->isActive() ? 1 : 0; q.is_new = r->isNew ? 1 : 0; q.state_energy = (float) r->state_energy;
-                R.push_back(q); flat.push_back(r);
-                if (anyLin) {
-                    ldso_rawjac_t j;
-                    memset(&j, 0, sizeof(j));
-                    if (r->isLinearized) toRaw(*r->J, j);
-                    LJ.push_back(j);
-                    for (int k = 0; k < 8; k++) RTZ.push_back(r->isLinearized ? r->res_toZeroF[k] : 0.0f);
-                }
-            }
-            P.push_back(p); allPoints.push_back(ph);
-            mrb.push_back(ph->maxRelBaseline); ngr.push_back(ph->numGoodResiduals);
-            resBegin_.push_back((int32_t) R.size());
-        }
-    if (P.empty()) return 0;
-    lapU(1);
-    throwOn(ldso_ba_set_window(ba_, F, slots.data(), (int) P.size(), P.data(), (int) R.size(), R.data(), anyLin ? LJ.data() : nullptr, anyLin ? RTZ.data() : nullptr), "ldso_ba_set_window");
-    lapU(2);
-    throwOn(ldso_ba_set_point_stats(ba_, mrb.data(), ngr.data()), "ldso_ba_set_point_stats");
-    lapU(3);
+    lastUploadWasDelta = residentWindow && residentValid_ && uploadDelta(fs, slots, allPoints);
+    if (!lastUploadWasDelta) { residentValid_ = false; uploadFresh(fs, slots, allPoints, trustIndices); }
+    (lastUploadWasDelta ? uploadsDelta : uploadsFresh)++;
+    if (allPoints.empty()) { residentValid_ = false; return 0; }
+    rowFrames_.assign(fs.frames.begin(), fs.frames.end());
+    lastPoints_ = allPoints;                                         // keeps the rows' PointHessian objects alive while the window is resident
+    lapSince();
     const ldso_calib_t c = flatCalib(*fs.Hcalib->mpCH);
     throwOn(ldso_ba_set_frames(ba_, Fv.data(), &c), "ldso_ba_set_frames");                      // setAdjointsF + setPrecalcValues on the device
-    lapU(4);
+    lastUploadSeconds[4] += lapSince();
     const int n = CPARS + 8 * F;
     if ((int) fs.ef->HM.rows() == n) {
         std::vector<double> HM((size_t) n * n), bM((size_t) n);
         for (int i = 0; i < n; i++) { for (int j = 0; j < n; j++) HM[(size_t) i * n + j] = fs.ef->HM(i, j); bM[i] = fs.ef->bM[i]; }
         throwOn(ldso_ba_set_prior(ba_, HM.data(), bM.data()), "ldso_ba_set_prior");
     }
-    lapU(5);
-    return (int) P.size();
+    lastUploadSeconds[5] += lapSince();
+    return (int) allPoints.size();
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------------
@@ -289,18 +404,19 @@ float GpuBackend::optimize(FullSystem &fs, int mnumOptIts) {
     if (fs.frames.size() < 4) mnumOptIts = 15;
 
     std::vector<shared_ptr<PointHessian>> allPoints;
-    std::vector<shared_ptr<PointFrameResidual>> flat;
     if (useDevicePyramids) releasePyramids(fs);
     const auto tWall0 = std::chrono::steady_clock::now();
     auto lap = [&](int i, std::chrono::steady_clock::time_point &t) { const auto n_ = std::chrono::steady_clock::now(); lastOptimizeSeconds[i] = std::chrono::duration<double>(n_ - t).count(); t = n_; };
     auto tLap = tWall0;
-    if (uploadWindow(fs, allPoints, flat, /*trustIndices*/ true) == 0) return 0;
+    if (uploadWindow(fs, allPoints, /*trustIndices*/ true) == 0) return 0;
     lap(0, tLap);
-    const int F = (int) fs.frames.size(), P = (int) allPoints.size(), R = (int) flat.size();
+    const int F = (int) fs.frames.size(), P = (int) allPoints.size(), R = (int) flat_.size();
+    const std::vector<PointFrameResidual *> &flat = flat_;
 
-    // activeResiduals (:735-755) stays what the reference's later stages expect: the non-linearised residuals in traversal order
+    // activeResiduals (:735-755): only FullSystem::optimize itself reads the list (see fillActiveResiduals in the header)
     fs.activeResiduals.clear();
-    for (auto &r : flat) if (!r->isLinearized) fs.activeResiduals.push_back(r);
+    if (fillActiveResiduals)
+        for (int k = 0; k < P; k++) for (shared_ptr<PointFrameResidual> &r : allPoints[k]->residuals) if (!r->isLinearized) fs.activeResiduals.push_back(r);
 
     // the whole loop of :757-843 and the tail :845-851 (re-anchor the newest frame, adjoints, precalc, linearizeAll(true)) on the device
     float rmse = 0;
@@ -360,20 +476,25 @@ float GpuBackend::optimize(FullSystem &fs, int mnumOptIts) {
     for (int k = 0; k < P; k++) {
         PointHessian &ph = *allPoints[k];
         for (int i = resBegin_[k]; i < resBegin_[k + 1]; i++) {
-            shared_ptr<PointFrameResidual> &r = flat[i];
+            PointFrameResidual *r = flat[i];
             if (r->isLinearized) continue;
-            if (ph.lastResiduals[0].first == r) ph.lastResiduals[0].second = r->state_state;
-            else if (ph.lastResiduals[1].first == r) ph.lastResiduals[1].second = r->state_state;
+            if (ph.lastResiduals[0].first.get() == r) ph.lastResiduals[0].second = r->state_state;
+            else if (ph.lastResiduals[1].first.get() == r) ph.lastResiduals[1].second = r->state_state;
         }
     }
     for (int k = 0; k < P; k++) {
         PointHessian &ph = *allPoints[k];
         for (int i = resBegin_[k]; i < resBegin_[k + 1]; i++) {
             if (!rem[i]) continue;
-            shared_ptr<PointFrameResidual> r = flat[i];
+            shared_ptr<PointFrameResidual> r;
+            for (shared_ptr<PointFrameResidual> &q : ph.residuals) if (q.get() == flat[i]) { r = q; break; }
+            if (!r) continue;
             if (ph.lastResiduals[0].first == r) ph.lastResiduals[0].first = 0;
             else if (ph.lastResiduals[1].first == r) ph.lastResiduals[1].first = 0;
             fs.ef->dropResidual(r);                                                               // EnergyFunctional.cc:44-56
+            // ... and out of the resident window's host view: the next delta says dropResidual through the cleared bit
+            Row &row = rows_[k];
+            for (int t = 0; t < kMaxCols; t++) if (row.res[t] == flat[i]) { row.res[t] = nullptr; row.mask &= ~(1u << t); }
         }
     }
     int resInA = 0, resInL = 0;
@@ -394,7 +515,6 @@ float GpuBackend::optimize(FullSystem &fs, int mnumOptIts) {
             fr->aff_g2l = fr->frameHessian->aff_g2l();
         }
     }
-    lastPoints_ = allPoints;
     lap(3, tLap);
     return rmse;
 }
@@ -462,14 +582,62 @@ void GpuBackend::marginalizePoints(FullSystem &fs) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------------
+// void FullSystem::marginalizeFrame(shared_ptr<Frame> &frame)                                                      FullSystem.cc:602-645
+// ------------------------------------------------------------------------------------------------------------------------------------
+void GpuBackend::marginalizeFrame(FullSystem &fs, shared_ptr<Frame> &frame) {
+    EnergyFunctional &ef = *fs.ef;
+    shared_ptr<FrameHessian> fh = frame->frameHessian;
+    const int F = (int) fs.frames.size(), n = CPARS + 8 * F, nd = n - 8;
+    int col = -1;
+    for (int f = 0; f < F; f++) if (fs.frames[f].get() == frame.get()) col = f;
+    const bool resident = residentValid_ && (int) rowFrames_.size() == F && col >= 0 && rowFrames_[col].get() == frame.get();
+    if (!resident || (int) ef.HM.rows() != n) { fs.marginalizeFrame(frame); return; }          // no window of these frames on the device: the reference's member
+    // ---- EnergyFunctional::marginalizeFrame: the arithmetic (:80-136) on the device, on ef's own prior ----
+    {
+        std::vector<double> HM((size_t) n * n), bM((size_t) n), oH((size_t) nd * nd), ob((size_t) nd);
+        for (int i = 0; i < n; i++) { for (int j = 0; j < n; j++) HM[(size_t) i * n + j] = ef.HM(i, j); bM[i] = ef.bM[i]; }
+        throwOn(ldso_ba_set_prior(ba_, HM.data(), bM.data()), "ldso_ba_set_prior");
+        throwOn(ldso_ba_marginalize_frame(ba_, col, oH.data(), ob.data()), "ldso_ba_marginalize_frame");
+        ef.HM.resize(nd, nd); ef.bM.resize(nd);
+        for (int i = 0; i < nd; i++) { for (int j = 0; j < nd; j++) ef.HM(i, j) = oH[(size_t) i * nd + j]; ef.bM[i] = ob[i]; }
+    }
+    // ... its bookkeeping (:138-150)
+    for (unsigned int i = fh->idx; i + 1 < ef.frames.size(); i++) { ef.frames[i] = ef.frames[i + 1]; ef.frames[i]->idx = i; }
+    ef.frames.pop_back();
+    ef.nFrames--;
+    EFIndicesValid = false; EFAdjointsValid = false; EFDeltaValid = false;
+    ef.makeIDX();
+    // ---- drop all observations of existing points in that frame (:607-632): column `col` of the resident rows ----
+    for (Row &row : rows_) {
+        PointFrameResidual *rp = row.res[col];
+        if (!rp || row.host == col) continue;
+        if (!(row.feat->status == Feature::FeatureStatus::VALID && row.feat->point && row.feat->point->status == Point::PointStatus::ACTIVE)) continue;
+        PointHessian &ph = *row.ph;
+        shared_ptr<PointFrameResidual> r;
+        for (shared_ptr<PointFrameResidual> &q : ph.residuals) if (q.get() == rp) { r = q; break; }
+        if (!r) continue;
+        if (ph.lastResiduals[0].first == r) ph.lastResiduals[0].first = nullptr;
+        else if (ph.lastResiduals[1].first == r) ph.lastResiduals[1].first = nullptr;
+        ef.dropResidual(r);
+        row.res[col] = nullptr; row.mask &= ~(1u << col);
+    }
+    // ---- :634-644 ----
+    frame->ReleaseAll();
+    ldso::internal::deleteOutOrder<shared_ptr<Frame>>(fs.frames, frame);
+    for (unsigned int i = 0; i < fs.frames.size(); i++) fs.frames[i]->frameHessian->idx = i;
+    fs.setPrecalcValues();
+    ef.setAdjointsF(fs.Hcalib->mpCH);
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------
 // Point activation: the optimizeImmaturePoint calls of FullSystem::activatePointsMT_Reductor (:1196-1206) as one device call, then the
 // object construction of optimizeImmaturePoint's tail (:977-1008) on the host.
 // ------------------------------------------------------------------------------------------------------------------------------------
 void GpuBackend::activatePoints(FullSystem &fs, std::vector<shared_ptr<ImmaturePoint>> &toOptimize, std::vector<shared_ptr<PointHessian>> &optimized) {
     optimized.assign(toOptimize.size(), nullptr);
     if (toOptimize.empty()) return;
-    std::vector<shared_ptr<PointHessian>> allPoints; std::vector<shared_ptr<PointFrameResidual>> flat;
-    if (uploadWindow(fs, allPoints, flat) == 0) throw std::runtime_error("GpuBackend::activatePoints: the window holds no active point yet (activate on the host)");
+    std::vector<shared_ptr<PointHessian>> allPoints;
+    if (uploadWindow(fs, allPoints) == 0) throw std::runtime_error("GpuBackend::activatePoints: the window holds no active point yet (activate on the host)");
     const int F = (int) fs.frames.size();
     std::vector<ldso_immature_t> in(toOptimize.size());
     for (size_t k = 0; k < toOptimize.size(); k++) {

@@ -21,6 +21,7 @@
 #pragma once
 #include <map>
 #include <memory>
+#include <chrono>
 #include <mutex>
 #include <vector>
 
@@ -47,10 +48,28 @@ public:
     // optimize() leaves behind - flagPointsForRemoval re-linearises the residuals it marginalises (FullSystem.cc:1241-1250: r->linearize writes
     // r->J itself) and the next optimize() re-linearises everything.  On for host code that still accumulates from r->J.
     bool writeBackJacobians = false;
+    // The window stays RESIDENT on the device between two optimize() calls: the second call uploads a delta (ldso_ba_update_window) - which frames and points
+    // stayed, one bit per residual, the records of the freshly activated points - instead of flattening and uploading 2000 points and 12 000 residuals again.
+    // What the delta path relies on is what LDSO does: between two optimize() calls the host does not change a SURVIVING point's u / v / colours / inverse depth
+    // or the state of its residuals (it only removes points and residuals, adds one residual per point for the new key frame, and activates new points;
+    // FullSystem::makeKeyFrame :429-640).  Residual counts are checked per point and a point whose residual list changed in another way is re-read in full;
+    // invalidateWindow() (or residentWindow = false) forces the next optimize() to upload everything.
+    bool residentWindow = true;
+    void invalidateWindow() { residentValid_ = false; }
+    bool lastUploadWasDelta = false;
+    int uploadsDelta = 0, uploadsFresh = 0;          // how the windows of this backend's lifetime went over
+    // FullSystem::activeResiduals is only read inside FullSystem::optimize itself (FullSystem.cc:735-1770: linearizeAll / applyRes / setNewFrameEnergyTH - all of
+    // which run on the device here); filling it costs 12 000 shared_ptr copies per call.  On for host code that wants the list anyway.
+    bool fillActiveResiduals = false;
     int lastIterations = 0;              // GN iterations the device executed in the last optimize()
     double lastUploadSeconds[6] = {0, 0, 0, 0, 0, 0};  // of that: settings + image slots | flatten (host walk) | ldso_ba_set_window | set_point_stats | set_frames | set_prior
     double lastOptimizeSeconds[4] = {0, 0, 0, 0};      // wall clock of the last optimize(): flatten + upload | device | fetch | write-back into the objects
 
+    // void FullSystem::marginalizeFrame(shared_ptr<Frame> &frame) (FullSystem.cc:602-645): the Schur complement of EnergyFunctional::marginalizeFrame
+    // (EnergyFunctional.cc:72-151) through ldso_ba_marginalize_frame on the window optimize() left resident (ef's H_M / b_M go up first: 29 KB), the reference's
+    // bookkeeping on the host - with the residuals that target the frame found through the resident window's host view (one pointer per point) instead of a
+    // weak_ptr::lock() per residual of the window.
+    void marginalizeFrame(FullSystem &fs, shared_ptr<Frame> &frame);
     // ---- point marginalisation on the device (what follows optimize() in makeKeyFrame, FullSystem.cc:526-536) ----------------------------
     // flagPointsForRemoval: the POLICY of FullSystem::flagPointsForRemoval (FullSystem.cc:1208-1270: which points go OUT / OUTLIER / MARGINALIZED) without its inner
     // loop (:1241-1250: resetOOB + linearize + applyRes + fixLinearizationF of every residual of a point that gets marginalised) - the device pass of
@@ -111,7 +130,18 @@ private:
     std::map<ldso_tracker_t *, TrackerPyr> trackerPyr_;              // guarded by handlesMutex_
     PyrRef pyramidOf(const shared_ptr<FrameHessian> &fh);
     void releasePyramids(FullSystem &fs);
-    std::vector<int32_t> resBegin_;                                  // last upload: the residuals of point k are flat[resBegin_[k] .. resBegin_[k + 1])
+    std::vector<int32_t> resBegin_;                                  // last upload: the residuals of point k are flat_[resBegin_[k] .. resBegin_[k + 1])
+    // the resident window as the host sees it: one row per point in device order, its residual objects by window column (= target frame index)
+    static constexpr int kMaxCols = 16;
+    struct Row { PointHessian *ph; Feature *feat; uint32_t mask; int host; PointFrameResidual *res[kMaxCols]; };
+    std::vector<Row> rows_;
+    std::vector<shared_ptr<Frame>> rowFrames_;                       // the frame of every column of the resident window (held: the rows point into their features)
+    std::vector<PointFrameResidual *> flat_;                         // the residual objects in the device's flat order (point-major, target-ascending)
+    bool residentValid_ = false;
+    std::chrono::steady_clock::time_point lapT_;
+    double lapSince() { const auto n = std::chrono::steady_clock::now(); const double d = std::chrono::duration<double>(n - lapT_).count(); lapT_ = n; return d; }
+    bool uploadDelta(FullSystem &fs, const std::vector<int32_t> &slots, std::vector<shared_ptr<PointHessian>> &allPoints);
+    void uploadFresh(FullSystem &fs, const std::vector<int32_t> &slots, std::vector<shared_ptr<PointHessian>> &allPoints, bool trustIndices);
     int device_, maxFrames_, maxPoints_;
     // whose pyramid a tracker handle currently holds as "new frame": keyed by Frame::id, not by address (LDSO releases the FrameHessian of a
     // non-key frame after tracking, the allocator may hand the same address to the next frame)
@@ -121,7 +151,7 @@ private:
     std::mutex handlesMutex_;
     bool newFrameResident(ldso_tracker_t *t, const shared_ptr<FrameHessian> &fh);
     ldso_tracker_t *trackerOf(CoarseTracker &tr);
-    int uploadWindow(FullSystem &fs, std::vector<shared_ptr<PointHessian>> &allPoints, std::vector<shared_ptr<PointFrameResidual>> &flat, bool trustIndices = false);
+    int uploadWindow(FullSystem &fs, std::vector<shared_ptr<PointHessian>> &allPoints, bool trustIndices = false);
     void syncImageSlots(FullSystem &fs, std::vector<int32_t> &slots);
 };
 

@@ -509,6 +509,39 @@ def adapter_line(name="C3"):
             out["split_ms" if not wb else "split_ms_with_jacobian_write_back"] = {"flatten_upload": round(sp[0] * 1e3, 3), "device": round(sp[1] * 1e3, 3), "fetch": round(sp[2] * 1e3, 3),
                                                                                   "write_back": round(sp[3] * 1e3, 3)}
             out["iterations_executed"] = its
+        # the window RESIDENT between two optimize() calls (GpuBackend::residentWindow, ldso_ba_update_window): (a) a second optimize(6) on the same graph - every
+        # point survives, nothing fresh: the floor of the delta path; (b) key frames in FullSystem::makeKeyFrame's order (tests/adapter_sequence_common.py: the oldest
+        # frame leaves, a new one arrives with one residual per surviving point, ~10 % of the points are freshly activated) - optimize()'s wall time per key frame
+        A.set_write_back_jacobians(False)
+        ts2, sp2, up2 = [], [], []
+        for rep in range(5):
+            r = pr.RefWindow(win); r.fs_attach()
+            A.optimize(r, 6)
+            t0 = time.perf_counter(); A.optimize(r, 6); ts2.append(time.perf_counter() - t0); sp2.append(A.last_optimize_times().copy()); up2.append(A.last_upload_times().copy())
+            r.close()
+        sp = np.median(np.array(sp2[1:]), axis=0); up = np.median(np.array(up2[1:]), axis=0)
+        out["resident_window"] = {"second_optimize_on_the_same_graph_ms": round(float(np.median(ts2[1:])) * 1e3, 3),
+                                  "split_ms": {"flatten_upload": round(sp[0] * 1e3, 3), "device": round(sp[1] * 1e3, 3), "fetch": round(sp[2] * 1e3, 3), "write_back": round(sp[3] * 1e3, 3)},
+                                  "flatten_upload_split_ms": dict(zip(("settings_images", "host_walk", "update_window", "set_point_stats", "set_frames", "set_prior"), [round(float(v) * 1e3, 3) for v in up]))}
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from adapter_sequence_common import run_sequence
+            Kseq = 4
+            wseq = synth.make_config(name, extra_frames=Kseq)
+            for resident in (True, False):
+                A2 = pr.GpuAdapter(max_frames=win.F + 2, max_points=2 * win.P)
+                A2.set_resident_window(resident)
+                times, ups = [], []
+                run_sequence(wseq, Kseq, adapter=A2, max_frames=win.F, per_frame=max(120, win.P // 20), on_keyframe=lambda rec: (times.append(A2.last_optimize_times().copy()), ups.append(A2.last_upload_times().copy())))
+                d_, f_ = A2.upload_counts()
+                A2.close()
+                tt = np.array(times[1:]); uu = np.array(ups[1:])          # the first key frame holds the handle's first (full) upload
+                out["resident_window"]["keyframe_sequence_resident" if resident else "keyframe_sequence_full_upload"] = {
+                    "key_frames_timed": int(len(tt)), "optimize_ms_median": round(float(np.median(tt.sum(axis=1))) * 1e3, 3),
+                    "split_ms_median": dict(zip(("flatten_upload", "device", "fetch", "write_back"), [round(float(v) * 1e3, 3) for v in np.median(tt, axis=0)])),
+                    "host_walk_ms_median": round(float(np.median(uu[:, 1])) * 1e3, 3), "uploads_delta_full": [d_, f_]}
+        except Exception as e:          # informational leg
+            out["resident_window"]["keyframe_sequence_error"] = repr(e)[:200]
         tr = []
         for rep in range(3):
             r = pr.RefWindow(win); r.fs_attach()

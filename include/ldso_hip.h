@@ -97,6 +97,23 @@ int ldso_ba_get_image(ldso_ba_t *h, int slot, float *out_w_h_3);
  * (R entries, may be NULL) are read where residuals[i].is_linearized != 0. */
 int ldso_ba_set_window(ldso_ba_t *h, int F, const int32_t *image_slot, int P, const ldso_point_t *points,
                        int R, const ldso_residual_t *residuals, const ldso_rawjac_t *linJ, const float *lin_res_toZeroF);
+/* The window of the next optimize() as a DELTA against the resident one: what the reference's own maintenance calls do to the window between two key
+ * frames, in one call on the order EnergyFunctional::makeIDX produces (EnergyFunctional.cc: insertFrame :32, insertResidual :26, dropResidual :63,
+ * removePoint :153, dropPointsF :224, marginalizeFrame :72, makeIDX :380).  Nothing of the surviving points crosses PCIe: their geometry, colours, inverse
+ * depths, maxRelBaseline / numGoodResiduals and per-residual state / energy / activity are taken from the resident window on the device.
+ *   frame_from[f]  old index of new frame f (old frames that appear nowhere were marginalised; survivors keep their order), -1 = insertFrame (last)
+ *   point_from[i]  old row of new point i (old rows that appear nowhere were removed / dropped / marginalised; survivors keep their order),
+ *                  -1 - k = the k-th fresh point (insertPoint), numbered in window order
+ *   res_mask[i]    bit t: point i has a residual with target frame t (new numbering).  Set where the resident slot is empty = insertResidual (IN, energy 0,
+ *                  isNew); clear where it is occupied = dropResidual
+ *   fresh[n_fresh], fresh_res[n_fresh_res], fresh_mrb, fresh_ngr   the new points as in ldso_ba_set_window (host = new frame index), their residuals
+ *                  point-major and target-ascending with .point = index into fresh, PointHessian::maxRelBaseline / numGoodResiduals
+ * Flat residual order of the new window: point-major, target-ascending.  The result equals a fresh ldso_ba_set_window + ldso_ba_set_point_stats of the same
+ * objects byte for byte (tests/test_resident_gpu.py); ldso_ba_set_frames / ldso_ba_set_prior follow as after ldso_ba_set_window.  Windows with linearised
+ * residuals, shards and the first window of a handle go through ldso_ba_set_window. */
+int ldso_ba_update_window(ldso_ba_t *h, int F, const int32_t *image_slot, const int32_t *frame_from, int P, const int32_t *point_from, const uint32_t *res_mask,
+                          int n_fresh, const ldso_point_t *fresh, int n_fresh_res, const ldso_residual_t *fresh_res, const float *fresh_mrb,
+                          const int32_t *fresh_ngr);
 /* Frame / calibration state (FrameHessian::setState..., CalibHessian::setValue) and the
  * marginalisation prior HM,bM ((8F+4)^2 row-major, (8F+4); NULL = zero).  ldso_ba_set_frames also performs
  * EnergyFunctional::setAdjointsF (EnergyFunctional.cc:431-489) and FullSystem::setPrecalcValues

@@ -165,6 +165,22 @@ class BA:
         self.F, self.P, self.R = len(sl), len(pts), len(res)
         _chk(self.L.ldso_ba_set_window(self.h, C.c_int(self.F), _p(sl), C.c_int(self.P), _p(pts), C.c_int(self.R), _p(res), _p(J), _p(rt)))
 
+    def set_point_stats(self, max_rel_baseline, num_good_residuals):
+        a = np.ascontiguousarray(max_rel_baseline, np.float32); b = np.ascontiguousarray(num_good_residuals, np.int32)
+        assert len(a) == len(b) == self.P
+        _chk(self.L.ldso_ba_set_point_stats(self.h, _p(a), _p(b)))
+
+    def update_window(self, image_slots, frame_from, point_from, res_mask, fresh=None, fresh_res=None, fresh_mrb=None, fresh_ngr=None):
+        """ldso_ba_update_window: the next window as a delta against the resident one (include/ldso_hip.h)."""
+        sl = np.ascontiguousarray(image_slots, np.int32); ff = np.ascontiguousarray(frame_from, np.int32)
+        pf = np.ascontiguousarray(point_from, np.int32); mk = np.ascontiguousarray(res_mask, np.uint32)
+        assert len(sl) == len(ff) and len(pf) == len(mk)
+        nf = 0 if fresh is None else len(fresh); nr = 0 if fresh_res is None else len(fresh_res)
+        fp = np.ascontiguousarray(fresh) if nf else None; fr = np.ascontiguousarray(fresh_res) if nr else None
+        fm = np.ascontiguousarray(fresh_mrb, np.float32) if nf else None; fg = np.ascontiguousarray(fresh_ngr, np.int32) if nf else None
+        _chk(self.L.ldso_ba_update_window(self.h, C.c_int(len(sl)), _p(sl), _p(ff), C.c_int(len(pf)), _p(pf), _p(mk), C.c_int(nf), _p(fp), C.c_int(nr), _p(fr), _p(fm), _p(fg)))
+        self.F, self.P, self.R = len(sl), len(pf), int(sum(bin(int(m)).count("1") for m in mk))
+
     def set_frames(self, frames, calib):
         fr = np.ascontiguousarray(frames)
         c = np.ascontiguousarray(calib)

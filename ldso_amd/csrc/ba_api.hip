@@ -202,6 +202,83 @@ __global__ __launch_bounds__(256) void k_point_stats(PtRec *__restrict__ a, PtRe
     const float m = mrb[i]; const int32_t g = ngr[i];
     a[i].maxRelBS = m; a[i].numGood = g; b[i].maxRelBS = m; b[i].numGood = g;
 }
+// ---------------------------------------------------------------------------------------------------------------------------------------------------
+// ldso_ba_update_window: the staging image a full ldso_ba_set_window of the SAME window would have uploaded, built ON THE DEVICE from the resident window
+// (the applied set) and a small delta - which frames stay (EnergyFunctional::marginalizeFrame / insertFrame), which points stay and in which order (removePoint,
+// dropPointsF, makeIDX), which residuals a point has (insertResidual / dropResidual as one bit per target frame) and the records of the fresh points.  One thread
+// per (point, slot).  What is carried over is exactly what the host objects carry between two optimize() calls: u, v, priorF, colour / weights, the inverse depth,
+// maxRelBaseline / numGoodResiduals, and per residual state_state, state_energy, isActive, isNew - everything else starts as ldso_ba_set_window starts it, so
+// that the resident window and a fresh upload of the same objects are the same bytes (tests/test_resident_gpu.py).
+// ---------------------------------------------------------------------------------------------------------------------------------------------------
+struct WinDelta {
+    // the resident window (read)
+    const PtGeo *oGeo; const PtCw *oPcw; const int32_t *oHost; const SlotTab *oTab; const SlotRec *oSlot; const PtRec *oPt;
+    int oF, oFS, oP;
+    // the delta (device copies inside the staging arena)
+    const int32_t *frameFrom;      // [F]  old index of new frame f, -1 = inserted
+    const int32_t *pointFrom;      // [P]  old row of new point i, -1 - k = the k-th fresh point
+    const uint32_t *resMask;       // [P]  bit t: the point has a residual whose target is frame t
+    const int32_t *resBegin;       // [P + 1] flat index of the point's first residual (flat order: point-major, target-ascending)
+    const ldso_point_t *fresh; const ldso_residual_t *freshRes; const int32_t *freshResBegin;      // the fresh points, their residuals (target-ascending), first residual of fresh point k
+    const float *freshMrb; const int32_t *freshNgr;
+    int F, FS, P;
+    // the image (written)
+    PtGeo *geo; PtCw *pcw; int32_t *phost; SlotTab *tab; SlotRec *sr; float *mrb; int32_t *ngr;
+};
+__global__ __launch_bounds__(256) void k_win_rebuild(WinDelta W) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= W.P * W.FS) return;
+    const int row = q / W.FS, col = q - row * W.FS;
+    const int from = W.pointFrom[row];
+    const uint32_t mask = W.resMask[row];
+    SlotTab t{-1, 0, 0, -1};
+    SlotRec r;
+#pragma unroll
+    for (int k = 0; k < 8; k++) { r.e[k].jp = 0.0f; r.e[k].m.i = 0; }
+    r.e[LD_SM_STATE].m.i = LDSO_RES_OOB;
+    if (col < W.F && ((mask >> col) & 1u)) {
+        const int below = __popc(mask & ((1u << col) - 1u));
+        t.rflat = W.resBegin[row] + below;
+        const int oc = (from >= 0) ? W.frameFrom[col] : -1;
+        if (from >= 0) {
+            const size_t os = (size_t) from * W.oFS + (oc >= 0 ? oc : 0);
+            if (oc >= 0 && W.oTab[os].rflat >= 0) {          // the residual was there: its state lives on
+                const SlotRec o = W.oSlot[os];
+                t.rnew = W.oTab[os].rnew;
+                r.e[LD_SM_STATE].m.i = o.e[LD_SM_STATE].m.i; r.e[LD_SM_ACTIVE].m.i = o.e[LD_SM_ACTIVE].m.i; r.e[LD_SM_ENERGY].m.f = o.e[LD_SM_ENERGY].m.f;
+            } else {                                          // insertResidual for a point of the window (FullSystem.cc:447-470: state IN, energy 0, not active yet)
+                t.rnew = 1;
+                r.e[LD_SM_STATE].m.i = LDSO_RES_IN; r.e[LD_SM_ACTIVE].m.i = 0; r.e[LD_SM_ENERGY].m.f = 0.0f;
+            }
+        } else {
+            const ldso_residual_t fr = W.freshRes[W.freshResBegin[-1 - from] + below];
+            t.rnew = fr.is_new ? 1 : 0;
+            r.e[LD_SM_STATE].m.i = fr.state_state; r.e[LD_SM_ACTIVE].m.i = fr.is_active ? 1 : 0; r.e[LD_SM_ENERGY].m.f = fr.state_energy;
+        }
+    }
+    W.tab[q] = t; W.sr[q] = r;
+    if (col < 8) W.pcw[(size_t) row * 8 + col] = (from >= 0) ? W.oPcw[(size_t) from * 8 + col] : PtCw{W.fresh[-1 - from].color[col], W.fresh[-1 - from].weights[col]};
+    if (col == 0) {
+        PtGeo g;
+        memset(&g, 0, sizeof(g));
+        int host;
+        if (from >= 0) {
+            const PtGeo o = W.oGeo[from];
+            g.u = o.u; g.v = o.v; g.priorF = o.priorF; g.idepth = o.idepth; g.idepth_zero = o.idepth; g.idepth_backup = o.idepth;          // setIdepthZero(idepth) after every optimize()
+            const int oh = W.oHost[from];
+            host = -1;
+            for (int f = 0; f < W.F; f++) host = (W.frameFrom[f] == oh) ? f : host;
+            W.mrb[row] = W.oPt[from].maxRelBS; W.ngr[row] = W.oPt[from].numGood;
+        } else {
+            const ldso_point_t &p = W.fresh[-1 - from];
+            g.u = p.u; g.v = p.v; g.priorF = p.priorF; g.idepth = p.idepth; g.idepth_zero = p.idepth_zero; g.idepth_backup = p.idepth;
+            host = p.host;
+            W.mrb[row] = W.freshMrb[-1 - from]; W.ngr[row] = W.freshNgr[-1 - from];
+        }
+        W.geo[row] = g; W.phost[row] = host;
+    }
+}
+
 // host side of the arena: reserve (16-byte aligned) room, remember where it goes
 struct WinStage {
     char *base; size_t cap, used; WinXfer *tab; int n;
@@ -210,6 +287,13 @@ struct WinStage {
         if (n >= LD_XFER_MAX || used + bytes > cap) return nullptr;
         T *p = reinterpret_cast<T *>(base + used);
         if (count) { tab[n].dst = dst; tab[n].src = used; tab[n].words = count * sizeof(T) / 4; n++; }
+        used += bytes;
+        return p;
+    }
+    template <class T> T *raw(size_t count) {          // room without a destination (operands of k_win_rebuild)
+        const size_t bytes = (count * sizeof(T) + 15) & ~(size_t) 15;
+        if (used + bytes > cap) return nullptr;
+        T *p = reinterpret_cast<T *>(base + used);
         used += bytes;
         return p;
     }
@@ -613,6 +697,165 @@ int ldso_ba_set_point_stats(ldso_ba_t *H, const float *maxRelBaseline, const int
     CHK(hipGetLastError());
     CHK(hipStreamSynchronize(H->stream));          // the arena is handed back to the next ldso_ba_set_window
     return LDSO_OK;
+}
+
+// The window of the next optimize() as a DELTA against the resident one - what the reference's own maintenance calls do to the window between two key frames
+// (EnergyFunctional.cc: insertFrame :32, insertResidual :26, dropResidual :63, removePoint :153, dropPointsF :224, marginalizeFrame :72, makeIDX :380), expressed
+// in one call on the order makeIDX produces:
+//   frame_from[f]   the old index of new frame f (frames that appear nowhere were marginalised), -1 = insertFrame
+//   point_from[i]   the old row of new point i (rows that appear nowhere were removed / dropped / marginalised), -1 - k = the k-th fresh point (insertPoint);
+//                   surviving points keep their relative order (makeIDX walks frames, then the host frame's features: both orders are stable)
+//   res_mask[i]     bit t set: point i has a residual with target frame t (NEW numbering).  Against the resident slots this says insertResidual (bit set, slot
+//                   empty: the residual starts IN, energy 0, isNew) and dropResidual (slot occupied, bit clear)
+//   fresh / fresh_res / fresh_mrb / fresh_ngr   the new points in the layout of ldso_ba_set_window (host = new frame index), their residuals point-major and
+//                   target-ascending with .point = index into `fresh`, PointHessian::maxRelBaseline / numGoodResiduals
+// The flat residual order of the new window (ldso_ba_get_residuals ...) is point-major, target-ascending.  The result is the window a fresh ldso_ba_set_window +
+// ldso_ba_set_point_stats of the same objects produces, byte for byte; ldso_ba_set_frames / ldso_ba_set_prior follow as they do there.
+int ldso_ba_update_window(ldso_ba_t *H, int F, const int32_t *image_slot, const int32_t *frame_from, int P, const int32_t *point_from, const uint32_t *res_mask,
+                          int n_fresh, const ldso_point_t *fresh, int n_fresh_res, const ldso_residual_t *fresh_res, const float *fresh_mrb, const int32_t *fresh_ngr) {
+    REQ(H && image_slot && frame_from && point_from && res_mask, "ldso_ba_update_window: null argument");
+    REQ(H->D.P > 0 && !H->pendingApply, "ldso_ba_update_window: no resident window, or a linearisation is pending (ldso_ba_apply_res first)");
+    REQ(!H->hasL, "ldso_ba_update_window: the resident window holds linearised residuals (use ldso_ba_set_window)");
+    REQ(H->D.pBegin == 0 && H->D.pEnd == H->D.P, "ldso_ba_update_window: sharded window");
+    REQ(F >= 2 && F <= H->maxF && P >= 1 && P <= H->maxP && n_fresh >= 0 && n_fresh_res >= 0, "ldso_ba_update_window: window exceeds the handle's capacity");
+    REQ(n_fresh == 0 || (fresh && fresh_mrb && fresh_ngr), "ldso_ba_update_window: fresh points without records");
+    REQ(n_fresh_res == 0 || fresh_res, "ldso_ba_update_window: fresh residuals without records");
+    CHK(hipSetDevice(H->device));
+    const BaDims oD = H->D;
+    const int FS = (F + 7) / 8 * 8;
+    const size_t PS = (size_t) P * FS;
+    // ---- validate the delta on the host (indices only; nothing of the resident data is read back) ----
+    {
+        std::vector<char> seen(oD.F, 0);
+        for (int f = 0; f < F; f++) {
+            REQ(frame_from[f] >= -1 && frame_from[f] < oD.F, "ldso_ba_update_window: frame_from out of range");
+            if (frame_from[f] >= 0) { REQ(!seen[frame_from[f]], "ldso_ba_update_window: an old frame appears twice"); seen[frame_from[f]] = 1; }
+            REQ(f == 0 || frame_from[f] < 0 || frame_from[f - 1] < frame_from[f], "ldso_ba_update_window: surviving frames must keep their order, inserted frames come last");
+            REQ(image_slot[f] >= 0 && image_slot[f] < H->maxF && H->imgSlots[image_slot[f]] != nullptr, "ldso_ba_update_window: image slot not set");
+        }
+    }
+    std::vector<int32_t> resBegin((size_t) P + 1), freshResBegin((size_t) n_fresh + 1, 0), newHost((size_t) P);
+    {
+        std::vector<int32_t> oldToNew(oD.F, -1);
+        for (int f = 0; f < F; f++) if (frame_from[f] >= 0) oldToNew[frame_from[f]] = f;
+        int lastOld = -1, nextFresh = 0, acc = 0;
+        const uint32_t fmask = (F >= 32) ? 0xFFFFFFFFu : ((1u << F) - 1u);
+        for (int k = 0; k < n_fresh; k++) freshResBegin[k + 1] = 0;
+        int fr = 0;
+        for (int i = 0; i < P; i++) {
+            const int from = point_from[i];
+            int host;
+            if (from >= 0) {
+                REQ(from < oD.P && from > lastOld, "ldso_ba_update_window: surviving points must keep their order");
+                lastOld = from;
+                host = oldToNew[H->h_phost[from]];
+                REQ(host >= 0, "ldso_ba_update_window: a surviving point is hosted by a frame that left the window");
+            } else {
+                REQ(-1 - from == nextFresh && nextFresh < n_fresh, "ldso_ba_update_window: fresh points must be numbered in window order");
+                host = fresh[nextFresh].host;
+                REQ(host >= 0 && host < F, "ldso_ba_update_window: fresh point host out of range");
+                const int cnt = __builtin_popcount(res_mask[i]);
+                freshResBegin[nextFresh] = fr;
+                for (int c = 0; c < cnt; c++) {
+                    REQ(fr < n_fresh_res && fresh_res[fr].point == nextFresh && !fresh_res[fr].is_linearized && ((res_mask[i] >> fresh_res[fr].target) & 1u)
+                        && (c == 0 || fresh_res[fr - 1].target < fresh_res[fr].target), "ldso_ba_update_window: fresh residuals must be point-major, target-ascending and match res_mask");
+                    fr++;
+                }
+                nextFresh++;
+            }
+            REQ((res_mask[i] & ~fmask) == 0 && !((res_mask[i] >> host) & 1u), "ldso_ba_update_window: res_mask names a frame outside the window or the host itself");
+            REQ(i == 0 || newHost[i - 1] <= host, "ldso_ba_update_window: points must be ordered by host frame (EnergyFunctional::allPoints order)");
+            newHost[i] = host;
+            resBegin[i] = acc; acc += __builtin_popcount(res_mask[i]);
+        }
+        resBegin[P] = acc;
+        freshResBegin[n_fresh] = fr;
+        REQ(nextFresh == n_fresh && fr == n_fresh_res, "ldso_ba_update_window: unused fresh points / residuals");
+    }
+    const int R = resBegin[P];
+    // ---- arena: [table | delta | image]; only table + delta cross PCIe ----
+    auto A16 = [](size_t b) { return (b + 15) & ~(size_t) 15; };
+    const size_t tabBytes = A16(LD_XFER_MAX * sizeof(WinXfer));
+    const size_t deltaBytes = A16((size_t) F * 4) + 2 * A16((size_t) P * 4) + A16(((size_t) P + 1) * 4) + A16((size_t) n_fresh * sizeof(ldso_point_t)) + A16((size_t) n_fresh_res * sizeof(ldso_residual_t))
+                              + A16(((size_t) n_fresh + 1) * 4) + 2 * A16((size_t) n_fresh * 4);
+    const size_t need = tabBytes + deltaBytes + A16((size_t) P * sizeof(PtGeo)) + A16((size_t) P * 8 * sizeof(PtCw)) + A16((size_t) P * 4) + A16(PS * sizeof(SlotTab)) + A16(PS * sizeof(SlotRec))
+                        + 2 * A16((size_t) P * 4) + 64;
+    if (need > H->stageCap) {          // the arena only ever holds staging data: growing it loses nothing of the resident window
+        CHK(hipStreamSynchronize(H->stream));
+        if (H->h_stage) hipHostFree(H->h_stage);
+        if (H->d_stage) hipFree(H->d_stage);
+        H->h_stage = nullptr; H->d_stage = nullptr; H->stageCap = 0; H->stageBusy = false;
+        const size_t cap = need + need / 4;
+        CHK(hipHostMalloc((void **) &H->h_stage, cap));
+        CHK(hipMalloc((void **) &H->d_stage, cap));
+        H->stageCap = cap;
+    }
+    if (H->stageBusy) { CHK(hipStreamSynchronize(H->stream)); H->stageBusy = false; }
+    WinStage W{H->h_stage, H->stageCap, tabBytes, reinterpret_cast<WinXfer *>(H->h_stage), 0};
+    int32_t *hFrameFrom = W.raw<int32_t>(F), *hPointFrom = W.raw<int32_t>(P);
+    uint32_t *hMask = W.raw<uint32_t>(P);
+    int32_t *hResBegin = W.raw<int32_t>((size_t) P + 1);
+    ldso_point_t *hFresh = W.raw<ldso_point_t>(n_fresh);
+    ldso_residual_t *hFreshRes = W.raw<ldso_residual_t>(n_fresh_res);
+    int32_t *hFreshResBegin = W.raw<int32_t>((size_t) n_fresh + 1);
+    float *hMrb = W.raw<float>(n_fresh); int32_t *hNgr = W.raw<int32_t>(n_fresh);
+    REQ(hFrameFrom && hPointFrom && hMask && hResBegin && hFresh && hFreshRes && hFreshResBegin && hMrb && hNgr, "ldso_ba_update_window: staging arena too small (internal)");
+    const size_t upBytes = W.used;
+    memcpy(hFrameFrom, frame_from, (size_t) F * 4); memcpy(hPointFrom, point_from, (size_t) P * 4); memcpy(hMask, res_mask, (size_t) P * 4);
+    memcpy(hResBegin, resBegin.data(), ((size_t) P + 1) * 4); memcpy(hFreshResBegin, freshResBegin.data(), ((size_t) n_fresh + 1) * 4);
+    if (n_fresh) { memcpy(hFresh, fresh, (size_t) n_fresh * sizeof(ldso_point_t)); memcpy(hMrb, fresh_mrb, (size_t) n_fresh * 4); memcpy(hNgr, fresh_ngr, (size_t) n_fresh * 4); }
+    if (n_fresh_res) memcpy(hFreshRes, fresh_res, (size_t) n_fresh_res * sizeof(ldso_residual_t));
+    BaPtrs &B = H->B;
+    // the image region: same destinations, same order, same zero fills as ldso_ba_set_window
+    PtGeo *geo = W.put(B.pgeo, P);
+    PtCw *pcw = W.put(B.pcw, (size_t) P * 8);
+    int32_t *phost = W.put(B.phost, P);
+    SlotTab *tab = W.put(B.rtab, PS);
+    SlotRec *sr = W.put(H->sets[0].slot, PS);
+    REQ(geo && pcw && phost && tab && sr, "ldso_ba_update_window: staging arena too small (internal)");
+    float *mrb = W.raw<float>(P); int32_t *ngr = W.raw<int32_t>(P);
+    REQ(mrb && ngr, "ldso_ba_update_window: staging arena too small (internal)");
+    auto dev = [&](const void *hp) { return H->d_stage + (reinterpret_cast<const char *>(hp) - H->h_stage); };
+    WinDelta Wd;
+    const ResSet &So = H->sets[H->cur];
+    Wd.oGeo = B.pgeo; Wd.oPcw = B.pcw; Wd.oHost = B.phost; Wd.oTab = B.rtab; Wd.oSlot = So.slot; Wd.oPt = So.pt; Wd.oF = oD.F; Wd.oFS = oD.FS; Wd.oP = oD.P;
+    Wd.frameFrom = (const int32_t *) dev(hFrameFrom); Wd.pointFrom = (const int32_t *) dev(hPointFrom); Wd.resMask = (const uint32_t *) dev(hMask); Wd.resBegin = (const int32_t *) dev(hResBegin);
+    Wd.fresh = (const ldso_point_t *) dev(hFresh); Wd.freshRes = (const ldso_residual_t *) dev(hFreshRes); Wd.freshResBegin = (const int32_t *) dev(hFreshResBegin);
+    Wd.freshMrb = (const float *) dev(hMrb); Wd.freshNgr = (const int32_t *) dev(hNgr);
+    Wd.F = F; Wd.FS = FS; Wd.P = P;
+    Wd.geo = (PtGeo *) dev(geo); Wd.pcw = (PtCw *) dev(pcw); Wd.phost = (int32_t *) dev(phost); Wd.tab = (SlotTab *) dev(tab); Wd.sr = (SlotRec *) dev(sr); Wd.mrb = (float *) dev(mrb); Wd.ngr = (int32_t *) dev(ngr);
+    // from here on the handle describes the new window (a failure leaves it without one, as in ldso_ba_set_window)
+    struct WinGuard { ldso_ba *H; bool ok; ~WinGuard() { if (!ok) { H->D.P = 0; H->D.R = 0; H->R = 0; H->appliedValid = false; H->itemValid = false; } } } guard{H, false};
+    BaDims &D = H->D;
+    D.F = F; D.FS = FS; D.P = P; D.R = R; D.n = 8 * F + 4; D.GS = 8 * D.FS + LD_GEXTRA; D.w = H->w; D.h = H->h; D.nsg = D.FS / 8;
+    D.pBegin = 0; D.pEnd = P; D.wM3G = (float) (H->w - 3); D.hM3G = (float) (H->h - 3); D.nL = 0;
+    H->GSP = (D.GS + 15) / 16 * 16;
+    H->R = R;
+    H->imageSlot.assign(image_slot, image_slot + F);
+    for (int f = 0; f < F; f++) B.img[f] = H->imgSlots[image_slot[f]];
+    H->h_phost.assign(newHost.begin(), newHost.end());
+    H->flat2slot.assign(R, -1);
+    for (int i = 0; i < P; i++) { int k = resBegin[i]; for (int t = 0; t < F; t++) if ((res_mask[i] >> t) & 1u) H->flat2slot[k++] = (int32_t) ((size_t) i * FS + t); }
+    H->hasL = false; H->cur = 0; H->pendingApply = false; H->appliedValid = false; H->itemValid = false;
+    bool okT = W.again(H->sets[1].slot, sr, PS);
+    for (int s_ = 0; s_ < 2; s_++) {
+        ResSet &S = H->sets[s_];
+        okT = okT && W.zero(S.pt, (size_t) P) && W.zero(S.acc, (size_t) P) && W.zero(S.G, (size_t) P * D.GS);
+    }
+    okT = okT && W.zero(B.HM, (size_t) D.n * D.n) && W.zero(B.bM, (size_t) D.n) && W.zero(B.scalars, (size_t) 16) && W.zero(B.scPart, (size_t) LD_SC_SPLITS * H->GSP * H->GSP);
+    REQ(okT, "ldso_ba_update_window: upload table overflow (internal)");
+    H->hasPrior = false;
+    CHK(hipMemcpyAsync(H->d_stage, H->h_stage, upBytes, hipMemcpyHostToDevice, H->stream));
+    hipLaunchKernelGGL(k_win_rebuild, dim3((unsigned) ((PS + 255) / 256)), dim3(256), 0, H->stream, Wd);
+    CHK(hipGetLastError());
+    hipLaunchKernelGGL(k_win_scatter, dim3(256), dim3(256), 0, H->stream, (const char *) H->d_stage, W.n);
+    CHK(hipGetLastError());
+    hipLaunchKernelGGL(k_point_stats, dim3((unsigned) ((P + 255) / 256)), dim3(256), 0, H->stream, H->sets[0].pt, H->sets[1].pt, (const float *) Wd.mrb, (const int32_t *) Wd.ngr, P);
+    CHK(hipGetLastError());
+    CHK(hipStreamSynchronize(H->stream));
+    const int rc_ = build_chunks(H);
+    guard.ok = (rc_ == LDSO_OK);
+    return rc_;
 }
 
 // Points per workgroup of the fused linearisation.  0 (default): the smallest chunk that keeps ONE window's grid within one workgroup per CU

@@ -398,6 +398,14 @@ class GpuAdapter:
     def pyramids_built(self) -> int:
         return int(self.A.adp_pyramids_built(self.h))
 
+    def set_resident_window(self, on: bool):
+        self.A.adp_set_resident_window(self.h, C.c_int(1 if on else 0))
+
+    def upload_counts(self):
+        d, f = C.c_int(), C.c_int()
+        self.A.adp_upload_counts(self.h, C.byref(d), C.byref(f))
+        return d.value, f.value
+
     def set_write_back_jacobians(self, on: bool):
         self.A.adp_set_write_back_jacobians(self.h, C.c_int(1 if on else 0))
 
