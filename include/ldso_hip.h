@@ -114,6 +114,26 @@ int ldso_ba_set_window(ldso_ba_t *h, int F, const int32_t *image_slot, int P, co
 int ldso_ba_update_window(ldso_ba_t *h, int F, const int32_t *image_slot, const int32_t *frame_from, int P, const int32_t *point_from, const uint32_t *res_mask,
                           int n_fresh, const ldso_point_t *fresh, int n_fresh_res, const ldso_residual_t *fresh_res, const float *fresh_mrb,
                           const int32_t *fresh_ngr);
+/* The same delta recorded call by call, as the reference edits its window (EnergyFunctional.cc; host-side bookkeeping until the commit, which applies the
+ * edit as ONE ldso_ba_update_window and rejects an invalid one without touching the resident window).  Frames and residual targets are named by their index
+ * in the RESIDENT window (frames inserted during the edit: the id ldso_ba_insert_frame returns), points by their resident row:
+ *   ldso_ba_remove_frame    EnergyFunctional::marginalizeFrame :72 / FullSystem::marginalizeFrame FullSystem.cc:602-645 - the frame leaves, with the residuals
+ *                           that target it and the points it hosts (the prior's Schur complement is ldso_ba_marginalize_frame)
+ *   ldso_ba_insert_frame    insertFrame :32
+ *   ldso_ba_remove_points   removePoint :153, dropPointsF :224, the points marginalizePointsF :165 absorbed
+ *   ldso_ba_drop_residuals  dropResidual :63          ldso_ba_add_residuals   insertResidual :26 (IN, energy 0, isNew)
+ *   ldso_ba_add_points      insertPoint + its residuals: n points in the layout of ldso_ba_set_window (host / target = frame ids of this edit, residuals[].point =
+ *                           index into the call's points), each placed in front of resident row before_row[i] (number of rows = at the end): makeIDX :380 order
+ *   ldso_ba_window_commit   surviving frames keep their order, inserted frames follow */
+int ldso_ba_window_begin(ldso_ba_t *h);
+int ldso_ba_remove_frame(ldso_ba_t *h, int frame_idx);
+int ldso_ba_insert_frame(ldso_ba_t *h, int image_slot, int *frame_id_out);
+int ldso_ba_remove_points(ldso_ba_t *h, int n, const int32_t *rows);
+int ldso_ba_drop_residuals(ldso_ba_t *h, int n, const int32_t *rows, const int32_t *targets);
+int ldso_ba_add_residuals(ldso_ba_t *h, int n, const int32_t *rows, const int32_t *targets);
+int ldso_ba_add_points(ldso_ba_t *h, int n, const ldso_point_t *points, const int32_t *before_row, int n_res, const ldso_residual_t *residuals,
+                       const float *max_rel_baseline, const int32_t *num_good_residuals);
+int ldso_ba_window_commit(ldso_ba_t *h);
 /* Frame / calibration state (FrameHessian::setState..., CalibHessian::setValue) and the
  * marginalisation prior HM,bM ((8F+4)^2 row-major, (8F+4); NULL = zero).  ldso_ba_set_frames also performs
  * EnergyFunctional::setAdjointsF (EnergyFunctional.cc:431-489) and FullSystem::setPrecalcValues

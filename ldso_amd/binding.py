@@ -181,6 +181,39 @@ class BA:
         _chk(self.L.ldso_ba_update_window(self.h, C.c_int(len(sl)), _p(sl), _p(ff), C.c_int(len(pf)), _p(pf), _p(mk), C.c_int(nf), _p(fp), C.c_int(nr), _p(fr), _p(fm), _p(fg)))
         self.F, self.P, self.R = len(sl), len(pf), int(sum(bin(int(m)).count("1") for m in mk))
 
+    # ---- the same delta call by call (ldso_ba_window_begin .. ldso_ba_window_commit) ----
+    def window_begin(self):
+        _chk(self.L.ldso_ba_window_begin(self.h))
+
+    def remove_frame(self, frame_idx):
+        _chk(self.L.ldso_ba_remove_frame(self.h, C.c_int(frame_idx)))
+
+    def insert_frame(self, image_slot) -> int:
+        fid = C.c_int()
+        _chk(self.L.ldso_ba_insert_frame(self.h, C.c_int(image_slot), C.byref(fid)))
+        return fid.value
+
+    def remove_points(self, rows):
+        a = np.ascontiguousarray(rows, np.int32)
+        _chk(self.L.ldso_ba_remove_points(self.h, C.c_int(len(a)), _p(a)))
+
+    def drop_residuals(self, rows, targets):
+        a = np.ascontiguousarray(rows, np.int32); b = np.ascontiguousarray(targets, np.int32)
+        _chk(self.L.ldso_ba_drop_residuals(self.h, C.c_int(len(a)), _p(a), _p(b)))
+
+    def add_residuals(self, rows, targets):
+        a = np.ascontiguousarray(rows, np.int32); b = np.ascontiguousarray(targets, np.int32)
+        _chk(self.L.ldso_ba_add_residuals(self.h, C.c_int(len(a)), _p(a), _p(b)))
+
+    def add_points(self, points, before_row, residuals, mrb=None, ngr=None):
+        pts = np.ascontiguousarray(points); br = np.ascontiguousarray(before_row, np.int32); res = np.ascontiguousarray(residuals)
+        m = np.ascontiguousarray(mrb, np.float32) if mrb is not None else None; g = np.ascontiguousarray(ngr, np.int32) if ngr is not None else None
+        _chk(self.L.ldso_ba_add_points(self.h, C.c_int(len(pts)), _p(pts), _p(br), C.c_int(len(res)), _p(res), _p(m), _p(g)))
+
+    def window_commit(self, F, P, R):
+        _chk(self.L.ldso_ba_window_commit(self.h))
+        self.F, self.P, self.R = F, P, R
+
     def set_frames(self, frames, calib):
         fr = np.ascontiguousarray(frames)
         c = np.ascontiguousarray(calib)

@@ -100,6 +100,17 @@ struct ldso_ba {
     char *h_down = nullptr;             // pinned arena of the fetch functions (ldso_ba_get_residuals / _points / _frames): device -> pinned host at link speed, one wait
     size_t downCap = 0;
     bool stageBusy = false;            // an asynchronous copy out of h_stage may still be in flight (ldso_ba_set_prior): the next user of the arena waits first
+    // an edit of the resident window being recorded (ldso_ba_window_begin .. ldso_ba_window_commit): frames and residual targets are named by their index in the
+    // RESIDENT window (inserted frames: oF, oF + 1, ...), points by their resident row
+    struct NewPoint { ldso_point_t p; int before; std::vector<ldso_residual_t> res; float mrb; int32_t ngr; };
+    struct WindowEdit {
+        bool active = false;
+        int oF = 0, oP = 0;
+        std::vector<char> frameGone, rowGone;
+        std::vector<int32_t> insertedSlots;
+        std::vector<uint32_t> mask;          // per resident row, bit = edit-time frame id
+        std::vector<NewPoint> fresh;
+    } edit;
     char *h_stage = nullptr, *d_stage = nullptr;
     size_t stageCap = 0;
     // profiling
@@ -856,6 +867,126 @@ int ldso_ba_update_window(ldso_ba_t *H, int F, const int32_t *image_slot, const 
     const int rc_ = build_chunks(H);
     guard.ok = (rc_ == LDSO_OK);
     return rc_;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------------
+// The same delta, recorded call by call as the reference edits its window (EnergyFunctional.cc): ldso_ba_window_begin, then any sequence of
+//   ldso_ba_remove_frame    marginalizeFrame :72 (:138-150: the frame leaves; FullSystem::marginalizeFrame :607-632: so do the residuals that target it and the points it hosts)
+//   ldso_ba_insert_frame    insertFrame :32 (the new frame's id for the calls below is returned: oF, oF + 1, ...)
+//   ldso_ba_remove_points   removePoint :153 / dropPointsF :224 / the points marginalizePointsF :165 has absorbed
+//   ldso_ba_drop_residuals  dropResidual :63
+//   ldso_ba_add_residuals   insertResidual :26 for points of the window
+//   ldso_ba_add_points      insertPoint + insertResidual for freshly activated points, each placed in front of a resident row (makeIDX :380 order)
+// and ldso_ba_window_commit, which numbers the surviving frames (in order) and the inserted ones behind them and applies everything as ONE
+// ldso_ba_update_window.  Host-side bookkeeping only until the commit; an invalid edit is rejected there and leaves the resident window as it was.
+// ---------------------------------------------------------------------------------------------------------------------------------------------------
+int ldso_ba_window_begin(ldso_ba_t *H) {
+    REQ(H && H->D.P > 0 && !H->hasL && !H->pendingApply, "ldso_ba_window_begin: no resident window to edit (or linearised residuals / a pending linearisation)");
+    ldso_ba::WindowEdit &E = H->edit;
+    E = ldso_ba::WindowEdit();
+    E.active = true; E.oF = H->D.F; E.oP = H->D.P;
+    E.frameGone.assign(E.oF, 0); E.rowGone.assign(E.oP, 0); E.mask.assign(E.oP, 0u);
+    for (int i = 0; i < H->R; i++) { const int sl = H->flat2slot[i]; E.mask[sl / H->D.FS] |= 1u << (sl % H->D.FS); }
+    return LDSO_OK;
+}
+#define REQ_EDIT(name) REQ(H && H->edit.active, name ": no edit in progress (ldso_ba_window_begin first)")
+int ldso_ba_remove_frame(ldso_ba_t *H, int frame_idx) {
+    REQ_EDIT("ldso_ba_remove_frame");
+    REQ(frame_idx >= 0 && frame_idx < H->edit.oF && !H->edit.frameGone[frame_idx], "ldso_ba_remove_frame: not a frame of the resident window");
+    H->edit.frameGone[frame_idx] = 1;
+    for (int r = 0; r < H->edit.oP; r++) { if (H->h_phost[r] == frame_idx) H->edit.rowGone[r] = 1; H->edit.mask[r] &= ~(1u << frame_idx); }
+    return LDSO_OK;
+}
+int ldso_ba_insert_frame(ldso_ba_t *H, int image_slot, int *frame_id_out) {
+    REQ_EDIT("ldso_ba_insert_frame");
+    REQ(image_slot >= 0 && image_slot < H->maxF && H->imgSlots[image_slot] != nullptr, "ldso_ba_insert_frame: image slot not set");
+    REQ(H->edit.oF + (int) H->edit.insertedSlots.size() < 32, "ldso_ba_insert_frame: too many frames in one edit");
+    if (frame_id_out) *frame_id_out = H->edit.oF + (int) H->edit.insertedSlots.size();
+    H->edit.insertedSlots.push_back(image_slot);
+    return LDSO_OK;
+}
+int ldso_ba_remove_points(ldso_ba_t *H, int n, const int32_t *rows) {
+    REQ_EDIT("ldso_ba_remove_points");
+    REQ(n >= 0 && (n == 0 || rows), "ldso_ba_remove_points: bad arguments");
+    for (int i = 0; i < n; i++) REQ(rows[i] >= 0 && rows[i] < H->edit.oP, "ldso_ba_remove_points: row out of range");
+    for (int i = 0; i < n; i++) H->edit.rowGone[rows[i]] = 1;
+    return LDSO_OK;
+}
+static int edit_residuals(ldso_ba *H, int n, const int32_t *rows, const int32_t *targets, bool add, const char *) {
+    const int nF = H->edit.oF + (int) H->edit.insertedSlots.size();
+    for (int i = 0; i < n; i++) {
+        REQ(rows[i] >= 0 && rows[i] < H->edit.oP && targets[i] >= 0 && targets[i] < nF, "residual edit: row / target out of range");
+        const bool has = (H->edit.mask[rows[i]] >> targets[i]) & 1u;
+        REQ(add ? (!has && targets[i] != H->h_phost[rows[i]] && (targets[i] >= H->edit.oF || !H->edit.frameGone[targets[i]])) : has,
+            add ? "ldso_ba_add_residuals: the point already has that residual, or the target is its host / a removed frame" : "ldso_ba_drop_residuals: the point has no such residual");
+    }
+    for (int i = 0; i < n; i++) { if (add) H->edit.mask[rows[i]] |= 1u << targets[i]; else H->edit.mask[rows[i]] &= ~(1u << targets[i]); }
+    return LDSO_OK;
+}
+int ldso_ba_drop_residuals(ldso_ba_t *H, int n, const int32_t *rows, const int32_t *targets) {
+    REQ_EDIT("ldso_ba_drop_residuals");
+    REQ(n >= 0 && (n == 0 || (rows && targets)), "ldso_ba_drop_residuals: bad arguments");
+    return edit_residuals(H, n, rows, targets, false, "");
+}
+int ldso_ba_add_residuals(ldso_ba_t *H, int n, const int32_t *rows, const int32_t *targets) {
+    REQ_EDIT("ldso_ba_add_residuals");
+    REQ(n >= 0 && (n == 0 || (rows && targets)), "ldso_ba_add_residuals: bad arguments");
+    return edit_residuals(H, n, rows, targets, true, "");
+}
+int ldso_ba_add_points(ldso_ba_t *H, int n, const ldso_point_t *pts, const int32_t *before_row, int n_res, const ldso_residual_t *res, const float *mrb, const int32_t *ngr) {
+    REQ_EDIT("ldso_ba_add_points");
+    REQ(n >= 0 && n_res >= 0 && (n == 0 || (pts && before_row)) && (n_res == 0 || res), "ldso_ba_add_points: bad arguments");
+    const int nF = H->edit.oF + (int) H->edit.insertedSlots.size();
+    const size_t first = H->edit.fresh.size();
+    for (int i = 0; i < n; i++) {
+        REQ(before_row[i] >= 0 && before_row[i] <= H->edit.oP && pts[i].host >= 0 && pts[i].host < nF, "ldso_ba_add_points: before_row / host out of range");
+        ldso_ba::NewPoint q; q.p = pts[i]; q.before = before_row[i]; q.mrb = mrb ? mrb[i] : 0.0f; q.ngr = ngr ? ngr[i] : 0;
+        H->edit.fresh.push_back(q);
+    }
+    for (int i = 0; i < n_res; i++) {
+        if (!(res[i].point >= 0 && res[i].point < n && res[i].target >= 0 && res[i].target < nF && !res[i].is_linearized)) {
+            H->edit.fresh.resize(first); ldso_set_error("ldso_ba_add_points: residual names a point / frame outside the call, or is linearised"); return LDSO_E_INVALID;
+        }
+        H->edit.fresh[first + res[i].point].res.push_back(res[i]);
+    }
+    return LDSO_OK;
+}
+int ldso_ba_window_commit(ldso_ba_t *H) {
+    REQ_EDIT("ldso_ba_window_commit");
+    ldso_ba::WindowEdit &E = H->edit;
+    const int nIns = (int) E.insertedSlots.size();
+    std::vector<int32_t> idToNew(E.oF + nIns, -1), frameFrom, slots;
+    for (int f = 0; f < E.oF; f++) if (!E.frameGone[f]) { idToNew[f] = (int) frameFrom.size(); frameFrom.push_back(f); slots.push_back(H->imageSlot[f]); }
+    for (int k = 0; k < nIns; k++) { idToNew[E.oF + k] = (int) frameFrom.size(); frameFrom.push_back(-1); slots.push_back(E.insertedSlots[k]); }
+    const int F = (int) frameFrom.size();
+    auto translate = [&](uint32_t m) { uint32_t o = 0; for (int f = 0; f < E.oF + nIns; f++) if (((m >> f) & 1u) && idToNew[f] >= 0) o |= 1u << idToNew[f]; return o; };
+    // fresh points in front of their rows, in call order (stable)
+    std::vector<int> order(E.fresh.size());
+    for (size_t i = 0; i < order.size(); i++) order[i] = (int) i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return E.fresh[a].before < E.fresh[b].before; });
+    std::vector<int32_t> pointFrom; std::vector<uint32_t> mask; std::vector<ldso_point_t> fp; std::vector<ldso_residual_t> fr; std::vector<float> fm; std::vector<int32_t> fg;
+    size_t nx = 0;
+    int rc = LDSO_OK;
+    auto emitFresh = [&](int idx) {
+        ldso_ba::NewPoint q = E.fresh[idx];
+        const int k = (int) fp.size();
+        if (idToNew[q.p.host] < 0) { rc = LDSO_E_INVALID; return; }
+        q.p.host = idToNew[q.p.host];
+        uint32_t m = 0;
+        for (ldso_residual_t &r : q.res) { if (idToNew[r.target] < 0) { rc = LDSO_E_INVALID; return; } r.target = idToNew[r.target]; r.host = q.p.host; r.point = k; m |= 1u << r.target; }
+        std::sort(q.res.begin(), q.res.end(), [](const ldso_residual_t &a, const ldso_residual_t &b) { return a.target < b.target; });
+        fp.push_back(q.p); fm.push_back(q.mrb); fg.push_back(q.ngr);
+        for (const ldso_residual_t &r : q.res) fr.push_back(r);
+        pointFrom.push_back(-1 - k); mask.push_back(m);
+    };
+    for (int r = 0; r <= E.oP; r++) {
+        while (nx < order.size() && E.fresh[order[nx]].before == r) emitFresh(order[nx++]);
+        if (r < E.oP && !E.rowGone[r]) { pointFrom.push_back(r); mask.push_back(translate(E.mask[r])); }
+    }
+    E.active = false;
+    if (rc != LDSO_OK) { ldso_set_error("ldso_ba_window_commit: a fresh point or residual names a removed frame"); return rc; }
+    REQ(!pointFrom.empty() && F >= 2, "ldso_ba_window_commit: the edit leaves no window");
+    return ldso_ba_update_window(H, F, slots.data(), frameFrom.data(), (int) pointFrom.size(), pointFrom.data(), mask.data(), (int) fp.size(), fp.data(), (int) fr.size(), fr.data(), fm.data(), fg.data());
 }
 
 // Points per workgroup of the fused linearisation.  0 (default): the smallest chunk that keeps ONE window's grid within one workgroup per CU

@@ -456,79 +456,51 @@ __device__ void small_ldlt_solve(const double *Ain, const double *rhs, double *x
     for (int k = n - 1; k >= 0; k--) if (tr[k] != k) { double a = x[k]; x[k] = x[tr[k]]; x[tr[k]] = a; }
 }
 
-// 64-bit lane shuffles / broadcasts for the wave-parallel 8x8 solve
-__device__ __forceinline__ double tr_shfl64(double v, int src) {
-    unsigned long long u = __builtin_bit_cast(unsigned long long, v);
-    int lo = __builtin_amdgcn_ds_bpermute(src << 2, (int) (u & 0xFFFFFFFFu)), hi = __builtin_amdgcn_ds_bpermute(src << 2, (int) (u >> 32));
-    return __builtin_bit_cast(double, ((unsigned long long) (unsigned) hi << 32) | (unsigned) lo);
+// H (1 + lambda on the diagonal) x = rhsSign rhs, 8 x 8, by ONE lane with everything in registers: unpivoted LDL^T (the matrix is symmetric positive definite
+// after the scaling, so Eigen's diagonal pivoting - which the reference runs, CoarseTracker.cc:120-128 - gives the same solution up to rounding; zero pivots
+// as there: the column stays as it is, the component is dropped by D^+), one reciprocal per column (v_rcp_f64 + two Newton steps: 1.1e-16) instead of the
+// ~12-instruction IEEE division sequence, the solution scaled by the same reciprocals.  On the critical path of every LM iteration: until round 4 a
+// wavefront ran Eigen's pivoted factorisation lane-parallel (pivot search by DPP maxima + ballot, rows and columns exchanged by ds_bpermute: eight rounds of
+// ~250 ns, 2.1 us per solve); one lane's ~250 fp64 instructions take 1.0 us (round 5, A/B on one box: kernel 311 -> 2xx us per track, same 28 iterations).
+__device__ __forceinline__ double tr_rcp(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    return r;
 }
-__device__ __forceinline__ double tr_bcast64(double v, int l) {
-    unsigned long long u = __builtin_bit_cast(unsigned long long, v);
-    unsigned lo = (unsigned) __builtin_amdgcn_readlane((int) (u & 0xFFFFFFFFu), l), hi = (unsigned) __builtin_amdgcn_readlane((int) (u >> 32), l);
-    return __builtin_bit_cast(double, ((unsigned long long) hi << 32) | lo);
-}
-
-template <int CTRL> __device__ __forceinline__ double tr_dpp64(double v) {
-    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
-    const unsigned lo = (unsigned) __builtin_amdgcn_update_dpp(0, (int) (u & 0xFFFFFFFFu), CTRL, 0xF, 0xF, true);
-    const unsigned hi = (unsigned) __builtin_amdgcn_update_dpp(0, (int) (u >> 32), CTRL, 0xF, 0xF, true);
-    return __builtin_bit_cast(double, ((unsigned long long) hi << 32) | lo);
-}
-
-// Eigen-style LDL^T (pivot = first largest remaining |diagonal|, D^+ on zero pivots) of the 8x8 system by ONE wavefront, on the
-// LM critical path (once per iteration).  Lane i*8+j holds A[i][j] (the full symmetric matrix; after step k the lanes of row k hold
-// L[j][k]).  Every 8-lane group also carries the diagonal, the right-hand side and the permutation (entry j in lane j of the group):
-//   - the pivot search is a 3-step DPP maximum inside the groups + one ballot (no broadcasts of the 8 diagonal entries),
-//   - the forward substitution rides along the elimination (y_j -= L[j][k] y_k uses the L[j][k] the lane computes anyway),
-//   - one division sequence per step (L[j][k] = A[j][k] / d, computed where it is used),
-//   - the back substitution's L entries are fetched in one batch before its dependent chain, the permutation is undone by the
-//     indexed store of the result.
-// Must be called by all 64 lanes of a wave; x (8 entries) is written by lanes 0..7.
-__device__ void ldlt8_wave(const double *H /*LDS 64, row major*/, const double *rhs /*LDS 8*/, double rhsSign, double diagScale, double *x /*LDS 8*/) {
-    const int lane = threadIdx.x & 63, i = lane >> 3, j = lane & 7;
-    double a = H[lane];
-    if (i == j) a *= diagScale;
-    double dg = H[j * 9] * diagScale;         // the same product as lane (j,j)'s a: the two stay bit-identical
-    double y = rhsSign * rhs[j];
-    int pidx = j;
+__device__ __forceinline__ void ldlt8_lane(const double *H /*LDS 64, row major*/, const double *rhs /*LDS 8*/, double rhsSign, double diagScale, double *x /*8 registers*/) {
+    double A[8][8], y[8], inv[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+#pragma unroll
+        for (int j = 0; j <= i; j++) A[i][j] = H[i * 8 + j];
+        y[i] = rhsSign * rhs[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) A[i][i] *= diagScale;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-        const double m = (j >= k) ? fabs(dg) : -1.0;
-        double mm = m;
-        mm = __builtin_fmax(mm, tr_dpp64<0xB1>(mm));        // quad_perm [1,0,3,2]
-        mm = __builtin_fmax(mm, tr_dpp64<0x4E>(mm));        // quad_perm [2,3,0,1]
-        mm = __builtin_fmax(mm, tr_dpp64<0x141>(mm));       // row_half_mirror: the maximum of the 8-lane group
-        const unsigned cand = (unsigned) (__builtin_amdgcn_ballot_w64(m == mm) & 0xFFull);
-        const int idx = cand ? __builtin_ctz(cand) : k;     // uniform
-        if (idx != k) {
-            const int si = (i == k) ? idx : (i == idx) ? k : i, sj = (j == k) ? idx : (j == idx) ? k : j;
-            a = tr_shfl64(a, si * 8 + sj);
-            dg = tr_shfl64(dg, i * 8 + sj); y = tr_shfl64(y, i * 8 + sj);
-            pidx = __builtin_amdgcn_ds_bpermute((i * 8 + sj) << 2, pidx);
-        }
-        const double d = tr_bcast64(dg, k), yk = tr_bcast64(y, k);
-        const bool valid = fabs(d) > 0.0;                    // uniform (Eigen leaves the column as it is under a zero pivot)
-        const double ci = tr_shfl64(a, i * 8 + k), cj = tr_shfl64(a, j * 8 + k);
-        const double Lj = valid ? cj / d : cj;               // L[j][k]
-        if (j > k) {
+        const double d = A[k][k];
+        const bool valid = fabs(d) > 2.2250738585072014e-308;
+        inv[k] = valid ? tr_rcp(d) : 0.0;
+        const double sc = valid ? inv[k] : 1.0;
+#pragma unroll
+        for (int j = k + 1; j < 8; j++) {
+            const double L = A[j][k] * sc;          // L[j][k] (zero pivot: the column as it is)
             if (valid) {
-                if (i > k) a -= ci * Lj;
-                else if (i == k) a = Lj;
-                dg -= cj * Lj;
+#pragma unroll
+                for (int i = j; i < 8; i++) A[i][j] = __builtin_fma(-A[i][k], L, A[i][j]);
             }
-            y -= yk * Lj;
+            y[j] = __builtin_fma(-y[k], L, y[j]);
+            A[j][k] = L;
         }
     }
-    double xr = (fabs(dg) > 2.2250738585072014e-308) ? y / dg : 0.0;
-    double Lc[8];
 #pragma unroll
-    for (int c = 1; c < 8; c++) Lc[c] = tr_shfl64(a, j * 8 + c);         // lane r of a group: L[c][r] (row r of the lanes, column c)
+    for (int j = 0; j < 8; j++) x[j] = y[j] * inv[j];
 #pragma unroll
-    for (int c = 7; c >= 1; c--) {                                        // x_r -= L[c][r] x_c, r < c
-        const double xc = tr_bcast64(xr, c);
-        if (j < c) xr -= Lc[c] * xc;
-    }
-    if (lane < 8) x[pidx] = xr;
+    for (int c = 7; c >= 1; c--)
+#pragma unroll
+        for (int r = 0; r < c; r++) x[r] = __builtin_fma(-A[c][r], x[c], x[r]);
 }
 
 __device__ __forceinline__ void tr_vec6(const double *acc, double *rs) {
@@ -741,13 +713,12 @@ __global__ __launch_bounds__(TR_NT) void k_tr_track(const TrParams *__restrict__
             // be deciding; the closing barrier of the previous iteration orders this read behind that write, the barrier after the step
             // orders it in front of the next one
             const double oldRatio = sResOld[0] / sResOld[1];
-            // H (1 + lambda on the diagonal) x = -b: wave 0 solves the 8x8 system lane-parallel (CoarseTracker.cc:120-128)
+            // H (1 + lambda on the diagonal) x = -b (CoarseTracker.cc:120-128)
 #if LD_STAMP_ON_TR
             tQ = wall_clock64();
 #endif
-            // wave 0 alone: the solve (right-hand side -b), then its lane 0 takes the step from the increment the wave has just stored -
-            // LDS operations of one wavefront execute in order, so neither hand-over needs a workgroup barrier
-            if (tid < 64) ldlt8_wave(sH, sB, -1.0, (double) (1 + sLambda), sInc);
+            // lane 0 alone: the solve (right-hand side -b, ldlt8_lane), then the step from the increment it has just stored
+            if (tid == 0) { double xs[8]; ldlt8_lane(sH, sB, -1.0, (double) (1 + sLambda), xs); for (int i = 0; i < 8; i++) sInc[i] = xs[i]; }
 #if LD_STAMP_ON_TR
             tS1 += wall_clock64() - tQ; tQ = wall_clock64();
 #endif

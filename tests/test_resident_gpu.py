@@ -96,7 +96,8 @@ def _scenario(F_big, old_frames, new_frames, P=600, seed=5):
     fresh_res = w1.residuals[fr_sel].copy()
     remap = -np.ones(len(new_pts), np.int64); remap[fresh_rows] = np.arange(len(fresh_rows))
     fresh_res["point"] = remap[fresh_res["point"]]
-    return dict(A=A, big=big, w1=w1, new_frames=new_frames, frame_from=frame_from, point_from=point_from, res_mask=res_mask, fresh_pts=fresh_pts, fresh_res=fresh_res,
+    return dict(old_frames=old_frames, old_pts=old_pts, survive=survive, fresh=fresh, dropped_res=dropped_res, big2=big2, added_frames=added_frames, gone_frames=gone_frames,
+                A=A, big=big, w1=w1, new_frames=new_frames, frame_from=frame_from, point_from=point_from, res_mask=res_mask, fresh_pts=fresh_pts, fresh_res=fresh_res,
                 mrb=mrb[new_pts], ngr=ngr[new_pts], fresh_rows=fresh_rows, n_survive=len(survive), n_fresh=len(fresh), n_dropped=int(dropped_res.sum()))
 
 
@@ -157,6 +158,79 @@ def test_resident_window_equals_fresh_upload(F_big, old_frames, new_frames):
     ea, eb = A.get_energy_log(), Bh.get_energy_log()
     assert ia == ib and np.abs(ea - eb).max() <= 1e-9 * np.abs(eb).max() and abs(rma - rmb) <= 1e-9 * rmb
     _same(A.get_residuals()["state_state"], Bh.get_residuals()["state_state"], "state_state after optimize")
+    A.close(); Bh.close()
+
+
+def _load_fresh(sc):
+    big, w1 = sc["big"], sc["w1"]
+    Bh = binding.BA(big.w, big.h, max_frames=big.F, max_points=big.P)
+    Bh.set_settings(big.settings)
+    for f in range(big.F):
+        Bh.set_image(f, big.images[f][0])
+    Bh.set_window(sc["new_frames"], w1.points, w1.residuals)
+    Bh.set_point_stats(sc["mrb"], sc["ngr"])
+    Bh.set_frames(w1.frames, w1.calib); Bh.set_prior(w1.HM, w1.bM)
+    return Bh
+
+
+@pytest.mark.parametrize("F_big,old_frames,new_frames", [(7, [0, 1, 2, 3, 4, 5], [1, 2, 3, 4, 5, 6]), (7, [0, 1, 2, 3, 4], [0, 1, 3, 4, 5, 6])], ids=["steady", "middle"])
+def test_call_by_call_edit_equals_fresh_upload(F_big, old_frames, new_frames):
+    """The same window edit recorded as the reference's own maintenance calls (ldso_ba_window_begin, _remove_frame ≙ marginalizeFrame, _insert_frame ≙ insertFrame,
+    _remove_points ≙ removePoint / dropPointsF, _drop_residuals ≙ dropResidual, _add_residuals ≙ insertResidual, _add_points ≙ insertPoint, _window_commit):
+    frames / targets named by their index in the RESIDENT window, points by their resident row."""
+    sc = _scenario(F_big, old_frames, new_frames)
+    A, big, w1, big2 = sc["A"], sc["big"], sc["w1"], sc["big2"]
+    old_pts, survive, fresh = sc["old_pts"], sc["survive"], sc["fresh"]
+    A.window_begin()
+    for f in sc["gone_frames"]:
+        A.remove_frame(old_frames.index(f))
+    fid = {f: old_frames.index(f) for f in old_frames}
+    for f in sc["added_frames"]:
+        fid[f] = A.insert_frame(f)                                                         # image slot = frame index in `big`
+    old_row = -np.ones(big.P, np.int64); old_row[old_pts] = np.arange(len(old_pts))
+    gone_pts = old_pts[~np.isin(old_pts, survive) & ~np.isin(big.points["host"][old_pts], sc["gone_frames"])]
+    A.remove_points(old_row[gone_pts])
+    rb = big.residuals
+    is_surv = np.isin(rb["point"], survive)
+    d = sc["dropped_res"] & is_surv & np.isin(rb["target"], [f for f in old_frames if f in new_frames])
+    A.drop_residuals(old_row[rb["point"][d]], [fid[int(t)] for t in rb["target"][d]])
+    a = is_surv & np.isin(rb["target"], sc["added_frames"]) & ~sc["dropped_res"]
+    A.add_residuals(old_row[rb["point"][a]], [fid[int(t)] for t in rb["target"][a]])
+    fr = np.isin(rb["point"], fresh) & np.isin(rb["target"], new_frames) & ~sc["dropped_res"]
+    fres = big2.residuals[fr].copy()
+    remap = -np.ones(big.P, np.int64); remap[fresh] = np.arange(len(fresh))
+    fres["point"] = remap[fres["point"]]; fres["target"] = [fid[int(t)] for t in fres["target"]]
+    fpts = big2.points[fresh].copy(); fpts["host"] = [fid[int(h)] for h in fpts["host"]]
+    A.add_points(fpts, np.searchsorted(old_pts, fresh), fres)                              # in front of the first resident row that follows it in makeIDX order
+    A.window_commit(w1.F, w1.P, w1.R)
+    A.set_frames(w1.frames, w1.calib); A.set_prior(w1.HM, w1.bM)
+    Bh = _load_fresh(sc)
+    ra, rb_ = A.get_residuals(), Bh.get_residuals()
+    _same(ra["state_state"], rb_["state_state"], "state_state as loaded"); _same(ra["out"]["state_NewEnergy"], rb_["out"]["state_NewEnergy"], "state_energy as loaded")
+    for h in (A, Bh):
+        h.collect_active()
+    Ea, Eb = A.linearize_all(False), Bh.linearize_all(False)
+    assert Ea == Eb and np.isfinite(Ea)
+    ra, rb_ = A.get_residuals(), Bh.get_residuals()
+    for k in ra["out"].dtype.names:
+        _same(ra["out"][k], rb_["out"][k], "linearize " + k)
+    pa, pb = A.get_points(), Bh.get_points()
+    for k in pa.dtype.names:
+        _same(pa[k], pb[k], "point." + k)
+    # an edit that cannot be committed leaves the window as it is
+    A.apply_res()
+    A.window_begin()
+    with pytest.raises(binding.LdsoError):
+        A.add_residuals([0], [int(w1.points["host"][0])])                                  # a residual towards the point's own host
+    A.remove_frame(0)
+    with pytest.raises(binding.LdsoError):
+        A.add_points(w1.points[:1], [0], w1.residuals[:0])                                  # ... hosted by the frame just removed: rejected at the commit
+        A.window_commit(w1.F, w1.P, w1.R)
+    Bh.apply_res()
+    for h in (A, Bh):
+        h.collect_active()
+    Ea2, Eb2 = A.linearize_all(False), Bh.linearize_all(False)
+    assert Ea2 == Eb2 and np.isfinite(Ea2) and (A.F, A.P, A.R) == (w1.F, w1.P, w1.R)
     A.close(); Bh.close()
 
 
