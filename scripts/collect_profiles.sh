@@ -28,9 +28,12 @@ if [ "$WHAT" = all ] || [ "$WHAT" = stats ]; then
   ( cd "$ROOT" && timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/stats_tracker" -o stats --output-format csv -- python scripts/bench_tracker.py > "$OUT/stats_tracker.log" 2>&1 )
   # the sharded iteration on one GPU (the multi-GPU step with one rank owning every point): k_reduce + k_gn_export -> exchange -> k_gn_solve -> k_linearize,
   # once with the no-op all-reduce (= what RCCL brackets) and once through the peer-write exchange (k_p2p_push / k_p2p_sum)
-  for CFG in C3 C4; do
+  # (DIST_CFGS / DIST_P2P in the environment trim this part: the sharded iteration did not change in round 5 and GPU minutes were short)
+  for CFG in ${DIST_CFGS-C3 C4}; do
     timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/stats_dist_$CFG" -o stats --output-format csv -- $B --steps 300 --warmup 30 --no-extras --config $CFG --force-dist-path > "$OUT/stats_dist_$CFG.log" 2>&1
+    if [ "${DIST_P2P-1}" = 1 ]; then
     timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/stats_dist_p2p_$CFG" -o stats --output-format csv -- $B --steps 300 --warmup 30 --no-extras --config $CFG --force-dist-path --allreduce p2p > "$OUT/stats_dist_p2p_$CFG.log" 2>&1
+    fi
   done
 fi
 if [ "$WHAT" = all ] || [ "$WHAT" = pmc ]; then
