@@ -311,7 +311,9 @@ bool GpuBackend::uploadDelta(FullSystem &fs, const std::vector<int32_t> &slots, 
                 for (int c = 0; c < oF; c++)
                     if (((o.mask >> c) & 1u) && oldToNew[c] >= 0) { n.mask |= 1u << oldToNew[c]; n.res[oldToNew[c]] = o.res[c]; }
                 int cnt = __builtin_popcount(n.mask);
-                bool ok = have >= cnt && have - cnt <= nInserted;
+                // (a point that got NO residual for a frame inserted since - LDSO gives every active point one, FullSystem.cc:447-470 - may as well have lost one
+                // and gained one: equal counts prove nothing then, its list is re-read)
+                bool ok = have >= cnt && have - cnt <= nInserted && !(nInserted > 0 && have == cnt);
                 for (int k = cnt; ok && k < have; k++) {          // insertResidual appends (FullSystem.cc:447-470): the new ones are the last
                     PointFrameResidual &r = *ph->residuals[k];
                     const int t = columnOf(r);
