@@ -457,6 +457,7 @@ float GpuBackend::optimize(FullSystem &fs, int mnumOptIts) {
     }
     // points (doStepFromBackup :1595-1606, AccumulatedSCHessian.cc:9-51, the fixing pass :1521-1536)
     for (int k = 0; k < P; k++) {
+        if (k + 8 < P) { const char *nx = (const char *) allPoints[k + 8].get(); __builtin_prefetch(nx, 1); __builtin_prefetch(nx + 64, 1); __builtin_prefetch(nx + 192, 1); __builtin_prefetch(nx + 256, 1); }      // 304-byte objects
         PointHessian &ph = *allPoints[k];
         ph.setIdepth(po[k].idepth); ph.setIdepthZero(po[k].idepth);
         ph.step = po[k].step; ph.HdiF = po[k].HdiF; ph.bdSumF = po[k].bdSumF; ph.idepth_hessian = po[k].idepth_hessian;
@@ -466,6 +467,8 @@ float GpuBackend::optimize(FullSystem &fs, int mnumOptIts) {
     }
     // residuals: applyRes(true) of the fixing pass (Residuals.h:70-87), lastResiduals bookkeeping and removal (:1472-1489)
     for (int i = 0; i < R; i++) {
+        // 12 000 separately allocated objects: the walk is a chain of cache misses unless the next ones are already on their way
+        if (i + 12 < R) { const char *nx = (const char *) flat[i + 12]; __builtin_prefetch(nx, 1); __builtin_prefetch(nx + 176, 1); __builtin_prefetch(nx + 240, 1); __builtin_prefetch(nx + 287, 1); }      // state | centre | JpJdF (288-byte objects)
         PointFrameResidual &r = *flat[i];
         if (r.isLinearized) continue;                                                            // not in activeResiduals: untouched by optimize()
         r.state_NewEnergy = ro[i].state_NewEnergy; r.state_NewEnergyWithOutlier = ro[i].state_NewEnergyWithOutlier; r.state_NewState = (ResState) ro[i].state_NewState;

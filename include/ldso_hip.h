@@ -204,7 +204,9 @@ int ldso_ba_marginalize_frame(ldso_ba_t *h, int frame_idx, double *HM_out, doubl
 int ldso_ba_activate_points(ldso_ba_t *h, int n, const ldso_immature_t *points, int min_obs, float min_idepth_hessian, int gn_iterations,
                             ldso_activation_t *out);
 /* Asynchronous variant used by bench.py: enqueue `iters` Gauss-Newton iterations (solveSystem +
- * doStepFromBackup + linearizeAll + applyRes) on the handle's stream and return immediately. */
+ * doStepFromBackup + linearizeAll + applyRes) on the handle's stream and return immediately.  The launch sequence of a call is captured into a HIP graph the
+ * first time and replayed when the same call comes again (same window, settings, stream, first iteration and count: the key is a hash of every launch
+ * argument); LDSO_GN_GRAPHS=0 in the environment at handle creation: launch by launch.  Same kernels, same arguments, same order either way. */
 int ldso_ba_enqueue_gn(ldso_ba_t *h, int first_iteration, int iters);
 int ldso_ba_sync(ldso_ba_t *h);
 

@@ -120,6 +120,11 @@ struct ldso_ba {
     int tcnt[5] = {0, 0, 0, 0, 0};
     int lastIterations = 0;
     bool noFusedLaunch = false;        // debug: k_reduce and k_gn_solve as two launches even where the fused k_reduce_solve applies
+    // ldso_ba_enqueue_gn replays a cached HIP graph when the same launch sequence was enqueued before: the key is a hash over EVERYTHING the launches take as
+    // arguments (pointer tables, dimensions, both residual sets, settings, chunk geometry, flags, stream, first iteration, count, parity of the sets)
+    struct GnGraph { unsigned long long sig; hipGraphExec_t exec; hipGraph_t graph; };
+    std::vector<GnGraph> gnGraphs;
+    bool gnUseGraphs = true;
     double *distBuf = nullptr;         // ldso_ba_enqueue_gn_rccl / _p2p: all-reduce buffer [HFinal | bFinal | scalars | candidates]
     unsigned p2pSeq = 0;               // ldso_ba_enqueue_gn_p2p: exchanges done (the tag of the hand-over words)
     int *d_p2pErr = nullptr;           // set by k_p2p_sum when a peer's words did not arrive in time
@@ -372,6 +377,7 @@ int ldso_ba_create(int device, int w, int h, int max_frames, int max_points, lds
     REQ(device >= 0 && device < ndev, "ldso_ba_create: device index out of range");
     CHK(hipSetDevice(device));
     ldso_ba *H = new ldso_ba();
+    { const char *e = getenv("LDSO_GN_GRAPHS"); if (e && e[0] == '0') H->gnUseGraphs = false; }
     const int r = create_body(H, device, w, h, max_frames, max_points);
     if (r != LDSO_OK) { const std::string keep = g_err; ldso_ba_destroy(H); g_err = keep; return r; }      // nothing of a half-built handle leaks
     *out = H;
@@ -438,6 +444,7 @@ int ldso_ba_destroy(ldso_ba_t *H) {
     if (H->distBuf) hipFree(H->distBuf);
     if (H->d_p2pErr) hipFree(H->d_p2pErr);
     for (auto &t : H->timers) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
+    for (ldso_ba::GnGraph &g : H->gnGraphs) { hipGraphExecDestroy(g.exec); hipGraphDestroy(g.graph); }
     if (H->ownStream && H->stream) hipStreamDestroy(H->stream);
     delete H;
     return LDSO_OK;
@@ -1315,12 +1322,62 @@ static int enqueue_iteration(ldso_ba *H, int iteration, double lambda, int logId
     return LDSO_OK;
 }
 
+static unsigned long long fnv1a(unsigned long long h, const void *p, size_t n) {
+    const unsigned char *b = (const unsigned char *) p;
+    for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; }
+    return h;
+}
+// everything the launches of `iters` forced iterations take as arguments
+static unsigned long long gn_signature(const ldso_ba *H, int first_iteration, int iters) {
+    unsigned long long h = 1469598103934665603ull;
+    h = fnv1a(h, &H->B, sizeof(H->B)); h = fnv1a(h, &H->D, sizeof(H->D)); h = fnv1a(h, H->sets, sizeof(H->sets)); h = fnv1a(h, &H->settings, sizeof(H->settings));
+    h = fnv1a(h, &H->chunkStarts, sizeof(H->chunkStarts)); h = fnv1a(h, &H->linHead, sizeof(H->linHead));
+    const long long misc[12] = {first_iteration, iters, H->cur, H->hasL, H->hasPrior, H->GSP, H->linHeadOk, H->noFusedLaunch, H->numCU, (long long) (size_t) H->stream, (long long) (size_t) H->ownAcc,
+                                (long long) (size_t) H->d_waitCtr};
+    return fnv1a(h, misc, sizeof(misc));
+}
+static int enqueue_gn_plain(ldso_ba *H, int first_iteration, int iters) {
+    CHK(hipMemsetAsync(H->d_waitCtr, 0, 4 * sizeof(int), H->stream));      // an aborted launch must not leave the producer counter armed
+    for (int i = 0; i < iters; i++) RUN(enqueue_iteration(H, first_iteration + i, 1e-1, -1, true));
+    return LDSO_OK;
+}
+// The iterations are 2-3 dependent launches each, the host runs far ahead of the device, and what is left to remove on the device side is the per-packet work of the
+// command processor: the same sequence captured ONCE into a HIP graph and replayed is 35.55 against 36.04 us per iteration at C3 (scripts/r5/graph_gn.py).  The
+// graph is keyed by a hash of every launch argument (gn_signature): anything that changes what the kernels are handed - a new window, other settings, a prior,
+// another stream, another iteration index (the orthogonalisation starts at iteration 2) - captures anew; profiling runs (per-kernel events) and callers that are
+// capturing themselves take the plain path.  LDSO_GN_GRAPHS=0 turns it off.
 int ldso_ba_enqueue_gn(ldso_ba_t *H, int first_iteration, int iters) {
     REQ(H && H->D.P > 0 && iters >= 0, "bad arguments");
     REQ_UNSHARDED("ldso_ba_enqueue_gn");
     CHK(hipSetDevice(H->device));
-    CHK(hipMemsetAsync(H->d_waitCtr, 0, 4 * sizeof(int), H->stream));      // an aborted launch must not leave the producer counter armed
-    for (int i = 0; i < iters; i++) RUN(enqueue_iteration(H, first_iteration + i, 1e-1, -1, true));
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (!H->gnUseGraphs || H->profile || iters < 2 || H->B.acc != H->ownAcc || hipStreamIsCapturing(H->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone)
+        return enqueue_gn_plain(H, first_iteration, iters);
+    const unsigned long long sig = gn_signature(H, first_iteration, iters);
+    for (ldso_ba::GnGraph &g : H->gnGraphs)
+        if (g.sig == sig) {
+            CHK(hipGraphLaunch(g.exec, H->stream));
+            if (iters & 1) H->cur ^= 1;          // what the captured enqueue did to the handle's host state: the sets swap once per iteration
+            H->appliedValid = true;
+            return LDSO_OK;
+        }
+    // capture; the handle's host state advances as in a plain enqueue, the device work happens at the launch below
+    const int cur0 = H->cur;
+    hipGraph_t graph = nullptr;
+    if (hipStreamBeginCapture(H->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void) hipGetLastError(); return enqueue_gn_plain(H, first_iteration, iters); }
+    const int rc = enqueue_gn_plain(H, first_iteration, iters);
+    const hipError_t ec = hipStreamEndCapture(H->stream, &graph);
+    hipGraphExec_t exec = nullptr;
+    if (rc != LDSO_OK || ec != hipSuccess || graph == nullptr || hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+        (void) hipGetLastError();
+        if (graph) hipGraphDestroy(graph);
+        H->cur = cur0;                            // nothing ran: enqueue for real
+        H->gnUseGraphs = false;                   // this runtime / stream does not capture the sequence: do not try again
+        return enqueue_gn_plain(H, first_iteration, iters);
+    }
+    if (H->gnGraphs.size() >= 4) { hipGraphExecDestroy(H->gnGraphs.front().exec); hipGraphDestroy(H->gnGraphs.front().graph); H->gnGraphs.erase(H->gnGraphs.begin()); }
+    H->gnGraphs.push_back(ldso_ba::GnGraph{sig, exec, graph});
+    CHK(hipGraphLaunch(exec, H->stream));
     return LDSO_OK;
 }
 
