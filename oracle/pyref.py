@@ -18,7 +18,8 @@ _LIB = None
 
 
 def lib_path() -> str:
-    return os.path.join(_HERE, "_ref", "libldso_ref.so")
+    # LDSO_REF_LIB: another build of the reference-compiled library (e.g. an AddressSanitizer build)
+    return os.environ.get("LDSO_REF_LIB") or os.path.join(_HERE, "_ref", "libldso_ref.so")
 
 
 def available() -> bool:
@@ -312,7 +313,8 @@ _ADP = None
 
 
 def adapter_path() -> str:
-    return os.path.join(_HERE, "..", "adapter", "_build", "libldso_adapter_test.so")
+    # LDSO_ADAPTER_LIB: another build of the harness library (e.g. an AddressSanitizer build, run with LD_PRELOAD=libasan.so)
+    return os.environ.get("LDSO_ADAPTER_LIB") or os.path.join(_HERE, "..", "adapter", "_build", "libldso_adapter_test.so")
 
 
 def adapter_available() -> bool:

@@ -718,7 +718,10 @@ void *ref_fs_build_immature(void *h, int n, const ldso_immature_t *pts, int min_
 }
 void ref_fs_free_immature(void *vec) {
     auto *v = (std::vector<shared_ptr<ImmaturePoint>> *) vec;
-    for (auto &ip : *v) if (ip && ip->feature) ip->feature->ReleaseAll();
+    // make_immature's features are owned by their immature point alone (they are in no frame's list): Feature::ReleaseImmature (Feature.cc:26-31) drops that
+    // owner FIRST (ip->feature = nullptr) and then writes its own member - into a Feature that no longer exists unless somebody else holds it.  Hold it here.
+    // (An AddressSanitizer build of this library found it: heap-use-after-free, an occasional "corrupted double-linked list" in tests/test_adapter_gpu.py.)
+    for (auto &ip : *v) if (ip) { shared_ptr<Feature> f = ip->feature; if (f) f->ReleaseAll(); }
     delete v;
 }
 
