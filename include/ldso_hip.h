@@ -403,7 +403,7 @@ int ldso_init_calc_res_and_gs(ldso_initializer_t *t, int lvl, const double refTo
                               float *H, float *b, float *Hsc, float *bsc, float *res, float *ec);
 int ldso_init_set_new_frame(ldso_initializer_t *t, const float *irradiance, float ab_exposure);
 /* debug builds (LDSO_STAMPS=1): accumulated device-side counters, zeros otherwise */
-int ldso_init_debug_counters(ldso_initializer_t *t, long long out[4]);
+int ldso_init_debug_counters(ldso_initializer_t *t, long long out[8]);
 
 #ifdef __cplusplus
 }

@@ -10,13 +10,17 @@
 //                state (lambda, fails, iteration, level) in device memory, solves the damped 6x6 / 8x8 system with a
 //                lane-parallel pivoted LDL^T, and runs everything that is sequential in the reference: optReg (:430-459),
 //                propagateDown/Up (:462-522) and the neighbour average of resetPoints (:629-641).
-// The host enqueues BEGIN + the maximal number of (eval, ctl) pairs once; finished levels / a finished frame make the
+//   k_ini_prep   grid kernel between the two: the per-lane inputs of the optReg sweep that follows if the step is accepted.
+// The host enqueues BEGIN + the maximal number of (eval, prep, ctl) triples once; finished levels / a finished frame make the
 // remaining launches return at once (device-side `done`), so there is no host round trip inside trackFrame.
 //
 // optReg and the resetPoints average update points IN PLACE in index order, reading neighbours that may already have been
-// updated.  That order is kept exactly: the host builds, per level, a schedule of passes of <= 64 points such that every
-// neighbour with a lower index sits in an earlier pass and every reader with a lower index in an earlier-or-equal pass; one
-// wavefront executes the passes with the working values in LDS (reads before writes within a pass by lock-step execution).
+// updated.  That order is kept exactly: the host builds, per level, a schedule of passes such that every neighbour with a
+// lower index sits in an earlier pass and every reader with a lower index in an earlier-or-equal pass; one wavefront executes
+// the passes with the working values in LDS (reads before writes within a pass by lock-step execution).  The dependency
+// depth of that order (a diagonal front through the raster: 200-590 passes per level at 640 x 480, 20-40 points wide) is what
+// a sweep costs, so a pass is made as short as it can be: optReg with two lanes per point and a fixed selection instead of a
+// count-dependent one (ini_sw2_point: 28 instructions, 0.11 us per pass; round 4: one lane, a 10-key sorting network, 0.38 us).
 #include <hip/hip_runtime.h>
 #include <vector>
 #include <string>
@@ -54,10 +58,16 @@ struct IniLevel {
     float *u, *v, *idepth, *idepth_new, *iR, *iRSumNum, *lastHessian, *lastHessian_new, *maxstep, *energy0, *energy1, *energy_new0, *energy_new1, *outlierTH;
     int *isGood, *isGood_new, *parent, *nb;
     float *jb[2];                       // [n][10]
+    // resetPoints sweep (top level only; one lane per point):
     const int *sched;                   // [nPass][64] point index or -1
     const int *schedOff;                // [nPass][64] LDS byte offset of the point's key (dummy slot n*4 for idle lanes)
     const int *schedNb;                 // [nPass][64][INI_NB] LDS byte offsets of the neighbours' keys in schedule order (dummy slot: none)
-    float *schedIdv;                    // [nPass][64] idepth of the scheduled points (gathered before an optReg sweep)
+    // optReg sweep (two lanes per point): schedule of passes of <= 32 points and the per-lane inputs ini_prep writes before every sweep
+    int nPass2;
+    int nIdle;
+    const int *slotOf;                  // [n] place of the point in the schedule: pass * 32 + position
+    const int *idleSlot;                // [nIdle] places (of nPass2 + INI_SWPAD passes) that hold no point
+    int4 *swRec;                        // [nPass2 + INI_SWPAD][64][2]: see SwRec
     const int *childOff, *childIdx;     // children (points of level - 1) of every point of this level, ascending
 };
 
@@ -69,7 +79,10 @@ struct IniCtl {
     float H[64], b[8], Hsc[64], bsc[8], resOld[3];
     float Hn[64], bn[8], Hscn[64], bscn[8], resNew[3], ec[3];
     int lvl, mode, iteration, fails, done, snapped, snappedAt, frameID, jbSel, applyPending, evals, ready;
-    long long dbgSweepTicks, dbgSweepPasses, dbgCtlTicks, dbgSweeps;     // LDSO_STAMPS builds only (100 MHz wall clock)
+    int idleWritten;                    // the records of the schedule places that hold no point are written (ini_prep_idle)
+    int ldsBase;                        // LDS address of the control block's key array (the sweep records hold LDS addresses)
+    int prepReady;                      // k_ini_prep has written the records of the level for the step this evaluation tried; consumed by the control step
+    long long dbgSweepTicks, dbgSweepPasses, dbgCtlTicks, dbgSweeps, dbgPrepTicks, dbgFrontTicks, dbgTailTicks, dbgSpare;     // LDSO_STAMPS builds only (100 MHz wall clock)
 };
 
 struct IniParams {
@@ -365,82 +378,126 @@ __device__ void ini_ldlt_wave(float a, float rhsLane, int nn, float *x /*LDS 8*/
     if (lane < 8) x[lane] = (lane < nn) ? xr : 0.0f;
 }
 
-#define CE(a, b) do { const float lo_ = fminf(a, b), hi_ = fmaxf(a, b); a = lo_; b = hi_; } while (0)
-
 // The in-place sequential sweeps (see file header).  sIR[j] = key of iR of point j if it is good, INI_NOKEY otherwise; filled by the caller.
-// op 0: optReg (:439-457); op 1: neighbour average of resetPoints (:629-641).
+// Behind the keys: sIR[n] = INI_NOKEY (dummy of absent / not-good neighbours and of idle lanes), sIR[n + 1] = INI_MINKEY, sIR[n + 2] = a slot nobody reads.
+// Order-preserving integer key of a (non-NaN) float: integer min/max need no NaN canonicalisation.  INI_NOKEY = point not good.
+#define INI_NOKEY 0x7fffffff
+#define INI_MINKEY ((int) 0x80000000)
+#define INI_LDS_EXTRA 3
+__device__ __forceinline__ int ini_key(float f) { const int b = __builtin_bit_cast(int, f); return b ^ ((b >> 31) & 0x7fffffff); }
+__device__ __forceinline__ float ini_unkey(int k) { return __builtin_bit_cast(float, k ^ ((k >> 31) & 0x7fffffff)); }
+// unconditional prefetch: the schedule arrays carry INI_SWPAD passes of padding (idle lanes) behind the last pass
+#define INI_SWPAD 16
+
+// ---- resetPoints' neighbour average (:629-641), one lane per point: a point that gets an average BECOMES good for the points behind it, and the float sum runs in
+// neighbour order - nothing of it can be prepared or split.  Top level only, once per frame.
 // Sweep inputs of one scheduled point: LDS BYTE offsets of its own key and of its 10 neighbours' keys (an absent neighbour and an
-// idle lane point at the dummy slot sK[n], which always holds INI_NOKEY - no clamps or selects in the loop), and its idepth.
-struct SwIn { int self; int4 a, b, c; float id; };
-// unconditional: the schedule arrays carry INI_SWPAD passes of padding (dummy slot) behind the last pass
-#define INI_SWPAD 8
+// idle lane point at the dummy slot sK[n], which always holds INI_NOKEY - no clamps or selects in the loop).
+struct SwIn { int self; int4 a, b, c; };
 __device__ __forceinline__ SwIn ini_sw_load(const IniLevel &L, int p, int lane) {
     SwIn r;
     const size_t q = (size_t) p * 64 + lane;
     r.self = L.schedOff[q];
     const int4 *row = (const int4 *) (L.schedNb + q * INI_NB);
     r.a = row[0]; r.b = row[1]; r.c = row[2];
-    r.id = L.schedIdv[q];
     return r;
 }
-// Order-preserving integer key of a (non-NaN) float: integer min/max need no NaN canonicalisation.  INI_NOKEY = point not good.
-#define INI_NOKEY 0x7fffffff
-__device__ __forceinline__ int ini_key(float f) { const int b = __builtin_bit_cast(int, f); return b ^ ((b >> 31) & 0x7fffffff); }
-__device__ __forceinline__ float ini_unkey(int k) { return __builtin_bit_cast(float, k ^ ((k >> 31) & 0x7fffffff)); }
-#define CEI(a, b) do { const int lo_ = min(a, b), hi_ = max(a, b); a = lo_; b = hi_; } while (0)
-
-template <int OP>
 __device__ __forceinline__ void ini_sw_point(const SwIn &r, int *sK, int dummyOff) {
-    const float regWeight = 0.8f;
     char *base = (char *) sK;
 #define GK(off) (*(const int *) (base + (off)))
     int v[10] = {GK(r.a.x), GK(r.a.y), GK(r.a.z), GK(r.a.w), GK(r.b.x), GK(r.b.y), GK(r.b.z), GK(r.b.w), GK(r.c.x), GK(r.c.y)};
     const int self = GK(r.self);
 #undef GK
-    if (OP == 0) {
-        int nnn = 0;
+    float snd = 0, sn = 0;
 #pragma unroll
-        for (int q = 0; q < 10; q++) nnn += (v[q] != INI_NOKEY) ? 1 : 0;
-        // 29-comparator sorting network for 10 keys; std::nth_element's result at position nnn/2 is the (nnn/2)-th smallest
-        CEI(v[0], v[5]); CEI(v[1], v[6]); CEI(v[2], v[7]); CEI(v[3], v[8]); CEI(v[4], v[9]);
-        CEI(v[0], v[3]); CEI(v[1], v[4]); CEI(v[5], v[8]); CEI(v[6], v[9]);
-        CEI(v[0], v[2]); CEI(v[3], v[6]); CEI(v[7], v[9]);
-        CEI(v[0], v[1]); CEI(v[2], v[4]); CEI(v[5], v[7]); CEI(v[8], v[9]);
-        CEI(v[1], v[2]); CEI(v[3], v[5]); CEI(v[4], v[6]); CEI(v[7], v[8]);
-        CEI(v[1], v[3]); CEI(v[2], v[5]); CEI(v[4], v[7]); CEI(v[6], v[8]);
-        CEI(v[2], v[3]); CEI(v[4], v[5]); CEI(v[6], v[7]);
-        CEI(v[3], v[4]); CEI(v[5], v[6]);
-        const int m = nnn >> 1;
-        const int mk = (m == 0) ? v[0] : (m == 1) ? v[1] : (m == 2) ? v[2] : (m == 3) ? v[3] : (m == 4) ? v[4] : v[5];
-        // the dummy slot is never good, so idle lanes never write
-        if (self != INI_NOKEY && nnn > 2) *(int *) (base + r.self) = ini_key((1 - regWeight) * r.id + regWeight * ini_unkey(mk));
-    } else {
-        float snd = 0, sn = 0;
-#pragma unroll
-        for (int q = 0; q < 10; q++) if (v[q] != INI_NOKEY) { snd += ini_unkey(v[q]); sn += 1; }
-        if (r.self != dummyOff && self == INI_NOKEY && sn > 0) *(int *) (base + r.self) = ini_key(snd / sn);
-    }
+    for (int q = 0; q < 10; q++) if (v[q] != INI_NOKEY) { snd += ini_unkey(v[q]); sn += 1; }
+    if (r.self != dummyOff && self == INI_NOKEY && sn > 0) *(int *) (base + r.self) = ini_key(snd / sn);
 }
 // Executed by wave 0.  The pass inputs are stored in schedule order, so every pass needs one level of coalesced global loads,
-// issued four passes ahead; the dependent chain of a pass is LDS gather -> median -> LDS write.
-template <int OP>
-__device__ void ini_sweep(const IniLevel &L, int *sIR) {
+// issued four passes ahead; the dependent chain of a pass is LDS gather -> sum -> LDS write.
+__device__ void ini_sweep_reset(const IniLevel &L, int *sIR) {
     if (threadIdx.x >= 64) return;
     const int lane = threadIdx.x;
     if (L.nPass == 0) return;
     const int dummyOff = L.n * 4;
     SwIn r0 = ini_sw_load(L, 0, lane), r1 = ini_sw_load(L, 1, lane), r2 = ini_sw_load(L, 2, lane), r3 = ini_sw_load(L, 3, lane);
     for (int p = 0; p < L.nPass; p += 4) {
-        ini_sw_point<OP>(r0, sIR, dummyOff); r0 = ini_sw_load(L, p + 4, lane);
-        ini_sw_point<OP>(r1, sIR, dummyOff); r1 = ini_sw_load(L, p + 5, lane);
-        ini_sw_point<OP>(r2, sIR, dummyOff); r2 = ini_sw_load(L, p + 6, lane);
-        ini_sw_point<OP>(r3, sIR, dummyOff); r3 = ini_sw_load(L, p + 7, lane);
+        ini_sw_point(r0, sIR, dummyOff); r0 = ini_sw_load(L, p + 4, lane);
+        ini_sw_point(r1, sIR, dummyOff); r1 = ini_sw_load(L, p + 5, lane);
+        ini_sw_point(r2, sIR, dummyOff); r2 = ini_sw_load(L, p + 6, lane);
+        ini_sw_point(r3, sIR, dummyOff); r3 = ini_sw_load(L, p + 7, lane);
     }
 }
 
-__device__ void ini_fill(const IniLevel &L, int *sIR, int pending, const float *idv) {
+// ---- optReg (:430-459), TWO lanes per point.  Which points are good does not change during the sweep, so everything but the median itself is prepared in parallel
+// (ini_prep) right before it: the reference takes nth_element(nnn / 2) of the nnn good neighbours' iR.  Of the 10 - nnn others, 5 - nnn / 2 are pointed at a slot
+// holding the smallest key and the rest at one holding the largest: the wanted value is then ALWAYS the 6th smallest of ten keys - a fixed selection, no count,
+// no select chain.  Lane 2p sorts neighbours 0-4 of its point, lane 2p + 1 neighbours 5-9 (3-input min / med / max: 15 instructions); with a_1 <= .. <= a_5 and
+// b_1 <= .. <= b_5 the 6th smallest of the union is min_i max(a_i, b_(6-i)): five maxima against the partner lane's registers (DPP) and two 3-input minima.
+// A point that is not written (not good, or nnn <= 2) has its result directed at a slot nobody reads; so have the odd lanes and the idle ones.
+// Per lane: a = {LDS addresses of keys 0..3 of its half}, b = {the 5th, LDS address the result goes to, idepth (float bits), -}; addresses, not offsets into
+// the key array: a ds_read takes them as they are
+struct SwRec { int4 a, b; };
+typedef __attribute__((address_space(3))) int ini_lds_int;
+__device__ __forceinline__ SwRec ini_sw2_load(const IniLevel &L, int p, int lane) {
+    const int4 *r = L.swRec + ((size_t) p * 64 + lane) * 2;
+    SwRec o; o.a = r[0]; o.b = r[1];
+    return o;
+}
+__device__ __forceinline__ int ini_min3(int a, int b, int c) { int r; asm("v_min3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ int ini_med3(int a, int b, int c) { int r; asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ int ini_max3(int a, int b, int c) { int r; asm("v_max3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ int ini_pair(int x) { return __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true); }      // the other lane of the pair
+__device__ __forceinline__ void ini_sw2_point(const SwRec &r) {
+    const float regWeight = 0.8f;
+#define GK(adr) (*(const ini_lds_int *) (unsigned long long) (unsigned) (adr))
+    const int v0 = GK(r.a.x), v1 = GK(r.a.y), v2 = GK(r.a.z), v3 = GK(r.a.w), v4 = GK(r.b.x);
+#undef GK
+    // sort five: s = sorted (v0, v1, v2), t = sorted (v3, v4), merged rank k = min over i + j = k of max(s_i, t_j)
+    const int s1 = ini_min3(v0, v1, v2), s2 = ini_med3(v0, v1, v2), s3 = ini_max3(v0, v1, v2);
+    const int t1 = min(v3, v4), t2 = max(v3, v4);
+    const int m1 = min(s1, t1);
+    const int m2 = ini_min3(s2, max(s1, t1), t2);
+    const int m3 = ini_min3(s3, max(s2, t1), max(s1, t2));
+    const int m4 = min(max(s3, t1), max(s2, t2));
+    const int m5 = max(s3, t2);
+    // 6th smallest of the pair's ten
+    const int x1 = max(m1, ini_pair(m5)), x2 = max(m2, ini_pair(m4)), x3 = max(m3, ini_pair(m3)), x4 = max(m4, ini_pair(m2)), x5 = max(m5, ini_pair(m1));
+    const int mk = ini_min3(ini_min3(x1, x2, x3), x4, x5);
+    *(ini_lds_int *) (unsigned long long) (unsigned) r.b.y = ini_key((1 - regWeight) * __builtin_bit_cast(float, r.b.z) + regWeight * ini_unkey(mk));
+}
+// Wavefront 0 sweeps, with the inputs of INI_SW_DEPTH passes in flight.  remote: the records were written by other compute units (k_ini_prep) and lie in
+// memory, not in this XCD's L2 - the other wavefronts of the block pull them in, in sweep order, ahead of wavefront 0 (one dword per 128-byte line).
+#ifndef INI_SW_DEPTH
+#define INI_SW_DEPTH 8
+#endif
+#ifndef INI_SW_TOUCH
+#define INI_SW_TOUCH 1
+#endif
+__device__ void ini_sweep_reg(const IniLevel &L, int *sIR, bool remote) {
+    if (L.nPass2 == 0) return;
+    if (threadIdx.x >= 64) {
+        if (!(INI_SW_TOUCH && remote)) return;
+        const int *rec = (const int *) L.swRec;
+        const int nLines = (L.nPass2 + INI_SWPAD) * 16;                  // 64 lanes x 32 bytes per pass
+        int acc = 0;
+        for (int l = threadIdx.x - 64; l < nLines; l += blockDim.x - 64) acc ^= rec[(size_t) l * 32];
+        asm volatile("" :: "v"(acc));
+        return;
+    }
+    const int lane = threadIdx.x;
+    SwRec r[INI_SW_DEPTH];
+#pragma unroll
+    for (int u = 0; u < INI_SW_DEPTH; u++) r[u] = ini_sw2_load(L, u, lane);
+    for (int p = 0; p < L.nPass2; p += INI_SW_DEPTH) {
+#pragma unroll
+        for (int u = 0; u < INI_SW_DEPTH; u++) { ini_sw2_point(r[u]); r[u] = ini_sw2_load(L, p + INI_SW_DEPTH + u, lane); }
+    }
+}
+
+__device__ void ini_fill(const IniLevel &L, int *sIR, int pending) {
     const int nt = blockDim.x;
-    if (threadIdx.x == 0) sIR[L.n] = INI_NOKEY;          // dummy slot of absent neighbours / idle lanes
+    if (threadIdx.x == 0) { sIR[L.n] = INI_NOKEY; sIR[L.n + 1] = INI_MINKEY; sIR[L.n + 2] = INI_NOKEY; }
     for (int j0 = threadIdx.x; j0 < L.n; j0 += 4 * nt) {
         int g[4], gn[4]; float r[4];
 #pragma unroll
@@ -448,31 +505,69 @@ __device__ void ini_fill(const IniLevel &L, int *sIR, int pending, const float *
 #pragma unroll
         for (int u = 0; u < 4; u++) { const int j = j0 + u * nt; if (j < L.n) sIR[j] = (g[u] && gn[u]) ? ini_key(r[u]) : INI_NOKEY; }
     }
-    if (idv) {
-        const int m = L.nPass * 64;
-        for (int q0 = threadIdx.x; q0 < m; q0 += 4 * nt) {
-            int i[4]; float v[4];
+}
+// The inputs of an optReg sweep of one point (its record pair goes to the point's place in the schedule).  good(j): point j is good in the view the sweep works on.
+template <class Good>
+__device__ __forceinline__ void ini_prep_point(const IniLevel &L, int i, int place, const int4 &na, const int4 &nb_, const int4 &nc, float id, int base, Good good) {
+    const int offMax = base + L.n * 4, offMin = offMax + 4, offNone = offMax + 8;
+    const int j[10] = {na.x, na.y, na.z, na.w, nb_.x, nb_.y, nb_.z, nb_.w, nc.x, nc.y};
+    int off[10], nnn = 0;
 #pragma unroll
-            for (int u = 0; u < 4; u++) { const int q = q0 + u * nt; i[u] = (q < m) ? L.sched[q] : -1; }
+    for (int e = 0; e < 10; e++) { const bool g = j[e] >= 0 && good(max(j[e], 0)); off[e] = g ? base + j[e] * 4 : -1; nnn += g ? 1 : 0; }
+    int low = 5 - (nnn >> 1);
 #pragma unroll
-            for (int u = 0; u < 4; u++) v[u] = (i[u] >= 0) ? idv[i[u]] : 0.0f;
+    for (int e = 0; e < 10; e++) if (off[e] < 0) { off[e] = (low > 0) ? offMin : offMax; low--; }
+    const int selfOff = (good(i) && nnn > 2) ? base + i * 4 : offNone;
+    const int idb = __builtin_bit_cast(int, id);
+    int4 *dst = L.swRec + (size_t) place * 4;                           // two lanes x two int4
+    dst[0] = make_int4(off[0], off[1], off[2], off[3]); dst[1] = make_int4(off[4], selfOff, idb, 0);
+    dst[2] = make_int4(off[5], off[6], off[7], off[8]); dst[3] = make_int4(off[9], offNone, idb, 0);
+}
+// ... by the control block itself (sIR holds the keys): 2.4 MB through ONE compute unit at the two big levels, ~50 us.  Only where the sweep follows a change of
+// the level made by the control step (propagateDown / propagateUp, a step that snaps); the sweep behind an accepted step is prepared by k_ini_prep.
+__device__ void ini_prep(const IniLevel &L, const int *sIR, const float *idv) {
+    const int nt = blockDim.x;
+    const int base = (int) (unsigned long long) (const ini_lds_int *) sIR;
+    for (int j0 = threadIdx.x; j0 < L.n; j0 += 4 * nt) {
+        int q[4]; int4 na[4], nb_[4], nc[4]; float id[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) { const int q = q0 + u * nt; if (q < m) L.schedIdv[q] = v[u]; }
+        for (int u = 0; u < 4; u++) {
+            const int i = min(j0 + u * nt, L.n - 1);
+            const int4 *row = (const int4 *) (L.nb + (size_t) i * INI_NB);
+            q[u] = L.slotOf[i]; na[u] = row[0]; nb_[u] = row[1]; nc[u] = row[2]; id[u] = idv[i];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = j0 + u * nt;
+            if (i < L.n) ini_prep_point(L, i, q[u], na[u], nb_[u], nc[u], id[u], base, [&](int j) { return sIR[j] != INI_NOKEY; });
         }
     }
 }
+// the schedule places no point has: once per handle (BEGIN), every level
+__device__ void ini_prep_idle(const IniLevel &L, const int *sIR) {
+    const int base = (int) (unsigned long long) (const ini_lds_int *) sIR;
+    const int offMax = base + L.n * 4, offNone = offMax + 8;
+    const int4 i1 = make_int4(offMax, offMax, offMax, offMax), i2 = make_int4(offMax, offNone, 0, 0);
+    for (int k = threadIdx.x; k < L.nIdle; k += blockDim.x) { int4 *dst = L.swRec + (size_t) L.idleSlot[k] * 4; dst[0] = i1; dst[1] = i2; dst[2] = i1; dst[3] = i2; }
+}
 
 // optReg(lvl) (:430-459).  pending: an accepted step has not been applied to the arrays yet (lazy applyStep) - use its view.
-__device__ void ini_opt_reg(const IniLevel &L, int *sIR, int snapped, int pending, IniCtl *dbg) {
+__device__ void ini_opt_reg(const IniLevel &L, int *sIR, int snapped, int pending, IniCtl *ctl) {
     if (!snapped) { for (int j = threadIdx.x; j < L.n; j += blockDim.x) L.iR[j] = 1.0f; __syncthreads(); return; }
-    ini_fill(L, sIR, pending, pending ? L.idepth_new : L.idepth);
+#ifdef LDSO_STAMPS
+    const long long tp_ = wall_clock64();
+#endif
+    ini_fill(L, sIR, pending);
+    __syncthreads();
+    const bool remote = pending && ctl->prepReady;                                                  // k_ini_prep has written them
+    if (!remote) ini_prep(L, sIR, pending ? L.idepth_new : L.idepth);
     __syncthreads();
 #ifdef LDSO_STAMPS
     const long long t0_ = wall_clock64();
 #endif
-    ini_sweep<0>(L, sIR);
+    ini_sweep_reg(L, sIR, remote);
 #ifdef LDSO_STAMPS
-    if (threadIdx.x == 0) { dbg->dbgSweepTicks += wall_clock64() - t0_; dbg->dbgSweepPasses += L.nPass; dbg->dbgSweeps++; }
+    if (threadIdx.x == 0) { const long long t1_ = wall_clock64(); ctl->dbgSweepTicks += t1_ - t0_; ctl->dbgPrepTicks += t0_ - tp_; ctl->dbgSweepPasses += L.nPass2; ctl->dbgSweeps++; }
 #endif
     __syncthreads();
     for (int j = threadIdx.x; j < L.n; j += blockDim.x) { const int kk = sIR[j]; if (kk != INI_NOKEY) L.iR[j] = ini_unkey(kk); }
@@ -503,9 +598,9 @@ __device__ void ini_flush_apply(const IniLevel &L) {   // applyStep (:673-687) f
 #define INI_STEP 1
 #define INI_STAGE 2
 
-__global__ __launch_bounds__(INI_CT) void k_ini_ctl(IniParams P, int phase) {
-    IniCtl *ctl = P.ctl;
-    extern __shared__ int sIR[];
+// The control step proper.  ctl is the block's LDS copy of the control record (k_ini_ctl): the decision, the bookkeeping and the pose update are one lane's
+// chains of dependent reads and writes of it.
+__device__ __forceinline__ void ini_ctl_body(const IniParams &P, int phase, IniCtl *ctl, int *sIR) {
     __shared__ double sSum[INI_NPART];
     __shared__ double sPart[INI_CT / 128][128];
     __shared__ float sX[8];
@@ -529,11 +624,13 @@ __global__ __launch_bounds__(INI_CT) void k_ini_ctl(IniParams P, int phase) {
             ctl->lvl = top; ctl->mode = 0; ctl->done = 0; ctl->evals = 0; ctl->applyPending = 0; ctl->iteration = 0; ctl->fails = 0; ctl->lambda = 0.1f;
             for (int q = 0; q < 8; q++) ctl->inc[q] = 0;
         }
+        if (!ctl->idleWritten) for (int l = 0; l < P.levels; l++) ini_prep_idle(P.L[l], sIR);
         __syncthreads();
+        if (tid == 0) { ctl->idleWritten = 1; ctl->ldsBase = (int) (unsigned long long) (const ini_lds_int *) sIR; ctl->prepReady = 0; }
         const IniLevel &L = P.L[top];
-        ini_fill(L, sIR, 0, nullptr);
+        ini_fill(L, sIR, 0);
         __syncthreads();
-        ini_sweep<1>(L, sIR);
+        ini_sweep_reset(L, sIR);
         __syncthreads();
         for (int j = tid; j < L.n; j += blockDim.x) {
             const int kk = sIR[j];
@@ -542,10 +639,8 @@ __global__ __launch_bounds__(INI_CT) void k_ini_ctl(IniParams P, int phase) {
         return;
     }
 
-    if (phase == INI_STEP && ctl->done) return;
 #ifdef LDSO_STAMPS
     const long long tk0_ = wall_clock64();
-    struct TkEnd { IniCtl *c; long long t0; __device__ ~TkEnd() { if (threadIdx.x == 0) c->dbgCtlTicks += wall_clock64() - t0; } } tkEnd_{ctl, tk0_};
 #endif
     const int lvl = ctl->lvl;
     const IniLevel &L = P.L[lvl];
@@ -632,6 +727,9 @@ __global__ __launch_bounds__(INI_CT) void k_ini_ctl(IniParams P, int phase) {
     }
     __syncthreads();
     const int accept = sFlag[0], quit = sFlag[1], doOpt = sFlag[2], snapped = sFlag[3];
+#ifdef LDSO_STAMPS
+    if (tid == 0) ctl->dbgFrontTicks += wall_clock64() - tk0_;
+#endif
     if (doOpt) ini_opt_reg(L, sIR, snapped, 1, ctl);                 // applyStep (pending) + optReg (:137-138)
 
     if (quit) {
@@ -697,6 +795,9 @@ __global__ __launch_bounds__(INI_CT) void k_ini_ctl(IniParams P, int phase) {
     }
 
     // ---- next increment (:90-111) ----
+#ifdef LDSO_STAMPS
+    const long long tt0_ = wall_clock64();
+#endif
     if (tid < 64) {
         const int i = tid >> 3, j = tid & 7;
         const float lambda = ctl->lambda;
@@ -727,7 +828,50 @@ __global__ __launch_bounds__(INI_CT) void k_ini_ctl(IniParams P, int phase) {
         for (int q = 0; q < 12; q++) ctl->Tnew[q] = Tn[q];
         ctl->aNew = ctl->aCur + ctl->inc[6];
         ctl->bNew = ctl->bCur + ctl->inc[7];
+#ifdef LDSO_STAMPS
+        ctl->dbgTailTicks += wall_clock64() - tt0_;
+#endif
     }
+}
+
+__global__ __launch_bounds__(INI_CT) void k_ini_ctl(IniParams P, int phase) {
+    extern __shared__ int sIR[];
+    __shared__ IniCtl sCtl;
+    static_assert(sizeof(IniCtl) % 4 == 0, "IniCtl is copied in dwords");
+    if (phase == INI_STEP && P.ctl->done) return;           // the frame is finished: the rest of the enqueued launches return at once
+#ifdef LDSO_STAMPS
+    const long long tk0_ = wall_clock64();
+#endif
+    for (int q = threadIdx.x; q < (int) (sizeof(IniCtl) / 4); q += blockDim.x) ((int *) &sCtl)[q] = ((const int *) P.ctl)[q];
+    __syncthreads();
+    ini_ctl_body(P, phase, &sCtl, sIR);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        sCtl.prepReady = 0;
+#ifdef LDSO_STAMPS
+        if (phase != INI_BEGIN) sCtl.dbgCtlTicks += wall_clock64() - tk0_;
+#endif
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < (int) (sizeof(IniCtl) / 4); q += blockDim.x) ((int *) P.ctl)[q] = ((const int *) &sCtl)[q];
+}
+
+// The sweep inputs of the step an evaluation has just tried, by the whole chip instead of the control block (launched between k_ini_eval and k_ini_ctl): if the
+// control step accepts it, optReg (:137-138) sweeps the level in the view "good and still good after the step" with the new inverse depths - both final when
+// k_ini_eval ends.  Wasted when the step is rejected (a few us beside the evaluation).
+#define INI_PT 256
+__global__ __launch_bounds__(INI_PT) void k_ini_prep(IniParams P) {
+    const IniCtl *ctl = P.ctl;
+    // nothing to prepare: frame finished; optReg only resets iR before the snap (a step that snaps is prepared by the control step itself); first evaluation of a level
+    if (ctl->done || !ctl->snapped || ctl->mode == 0) return;
+    const IniLevel &L = P.L[ctl->lvl];
+    const int base = ctl->ldsBase;
+    for (int i = blockIdx.x * INI_PT + threadIdx.x; i < L.n; i += gridDim.x * INI_PT) {
+        const int4 *row = (const int4 *) (L.nb + (size_t) i * INI_NB);
+        const int4 na = row[0], nb_ = row[1], nc = row[2];
+        ini_prep_point(L, i, L.slotOf[i], na, nb_, nc, L.idepth_new[i], base, [&](int j) { return L.isGood[j] && L.isGood_new[j]; });
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) P.ctl->prepReady = 1;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -743,6 +887,9 @@ struct ldso_initializer {
     float *d_color = nullptr;
     int n[INI_MAXL] = {0};
     size_t ldsBytes = 0;
+    int prepBlocks = 1;                 // k_ini_prep: one thread per point of the largest level
+    bool snappedAtFrameStart = false;   // host copy of the state's snapped (get_state / set_state / set_first): before the snap optReg does not sweep and the
+                                        // k_ini_prep launches would be empty (the frame that snaps prepares its sweeps in the control block)
     bool haveFirst = false, haveNew = false;
 };
 
@@ -890,7 +1037,32 @@ int ldso_init_set_first(ldso_initializer_t *H, const float calib[4], const float
         }
         { int r_ = ini_upload(H, &L.parent, parent); if (r_ != LDSO_OK) return r_; }
         { int r_ = ini_upload(H, &L.nb, nb); if (r_ != LDSO_OK) return r_; }
-        // sweep schedule: dep(i) = max(dep(j) + 1 over neighbours j < i, dep(k) over readers k < i of i)
+        // optReg sweep schedule (all levels; two lanes per point: passes of <= 32): point i goes into the first pass with a free place that is behind the passes
+        // of all its neighbours j < i and not before the pass of any reader k < i of i - first fit in index order (both conditions only look at lower indices).
+        // 640 x 480: 341 / 719 / 654 / 196 passes for 8.4k / 18.4k / 17.2k / 3.8k points (dependency depth 341 / 586 / 412 / 196)
+        {
+            std::vector<int> pass(n, 0), rd(n, 0), fillOf;
+            for (int i = 0; i < n; i++) {
+                int e = rd[i];
+                for (int q = 0; q < 10; q++) { const int j = nb[(size_t) i * INI_NB + q]; if (j >= 0 && j < i) e = std::max(e, pass[j] + 1); }
+                while (e < (int) fillOf.size() && fillOf[e] >= 32) e++;
+                if (e >= (int) fillOf.size()) fillOf.resize(e + 1, 0);
+                pass[i] = e;
+                for (int q = 0; q < 10; q++) { const int j = nb[(size_t) i * INI_NB + q]; if (j > i) rd[j] = std::max(rd[j], e); }
+                fillOf[e]++;
+            }
+            L.nPass2 = (int) fillOf.size();
+            std::vector<int> slotOf(n), at(L.nPass2, 0), idleSlot;
+            for (int i = 0; i < n; i++) slotOf[i] = pass[i] * 32 + at[pass[i]]++;
+            for (int p = 0; p < L.nPass2 + INI_SWPAD; p++) for (int q = (p < L.nPass2 ? at[p] : 0); q < 32; q++) idleSlot.push_back(p * 32 + q);
+            L.nIdle = (int) idleSlot.size();
+            { int *p = nullptr; int r_ = ini_upload(H, &p, slotOf); if (r_ != LDSO_OK) return r_; L.slotOf = p; }
+            { int *p = nullptr; int r_ = ini_upload(H, &p, idleSlot); if (r_ != LDSO_OK) return r_; L.idleSlot = p; }
+            IA(H->levelAllocs, L.swRec, (size_t) (L.nPass2 + INI_SWPAD) * 64 * 2);      // per-lane inputs: ini_prep writes them before every sweep (the places without a point: once)
+        }
+        if (l + 1 < H->levels) { L.nPass = 0; L.sched = nullptr; L.schedOff = nullptr; L.schedNb = nullptr; }
+        else {
+        // resetPoints sweep schedule (top level): dep(i) = max(dep(j) + 1 over neighbours j < i, dep(k) over readers k < i of i)
         std::vector<int> dep(n, 0);
         {
             std::vector<int> rd(n, 0);      // max dep of the lower-indexed readers seen so far
@@ -923,7 +1095,7 @@ int ldso_init_set_first(ldso_initializer_t *H, const float calib[4], const float
                 }
             int *p = nullptr; int r_ = ini_upload(H, &p, snb); if (r_ != LDSO_OK) return r_; L.schedNb = p;
             p = nullptr; r_ = ini_upload(H, &p, soff); if (r_ != LDSO_OK) return r_; L.schedOff = p;
-            IA(H->levelAllocs, L.schedIdv, sched.size());
+        }
         }
         // children lists (points of level l-1 whose parent is p), ascending child index
         std::vector<int> off(n + 1, 0), idx(nDown);
@@ -938,8 +1110,10 @@ int ldso_init_set_first(ldso_initializer_t *H, const float calib[4], const float
         { int *p = nullptr; int r_ = ini_upload(H, &p, idx); if (r_ != LDSO_OK) return r_; L.childIdx = p; }
         { int r_ = ini_put_points(H, l, pts); if (r_ != LDSO_OK) return r_; }
     }
-    H->ldsBytes = (maxN + 1) * sizeof(float);
+    H->ldsBytes = (maxN + INI_LDS_EXTRA) * sizeof(float);
+    H->prepBlocks = (int) std::max<size_t>(1, (maxN + INI_PT - 1) / INI_PT);
     CHK(hipFuncSetAttribute((const void *) k_ini_ctl, hipFuncAttributeMaxDynamicSharedMemorySize, (int) H->ldsBytes));
+    H->snappedAtFrameStart = false;
     // state of setFirst (:612-614)
     IniCtl c; memset(&c, 0, sizeof(c));
     c.Tcur[0] = c.Tcur[5] = c.Tcur[10] = 1.0; c.Tnew[0] = c.Tnew[5] = c.Tnew[10] = 1.0; c.done = 1;
@@ -966,6 +1140,7 @@ int ldso_init_get_state(ldso_initializer_t *H, ldso_init_state_t *s) {
     CHK(hipMemcpyAsync(&c, H->P.ctl, sizeof(c), hipMemcpyDeviceToHost, H->stream));
     CHK(hipStreamSynchronize(H->stream));
     memcpy(s->thisToNext, c.Tcur, sizeof(c.Tcur));
+    H->snappedAtFrameStart = c.snapped != 0;
     s->aff_a = c.aCur; s->aff_b = c.bCur; s->snapped = c.snapped; s->snappedAt = c.snappedAt; s->frameID = c.frameID;
     s->ready = c.snapped && c.frameID > c.snappedAt + 5; s->evals = c.evals; s->pad_ = 0;
     return LDSO_OK;
@@ -980,6 +1155,7 @@ int ldso_init_set_state(ldso_initializer_t *H, const ldso_init_state_t *s) {
     memcpy(c.Tcur, s->thisToNext, sizeof(c.Tcur)); memcpy(c.Tnew, s->thisToNext, sizeof(c.Tnew));
     c.aCur = (float) s->aff_a; c.bCur = (float) s->aff_b; c.aNew = c.aCur; c.bNew = c.bCur;
     c.snapped = s->snapped; c.snappedAt = s->snappedAt; c.frameID = s->frameID;
+    H->snappedAtFrameStart = c.snapped != 0;
     CHK(hipMemcpyAsync(H->P.ctl, &c, sizeof(c), hipMemcpyHostToDevice, H->stream));
     CHK(hipStreamSynchronize(H->stream));
     return LDSO_OK;
@@ -997,6 +1173,7 @@ int ldso_init_track_frame(ldso_initializer_t *H, const float *irradiance, float 
     hipLaunchKernelGGL(k_ini_ctl, dim3(1), dim3(INI_CT), H->ldsBytes, H->stream, H->P, INI_BEGIN);
     for (int p = 0; p < pairs; p++) {
         hipLaunchKernelGGL(k_ini_eval, dim3(INI_MAXBLK), dim3(INI_NT), 0, H->stream, H->P, 0);
+        if (H->snappedAtFrameStart) hipLaunchKernelGGL(k_ini_prep, dim3(H->prepBlocks), dim3(INI_PT), 0, H->stream, H->P);
         hipLaunchKernelGGL(k_ini_ctl, dim3(1), dim3(INI_CT), H->ldsBytes, H->stream, H->P, INI_STEP);
     }
     CHK(hipGetLastError());
@@ -1010,14 +1187,15 @@ int ldso_init_track_frame(ldso_initializer_t *H, const float *irradiance, float 
     return LDSO_OK;
 }
 
-// debug (LDSO_STAMPS builds): accumulated device-side ticks (100 MHz): sweep ticks, sweep passes, control-kernel ticks, sweeps
-int ldso_init_debug_counters(ldso_initializer_t *H, long long out[4]) {
+// debug (LDSO_STAMPS builds): accumulated device-side ticks (100 MHz): sweep ticks, sweep passes, control-kernel ticks, sweeps, fill + prepare ticks,
+// ticks up to the accept decision, ticks of the next increment (solve, exp), -
+int ldso_init_debug_counters(ldso_initializer_t *H, long long out[8]) {
     REQ(H && out, "null argument");
     CHK(hipSetDevice(H->device));
     CHK(hipStreamSynchronize(H->stream));
     IniCtl c;
     CHK(hipMemcpy(&c, H->P.ctl, sizeof(c), hipMemcpyDeviceToHost));
-    out[0] = c.dbgSweepTicks; out[1] = c.dbgSweepPasses; out[2] = c.dbgCtlTicks; out[3] = c.dbgSweeps;
+    out[0] = c.dbgSweepTicks; out[1] = c.dbgSweepPasses; out[2] = c.dbgCtlTicks; out[3] = c.dbgSweeps; out[4] = c.dbgPrepTicks; out[5] = c.dbgFrontTicks; out[6] = c.dbgTailTicks; out[7] = c.dbgSpare;
     return LDSO_OK;
 }
 

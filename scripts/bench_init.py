@@ -21,8 +21,10 @@ for k in range(n):
     g.set_new_frame(img, 1.0)
     t0 = time.perf_counter(); sg = g.track_frame(); tg = time.perf_counter() - t0
     import ctypes as C
-    dbg = (C.c_longlong * 4)(); g.L.ldso_init_debug_counters(g.h, dbg)
-    if dbg[3]: print("   sweeps", dbg[3], "passes", dbg[1], "sweep us %.0f (%.2f us/pass)" % (dbg[0] / 100.0, dbg[0] / 100.0 / max(dbg[1], 1)), "ctl kernels us %.0f" % (dbg[2] / 100.0))
+    dbg = (C.c_longlong * 8)(); g.L.ldso_init_debug_counters(g.h, dbg)
+    if dbg[3]:       # -DLDSO_STAMPS builds; the counters accumulate over the frames
+        print("   sweeps", dbg[3], "passes", dbg[1], "sweep us %.0f (%.3f us/pass)" % (dbg[0] / 100.0, dbg[0] / 100.0 / max(dbg[1], 1)), "ctl kernels us %.0f" % (dbg[2] / 100.0),
+              "of it: fill+prepare %.0f, up to the decision %.0f, next increment %.0f" % (dbg[4] / 100.0, dbg[5] / 100.0, dbg[6] / 100.0))
     To, Tg = so["thisToNext"].reshape(3, 4), sg["thisToNext"].reshape(3, 4)
     p0o, p0g = o.points(0), g.points(0)
     gd = (p0o["isGood"] != 0) & (p0g["isGood"] != 0)
