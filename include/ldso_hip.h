@@ -402,6 +402,11 @@ int ldso_init_set_points(ldso_initializer_t *t, int lvl, const ldso_init_point_t
 int ldso_init_calc_res_and_gs(ldso_initializer_t *t, int lvl, const double refToNew[12], double aff_a, double aff_b,
                               float *H, float *b, float *Hsc, float *bsc, float *res, float *ec);
 int ldso_init_set_new_frame(ldso_initializer_t *t, const float *irradiance, float ab_exposure);
+/* Host logic, no device: the schedule of the in-place optReg sweep (CoarseInitializer.cc:430-459: points are updated in index order, reading neighbours that
+ * may already have been updated) as ldso_init_set_first builds it for one level.  neighbours [n][10] (-1 = none), width = points per pass (32 on the device).
+ * pass_out[i] = pass of point i: every neighbour j < i in an earlier pass, every neighbour j > i in the same or a later one, <= width points per pass.
+ * Returns the number of passes, or a negative LDSO_E_* code. */
+int ldso_init_sweep_schedule(int n, const int *neighbours, int width, int *pass_out);
 /* debug builds (LDSO_STAMPS=1): accumulated device-side counters, zeros otherwise */
 int ldso_init_debug_counters(ldso_initializer_t *t, long long out[8]);
 

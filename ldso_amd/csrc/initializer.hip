@@ -81,6 +81,8 @@ struct IniCtl {
     int lvl, mode, iteration, fails, done, snapped, snappedAt, frameID, jbSel, applyPending, evals, ready;
     int idleWritten;                    // the records of the schedule places that hold no point are written (ini_prep_idle)
     int ldsBase;                        // LDS address of the control block's key array (the sweep records hold LDS addresses)
+    int sweepDue, upGoing;              // level + 1 whose optReg sweep (view: good points, applied depths) is the next control step's; in the propagateUp chain
+    int steps;                          // control steps of this frame so far (INI_STEP launches that did something)
     int prepReady;                      // k_ini_prep has written the records of the level for the step this evaluation tried; consumed by the control step
     long long dbgSweepTicks, dbgSweepPasses, dbgCtlTicks, dbgSweeps, dbgPrepTicks, dbgFrontTicks, dbgTailTicks, dbgSpare;     // LDSO_STAMPS builds only (100 MHz wall clock)
 };
@@ -109,7 +111,7 @@ __device__ __forceinline__ int ini_nblocks(int n, int gridCap) { const int nb = 
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(INI_NT) void k_ini_eval(IniParams P, int stage) {
     const IniCtl *ctl = P.ctl;
-    if (!stage && ctl->done) return;
+    if (!stage && (ctl->done || ctl->sweepDue)) return;         // frame finished / a level transition's control step comes first
     const int lvl = ctl->lvl;
     const IniLevel &L = P.L[lvl];
     const int n = L.n;
@@ -552,14 +554,14 @@ __device__ void ini_prep_idle(const IniLevel &L, const int *sIR) {
 }
 
 // optReg(lvl) (:430-459).  pending: an accepted step has not been applied to the arrays yet (lazy applyStep) - use its view.
-__device__ void ini_opt_reg(const IniLevel &L, int *sIR, int snapped, int pending, IniCtl *ctl) {
+__device__ void ini_opt_reg(const IniLevel &L, int *sIR, int snapped, int pending, bool prepared, IniCtl *ctl) {
     if (!snapped) { for (int j = threadIdx.x; j < L.n; j += blockDim.x) L.iR[j] = 1.0f; __syncthreads(); return; }
 #ifdef LDSO_STAMPS
     const long long tp_ = wall_clock64();
 #endif
     ini_fill(L, sIR, pending);
     __syncthreads();
-    const bool remote = pending && ctl->prepReady;                                                  // k_ini_prep has written them
+    const bool remote = prepared && ctl->prepReady;                                                 // k_ini_prep has written them (for this very sweep: prepared)
     if (!remote) ini_prep(L, sIR, pending ? L.idepth_new : L.idepth);
     __syncthreads();
 #ifdef LDSO_STAMPS
@@ -598,6 +600,58 @@ __device__ void ini_flush_apply(const IniLevel &L) {   // applyStep (:673-687) f
 #define INI_STEP 1
 #define INI_STAGE 2
 
+// propagateDown(lvl) (:498-522) into level lvl - 1
+__device__ void ini_propagate_down(const IniParams &P, int lvl) {
+    const IniLevel &L = P.L[lvl];
+    const int tid = threadIdx.x;
+    const IniLevel &F = P.L[lvl - 1];
+    const int nt = blockDim.x;
+    for (int j0 = tid; j0 < F.n; j0 += 4 * nt) {
+        int pa[4], pg[4], fg[4]; float plh[4], pir[4], fir[4], flh[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int j = min(j0 + u * nt, F.n - 1); pa[u] = F.parent[j]; fg[u] = F.isGood[j]; fir[u] = F.iR[j]; flh[u] = F.lastHessian[j]; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) { pg[u] = L.isGood[pa[u]]; plh[u] = L.lastHessian[pa[u]]; pir[u] = L.iR[pa[u]]; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int j = j0 + u * nt;
+            if (j >= F.n) continue;
+            if (!pg[u] || plh[u] < 0.1f) continue;
+            if (!fg[u]) {
+                const float r = pir[u];
+                F.iR[j] = r; F.idepth[j] = r; F.idepth_new[j] = r; F.isGood[j] = 1; F.lastHessian[j] = 0;
+            } else {
+                const float newiR = (fir[u] * flh[u] * 2 + pir[u] * plh[u]) / (flh[u] * 2 + plh[u]);
+                F.iR[j] = newiR; F.idepth[j] = newiR; F.idepth_new[j] = newiR;
+            }
+        }
+    }
+}
+// propagateUp(s) (:462-496) into level s + 1
+__device__ void ini_propagate_up(const IniParams &P, int s) {
+    const IniLevel &S = P.L[s], &D = P.L[s + 1];
+    for (int p = threadIdx.x; p < D.n; p += blockDim.x) {
+        float a = 0, sum = 0;
+        for (int q = D.childOff[p]; q < D.childOff[p + 1]; q++) {
+            const int c = D.childIdx[q];
+            if (!S.isGood[c]) continue;
+            a += S.iR[c] * S.lastHessian[c];
+            sum += S.lastHessian[c];
+        }
+        D.iRSumNum[p] = sum;
+        if (sum > 0) { const float r = a / sum; D.iR[p] = r; D.idepth[p] = r; D.isGood[p] = 1; }
+        else D.iR[p] = a;
+    }
+}
+// the end of trackFrame (:165-177), one lane
+__device__ __forceinline__ void ini_frame_end(IniCtl *ctl) {
+    ctl->frameID++;
+    if (!ctl->snapped) ctl->snappedAt = 0;
+    if (ctl->snapped && ctl->snappedAt == 0) ctl->snappedAt = ctl->frameID;
+    ctl->ready = ctl->snapped && ctl->frameID > ctl->snappedAt + 5;
+    ctl->done = 1;
+}
+
 // The control step proper.  ctl is the block's LDS copy of the control record (k_ini_ctl): the decision, the bookkeeping and the pose update are one lane's
 // chains of dependent reads and writes of it.
 __device__ __forceinline__ void ini_ctl_body(const IniParams &P, int phase, IniCtl *ctl, int *sIR) {
@@ -626,7 +680,7 @@ __device__ __forceinline__ void ini_ctl_body(const IniParams &P, int phase, IniC
         }
         if (!ctl->idleWritten) for (int l = 0; l < P.levels; l++) ini_prep_idle(P.L[l], sIR);
         __syncthreads();
-        if (tid == 0) { ctl->idleWritten = 1; ctl->ldsBase = (int) (unsigned long long) (const ini_lds_int *) sIR; ctl->prepReady = 0; }
+        if (tid == 0) { ctl->idleWritten = 1; ctl->ldsBase = (int) (unsigned long long) (const ini_lds_int *) sIR; ctl->prepReady = 0; ctl->steps = 0; ctl->sweepDue = 0; ctl->upGoing = 0; }
         const IniLevel &L = P.L[top];
         ini_fill(L, sIR, 0);
         __syncthreads();
@@ -642,6 +696,19 @@ __device__ __forceinline__ void ini_ctl_body(const IniParams &P, int phase, IniC
 #ifdef LDSO_STAMPS
     const long long tk0_ = wall_clock64();
 #endif
+    if (phase == INI_STEP && ctl->sweepDue) {                   // a level transition of a snapped frame: the sweep behind propagateDown / propagateUp, then what follows it
+        const int sl = ctl->sweepDue - 1, up = ctl->upGoing;
+        ini_opt_reg(P.L[sl], sIR, 1, 0, true, ctl);
+        if (up && sl + 1 < P.levels) {
+            ini_propagate_up(P, sl);
+            __syncthreads();
+            if (tid == 0) ctl->sweepDue = sl + 2;
+        } else if (tid == 0) {
+            ctl->sweepDue = 0;
+            if (up) { ctl->upGoing = 0; ini_frame_end(ctl); }
+        }
+        return;
+    }
     const int lvl = ctl->lvl;
     const IniLevel &L = P.L[lvl];
     const int n = L.n;
@@ -730,66 +797,34 @@ __device__ __forceinline__ void ini_ctl_body(const IniParams &P, int phase, IniC
 #ifdef LDSO_STAMPS
     if (tid == 0) ctl->dbgFrontTicks += wall_clock64() - tk0_;
 #endif
-    if (doOpt) ini_opt_reg(L, sIR, snapped, 1, ctl);                 // applyStep (pending) + optReg (:137-138)
+    if (doOpt) ini_opt_reg(L, sIR, snapped, 1, true, ctl);                 // applyStep (pending) + optReg (:137-138)
 
     if (quit) {
         if (accept) ini_flush_apply(L);
         if (tid == 0) ctl->applyPending = 0;
-        if (lvl > 0) {                                          // propagateDown(lvl) (:498-522) into level lvl-1
-            const IniLevel &F = P.L[lvl - 1];
-            const int nt = blockDim.x;
-            for (int j0 = tid; j0 < F.n; j0 += 4 * nt) {
-                int pa[4], pg[4], fg[4]; float plh[4], pir[4], fir[4], flh[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) { const int j = min(j0 + u * nt, F.n - 1); pa[u] = F.parent[j]; fg[u] = F.isGood[j]; fir[u] = F.iR[j]; flh[u] = F.lastHessian[j]; }
-#pragma unroll
-                for (int u = 0; u < 4; u++) { pg[u] = L.isGood[pa[u]]; plh[u] = L.lastHessian[pa[u]]; pir[u] = L.iR[pa[u]]; }
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int j = j0 + u * nt;
-                    if (j >= F.n) continue;
-                    if (!pg[u] || plh[u] < 0.1f) continue;
-                    if (!fg[u]) {
-                        const float r = pir[u];
-                        F.iR[j] = r; F.idepth[j] = r; F.idepth_new[j] = r; F.isGood[j] = 1; F.lastHessian[j] = 0;
-                    } else {
-                        const float newiR = (fir[u] * flh[u] * 2 + pir[u] * plh[u]) / (flh[u] * 2 + plh[u]);
-                        F.iR[j] = newiR; F.idepth[j] = newiR; F.idepth_new[j] = newiR;
-                    }
-                }
-            }
+        // Once snapped, the optReg sweep that follows a propagation is the next control step's (ini_transition_step): k_ini_prep prepares it in between, on the
+        // whole chip, instead of this block streaming the level's records through one compute unit (~50 us at the big levels)
+        if (lvl > 0) {
+            ini_propagate_down(P, lvl);
             __syncthreads();
-            ini_opt_reg(F, sIR, snapped, 0, ctl);
+            if (snapped) { if (tid == 0) ctl->sweepDue = lvl; }          // level lvl - 1, stored + 1
+            else ini_opt_reg(P.L[lvl - 1], sIR, 0, 0, false, ctl);
             if (tid == 0) {
                 ctl->lvl = lvl - 1; ctl->mode = 0;
                 for (int q = 0; q < 12; q++) ctl->Tnew[q] = ctl->Tcur[q];
                 ctl->aNew = ctl->aCur; ctl->bNew = ctl->bCur;
             }
-        } else {                                                // :165-177
-            for (int s = 0; s + 1 < P.levels; s++) {            // propagateUp(s) (:462-496)
-                const IniLevel &S = P.L[s], &D = P.L[s + 1];
-                for (int p = tid; p < D.n; p += blockDim.x) {
-                    float a = 0, sum = 0;
-                    for (int q = D.childOff[p]; q < D.childOff[p + 1]; q++) {
-                        const int c = D.childIdx[q];
-                        if (!S.isGood[c]) continue;
-                        a += S.iR[c] * S.lastHessian[c];
-                        sum += S.lastHessian[c];
-                    }
-                    D.iRSumNum[p] = sum;
-                    if (sum > 0) { const float r = a / sum; D.iR[p] = r; D.idepth[p] = r; D.isGood[p] = 1; }
-                    else D.iR[p] = a;
-                }
+        } else if (snapped && P.levels > 1) {                   // :165-177, continued by the transition steps
+            ini_propagate_up(P, 0);
+            __syncthreads();
+            if (tid == 0) { ctl->sweepDue = 2; ctl->upGoing = 1; }
+        } else {
+            for (int s = 0; s + 1 < P.levels; s++) {
+                ini_propagate_up(P, s);
                 __syncthreads();
-                ini_opt_reg(D, sIR, snapped, 0, ctl);
+                ini_opt_reg(P.L[s + 1], sIR, snapped, 0, false, ctl);
             }
-            if (tid == 0) {
-                ctl->frameID++;
-                if (!ctl->snapped) ctl->snappedAt = 0;
-                if (ctl->snapped && ctl->snappedAt == 0) ctl->snappedAt = ctl->frameID;
-                ctl->ready = ctl->snapped && ctl->frameID > ctl->snappedAt + 5;
-                ctl->done = 1;
-            }
+            if (tid == 0) ini_frame_end(ctl);
         }
         return;
     }
@@ -848,6 +883,7 @@ __global__ __launch_bounds__(INI_CT) void k_ini_ctl(IniParams P, int phase) {
     __syncthreads();
     if (threadIdx.x == 0) {
         sCtl.prepReady = 0;
+        if (phase == INI_STEP) sCtl.steps++;
 #ifdef LDSO_STAMPS
         if (phase != INI_BEGIN) sCtl.dbgCtlTicks += wall_clock64() - tk0_;
 #endif
@@ -862,14 +898,19 @@ __global__ __launch_bounds__(INI_CT) void k_ini_ctl(IniParams P, int phase) {
 #define INI_PT 256
 __global__ __launch_bounds__(INI_PT) void k_ini_prep(IniParams P) {
     const IniCtl *ctl = P.ctl;
-    // nothing to prepare: frame finished; optReg only resets iR before the snap (a step that snaps is prepared by the control step itself); first evaluation of a level
-    if (ctl->done || !ctl->snapped || ctl->mode == 0) return;
-    const IniLevel &L = P.L[ctl->lvl];
+    // nothing to prepare: frame finished; optReg only resets iR before the snap (a step that snaps is prepared by the control step itself)
+    if (ctl->done || !ctl->snapped) return;
+    const int due = ctl->sweepDue;
+    if (!due && ctl->mode == 0) return;                         // first evaluation of a level: no step to accept
+    // the sweep behind a propagation (level due - 1: good points, applied depths) or the one behind the step just evaluated (good and still good, new depths)
+    const IniLevel &L = P.L[due ? due - 1 : ctl->lvl];
+    const float *idv = due ? L.idepth : L.idepth_new;
     const int base = ctl->ldsBase;
     for (int i = blockIdx.x * INI_PT + threadIdx.x; i < L.n; i += gridDim.x * INI_PT) {
         const int4 *row = (const int4 *) (L.nb + (size_t) i * INI_NB);
         const int4 na = row[0], nb_ = row[1], nc = row[2];
-        ini_prep_point(L, i, L.slotOf[i], na, nb_, nc, L.idepth_new[i], base, [&](int j) { return L.isGood[j] && L.isGood_new[j]; });
+        if (due) ini_prep_point(L, i, L.slotOf[i], na, nb_, nc, idv[i], base, [&](int j) { return L.isGood[j] != 0; });
+        else ini_prep_point(L, i, L.slotOf[i], na, nb_, nc, idv[i], base, [&](int j) { return L.isGood[j] && L.isGood_new[j]; });
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) P.ctl->prepReady = 1;
 }
@@ -888,6 +929,8 @@ struct ldso_initializer {
     int n[INI_MAXL] = {0};
     size_t ldsBytes = 0;
     int prepBlocks = 1;                 // k_ini_prep: one thread per point of the largest level
+    int lastSteps = 0, stepsTaken = 0;  // control steps of the previous frame / of the frame just read back (get_state)
+    bool frameDone = false;
     bool snappedAtFrameStart = false;   // host copy of the state's snapped (get_state / set_state / set_first): before the snap optReg does not sweep and the
                                         // k_ini_prep launches would be empty (the frame that snaps prepares its sweeps in the control block)
     bool haveFirst = false, haveNew = false;
@@ -908,6 +951,81 @@ template <class T> static int ini_alloc(std::vector<void *> &v, T **p, size_t n)
 #define IA(vec, ptr, n) do { int r_ = ini_alloc(vec, &(ptr), (n)); if (r_ != LDSO_OK) return r_; } while (0)
 
 // upload helper: host vector -> new device array
+// The schedule of the optReg sweep: pass[i] for every point such that (a) every neighbour j < i of i sits in an EARLIER pass (i reads j's new value), (b) every
+// neighbour j > i of i sits in the SAME or a later pass (i reads j's old value; reads come before writes within a pass) and (c) no pass holds more than `width`
+// points.  The reference's in-place loop over i (CoarseInitializer.cc:430-459) is pass 0, 1, 2, ... of this schedule executed in order.
+// Two constructions, the shorter one wins: first fit in index order (both conditions only look at lower indices), and list scheduling by the length of the
+// chain that still hangs on a point (the dependency depth is a diagonal front through the raster; where it is wider than a pass, the points with the longest
+// tails go first).  640 x 480 (8.4k / 18.4k / 17.2k / 3.8k points, depth 341 / 586 / 412 / 196): first fit 341 / 719 / 654 / 196 passes, list 341 / 642 / 606 / 196.
+static bool ini_schedule_valid(int n, const int *nb, int width, const std::vector<int> &pass, int nPass) {
+    std::vector<int> cnt(std::max(nPass, 1), 0);
+    for (int i = 0; i < n; i++) {
+        if (pass[i] < 0 || pass[i] >= nPass || ++cnt[pass[i]] > width) return false;
+        for (int q = 0; q < 10; q++) {
+            const int j = nb[(size_t) i * 10 + q];
+            if (j < 0 || j == i) continue;
+            if (j < i ? !(pass[j] < pass[i]) : !(pass[j] >= pass[i])) return false;
+        }
+    }
+    return true;
+}
+static int ini_sweep_schedule(int n, const int *nb, int width, int *passOut) {
+    if (n <= 0) return 0;
+    // first fit
+    std::vector<int> ff(n, 0), rd(n, 0), fillOf;
+    for (int i = 0; i < n; i++) {
+        int e = rd[i];
+        for (int q = 0; q < 10; q++) { const int j = nb[(size_t) i * 10 + q]; if (j >= 0 && j < i) e = std::max(e, ff[j] + 1); }
+        while (e < (int) fillOf.size() && fillOf[e] >= width) e++;
+        if (e >= (int) fillOf.size()) fillOf.resize(e + 1, 0);
+        ff[i] = e;
+        for (int q = 0; q < 10; q++) { const int j = nb[(size_t) i * 10 + q]; if (j > i && j < n) rd[j] = std::max(rd[j], e); }
+        fillOf[e]++;
+    }
+    const int nFF = (int) fillOf.size();
+    // list scheduling.  after[j]: the points i > j that have j as a neighbour (i waits for j's pass to be over); before[j]: the readers i < j of j (j must not
+    // come before them); tail[i]: passes that must still follow the pass of i
+    std::vector<int> offA(n + 1, 0), offB(n + 1, 0), waits(n, 0);
+    for (int i = 0; i < n; i++) for (int q = 0; q < 10; q++) { const int j = nb[(size_t) i * 10 + q]; if (j < 0 || j >= n || j == i) continue; if (j < i) { offA[j + 1]++; waits[i]++; } else offB[j + 1]++; }
+    for (int i = 0; i < n; i++) { offA[i + 1] += offA[i]; offB[i + 1] += offB[i]; }
+    std::vector<int> after(offA[n]), before(offB[n]), curA(offA.begin(), offA.end() - 1), curB(offB.begin(), offB.end() - 1);
+    for (int i = 0; i < n; i++) for (int q = 0; q < 10; q++) { const int j = nb[(size_t) i * 10 + q]; if (j < 0 || j >= n || j == i) continue; if (j < i) after[curA[j]++] = i; else before[curB[j]++] = i; }
+    std::vector<int> tail(n, 0);
+    for (int i = n - 1; i >= 0; i--) {
+        int t = 0;
+        for (int a = offA[i]; a < offA[i + 1]; a++) t = std::max(t, tail[after[a]] + 1);
+        for (int q = 0; q < 10; q++) { const int j = nb[(size_t) i * 10 + q]; if (j > i && j < n) t = std::max(t, tail[j]); }
+        tail[i] = t;
+    }
+    std::vector<int> ls(n, -1), ready, chosen, deferred;
+    std::vector<char> inPass(n, 0);
+    for (int i = 0; i < n; i++) if (waits[i] == 0) ready.push_back(i);
+    int left = n, t = 0;
+    bool stuck = false;
+    while (left > 0 && !stuck) {
+        std::sort(ready.begin(), ready.end(), [&](int a, int b) { return tail[a] != tail[b] ? tail[a] > tail[b] : a < b; });
+        chosen.clear(); deferred.clear();
+        auto free_ = [&](int i) { for (int a = offB[i]; a < offB[i + 1]; a++) { const int k = before[a]; if (ls[k] < 0 && !inPass[k]) return false; } return true; };
+        for (int i : ready) { if ((int) chosen.size() < width && free_(i)) { chosen.push_back(i); inPass[i] = 1; } else deferred.push_back(i); }
+        for (bool again = true; again && (int) chosen.size() < width;) {          // readers chosen later in the priority order free the points they held back
+            again = false;
+            for (size_t d = 0; d < deferred.size(); d++) {
+                const int i = deferred[d];
+                if (i >= 0 && (int) chosen.size() < width && free_(i)) { chosen.push_back(i); inPass[i] = 1; deferred[d] = -1; again = true; }
+            }
+        }
+        if (chosen.empty()) { stuck = true; break; }
+        ready.clear();
+        for (int i : deferred) if (i >= 0) ready.push_back(i);
+        for (int i : chosen) { ls[i] = t; inPass[i] = 0; left--; }
+        for (int i : chosen) for (int a = offA[i]; a < offA[i + 1]; a++) if (--waits[after[a]] == 0) ready.push_back(after[a]);
+        t++;
+    }
+    const bool useList = !stuck && t < nFF && ini_schedule_valid(n, nb, width, ls, t);
+    for (int i = 0; i < n; i++) passOut[i] = useList ? ls[i] : ff[i];
+    return useList ? t : nFF;
+}
+
 template <class T> static int ini_upload(ldso_initializer *H, T **dst, const std::vector<T> &src) {
     IA(H->levelAllocs, *dst, src.size());
     if (!src.empty()) CHK(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
@@ -1037,21 +1155,11 @@ int ldso_init_set_first(ldso_initializer_t *H, const float calib[4], const float
         }
         { int r_ = ini_upload(H, &L.parent, parent); if (r_ != LDSO_OK) return r_; }
         { int r_ = ini_upload(H, &L.nb, nb); if (r_ != LDSO_OK) return r_; }
-        // optReg sweep schedule (all levels; two lanes per point: passes of <= 32): point i goes into the first pass with a free place that is behind the passes
-        // of all its neighbours j < i and not before the pass of any reader k < i of i - first fit in index order (both conditions only look at lower indices).
-        // 640 x 480: 341 / 719 / 654 / 196 passes for 8.4k / 18.4k / 17.2k / 3.8k points (dependency depth 341 / 586 / 412 / 196)
+        // optReg sweep schedule (all levels; two lanes per point: passes of <= 32 points): ini_sweep_schedule
         {
-            std::vector<int> pass(n, 0), rd(n, 0), fillOf;
-            for (int i = 0; i < n; i++) {
-                int e = rd[i];
-                for (int q = 0; q < 10; q++) { const int j = nb[(size_t) i * INI_NB + q]; if (j >= 0 && j < i) e = std::max(e, pass[j] + 1); }
-                while (e < (int) fillOf.size() && fillOf[e] >= 32) e++;
-                if (e >= (int) fillOf.size()) fillOf.resize(e + 1, 0);
-                pass[i] = e;
-                for (int q = 0; q < 10; q++) { const int j = nb[(size_t) i * INI_NB + q]; if (j > i) rd[j] = std::max(rd[j], e); }
-                fillOf[e]++;
-            }
-            L.nPass2 = (int) fillOf.size();
+            std::vector<int> pass(n, 0), nb10((size_t) n * 10);
+            for (int i = 0; i < n; i++) for (int q = 0; q < 10; q++) nb10[(size_t) i * 10 + q] = nb[(size_t) i * INI_NB + q];
+            L.nPass2 = ini_sweep_schedule(n, nb10.data(), 32, pass.data());
             std::vector<int> slotOf(n), at(L.nPass2, 0), idleSlot;
             for (int i = 0; i < n; i++) slotOf[i] = pass[i] * 32 + at[pass[i]]++;
             for (int p = 0; p < L.nPass2 + INI_SWPAD; p++) for (int q = (p < L.nPass2 ? at[p] : 0); q < 32; q++) idleSlot.push_back(p * 32 + q);
@@ -1140,7 +1248,7 @@ int ldso_init_get_state(ldso_initializer_t *H, ldso_init_state_t *s) {
     CHK(hipMemcpyAsync(&c, H->P.ctl, sizeof(c), hipMemcpyDeviceToHost, H->stream));
     CHK(hipStreamSynchronize(H->stream));
     memcpy(s->thisToNext, c.Tcur, sizeof(c.Tcur));
-    H->snappedAtFrameStart = c.snapped != 0;
+    H->snappedAtFrameStart = c.snapped != 0; H->frameDone = c.done != 0; H->stepsTaken = c.steps;
     s->aff_a = c.aCur; s->aff_b = c.bCur; s->snapped = c.snapped; s->snappedAt = c.snappedAt; s->frameID = c.frameID;
     s->ready = c.snapped && c.frameID > c.snappedAt + 5; s->evals = c.evals; s->pad_ = 0;
     return LDSO_OK;
@@ -1168,23 +1276,45 @@ int ldso_init_track_frame(ldso_initializer_t *H, const float *irradiance, float 
     if (irradiance) { int r_ = ldso_init_set_new_frame(H, irradiance, ab_exposure); if (r_ != LDSO_OK) return r_; }
     REQ(H->haveNew, "ldso_init_track_frame: no new frame");
     const int maxIterations[5] = {5, 5, 10, 30, 50};
-    int pairs = 0;
-    for (int l = 0; l < H->levels; l++) pairs += maxIterations[l] + 2;
+    int steps = 0;                                                          // the most control steps a frame can take
+    for (int l = 0; l < H->levels; l++) steps += maxIterations[l] + 2;
+    steps += 2 * (H->levels - 1);                                           // the transition steps of a snapped frame (down and up)
+    // Control steps behind the one that finishes the frame return at once, but each still costs a dispatch (2-3 us, three kernels per step): a frame takes 19-40 of
+    // the 58 possible steps at four levels.  So: enqueue what the previous frame took plus a margin, read the state back (the call does that anyway), and enqueue
+    // the rest only if the frame is not finished - one more round trip in the rare case, 10-30 empty steps fewer in the usual one.
+    int first = std::min(steps, H->lastSteps > 0 ? H->lastSteps + H->lastSteps / 4 + 4 : steps);
     hipLaunchKernelGGL(k_ini_ctl, dim3(1), dim3(INI_CT), H->ldsBytes, H->stream, H->P, INI_BEGIN);
-    for (int p = 0; p < pairs; p++) {
-        hipLaunchKernelGGL(k_ini_eval, dim3(INI_MAXBLK), dim3(INI_NT), 0, H->stream, H->P, 0);
-        if (H->snappedAtFrameStart) hipLaunchKernelGGL(k_ini_prep, dim3(H->prepBlocks), dim3(INI_PT), 0, H->stream, H->P);
-        hipLaunchKernelGGL(k_ini_ctl, dim3(1), dim3(INI_CT), H->ldsBytes, H->stream, H->P, INI_STEP);
-    }
-    CHK(hipGetLastError());
     ldso_init_state_t st;
-    int r_ = ldso_init_get_state(H, &st);
-    if (r_ != LDSO_OK) return r_;
+    for (int from = 0; from < steps;) {
+        for (int p = from; p < first; p++) {
+            hipLaunchKernelGGL(k_ini_eval, dim3(INI_MAXBLK), dim3(INI_NT), 0, H->stream, H->P, 0);
+            if (H->snappedAtFrameStart) hipLaunchKernelGGL(k_ini_prep, dim3(H->prepBlocks), dim3(INI_PT), 0, H->stream, H->P);
+            hipLaunchKernelGGL(k_ini_ctl, dim3(1), dim3(INI_CT), H->ldsBytes, H->stream, H->P, INI_STEP);
+        }
+        CHK(hipGetLastError());
+        int r_ = ldso_init_get_state(H, &st);
+        if (r_ != LDSO_OK) return r_;
+        if (H->frameDone) break;
+        from = first; first = steps;
+    }
+    REQ(H->frameDone, "ldso_init_track_frame: the frame did not finish within the maximal number of control steps (internal)");
+    H->lastSteps = H->stepsTaken;
     bool fin = true;
     for (int q = 0; q < 12; q++) fin = fin && std::isfinite(st.thisToNext[q]);
     if (state_out) *state_out = st;
     if (!fin) { ldso_set_error("ldso_init_track_frame: non-finite pose"); return LDSO_E_NONFINITE; }
     return LDSO_OK;
+}
+
+// host logic only (no device): the optReg sweep schedule ldso_init_set_first builds for a level
+int ldso_init_sweep_schedule(int n, const int *neighbours, int width, int *pass_out) {
+    REQ(n >= 0 && (n == 0 || (neighbours && pass_out)) && width >= 1, "ldso_init_sweep_schedule: bad argument");
+    for (size_t q = 0; q < (size_t) n * 10; q++) REQ(neighbours[q] >= -1 && neighbours[q] < n, "ldso_init_sweep_schedule: neighbour index out of range");
+    std::vector<int> pass(n);
+    const int np = ini_sweep_schedule(n, neighbours, width, pass.data());
+    REQ(ini_schedule_valid(n, neighbours, width, pass, np), "ldso_init_sweep_schedule: internal error (schedule violates the update order)");
+    for (int i = 0; i < n; i++) pass_out[i] = pass[i];
+    return np;
 }
 
 // debug (LDSO_STAMPS builds): accumulated device-side ticks (100 MHz): sweep ticks, sweep passes, control-kernel ticks, sweeps, fill + prepare ticks,

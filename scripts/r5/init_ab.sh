@@ -1,8 +1,8 @@
 #!/bin/bash
-mkdir -p gpurun_out/ini4
-O=gpurun_out/ini4
+mkdir -p gpurun_out/${OUT:-init_ab}
+O=gpurun_out/${OUT:-init_ab}
 timeout 600 python -m pytest tests/test_init_gpu.py -m gpu -q -x -p no:cacheprovider > $O/pytest_init.log 2>&1; echo "pytest_init rc=$?" > $O/rc.txt
-for v in inid4t0_st inid4t1_st inid8t0_st inid8t1_st new; do
+for v in ${VARIANTS:-new}; do
   if [ $v = new ]; then unset LDSO_HIP_LIB; else export LDSO_HIP_LIB=$PWD/ldso_amd/libldso_hip_$v.so; fi
   timeout 300 python scripts/bench_init.py 640 480 6 > $O/bench_init_$v.log 2>&1; echo "$v rc=$?" >> $O/rc.txt
 done
