@@ -402,6 +402,12 @@ int ldso_init_set_points(ldso_initializer_t *t, int lvl, const ldso_init_point_t
 int ldso_init_calc_res_and_gs(ldso_initializer_t *t, int lvl, const double refToNew[12], double aff_a, double aff_b,
                               float *H, float *b, float *Hsc, float *bsc, float *res, float *ec);
 int ldso_init_set_new_frame(ldso_initializer_t *t, const float *irradiance, float ab_exposure);
+/* Launch schedule of ldso_init_track_frame (tuning / debugging; the results do not depend on it, bit for bit: tests/test_init_gpu.py).
+ * first_steps: control steps (evaluation + control launch) enqueued before the state is read back for the first time; the rest of the
+ *   frame's maximum is enqueued only if the frame has not finished by then.  0 (default) = what the previous frame took + 25 % + 4.
+ * prepare_on_grid: 1 (default) = the inputs of the optReg sweeps are prepared by a grid kernel between evaluation and control step
+ *   once the initialiser has snapped; 0 = by the control block itself (one compute unit), as in the frame that snaps. */
+int ldso_init_set_schedule(ldso_initializer_t *t, int first_steps, int prepare_on_grid);
 /* Host logic, no device: the schedule of the in-place optReg sweep (CoarseInitializer.cc:430-459: points are updated in index order, reading neighbours that
  * may already have been updated) as ldso_init_set_first builds it for one level.  neighbours [n][10] (-1 = none), width = points per pass (32 on the device).
  * pass_out[i] = pass of point i: every neighbour j < i in an earlier pass, every neighbour j > i in the same or a later one, <= width points per pass.

@@ -685,6 +685,10 @@ class Initializer:
         _chk(self.L.ldso_init_set_first(self.h, _p(k), _p(img), C.c_float(exposure), pp, _p(n), C.c_float(huberTH), C.c_int(1 if fixAffine else 0)))
         self.n = [int(x) for x in n]
 
+    def set_schedule(self, first_steps=0, prepare_on_grid=True):
+        """Launch schedule of track_frame (ldso_init_set_schedule): the results do not depend on it."""
+        _chk(self.L.ldso_init_set_schedule(self.h, C.c_int(first_steps), C.c_int(1 if prepare_on_grid else 0)))
+
     def set_new_frame(self, irradiance, exposure=1.0):
         img = np.ascontiguousarray(irradiance, np.float32)
         assert img.shape == (self.hh, self.w)

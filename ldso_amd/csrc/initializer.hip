@@ -930,6 +930,8 @@ struct ldso_initializer {
     size_t ldsBytes = 0;
     int prepBlocks = 1;                 // k_ini_prep: one thread per point of the largest level
     int lastSteps = 0, stepsTaken = 0;  // control steps of the previous frame / of the frame just read back (get_state)
+    int firstSteps = 0;                 // ldso_init_set_schedule: control steps of the first batch (0 = by the previous frame)
+    bool prepareOnGrid = true;          // ldso_init_set_schedule: k_ini_prep launches (false: the control block prepares every sweep)
     bool frameDone = false;
     bool snappedAtFrameStart = false;   // host copy of the state's snapped (get_state / set_state / set_first): before the snap optReg does not sweep and the
                                         // k_ini_prep launches would be empty (the frame that snaps prepares its sweeps in the control block)
@@ -1282,13 +1284,14 @@ int ldso_init_track_frame(ldso_initializer_t *H, const float *irradiance, float 
     // Control steps behind the one that finishes the frame return at once, but each still costs a dispatch (2-3 us, three kernels per step): a frame takes 19-40 of
     // the 58 possible steps at four levels.  So: enqueue what the previous frame took plus a margin, read the state back (the call does that anyway), and enqueue
     // the rest only if the frame is not finished - one more round trip in the rare case, 10-30 empty steps fewer in the usual one.
-    int first = std::min(steps, H->lastSteps > 0 ? H->lastSteps + H->lastSteps / 4 + 4 : steps);
+    int first = std::min(steps, H->firstSteps > 0 ? H->firstSteps : H->lastSteps > 0 ? H->lastSteps + H->lastSteps / 4 + 4 : steps);
+    const bool prep = H->snappedAtFrameStart && H->prepareOnGrid;
     hipLaunchKernelGGL(k_ini_ctl, dim3(1), dim3(INI_CT), H->ldsBytes, H->stream, H->P, INI_BEGIN);
     ldso_init_state_t st;
     for (int from = 0; from < steps;) {
         for (int p = from; p < first; p++) {
             hipLaunchKernelGGL(k_ini_eval, dim3(INI_MAXBLK), dim3(INI_NT), 0, H->stream, H->P, 0);
-            if (H->snappedAtFrameStart) hipLaunchKernelGGL(k_ini_prep, dim3(H->prepBlocks), dim3(INI_PT), 0, H->stream, H->P);
+            if (prep) hipLaunchKernelGGL(k_ini_prep, dim3(H->prepBlocks), dim3(INI_PT), 0, H->stream, H->P);
             hipLaunchKernelGGL(k_ini_ctl, dim3(1), dim3(INI_CT), H->ldsBytes, H->stream, H->P, INI_STEP);
         }
         CHK(hipGetLastError());
@@ -1303,6 +1306,12 @@ int ldso_init_track_frame(ldso_initializer_t *H, const float *irradiance, float 
     for (int q = 0; q < 12; q++) fin = fin && std::isfinite(st.thisToNext[q]);
     if (state_out) *state_out = st;
     if (!fin) { ldso_set_error("ldso_init_track_frame: non-finite pose"); return LDSO_E_NONFINITE; }
+    return LDSO_OK;
+}
+
+int ldso_init_set_schedule(ldso_initializer_t *H, int first_steps, int prepare_on_grid) {
+    REQ(H && first_steps >= 0, "ldso_init_set_schedule: bad argument");
+    H->firstSteps = first_steps; H->prepareOnGrid = prepare_on_grid != 0;
     return LDSO_OK;
 }
 

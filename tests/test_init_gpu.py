@@ -95,6 +95,32 @@ def test_track_frame_sequence():
     assert corr > 0.85, corr
 
 
+def test_launch_schedule_does_not_change_results():
+    """ldso_init_set_schedule: the number of control steps enqueued before the first read-back (1: every frame needs the second batch; 1000: everything at once) and
+    who prepares the inputs of the optReg sweeps (the grid kernel k_ini_prep, or the control block as in the frame that snaps) - same states, same points, bit for bit."""
+    from ldso_amd import binding
+    n = 6
+    seq, L, pts, o, g = _setup(n)
+    variants = []
+    for first, grid in ((1, True), (1000, True), (0, False)):
+        h = binding.Initializer(g.w, g.hh, L)
+        h.set_first(seq["K4"], seq["first"], pts)
+        h.set_schedule(first, grid)
+        variants.append(h)
+    for k in range(n):
+        img = seq["frames"][k]
+        ref = g.track_frame(img, 1.0)
+        for h in variants:
+            st = h.track_frame(img, 1.0)
+            assert st.tobytes() == ref.tobytes(), k
+            for lvl in range(L):
+                a, b = g.points(lvl), h.points(lvl)
+                assert a.tobytes() == b.tobytes(), (k, lvl)
+    assert ref["snapped"] == 1
+    for h in variants:
+        h.close()
+
+
 def test_sequential_sweeps_exact():
     """optReg / propagateUp / resetPoints keep the reference's in-place index order: after one snapped trackFrame started from
     the same state the regularised depths of the two paths differ only through the (tolerance-level) LM inputs; with identical
