@@ -428,12 +428,14 @@ float GpuBackend::optimize(FullSystem &fs, int mnumOptIts) {
     lap(1, tLap);
 
     // ---- write back ----------------------------------------------------------------------------------------------------------------
-    std::vector<ldso_res_out_t> ro((size_t) R); std::vector<int32_t> st((size_t) R), act((size_t) R), rem((size_t) R);
-    std::vector<ldso_point_out_t> po((size_t) P); std::vector<ldso_frame_t> fo((size_t) F); std::vector<double> fstep((size_t) F * 10);
+    // the landing buffers are members: 1 MB of fresh vectors per call is 1 MB of page faults and zero fill per call; everything in them is overwritten by the fetch
+    if (wbRes_.size() < (size_t) R) { wbRes_.resize((size_t) R); wbState_.resize((size_t) R); wbActive_.resize((size_t) R); wbRemove_.resize((size_t) R); }
+    if (wbPoints_.size() < (size_t) P) wbPoints_.resize((size_t) P);
+    if (wbFrames_.size() < (size_t) F) { wbFrames_.resize((size_t) F); wbStep_.resize((size_t) F * 10); }
+    std::vector<ldso_res_out_t> &ro = wbRes_; std::vector<int32_t> &st = wbState_, &act = wbActive_, &rem = wbRemove_;
+    std::vector<ldso_point_out_t> &po = wbPoints_; std::vector<ldso_frame_t> &fo = wbFrames_; std::vector<double> &fstep = wbStep_;
     double cv[4], cs[4];
-    throwOn(ldso_ba_get_residuals(ba_, ro.data(), st.data(), act.data(), rem.data()), "ldso_ba_get_residuals");
-    throwOn(ldso_ba_get_points(ba_, po.data()), "ldso_ba_get_points");
-    throwOn(ldso_ba_get_frames(ba_, fo.data(), fstep.data(), cv, cs, nullptr), "ldso_ba_get_frames");
+    throwOn(ldso_ba_get_results(ba_, ro.data(), st.data(), act.data(), rem.data(), po.data(), fo.data(), fstep.data(), cv, cs), "ldso_ba_get_results");      // one synchronisation
     std::vector<ldso_rawjac_t> Jv;
     if (writeBackJacobians) {
         std::vector<int32_t> ids((size_t) R);

@@ -135,6 +135,9 @@ private:
     static constexpr int kMaxCols = 16;
     struct Row { PointHessian *ph; Feature *feat; uint32_t mask; int host; PointFrameResidual *res[kMaxCols]; };
     std::vector<Row> rows_;
+    // optimize()'s write-back: where ldso_ba_get_results lands (kept across calls)
+    std::vector<ldso_res_out_t> wbRes_; std::vector<int32_t> wbState_, wbActive_, wbRemove_;
+    std::vector<ldso_point_out_t> wbPoints_; std::vector<ldso_frame_t> wbFrames_; std::vector<double> wbStep_;
     std::vector<shared_ptr<Frame>> rowFrames_;                       // the frame of every column of the resident window (held: the rows point into their features)
     std::vector<PointFrameResidual *> flat_;                         // the residual objects in the device's flat order (point-major, target-ascending)
     bool residentValid_ = false;

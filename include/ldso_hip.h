@@ -270,6 +270,10 @@ int ldso_ba_get_residuals(ldso_ba_t *h, ldso_res_out_t *out, int32_t *state_stat
 int ldso_ba_get_points(ldso_ba_t *h, ldso_point_out_t *out);
 int ldso_ba_get_frames(ldso_ba_t *h, ldso_frame_t *frames, double *step /*F*10*/, double *calib_value, double *calib_step,
                        double *pre_worldToCam /*F*12*/);
+/* ldso_ba_get_residuals + ldso_ba_get_points + ldso_ba_get_frames behind ONE stream synchronisation (what FullSystem::optimize's tail reads back in one go:
+ * FullSystem.cc:815-864).  res / state_state / is_active / to_remove / frames / step / calib_* may be NULL, points must not; the outputs equal the three getters'. */
+int ldso_ba_get_results(ldso_ba_t *h, ldso_res_out_t *res, int32_t *state_state, int32_t *is_active, int32_t *to_remove, ldso_point_out_t *points,
+                        ldso_frame_t *frames, double *step /*F*10*/, double *calib_value, double *calib_step);
 /* Stitched systems of the last solve, (8F+4)^2 / (8F+4) doubles, reference ordering [calib | frames]. */
 int ldso_ba_get_system(ldso_ba_t *h, double *HA, double *bA, double *HL, double *bL, double *Hsc, double *bsc,
                        double *HFinal, double *bFinal, double *x);
@@ -404,7 +408,7 @@ int ldso_init_calc_res_and_gs(ldso_initializer_t *t, int lvl, const double refTo
 int ldso_init_set_new_frame(ldso_initializer_t *t, const float *irradiance, float ab_exposure);
 /* Launch schedule of ldso_init_track_frame (tuning / debugging; the results do not depend on it, bit for bit: tests/test_init_gpu.py).
  * first_steps: control steps (evaluation + control launch) enqueued before the state is read back for the first time; the rest of the
- *   frame's maximum is enqueued only if the frame has not finished by then.  0 (default) = what the previous frame took + 25 % + 4.
+ *   frame's maximum is enqueued only if the frame has not finished by then.  0 (default) = what the previous frame took + 25 % + 4 (first frame: half of the maximum).
  * prepare_on_grid: 1 (default) = the inputs of the optReg sweeps are prepared by a grid kernel between evaluation and control step
  *   once the initialiser has snapped; 0 = by the control block itself (one compute unit), as in the frame that snaps. */
 int ldso_init_set_schedule(ldso_initializer_t *t, int first_steps, int prepare_on_grid);

@@ -385,6 +385,14 @@ class BA:
         _chk(self.L.ldso_ba_get_frames(self.h, _p(fr), _p(step), _p(cv), _p(cs), _p(pre)))
         return dict(frames=fr, step=step, calib_value=cv, calib_step=cs, pre_worldToCam=pre)
 
+    def get_results(self):
+        """ldso_ba_get_results: residuals + points + frames behind one synchronisation; the same records as the three getters."""
+        out = np.zeros(self.R, synth.RES_OUT_DTYPE); st = np.zeros(self.R, np.int32); act = np.zeros(self.R, np.int32); rem = np.zeros(self.R, np.int32)
+        pts = np.zeros(self.P, synth.POINT_OUT_DTYPE)
+        fr = np.zeros(self.F, synth.FRAME_DTYPE); step = np.zeros((self.F, 10)); cv, cs = np.zeros(4), np.zeros(4)
+        _chk(self.L.ldso_ba_get_results(self.h, _p(out), _p(st), _p(act), _p(rem), _p(pts), _p(fr), _p(step), _p(cv), _p(cs)))
+        return dict(residuals=dict(out=out, state_state=st, is_active=act, to_remove=rem), points=pts, frames=dict(frames=fr, step=step, calib_value=cv, calib_step=cs))
+
     def get_system(self):
         n = 8 * self.F + 4
         d = {k: np.zeros((n, n)) for k in ("HA", "HL", "Hsc", "HFinal")}

@@ -1283,8 +1283,8 @@ int ldso_init_track_frame(ldso_initializer_t *H, const float *irradiance, float 
     steps += 2 * (H->levels - 1);                                           // the transition steps of a snapped frame (down and up)
     // Control steps behind the one that finishes the frame return at once, but each still costs a dispatch (2-3 us, three kernels per step): a frame takes 19-40 of
     // the 58 possible steps at four levels.  So: enqueue what the previous frame took plus a margin, read the state back (the call does that anyway), and enqueue
-    // the rest only if the frame is not finished - one more round trip in the rare case, 10-30 empty steps fewer in the usual one.
-    int first = std::min(steps, H->firstSteps > 0 ? H->firstSteps : H->lastSteps > 0 ? H->lastSteps + H->lastSteps / 4 + 4 : steps);
+    // the rest only if the frame is not finished - one more round trip in the rare case, 10-30 empty steps fewer in the usual one.  (First frame: half of the maximum.)
+    int first = std::min(steps, H->firstSteps > 0 ? H->firstSteps : H->lastSteps > 0 ? H->lastSteps + H->lastSteps / 4 + 4 : (steps + 1) / 2);
     const bool prep = H->snappedAtFrameStart && H->prepareOnGrid;
     hipLaunchKernelGGL(k_ini_ctl, dim3(1), dim3(INI_CT), H->ldsBytes, H->stream, H->P, INI_BEGIN);
     ldso_init_state_t st;

@@ -128,6 +128,26 @@ def test_optimize_small(small):
     assert rel(fg["frames"]["nullspaces_pose"][-1], fo["frames"]["nullspaces_pose"][-1]) < 1e-3
 
 
+def test_get_results_equals_the_three_getters(small):
+    """ldso_ba_get_results (one synchronisation, the drop-in's write-back) against ldso_ba_get_residuals / _points / _frames: the same bytes - after an optimize()
+    and with a linearisation pending (the "new" values then come from the other residual set)."""
+    g = binding.BA.from_window(small)
+
+    def same():
+        r, p, f = g.get_residuals(), g.get_points(), g.get_frames()
+        a = g.get_results()
+        for k in ("out", "state_state", "is_active", "to_remove"):
+            assert a["residuals"][k].tobytes() == r[k].tobytes(), k
+        assert a["points"].tobytes() == p.tobytes()
+        for k in ("frames", "step", "calib_value", "calib_step"):
+            assert a["frames"][k].tobytes() == f[k].tobytes(), k
+
+    g.optimize(3, force_all=True)
+    same()
+    g.linearize_all(False)                                  # pending: not applied
+    same()
+
+
 def test_optimize_canbreak_path(small):
     """un-forced optimize: the host reads `canbreak` every iteration like the reference loop (FullSystem.cc:829)."""
     o = po.OracleWindow(small)
