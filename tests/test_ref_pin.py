@@ -394,6 +394,22 @@ def _traced_points(win, per_frame):
     return pts[keep].copy(), true_id[keep]
 
 
+def test_immature_points_of_the_harness_are_released_cleanly():
+    """ref_fs_build_immature / ref_fs_free_immature (oracle/ref_driver.cc: the ImmaturePoint objects the adapter's activation test hands to GpuBackend::activatePoints) with points
+    that were never activated - the case in which the harness once let Feature::ReleaseImmature (Feature.cc:26-31) destroy the feature it was running in.  Nothing to compare:
+    the test is for scripts/asan_check.sh (AddressSanitizer build of this library); without it, it must simply not crash, many times over."""
+    import ctypes as C
+    win = synth.make_config("small", extra_frames=2)
+    pts, _ = _traced_points(win, 40)
+    r = pr.RefWindow(win); r.fs_attach()
+    r.L.ref_fs_build_immature.restype = C.c_void_p
+    rec = np.ascontiguousarray(pts)
+    for _ in range(20):
+        vec = C.c_void_p(r.L.ref_fs_build_immature(r.h, C.c_int(len(rec)), rec.ctypes.data_as(C.c_void_p), C.c_int(1), C.c_float(100.0), C.c_int(3)))
+        assert vec.value
+        r.L.ref_fs_free_immature(vec)
+
+
 @pytest.mark.parametrize("name,per_frame", [("small", 120), ("C3", 60)])
 def test_fullsystem_optimize_immature_point_pinned(name, per_frame):
     """shared_ptr<PointHessian> FullSystem::optimizeImmaturePoint (FullSystem.cc:892-1010, the member; ImmaturePoint::linearizeResidual from
