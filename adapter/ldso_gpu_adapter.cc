@@ -256,7 +256,8 @@ void GpuBackend::uploadFresh(FullSystem &fs, const std::vector<int32_t> &slots, 
     lastUploadSeconds[2] += lapSince();
     throwOn(ldso_ba_set_point_stats(ba_, mrb.data(), ngr.data()), "ldso_ba_set_point_stats");
     lastUploadSeconds[3] += lapSince();
-    residentValid_ = !anyLin;                                        // ldso_ba_update_window does not carry linearised residuals
+    residentValid_ = !anyLin;                                        // ldso_ba_update_window does not carry linearised residuals: the next call uploads in full again
+    if (anyLin) uploadsFreshBecauseLinearized++;                     // (counted: in LDSO's own flow isLinearized is never set - FullSystem.cc:1241-1250 fixes and marginalises in one go)
 }
 
 // The window as a delta against the one the last optimize() left on the device (ldso_ba_update_window).  Surviving points are recognised by walking the new
@@ -319,6 +320,21 @@ bool GpuBackend::uploadDelta(FullSystem &fs, const std::vector<int32_t> &slots, 
                     const int t = columnOf(r);
                     ok = !r.isLinearized && t >= 0 && t < F && t != f && frameFrom[t] < 0 && !((n.mask >> t) & 1u);
                     if (ok) { n.mask |= 1u << t; n.res[t] = &r; }
+                }
+                // every residual of the point's CURRENT list must be one of the pointers cached above, and every cached pointer must still be in the list: a host
+                // that dropped a residual and created another one for the same target between two optimize() calls (equal counts, nothing inserted) would
+                // otherwise leave a dangling PointFrameResidual* in flat_ (round-5 advisor).  targetIDX is the hint (makeIDX keeps it current in LDSO's own
+                // flow: one compare per residual), the scan over the row is the fallback.
+                if (ok) {
+                    uint32_t seen = 0;
+                    for (int k = 0; ok && k < have; k++) {
+                        const PointFrameResidual *r = ph->residuals[k].get();
+                        int c = r->targetIDX;
+                        if (!(c >= 0 && c < F && n.res[c] == r)) { c = -1; for (int t = 0; t < F; t++) if (n.res[t] == r) { c = t; break; } }
+                        if (c < 0 || ((seen >> c) & 1u)) ok = false; else seen |= 1u << c;
+                    }
+                    ok = ok && seen == n.mask;
+                    if (!ok) residentPointerMismatches++;
                 }
                 if (!ok && !reread()) return false;
                 pointFrom.push_back((int32_t) j);
@@ -598,7 +614,8 @@ void GpuBackend::marginalizeFrame(FullSystem &fs, shared_ptr<Frame> &frame) {
     int col = -1;
     for (int f = 0; f < F; f++) if (fs.frames[f].get() == frame.get()) col = f;
     const bool resident = residentValid_ && (int) rowFrames_.size() == F && col >= 0 && rowFrames_[col].get() == frame.get();
-    if (!resident || (int) ef.HM.rows() != n) { fs.marginalizeFrame(frame); return; }          // no window of these frames on the device: the reference's member
+    if (!resident || (int) ef.HM.rows() != n) { margFrameHostFallback++; fs.marginalizeFrame(frame); return; }          // no window of these frames on the device: the reference's member (counted)
+    margFrameDevice++;
     // ---- EnergyFunctional::marginalizeFrame: the arithmetic (:80-136) on the device, on ef's own prior ----
     {
         std::vector<double> HM((size_t) n * n), bM((size_t) n), oH((size_t) nd * nd), ob((size_t) nd);

@@ -58,6 +58,11 @@ public:
     void invalidateWindow() { residentValid_ = false; }
     bool lastUploadWasDelta = false;
     int uploadsDelta = 0, uploadsFresh = 0;          // how the windows of this backend's lifetime went over
+    int uploadsFreshBecauseLinearized = 0;           // ... of the full uploads: windows that held linearised residuals (ldso_ba_update_window does not carry them)
+    int residentPointerMismatches = 0;               // resident points whose cached residual pointers no longer matched PointHessian::residuals (their list was re-read)
+    // marginalizeFrame(): how often the device path ran, and how often the call fell back to the reference's HOST member (FullSystem::marginalizeFrame ->
+    // EnergyFunctional.cc:72-151) because no window of these frames was resident - a maintainer sees here when the drop-in did not take the device path
+    int margFrameDevice = 0, margFrameHostFallback = 0;
     // FullSystem::activeResiduals is only read inside FullSystem::optimize itself (FullSystem.cc:735-1770: linearizeAll / applyRes / setNewFrameEnergyTH - all of
     // which run on the device here); filling it costs 12 000 shared_ptr copies per call.  On for host code that wants the list anyway.
     bool fillActiveResiduals = false;
@@ -133,6 +138,7 @@ private:
     std::vector<int32_t> resBegin_;                                  // last upload: the residuals of point k are flat_[resBegin_[k] .. resBegin_[k + 1])
     // the resident window as the host sees it: one row per point in device order, its residual objects by window column (= target frame index)
     static constexpr int kMaxCols = 16;
+    static_assert(kMaxCols >= LDSO_MAX_FRAMES, "a row of the resident window holds one residual pointer per window column");
     struct Row { PointHessian *ph; Feature *feat; uint32_t mask; int host; PointFrameResidual *res[kMaxCols]; };
     std::vector<Row> rows_;
     // optimize()'s write-back: where ldso_ba_get_results lands (kept across calls)

@@ -120,10 +120,12 @@ struct ldso_ba {
     int tcnt[5] = {0, 0, 0, 0, 0};
     int lastIterations = 0;
     bool noFusedLaunch = false;        // debug: k_reduce and k_gn_solve as two launches even where the fused k_reduce_solve applies
-    // ldso_ba_enqueue_gn replays a cached HIP graph when the same launch sequence was enqueued before: the key is a hash over EVERYTHING the launches take as
-    // arguments (pointer tables, dimensions, both residual sets, settings, chunk geometry, flags, stream, first iteration, count, parity of the sets)
-    struct GnGraph { unsigned long long sig; hipGraphExec_t exec; hipGraph_t graph; };
+    // ldso_ba_enqueue_gn replays a cached HIP graph when the same launch sequence was enqueued before: the key is EVERYTHING the launches take as
+    // arguments (pointer tables, dimensions, both residual sets, settings, chunk geometry, flags, stream, first iteration, count, parity of the sets),
+    // byte for byte (round 6: the 64-bit hash of those bytes only pre-selects - a collision must not replay another window's launches)
+    struct GnGraph { unsigned long long sig; std::vector<unsigned char> key; hipGraphExec_t exec; hipGraph_t graph; };
     std::vector<GnGraph> gnGraphs;
+    std::vector<unsigned char> gnKeyScratch;      // the key of the current call (kept to avoid an allocation per enqueue)
     bool gnUseGraphs = true;
     double *distBuf = nullptr;         // ldso_ba_enqueue_gn_rccl / _p2p: all-reduce buffer [HFinal | bFinal | scalars | candidates]
     unsigned p2pSeq = 0;               // ldso_ba_enqueue_gn_p2p: exchanges done (the tag of the hand-over words)
@@ -775,7 +777,9 @@ int ldso_ba_update_window(ldso_ba_t *H, int F, const int32_t *image_slot, const 
                 const int cnt = __builtin_popcount(res_mask[i]);
                 freshResBegin[nextFresh] = fr;
                 for (int c = 0; c < cnt; c++) {
-                    REQ(fr < n_fresh_res && fresh_res[fr].point == nextFresh && !fresh_res[fr].is_linearized && ((res_mask[i] >> fresh_res[fr].target) & 1u)
+                    REQ(fr < n_fresh_res && fresh_res[fr].target >= 0 && fresh_res[fr].target < F && fresh_res[fr].host == host,
+                        "ldso_ba_update_window: fresh residual names a target outside the window or another host than its point's");
+                    REQ(fresh_res[fr].point == nextFresh && !fresh_res[fr].is_linearized && ((res_mask[i] >> fresh_res[fr].target) & 1u)
                         && (c == 0 || fresh_res[fr - 1].target < fresh_res[fr].target), "ldso_ba_update_window: fresh residuals must be point-major, target-ascending and match res_mask");
                     fr++;
                 }
@@ -1123,7 +1127,7 @@ static int refresh_item(ldso_ba *H) {
 static int launch_linearize(ldso_ba *H, bool fix, int stepMode, int itCheck) {
     t_begin(H, 0);
     GnInit gi; gi.enable = (H->D.pBegin > 0) ? 2 : 1; gi.hasPrior = H->hasPrior ? 1 : 0; gi.calibPrior = H->settings.initialCalibHessian; gi.itCheck = itCheck;
-    if (!fix && !H->hasL && gi.enable == 1 && H->linHeadOk) {
+    if (!fix && !H->hasL && gi.enable == 1 && H->linHeadOk && H->B.dumpJ == nullptr) {          // (the Jacobian dump of ldso_ba_set_debug_dump: the argument-based kernel)
         // the plain linearisation (GN iterations) of one window, one or two slot groups: descriptor and chunk geometry in the kernel arguments (k_linearize_one;
         // until round 3 k_linearize_batch with one window for F <= 8 and the argument-based kernel for F > 8)
         CHK(ba_launch_linearize_one(H->B, H->D, H->sets[H->cur], H->sets[H->cur ^ 1], H->settings, stepMode, gi, H->linHead, H->stream));
@@ -1327,15 +1331,18 @@ static unsigned long long fnv1a(unsigned long long h, const void *p, size_t n) {
     for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; }
     return h;
 }
-// everything the launches of `iters` forced iterations take as arguments
-static unsigned long long gn_signature(const ldso_ba *H, int first_iteration, int iters) {
-    unsigned long long h = 1469598103934665603ull;
-    h = fnv1a(h, &H->B, sizeof(H->B)); h = fnv1a(h, &H->D, sizeof(H->D)); h = fnv1a(h, H->sets, sizeof(H->sets)); h = fnv1a(h, &H->settings, sizeof(H->settings));
-    h = fnv1a(h, &H->chunkStarts, sizeof(H->chunkStarts)); h = fnv1a(h, &H->linHead, sizeof(H->linHead));
+// everything the launches of `iters` forced iterations take as arguments, as bytes (the cache key) ...
+static void gn_key(const ldso_ba *H, int first_iteration, int iters, std::vector<unsigned char> &key) {
+    key.clear();
+    auto put = [&key](const void *p, size_t n) { const unsigned char *b = (const unsigned char *) p; key.insert(key.end(), b, b + n); };
+    put(&H->B, sizeof(H->B)); put(&H->D, sizeof(H->D)); put(H->sets, sizeof(H->sets)); put(&H->settings, sizeof(H->settings));
+    put(&H->chunkStarts, sizeof(H->chunkStarts)); put(&H->linHead, sizeof(H->linHead));
     const long long misc[12] = {first_iteration, iters, H->cur, H->hasL, H->hasPrior, H->GSP, H->linHeadOk, H->noFusedLaunch, H->numCU, (long long) (size_t) H->stream, (long long) (size_t) H->ownAcc,
                                 (long long) (size_t) H->d_waitCtr};
-    return fnv1a(h, misc, sizeof(misc));
+    put(misc, sizeof(misc));
 }
+// ... and their 64-bit hash (pre-selection only: a hit is confirmed on the bytes)
+static unsigned long long gn_signature(const std::vector<unsigned char> &key) { return fnv1a(1469598103934665603ull, key.data(), key.size()); }
 static int enqueue_gn_plain(ldso_ba *H, int first_iteration, int iters) {
     CHK(hipMemsetAsync(H->d_waitCtr, 0, 4 * sizeof(int), H->stream));      // an aborted launch must not leave the producer counter armed
     for (int i = 0; i < iters; i++) RUN(enqueue_iteration(H, first_iteration + i, 1e-1, -1, true));
@@ -1353,9 +1360,11 @@ int ldso_ba_enqueue_gn(ldso_ba_t *H, int first_iteration, int iters) {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (!H->gnUseGraphs || H->profile || iters < 2 || H->B.acc != H->ownAcc || hipStreamIsCapturing(H->stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone)
         return enqueue_gn_plain(H, first_iteration, iters);
-    const unsigned long long sig = gn_signature(H, first_iteration, iters);
+    std::vector<unsigned char> &key = H->gnKeyScratch;
+    gn_key(H, first_iteration, iters, key);
+    const unsigned long long sig = gn_signature(key);
     for (ldso_ba::GnGraph &g : H->gnGraphs)
-        if (g.sig == sig) {
+        if (g.sig == sig && g.key == key) {
             CHK(hipGraphLaunch(g.exec, H->stream));
             if (iters & 1) H->cur ^= 1;          // what the captured enqueue did to the handle's host state: the sets swap once per iteration
             H->appliedValid = true;
@@ -1376,7 +1385,7 @@ int ldso_ba_enqueue_gn(ldso_ba_t *H, int first_iteration, int iters) {
         return enqueue_gn_plain(H, first_iteration, iters);
     }
     if (H->gnGraphs.size() >= 4) { hipGraphExecDestroy(H->gnGraphs.front().exec); hipGraphDestroy(H->gnGraphs.front().graph); H->gnGraphs.erase(H->gnGraphs.begin()); }
-    H->gnGraphs.push_back(ldso_ba::GnGraph{sig, exec, graph});
+    H->gnGraphs.push_back(ldso_ba::GnGraph{sig, key, exec, graph});
     CHK(hipGraphLaunch(exec, H->stream));
     return LDSO_OK;
 }

@@ -21,6 +21,9 @@
 #include <type_traits>
 #include "ba_dev.h"
 
+#ifndef LD_PIPE_ARGS
+#define LD_PIPE_ARGS 1          // the argument-based kernels (fix / linearised / marginalisation / dump passes) up to 8 key frames run the software pipeline too
+#endif
 #define RES_IN 0
 #define RES_OOB 1
 #define RES_OUTLIER 2
@@ -127,16 +130,37 @@ enum { RS_SLOT = 0, RS_PT = 1, RS_ACC = 2, RS_CAND = 3, RS_G = 4, RS_TOPA = 5, R
 // flat index of entry (r,c), r<=c, in the packed upper triangle of a 13x13 matrix
 __host__ __device__ constexpr int tri13(int r, int c) { return r * 13 - (r * (r - 1)) / 2 + (c - r); }
 
-// Everything a wave reads from HBM for one point besides the image taps.  The first point's record is loaded before the LDS staging of the block
-// (its latency overlaps the staging); later points load theirs at the top of their pass.
+// Everything a wave reads from HBM for one point besides the image taps.  Round 6: the records of a point are loaded TWO points ahead of the
+// arithmetic that consumes them and its image taps ONE point ahead (software pipeline of linearize_body), so nothing of a point may sit in scalar
+// registers while it waits (an outstanding s_load makes every LDS wait of the point in front of it a full lgkmcnt(0)): the 64-byte PtGeo and PtRec
+// of the point arrive as ONE VGPR each (lane L holds dword L & 15 - the 16 lanes of a row read one 64-byte line, the four rows the same line) and
+// are read out with v_readlane where they are used.
 template <int NSG>
 struct PtIn {
-    float pu, pv, idp, idz, priorF, color, wgt;
-    float pstep;                  // input of the fused point step (resubstituteFPt)
-    PtRec rec;                    // the point's Schur scalars of the applied set (one scalar load: scalar registers)
+    float rgeo, rrec;             // dword (lane & 15) of the point's PtGeo / of its PtRec in the applied set
+    float color, wgt;
     int rflat[NSG], rlin[NSG], rnew[NSG], rlidx[NSG];     // SlotTab of this lane's slot(s)
     float jp[NSG], m[NSG];        // this lane's pair of the slot record: JpJdF[k] and scalar k (LD_SM_*; integers as raw bits)
 };
+// dword i of a record held one-dword-per-lane (wave-uniform result: a scalar register)
+#define RLF(v, i) __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, (v)), (i)))
+#define RLI(v, i) __builtin_amdgcn_readlane(__builtin_bit_cast(int, (v)), (i))
+// PtGeo dwords (ba_dev.h)
+#define GEO_U 0
+#define GEO_V 1
+#define GEO_PRIOR 2
+#define GEO_IDP 4
+#define GEO_IDZ 5
+#define GEO_STEP 6
+// PtRec dwords (ba_dev.h)
+#define REC_HDI 0
+#define REC_BDSUM 1
+#define REC_IDH 2
+#define REC_NACT 3
+#define REC_HCDA 4
+#define REC_HCDL 8
+#define REC_MAXRELBS 12
+#define REC_NUMGOOD 13
 
 // element i of a device array with the BYTE offset computed in 32 bits: base pointer (SGPR pair) + zero-extended
 // lane offset is the addressing mode the hardware has (saddr + voffset); a 64-bit per-lane address costs two registers and a
@@ -146,23 +170,8 @@ struct PtIn {
 // vmcnt (every s_waitcnt lgkmcnt(0) of a scalar load then waits for all vector memory traffic in flight).  Every table of a window is
 // hipMalloc'ed device memory: the access is made through an address_space(1) (global) pointer -> global_load/store v, v_off, s[base].
 template <class T> using gptr_t = __attribute__((address_space(1))) T *;
-// ... where the base pointers were fetched just in time (DESC).  The argument-based kernels keep the generic access: measured at C5
-// (k_linearize<2,...>, A/B on one box) 44.8 us with flat accesses and ds_bpermute slot sums against 47.0 us with the global accesses and
-// permlane butterflies that the descriptor-based kernel uses - there the pointers sit in SGPRs from the start and the compiler's own
-// flat addressing / waitcnt placement is the better schedule.
-template <bool GLOBAL> struct at_sel;
-template <> struct at_sel<true> {
-    template <class T> static __device__ __forceinline__ __attribute__((address_space(1))) T &ref(T *p, unsigned i) { return *(gptr_t<T>) ((gptr_t<char>) p + (size_t) (i * (unsigned) sizeof(T))); }
-};
-template <> struct at_sel<false> {
-    template <class T> static __device__ __forceinline__ T &ref(T *p, unsigned i) { return *(T *) ((char *) p + (size_t) (i * (unsigned) sizeof(T))); }
-};
-#define AT(ptr, i) (at_sel<DESC>::ref((ptr), (unsigned) (i)))
-// Per-POINT data have a wave-uniform address - a wavefront works on one point at a time.  Read through a constant-address-space pointer with
-// the index in an SGPR they become scalar loads (s_load_dwordxN, scalar cache): no vector memory instruction, no VGPR address, nothing on
-// vmcnt.  Legal because no wavefront reads an entry again after anybody has written it inside one launch (a point belongs to one wavefront;
-// what it stores depends on what it loaded), and the scalar cache is invalidated at the launch boundary.
-template <class T> using cptr_t = const __attribute__((address_space(4))) T *;
+template <class T> static __device__ __forceinline__ __attribute__((address_space(1))) T &at_g(T *p, unsigned i) { return *(gptr_t<T>) ((gptr_t<char>) p + (size_t) (i * (unsigned) sizeof(T))); }
+#define AT(ptr, i) (at_g((ptr), (unsigned) (i)))
 
 typedef int v4i32_t __attribute__((ext_vector_type(4)));
 typedef float v8f_t __attribute__((ext_vector_type(8)));
@@ -170,32 +179,24 @@ typedef int v2i32_t __attribute__((ext_vector_type(2)));
 typedef float v2f_t __attribute__((ext_vector_type(2)));
 typedef float v4f_t __attribute__((ext_vector_type(4)));
 
-// The record of one point as a wavefront needs it: the first half of its PtGeo and its PtRec (two scalar loads - the index is wave-uniform),
-// this lane's (colour, weight) pair (one dwordx2), and per slot group one dwordx4 (SlotTab, the same 16 bytes for the 8 lanes of a slot) and
-// one dwordx2 (this lane's pair of the 64-byte SlotRec): 1 + 2 NSG vector loads (round 3: 9 + 9 NSG + 13).
+// The record of one point as a wavefront needs it: one dword of its PtGeo and of its PtRec per lane, this lane's (colour, weight) pair (one
+// dwordx2), and per slot group one dwordx2 / dwordx4 (SlotTab, the same 16 bytes for the 8 lanes of a slot) and one dwordx2 (this lane's pair of
+// the 64-byte SlotRec): 3 + 2 NSG vector loads, no scalar load.
 template <int NSG, bool HAS_L, bool FIX, bool DESC>
-static __device__ __forceinline__ void load_point(PtIn<NSG> &q, const BaPtrs &B, const ResSet &cur, unsigned FS, unsigned p, unsigned s, unsigned k, int stepMode) {
+static __device__ __forceinline__ void load_point(PtIn<NSG> &q, const BaPtrs &B, const ResSet &cur, unsigned FS, unsigned p, unsigned s, unsigned k, unsigned lane) {
+    const unsigned pU = (unsigned) __builtin_amdgcn_readfirstlane((int) p);
     {
         const v16i_t b0 = ldg16<DESC, OFF_B0>(&B);
-        const PtGeo *geo = GP(const PtGeo, b0, BP_GEO);
+        const float *geo = GP(const float, b0, BP_GEO);
         const v2f_t *pcw = GP(const v2f_t, b0, BP_CW);
         const v4i32_t *rtab = GP(const v4i32_t, b0, BP_RTAB);
-        // dwords 0..7 of the point's PtGeo (u, v, prior | idepth, idepth_zero, step): wave-uniform address -> ONE scalar load
-        // (a float vector, indexed directly: __builtin_bit_cast(float, v[i]) of an integer ext-vector ELEMENT is miscompiled by this clang - every
-        // element became element 0, found on the first GPU run of the record layout)
-        const v8f_t g8 = *(cptr_t<v8f_t>) ((unsigned long long) geo + (unsigned long long) ((unsigned) __builtin_amdgcn_readfirstlane((int) p) * (unsigned) sizeof(PtGeo)));
-        q.pu = g8[0]; q.pv = g8[1]; q.priorF = g8[2];
-        q.idp = g8[4]; q.idz = g8[5]; q.pstep = g8[6];
-        // addresses = (uniform base advanced to the point, on the scalar side) + (a lane offset that never changes): no per-point VGPR address
-        // arithmetic, and no VGPR shared between one load's address and another load's destination (the allocator had put the slot-record
-        // address into a register of the SlotTab destination: a vmcnt(0) between the two loads, i.e. two serialised latencies)
-        const unsigned pU = (unsigned) __builtin_amdgcn_readfirstlane((int) p);
+        // addresses = (uniform base advanced to the point, on the scalar side) + (a lane offset that never changes)
+        q.rgeo = AT(geo + (size_t) pU * (sizeof(PtGeo) / 4), lane & 15u);
         const v2f_t cw = AT(pcw + (size_t) pU * 8, k);
         q.color = cw.x; q.wgt = cw.y;
 #pragma unroll
         for (int g = 0; g < NSG; g++) {
-            // slot tables are dense [P][FS]: every index is readable.  Only the half of the entry this variant uses is loaded: dead lanes of a
-            // wider destination get re-used by the allocator for the next load's address, which costs a vmcnt(0) between the two loads
+            // slot tables are dense [P][FS]: every index is readable.  Only the half of the entry this variant uses is loaded
             if constexpr (FIX || HAS_L) {
                 const v4i32_t t4 = AT(rtab + (size_t) pU * FS, g * 8 + s);
                 q.rflat[g] = t4.x; q.rlin[g] = t4.y; q.rnew[g] = FIX ? t4.z : 0; q.rlidx[g] = HAS_L ? t4.w : 0;
@@ -204,15 +205,12 @@ static __device__ __forceinline__ void load_point(PtIn<NSG> &q, const BaPtrs &B,
                 q.rflat[g] = t2.x; q.rlin[g] = t2.y; q.rnew[g] = 0; q.rlidx[g] = 0;
             }
         }
-        (void) stepMode;
     }
     {
         const v16i_t s0 = ldg16<DESC, OFF_S0>(&cur);
         const v2f_t *slots = GP(const v2f_t, s0, RS_SLOT);
-        const PtRec *pts = GP(const PtRec, s0, RS_PT);
-        // wave-uniform 64-byte record: through the constant address space with the index in a scalar register -> s_load_dwordx16 (see PT())
-        const unsigned pU = (unsigned) __builtin_amdgcn_readfirstlane((int) p);
-        q.rec = __builtin_bit_cast(PtRec, *(cptr_t<v16i_t>) ((unsigned long long) pts + (unsigned long long) (pU * (unsigned) sizeof(PtRec))));
+        const float *pts = GP(const float, s0, RS_PT);
+        q.rrec = AT(pts + (size_t) pU * (sizeof(PtRec) / 4), lane & 15u);
 #pragma unroll
         for (int g = 0; g < NSG; g++) {
             const v2f_t e = AT(slots + (size_t) pU * FS * 8, (g * 8 + s) * 8 + k);
@@ -220,6 +218,11 @@ static __device__ __forceinline__ void load_point(PtIn<NSG> &q, const BaPtrs &B,
         }
     }
 }
+
+// What the front half of a slot group (pattern projection -> tap loads) hands to its back half (everything behind the image taps), one group
+// later: the 12 tap dwords (in flight) and the projected pixel.  PtStep: the inverse depth of the point after the fused point step.
+struct TapsG { float t[12]; float Ku, Kv; };
+struct PtStep { float idp, idz; };
 
 // stepMode != 0 fuses the point part of resubstituteF_MT + backupState + doStepFromBackup (EnergyFunctional.cc:518-547,
 // FullSystem.cc:1585-1602, 1625-1673) in front of the linearisation of each point (what k_point_step does with
@@ -278,9 +281,12 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
     float xc0 = 0, xc1 = 0, xc2 = 0, xc3 = 0;
     if (stepMode & 1) { xc0 = B.xc[0]; xc1 = B.xc[1]; xc2 = B.xc[2]; xc3 = B.xc[3]; }
 
-    PtIn<NSG> nx;
-    int pi = wave;
-    if (pi < np) load_point<NSG, HAS_L, FIX, DESC>(nx, B, cur, FS, p0 + pi, s, k, stepMode);
+    // ---- software pipeline over the points of this wavefront (round 6) ---------------------------------------------------------------
+    // point i: back half (arithmetic behind the taps) | point i + 1: front half (taps in flight) | point i + 2: records in flight.
+    const int waveU = __builtin_amdgcn_readfirstlane(wave);
+    PtIn<NSG> qa = {}, qb = {}, qc = {};
+    int pi = waveU;
+    if (pi < np) load_point<NSG, HAS_L, FIX, DESC>(qa, B, cur, FS, p0 + pi, s, k, lane);
 
     // ---- staging: all global loads first (one latency level), then the LDS stores --------------------------------
     {
@@ -311,7 +317,7 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
 #pragma unroll
         for (int u = 0; u < NAB; u++) { const int i = tid + u * 64 * LD_WAVES; if (i < FS * 64) { sAdH[i] = ahv[u]; sAdT[i] = atv[u]; } }
         if ((stepMode & 1) && tid < FS * 8) sXa[tid] = xav;
-        if (tid < FS) sImg[tid] = (tid < F) ? B.img[tid] : nullptr;
+        if (tid < FS) sImg[tid] = B.img[(tid < F) ? tid : 0];          // slots behind F: a readable image (their taps are loaded and never used)
     }
     if (HAS_L) for (int i = tid; i < LD_WAVES * FS * LD_TOPN; i += blockDim.x) sTopL[i] = 0.0f;
     __syncthreads();
@@ -339,39 +345,31 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
     float nidSum = 0.0f;
     int nidCnt = 0;
 
-    auto point_body = [&](const unsigned p, const PtIn<NSG> &q) {
-        if (pi == wave) LSTAMP(2);
-        // the uniform scalars of each slot record sit in the m of lanes 3 (energy), 5 (state), 6 (activity) of its 8-lane group
-        int qState[NSG], qActive[NSG];
-        float qEnergy[NSG];
-#pragma unroll
-        for (int g = 0; g < NSG; g++) {
-            float l1, h1, l2, h2, l3, h3;
-            group_bcast_pair<1>(q.m[g], k, l1, h1); group_bcast_pair<2>(q.m[g], k, l2, h2); group_bcast_pair<3>(q.m[g], k, l3, h3);
-            qState[g] = __builtin_bit_cast(int, h1); qActive[g] = __builtin_bit_cast(int, h2); qEnergy[g] = l3;
-            (void) l1; (void) l2; (void) h3;
-        }
-        const float pu = q.pu, pv = q.pv, priorF = MARG ? q.priorF * S.idepthFixPriorMargFac : q.priorF;
-        const bool flagged = MARG ? (margFlags[p] != 0) : true;
-        const float color = q.color, wgt = q.wgt;
-        float idp = q.idp, idz = q.idz;
+    // ================= FRONT half, per point: the fused point step ===============================================================
+    auto pstep = [&](const unsigned p, const PtIn<NSG> &q) -> PtStep {
+        float idp = RLF(q.rgeo, GEO_IDP), idz = RLF(q.rgeo, GEO_IDZ);
         if (stepMode & 1) {
             // ---- resubstituteFPt for this point, then backupState + doStepFromBackup (stepfacD = 1) ------------
+            const float rHdi = RLF(q.rrec, REC_HDI), rBd = RLF(q.rrec, REC_BDSUM), rIdH = RLF(q.rrec, REC_IDH);
             float step = 0.0f;
-            if (q.rec.nActive > 0) {
-                float b = q.rec.bdSumF;
+            if (RLI(q.rrec, REC_NACT) > 0) {
+                float b = rBd;
                 float dot = 0;
-                dot += xc0 * (q.rec.HcdA[0] + q.rec.HcdL[0]); dot += xc1 * (q.rec.HcdA[1] + q.rec.HcdL[1]); dot += xc2 * (q.rec.HcdA[2] + q.rec.HcdL[2]); dot += xc3 * (q.rec.HcdA[3] + q.rec.HcdL[3]);
+                dot += xc0 * (RLF(q.rrec, REC_HCDA + 0) + RLF(q.rrec, REC_HCDL + 0)); dot += xc1 * (RLF(q.rrec, REC_HCDA + 1) + RLF(q.rrec, REC_HCDL + 1));
+                dot += xc2 * (RLF(q.rrec, REC_HCDA + 2) + RLF(q.rrec, REC_HCDL + 2)); dot += xc3 * (RLF(q.rrec, REC_HCDA + 3) + RLF(q.rrec, REC_HCDL + 3));
                 b -= dot;
 #pragma unroll
                 for (int g = 0; g < NSG; g++) {
                     const int t = g * 8 + s;
-                    const bool act = (t < F) && (q.rflat[g] >= 0) && (qActive[g] != 0);
+                    // the activity flag of the slot record sits in the m of lane 6 of its 8-lane group
+                    float l2, h2;
+                    group_bcast_pair<2>(q.m[g], k, l2, h2); (void) l2;
+                    const bool act = (t < F) && (q.rflat[g] >= 0) && (__builtin_bit_cast(int, h2) != 0);
                     float sres = seq8(sXa[t * 8 + k] * q.jp[g], k, lane);
                     sres = act ? sres : 0.0f;
                     b -= sum_slots(sres, a16, a32);
                 }
-                if (isfinite(b)) step = -b * q.rec.HdiF; else { step = q.pstep; if (lane == 0) *(gptr_t<double>) (unsigned long long) (B.scalars + 4) = 1.0; }
+                if (isfinite(b)) step = -b * rHdi; else { step = RLF(q.rgeo, GEO_STEP); if (lane == 0) *(gptr_t<double>) (unsigned long long) (B.scalars + 4) = 1.0; }
             }
             const float ni = idp + 1.0f * step;
             {
@@ -381,26 +379,93 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
                 v4f_t *w_geo = GP(v4f_t, b0, BP_GEO);
                 if (lane == 1 || lane == 2) {
                     v4f_t v;
-                    v.x = (lane == 1) ? ni : q.rec.HdiF; v.y = (lane == 1) ? ni : q.rec.bdSumF; v.z = (lane == 1) ? step : q.rec.idH; v.w = (lane == 1) ? idp : 0.0f;
+                    v.x = (lane == 1) ? ni : rHdi; v.y = (lane == 1) ? ni : rBd; v.z = (lane == 1) ? step : rIdH; v.w = (lane == 1) ? idp : 0.0f;
                     AT(w_geo, p * 4 + (unsigned) lane) = v;
                 }
             }
             idp = ni; idz = ni;
         }
-        const float deltaF = idp - idz;
-        float HddA = 0, bdA = 0, HcdA0 = 0, HcdA1 = 0, HcdA2 = 0, HcdA3 = 0;
-        float HddL = 0, bdL = 0, HcdL0 = 0, HcdL1 = 0, HcdL2 = 0, HcdL3 = 0;
-        float hostPart = 0.0f;       // this lane's partial of the host block of g_p (component k)
-        // AccumulatedSCHessian.cc:14-21: the SOLVE that finds a point without an active residual zeroes its maxRelBaseline - i.e. the solve whose
-        // point step is fused in front of this pass (q.rec.nActive = active residuals of the linearisation that solve used).  A pass that is followed
-        // by no solve (the last linearizeAll(false) of optimize(), the fixing pass) zeroes nothing.
-        float maxRelBS = ((stepMode & 1) && q.rec.nActive <= 0) ? 0.0f : q.rec.maxRelBS;
-        int numGood = q.rec.numGood;
-        int nActive = 0;
-        float gT[NSG];
+        PtStep r; r.idp = idp; r.idz = idz;
+        return r;
+    };
+    // ================= FRONT half, per slot group: pattern projection, tap loads ====================================================
+    auto front_g = [&](auto gc, const PtIn<NSG> &q, const PtStep &ps, TapsG &T) {
+        constexpr int g = decltype(gc)::value;
+        const float pu = RLF(q.rgeo, GEO_U), pv = RLF(q.rgeo, GEO_V);
+        const float idp = ps.idp;
+        float l1, h1;
+        group_bcast_pair<1>(q.m[g], k, l1, h1); (void) l1;          // the state of the slot record: m of lane 5 of the group
+        const int qState = __builtin_bit_cast(int, h1);
+        const int t = g * 8 + s;
+        const bool exists = (t < F) && (q.rflat[g] >= 0);           // MARG: the flag of the point is read by the back half; unflagged points load taps nobody uses
+        const bool isLin = MARG ? false : (exists && (q.rlin[g] != 0));
+        const bool reset = MARG || ((stepMode & 2) && !isLin);
+        const int st = exists ? (reset ? RES_IN : qState) : RES_OOB;
+        const DevPair &pr = sPair[t];
+        // ---- pattern pixel projection at the current state (ResidualProjections.h:24-33) ---------
+        float px_ = pu + (float) ox, py_ = pv + (float) oy;
+        float q0 = ((pr.KRKi[0] * px_ + pr.KRKi[1] * py_) + pr.KRKi[2] * 1.0f) + pr.Kt[0] * idp;
+        float q1 = ((pr.KRKi[3] * px_ + pr.KRKi[4] * py_) + pr.KRKi[5] * 1.0f) + pr.Kt[1] * idp;
+        float q2 = ((pr.KRKi[6] * px_ + pr.KRKi[7] * py_) + pr.KRKi[8] * 1.0f) + pr.Kt[2] * idp;
+        float Ku = q0 / q2, Kv = q1 / q2;
+        const bool pixOK = Ku > 1.1f && Kv > 1.1f && Ku < wM3G && Kv < hM3G;
+        T.Ku = Ku; T.Kv = Kv;
+        // ---- the 4 x 12 bytes under the projected pixel (GlobalFuncs.h:89-103): every lane loads - lanes without a sample read pixel 0 of a
+        // readable image (one line for all of them), so that the loads sit in straight-line code one group ahead of their use
+        const bool want = exists && !isLin && st != RES_OOB && pixOK;
+        const int ix = (int) Ku, iy = (int) Kv;
+        const unsigned off = want ? (unsigned) (3 * (ix + iy * W)) : 0u;
+        const float *ib = DESC ? sImg[t] : B.img[(t < F) ? t : 0];
+        const gptr_t<const float> bp = (gptr_t<const float>) (unsigned long long) ib + off;
+        const gptr_t<const float> bq = bp + 3 * W;
+        const v4f_t r0a = *(gptr_t<const v4f_t>) bp; const v2f_t r0b = *(gptr_t<const v2f_t>) (bp + 4);
+        const v4f_t r1a = *(gptr_t<const v4f_t>) bq; const v2f_t r1b = *(gptr_t<const v2f_t>) (bq + 4);
+        T.t[0] = r0a.x; T.t[1] = r0a.y; T.t[2] = r0a.z; T.t[3] = r0a.w; T.t[4] = r0b.x; T.t[5] = r0b.y;
+        T.t[6] = r1a.x; T.t[7] = r1a.y; T.t[8] = r1a.z; T.t[9] = r1a.w; T.t[10] = r1b.x; T.t[11] = r1b.y;
+    };
 
-#pragma unroll
-        for (int g = 0; g < NSG; g++) {
+    // ================= BACK half of a point: everything behind the image taps ================================================================
+    // per-point state of the back half (set by back_begin, updated by back_g of every slot group, consumed by back_end)
+    float pu = 0, pv = 0, priorF = 0, color = 0, wgt = 0, idp = 0, idz = 0, deltaF = 0;
+    bool flagged = true;
+    int recNActive = 0;
+    float HddA = 0, bdA = 0, HcdA0 = 0, HcdA1 = 0, HcdA2 = 0, HcdA3 = 0;
+    float HddL = 0, bdL = 0, HcdL0 = 0, HcdL1 = 0, HcdL2 = 0, HcdL3 = 0;
+    float hostPart = 0.0f;       // this lane's partial of the host block of g_p (component k)
+    float maxRelBS = 0.0f;
+    int numGood = 0, nActive = 0;
+    float gT[NSG];
+    auto back_begin = [&](const unsigned p, const PtIn<NSG> &q, const PtStep &ps) {
+        pu = RLF(q.rgeo, GEO_U); pv = RLF(q.rgeo, GEO_V);
+        priorF = MARG ? RLF(q.rgeo, GEO_PRIOR) * S.idepthFixPriorMargFac : RLF(q.rgeo, GEO_PRIOR);
+        flagged = MARG ? (margFlags[p] != 0) : true;
+        color = q.color; wgt = q.wgt;
+        idp = ps.idp; idz = ps.idz;
+        recNActive = RLI(q.rrec, REC_NACT);
+        deltaF = idp - idz;
+        HddA = 0; bdA = 0; HcdA0 = 0; HcdA1 = 0; HcdA2 = 0; HcdA3 = 0;
+        HddL = 0; bdL = 0; HcdL0 = 0; HcdL1 = 0; HcdL2 = 0; HcdL3 = 0;
+        hostPart = 0.0f;
+        // AccumulatedSCHessian.cc:14-21: the SOLVE that finds a point without an active residual zeroes its maxRelBaseline - i.e. the solve whose
+        // point step is fused in front of this pass (PtRec.nActive = active residuals of the linearisation that solve used).  A pass that is followed
+        // by no solve (the last linearizeAll(false) of optimize(), the fixing pass) zeroes nothing.
+        maxRelBS = ((stepMode & 1) && recNActive <= 0) ? 0.0f : RLF(q.rrec, REC_MAXRELBS);
+        numGood = RLI(q.rrec, REC_NUMGOOD);
+        nActive = 0;
+    };
+
+    auto back_g = [&](auto gc, const unsigned p, const PtIn<NSG> &q, const TapsG &T) {
+        constexpr int g = decltype(gc)::value;
+        // the uniform scalars of the slot record sit in the m of lanes 3 (energy), 5 (state), 6 (activity) of its 8-lane group
+        int qState[NSG], qActive[NSG];
+        float qEnergy[NSG];
+        {
+            float l1, h1, l2, h2, l3, h3;
+            group_bcast_pair<1>(q.m[g], k, l1, h1); group_bcast_pair<2>(q.m[g], k, l2, h2); group_bcast_pair<3>(q.m[g], k, l3, h3);
+            qState[g] = __builtin_bit_cast(int, h1); qActive[g] = __builtin_bit_cast(int, h2); qEnergy[g] = l3;
+            (void) l1; (void) l2; (void) h3;
+        }
+        {
             const int t = g * 8 + s;
             const unsigned slot = p * (unsigned) FS + (unsigned) t;
             const bool exists = (t < F) && (q.rflat[g] >= 0) && flagged;
@@ -434,35 +499,26 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
             float uu = ptp0 * drescale, vv = ptp1 * drescale;
             float cKu = uu * fx + cx, cKv = vv * fy + cy;
             bool centerOK = (drescale > 0) && cKu > 1.1f && cKv > 1.1f && cKu < wM3G && cKv < hM3G;
-            // ---- pattern pixel projection at the current state (ResidualProjections.h:24-33) ---------
-            float px_ = pu + (float) ox, py_ = pv + (float) oy;
-            float q0 = ((pr.KRKi[0] * px_ + pr.KRKi[1] * py_) + pr.KRKi[2] * 1.0f) + pr.Kt[0] * idp;
-            float q1 = ((pr.KRKi[3] * px_ + pr.KRKi[4] * py_) + pr.KRKi[5] * 1.0f) + pr.Kt[1] * idp;
-            float q2 = ((pr.KRKi[6] * px_ + pr.KRKi[7] * py_) + pr.KRKi[8] * 1.0f) + pr.Kt[2] * idp;
-            float Ku = q0 / q2, Kv = q1 / q2;
+            // ---- pattern pixel projection at the current state: done by the front half (ResidualProjections.h:24-33) ---------
+            const float Ku = T.Ku, Kv = T.Kv;
             bool pixOK = Ku > 1.1f && Kv > 1.1f && Ku < wM3G && Kv < hM3G;
-            if (pi == wave && g == 0) LSTAMP(3);
-            // ---- bilinear Vec3f sample of the target image (GlobalFuncs.h:89-103) ---------------------
+            // ---- bilinear Vec3f sample of the target image (GlobalFuncs.h:89-103) from the taps the front half loaded ---------------------
             float hit0 = 0, hit1 = 0, hit2 = 0;
-            if (compute && centerOK && pixOK) {
-                int ix = (int) Ku, iy = (int) Kv;
-                float dx = Ku - ix, dy = Kv - iy, dxdy = dx * dy;
-                // descriptor in memory: the pointer from LDS; kernel arguments: the table sits in scalar registers, selected per lane
-                float a0, a1, a2, b0_, b1, b2, c0_, c1_, c2_, d0, d1, d2;
-                {
-                    const float *bp = (DESC ? sImg[t] : B.img[t]) + 3 * (ix + iy * W);
-                    a0 = bp[0]; a1 = bp[1]; a2 = bp[2]; b0_ = bp[3]; b1 = bp[4]; b2 = bp[5];
-                    const float *bq = bp + 3 * W;
-                    c0_ = bq[0]; c1_ = bq[1]; c2_ = bq[2]; d0 = bq[3]; d1 = bq[4]; d2 = bq[5];
-                }
-                float w11 = dxdy, w01 = dy - dxdy, w10 = dx - dxdy, w00 = 1 - dx - dy + dxdy;
-                hit0 = ((w11 * d0 + w01 * c0_) + w10 * b0_) + w00 * a0;
-                hit1 = ((w11 * d1 + w01 * c1_) + w10 * b1) + w00 * a1;
-                hit2 = ((w11 * d2 + w01 * c2_) + w10 * b2) + w00 * a2;
+            {
+                const int ix = (int) Ku, iy = (int) Kv;
+                const float dx = Ku - ix, dy = Kv - iy, dxdy = dx * dy;
+                (void) iy;
+                const float a0 = T.t[0], a1 = T.t[1], a2 = T.t[2], b0_ = T.t[3], b1 = T.t[4], b2 = T.t[5];
+                const float c0_ = T.t[6], c1_ = T.t[7], c2_ = T.t[8], d0 = T.t[9], d1 = T.t[10], d2 = T.t[11];
+                const float w11 = dxdy, w01 = dy - dxdy, w10 = dx - dxdy, w00 = 1 - dx - dy + dxdy;
+                const float h0 = ((w11 * d0 + w01 * c0_) + w10 * b0_) + w00 * a0;
+                const float h1 = ((w11 * d1 + w01 * c1_) + w10 * b1) + w00 * a1;
+                const float h2 = ((w11 * d2 + w01 * c2_) + w10 * b2) + w00 * a2;
+                const bool smp = compute && centerOK && pixOK;
+                hit0 = smp ? h0 : 0.0f; hit1 = smp ? h1 : 0.0f; hit2 = smp ? h2 : 0.0f;
             }
             bool laneBad = compute && (!centerOK || !pixOK || !isfinite(hit0));
             unsigned long long badMask = __ballot(laneBad);
-            if (pi == wave && g == 0) LSTAMP(4);
             bool anyBad = ((badMask >> (s * 8)) & 0xFFull) != 0;
             if (compute && anyBad) { newState = RES_OOB; ret = (double) newEnergy; compute = false; }
 
@@ -685,7 +741,9 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
             if (FIX) { float m = maxRelBS; m = fmaxf(m, __shfl_xor(m, 8, 64)); m = fmaxf(m, __shfl_xor(m, 16, 64)); m = fmaxf(m, __shfl_xor(m, 32, 64)); maxRelBS = m; }
 
             // ---- per-slot outputs: the slot's SlotRec of the next set, lane k stores its own pair (one dwordx2 store per lane) ------------
-            if (t < F) {
+            {
+                // stored by EVERY lane, also for the padding slots behind F (the table is dense [P][FS]; they keep the zeros of the upload): a store under a
+                // branch cannot be counted by the in-order memory counter, and everything in flight in front of it would be waited for with vmcnt(0)
                 const v16i_t o0 = ldg16<DESC, OFF_S0>(&nxt);
                 v2f_t *o_slot = GP(v2f_t, o0, RS_SLOT);
                 float *o_cand = GP(float, o0, RS_CAND);
@@ -693,14 +751,12 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
                 const float cenK = compute ? (k == 0 ? c0 : k == 1 ? c1 : c2) : q.m[g];      // k < 3 only: lanes 0..2 hold the old centre in their m
                 float mOut = (k < 3) ? cenK : (k == LD_SM_ENERGY) ? newEnergy : (k == LD_SM_EWO) ? ewo_
                            : __builtin_bit_cast(float, (k == LD_SM_STATE) ? newState : (k == LD_SM_ACTIVE) ? activeNew : toRemove);
-                v2f_t e; e.x = jp; e.y = mOut;
+                v2f_t e; e.x = (t < F) ? jp : 0.0f; e.y = (t < F) ? mOut : 0.0f;
                 AT(o_slot, slot * 8 + (unsigned) k) = e;
-                if (k == 0) {
-                    if (t == F - 1) AT(o_cand, p) = ewo_;
-                    if (doLin) energySum += ret;
-                }
+                if (k == 0 && t == F - 1) AT(o_cand, p) = ewo_;
+                if (k == 0 && t < F && doLin) energySum += ret;
             }
-            if (dumpJ != nullptr && compute) {
+            if (!DESC && dumpJ != nullptr && compute) {          // (debug dump: the step-wise entry points only)
                 auto &o = *(gptr_t<ldso_rawjac_t>) (unsigned long long) (dumpJ + q.rflat[g]);          // global, not flat: a pending flat access makes every later wait a vmcnt(0)
                 o.resF[k] = resF; o.JIdx[0][k] = gx; o.JIdx[1][k] = gy; o.JabF[0][k] = jab0; o.JabF[1][k] = jab1;
                 if (k == 0) {
@@ -712,9 +768,11 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
                     o.Jab2[0] = Jab00; o.Jab2[1] = Jab01; o.Jab2[2] = Jab01; o.Jab2[3] = Jab11;
                 }
             }
-        }   // slot groups
+        }   // slot group
+    };   // back_g
 
-        if (pi == wave) LSTAMP(5);
+    auto back_end = [&](const unsigned p, const PtIn<NSG> &q) {
+        (void) q;
         // ================= per-point Schur quantities (AccumulatedSCHessian.cc:9-31) =====================
         float HdiF = 0, bdSumF = 0, idH = 0;
         float Hc0 = HcdA0 + HcdL0, Hc1 = HcdA1 + HcdL1, Hc2 = HcdA2 + HcdL2, Hc3 = HcdA3 + HcdL3;
@@ -759,14 +817,71 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
             }
             if (lane == 0) { nidSum += fabsf(idp); nidCnt++; }
         }
-    };   // point_body
+    };   // back_end
 
     {
+        // The software pipeline.  F <= 8 (one slot group per point): the taps of point i + 1 are in flight while point i is worked on.  F > 8: the unit is
+        // the slot group - the taps of the point's second group, then of the next point's first group, are in flight behind the group that is worked on.
+        // The records of point i + 2 are in flight in both cases.
+        using G0 = std::integral_constant<int, 0>;
+        using G1 = std::integral_constant<int, NSG - 1>;
+        constexpr bool PIPE = DESC || (NSG == 1 && LD_PIPE_ARGS);
+        PtStep sa = {0, 0}, sb = {0, 0};
+        TapsG ta = {}, tb = {};
+        // The loads of the pipeline are issued UNCONDITIONALLY (behind the last point of the wavefront they re-read that point, nobody uses the result): the
+        // memory counter of a wavefront is in order, so a load can only be waited for precisely (vmcnt(N), N = operations issued behind it) when the compiler
+        // can COUNT what is issued behind it - a load or store under a branch counts as zero, and the first version of this loop (loads under `if (next point
+        // exists)`) waited with vmcnt(0) for everything in flight in front of every use: no overlap at all (r6 call 1: 219 -> 207 us for the batch).
+        if (pi < np) {
+            sa = pstep((unsigned) (p0 + pi), qa); front_g(G0{}, qa, sa, ta);
+            if (DESC && PIPE && np <= LD_WAVES) {          // (the argument-based kernels keep one copy of the point's code: with two they spill)
+                // one point per wavefront (a single window spread over the whole chip, C3): nothing to overlap it with - the point straight through, without
+                // the pipeline's look-ahead loads (measured with them: 13.5 -> 14.7 us at C3); above 8 key frames both slot groups' taps are in flight together
+                const unsigned p = (unsigned) (p0 + pi);
+                if constexpr (NSG > 1) front_g(G1{}, qa, sa, tb);
+                back_begin(p, qa, sa);
+                back_g(G0{}, p, qa, ta);
+                if constexpr (NSG > 1) back_g(G1{}, p, qa, tb);
+                back_end(p, qa);
+            } else {
+            if constexpr (PIPE) load_point<NSG, HAS_L, FIX, DESC>(qb, B, cur, FS, (unsigned) (p0 + ((pi + LD_WAVES < np) ? pi + LD_WAVES : pi)), s, k, lane);
 #pragma clang loop unroll(disable)
-        for (; pi < np; pi += LD_WAVES) {
-            const unsigned p = (unsigned) (p0 + pi);
-            if (pi != wave) load_point<NSG, HAS_L, FIX, DESC>(nx, B, cur, FS, p, s, k, stepMode);       // the first record was loaded before the staging
-            point_body(p, nx);
+            do {
+                const unsigned p = (unsigned) (p0 + pi);
+                const bool n1 = pi + LD_WAVES < np, n2 = pi + 2 * LD_WAVES < np;
+                const unsigned p1 = n1 ? p + LD_WAVES : p, p2 = n2 ? p + 2 * LD_WAVES : p1;
+                if constexpr (!PIPE) {
+                    // the cold variants above 8 key frames (fix / linearised / marginalisation passes): no taps in flight behind the arithmetic - with two slot
+                    // groups the pipelined form does not fit the register file (100+ spilled registers, measured)
+                    (void) n1; (void) n2; (void) p1; (void) p2; (void) qb; (void) qc; (void) sb; (void) tb;
+                    if (pi != waveU) { load_point<NSG, HAS_L, FIX, DESC>(qa, B, cur, FS, p, s, k, lane); sa = pstep(p, qa); front_g(G0{}, qa, sa, ta); }
+                    back_begin(p, qa, sa);
+                    back_g(G0{}, p, qa, ta);
+                    front_g(G1{}, qa, sa, ta);
+                    back_g(G1{}, p, qa, ta);
+                    back_end(p, qa);
+                } else if constexpr (NSG == 1) {
+                    if (n1) sb = pstep(p1, qb);          // (the fused point step stores: only for a real next point)
+                    front_g(G0{}, qb, sb, tb);
+                    load_point<NSG, HAS_L, FIX, DESC>(qc, B, cur, FS, p2, s, k, lane);
+                    back_begin(p, qa, sa);
+                    back_g(G0{}, p, qa, ta);
+                    back_end(p, qa);
+                    ta = tb;
+                } else {
+                    front_g(G1{}, qa, sa, tb);
+                    back_begin(p, qa, sa);
+                    back_g(G0{}, p, qa, ta);
+                    if (n1) sb = pstep(p1, qb);
+                    front_g(G0{}, qb, sb, ta);
+                    load_point<NSG, HAS_L, FIX, DESC>(qc, B, cur, FS, p2, s, k, lane);
+                    back_g(G1{}, p, qa, tb);
+                    back_end(p, qa);
+                }
+                if constexpr (PIPE) { qa = qb; qb = qc; sa = sb; }
+                pi += LD_WAVES;
+            } while (pi < np);
+            }
         }
     }   // points of this wave
 

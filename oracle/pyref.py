@@ -110,8 +110,12 @@ class RefWindow:
             pass
 
     # --- the reference's own FullSystem members on this window (FullSystem.cc compiled unmodified; ref_driver.cc ref_fs_*) ---------
-    def fs_attach(self, multithreading=False):
-        self.L.ref_fs_attach(self.h, C.c_int(1 if multithreading else 0))
+    def fs_attach(self, multithreading=None):
+        # the choice sticks to the window: later helpers re-attach without an argument (fs_handle) and must not switch the reference's
+        # process-wide `multiThreading` back
+        if multithreading is not None:
+            self._mt = bool(multithreading)
+        self.L.ref_fs_attach(self.h, C.c_int(1 if getattr(self, "_mt", False) else 0))
 
     def fs_log(self) -> str:
         n = self.L.ref_fs_log(self.h, None, C.c_int(0))

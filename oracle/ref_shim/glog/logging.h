@@ -9,7 +9,8 @@
 #include <type_traits>
 #include <utility>
 namespace ref_shim {
-inline std::string *&log_capture_slot() { static std::string *p = nullptr; return p; }
+// (per thread: the tracking thread and the mapping thread of tests/test_adapter_threads_gpu.py log side by side; the reference's IndexThreadReduce workers have no slot and stay silent)
+inline std::string *&log_capture_slot() { static thread_local std::string *p = nullptr; return p; }
 template <class T, class = void> struct is_streamable : std::false_type {};
 template <class T> struct is_streamable<T, std::void_t<decltype(std::declval<std::ostream &>() << std::declval<const T &>())>> : std::true_type {};
 struct NullLog {

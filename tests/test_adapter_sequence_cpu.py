@@ -35,3 +35,22 @@ def test_reference_leg_of_the_key_frame_sequence_slides_a_window():
     assert np.abs(last["HM"]).max() > 0 and np.allclose(last["HM"], last["HM"].T, rtol=1e-9, atol=1e-6 * np.abs(last["HM"]).max())
     assert list(last["ids"]) == sorted(last["ids"]) and last["ids"][0] > int(win.frames["frameID"].min()), "the oldest frames are gone"
     r.close()
+
+
+def test_reference_against_itself_is_the_yardstick_of_the_sequence_test():
+    """tests/test_adapter_sequence_gpu.py bounds the drop-in's distance to the reference by 3 x the distance between two runs of the REFERENCE ITSELF over the
+    same eight key frames: the single-threaded -O2 pin build against (i) its own 6-worker IndexThreadReduce (IndexThreadReduce.h:126-139: chunks go to whichever
+    worker asks first, the per-thread float accumulators sum in another order every run) and (ii) the -O3 build of the same translation units.  This is the CPU
+    half: the yardstick exists, both kinds of run keep the same key frames, and they really are different arithmetic (non-zero distances) - a sliding-window
+    system amplifies rounding differences through threshold decisions (an immature point traced to one side of `interval < 8`, a residual to one side of its
+    outlier energy), which is why the end-to-end distances are 1e-4 .. 1e-2 and not the 1e-6 of a single stage."""
+    from adapter_sequence_common import reference_yardstick, QUANTITIES
+    yard, per = reference_yardstick("small", 8, mt_runs=2)
+    print("reference vs reference over 8 key frames:", {k: {q: float("%.3g" % v) for q, v in d.items()} for k, d in per.items()})
+    assert set(yard) == set(QUANTITIES)
+    assert "O3_build" in per, "this container builds oracle/_ref/fast/libldso_ref.so and adapter/_build_fast (make -C oracle ref_fast; make -C adapter fast)"
+    for name, d in per.items():
+        assert all(np.isfinite(v) for v in d.values()), name
+        assert d["counts"] <= 8 and d["unmatched_points"] <= 40, (name, d)          # two runs of the reference stay the same system
+    assert per["O3_build"]["pose"] > 0 and per["O3_build"]["HM"] > 0, "the -O3 build rounds differently from the pin build"
+    assert max(per[k]["bM"] for k in per if k.startswith("six_threads")) > 0, "six workers sum in another order than one"

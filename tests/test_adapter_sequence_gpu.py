@@ -27,7 +27,7 @@ def test_eight_key_frames_through_the_adapter_follow_the_reference(device_marg):
     """device_marg: the point marginalisation after optimize() through GpuBackend::flagPointsForRemoval + marginalizePoints (the policy on the host, the
     re-linearise / fix / accumulate pass of FullSystem.cc:1241-1250 + EnergyFunctional.cc:165-222 as ldso_ba_marginalize_points on the resident window)
     instead of the reference's host members on what the adapter wrote back"""
-    from adapter_sequence_common import run_sequence
+    from adapter_sequence_common import run_sequence, reference_yardstick, sequence_distance, QUANTITIES
     win = synth.make_config("small", extra_frames=K)
     r_ref, log_ref = run_sequence(win, K)
     A = pr.GpuAdapter(max_frames=8, max_points=4000)
@@ -40,41 +40,21 @@ def test_eight_key_frames_through_the_adapter_follow_the_reference(device_marg):
     # FrameHessian::dIp on the device: ONE pyramid per frame seen (the 5 frames of the initial window + the 8 new key frames), shared by the tracer, the
     # BA image slot and - in a full system - the coarse trackers; built from 4 bytes per pixel
     assert A.pyramids_built() == win.F + K, A.pyramids_built()
-    worst = dict(pose=0.0, aff=0.0, HM=0.0, bM=0.0, idepth_max=0.0, idepth_med=0.0, rmse=0.0, counts=0, unmatched_points=0)
-    for a, b in zip(log_ref, log_adp):
-        sa, sb = a["summary"], b["summary"]
-        assert not a["lost"] and not b["lost"]
-        assert sa["F"] == sb["F"] and np.array_equal(sa["ids"], sb["ids"]), "same key frames in the window"
-        # The two graphs run DIFFERENT arithmetic for three stages (the device's summation orders): their states agree to ~1e-6, so an immature
-        # point or a residual sitting exactly on a threshold (trace interval < 8, outlier energy, inlier count) may go the other way - a handful
-        # per key frame at most, and the difference must not grow
-        dc = max(abs(a["candidates"] - b["candidates"]), abs(a["new_residuals"] - b["new_residuals"]), abs(a["activated"] - b["activated"]), abs(a["points"] - b["points"]),
-                 int(np.abs(sa["points"] - sb["points"]).max()), int(np.abs(sa["immature"] - sb["immature"]).max()))
-        assert dc <= 8, (a["k"], {k: (a[k], b[k]) for k in ("candidates", "activated", "new_residuals", "points")}, sa["points"], sb["points"], sa["immature"], sb["immature"])
-        assert int(np.abs(sa["residuals"] - sb["residuals"]).max()) <= 40, (sa["residuals"], sb["residuals"])
-        worst["counts"] = max(worst["counts"], dc)
-        worst["rmse"] = max(worst["rmse"], abs(a["rmse"] - b["rmse"]) / a["rmse"])
-        scale = np.abs(sa["c2w"][:, :, 3]).max()
-        worst["pose"] = max(worst["pose"], float(np.abs(sa["c2w"] - sb["c2w"]).max() / max(scale, 1.0)))
-        worst["aff"] = max(worst["aff"], float(np.abs(sa["aff"] - sb["aff"]).max()))
-        if np.abs(sa["HM"]).max() > 0:
-            worst["HM"] = max(worst["HM"], _rel(sb["HM"], sa["HM"])); worst["bM"] = max(worst["bM"], _rel(sb["bM"], sa["bM"]))
-        # inverse depths of the points both graphs hold, matched by (host key frame, pixel)
-        ka = {(int(h), float(u), float(v)): float(d) for h, (u, v), d in zip(sa["host"], sa["uv"], sa["idepth"])}
-        kb = {(int(h), float(u), float(v)): float(d) for h, (u, v), d in zip(sb["host"], sb["uv"], sb["idepth"])}
-        both = sorted(set(ka) & set(kb))
-        worst["unmatched_points"] = max(worst["unmatched_points"], len(set(ka) ^ set(kb)))
-        assert len(both) > 0.97 * max(len(ka), len(kb))
-        e = np.array([abs(ka[q] - kb[q]) / max(abs(ka[q]), 1e-3) for q in both])
-        worst["idepth_max"] = max(worst["idepth_max"], float(e.max())); worst["idepth_med"] = max(worst["idepth_med"], float(np.median(e)))
-    print("adapter sequence (device marginalisation: %s), worst over" % device_marg, K, "key frames:", {k: (round(v, 7) if isinstance(v, float) else v) for k, v in worst.items()})
-    # observed on MI355X (round 4): rmse 1.9e-3, pose 2.0e-4 of the scene scale, affine 0.02 (b is in intensity units, 0..255), H_M 1.3e-3, b_M 2.3e-2,
-    # inverse depths 1e-4 median / 8e-4 maximum, <= 1 object per count, 5 points held by one graph only - limits = 2..3 x observed
-    observe(("sequence_dm_" if device_marg else "sequence_") + "rmse", worst["rmse"], 5e-3)
-    observe(("sequence_dm_" if device_marg else "sequence_") + "pose", worst["pose"], 6e-4); observe(("sequence_dm_" if device_marg else "sequence_") + "affine", worst["aff"], 6e-2)
-    observe(("sequence_dm_" if device_marg else "sequence_") + "HM", worst["HM"], 4e-3); observe(("sequence_dm_" if device_marg else "sequence_") + "bM", worst["bM"], 6e-2)
-    observe(("sequence_dm_" if device_marg else "sequence_") + "idepth_median", worst["idepth_med"], 3e-4); observe(("sequence_dm_" if device_marg else "sequence_") + "idepth_max", worst["idepth_max"], 3e-3)
-    observe(("sequence_dm_" if device_marg else "sequence_") + "unmatched_points", worst["unmatched_points"], 20)
+    # The two graphs run DIFFERENT arithmetic for three stages (the device's summation orders): their states agree to ~1e-6 after one stage, and a
+    # sliding-window system amplifies that through threshold decisions (an immature point on one side of `interval < 8`, a residual on one side of its
+    # outlier energy, a point on one side of the inlier count).  HOW FAR two correct implementations drift apart over these eight key frames is measured on
+    # the reference itself (adapter_sequence_common.reference_yardstick: the pin build against its own 6-worker IndexThreadReduce, whose float sums change
+    # from run to run, and against the -O3 build of the same translation units); the drop-in may be at most K_YARD x as far from the reference as the
+    # reference is from itself, per quantity.  No limit below is derived from the product's own output.
+    K_YARD = 3.0
+    yard, per = reference_yardstick("small", K, log_ref=log_ref, mt_runs=2)
+    worst, same = sequence_distance(log_ref, log_adp)
+    assert same, "same key frames in the window after every key frame, >= 97 % of the points held by both graphs"
+    tag = "sequence_dm_" if device_marg else "sequence_"
+    print("adapter sequence (device marginalisation: %s), worst over" % device_marg, K, "key frames:", {k: float("%.3g" % v) for k, v in worst.items()},
+          "| reference vs reference:", {k: float("%.3g" % v) for k, v in yard.items()})
+    for q in QUANTITIES:
+        observe(tag + q, worst[q], K_YARD * yard[q])
     A.close()
 
 

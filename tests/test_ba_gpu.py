@@ -288,7 +288,17 @@ def test_marginalize_points(small, with_prior):
     HM2o, bM2o = o.get_prior()
     HM2g, bM2g = g.marginalize_frame(0)
     assert HM2g.shape == HM2o.shape == (8 * (win.F - 1) + 4,) * 2
-    assert blockrel(HM2g, HM2o, 4) < 5 * TOL and rel(HM2g, HM2o) < 5 * TOL and rel(bM2g, bM2o) < 5 * TOL
+    # marginalizeFrame is fp64 on both sides: what separates HM2g from HM2o is the fp32 difference of their inputs (HMg vs HMo, within TOL above) pushed through the
+    # inverse of the frame's 8 x 8 block - measured apart (tests/test_fullsize_gpu.py::test_c5_end_to_end has the same three steps at C5):
+    g.set_prior(HMo, bMo)                                   # (i) the device on the oracle's prior = the oracle's result
+    HM2i, bM2i = g.marginalize_frame(0)
+    observe("marginalize_frame_same_input", max(blockrel(HM2i, HM2o, 4), rel(bM2i, bM2o)), 1e-9)
+    w2b = copy.deepcopy(w2); w2b.HM, w2b.bM = HMg, bMg      # (ii) the oracle on the device's prior = the device's result
+    ob = po.OracleWindow(w2b); ob.marginalize_frame(0)
+    HM2b, bM2b = ob.get_prior(); ob.close()
+    observe("marginalize_frame_device_input", max(blockrel(HM2g, HM2b, 4), rel(bM2g, bM2b)), 1e-9)
+    sens_H, sens_b = blockrel(HM2b, HM2o, 4), rel(bM2b, bM2o)          # (iii) the chained difference = the oracle's own sensitivity to the input difference
+    assert blockrel(HM2g, HM2o, 4) <= 1.01 * sens_H + 1e-8 and rel(bM2g, bM2o) <= 1.01 * sens_b + 1e-8, (blockrel(HM2g, HM2o, 4), sens_H, rel(bM2g, bM2o), sens_b)
     assert np.abs(HM2g - HM2g.T).max() <= 1e-9 * np.abs(HM2g).max()
 
 

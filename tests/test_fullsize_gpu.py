@@ -10,7 +10,7 @@ import copy
 import numpy as np
 import pytest
 
-from conftest import rel, blockrel, get_window
+from conftest import observe, rel, blockrel, get_window
 from ldso_amd import synth, binding
 from oracle import pyoracle as po
 
@@ -202,7 +202,21 @@ def test_c5_end_to_end():
     HM2o, bM2o = o.get_prior()
     HM2g, bM2g = g.marginalize_frame(0)
     assert HM2g.shape == (92, 92)
-    assert blockrel(HM2g, HM2o, 4) < 5 * TOL and rel(bM2g, bM2o) < 5 * TOL
+    # marginalizeFrame is fp64 on both sides; what separates HM2g from HM2o is the fp32 difference of their INPUTS (HMg vs HMo, within TOL above) pushed through
+    # the inverse of the frame's 8 x 8 block.  Measured apart (round 6; until round 5 this was one comparison at 5 x TOL):
+    #  (i) the device on the ORACLE's prior is the oracle's result to fp64 rounding,
+    g.set_prior(HMo, bMo)
+    HM2i, bM2i = g.marginalize_frame(0)
+    observe("c5_marginalize_frame_same_input_HM", blockrel(HM2i, HM2o, 4), 1e-9); observe("c5_marginalize_frame_same_input_bM", rel(bM2i, bM2o), 1e-9)
+    #  (ii) the oracle's own arithmetic on the DEVICE's prior is the device's result (same bound),
+    w2b = copy.deepcopy(w2); w2b.HM, w2b.bM = HMg, bMg
+    ob = po.OracleWindow(w2b); ob.marginalize_frame(0)
+    HM2b, bM2b = ob.get_prior(); ob.close()
+    observe("c5_marginalize_frame_device_input_HM", blockrel(HM2g, HM2b, 4), 1e-9); observe("c5_marginalize_frame_device_input_bM", rel(bM2g, bM2b), 1e-9)
+    #  (iii) and the chained difference is the oracle's own sensitivity to that input difference (blockrel(HM2b, HM2o)): no tolerance of its own
+    sens_H, sens_b = blockrel(HM2b, HM2o, 4), rel(bM2b, bM2o)
+    assert blockrel(HM2g, HM2o, 4) <= 1.01 * sens_H + 1e-8 and rel(bM2g, bM2o) <= 1.01 * sens_b + 1e-8, (blockrel(HM2g, HM2o, 4), sens_H, rel(bM2g, bM2o), sens_b)
+    print("C5 marginalizeFrame: chained difference to the oracle", blockrel(HM2g, HM2o, 4), rel(bM2g, bM2o), "= the oracle's sensitivity to the prior's fp32 difference", sens_H, sens_b)
 
     # F = 11: window rebuilt without frame 0, carrying the DEVICE's prior; 10 more iterations on both sides
     ex = o.export_window(); fo = o.get_frames()
@@ -222,4 +236,13 @@ def test_c5_end_to_end():
     assert np.all(np.abs(eg - eo) <= TOL * np.abs(eo)), (eo, eg)
     assert abs(rmo - rmg) <= TOL * rmo
     ro, rg = o3.get_residuals(False), g3.get_residuals()
-    assert (ro["state_state"] != rg["state_state"]).sum() <= 2e-3 * w3.R
+    # Residual states after 10 iterations: a state can only differ where the residual sits AT its outlier threshold - the energies of the two sides agree to
+    # TOL, so a residual whose energy is further than 100 x TOL (relative) from max(frameEnergyTH of host, target) in the oracle's run is on the same side on
+    # the device.  (Until round 5: "at most 0.2 % differ", a number taken from the product's own output.  Observed on MI355X: 0 differ, 3 of 63 250 are that
+    # close; the oracle's -O3 and six-thread builds against its portable build: 0 differ.)
+    flipped = np.nonzero(ro["state_state"] != rg["state_state"])[0]
+    fr3 = o3.get_frames()["frames"]
+    th = np.maximum(fr3["frameEnergyTH"][w3.residuals["host"]], fr3["frameEnergyTH"][w3.residuals["target"]])
+    near = np.abs(ro["out"]["state_NewEnergyWithOutlier"] - th) <= 100 * TOL * th
+    assert np.all(near[flipped]), ("residual states differ away from the outlier threshold", flipped[~near[flipped]][:10])
+    print("C5 / F = 11 after 10 iterations: residual states differing", len(flipped), "of", w3.R, "| within 1e-2 of their threshold in the oracle:", int(near.sum()))
