@@ -156,6 +156,12 @@ int ldso_ba_set_shard(ldso_ba_t *h, int point_begin, int point_end);
  * are formed per chunk: two handles agree bit for bit only under the same chunking. */
 int ldso_ba_set_chunk_points(ldso_ba_t *h, int points_per_workgroup);
 int ldso_ba_get_chunk_points(ldso_ba_t *h, int *points_per_workgroup, int *workgroups);
+/* The chunks themselves: ends[i] = one past the last point of chunk i (ascending, the last one = number of points; chunks never straddle a host frame -
+ * a cut is added at every host boundary).  ldso_ba_batch_create cuts the windows of a batch UNEVENLY (every workgroup of the batched launch gets the same
+ * amount of work, round 6); ldso_ba_get_chunk_cuts returns the cuts in force (n_out = their number; ends may be NULL to ask for the count),
+ * ldso_ba_set_chunk_cuts applies them to another handle holding a window of the same shape (n = 0: back to ldso_ba_set_chunk_points' policy). */
+int ldso_ba_get_chunk_cuts(ldso_ba_t *h, int32_t *ends, int cap, int *n_out);
+int ldso_ba_set_chunk_cuts(ldso_ba_t *h, const int32_t *ends, int n);
 size_t ldso_ba_reduce_doubles(ldso_ba_t *h);
 
 /* --- the optimisation slice, one entry per reference function ------------------------------------ */
@@ -230,7 +236,8 @@ typedef struct ldso_ba_batch ldso_ba_batch_t;
 int ldso_ba_batch_create(ldso_ba_t *const *handles, int n, ldso_ba_batch_t **out);
 int ldso_ba_batch_enqueue_gn(ldso_ba_batch_t *b, int first_iteration, int iters);
 int ldso_ba_batch_destroy(ldso_ba_batch_t *b);
-/* points per workgroup ldso_ba_batch_create gave the windows of the batch (0: their single-window chunking was kept; ldso_ba_batch_destroy restores it) */
+/* points per workgroup ldso_ba_batch_create gave the windows of the batch - since round 6 the AVERAGE, rounded: the cuts are uneven, ldso_ba_get_chunk_cuts has
+ * them - (0: their single-window chunking was kept; ldso_ba_batch_destroy restores it) */
 int ldso_ba_batch_chunk_points(ldso_ba_batch_t *b, int *points_per_workgroup);
 /* bench / profiling: average duration [us] of the batched k_linearize over `reps` back-to-back launches (HIP events on the batch's stream) */
 int ldso_ba_batch_time_linearize(ldso_ba_batch_t *b, int reps, double *avg_us);

@@ -260,6 +260,18 @@ class BA:
     def set_chunk_points(self, n):
         _chk(self.L.ldso_ba_set_chunk_points(self.h, C.c_int(n)))
 
+    def get_chunk_cuts(self):
+        """ends of the chunks in force (one past the last point of every chunk)"""
+        n = C.c_int()
+        _chk(self.L.ldso_ba_get_chunk_cuts(self.h, None, C.c_int(0), C.byref(n)))
+        ends = np.zeros(n.value, np.int32)
+        _chk(self.L.ldso_ba_get_chunk_cuts(self.h, _p(ends), C.c_int(len(ends)), C.byref(n)))
+        return ends
+
+    def set_chunk_cuts(self, ends):
+        ends = np.ascontiguousarray(ends, np.int32)
+        _chk(self.L.ldso_ba_set_chunk_cuts(self.h, _p(ends) if len(ends) else None, C.c_int(len(ends))))
+
     def get_chunk_points(self):
         n, w = C.c_int(), C.c_int()
         _chk(self.L.ldso_ba_get_chunk_points(self.h, C.byref(n), C.byref(w)))

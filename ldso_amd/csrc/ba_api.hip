@@ -35,7 +35,7 @@ hipError_t ba_launch_acc_init(const BaPtrs &B, const BaDims &D, const GnInit &gi
 hipError_t ba_launch_gn_export(const BaPtrs &B, const BaDims &D, const ResSet &S, double *tail, hipStream_t st);
 hipError_t ba_launch_activate(const BaPtrs &B, const BaDims &D, const ldso_settings_t &S, const ldso_immature_t *d_pts, ldso_activation_t *d_out, int n, int minObs,
                               float minIdepthH_act, int GNIts, hipStream_t st);
-hipError_t ba_launch_linearize_batch(const BatchItem *d_items, const BatchBlock *d_blocks, int totalChunks, int FS, int cur, const ldso_settings_t &S, int stepMode, float calibPrior, hipStream_t st, int itCheck = -1);
+hipError_t ba_launch_linearize_batch(const BatchItem *d_items, const BatchBlock *d_blocks, int totalChunks, const int32_t *d_wgStart, int nWG, int FS, int cur, const ldso_settings_t &S, int stepMode, float calibPrior, hipStream_t st, int itCheck = -1);
 hipError_t ba_launch_reduce_batch(const BatchItem *d_items, int nWin, int totalBlocks, int cur, float calibPrior, double l1, double il, hipStream_t st);
 hipError_t ba_launch_gn_solve_batch(const BatchItem *d_items, int nWin, const BaDims &Dmax, int cur, const ldso_settings_t &St, int iteration, double lambda, hipStream_t st);
 hipError_t ba_launch_lm_energies(const BaPtrs &B, const BaDims &D, const ResSet &S, float calibPrior, bool hasPrior, hipStream_t st);
@@ -94,6 +94,7 @@ struct ldso_ba {
     bool linHeadOk = false;            // the chunks are regular (every host cut into CH-point pieces): true for everything build_chunks produces
     const void *inBatch = nullptr;     // the ldso_ba_batch this handle belongs to (at most one; it must outlive the batch: ldso_ba_destroy refuses while set)
     int chunkPoints = 0;               // points per workgroup of k_linearize: 0 = as few as keep the grid within one wave of workgroups (one window alone on the chip)
+    std::vector<int32_t> chunkCuts;    // explicit chunk ends (ldso_ba_set_chunk_cuts / ldso_ba_batch_create: uneven chunks, one workload per workgroup); empty: regular chunks of chunkPoints
     BatchItem itemShadow;
     bool itemValid = false;
     int *h_stop = nullptr, *d_stop = nullptr;      // host-mapped word (and its device address): which iteration ended an un-forced optimize() loop
@@ -545,7 +546,10 @@ static int build_chunks(ldso_ba *H) {
     BaDims &D = H->D;
     // smallest multiple of 4 points per chunk that keeps the grid within one wave of workgroups (one per CU)
     int CH = 4;
-    if (H->chunkPoints > 0) CH = H->chunkPoints;      // ldso_ba_set_chunk_points / ldso_ba_batch_create: many windows share a launch, fewer and fatter workgroups
+    if (!H->chunkCuts.empty() && H->chunkCuts.back() != D.pEnd) H->chunkCuts.clear();          // cuts made for another window: back to the regular policy
+    const std::vector<int32_t> &cuts = H->chunkCuts;          // explicit ends (ascending): a chunk also ends at every host boundary
+    if (!cuts.empty()) CH = 1 << 30;
+    else if (H->chunkPoints > 0) CH = H->chunkPoints;      // ldso_ba_set_chunk_points / ldso_ba_batch_create: many windows share a launch, fewer and fatter workgroups
     else for (;; CH += 4) {
         int cnt = 0, run = 0, prev = -1;
         for (int q = D.pBegin; q < D.pEnd; q++) { int hq = H->h_phost[q]; if (hq != prev) { cnt += (run + CH - 1) / CH; run = 0; prev = hq; } run++; }
@@ -554,11 +558,14 @@ static int build_chunks(ldso_ba *H) {
     }
     std::vector<int32_t> p0, cn, ch, cs(D.F + 1, 0);
     int p = D.pBegin;
+    size_t ci = 0;
     for (int hst = 0; hst < D.F; hst++) {
         cs[hst] = (int) p0.size();
         while (p < D.pEnd && H->h_phost[p] == hst) {
             int e = p;
-            while (e < D.pEnd && H->h_phost[e] == hst && e - p < CH) e++;
+            while (ci < cuts.size() && cuts[ci] <= p) ci++;
+            const int stop = ci < cuts.size() ? cuts[ci] : D.pEnd;
+            while (e < D.pEnd && H->h_phost[e] == hst && e - p < CH && e < stop) e++;
             p0.push_back(p); cn.push_back(e - p); ch.push_back(hst);
             p = e;
         }
@@ -1019,6 +1026,22 @@ int ldso_ba_set_chunk_points(ldso_ba_t *H, int points_per_workgroup) {
     REQ(H && points_per_workgroup >= 0 && points_per_workgroup % 4 == 0 && points_per_workgroup <= 1024, "ldso_ba_set_chunk_points: 0 or a multiple of 4 up to 1024");
     REQ(!H->pendingApply, "ldso_ba_set_chunk_points: a linearisation is pending (ldso_ba_apply_res first)");
     H->chunkPoints = points_per_workgroup;
+    if (H->D.P > 0) { CHK(hipSetDevice(H->device)); return rechunk(H); }
+    return LDSO_OK;
+}
+int ldso_ba_get_chunk_cuts(ldso_ba_t *H, int32_t *ends, int cap, int *n_out) {
+    REQ(H && n_out && H->D.P > 0, "ldso_ba_get_chunk_cuts: bad arguments / no window");
+    const int n = (int) H->h_blocks.size();
+    *n_out = n;
+    if (ends) { REQ(cap >= n, "ldso_ba_get_chunk_cuts: buffer too small"); for (int i = 0; i < n; i++) ends[i] = H->h_blocks[i].p0 + H->h_blocks[i].np; }
+    return LDSO_OK;
+}
+int ldso_ba_set_chunk_cuts(ldso_ba_t *H, const int32_t *ends, int n) {
+    REQ(H && n >= 0 && (n == 0 || ends), "ldso_ba_set_chunk_cuts: bad arguments");
+    REQ(!H->pendingApply, "ldso_ba_set_chunk_cuts: a linearisation is pending (ldso_ba_apply_res first)");
+    REQ(H->inBatch == nullptr, "ldso_ba_set_chunk_cuts: the handle belongs to a batch (its chunks are the batch's)");
+    for (int i = 0; i < n; i++) REQ(ends[i] > (i ? ends[i - 1] : 0) && ends[i] <= (H->D.P > 0 ? H->D.P : H->maxP), "ldso_ba_set_chunk_cuts: ends must ascend and stay inside the window");
+    H->chunkCuts.assign(ends, ends + n);
     if (H->D.P > 0) { CHK(hipSetDevice(H->device)); return rechunk(H); }
     return LDSO_OK;
 }
@@ -1621,6 +1644,13 @@ struct ldso_ba_batch {
     int totalChunks = 0, totalReduce = 0, FS = 0, cur = 0;
     int n0 = 0;                        // windows in the first half (= all of them for batches under 4 windows)
     int halfChunks[2] = {0, 0}, halfReduce[2] = {0, 0};
+    // Balanced launches (round 6): workgroup w of a batched k_linearize works through the blocks [wgStart[w], wgStart[w + 1]) of its launch's table, cut by
+    // ldso_ba_batch_create so that every workgroup carries the same load.  wg[0] = the whole batch, wg[1] / wg[2] = the halves; empty: one block per workgroup
+    std::vector<int32_t> wg[3];
+    int32_t *d_wg = nullptr; size_t wgCap = 0;
+    std::vector<int32_t> wgHost;       // what d_wg holds (kept: the copy is asynchronous)
+    int nWG[3] = {0, 0, 0}; size_t wgOff[3] = {0, 0, 0};
+    bool balanced = false;
     hipStream_t aux = nullptr;         // second stream: the two halves run half an iteration apart
     hipEvent_t ev0 = nullptr, ev1 = nullptr, evEnd = nullptr;
     BaDims Dmax;
@@ -1655,13 +1685,73 @@ static int batch_refresh(ldso_ba_batch *Bt) {
         CHK(hipStreamSynchronize(H0->stream));
         if (Bt->aux) CHK(hipStreamSynchronize(Bt->aux));
         if (Bt->d_blocks) hipFree(Bt->d_blocks);
+    if (Bt->d_wg) hipFree(Bt->d_wg);
         Bt->d_blocks = nullptr; Bt->blocksCap = 0;
         void *q = nullptr;
         CHK(hipMalloc(&q, Bt->blocks.size() * sizeof(BatchBlock)));
         Bt->d_blocks = (BatchBlock *) q; Bt->blocksCap = Bt->blocks.size();
     }
     CHK(hipMemcpyAsync(Bt->d_blocks, Bt->blocks.data(), Bt->blocks.size() * sizeof(BatchBlock), hipMemcpyHostToDevice, H0->stream));
+    if (Bt->balanced) {
+        // the per-workgroup block ranges of the three launches (whole batch | half A | half B), valid while the windows keep the chunks ldso_ba_batch_create cut
+        bool ok = (int) Bt->wg[0].size() >= 2 && Bt->wg[0].back() == Bt->totalChunks && Bt->wg[1].back() == Bt->halfChunks[0] && (Bt->halfChunks[1] == 0 || Bt->wg[2].back() == Bt->halfChunks[1]);
+        REQ(ok, "ldso_ba_batch: the windows of the batch were re-chunked behind its back (ldso_ba_set_window / ldso_ba_set_chunk_points on a member): destroy and re-create the batch");
+        std::vector<int32_t> all;
+        for (int u = 0; u < 3; u++) { Bt->wgOff[u] = all.size(); Bt->nWG[u] = Bt->wg[u].empty() ? 0 : (int) Bt->wg[u].size() - 1; all.insert(all.end(), Bt->wg[u].begin(), Bt->wg[u].end()); }
+        if (all.size() > Bt->wgCap) {
+            CHK(hipStreamSynchronize(H0->stream));
+            if (Bt->aux) CHK(hipStreamSynchronize(Bt->aux));
+            if (Bt->d_wg) hipFree(Bt->d_wg);
+            Bt->d_wg = nullptr; Bt->wgCap = 0;
+            void *q = nullptr;
+            CHK(hipMalloc(&q, all.size() * sizeof(int32_t)));
+            Bt->d_wg = (int32_t *) q; Bt->wgCap = all.size();
+        }
+        Bt->wgHost.swap(all);
+        CHK(hipMemcpyAsync(Bt->d_wg, Bt->wgHost.data(), Bt->wgHost.size() * sizeof(int32_t), hipMemcpyHostToDevice, H0->stream));
+    }
     return LDSO_OK;
+}
+
+// Cut the windows [i0, i1) of a batch into chunks so that `nWG` workgroups, each working through a run of consecutive chunks, carry the same load.  A chunk
+// (= one pass of linearize_body: operand staging, software-pipeline fill, block reduction) costs `c0` point-equivalents on top of its points, and never
+// straddles a host frame.  The smallest per-workgroup budget that fits all points into nWG workgroups is found by bisection; cuts[i] receives the chunk ends
+// of window i, wg the first chunk of every workgroup (nWG + 1 entries, counted over the windows [i0, i1) in order).
+static void balance_batch(ldso_ba *const *handles, int i0, int i1, int nWG, int c0, std::vector<std::vector<int32_t>> &cuts, std::vector<int32_t> &wg) {
+    struct Seg { int win, p0, n; };
+    std::vector<Seg> segs;
+    long total = 0;
+    for (int i = i0; i < i1; i++) {
+        const ldso_ba *H = handles[i];
+        int p = 0;
+        while (p < H->D.P) { int e = p; while (e < H->D.P && H->h_phost[e] == H->h_phost[p]) e++; segs.push_back(Seg{i, p, e - p}); total += e - p; p = e; }
+    }
+    auto run = [&](long budget, bool emit) -> bool {
+        size_t si = 0; int used = 0;          // points of segs[si] already handed out
+        int blocks = 0;
+        if (emit) { wg.assign(1, 0); for (int i = i0; i < i1; i++) cuts[i].clear(); }
+        for (int w = 0; w < nWG && si < segs.size(); w++) {
+            long left = budget;
+            while (si < segs.size()) {
+                const int rem = segs[si].n - used;
+                long can = left - c0;
+                if (can < LD_WAVES && left != budget) break;          // not worth a chunk of its own here: the next workgroup takes it
+                if (can < 1) can = 1;
+                int take = (int) std::min<long>(rem, can);
+                if (take < rem) { take = std::max(take / LD_WAVES * LD_WAVES, 1); if (rem - take < LD_WAVES) take = rem; }          // whole rounds of the workgroup's wavefronts, no crumbs left behind
+                if (emit) cuts[segs[si].win].push_back(segs[si].p0 + used + take);
+                blocks++; left -= c0 + take; used += take;
+                if (used == segs[si].n) { si++; used = 0; }
+                if (left <= 0) break;
+            }
+            if (emit) wg.push_back(blocks);
+        }
+        if (emit) while ((int) wg.size() < nWG + 1) wg.push_back(blocks);
+        return si == segs.size();
+    };
+    long lo = total / nWG, hi = total + (long) c0 * (long) segs.size() + 1;
+    while (lo < hi) { const long mid = (lo + hi) / 2; if (run(mid, false)) hi = mid; else lo = mid + 1; }
+    run(lo, true);
 }
 
 int ldso_ba_batch_create(ldso_ba_t *const *handles, int n, ldso_ba_batch_t **out) {
@@ -1687,25 +1777,53 @@ int ldso_ba_batch_create(ldso_ba_t *const *handles, int n, ldso_ba_batch_t **out
     // costs - operand staging, block reduction, ~4.5 us - are then a fraction of its life) while the grid still holds a few workgroups
     // per CU for balance.  Handles with an explicit ldso_ba_set_chunk_points keep theirs.
     int Bt_chunk = 0;
+    bool balanced = false;
+    std::vector<int32_t> wgTab[3];
     {
         long total = 0;
         for (int i = 0; i < n; i++) total += handles[i]->D.P;
-        int ppw = (int) (total / ((long) H0->numCU * LD_WAVES));               // points per wavefront slot of the chip, capped at 6 (round 3, capped at 4: 338 / 259 / 216 / 221 / 217 us per
-                                                                                 // launch of 32 C3 windows at 1 / 2 / 4 / 6 / 8 points per wavefront; 84 / 65 / 54 / 70 / 70 us for 8 windows)
-        if (const char *e = getenv("LDSO_BATCH_PPW")) { if (*e) ppw = atoi(e); }             // kernel experiments
-        ppw = ppw < 1 ? 1 : ppw > 8 ? 8 : ppw;
-        if (!getenv("LDSO_BATCH_PPW") && ppw > 6) ppw = 6;          // round 4 (record-layout kernel, k_reduce_batch_dense at 4 workgroups per CU), B = 32: 122.0 / 139.3 / 128.6 k window-iterations/s at 4 / 6 / 8
-        const int CH = ppw * LD_WAVES;
-        Bt_chunk = ppw > 1 ? CH : 0;
-        for (int i = 0; i < n; i++) if (handles[i]->chunkPoints == 0 && ppw > 1) {      // ppw == 1: the single-window chunking already is the right one
-            handles[i]->chunkPoints = CH;
-            const int r_ = rechunk(handles[i]);
-            handles[i]->chunkPoints = 0;                                         // the policy stays "automatic": the next ldso_ba_set_window re-chunks for a single window
-            if (r_ != LDSO_OK) { for (int k = 0; k <= i; k++) rechunk(handles[k]); return r_; }      // leave nobody with the batch's chunks
+        int ppw = (int) (total / ((long) H0->numCU * LD_WAVES));               // points per wavefront slot of the chip
+        const char *e = getenv("LDSO_BATCH_PPW");                              // kernel experiments: the regular chunks of rounds 3-5 with this many points per wavefront
+        bool every = true;
+        for (int i = 0; i < n; i++) every = every && handles[i]->chunkPoints == 0 && handles[i]->chunkCuts.empty();
+        if (ppw > 1 && every && !(e && *e)) {
+            // Round 6: every workgroup of a launch gets the SAME load.  With regular chunks the batched launch ran as ceil(chunks / CUs) rounds of equal
+            // workgroups - 1344 on 256 CUs: the last round a quarter full - and every chunk paid its fixed costs (staging, pipeline fill, block reduction:
+            // about two points per wavefront) for six points per wavefront.  Now one workgroup per CU and launch works through a run of chunks cut to measure.
+            const int n0 = (n >= 4) ? n / 2 : n, c0 = 2 * LD_WAVES;
+            std::vector<std::vector<int32_t>> cuts((size_t) n);
+            balance_batch(handles, 0, n0, H0->numCU, c0, cuts, wgTab[1]);
+            if (n0 < n) balance_batch(handles, n0, n, H0->numCU, c0, cuts, wgTab[2]);
+            // the whole-batch launch (ldso_ba_batch_time_linearize) runs the two halves' workgroups one after the other
+            wgTab[0] = wgTab[1];
+            if (n0 < n) for (size_t u = 1; u < wgTab[2].size(); u++) wgTab[0].push_back(wgTab[1].back() + wgTab[2][u]);
+            for (int i = 0; i < n; i++) {
+                handles[i]->chunkCuts = cuts[i];
+                const int r_ = rechunk(handles[i]);
+                if (r_ != LDSO_OK) { for (int k = 0; k <= i; k++) { handles[k]->chunkCuts.clear(); rechunk(handles[k]); } return r_; }      // leave nobody with the batch's chunks
+            }
+            long chunks = 0;
+            for (int i = 0; i < n; i++) chunks += handles[i]->D.nChunks;
+            Bt_chunk = (int) std::max<long>(1, (total + chunks / 2) / chunks);
+            balanced = true;
+        } else {
+            if (e && *e) ppw = atoi(e);
+            ppw = ppw < 1 ? 1 : ppw > 8 ? 8 : ppw;
+            if (!(e && *e) && ppw > 6) ppw = 6;
+            const int CH = ppw * LD_WAVES;
+            Bt_chunk = ppw > 1 ? CH : 0;
+            for (int i = 0; i < n; i++) if (handles[i]->chunkPoints == 0 && handles[i]->chunkCuts.empty() && ppw > 1) {      // ppw == 1: the single-window chunking already is the right one
+                handles[i]->chunkPoints = CH;
+                const int r_ = rechunk(handles[i]);
+                handles[i]->chunkPoints = 0;                                         // the policy stays "automatic": the next ldso_ba_set_window re-chunks for a single window
+                if (r_ != LDSO_OK) { for (int k = 0; k <= i; k++) rechunk(handles[k]); return r_; }      // leave nobody with the batch's chunks
+            }
         }
     }
     ldso_ba_batch *Bt = new ldso_ba_batch();
     Bt->chunkPoints = Bt_chunk;
+    Bt->balanced = balanced;
+    for (int u = 0; u < 3; u++) Bt->wg[u] = wgTab[u];
     Bt->h.assign(handles, handles + n);
     Bt->items.resize(2 * (size_t) n);
     Bt->n0 = (n >= 4) ? n / 2 : n;
@@ -1744,8 +1862,10 @@ int ldso_ba_batch_destroy(ldso_ba_batch_t *Bt) {
     if (Bt->evEnd) hipEventDestroy(Bt->evEnd);
     if (Bt->d_items) hipFree(Bt->d_items);
     if (Bt->d_blocks) hipFree(Bt->d_blocks);
+    if (Bt->d_wg) hipFree(Bt->d_wg);
     // back to the single-window chunking (handles that were re-chunked by ldso_ba_batch_create)
-    if (Bt->chunkPoints > 0) for (ldso_ba *H : Bt->h) if (H->chunkPoints == 0 && H->D.P > 0) rechunk(H);
+    if (Bt->balanced) { for (ldso_ba *H : Bt->h) { H->chunkCuts.clear(); if (H->D.P > 0) rechunk(H); } }
+    else if (Bt->chunkPoints > 0) for (ldso_ba *H : Bt->h) if (H->chunkPoints == 0 && H->D.P > 0) rechunk(H);
     for (ldso_ba *H : Bt->h) if (H->inBatch == Bt) H->inBatch = nullptr;
     delete Bt;
     return LDSO_OK;
@@ -1774,11 +1894,11 @@ int ldso_ba_batch_enqueue_gn(ldso_ba_batch_t *Bt, int first_iteration, int iters
         CHK(ba_launch_reduce_batch(itA, n0, Bt->halfReduce[0], cur, H0->settings.initialCalibHessian, l1, il, H0->stream));
         CHK(ba_launch_gn_solve_batch(itA, n0, Bt->Dmax, cur, H0->settings, first_iteration + i, 1e-1, H0->stream));
         if (n1 > 0 && i == 0) { CHK(hipEventRecord(Bt->ev1, H0->stream)); CHK(hipStreamWaitEvent(Bt->aux, Bt->ev1, 0)); }
-        CHK(ba_launch_linearize_batch(itA, Bt->d_blocks + Bt->totalChunks, Bt->halfChunks[0], Bt->FS, cur, H0->settings, 1, H0->settings.initialCalibHessian, H0->stream));
+        CHK(ba_launch_linearize_batch(itA, Bt->d_blocks + Bt->totalChunks, Bt->halfChunks[0], Bt->balanced ? Bt->d_wg + Bt->wgOff[1] : nullptr, Bt->nWG[1], Bt->FS, cur, H0->settings, 1, H0->settings.initialCalibHessian, H0->stream));
         if (n1 > 0) {
             CHK(ba_launch_reduce_batch(itB, n1, Bt->halfReduce[1], cur, H0->settings.initialCalibHessian, l1, il, Bt->aux));
             CHK(ba_launch_gn_solve_batch(itB, n1, Bt->Dmax, cur, H0->settings, first_iteration + i, 1e-1, Bt->aux));
-            CHK(ba_launch_linearize_batch(itB, Bt->d_blocks + Bt->totalChunks + Bt->halfChunks[0], Bt->halfChunks[1], Bt->FS, cur, H0->settings, 1, H0->settings.initialCalibHessian, Bt->aux));
+            CHK(ba_launch_linearize_batch(itB, Bt->d_blocks + Bt->totalChunks + Bt->halfChunks[0], Bt->halfChunks[1], Bt->balanced ? Bt->d_wg + Bt->wgOff[2] : nullptr, Bt->nWG[2], Bt->FS, cur, H0->settings, 1, H0->settings.initialCalibHessian, Bt->aux));
         }
         cur ^= 1;
     }
@@ -1796,9 +1916,9 @@ int ldso_ba_batch_time_linearize(ldso_ba_batch_t *Bt, int reps, double *avg_us) 
     RUN(batch_refresh(Bt));
     hipEvent_t a, b;
     CHK(hipEventCreate(&a)); CHK(hipEventCreate(&b));
-    CHK(ba_launch_linearize_batch(Bt->d_items, Bt->d_blocks, Bt->totalChunks, Bt->FS, H0->cur, H0->settings, 0, H0->settings.initialCalibHessian, H0->stream));
+    CHK(ba_launch_linearize_batch(Bt->d_items, Bt->d_blocks, Bt->totalChunks, Bt->balanced ? Bt->d_wg + Bt->wgOff[0] : nullptr, Bt->nWG[0], Bt->FS, H0->cur, H0->settings, 0, H0->settings.initialCalibHessian, H0->stream));
     CHK(hipEventRecord(a, H0->stream));
-    for (int i = 0; i < reps; i++) CHK(ba_launch_linearize_batch(Bt->d_items, Bt->d_blocks, Bt->totalChunks, Bt->FS, H0->cur, H0->settings, 0, H0->settings.initialCalibHessian, H0->stream));
+    for (int i = 0; i < reps; i++) CHK(ba_launch_linearize_batch(Bt->d_items, Bt->d_blocks, Bt->totalChunks, Bt->balanced ? Bt->d_wg + Bt->wgOff[0] : nullptr, Bt->nWG[0], Bt->FS, H0->cur, H0->settings, 0, H0->settings.initialCalibHessian, H0->stream));
     CHK(hipEventRecord(b, H0->stream));
     CHK(hipEventSynchronize(b));
     float ms = 0;

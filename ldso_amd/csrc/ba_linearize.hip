@@ -21,6 +21,9 @@
 #include <type_traits>
 #include "ba_dev.h"
 
+#ifndef LD_LDG_PLAIN
+#define LD_LDG_PLAIN 0
+#endif
 #ifndef LD_PIPE_ARGS
 #define LD_PIPE_ARGS 1          // the argument-based kernels (fix / linearised / marginalisation / dump passes) up to 8 key frames run the software pipeline too
 #endif
@@ -100,6 +103,9 @@ __device__ __forceinline__ float sum_slots(float x, int a16, int a32) {
 typedef int v16i_t __attribute__((ext_vector_type(16)));
 template <bool DESC, int OFF> static __device__ __forceinline__ v16i_t ldg16(const void *base) {
     v16i_t t;
+#if LD_LDG_PLAIN
+    if (DESC) return *(const __attribute__((address_space(4))) v16i_t *) ((unsigned long long) base + OFF);          // experiment: the compiler's own scalar load, free to be hoisted / merged
+#endif
     if (DESC) asm volatile("s_load_dwordx16 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : "s"(base), "n"(OFF) : "memory");
     else __builtin_memcpy(&t, (const char *) base + OFF, 64);          // kernel arguments: the compiler's own scalar loads
     return t;
@@ -236,14 +242,18 @@ struct PtStep { float idp, idz; };
 // The body is shared by k_linearize (one window: everything arrives as kernel arguments, i.e. in scalar registers) and
 // k_linearize_batch (many independent windows per launch: the descriptors live in device memory).  chunk = index of the
 // workgroup's chunk inside ITS window, gridBlocks = workgroups of that window (partition of the accumulator initialisation).
-template <int NSG, bool HAS_L, bool FIX, bool MARG, bool DESC>
+template <int NSG, bool HAS_L, bool FIX, bool MARG, bool DESC, bool ONE = false>
 static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaDims &D, const ResSet &cur, const ResSet &nxt, const ldso_settings_t &S, const int stepMode,
                                                       const GnInit &gi, const int32_t *__restrict__ margFlags, const int chunk, const int gridBlocks,
                                                       const int p0, const int np, const int h) {
     if (LD_ITER_SKIPPED(B, gi.itCheck)) return;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int FS = D.FS, F = D.F;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, s = lane >> 3, k = lane & 7;
+    // (opaque to the compiler: inside the batched kernel's loop over the blocks of a workgroup everything derived from the lane index is loop-invariant, and hoisted
+    // out of that loop it stays live through the point loop - 24 VGPRs, measured: 184 -> 208, and with them the CU sharing with the other half-batch's reduce kernel)
+    int tid_ = (int) threadIdx.x;
+    asm volatile("" : "+v"(tid_));
+    const int tid = tid_, wave = tid >> 6, lane = tid & 63, s = lane >> 3, k = lane & 7;
     const long long t0_ = wall_clock64();
 #define LSTAMP(i) do { if (LD_STAMP_ON && chunk == 0 && tid == 0) B.energyLog[8 + (i)] = (double) (wall_clock64() - t0_); } while (0)
 
@@ -828,13 +838,21 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
         constexpr bool PIPE = DESC || (NSG == 1 && LD_PIPE_ARGS);
         PtStep sa = {0, 0}, sb = {0, 0};
         TapsG ta = {}, tb = {};
+#if LD_STAMP_ON
+        // cycle accounting of the pipelined loop (wave 0 of chunk 0 -> energyLog[24 + i]): shader-clock cycles per phase, summed over the wave's points
+        long long cy_[6] = {0, 0, 0, 0, 0, 0}, ct_ = 0;
+#define LCYC(i) do { const long long n_ = (long long) __builtin_readcyclecounter(); if ((i) > 0) cy_[i] += n_ - ct_; ct_ = n_; cy_[5] += ((i) == 0); } while (0)
+#else
+#define LCYC(i) do { } while (0)
+#endif
         // The loads of the pipeline are issued UNCONDITIONALLY (behind the last point of the wavefront they re-read that point, nobody uses the result): the
         // memory counter of a wavefront is in order, so a load can only be waited for precisely (vmcnt(N), N = operations issued behind it) when the compiler
         // can COUNT what is issued behind it - a load or store under a branch counts as zero, and the first version of this loop (loads under `if (next point
         // exists)`) waited with vmcnt(0) for everything in flight in front of every use: no overlap at all (r6 call 1: 219 -> 207 us for the batch).
         if (pi < np) {
             sa = pstep((unsigned) (p0 + pi), qa); front_g(G0{}, qa, sa, ta);
-            if (DESC && PIPE && np <= LD_WAVES) {          // (the argument-based kernels keep one copy of the point's code: with two they spill)
+            if (ONE && PIPE && np <= LD_WAVES) {          // (k_linearize_one only: the argument-based kernels spill with two copies of the point's code, and the batched kernel
+                                                          // must stay below 192 VGPRs - it shares its CUs with the other half-batch's k_reduce_batch_dense, 128 VGPRs at 4 wavefronts per SIMD)
                 // one point per wavefront (a single window spread over the whole chip, C3): nothing to overlap it with - the point straight through, without
                 // the pipeline's look-ahead loads (measured with them: 13.5 -> 14.7 us at C3); above 8 key frames both slot groups' taps are in flight together
                 const unsigned p = (unsigned) (p0 + pi);
@@ -861,12 +879,20 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
                     back_g(G1{}, p, qa, ta);
                     back_end(p, qa);
                 } else if constexpr (NSG == 1) {
+                    LCYC(0);
                     if (n1) sb = pstep(p1, qb);          // (the fused point step stores: only for a real next point)
                     front_g(G0{}, qb, sb, tb);
+                    LCYC(1);          // point step + projection + tap issue of the next point
                     load_point<NSG, HAS_L, FIX, DESC>(qc, B, cur, FS, p2, s, k, lane);
+                    LCYC(2);          // record loads issued
                     back_begin(p, qa, sa);
                     back_g(G0{}, p, qa, ta);
                     back_end(p, qa);
+                    LCYC(3);          // everything behind the taps of this point
+#if LD_STAMP_ON
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+                    LCYC(4);          // what is still in flight at the end of the iteration (stamps build only: waits for the stores too)
                     ta = tb;
                 } else {
                     front_g(G1{}, qa, sa, tb);
@@ -883,6 +909,9 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
             } while (pi < np);
             }
         }
+#if LD_STAMP_ON
+        if (chunk == 0 && tid == 0) for (int u = 0; u < 6; u++) B.energyLog[24 + u] = (double) cy_[u];
+#endif
     }   // points of this wave
 
     LSTAMP(6);
@@ -950,12 +979,20 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize(BaPtrs B, BaDims D,
 // launch.  Workgroup -> window by the prefix of chunk counts (items[w].linBlock0); `cur` = which residual set is the applied one
 // (all windows of a batch iterate in lockstep).
 template <int NSG>
-__global__ __launch_bounds__(64 * LD_WAVES) void k_linearize_batch(const BatchItem *__restrict__ items, const BatchBlock *__restrict__ blocks, int cur, ldso_settings_t S, int stepMode,
-                                                                   float calibPrior, int itCheck) {
-    const BatchBlock bb = blocks[blockIdx.x];                   // one scalar 16-byte load: window, first point, point count, host | chunk
-    const BatchItem &it = items[bb.win];
-    GnInit gi; gi.enable = 1; gi.hasPrior = it.hasPrior; gi.calibPrior = calibPrior; gi.itCheck = itCheck;
-    linearize_body<NSG, false, false, false, true>(it.B, it.D, it.set[cur], it.set[cur ^ 1], S, stepMode, gi, nullptr, bb.host_chunk >> 8, it.D.nChunks, bb.p0, bb.np, bb.host_chunk & 0xFF);
+__global__ __launch_bounds__(64 * LD_WAVES) void k_linearize_batch(const BatchItem *__restrict__ items, const BatchBlock *__restrict__ blocks, const int32_t *__restrict__ wgStart, int cur,
+                                                                   ldso_settings_t S, int stepMode, float calibPrior, int itCheck) {
+    // wgStart != nullptr (round 6): this workgroup works through the blocks [wgStart[w], wgStart[w + 1]) - ldso_ba_batch_create cut the windows so that every
+    // workgroup of the launch (one per CU) carries the same load; nullptr: one block per workgroup
+    int b0 = (int) blockIdx.x, b1 = b0 + 1;
+    if (wgStart != nullptr) { b0 = wgStart[blockIdx.x]; b1 = wgStart[blockIdx.x + 1]; }
+#pragma clang loop unroll(disable)
+    for (int b = b0; b < b1; b++) {
+        const BatchBlock bb = blocks[b];                            // one scalar 16-byte load: window, first point, point count, host | chunk
+        const BatchItem &it = items[bb.win];
+        GnInit gi; gi.enable = 1; gi.hasPrior = it.hasPrior; gi.calibPrior = calibPrior; gi.itCheck = itCheck;
+        linearize_body<NSG, false, false, false, true>(it.B, it.D, it.set[cur], it.set[cur ^ 1], S, stepMode, gi, nullptr, bb.host_chunk >> 8, it.D.nChunks, bb.p0, bb.np, bb.host_chunk & 0xFF);
+        __syncthreads();                                            // the next block re-uses the operand / reduction LDS
+    }
 }
 
 // The GN-iteration linearisation of ONE window with everything a workgroup needs before its first operand load in the KERNEL ARGUMENTS: the whole
@@ -981,7 +1018,7 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize_one(OneArgs a) {
 #pragma unroll
     for (int i = 0; i < LD_MAXF; i++) { const bool m = (i == h); c0 = m ? hd.cs[i] : c0; q0 = m ? hd.hostP0[i] : q0; q1 = m ? hd.hostP0[i + 1] : q1; }
     const int p0 = q0 + (chunk - c0) * hd.CH, np = min(hd.CH, q1 - p0);
-    linearize_body<NSG, false, false, false, true>(A.B, A.D, A.cur, A.nxt, a.S, a.stepMode, a.gi, nullptr, chunk, (int) gridDim.x, p0, np, h);
+    linearize_body<NSG, false, false, false, true, true>(A.B, A.D, A.cur, A.nxt, a.S, a.stepMode, a.gi, nullptr, chunk, (int) gridDim.x, p0, np, h);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1039,15 +1076,18 @@ hipError_t ba_launch_linearize_marg(const BaPtrs &B, const BaDims &D, const ResS
     return launch_one<2, false, false, true>(B, D, cur, nxt, S, 0, gi, st, margFlags);
 }
 
-hipError_t ba_launch_linearize_batch(const BatchItem *d_items, const BatchBlock *d_blocks, int totalChunks, int FS, int cur, const ldso_settings_t &S, int stepMode, float calibPrior, hipStream_t st, int itCheck) {
+hipError_t ba_launch_linearize_batch(const BatchItem *d_items, const BatchBlock *d_blocks, int totalChunks, const int32_t *d_wgStart, int nWG, int FS, int cur, const ldso_settings_t &S, int stepMode,
+                                     float calibPrior, hipStream_t st, int itCheck) {
     if (totalChunks == 0) return hipSuccess;
     const size_t lds = ba_linearize_lds_bytes(FS, false);
+    const int grid = d_wgStart != nullptr ? nWG : totalChunks;
+    if (grid <= 0) return hipSuccess;
     if (FS == 8) {
         if (lds > 48 * 1024) (void) hipFuncSetAttribute((const void *) k_linearize_batch<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-        hipLaunchKernelGGL(k_linearize_batch<1>, dim3(totalChunks), dim3(64 * LD_WAVES), lds, st, d_items, d_blocks, cur, S, stepMode, calibPrior, itCheck);
+        hipLaunchKernelGGL(k_linearize_batch<1>, dim3(grid), dim3(64 * LD_WAVES), lds, st, d_items, d_blocks, d_wgStart, cur, S, stepMode, calibPrior, itCheck);
     } else {
         if (lds > 48 * 1024) (void) hipFuncSetAttribute((const void *) k_linearize_batch<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-        hipLaunchKernelGGL(k_linearize_batch<2>, dim3(totalChunks), dim3(64 * LD_WAVES), lds, st, d_items, d_blocks, cur, S, stepMode, calibPrior, itCheck);
+        hipLaunchKernelGGL(k_linearize_batch<2>, dim3(grid), dim3(64 * LD_WAVES), lds, st, d_items, d_blocks, d_wgStart, cur, S, stepMode, calibPrior, itCheck);
     }
     return hipGetLastError();
 }

@@ -58,6 +58,8 @@ def lib_fast():
         L = C.CDLL(path)
         L.ref_create.restype = C.c_void_p
         L.ref_fs_time_optimize.restype = C.c_double
+        L.ref_fs_optimize.restype = C.c_float
+        L.ref_linearize_all.restype = C.c_double
         _LIB_FAST = L
     return _LIB_FAST
 
@@ -472,8 +474,11 @@ def make_images(color, levels):
 class RefTracker:
     """The reference's CoarseTracker (src/frontend/CoarseTracker.cc compiled unmodified), same inputs as pyoracle.OracleTracker."""
 
-    def __init__(self, w, h, levels, settings, calib):
-        self.L = lib()
+    def __init__(self, w, h, levels, settings, calib, fast=False):
+        # fast: the -O3 build of the same translation units (bench.py's tracker cpu_baseline: the reference's own CoarseTracker at its own optimisation level)
+        self.L = lib_fast() if fast else lib()
+        if self.L is None:
+            raise RuntimeError("oracle/_ref/libldso_ref_fast.so is not available on this host")
         self.L.ref_tr_create.restype = C.c_void_p
         self.levels = levels
         s = np.ascontiguousarray(settings); c = np.ascontiguousarray(calib)

@@ -496,11 +496,14 @@ def test_large_batch_is_rechunked_and_equals_solo_runs_under_the_same_chunking()
         g = binding.BA.from_window(w, stream=st); g.collect_active(); g.linearize_all(False); g.apply_res(); batch.append(g)
     b = binding.BABatch(batch)
     ch = b.chunk_points()
-    assert ch >= 16 and ch % 8 == 0, ch
+    assert ch >= 16, ch                                          # (the average: since round 6 the batch cuts its windows unevenly, one equal workload per workgroup)
+    cuts = [g.get_chunk_cuts() for g in batch]
+    assert all(c[-1] == 1750 and np.all(np.diff(c) > 0) for c in cuts)
+    assert len(set(len(c) for c in cuts)) > 1 or len(set(tuple(c) for c in cuts)) > 1, "windows at different places of the launch are cut differently"
     b.enqueue_gn(0, 4); b.sync(); torch.cuda.synchronize()
     for i in (0, 5, 11):
-        g = binding.BA.from_window(wins[i], stream=st); g.set_chunk_points(ch)
-        assert g.get_chunk_points()[0] == ch
+        g = binding.BA.from_window(wins[i], stream=st); g.set_chunk_cuts(cuts[i])
+        assert np.array_equal(g.get_chunk_cuts(), cuts[i])
         g.collect_active(); g.linearize_all(False); g.apply_res()
         g.set_debug_split_launch(True); g.enqueue_gn(0, 4); g.sync(); torch.cuda.synchronize()
         fs, fb = g.get_frames(), batch[i].get_frames()
