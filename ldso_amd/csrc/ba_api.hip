@@ -1790,10 +1790,17 @@ int ldso_ba_batch_create(ldso_ba_t *const *handles, int n, ldso_ba_batch_t **out
             // Round 6: every workgroup of a launch gets the SAME load.  With regular chunks the batched launch ran as ceil(chunks / CUs) rounds of equal
             // workgroups - 1344 on 256 CUs: the last round a quarter full - and every chunk paid its fixed costs (staging, pipeline fill, block reduction:
             // about two points per wavefront) for six points per wavefront.  Now one workgroup per CU and launch works through a run of chunks cut to measure.
-            const int n0 = (n >= 4) ? n / 2 : n, c0 = 2 * LD_WAVES;
+            int c0 = 2 * LD_WAVES;          // fixed cost of a chunk in points (two rounds of the workgroup's wavefronts)
+            if (const char *ec = getenv("LDSO_BATCH_C0")) { if (*ec) c0 = std::max(0, atoi(ec)); }          // kernel experiments
+            const int n0 = (n >= 4) ? n / 2 : n;
+            // A half-batch launch does not take every CU: the other half's k_reduce_batch_dense / k_gn_solve_batch run beside it (two streams), and a workgroup that
+            // owns its CU for the whole launch leaves them nothing to start on.  Measured (32 windows, MI355X): 128 / 192 / 208 / 224 / 240 / 256 workgroups per half
+            // -> 141.6 / 159.2 / 162.2 / 168.3 / 167.7 / 149.5 k window-iterations/s (profiles/r06_batch_sweeps.log).
+            int nWG = (n >= 4) ? std::max(1, H0->numCU * 7 / 8) : H0->numCU;
+            if (const char *ew = getenv("LDSO_BATCH_NWG")) { if (*ew) nWG = std::max(1, atoi(ew)); }          // kernel experiments
             std::vector<std::vector<int32_t>> cuts((size_t) n);
-            balance_batch(handles, 0, n0, H0->numCU, c0, cuts, wgTab[1]);
-            if (n0 < n) balance_batch(handles, n0, n, H0->numCU, c0, cuts, wgTab[2]);
+            balance_batch(handles, 0, n0, nWG, c0, cuts, wgTab[1]);
+            if (n0 < n) balance_batch(handles, n0, n, nWG, c0, cuts, wgTab[2]);
             // the whole-batch launch (ldso_ba_batch_time_linearize) runs the two halves' workgroups one after the other
             wgTab[0] = wgTab[1];
             if (n0 < n) for (size_t u = 1; u < wgTab[2].size(); u++) wgTab[0].push_back(wgTab[1].back() + wgTab[2][u]);

@@ -21,6 +21,9 @@
 #include <type_traits>
 #include "ba_dev.h"
 
+#ifndef LD_OPAQUE_K
+#define LD_OPAQUE_K 0          // experiment (round 6): masks derived from the lane index recomputed per point instead of kept in (spilled) SGPR pairs - 37 fewer vector instructions in the kernel and SLOWER (B = 32: 173 against 160 us, C5 44.2 against 43.1, one box): not used
+#endif
 #ifndef LD_LDG_PLAIN
 #define LD_LDG_PLAIN 0
 #endif
@@ -253,7 +256,8 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
     // out of that loop it stays live through the point loop - 24 VGPRs, measured: 184 -> 208, and with them the CU sharing with the other half-batch's reduce kernel)
     int tid_ = (int) threadIdx.x;
     asm volatile("" : "+v"(tid_));
-    const int tid = tid_, wave = tid >> 6, lane = tid & 63, s = lane >> 3, k = lane & 7;
+    const int tid = tid_, wave = tid >> 6, lane = tid & 63, s = lane >> 3, k = lane & 7, k_ = k, lane_ = lane;
+    (void) k_; (void) lane_;
     const long long t0_ = wall_clock64();
 #define LSTAMP(i) do { if (LD_STAMP_ON && chunk == 0 && tid == 0) B.energyLog[8 + (i)] = (double) (wall_clock64() - t0_); } while (0)
 
@@ -401,6 +405,9 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
     // ================= FRONT half, per slot group: pattern projection, tap loads ====================================================
     auto front_g = [&](auto gc, const PtIn<NSG> &q, const PtStep &ps, TapsG &T) {
         constexpr int g = decltype(gc)::value;
+#if LD_OPAQUE_K
+        int k = k_; asm volatile("" : "+v"(k));
+#endif
         const float pu = RLF(q.rgeo, GEO_U), pv = RLF(q.rgeo, GEO_V);
         const float idp = ps.idp;
         float l1, h1;
@@ -466,6 +473,9 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
 
     auto back_g = [&](auto gc, const unsigned p, const PtIn<NSG> &q, const TapsG &T) {
         constexpr int g = decltype(gc)::value;
+#if LD_OPAQUE_K
+        int k = k_; asm volatile("" : "+v"(k));
+#endif
         // the uniform scalars of the slot record sit in the m of lanes 3 (energy), 5 (state), 6 (activity) of its 8-lane group
         int qState[NSG], qActive[NSG];
         float qEnergy[NSG];
@@ -783,6 +793,9 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
 
     auto back_end = [&](const unsigned p, const PtIn<NSG> &q) {
         (void) q;
+#if LD_OPAQUE_K
+        int lane = lane_, k = k_; asm volatile("" : "+v"(lane), "+v"(k));
+#endif
         // ================= per-point Schur quantities (AccumulatedSCHessian.cc:9-31) =====================
         float HdiF = 0, bdSumF = 0, idH = 0;
         float Hc0 = HcdA0 + HcdL0, Hc1 = HcdA1 + HcdL1, Hc2 = HcdA2 + HcdL2, Hc3 = HcdA3 + HcdL3;
@@ -895,14 +908,22 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
                     LCYC(4);          // what is still in flight at the end of the iteration (stamps build only: waits for the stores too)
                     ta = tb;
                 } else {
+                    LCYC(0);
                     front_g(G1{}, qa, sa, tb);
                     back_begin(p, qa, sa);
                     back_g(G0{}, p, qa, ta);
+                    LCYC(1);          // second group's taps issued, first group worked through
                     if (n1) sb = pstep(p1, qb);
                     front_g(G0{}, qb, sb, ta);
                     load_point<NSG, HAS_L, FIX, DESC>(qc, B, cur, FS, p2, s, k, lane);
+                    LCYC(2);          // next point: step, first group's taps, records of the point behind it
                     back_g(G1{}, p, qa, tb);
                     back_end(p, qa);
+                    LCYC(3);          // second group + the point's Schur row
+#if LD_STAMP_ON
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+                    LCYC(4);
                 }
                 if constexpr (PIPE) { qa = qb; qb = qc; sa = sb; }
                 pi += LD_WAVES;

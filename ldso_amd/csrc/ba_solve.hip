@@ -495,11 +495,18 @@ static __device__ __forceinline__ void st2(double *p, double a, double b) { *(do
 //   NB  > 4: packed columns (column c holds rows c..M-1).
 #define LIX(i, c) ((NB == 4) ? ((c) * (M + 2) + (i)) : ((c) * M - (((c) * ((c) -1)) >> 1) + ((i) - (c))))
 
+// LD_MF7 = 1: the trailing update of the 112 x 112 system (9..13 key frames, C5) on the fp64 matrix cores like the 64 x 64 one (28 tiles, seven per wavefront, two
+// matrix rows per lane in phase 1).  Built, correct (24 GPU tests), and NOT faster: k_gn_solve 61.2 us with it, 61.2 without (round 6, one box) - a round of the
+// factorisation is 1.43 us of phase-1 issue, LDS round trips and the barrier either way (25 rounds = 36 us), the matrix cores only replace the cheapest part.
+#ifndef LD_MF7
+#define LD_MF7 0
+#endif
 static __host__ __device__ inline size_t solve_core_lds_doubles(int NB, int n) {
     size_t M = 16 * NB;
     size_t L = (NB == 4) ? M * (M + 2) : M * (M + 1) / 2;
     // NB == 4 (MFMA variant): two panel buffers [M][6] + per-wave private copies of F and G (4 waves x 2 x [64][4]) = 44 M
-    return L + 2 * (M + 8) /*D,Y*/ + (NB == 4 ? 46 : 30) * M /*F,G,panel (up to 8 columns, pitch 10)*/ + 2 * M /*scale,x*/ + 7 * (size_t) n + 16;
+    // (matrix-core variants, NB == 4 and NB == 7: two panel buffers [M][6] + per-wave private copies of F and G, 4 waves x 2 x [M][4], = 44 M)
+    return L + 2 * (M + 8) /*D,Y*/ + ((NB == 4 || (NB == 7 && LD_MF7)) ? 46 : 30) * M /*F,G,panel (up to 8 columns, pitch 10)*/ + 2 * M /*scale,x*/ + 7 * (size_t) n + 16;
 }
 
 // GN = true (k_gn_solve): the prologue also mirrors the frames / calibration (and, when they fit, the float
@@ -527,6 +534,9 @@ struct SolveIO {
 };
 
 typedef double __attribute__((ext_vector_type(4))) ld_d4;
+#ifndef LD_C7
+#define LD_C7 4          // columns per round of the 112 x 112 factorisation (VALU variant)
+#endif
 
 template <int NB, int C, bool GN, bool WAIT = false, bool MF = false>
 static __device__ __forceinline__ void solve_core(const BaPtrs &B, const BaDims &D, const ResSet &S, const ldso_settings_t &St, int iteration, double *sm, SolveIO &io) {
@@ -542,7 +552,7 @@ static __device__ __forceinline__ void solve_core(const BaPtrs &B, const BaDims 
     double *sFp = sY + M + 8;              // [M][CP]        (MF: panel buffer A)
     double *sGp = sFp + CP * M;            // [M][CP]        (MF: panel buffer B)
     double *sPn = sGp + CP * M;            // [M][CP]        (MF: per-wave copies of F, then of G: 2 x 4 x [64][4])
-    double *sSc = sPn + (MF ? 2 * 4 * 64 * 4 : CP * M);            // [M]
+    double *sSc = sPn + (MF ? 2 * 4 * M * 4 : CP * M);            // [M]
     double *sx = sSc + M;                  // [M]
     double *sNs = sx + M;                  // [7][n]
     const double *HF = B.sys + 3 * (n * n + n), *bF = HF + n * n;      // assembled by k_gather (step-wise path)
@@ -554,11 +564,27 @@ static __device__ __forceinline__ void solve_core(const BaPtrs &B, const BaDims 
     // MF (n + 1 <= 64): the trailing update runs on the fp64 matrix cores (v_mfma_f64_16x16x4_f64).  The ten 16x16 tiles of the lower
     // triangle live in MFMA accumulator layout, three slots per wavefront: lane l, register r of a slot <-> element
     // (16 ta + (l >> 4) + 4 r, 16 tb + (l & 15)) of tile (ta, tb); wave w holds (w,0) | (w+1,w... see the packed tables) - 15 = no tile.
-    static_assert(!MF || (NB == 4 && C == 4), "the MFMA variant is written for the 64x64 system, 4 columns per round");
+    static_assert(!MF || ((NB == 4 || NB == 7) && C == 4), "the MFMA variant is written for the 64x64 and the 112x112 system, 4 columns per round");
     const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int mta[3] = {(0x3210 >> (4 * wv)) & 15, (0xF321 >> (4 * wv)) & 15, (0xF332 >> (4 * wv)) & 15};
-    const int mtb[3] = {0, (0xF111 >> (4 * wv)) & 15, (0xF322 >> (4 * wv)) & 15};
-    ld_d4 Dv[3];
+    // NS tile slots per wavefront.  NB == 4: the hand-placed ten tiles (three slots; 15 = no tile).  NB == 7 (round 6, windows of 9..13 key frames - C5): the 28
+    // tiles of the lower triangle numbered column by column, wave w holds the tiles w, w + 4, w + 8, ... - as tile columns finish from the left every wave loses
+    // tiles at the same rate; RPL = 2 rows of the matrix per lane in phase 1 (112 rows on 64 lanes).
+    constexpr int NS = !MF ? 1 : (NB == 4 ? 3 : (NTILE + 3) / 4), RPL = (M + 63) / 64;
+    int mta[NS], mtb[NS];
+    if constexpr (MF && NB == 4) {
+        mta[0] = (0x3210 >> (4 * wv)) & 15; mta[1] = (0xF321 >> (4 * wv)) & 15; mta[2] = (0xF332 >> (4 * wv)) & 15;
+        mtb[0] = 0; mtb[1] = (0xF111 >> (4 * wv)) & 15; mtb[2] = (0xF322 >> (4 * wv)) & 15;
+    } else if constexpr (MF) {
+#pragma unroll
+        for (int s_ = 0; s_ < NS; s_++) {
+            const int t = wv + 4 * s_;          // tile number, column-major over the lower triangle: column b starts at b NB - b (b - 1) / 2
+            int b = 0;
+#pragma unroll
+            for (int q = 1; q < NB; q++) b += (t >= q * NB - (q * (q - 1)) / 2) ? 1 : 0;
+            mtb[s_] = b; mta[s_] = (t < NTILE) ? b + (t - (b * NB - (b * (b - 1)) / 2)) : 15;
+        }
+    } else { mta[0] = 15; mtb[0] = 0; }
+    ld_d4 Dv[NS];
     if (GN) { HF = B.acc; bF = HF + (size_t) n * n; }
 // branch-free (clamped offsets, masked values): bFinal follows HFinal in memory, so row n of the augmented system is HF[n*n + j].
 // Straight-line code matters here: in the fused kernel these loads are the first instructions after the wait (cold instruction cache).
@@ -584,12 +610,12 @@ _Pragma("unroll") \
 #define LD_LOAD_H_MF() do { \
         const int nn_ = n * n + n - 1; \
 _Pragma("unroll") \
-        for (int s_ = 0; s_ < 3; s_++) \
+        for (int s_ = 0; s_ < NS; s_++) \
 _Pragma("unroll") \
             for (int r = 0; r < 4; r++) { \
                 const int i = 16 * mta[s_] + (lane >> 4) + 4 * r, j = 16 * mtb[s_] + (lane & 15); \
                 const double q = HF[min(i * n + j, nn_)]; \
-                Dv[s_][r] = (mta[s_] < 4 && j < n && (!GN || j <= i) && i <= n) ? q : 0.0; \
+                Dv[s_][r] = (mta[s_] < NB && j < n && (!GN || j <= i) && i <= n) ? q : 0.0; \
             } \
         { const double q = HF[min(tid * n + tid, nn_)]; dS = (tid < n) ? q : 0.0; } \
     } while (0)
@@ -656,7 +682,7 @@ _Pragma("unroll") \
     if constexpr (MF) {
         __syncthreads();
 #pragma unroll
-        for (int s_ = 0; s_ < 3; s_++) {
+        for (int s_ = 0; s_ < NS; s_++) {
             const double sj = sSc[min(16 * mtb[s_] + (lane & 15), M - 1)];
 #pragma unroll
             for (int r = 0; r < 4; r++) {
@@ -665,10 +691,14 @@ _Pragma("unroll") \
                 Dv[s_][r] = si * Dv[s_][r] * sj;
             }
         }
-        // first panel (columns 0..3): the tiles of tile column 0 (slot 0 of every wave)
-        if ((lane & 15) < C) {
+        // first panel (columns 0..3): the tiles of tile column 0 (NB == 4: slot 0 of every wave)
 #pragma unroll
-            for (int r = 0; r < 4; r++) sFp[(16 * mta[0] + (lane >> 4) + 4 * r) * CP + (lane & 15)] = Dv[0][r];
+        for (int s_ = 0; s_ < NS; s_++) {
+            if (mta[s_] >= NB || mtb[s_] != 0) continue;          // uniform per wave
+            if ((lane & 15) < C) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) sFp[(16 * mta[s_] + (lane >> 4) + 4 * r) * CP + (lane & 15)] = Dv[s_][r];
+            }
         }
     } else {
         double sI[NB], sJ[NB];
@@ -706,9 +736,8 @@ _Pragma("unroll") \
         // MF: every wavefront replays phase 1 for all 64 rows (lane = row) - the four copies run side by side on the four SIMDs and
         // spare the hand-over of F / G through a workgroup barrier; the panel buffers alternate (one barrier per round)
         if (MF || tid < M) {
-            const int i = MF ? lane : tid;
             const double *sPr = MF ? (((k >> 2) & 1) ? sGp : sFp) : sPn;
-            double c[C][C], g[C], f[C], inv[C];
+            double c[C][C], inv[C];
 #pragma unroll
             for (int r = 0; r < C; r++)
 #pragma unroll
@@ -716,8 +745,15 @@ _Pragma("unroll") \
                     const double2 w = ld2(&sPr[(k + r) * CP + q2]);
                     c[r][q2] = w.x; if (q2 + 1 < C) c[r][q2 + 1] = w.y;
                 }
+            // this lane's row(s) of the panel: one (the row of the thread / of the lane), or - matrix-core variant above 64 rows - the rows lane and lane + 64
+            constexpr int NR = MF ? RPL : 1;
+            double g[NR][C], f[NR][C];
 #pragma unroll
-            for (int q2 = 0; q2 < C; q2 += 2) { const double2 w = ld2(&sPr[i * CP + q2]); g[q2] = w.x; g[q2 + 1] = w.y; }
+            for (int rr = 0; rr < NR; rr++) {
+                const int i = MF ? min(lane + 64 * rr, M - 1) : tid;
+#pragma unroll
+                for (int q2 = 0; q2 < C; q2 += 2) { const double2 w = ld2(&sPr[i * CP + q2]); g[rr][q2] = w.x; g[rr][q2 + 1] = w.y; }
+            }
             RCYC(0, true);          // panel in registers
             // l_r = c[r][q] / d_q once per pivot, every update ONE fma on it, this row's g decoupled from f: 38 fp64 instructions per round.  (Until round 4
             // every update was written as x -= (product of known values) * inv_q, which puts pivot d_{q+1} one fma behind the reciprocal of d_q but takes
@@ -733,45 +769,53 @@ _Pragma("unroll") \
                 for (int r = q + 1; r < C; r++) {
 #pragma unroll
                     for (int s_ = q + 1; s_ <= r; s_++) c[r][s_] = __builtin_fma(-l_[r], c[s_][q], c[r][s_]);
-                    g[r] = __builtin_fma(-g[q], l_[r], g[r]);
+#pragma unroll
+                    for (int rr = 0; rr < NR; rr++) g[rr][r] = __builtin_fma(-g[rr][q], l_[r], g[rr][r]);
                 }
             }
 #pragma unroll
-            for (int q = 0; q < C; q++) f[q] = g[q] * inv[q];
+            for (int rr = 0; rr < NR; rr++)
+#pragma unroll
+                for (int q = 0; q < C; q++) f[rr][q] = g[rr][q] * inv[q];
 #if LD_STAMP_ON
-            asm volatile("" :: "v"(f[C - 1]), "v"(g[C - 1]));
+            asm volatile("" :: "v"(f[0][C - 1]), "v"(g[0][C - 1]));
 #endif
             RCYC(1, false);         // 4 x 4 block and this row's multipliers issued
-            const bool below = (i >= k + C);
-            const bool rowOn = below && (i <= n), colOn = below && (i < n);
-            if constexpr (MF) {
-                double *Fw = sPn + wv * 256, *Gw = sPn + 1024 + wv * 256;       // this wave's own copies: [64 rows][4]
 #pragma unroll
-                for (int q2 = 0; q2 < C; q2 += 2) {
-                    st2(&Fw[i * 4 + q2], rowOn ? f[q2] : 0.0, rowOn ? f[q2 + 1] : 0.0);
-                    st2(&Gw[i * 4 + q2], colOn ? g[q2] : 0.0, colOn ? g[q2 + 1] : 0.0);
+            for (int rr = 0; rr < NR; rr++) {
+                const int i = MF ? lane + 64 * rr : tid;
+                if (MF && i >= M) continue;
+                const bool below = (i >= k + C);
+                const bool rowOn = below && (i <= n), colOn = below && (i < n);
+                if constexpr (MF) {
+                    double *Fw = sPn + wv * (M * 4), *Gw = sPn + 4 * M * 4 + wv * (M * 4);       // this wave's own copies: [M rows][4]
+#pragma unroll
+                    for (int q2 = 0; q2 < C; q2 += 2) {
+                        st2(&Fw[i * 4 + q2], rowOn ? f[rr][q2] : 0.0, rowOn ? f[rr][q2 + 1] : 0.0);
+                        st2(&Gw[i * 4 + q2], colOn ? g[rr][q2] : 0.0, colOn ? g[rr][q2 + 1] : 0.0);
+                    }
+                } else {
+#pragma unroll
+                    for (int q2 = 0; q2 < C; q2 += 2) {
+                        st2(&sFp[i * CP + q2], rowOn ? f[rr][q2] : 0.0, rowOn ? f[rr][q2 + 1] : 0.0);
+                        st2(&sGp[i * CP + q2], colOn ? g[rr][q2] : 0.0, colOn ? g[rr][q2 + 1] : 0.0);
+                    }
                 }
-            } else {
+                // L, y, D are stored once (MF: by wave 3 - it holds ONE tile, wave 0 holds three for the longest and is the wave the round's barrier waits for:
+                // 36.9 -> 35.6 us per iteration at C3, A/B x 3 on one box, profiles/r05_call0_solve_variants.log; skipping phase 1 in waves without a live tile was slower)
+                const bool keeper = !MF || wv == 3;
+                if (keeper && i > k && i < n) {       // L[i][k+q] for the rows of the pivot block (q < i-k) and all rows below it
 #pragma unroll
-                for (int q2 = 0; q2 < C; q2 += 2) {
-                    st2(&sFp[i * CP + q2], rowOn ? f[q2] : 0.0, rowOn ? f[q2 + 1] : 0.0);
-                    st2(&sGp[i * CP + q2], colOn ? g[q2] : 0.0, colOn ? g[q2 + 1] : 0.0);
+                    for (int q = 0; q < C; q++) if (i > k + q) sL[LIX(i, k + q)] = f[rr][q];
                 }
-            }
-            // L, y, D are stored once (MF: by wave 3 - it holds ONE tile, wave 0 holds three for the longest and is the wave the round's barrier waits for:
-            // 36.9 -> 35.6 us per iteration at C3, A/B x 3 on one box, profiles/r05_call0_solve_variants.log; skipping phase 1 in waves without a live tile was slower)
-            const bool keeper = !MF || wv == 3;
-            if (keeper && i > k && i < n) {       // L[i][k+q] for the rows of the pivot block (q < i-k) and all rows below it
+                if (keeper && i == n) {               // forward-substituted rhs (k + C <= n + C - 1 < M + C: sY has C spare entries)
 #pragma unroll
-                for (int q = 0; q < C; q++) if (i > k + q) sL[LIX(i, k + q)] = f[q];
-            }
-            if (keeper && i == n) {               // forward-substituted rhs (k + C <= n + C - 1 < M + C: sY has C spare entries)
+                    for (int q2 = 0; q2 < C; q2 += 2) st2(&sY[k + q2], g[rr][q2], g[rr][q2 + 1]);
+                }
+                if (keeper && i == k) {
 #pragma unroll
-                for (int q2 = 0; q2 < C; q2 += 2) st2(&sY[k + q2], g[q2], g[q2 + 1]);
-            }
-            if (keeper && i == k) {
-#pragma unroll
-                for (int q2 = 0; q2 < C; q2 += 2) st2(&sD[k + q2], c[q2][q2], c[q2 + 1][q2 + 1]);
+                    for (int q2 = 0; q2 < C; q2 += 2) st2(&sD[k + q2], c[q2][q2], c[q2 + 1][q2 + 1]);
+                }
             }
         }
         if constexpr (MF) {
@@ -780,11 +824,11 @@ _Pragma("unroll") \
             // wave's own LDS copies (same wave wrote them: no barrier).  Tile columns left of the next panel are finished.
             RCYC(2, true);          // F, G, L, y, D stored
             const int bDone = (k + C) >> 4, c0 = (k + C) & 15;
-            const double *Fw = sPn + wv * 256, *Gw = sPn + 1024 + wv * 256;
+            const double *Fw = sPn + wv * (M * 4), *Gw = sPn + 4 * M * 4 + wv * (M * 4);
             double *sPw = ((k >> 2) & 1) ? sFp : sGp;
 #pragma unroll
-            for (int s_ = 0; s_ < 3; s_++) {
-                if (mta[s_] > 3 || mtb[s_] < bDone) continue;          // uniform per wave
+            for (int s_ = 0; s_ < NS; s_++) {
+                if (mta[s_] >= NB || mtb[s_] < bDone) continue;          // uniform per wave
                 const double aop = -Fw[(16 * mta[s_] + (lane & 15)) * 4 + (lane >> 4)];
                 const double bop = Gw[(16 * mtb[s_] + (lane & 15)) * 4 + (lane >> 4)];
                 Dv[s_] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, Dv[s_], 0, 0, 0);
@@ -864,6 +908,8 @@ _Pragma("unroll") \
                 const double d = sD[min(i, M - 1)];
                 xr[sg] = (i < n && fabs(d) > TINY) ? sY[min(i, M - 1)] / d : 0.0;
             }
+            // (round 6, measured and not kept: the L entries fetched in blocks of 16 rows one block ahead of the chain, 32 + 32 doubles in registers - k_gn_solve at C5
+            // 61.2 -> 67.8 us; 8 columns per round in the factorisation, LD_C7 = 8: - 1 us)
 #pragma unroll 4
             for (int kk = n - 1; kk > 0; kk--) {           // x_i -= L[k][i] x_k for i < k
                 double lk[NSEG];
@@ -935,7 +981,7 @@ _Pragma("unroll") \
 template <bool GN, bool WAIT = false>
 static __device__ __forceinline__ void solve_core_dispatch(const BaPtrs &B, const BaDims &D, const ResSet &S, const ldso_settings_t &St, int iteration, double *sm, SolveIO &io) {
     if (D.n + 1 <= 64) solve_core<4, 4, GN, WAIT, true>(B, D, S, St, iteration, sm, io);
-    else if (D.n + 1 <= 112) solve_core<7, 4, GN, WAIT>(B, D, S, St, iteration, sm, io);
+    else if (D.n + 1 <= 112) solve_core<7, (LD_MF7 != 0) ? 4 : LD_C7, GN, WAIT, LD_MF7 != 0>(B, D, S, St, iteration, sm, io);
     else solve_core<9, 4, GN, WAIT>(B, D, S, St, iteration, sm, io);
 }
 

@@ -47,7 +47,7 @@ if [ "$WHAT" = all ] || [ "$WHAT" = pmc ]; then
   done
 fi
 if [ "$WHAT" = all ] || [ "$WHAT" = sq ]; then
-  for CFG in C3; do
+  for CFG in C3 C5; do
     timeout 300 rocprofv3 --kernel-trace --pmc $SQA -d "$OUT/sq_${CFG}_A" -o pmc --output-format csv -- $B --steps 40 --warmup 5 --no-extras --config $CFG > "$OUT/sq_${CFG}_A.log" 2>&1
     timeout 300 rocprofv3 --kernel-trace --pmc $SQB -d "$OUT/sq_${CFG}_B" -o pmc --output-format csv -- $B --steps 40 --warmup 5 --no-extras --config $CFG > "$OUT/sq_${CFG}_B.log" 2>&1
   done

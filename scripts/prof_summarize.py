@@ -60,14 +60,24 @@ for cfg in ("C3", "C4", "C5", "B32"):
         if not cc:
             continue
         acc = defaultdict(list)
+        bygrid = defaultdict(lambda: defaultdict(list))          # the batched linearisation: launches of different sizes under one name (whole batch / half batch / one window)
         keep = []
         for r in csv.DictReader(open(cc)):
             if r["Counter_Name"] != C:
                 continue
             name = r["Kernel_Name"].split("(")[0].replace("void ", "")
             acc[name].append(float(r["Counter_Value"]))
+            if name.startswith("k_linearize_batch"):
+                try:
+                    bygrid[name][int(r["Grid_Size"]) // max(int(r["Workgroup_Size"]), 1)].append(float(r["Counter_Value"]))
+                except (KeyError, ValueError):
+                    pass
             if len(keep) < 499 and name.startswith("k_"):
                 keep.append(r)
+        for name, g in bygrid.items():
+            d = res["kernels"].setdefault(name, {})
+            big = max(g)
+            d[f"{C}_KB_mean_whole_batch"] = round(sum(g[big]) / len(g[big]), 3); d[f"launches_{C}_whole_batch"] = len(g[big]); d["whole_batch_workgroups"] = big
         if keep:
             with open(os.path.join(dst, f"{tag}_pmc_{cfg}_{C}_counter_collection.csv"), "w", newline="") as f:
                 w = csv.DictWriter(f, fieldnames=list(keep[0].keys())); w.writeheader(); w.writerows(keep)
@@ -82,6 +92,8 @@ for cfg in ("C3", "C4", "C5", "B32"):
     for name, d in res["kernels"].items():
         if "FETCH_SIZE_KB_mean" in d and "WRITE_SIZE_KB_mean" in d:
             d["hbm_bytes_per_launch_corrected"] = int(round((2 * d["FETCH_SIZE_KB_mean"] + d["WRITE_SIZE_KB_mean"]) * 1024))
+        if "FETCH_SIZE_KB_mean_whole_batch" in d and "WRITE_SIZE_KB_mean_whole_batch" in d:
+            d["hbm_bytes_per_launch_corrected_whole_batch"] = int(round((2 * d["FETCH_SIZE_KB_mean_whole_batch"] + d["WRITE_SIZE_KB_mean_whole_batch"]) * 1024))
     json.dump(res, open(os.path.join(dst, f"{tag}_pmc_traffic_{cfg}.json"), "w"), indent=1)
     print("== pmc", cfg)
     for name, d in res["kernels"].items():
@@ -100,9 +112,18 @@ for cfg in ("C3", "C5", "B32"):
         if not cc:
             continue
         acc = defaultdict(lambda: defaultdict(list))
-        for r in csv.DictReader(open(cc)):
+        rows = list(csv.DictReader(open(cc)))
+        big = 0
+        if cfg == "B32":          # the whole-batch launches only (the largest grid): half-batch and single-window launches carry the same kernel name
+            for r in rows:
+                if "k_linearize_batch" in r["Kernel_Name"]:
+                    try: big = max(big, int(r["Grid_Size"]))
+                    except (KeyError, ValueError): pass
+        for r in rows:
             name = r["Kernel_Name"].split("(")[0].replace("void ", "")
             if name.startswith("k_linearize"):
+                if big and name.startswith("k_linearize_batch") and int(r["Grid_Size"]) != big:
+                    continue
                 acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
         for name, cs in acc.items():
             d = per.setdefault(name, {})
