@@ -21,6 +21,9 @@
 #include <type_traits>
 #include "ba_dev.h"
 
+#ifndef LD_MFMA_SUMS
+#define LD_MFMA_SUMS 0
+#endif
 #ifndef LD_OPAQUE_K
 #define LD_OPAQUE_K 0          // experiment (round 6): masks derived from the lane index recomputed per point instead of kept in (spilled) SGPR pairs - 37 fewer vector instructions in the kernel and SLOWER (B = 32: 173 against 160 us, C5 44.2 against 43.1, one box): not used
 #endif
@@ -92,6 +95,15 @@ __device__ __forceinline__ float seq8(float x, int k, int lane) {
 // butterflies were measured against this in rounds 3 and 4: bit-identical, 2 % slower in every configuration - removed.
 __device__ __forceinline__ float sum_slots(float x, int a16, int a32) {
     x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128, 0xF, 0xF, true));
+#if LD_MFMA_SUMS
+    // experiment (round 6): the sum over the four 16-lane rows on the fp32 matrix core instead of two ds_bpermute butterflies - v_mfma_f32_16x16x4_f32 with A = 1:
+    // D[i][j] = sum_k B[k][j], B[k][j] = the value of lane 16 k + j, every lane l reads column j = l & 15 back (all four result registers hold the same sum)
+    (void) a16; (void) a32;
+    typedef float v4f_ __attribute__((ext_vector_type(4)));
+    const v4f_ z = {0.0f, 0.0f, 0.0f, 0.0f};
+    const v4f_ d = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, x, z, 0, 0, 0);
+    return d[0];
+#endif
     x += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(a16, __builtin_bit_cast(int, x)));
     x += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(a32, __builtin_bit_cast(int, x)));
     return x;

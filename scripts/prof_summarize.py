@@ -133,6 +133,8 @@ for cfg in ("C3", "C5", "B32"):
         continue
     # the GN-iteration kernel = the one with the most launches
     name = max(per, key=lambda k: per[k].get("launches_A", 0))
+    if cfg == "B32" and any(k.startswith("k_linearize_batch") for k in per):          # (its whole-batch launches only, see above: fewer than the set-up launches of k_linearize_one)
+        name = [k for k in per if k.startswith("k_linearize_batch")][0]
     d = per[name]
     wc = d.get("SQ_WAVE_CYCLES", 0.0)
     der = {}
