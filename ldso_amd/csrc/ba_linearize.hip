@@ -21,6 +21,9 @@
 #include <type_traits>
 #include "ba_dev.h"
 
+#ifndef LD_PAIR
+#define LD_PAIR 1          // windows of 9..12 key frames: two points share the pass of the second slot group (k_linearize_one<2, true>)
+#endif
 #ifndef LD_MFMA_SUMS
 #define LD_MFMA_SUMS 0
 #endif
@@ -106,6 +109,12 @@ __device__ __forceinline__ float sum_slots(float x, int a16, int a32) {
 #endif
     x += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(a16, __builtin_bit_cast(int, x)));
     x += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(a32, __builtin_bit_cast(int, x)));
+    return x;
+}
+// sum over the 4 slots of a half-wave (lanes with equal k inside lanes 0..31 / 32..63), result in every lane of the half: the first two steps of sum_slots
+__device__ __forceinline__ float sum_half(float x, int a16) {
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128, 0xF, 0xF, true));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(a16, __builtin_bit_cast(int, x)));
     return x;
 }
 // ---- just-in-time pointer groups ------------------------------------------------------------------------------------------------
@@ -240,6 +249,42 @@ static __device__ __forceinline__ void load_point(PtIn<NSG> &q, const BaPtrs &B,
     }
 }
 
+// Pair mode (round 6, windows of 9..12 key frames): the second slot group of such a window uses 4 of its 8 slots, so TWO points share its pass - lanes 0..31 work on the
+// targets 8..11 of point A, lanes 32..63 on the targets 8..11 of point B (3 passes per 2 points instead of 4).  The records of a pair: PtGeo / PtRec with A in lanes
+// 0..31 and B in lanes 32..63 (dword lane & 15), both points' colours / weights, the first group's slot records of A and of B, the shared second group's.
+struct PairIn {
+    float rgeo, rrec, colA, wgtA, colB, wgtB;
+    int rfA0, rfB0, rf1;
+    float jpA0, mA0, jpB0, mB0, jp1, m1;
+};
+template <bool DESC>
+static __device__ __forceinline__ void load_pair(PairIn &q, const BaPtrs &B, const ResSet &cur, unsigned FS, unsigned pA, unsigned dAB, unsigned s, unsigned k, unsigned lane) {
+    const unsigned pU = (unsigned) __builtin_amdgcn_readfirstlane((int) pA), dU = (unsigned) __builtin_amdgcn_readfirstlane((int) dAB);
+    const unsigned hoff = (lane & 32u) ? dU : 0u;          // this lane's point, relative to A
+    const unsigned s1 = 8u + (s & 3u);                     // this lane's slot of the shared second group
+    {
+        const v16i_t b0 = ldg16<DESC, OFF_B0>(&B);
+        const float *geo = GP(const float, b0, BP_GEO);
+        const v2f_t *pcw = GP(const v2f_t, b0, BP_CW);
+        const v2i32_t *rtab = (const v2i32_t *) GP(const v4i32_t, b0, BP_RTAB);          // two dwordx2 per 16-byte entry: {rflat, rlin} first
+        q.rgeo = AT(geo + (size_t) pU * (sizeof(PtGeo) / 4), hoff * (unsigned) (sizeof(PtGeo) / 4) + (lane & 15u));
+        const v2f_t ca = AT(pcw + (size_t) pU * 8, k), cb = AT(pcw + (size_t) pU * 8, dU * 8u + k);
+        q.colA = ca.x; q.wgtA = ca.y; q.colB = cb.x; q.wgtB = cb.y;
+        q.rfA0 = AT(rtab + (size_t) pU * FS * 2, s * 2u).x;
+        q.rfB0 = AT(rtab + (size_t) pU * FS * 2, (dU * FS + s) * 2u).x;
+        q.rf1 = AT(rtab + (size_t) pU * FS * 2, (hoff * FS + s1) * 2u).x;
+    }
+    {
+        const v16i_t s0 = ldg16<DESC, OFF_S0>(&cur);
+        const v2f_t *slots = GP(const v2f_t, s0, RS_SLOT);
+        const float *pts = GP(const float, s0, RS_PT);
+        q.rrec = AT(pts + (size_t) pU * (sizeof(PtRec) / 4), hoff * (unsigned) (sizeof(PtRec) / 4) + (lane & 15u));
+        const v2f_t a0 = AT(slots + (size_t) pU * FS * 8, s * 8u + k), b0_ = AT(slots + (size_t) pU * FS * 8, (dU * FS + s) * 8u + k);
+        const v2f_t p1 = AT(slots + (size_t) pU * FS * 8, (hoff * FS + s1) * 8u + k);
+        q.jpA0 = a0.x; q.mA0 = a0.y; q.jpB0 = b0_.x; q.mB0 = b0_.y; q.jp1 = p1.x; q.m1 = p1.y;
+    }
+}
+
 // What the front half of a slot group (pattern projection -> tap loads) hands to its back half (everything behind the image taps), one group
 // later: the 12 tap dwords (in flight) and the projected pixel.  PtStep: the inverse depth of the point after the fused point step.
 struct TapsG { float t[12]; float Ku, Kv; };
@@ -257,7 +302,7 @@ struct PtStep { float idp, idz; };
 // The body is shared by k_linearize (one window: everything arrives as kernel arguments, i.e. in scalar registers) and
 // k_linearize_batch (many independent windows per launch: the descriptors live in device memory).  chunk = index of the
 // workgroup's chunk inside ITS window, gridBlocks = workgroups of that window (partition of the accumulator initialisation).
-template <int NSG, bool HAS_L, bool FIX, bool MARG, bool DESC, bool ONE = false>
+template <int NSG, bool HAS_L, bool FIX, bool MARG, bool DESC, bool ONE = false, bool PAIR = false>
 static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaDims &D, const ResSet &cur, const ResSet &nxt, const ldso_settings_t &S, const int stepMode,
                                                       const GnInit &gi, const int32_t *__restrict__ margFlags, const int chunk, const int gridBlocks,
                                                       const int p0, const int np, const int h) {
@@ -312,7 +357,7 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
     const int waveU = __builtin_amdgcn_readfirstlane(wave);
     PtIn<NSG> qa = {}, qb = {}, qc = {};
     int pi = waveU;
-    if (pi < np) load_point<NSG, HAS_L, FIX, DESC>(qa, B, cur, FS, p0 + pi, s, k, lane);
+    if (!PAIR && pi < np) load_point<NSG, HAS_L, FIX, DESC>(qa, B, cur, FS, p0 + pi, s, k, lane);
 
     // ---- staging: all global loads first (one latency level), then the LDS stores --------------------------------
     {
@@ -415,17 +460,17 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
         return r;
     };
     // ================= FRONT half, per slot group: pattern projection, tap loads ====================================================
-    auto front_g = [&](auto gc, const PtIn<NSG> &q, const PtStep &ps, TapsG &T) {
-        constexpr int g = decltype(gc)::value;
+    // MODE 0: the lanes' slots are the targets g * 8 + s of ONE point.  MODE 3 (PAIR, second slot group of windows of 9..12 key frames): lanes 0..31 hold the targets
+    // 8..11 of point A, lanes 32..63 the targets 8..11 of point B - pu / pv / idp are per-lane values then
+    auto front_x = [&](auto gc, auto mc, const PtIn<NSG> &q, const float pu, const float pv, const float idp, TapsG &T) {
+        constexpr int g = decltype(gc)::value, MODE = decltype(mc)::value;
 #if LD_OPAQUE_K
         int k = k_; asm volatile("" : "+v"(k));
 #endif
-        const float pu = RLF(q.rgeo, GEO_U), pv = RLF(q.rgeo, GEO_V);
-        const float idp = ps.idp;
         float l1, h1;
         group_bcast_pair<1>(q.m[g], k, l1, h1); (void) l1;          // the state of the slot record: m of lane 5 of the group
         const int qState = __builtin_bit_cast(int, h1);
-        const int t = g * 8 + s;
+        const int t = (MODE == 3) ? 8 + (s & 3) : g * 8 + s;
         const bool exists = (t < F) && (q.rflat[g] >= 0);           // MARG: the flag of the point is read by the back half; unflagged points load taps nobody uses
         const bool isLin = MARG ? false : (exists && (q.rlin[g] != 0));
         const bool reset = MARG || ((stepMode & 2) && !isLin);
@@ -452,6 +497,8 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
         T.t[0] = r0a.x; T.t[1] = r0a.y; T.t[2] = r0a.z; T.t[3] = r0a.w; T.t[4] = r0b.x; T.t[5] = r0b.y;
         T.t[6] = r1a.x; T.t[7] = r1a.y; T.t[8] = r1a.z; T.t[9] = r1a.w; T.t[10] = r1b.x; T.t[11] = r1b.y;
     };
+    using M0 = std::integral_constant<int, 0>;
+    auto front_g = [&](auto gc, const PtIn<NSG> &q, const PtStep &ps, TapsG &T) { front_x(gc, M0{}, q, RLF(q.rgeo, GEO_U), RLF(q.rgeo, GEO_V), ps.idp, T); };
 
     // ================= BACK half of a point: everything behind the image taps ================================================================
     // per-point state of the back half (set by back_begin, updated by back_g of every slot group, consumed by back_end)
@@ -483,8 +530,18 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
         nActive = 0;
     };
 
-    auto back_g = [&](auto gc, const unsigned p, const PtIn<NSG> &q, const TapsG &T) {
-        constexpr int g = decltype(gc)::value;
+    // pair mode (PAIR): the per-point sums below live as "one point per half-wave" - lanes 0..31 hold point A's value, lanes 32..63 point B's.  MODE 1 / 2: a full pass
+    // (8 slots) of point A / B, its slot sums go to that half only; MODE 3: the shared pass of the second slot group, sums per half-wave
+    float gT0B = 0.0f;            // (pair mode) the first group's G entries of point B (gT[0]: point A's; gT[1]: the shared second group's)
+    bool hasB = true;             // (pair mode) point B exists
+    const int half = lane >> 5;
+    auto back_x = [&](auto gc, auto mc, const unsigned p, const PtIn<NSG> &q, const TapsG &T) {
+        constexpr int g = decltype(gc)::value, MODE = decltype(mc)::value;
+        auto ACC = [&](float &X, const float v) {
+            if constexpr (MODE == 0) X += sum_slots(v, a16, a32);
+            else if constexpr (MODE == 3) X += sum_half(v, a16);
+            else { const float s_ = sum_slots(v, a16, a32); X += (half == MODE - 1) ? s_ : 0.0f; }
+        };
 #if LD_OPAQUE_K
         int k = k_; asm volatile("" : "+v"(k));
 #endif
@@ -498,7 +555,7 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
             (void) l1; (void) l2; (void) h3;
         }
         {
-            const int t = g * 8 + s;
+            const int t = (MODE == 3) ? 8 + (s & 3) : g * 8 + s;
             const unsigned slot = p * (unsigned) FS + (unsigned) t;
             const bool exists = (t < F) && (q.rflat[g] >= 0) && flagged;
             const bool isLin = MARG ? false : (exists && (q.rlin[g] != 0));
@@ -681,9 +738,9 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
             float sHc0 = accHere ? (x[0] * Ji2_0 + y[0] * Ji2_1) : 0.0f, sHc1 = accHere ? (x[1] * Ji2_0 + y[1] * Ji2_1) : 0.0f;
             float sHc2 = accHere ? (x[2] * Ji2_0 + y[2] * Ji2_1) : 0.0f, sHc3 = accHere ? (x[3] * Ji2_0 + y[3] * Ji2_1) : 0.0f;
             // sum over the 8 slots of this pass
-            bdA += sum_slots(sbd, a16, a32); HddA += sum_slots(sHdd, a16, a32);
-            HcdA0 += sum_slots(sHc0, a16, a32); HcdA1 += sum_slots(sHc1, a16, a32);
-            HcdA2 += sum_slots(sHc2, a16, a32); HcdA3 += sum_slots(sHc3, a16, a32);
+            ACC(bdA, sbd); ACC(HddA, sHdd);
+            ACC(HcdA0, sHc0); ACC(HcdA1, sHc1);
+            ACC(HcdA2, sHc2); ACC(HcdA3, sHc3);
             if (accHere && k == 0) nresA++;
 
             // ================= linearised residual, mode 1 (AccumulatedTopHessian.cc:29-31,44-63) =======
@@ -766,9 +823,14 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
                     for (int j = 0; j < 8; j++) { tgt = __builtin_fmaf(aT[j], vj[j], tgt); hpart = __builtin_fmaf(aH[j], vj[j], hpart); }
                 }
             }
-            hostPart += sum_slots(hpart, a16, a32);
-            gT[g] = tgt;
-            nActive += __popcll(__ballot(exists && activeNew && k == 0));
+            ACC(hostPart, hpart);
+            if constexpr (MODE == 2) gT0B = tgt; else gT[g] = tgt;
+            {
+                const unsigned long long am = __ballot(exists && activeNew && k == 0);
+                if constexpr (MODE == 0) nActive += __popcll(am);
+                else if constexpr (MODE == 3) nActive += __popcll(am & (half ? 0xFFFFFFFF00000000ull : 0x00000000FFFFFFFFull));
+                else nActive += (half == MODE - 1) ? __popcll(am) : 0;
+            }
             if (FIX) numGood += __popcll(newGoodMask);
             if (FIX) { float m = maxRelBS; m = fmaxf(m, __shfl_xor(m, 8, 64)); m = fmaxf(m, __shfl_xor(m, 16, 64)); m = fmaxf(m, __shfl_xor(m, 32, 64)); maxRelBS = m; }
 
@@ -784,8 +846,8 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
                 float mOut = (k < 3) ? cenK : (k == LD_SM_ENERGY) ? newEnergy : (k == LD_SM_EWO) ? ewo_
                            : __builtin_bit_cast(float, (k == LD_SM_STATE) ? newState : (k == LD_SM_ACTIVE) ? activeNew : toRemove);
                 v2f_t e; e.x = (t < F) ? jp : 0.0f; e.y = (t < F) ? mOut : 0.0f;
-                AT(o_slot, slot * 8 + (unsigned) k) = e;
-                if (k == 0 && t == F - 1) AT(o_cand, p) = ewo_;
+                if (MODE != 3 || hasB || half == 0) AT(o_slot, slot * 8 + (unsigned) k) = e;
+                if (k == 0 && t == F - 1 && (MODE != 3 || hasB || half == 0)) AT(o_cand, p) = ewo_;
                 if (k == 0 && t < F && doLin) energySum += ret;
             }
             if (!DESC && dumpJ != nullptr && compute) {          // (debug dump: the step-wise entry points only)
@@ -801,7 +863,8 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
                 }
             }
         }   // slot group
-    };   // back_g
+    };   // back_x
+    auto back_g = [&](auto gc, const unsigned p, const PtIn<NSG> &q, const TapsG &T) { back_x(gc, M0{}, p, q, T); };
 
     auto back_end = [&](const unsigned p, const PtIn<NSG> &q) {
         (void) q;
@@ -854,6 +917,122 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
         }
     };   // back_end
 
+    if constexpr (PAIR) {
+        static_assert(!PAIR || (NSG == 2 && DESC && !HAS_L && !FIX && !MARG), "pair mode: the GN-iteration kernels of windows of 9..12 key frames");
+        using G0 = std::integral_constant<int, 0>; using G1 = std::integral_constant<int, 1>;
+        using M1 = std::integral_constant<int, 1>; using M2 = std::integral_constant<int, 2>; using M3 = std::integral_constant<int, 3>;
+        // point step of a pair -> inverse depths, one point per half-wave
+        auto pstep_pair = [&](const unsigned pA, const unsigned dAB, const PairIn &q, float &idpH, float &idzH) {
+#define HSEL(v, i) (half ? RLF(v, 32 + (i)) : RLF(v, (i)))
+            idpH = HSEL(q.rgeo, GEO_IDP); idzH = HSEL(q.rgeo, GEO_IDZ);
+            if (stepMode & 1) {
+                auto active_of = [&](const float m) { float l2, h2; group_bcast_pair<2>(m, k, l2, h2); (void) l2; return __builtin_bit_cast(int, h2) != 0; };
+                const int t1 = 8 + (s & 3);
+                float sA = seq8(sXa[s * 8 + k] * q.jpA0, k, lane), sB = seq8(sXa[s * 8 + k] * q.jpB0, k, lane), s1 = seq8(sXa[t1 * 8 + k] * q.jp1, k, lane);
+                sA = ((s < F) && q.rfA0 >= 0 && active_of(q.mA0)) ? sA : 0.0f;
+                sB = ((s < F) && q.rfB0 >= 0 && active_of(q.mB0)) ? sB : 0.0f;
+                s1 = ((t1 < F) && q.rf1 >= 0 && active_of(q.m1)) ? s1 : 0.0f;
+                const float sumA = sum_slots(sA, a16, a32), sumB = sum_slots(sB, a16, a32), sum1 = sum_half(s1, a16);
+                const float rHdi = HSEL(q.rrec, REC_HDI), rBd = HSEL(q.rrec, REC_BDSUM), rIdH = HSEL(q.rrec, REC_IDH);
+                const int rNact = half ? RLI(q.rrec, 32 + REC_NACT) : RLI(q.rrec, REC_NACT);
+                float dot = 0;
+                dot += xc0 * (HSEL(q.rrec, REC_HCDA + 0) + HSEL(q.rrec, REC_HCDL + 0)); dot += xc1 * (HSEL(q.rrec, REC_HCDA + 1) + HSEL(q.rrec, REC_HCDL + 1));
+                dot += xc2 * (HSEL(q.rrec, REC_HCDA + 2) + HSEL(q.rrec, REC_HCDL + 2)); dot += xc3 * (HSEL(q.rrec, REC_HCDA + 3) + HSEL(q.rrec, REC_HCDL + 3));
+                float b = rBd;
+                b -= dot;
+                b -= (half ? sumB : sumA);          // (the order of the reference's sum: first group, then second)
+                b -= sum1;
+                float step = 0.0f;
+                const bool mine = (half == 0) || (dAB != 0);          // lanes of a point B that does not exist store nothing
+                if (rNact > 0) {
+                    if (isfinite(b)) step = -b * rHdi;
+                    else { step = HSEL(q.rgeo, GEO_STEP); if ((lane & 31) == 0 && mine) *(gptr_t<double>) (unsigned long long) (B.scalars + 4) = 1.0; }
+                }
+                const float ni = idpH + 1.0f * step;
+                {
+                    const v16i_t b0 = ldg16<DESC, OFF_B0>(&B);
+                    v4f_t *w_geo = GP(v4f_t, b0, BP_GEO);
+                    const int l5 = lane & 31;
+                    if ((l5 == 1 || l5 == 2) && mine) {
+                        v4f_t v;
+                        v.x = (l5 == 1) ? ni : rHdi; v.y = (l5 == 1) ? ni : rBd; v.z = (l5 == 1) ? step : rIdH; v.w = (l5 == 1) ? idpH : 0.0f;
+                        AT(w_geo, (pA + (half ? dAB : 0u)) * 4 + (unsigned) l5) = v;
+                    }
+                }
+                idpH = ni; idzH = ni;
+            }
+        };
+        PairIn ca = {}, cn = {};
+        float idpH = 0, idzH = 0, idpHn = 0, idzHn = 0;
+        TapsG ta = {}, tb = {};
+        auto viewA0 = [&](const PairIn &q) { PtIn<NSG> v = {}; v.rflat[0] = q.rfA0; v.jp[0] = q.jpA0; v.m[0] = q.mA0; return v; };
+        auto viewB0 = [&](const PairIn &q) { PtIn<NSG> v = {}; v.rflat[0] = q.rfB0; v.jp[0] = q.jpB0; v.m[0] = q.mB0; return v; };
+        auto view1 = [&](const PairIn &q, const bool withB) { PtIn<NSG> v = {}; v.rflat[1] = (half && !withB) ? -1 : q.rf1; v.jp[1] = q.jp1; v.m[1] = q.m1; return v; };
+        if (pi < np) {
+            const unsigned dA0 = (pi + LD_WAVES < np) ? LD_WAVES : 0;
+            load_pair<DESC>(ca, B, cur, FS, (unsigned) (p0 + pi), dA0, s, k, lane);          // (the classic first record load above is not used in pair mode)
+            pstep_pair((unsigned) (p0 + pi), dA0, ca, idpH, idzH);
+            front_x(G0{}, M0{}, viewA0(ca), RLF(ca.rgeo, GEO_U), RLF(ca.rgeo, GEO_V), RLF(idpH, 0), ta);
+#pragma clang loop unroll(disable)
+            do {
+                const unsigned pA = (unsigned) (p0 + pi);
+                hasB = pi + LD_WAVES < np;
+                const unsigned dAB = hasB ? LD_WAVES : 0, pB = pA + dAB;
+                const bool n1 = pi + 2 * LD_WAVES < np;
+                const unsigned pA1 = n1 ? pA + 2 * LD_WAVES : pA, dAB1 = (pi + 3 * LD_WAVES < np) ? LD_WAVES : 0;
+                // ---- the next pair's records, the first-group taps of point B ----
+                load_pair<DESC>(cn, B, cur, FS, pA1, dAB1, s, k, lane);
+                front_x(G0{}, M0{}, viewB0(ca), RLF(ca.rgeo, 32 + GEO_U), RLF(ca.rgeo, 32 + GEO_V), RLF(idpH, 32), tb);
+                // ---- per-point sums, one point per half-wave ----
+                HddA = 0; bdA = 0; HcdA0 = 0; HcdA1 = 0; HcdA2 = 0; HcdA3 = 0; hostPart = 0.0f; nActive = 0;
+                flagged = true; recNActive = 0;
+                // ---- first group of A (all 64 lanes) ----
+                pu = RLF(ca.rgeo, GEO_U); pv = RLF(ca.rgeo, GEO_V); color = ca.colA; wgt = ca.wgtA; idp = RLF(idpH, 0); idz = RLF(idzH, 0); deltaF = idp - idz;
+                back_x(G0{}, M1{}, pA, viewA0(ca), ta);
+                // ---- taps of the shared second group (per-lane point) ----
+                {
+                    const float puH = HSEL(ca.rgeo, GEO_U), pvH = HSEL(ca.rgeo, GEO_V);
+                    front_x(G1{}, M3{}, view1(ca, hasB), puH, pvH, idpH, ta);
+                }
+                // ---- first group of B ----
+                if (hasB) {
+                    pu = RLF(ca.rgeo, 32 + GEO_U); pv = RLF(ca.rgeo, 32 + GEO_V); color = ca.colB; wgt = ca.wgtB; idp = RLF(idpH, 32); idz = RLF(idzH, 32); deltaF = idp - idz;
+                    back_x(G0{}, M2{}, pB, viewB0(ca), tb);
+                }
+                // ---- the next pair: point steps, first-group taps of its A ----
+                if (n1) pstep_pair(pA1, dAB1, cn, idpHn, idzHn);
+                front_x(G0{}, M0{}, viewA0(cn), RLF(cn.rgeo, GEO_U), RLF(cn.rgeo, GEO_V), RLF(idpHn, 0), tb);
+                // ---- the shared second group ----
+                pu = HSEL(ca.rgeo, GEO_U); pv = HSEL(ca.rgeo, GEO_V); color = half ? ca.colB : ca.colA; wgt = half ? ca.wgtB : ca.wgtA; idp = idpH; idz = idzH; deltaF = idp - idz;
+                back_x(G1{}, M3{}, pA + (half ? dAB : 0u), view1(ca, hasB), ta);
+                // ---- the two points' Schur rows: the half-wave values made wave-uniform, then the classic tail ----
+                {
+                    const float H_ = HddA, b_ = bdA, c0_ = HcdA0, c1_ = HcdA1, c2_ = HcdA2, c3_ = HcdA3, hp_ = hostPart, g0A_ = gT[0], g1_ = gT[1];
+                    const int na_ = nActive;
+                    const float hpO = __shfl_xor(hp_, 32, 64), g1O = __shfl_xor(g1_, 32, 64);
+#pragma unroll
+                    for (int X = 0; X < 2; X++) {
+                        if (X == 1 && !hasB) break;
+                        const int L0 = 32 * X;
+                        HddA = RLF(H_, L0); bdA = RLF(b_, L0); HcdA0 = RLF(c0_, L0); HcdA1 = RLF(c1_, L0); HcdA2 = RLF(c2_, L0); HcdA3 = RLF(c3_, L0);
+                        nActive = RLI(na_, L0);
+                        hostPart = (half == X) ? hp_ : hpO;
+                        gT[0] = X ? gT0B : g0A_;
+                        gT[1] = (s < 4) ? ((half == X) ? g1_ : g1O) : 0.0f;          // lanes s >= 4 of the second group: the targets 12..15, not in the window
+                        priorF = RLF(ca.rgeo, L0 + GEO_PRIOR);
+                        idp = RLF(idpH, L0); idz = RLF(idzH, L0); deltaF = idp - idz;
+                        const int rN = RLI(ca.rrec, L0 + REC_NACT);
+                        maxRelBS = ((stepMode & 1) && rN <= 0) ? 0.0f : RLF(ca.rrec, L0 + REC_MAXRELBS);
+                        numGood = RLI(ca.rrec, L0 + REC_NUMGOOD);
+                        back_end(X ? pB : pA, PtIn<NSG>{});
+                    }
+                }
+                ca = cn; idpH = idpHn; idzH = idzHn; ta = tb;
+                pi += 2 * LD_WAVES;
+            } while (pi < np);
+        }
+#undef HSEL
+    } else
     {
         // The software pipeline.  F <= 8 (one slot group per point): the taps of point i + 1 are in flight while point i is worked on.  F > 8: the unit is
         // the slot group - the taps of the point's second group, then of the next point's first group, are in flight behind the group that is worked on.
@@ -980,6 +1159,15 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
         float a = 0;
 #pragma unroll
         for (int wv = 0; wv < LD_WAVES; wv++) a += sRed[wv * FS * LD_TOPN + i];
+        if constexpr (PAIR) {
+            // pair mode: the lanes 32..63 of the shared pass accumulated the targets 8..11 of their point in the cells of the slots 12..15
+            const int t_ = i / LD_TOPN;
+            if (t_ >= 12) a = 0.0f;
+            else if (t_ >= 8) {
+#pragma unroll
+                for (int wv = 0; wv < LD_WAVES; wv++) a += sRed[wv * FS * LD_TOPN + i + 4 * LD_TOPN];
+            }
+        }
         o_topA[(size_t) chunk * FS * LD_TOPN + i] = a;
         if (HAS_L) {
             float l = 0;
@@ -1035,7 +1223,7 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize_batch(const BatchIt
 // memory levels and nothing else (window of 5 MB on a chip that moves that in 0.7 us): kernel arguments -> workgroup table entry -> descriptor ->
 // operands -> LDS was four levels (k_linearize_batch<NSG, false>), this is two.
 struct OneArgs { BaPtrs B; BaDims D; ResSet cur, nxt; ldso_settings_t S; int stepMode; GnInit gi; LinHead hd; };
-template <int NSG>
+template <int NSG, bool PAIR = false>
 __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize_one(OneArgs a) {
     // The descriptor is addressed IN the kernarg segment (the only parameter starts at its offset 0): taking the address of the by-value parameter
     // itself would make the compiler copy it to scratch memory (536 bytes per lane, and a scalar load from a private address is meaningless).
@@ -1051,7 +1239,7 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize_one(OneArgs a) {
 #pragma unroll
     for (int i = 0; i < LD_MAXF; i++) { const bool m = (i == h); c0 = m ? hd.cs[i] : c0; q0 = m ? hd.hostP0[i] : q0; q1 = m ? hd.hostP0[i + 1] : q1; }
     const int p0 = q0 + (chunk - c0) * hd.CH, np = min(hd.CH, q1 - p0);
-    linearize_body<NSG, false, false, false, true, true>(A.B, A.D, A.cur, A.nxt, a.S, a.stepMode, a.gi, nullptr, chunk, (int) gridDim.x, p0, np, h);
+    linearize_body<NSG, false, false, false, true, true, PAIR>(A.B, A.D, A.cur, A.nxt, a.S, a.stepMode, a.gi, nullptr, chunk, (int) gridDim.x, p0, np, h);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1093,6 +1281,10 @@ hipError_t ba_launch_linearize_one(const BaPtrs &B, const BaDims &D, const ResSe
     if (D.nsg == 1) {
         if (lds > 48 * 1024) (void) hipFuncSetAttribute((const void *) k_linearize_one<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
         hipLaunchKernelGGL(k_linearize_one<1>, dim3(D.nChunks), dim3(64 * LD_WAVES), lds, st, a);
+    } else if (D.F <= 12 && LD_PAIR) {
+        // 9..12 key frames: the second slot group uses 4 of its 8 slots - two points share its pass (pair mode, round 6)
+        if (lds > 48 * 1024) (void) hipFuncSetAttribute((const void *) k_linearize_one<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+        hipLaunchKernelGGL((k_linearize_one<2, true>), dim3(D.nChunks), dim3(64 * LD_WAVES), lds, st, a);
     } else {
         if (lds > 48 * 1024) (void) hipFuncSetAttribute((const void *) k_linearize_one<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
         hipLaunchKernelGGL(k_linearize_one<2>, dim3(D.nChunks), dim3(64 * LD_WAVES), lds, st, a);
