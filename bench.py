@@ -741,6 +741,22 @@ def initializer_line():
             "evaluations_cpu_gpu": ev, "max_abs_pose_diff_last_frame": dT}
 
 
+def _host_cpu():
+    """model name and frequency governor of the host the CPU baseline ran on (the baseline drifts 200 -> 250 it/s between boxes)"""
+    model, gov = None, None
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip(); break
+    except OSError:
+        pass
+    try:
+        gov = open("/sys/devices/system/cpu/cpu0/cpufreq/scaling_governor").read().strip()
+    except OSError:
+        pass
+    return {"model": model, "governor": gov}
+
+
 def cpu_baseline(win):
     """Oracle (CPU restatement of the reference) timed on the host cores: GN iterations/s on the same window.
     Per-iteration time by differencing optimize(12) - optimize(2) (removes window set-up and the final fix pass)."""
@@ -769,7 +785,7 @@ def cpu_baseline(win):
     port = {"value": round(1.0 / res["mt6"], 2), "unit": "GN iters/s", "cores": 6, "kind": "port",
             "sample": f"median per-iteration time of optimize(12)-optimize(2) over ~8 s, same {win.F} KF x {win.P} pt window, 6 worker threads "
                       f"(reference NUM_THREADS) on a {ncpu}-vCPU host; -O3 -march=native" if fast else "portable build",
-            "single_thread_value": round(1.0 / res["st1"], 2), "host_vcpus": ncpu,
+            "single_thread_value": round(1.0 / res["st1"], 2), "host_vcpus": ncpu, "host_cpu": _host_cpu(),
             "upper_bound_of_reference": True,      # the restatement has no shared_ptr / weak_ptr.lock() graph: it is faster than the code it restates
             "window_recreated_per_sample": True}
     ref = reference_compiled_baseline(win)
@@ -832,7 +848,7 @@ def reference_compiled_baseline(win):
     return {"value": round(1.0 / res["mt6"], 2), "unit": "GN iters/s", "cores": 6, "kind": "reference",
             "sample": f"the reference's FullSystem::optimize on the same {win.F} KF x {win.P} pt window: median per-iteration time of optimize(12)-optimize(2) "
                       f"over ~8 s per mode, multiThreading = true (IndexThreadReduce, NUM_THREADS = 6) on a {os.cpu_count()}-vCPU host",
-            "single_thread_value": round(1.0 / res["st1"], 2), "host_vcpus": os.cpu_count(),
+            "single_thread_value": round(1.0 / res["st1"], 2), "host_vcpus": os.cpu_count(), "host_cpu": _host_cpu(),
             "build": "reference translation units compiled unmodified, g++ -O3 -march=x86-64-v3", "eigen": "shim (oracle/ref_shim: eager evaluation, no expression templates)",
             "window_recreated_per_sample": True}
 

@@ -134,6 +134,8 @@ int ldso_ba_add_residuals(ldso_ba_t *h, int n, const int32_t *rows, const int32_
 int ldso_ba_add_points(ldso_ba_t *h, int n, const ldso_point_t *points, const int32_t *before_row, int n_res, const ldso_residual_t *residuals,
                        const float *max_rel_baseline, const int32_t *num_good_residuals);
 int ldso_ba_window_commit(ldso_ba_t *h);
+/* the dimensions of the window the handle holds (what the getters below write: R residual records, P point records, F frames); any pointer may be NULL */
+int ldso_ba_get_dims(ldso_ba_t *h, int *F, int *P, int *R);
 /* Frame / calibration state (FrameHessian::setState..., CalibHessian::setValue) and the
  * marginalisation prior HM,bM ((8F+4)^2 row-major, (8F+4); NULL = zero).  ldso_ba_set_frames also performs
  * EnergyFunctional::setAdjointsF (EnergyFunctional.cc:431-489) and FullSystem::setPrecalcValues

@@ -179,7 +179,7 @@ class BA:
         fp = np.ascontiguousarray(fresh) if nf else None; fr = np.ascontiguousarray(fresh_res) if nr else None
         fm = np.ascontiguousarray(fresh_mrb, np.float32) if nf else None; fg = np.ascontiguousarray(fresh_ngr, np.int32) if nf else None
         _chk(self.L.ldso_ba_update_window(self.h, C.c_int(len(sl)), _p(sl), _p(ff), C.c_int(len(pf)), _p(pf), _p(mk), C.c_int(nf), _p(fp), C.c_int(nr), _p(fr), _p(fm), _p(fg)))
-        self.F, self.P, self.R = len(sl), len(pf), int(sum(bin(int(m)).count("1") for m in mk))
+        self._sync_dims()
 
     # ---- the same delta call by call (ldso_ba_window_begin .. ldso_ba_window_commit) ----
     def window_begin(self):
@@ -210,9 +210,16 @@ class BA:
         m = np.ascontiguousarray(mrb, np.float32) if mrb is not None else None; g = np.ascontiguousarray(ngr, np.int32) if ngr is not None else None
         _chk(self.L.ldso_ba_add_points(self.h, C.c_int(len(pts)), _p(pts), _p(br), C.c_int(len(res)), _p(res), _p(m), _p(g)))
 
-    def window_commit(self, F, P, R):
+    def _sync_dims(self):
+        """F / P / R as the HANDLE holds them (the getters size their numpy buffers from these: never from what a caller says)"""
+        F, P, R = C.c_int(), C.c_int(), C.c_int()
+        _chk(self.L.ldso_ba_get_dims(self.h, C.byref(F), C.byref(P), C.byref(R)))
+        self.F, self.P, self.R = F.value, P.value, R.value
+
+    def window_commit(self, F=None, P=None, R=None):
         _chk(self.L.ldso_ba_window_commit(self.h))
-        self.F, self.P, self.R = F, P, R
+        self._sync_dims()
+        assert (F is None or F == self.F) and (P is None or P == self.P) and (R is None or R == self.R), ((F, P, R), (self.F, self.P, self.R))
 
     def set_frames(self, frames, calib):
         fr = np.ascontiguousarray(frames)

@@ -1029,6 +1029,13 @@ int ldso_ba_set_chunk_points(ldso_ba_t *H, int points_per_workgroup) {
     if (H->D.P > 0) { CHK(hipSetDevice(H->device)); return rechunk(H); }
     return LDSO_OK;
 }
+int ldso_ba_get_dims(ldso_ba_t *H, int *F, int *P, int *R) {
+    REQ(H, "ldso_ba_get_dims: null handle");
+    if (F) *F = H->D.F;
+    if (P) *P = H->D.P;
+    if (R) *R = H->R;
+    return LDSO_OK;
+}
 int ldso_ba_get_chunk_cuts(ldso_ba_t *H, int32_t *ends, int cap, int *n_out) {
     REQ(H && n_out && H->D.P > 0, "ldso_ba_get_chunk_cuts: bad arguments / no window");
     const int n = (int) H->h_blocks.size();

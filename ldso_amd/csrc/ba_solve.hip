@@ -534,6 +534,9 @@ struct SolveIO {
 };
 
 typedef double __attribute__((ext_vector_type(4))) ld_d4;
+#ifndef LD_SKIP_DONE
+#define LD_SKIP_DONE 0          // experiment (round 6): finished tile columns of the 112 x 112 trailing update skipped (uniform branches): k_gn_solve 60.8 -> 63.5 us at C5 - not used
+#endif
 #ifndef LD_C7
 #define LD_C7 4          // columns per round of the 112 x 112 factorisation (VALU variant)
 #endif
@@ -848,21 +851,30 @@ _Pragma("unroll") \
         const int a0 = (k + C) >> 4, c0 = (k + C) & 15;
         double fi[NB][C], gj[NB][C];
 #pragma unroll
-        for (int a = 0; a < NB; a++)
+        for (int a = 0; a < NB; a++) {
+            if (NB > 4 && LD_SKIP_DONE && a < a0) {          // uniform: no live tile in this tile row / column any more
+#pragma unroll
+                for (int q = 0; q < C; q++) { fi[a][q] = 0.0; gj[a][q] = 0.0; }
+                continue;
+            }
 #pragma unroll
             for (int q2 = 0; q2 < C; q2 += 2) {
                 const double2 f0 = ld2(&sFp[(ty + 16 * a) * CP + q2]), g0 = ld2(&sGp[(tx + 16 * a) * CP + q2]);
                 fi[a][q2] = f0.x; fi[a][q2 + 1] = f0.y; gj[a][q2] = g0.x; gj[a][q2 + 1] = g0.y;
             }
+        }
+        // (tile columns left of the next panel are finished, their G is zero; skipping them - LD_SKIP_DONE - is slower: the round is a latency chain, not fma issue)
 #pragma unroll
-        for (int a = 0; a < NB; a++)
+        for (int b = 0; b < NB; b++) {
+            if (NB > 4 && LD_SKIP_DONE && b < a0) continue;          // uniform
 #pragma unroll
-            for (int b = 0; b <= a; b++) {
+            for (int a = b; a < NB; a++) {
                 double w = v[a * (a + 1) / 2 + b];
 #pragma unroll
                 for (int q = 0; q < C; q++) w = __builtin_fma(-fi[a][q], gj[b][q], w);
                 v[a * (a + 1) / 2 + b] = w;
             }
+        }
         // owners of columns k+C .. k+2C-1 publish them as the next panel
         const bool pub = (tx >= c0) && (tx < c0 + C);
 #pragma unroll
