@@ -236,6 +236,11 @@ int ldso_ba_gn_solve_reduced(ldso_ba_t *h, const void *reduce_buf_dev, int itera
  * fetched per handle as usual. */
 typedef struct ldso_ba_batch ldso_ba_batch_t;
 int ldso_ba_batch_create(ldso_ba_t *const *handles, int n, ldso_ba_batch_t **out);
+/* The chunking ldso_ba_batch_create applies, as host logic without a device (tests/test_batch_balance_cpu.py): n_seg runs of points that may share a chunk (one window's
+ * points of one host frame each, in launch order), n_wg workgroups, a chunk costing chunk_cost points on top of its own -> chunk_end[] (cumulative point counts, ascending,
+ * a chunk never spans two segments) and wg_first_chunk[n_wg + 1] (workgroup w works through the chunks [wg_first_chunk[w], wg_first_chunk[w + 1])), chosen so that the
+ * largest workgroup load (points + chunk_cost per chunk) is minimal for this greedy cut (bisection on the budget, *budget_out).  Returns the number of chunks. */
+int ldso_ba_balance_chunks(int n_seg, const int32_t *seg_points, int n_wg, int chunk_cost, int32_t *chunk_end, int cap, int32_t *wg_first_chunk, int64_t *budget_out);
 int ldso_ba_batch_enqueue_gn(ldso_ba_batch_t *b, int first_iteration, int iters);
 int ldso_ba_batch_destroy(ldso_ba_batch_t *b);
 /* points per workgroup ldso_ba_batch_create gave the windows of the batch - since round 6 the AVERAGE, rounded: the cuts are uneven, ldso_ba_get_chunk_cuts has

@@ -1724,19 +1724,16 @@ static int batch_refresh(ldso_ba_batch *Bt) {
 // (= one pass of linearize_body: operand staging, software-pipeline fill, block reduction) costs `c0` point-equivalents on top of its points, and never
 // straddles a host frame.  The smallest per-workgroup budget that fits all points into nWG workgroups is found by bisection; cuts[i] receives the chunk ends
 // of window i, wg the first chunk of every workgroup (nWG + 1 entries, counted over the windows [i0, i1) in order).
-static void balance_batch(ldso_ba *const *handles, int i0, int i1, int nWG, int c0, std::vector<std::vector<int32_t>> &cuts, std::vector<int32_t> &wg) {
-    struct Seg { int win, p0, n; };
-    std::vector<Seg> segs;
+// The balancer proper, host logic without a device (C-ABI: ldso_ba_balance_chunks, tests/test_batch_balance_cpu.py): segments (runs of points that may share a chunk: one
+// window's points of one host frame) in launch order -> chunk ends per segment (relative to the segment) and the first chunk of every workgroup.
+struct BalSeg { int owner, p0, n; };
+static long balance_segments(const std::vector<BalSeg> &segs, int nWG, int c0, std::vector<std::vector<int32_t>> *cutsByOwner, std::vector<int32_t> *wg, std::vector<int32_t> *flatEnds) {
     long total = 0;
-    for (int i = i0; i < i1; i++) {
-        const ldso_ba *H = handles[i];
-        int p = 0;
-        while (p < H->D.P) { int e = p; while (e < H->D.P && H->h_phost[e] == H->h_phost[p]) e++; segs.push_back(Seg{i, p, e - p}); total += e - p; p = e; }
-    }
+    for (const BalSeg &sg : segs) total += sg.n;
     auto run = [&](long budget, bool emit) -> bool {
         size_t si = 0; int used = 0;          // points of segs[si] already handed out
         int blocks = 0;
-        if (emit) { wg.assign(1, 0); for (int i = i0; i < i1; i++) cuts[i].clear(); }
+        if (emit) { if (wg) wg->assign(1, 0); if (flatEnds) flatEnds->clear(); }
         for (int w = 0; w < nWG && si < segs.size(); w++) {
             long left = budget;
             while (si < segs.size()) {
@@ -1746,19 +1743,48 @@ static void balance_batch(ldso_ba *const *handles, int i0, int i1, int nWG, int 
                 if (can < 1) can = 1;
                 int take = (int) std::min<long>(rem, can);
                 if (take < rem) { take = std::max(take / LD_WAVES * LD_WAVES, 1); if (rem - take < LD_WAVES) take = rem; }          // whole rounds of the workgroup's wavefronts, no crumbs left behind
-                if (emit) cuts[segs[si].win].push_back(segs[si].p0 + used + take);
+                if (emit) {
+                    if (cutsByOwner) (*cutsByOwner)[(size_t) segs[si].owner].push_back(segs[si].p0 + used + take);
+                    if (flatEnds) flatEnds->push_back(segs[si].p0 + used + take);
+                }
                 blocks++; left -= c0 + take; used += take;
                 if (used == segs[si].n) { si++; used = 0; }
                 if (left <= 0) break;
             }
-            if (emit) wg.push_back(blocks);
+            if (emit && wg) wg->push_back(blocks);
         }
-        if (emit) while ((int) wg.size() < nWG + 1) wg.push_back(blocks);
+        if (emit && wg) while ((int) wg->size() < nWG + 1) wg->push_back(blocks);
         return si == segs.size();
     };
-    long lo = total / nWG, hi = total + (long) c0 * (long) segs.size() + 1;
+    long lo = std::max<long>(1, total / std::max(nWG, 1)), hi = total + (long) c0 * (long) segs.size() + 1;
     while (lo < hi) { const long mid = (lo + hi) / 2; if (run(mid, false)) hi = mid; else lo = mid + 1; }
     run(lo, true);
+    return lo;
+}
+static void balance_batch(ldso_ba *const *handles, int i0, int i1, int nWG, int c0, std::vector<std::vector<int32_t>> &cuts, std::vector<int32_t> &wg) {
+    std::vector<BalSeg> segs;
+    for (int i = i0; i < i1; i++) {
+        const ldso_ba *H = handles[i];
+        cuts[i].clear();
+        int p = 0;
+        while (p < H->D.P) { int e = p; while (e < H->D.P && H->h_phost[e] == H->h_phost[p]) e++; segs.push_back(BalSeg{i, p, e - p}); p = e; }
+    }
+    balance_segments(segs, nWG, c0, &cuts, &wg, nullptr);
+}
+// host logic, no device: `n_seg` segments of seg_points[i] points each (in launch order; a chunk never spans two segments), `n_wg` workgroups, `chunk_cost` points of fixed
+// cost per chunk -> chunk_end[] (cumulative over ALL points, ascending, the last one = the total), wg_first_chunk[n_wg + 1]; returns the number of chunks (< 0: error / cap too small)
+int ldso_ba_balance_chunks(int n_seg, const int32_t *seg_points, int n_wg, int chunk_cost, int32_t *chunk_end, int cap, int32_t *wg_first_chunk, int64_t *budget_out) {
+    REQ(n_seg >= 1 && seg_points && n_wg >= 1 && chunk_cost >= 0 && chunk_end && wg_first_chunk, "ldso_ba_balance_chunks: bad arguments");
+    std::vector<BalSeg> segs;
+    int p = 0;
+    for (int i = 0; i < n_seg; i++) { REQ(seg_points[i] >= 1, "ldso_ba_balance_chunks: empty segment"); segs.push_back(BalSeg{0, p, seg_points[i]}); p += seg_points[i]; }
+    std::vector<int32_t> wg, ends;
+    const long budget = balance_segments(segs, n_wg, chunk_cost, nullptr, &wg, &ends);
+    if ((int) ends.size() > cap) { ldso_set_error("ldso_ba_balance_chunks: chunk_end[] too small"); return LDSO_E_INVALID; }
+    for (size_t i = 0; i < ends.size(); i++) chunk_end[i] = ends[i];
+    for (int w = 0; w <= n_wg; w++) wg_first_chunk[w] = wg[(size_t) w];
+    if (budget_out) *budget_out = budget;
+    return (int) ends.size();
 }
 
 int ldso_ba_batch_create(ldso_ba_t *const *handles, int n, ldso_ba_batch_t **out) {
