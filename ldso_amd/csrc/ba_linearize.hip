@@ -33,6 +33,15 @@
 #ifndef LD_LDG_PLAIN
 #define LD_LDG_PLAIN 0
 #endif
+#ifndef LD_STASH
+#define LD_STASH 1          // the records of the point in work wait in LDS (see STASH in linearize_body)
+#endif
+#ifndef LD_STASH_RD
+#define LD_STASH_RD 1
+#endif
+#ifndef LD_PEEL
+#define LD_PEEL 1
+#endif
 #ifndef LD_PIPE_ARGS
 #define LD_PIPE_ARGS 1          // the argument-based kernels (fix / linearised / marginalisation / dump passes) up to 8 key frames run the software pipeline too
 #endif
@@ -49,6 +58,9 @@ __device__ __forceinline__ float dpp_quad_xor1(float x) {   // quad_perm [1,0,3,
 }
 __device__ __forceinline__ float dpp_quad_xor2(float x) {   // quad_perm [2,3,0,1]
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dpp_quad_xor3(float x) {   // quad_perm [3,2,1,0]
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x1B, 0xF, 0xF, true));
 }
 __device__ __forceinline__ float dpp_half_mirror(float x) {   // lane i <-> 7-i within each 8-lane half row
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, true));
@@ -73,6 +85,29 @@ template <int J> __device__ __forceinline__ void group_bcast_pair(float x, int k
     const float a = dpp_quad_bcast<J>(x);           // lanes 0-3: x[J], lanes 4-7: x[4 + J]
     const float b = dpp_half_mirror(a);             // lanes 0-3: x[4 + J], lanes 4-7: x[J]
     lo = (k < 4) ? a : b; hi = (k < 4) ? b : a;
+}
+
+// lane-indexed choice among wave-uniform-per-slot values (k = pattern lane 0..7) as a binary tree over the bits of k: 7 (6: 5, 4: 3) v_cndmask with THREE lane masks.
+// Written with array elements in a chain of ternaries the choice became control flow (clang evaluates an array element of a conditional operator under a
+// branch; the chain of k == c branches is folded into a switch and lowered, for a divergent k, as a tree of exec-mask branches: ~14 vector + ~25 scalar
+// instructions per choice, round 6 ISA count) - scalar arguments of a function are selected.
+static __device__ __forceinline__ float sel2(const bool c, const float a, const float b) { return c ? a : b; }
+static __device__ __forceinline__ float selk8(const int k, const float a0, const float a1, const float a2, const float a3, const float a4, const float a5, const float a6, const float a7) {
+    const bool b0 = (k & 1) != 0, b1 = (k & 2) != 0, b2 = (k & 4) != 0;
+    const float l0 = sel2(b0, a1, a0), l1 = sel2(b0, a3, a2), l2 = sel2(b0, a5, a4), l3 = sel2(b0, a7, a6);
+    const float m0 = sel2(b1, l1, l0), m1 = sel2(b1, l3, l2);
+    return sel2(b2, m1, m0);
+}
+static __device__ __forceinline__ float selk4(const int k, const float a0, const float a1, const float a2, const float a3) {
+    const bool b0 = (k & 1) != 0, b1 = (k & 2) != 0;
+    return sel2(b1, sel2(b0, a3, a2), sel2(b0, a1, a0));
+}
+// k in 0..5 (lanes 6, 7 receive a4 / a5: their callers overwrite the result)
+static __device__ __forceinline__ float selk6(const int k, const float a0, const float a1, const float a2, const float a3, const float a4, const float a5) {
+    const bool b0 = (k & 1) != 0, b1 = (k & 2) != 0, b2 = (k & 4) != 0;
+    const float l0 = sel2(b0, a1, a0), l1 = sel2(b0, a3, a2), l2 = sel2(b0, a5, a4);
+    const float m0 = sel2(b1, l1, l0);
+    return sel2(b2, l2, m0);
 }
 
 // sum over the 8 lanes in the reference's sequential order ((((x0+x1)+x2)+...)+x7), result in all 8 lanes.
@@ -288,6 +323,8 @@ static __device__ __forceinline__ void load_pair(PairIn &q, const BaPtrs &B, con
 // What the front half of a slot group (pattern projection -> tap loads) hands to its back half (everything behind the image taps), one group
 // later: the 12 tap dwords (in flight) and the projected pixel.  PtStep: the inverse depth of the point after the fused point step.
 struct TapsG { float t[12]; float Ku, Kv; };
+// the bilinear sample of the target image at the projected pixel (I, dI/dx, dI/dy) - what is left of the taps once they have arrived
+struct Hit { float h0, h1, h2, Ku, Kv; };
 struct PtStep { float idp, idz; };
 
 // stepMode != 0 fuses the point part of resubstituteF_MT + backupState + doStepFromBackup (EnergyFunctional.cc:518-547,
@@ -320,14 +357,16 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
 
     // ---- LDS carve: pair structs of this host, float adjoints of this host, reduction scratch --------
     DevPair *sPair = (DevPair *) smem;                                  // [FS]
-    float *sAdH = smem + FS * (sizeof(DevPair) / 4);                    // [FS][64]
-    float *sAdT = sAdH + FS * 64;                                       // [FS][64]
-    float *sRed = sAdT + FS * 64;                                       // [LD_WAVES][FS][91] (+ topL [FS][91] when HAS_L)
+    float *sAd = smem + FS * (sizeof(DevPair) / 4);                     // [FS][8][8][2]: the float adjoints of (host, target) pairs, see the staging below
+    float *sRed = sAd + 2 * FS * 64;                                       // [LD_WAVES][FS][91] (+ topL [FS][91] when HAS_L)
     float *sTopL = sRed + LD_WAVES * FS * LD_TOPN;                        // [LD_WAVES][FS][91] when HAS_L: each (wave, slot) cell has ONE writer lane
     float *sXa = sTopL + (HAS_L ? LD_WAVES * FS * LD_TOPN : 0);                      // [FS][8] xAd of this host (stepMode)
     // [FS] level-0 image of every target frame: the per-lane pointer comes from LDS (64 cycles) instead of a dependent global load of the
     // descriptor's img[] table in front of every tap gather
     const float **sImg = (const float **) (sXa + FS * 8 + LD_TAIL_FLOATS);      // behind sE | sC | sN of the block reduction (see below)
+    // [LD_WAVES][2][2][64] x 16 bytes (one slot group per point, descriptor-based kernels): the records of the point in work wait here, written by the wavefront one point
+    // ahead (the software pipeline below) - each wavefront its own 4 KB, no barrier
+    float *sRec = (float *) (sImg + FS);
 
     if (gi.enable) {
         // initialise the HFinal / bFinal accumulator of the k_reduce that follows (lower triangle) with H_M and the diagonal
@@ -386,7 +425,12 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
 #pragma unroll
         for (int u = 0; u < NPB; u++) { const int i = tid + u * 64 * LD_WAVES; if (i < FS * PW) ((float *) sPair)[i] = pv[u]; }
 #pragma unroll
-        for (int u = 0; u < NAB; u++) { const int i = tid + u * 64 * LD_WAVES; if (i < FS * 64) { sAdH[i] = ahv[u]; sAdT[i] = atv[u]; } }
+        for (int u = 0; u < NAB; u++) {
+            // element (kk, j) of a pair's 8 x 8 adjoints at [t][kk][j ^ kk][target, host]: lane kk of a slot reads ITS row as four ds_read_b128 and meets the entry of
+            // column kk ^ r next to the r-th xor-permuted copy of the slot's JpJdF (the lifted Schur row below)
+            const int i = tid + u * 64 * LD_WAVES;
+            if (i < FS * 64) { const int kk = (i >> 3) & 7, e = (i & ~7) | ((i ^ kk) & 7); sAd[2 * e] = atv[u]; sAd[2 * e + 1] = ahv[u]; }
+        }
         if ((stepMode & 1) && tid < FS * 8) sXa[tid] = xav;
         if (tid < FS) sImg[tid] = B.img[(tid < F) ? tid : 0];          // slots behind F: a readable image (their taps are loaded and never used)
     }
@@ -448,10 +492,12 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
                 // idepth_hessian} as the solve that produced this step left them - two dwordx4 of ONE store instruction (round 3: seven stores)
                 const v16i_t b0 = ldg16<DESC, OFF_B0>(&B);
                 v4f_t *w_geo = GP(v4f_t, b0, BP_GEO);
-                if (lane == 1 || lane == 2) {
+                {
+                    // (every lane stores: odd lanes the dwords 4..7, even lanes the dwords 8..11 - 32 copies each, no exec-mask branch around the store)
+                    const bool l1 = (lane & 1) != 0;
                     v4f_t v;
-                    v.x = (lane == 1) ? ni : rHdi; v.y = (lane == 1) ? ni : rBd; v.z = (lane == 1) ? step : rIdH; v.w = (lane == 1) ? idp : 0.0f;
-                    AT(w_geo, p * 4 + (unsigned) lane) = v;
+                    v.x = l1 ? ni : rHdi; v.y = l1 ? ni : rBd; v.z = l1 ? step : rIdH; v.w = l1 ? idp : 0.0f;
+                    AT(w_geo, p * 4 + (l1 ? 1u : 2u)) = v;
                 }
             }
             idp = ni; idz = ni;
@@ -500,6 +546,24 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
     using M0 = std::integral_constant<int, 0>;
     auto front_g = [&](auto gc, const PtIn<NSG> &q, const PtStep &ps, TapsG &T) { front_x(gc, M0{}, q, RLF(q.rgeo, GEO_U), RLF(q.rgeo, GEO_V), ps.idp, T); };
 
+    // ================= the bilinear Vec3f sample of the target image (GlobalFuncs.h:89-103) from the taps the front half loaded ====================================
+    // (its own step since round 6: in the pipelined loop of one slot group per point it runs BEFORE the next point's front half, which then loads into the same
+    // registers - one set of 14 tap registers and no copy per point)
+    auto interp = [&](const TapsG &T) -> Hit {
+        Hit H;
+        const float Ku = T.Ku, Kv = T.Kv;
+        const int ix = (int) Ku, iy = (int) Kv;
+        const float dx = Ku - ix, dy = Kv - iy, dxdy = dx * dy;
+        const float a0 = T.t[0], a1 = T.t[1], a2 = T.t[2], b0_ = T.t[3], b1 = T.t[4], b2 = T.t[5];
+        const float c0_ = T.t[6], c1_ = T.t[7], c2_ = T.t[8], d0 = T.t[9], d1 = T.t[10], d2 = T.t[11];
+        const float w11 = dxdy, w01 = dy - dxdy, w10 = dx - dxdy, w00 = 1 - dx - dy + dxdy;
+        H.h0 = ((w11 * d0 + w01 * c0_) + w10 * b0_) + w00 * a0;
+        H.h1 = ((w11 * d1 + w01 * c1_) + w10 * b1) + w00 * a1;
+        H.h2 = ((w11 * d2 + w01 * c2_) + w10 * b2) + w00 * a2;
+        H.Ku = Ku; H.Kv = Kv;
+        return H;
+    };
+
     // ================= BACK half of a point: everything behind the image taps ================================================================
     // per-point state of the back half (set by back_begin, updated by back_g of every slot group, consumed by back_end)
     float pu = 0, pv = 0, priorF = 0, color = 0, wgt = 0, idp = 0, idz = 0, deltaF = 0;
@@ -532,10 +596,11 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
 
     // pair mode (PAIR): the per-point sums below live as "one point per half-wave" - lanes 0..31 hold point A's value, lanes 32..63 point B's.  MODE 1 / 2: a full pass
     // (8 slots) of point A / B, its slot sums go to that half only; MODE 3: the shared pass of the second slot group, sums per half-wave
+    float candE = -1.0f;          // energy of the point's residual into the newest frame without the outlier clamp (slot F - 1; candidate selection of the host)
     float gT0B = 0.0f;            // (pair mode) the first group's G entries of point B (gT[0]: point A's; gT[1]: the shared second group's)
     bool hasB = true;             // (pair mode) point B exists
     const int half = lane >> 5;
-    auto back_x = [&](auto gc, auto mc, const unsigned p, const PtIn<NSG> &q, const TapsG &T) {
+    auto back_x = [&](auto gc, auto mc, const unsigned p, const PtIn<NSG> &q, const Hit &T) {
         constexpr int g = decltype(gc)::value, MODE = decltype(mc)::value;
         auto ACC = [&](float &X, const float v) {
             if constexpr (MODE == 0) X += sum_slots(v, a16, a32);
@@ -591,20 +656,11 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
             // ---- pattern pixel projection at the current state: done by the front half (ResidualProjections.h:24-33) ---------
             const float Ku = T.Ku, Kv = T.Kv;
             bool pixOK = Ku > 1.1f && Kv > 1.1f && Ku < wM3G && Kv < hM3G;
-            // ---- bilinear Vec3f sample of the target image (GlobalFuncs.h:89-103) from the taps the front half loaded ---------------------
+            // ---- bilinear Vec3f sample of the target image: interp() above ---------------------
             float hit0 = 0, hit1 = 0, hit2 = 0;
             {
-                const int ix = (int) Ku, iy = (int) Kv;
-                const float dx = Ku - ix, dy = Kv - iy, dxdy = dx * dy;
-                (void) iy;
-                const float a0 = T.t[0], a1 = T.t[1], a2 = T.t[2], b0_ = T.t[3], b1 = T.t[4], b2 = T.t[5];
-                const float c0_ = T.t[6], c1_ = T.t[7], c2_ = T.t[8], d0 = T.t[9], d1 = T.t[10], d2 = T.t[11];
-                const float w11 = dxdy, w01 = dy - dxdy, w10 = dx - dxdy, w00 = 1 - dx - dy + dxdy;
-                const float h0 = ((w11 * d0 + w01 * c0_) + w10 * b0_) + w00 * a0;
-                const float h1 = ((w11 * d1 + w01 * c1_) + w10 * b1) + w00 * a1;
-                const float h2 = ((w11 * d2 + w01 * c2_) + w10 * b2) + w00 * a2;
                 const bool smp = compute && centerOK && pixOK;
-                hit0 = smp ? h0 : 0.0f; hit1 = smp ? h1 : 0.0f; hit2 = smp ? h2 : 0.0f;
+                hit0 = smp ? T.h0 : 0.0f; hit1 = smp ? T.h1 : 0.0f; hit2 = smp ? T.h2 : 0.0f;
             }
             bool laneBad = compute && (!centerOK || !pixOK || !isfinite(hit0));
             unsigned long long badMask = __ballot(laneBad);
@@ -679,8 +735,8 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
                     activeNew = 1;
                     // takeData (Residuals.h:123-128)
                     float v0 = JI00 * Jpdd0 + JI10 * Jpdd1, v1 = JI10 * Jpdd0 + JI11 * Jpdd1;
-                    float jx = (k == 0) ? x[4] : (k == 1) ? x[5] : (k == 2) ? x[6] : (k == 3) ? x[7] : (k == 4) ? x[8] : x[9];
-                    float jy = (k == 0) ? y[4] : (k == 1) ? y[5] : (k == 2) ? y[6] : (k == 3) ? y[7] : (k == 4) ? y[8] : y[9];
+                    const float jx = selk6(k, x[4], x[5], x[6], x[7], x[8], x[9]);
+                    const float jy = selk6(k, y[4], y[5], y[6], y[7], y[8], y[9]);
                     float j6 = JabJI00 * Jpdd0 + JabJI01 * Jpdd1, j7 = JabJI10 * Jpdd0 + JabJI11 * Jpdd1;
                     jp = (k < 6) ? (jx * v0 + jy * v1) : (k == 6 ? j6 : j7);
                 } else {
@@ -711,8 +767,8 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
             const float JI_r0 = sum8(resAcc * gx), JI_r1 = sum8(resAcc * gy);
             const float Jab_r0 = z10 * sum8(drdA * hw * resAcc), Jab_r1 = z11 * sum8(hw * resAcc), rr = sum8(resAcc * resAcc);
             if (accHere) {
-                const float xr1 = (k == 0) ? x[0] : (k == 1) ? x[1] : (k == 2) ? x[2] : (k == 3) ? x[3] : (k == 4) ? x[4] : (k == 5) ? x[5] : (k == 6) ? x[6] : x[7];
-                const float yr1 = (k == 0) ? y[0] : (k == 1) ? y[1] : (k == 2) ? y[2] : (k == 3) ? y[3] : (k == 4) ? y[4] : (k == 5) ? y[5] : (k == 6) ? y[6] : y[7];
+                const float xr1 = selk8(k, x[0], x[1], x[2], x[3], x[4], x[5], x[6], x[7]);
+                const float yr1 = selk8(k, y[0], y[1], y[2], y[3], y[4], y[5], y[6], y[7]);
                 const float t1a = __builtin_fmaf(JI00, xr1, JI10 * yr1), t1b = __builtin_fmaf(JI10, xr1, JI11 * yr1);
 #pragma unroll
                 for (int c = 0; c < 10; c++) accR[g][c] = __builtin_fmaf(t1a, x[c], __builtin_fmaf(t1b, y[c], accR[g][c]));
@@ -720,7 +776,7 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
                 accR[g][11] = __builtin_fmaf(xr1, JabJI10, __builtin_fmaf(yr1, JabJI11, accR[g][11]));
                 accR[g][12] = __builtin_fmaf(xr1, JI_r0, __builtin_fmaf(yr1, JI_r1, accR[g][12]));
                 // second row: 8, 9 (geometric) on lanes 0, 1; 10, 11 (affine) and 12 (residual) on lanes 2, 3, 4
-                const float xr2 = (k == 0) ? x[8] : x[9], yr2 = (k == 0) ? y[8] : y[9];
+                const float xr2 = sel2(k == 0, x[8], x[9]), yr2 = sel2(k == 0, y[8], y[9]);
                 const float t2a = __builtin_fmaf(JI00, xr2, JI10 * yr2), t2b = __builtin_fmaf(JI10, xr2, JI11 * yr2);
                 const float g8 = __builtin_fmaf(t2a, x[8], t2b * y[8]), g9 = __builtin_fmaf(t2a, x[9], t2b * y[9]);
                 const float g10 = __builtin_fmaf(xr2, JabJI00, yr2 * JabJI01), g11 = __builtin_fmaf(xr2, JabJI10, yr2 * JabJI11), g12 = __builtin_fmaf(xr2, JI_r0, yr2 * JI_r1);
@@ -813,14 +869,23 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
             // ================= lifted Schur row: target block and this slot's share of the host block ==
             float tgt = 0.0f, hpart = 0.0f;
             {
-                // all 8 components of JpJdF of this slot, gathered from the 8 lanes
-                float vj[8];
-                group_bcast_pair<0>(jp, k, vj[0], vj[4]); group_bcast_pair<1>(jp, k, vj[1], vj[5]);
-                group_bcast_pair<2>(jp, k, vj[2], vj[6]); group_bcast_pair<3>(jp, k, vj[3], vj[7]);
+                // component k of Ad^T JpJdF (target and host adjoint): lane k sums column k ^ r against the JpJdF component of lane k ^ r of its slot, r = 0..7 - the
+                // permuted copies are 7 DPP moves (i ^ 7 = half mirror, i ^ 4..6 = half mirror of i ^ 3..1) and both products one packed multiply-add per r.
+                // (Until round 6: all 8 components gathered into every lane - 8 DPP moves + 8 selects - and 16 multiply-adds whose operands the compiler packed with 12 moves.)
+                float vx[8];
+                vx[0] = jp; vx[1] = dpp_quad_xor1(jp); vx[2] = dpp_quad_xor2(jp); vx[3] = dpp_quad_xor3(jp); vx[7] = dpp_half_mirror(jp);
+                vx[6] = dpp_half_mirror(vx[1]); vx[5] = dpp_half_mirror(vx[2]); vx[4] = dpp_half_mirror(vx[3]);
                 if (exists && activeNew) {
-                    const float *aT = sAdT + t * 64 + k * 8, *aH = sAdH + t * 64 + k * 8;
+                    const v4f_t *ad = (const v4f_t *) (sAd + (t * 64 + k * 8) * 2);
+                    v2f_t acc = {0.0f, 0.0f};
 #pragma unroll
-                    for (int j = 0; j < 8; j++) { tgt = __builtin_fmaf(aT[j], vj[j], tgt); hpart = __builtin_fmaf(aH[j], vj[j], hpart); }
+                    for (int r = 0; r < 8; r += 2) {
+                        const v4f_t c = ad[r >> 1];
+                        const v2f_t c0_ = {c.x, c.y}, c1_ = {c.z, c.w}, v0_ = {vx[r], vx[r]}, v1_ = {vx[r + 1], vx[r + 1]};
+                        acc = __builtin_elementwise_fma(c0_, v0_, acc);
+                        acc = __builtin_elementwise_fma(c1_, v1_, acc);
+                    }
+                    tgt = acc.x; hpart = acc.y;
                 }
             }
             ACC(hostPart, hpart);
@@ -847,7 +912,8 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
                            : __builtin_bit_cast(float, (k == LD_SM_STATE) ? newState : (k == LD_SM_ACTIVE) ? activeNew : toRemove);
                 v2f_t e; e.x = (t < F) ? jp : 0.0f; e.y = (t < F) ? mOut : 0.0f;
                 if (MODE != 3 || hasB || half == 0) AT(o_slot, slot * 8 + (unsigned) k) = e;
-                if (k == 0 && t == F - 1 && (MODE != 3 || hasB || half == 0)) AT(o_cand, p) = ewo_;
+                if constexpr (PAIR) { if (k == 0 && t == F - 1 && (MODE != 3 || hasB || half == 0)) AT(o_cand, p) = ewo_; }
+                else { const int lf = (F - 1) - g * 8; if (lf >= 0 && lf < 8) candE = RLF(ewo_, lf * 8); (void) o_cand; }          // stored by back_end
                 if (k == 0 && t < F && doLin) energySum += ret;
             }
             if (!DESC && dumpJ != nullptr && compute) {          // (debug dump: the step-wise entry points only)
@@ -864,7 +930,7 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
             }
         }   // slot group
     };   // back_x
-    auto back_g = [&](auto gc, const unsigned p, const PtIn<NSG> &q, const TapsG &T) { back_x(gc, M0{}, p, q, T); };
+    auto back_g = [&](auto gc, const unsigned p, const PtIn<NSG> &q, const TapsG &T) { back_x(gc, M0{}, p, q, interp(T)); };
 
     auto back_end = [&](const unsigned p, const PtIn<NSG> &q) {
         (void) q;
@@ -894,24 +960,30 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
                 if (nActive == 0) val = 0.0f;
                 AT(Gall, g0 + 8u * (unsigned) t + (unsigned) k) = val;
             }
-            if (lane < LD_GEXTRA) {
-                float e = (lane == 0) ? Hc0 : (lane == 1) ? Hc1 : (lane == 2) ? Hc2 : (lane == 3) ? Hc3 : (lane == 4) ? bdSumF : (lane == 5) ? HdiF : 0.0f;
-                if (nActive == 0 && lane < 4) e = 0.0f;
-                AT(Gall, g0 + 8u * (unsigned) FS + (unsigned) lane) = e;
+            {
+                // (lane-indexed choices as select trees over the bits of the lane index, computed by every lane, and only the store under the lane condition: written as
+                // chains of lane == c they became a tree of exec-mask branches around the stores - which the in-order memory counter then cannot count, see the pipeline)
+                const bool z4 = nActive == 0;
+                const float e = selk8(lane & 7, z4 ? 0.0f : Hc0, z4 ? 0.0f : Hc1, z4 ? 0.0f : Hc2, z4 ? 0.0f : Hc3, bdSumF, HdiF, 0.0f, 0.0f);
+                // (stored by EVERY lane - eight copies of the same eight dwords: a store under a lane condition sits behind an exec-mask branch, which the in-order
+                // memory counter cannot count, and the wait for the next point's records in front of it becomes a wait for every store of this point)
+                static_assert(LD_GEXTRA == 8, "G row extras: one dword per lane & 7");
+                AT(Gall, g0 + 8u * (unsigned) FS + (unsigned) (lane & 7)) = e;
             }
             // the point's PtRec of the next set: lanes 0..3 store one dwordx4 each (ONE store instruction, 64 contiguous bytes); lane 4 the
             // accumulator scalars only the fetch functions read
             v4f_t *o_pt = GP(v4f_t, o0, RS_PT), *o_acc = GP(v4f_t, o0, RS_ACC);
-            if (lane < 4) {
+            {
+                const int l3 = lane & 3;
                 v4f_t v;
-                v.x = (lane == 0) ? HdiF : (lane == 1) ? HcdA0 : (lane == 2) ? HcdL0 : maxRelBS;
-                v.y = (lane == 0) ? bdSumF : (lane == 1) ? HcdA1 : (lane == 2) ? HcdL1 : __builtin_bit_cast(float, numGood);
-                v.z = (lane == 0) ? idH : (lane == 1) ? HcdA2 : (lane == 2) ? HcdL2 : 0.0f;
-                v.w = (lane == 0) ? __builtin_bit_cast(float, nActive) : (lane == 1) ? HcdA3 : (lane == 2) ? HcdL3 : 0.0f;
-                AT(o_pt, p * 4 + (unsigned) lane) = v;
-            } else if (lane == 4) {
-                v4f_t v; v.x = HddA; v.y = bdA; v.z = HddL; v.w = bdL;
-                AT(o_acc, p) = v;
+                v.x = selk4(l3, HdiF, HcdA0, HcdL0, maxRelBS);
+                v.y = selk4(l3, bdSumF, HcdA1, HcdL1, __builtin_bit_cast(float, numGood));
+                v.z = selk4(l3, idH, HcdA2, HcdL2, 0.0f);
+                v.w = selk4(l3, __builtin_bit_cast(float, nActive), HcdA3, HcdL3, 0.0f);
+                AT(o_pt, p * 4 + (unsigned) l3) = v;          // (every lane, sixteen copies of the same 64 bytes: see above)
+                v4f_t w; w.x = HddA; w.y = bdA; w.z = HddL; w.w = bdL;
+                AT(o_acc, p) = w;
+                if constexpr (!PAIR) { float *o_cand = GP(float, o0, RS_CAND); AT(o_cand, p) = candE; }
             }
             if (lane == 0) { nidSum += fabsf(idp); nidCnt++; }
         }
@@ -988,7 +1060,7 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
                 flagged = true; recNActive = 0;
                 // ---- first group of A (all 64 lanes) ----
                 pu = RLF(ca.rgeo, GEO_U); pv = RLF(ca.rgeo, GEO_V); color = ca.colA; wgt = ca.wgtA; idp = RLF(idpH, 0); idz = RLF(idzH, 0); deltaF = idp - idz;
-                back_x(G0{}, M1{}, pA, viewA0(ca), ta);
+                back_x(G0{}, M1{}, pA, viewA0(ca), interp(ta));
                 // ---- taps of the shared second group (per-lane point) ----
                 {
                     const float puH = HSEL(ca.rgeo, GEO_U), pvH = HSEL(ca.rgeo, GEO_V);
@@ -997,14 +1069,14 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
                 // ---- first group of B ----
                 if (hasB) {
                     pu = RLF(ca.rgeo, 32 + GEO_U); pv = RLF(ca.rgeo, 32 + GEO_V); color = ca.colB; wgt = ca.wgtB; idp = RLF(idpH, 32); idz = RLF(idzH, 32); deltaF = idp - idz;
-                    back_x(G0{}, M2{}, pB, viewB0(ca), tb);
+                    back_x(G0{}, M2{}, pB, viewB0(ca), interp(tb));
                 }
                 // ---- the next pair: point steps, first-group taps of its A ----
                 if (n1) pstep_pair(pA1, dAB1, cn, idpHn, idzHn);
                 front_x(G0{}, M0{}, viewA0(cn), RLF(cn.rgeo, GEO_U), RLF(cn.rgeo, GEO_V), RLF(idpHn, 0), tb);
                 // ---- the shared second group ----
                 pu = HSEL(ca.rgeo, GEO_U); pv = HSEL(ca.rgeo, GEO_V); color = half ? ca.colB : ca.colA; wgt = half ? ca.wgtB : ca.wgtA; idp = idpH; idz = idzH; deltaF = idp - idz;
-                back_x(G1{}, M3{}, pA + (half ? dAB : 0u), view1(ca, hasB), ta);
+                back_x(G1{}, M3{}, pA + (half ? dAB : 0u), view1(ca, hasB), interp(ta));
                 // ---- the two points' Schur rows: the half-wave values made wave-uniform, then the classic tail ----
                 {
                     const float H_ = HddA, b_ = bdA, c0_ = HcdA0, c1_ = HcdA1, c2_ = HcdA2, c3_ = HcdA3, hp_ = hostPart, g0A_ = gT[0], g1_ = gT[1];
@@ -1040,6 +1112,28 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
         using G0 = std::integral_constant<int, 0>;
         using G1 = std::integral_constant<int, NSG - 1>;
         constexpr bool PIPE = DESC || (NSG == 1 && LD_PIPE_ARGS);
+        // One slot group per point, descriptor-based kernels (round 6, second half): the records of the point in work are parked in the wavefront's own LDS by the
+        // iteration in front (two ds_write_b128) and read back where the back half starts (two ds_read_b128) instead of being rotated through a third register set
+        // (qa = qb, qb = qc: 16 vector moves per point of an issue-bound loop; LDS instructions have their own issue port)
+        constexpr bool STASH = DESC && NSG == 1 && !HAS_L && !FIX && LD_STASH;
+        int par = 0;
+        float *const myRec = sRec + wave * 1024 + lane * 4;          // [parity][half][lane][4 dwords]
+        auto stash = [&](const int pr_, const PtIn<NSG> &q) {
+            v4f_t a_, b_;
+            a_.x = q.rgeo; a_.y = q.rrec; a_.z = q.color; a_.w = q.wgt;
+            b_.x = __builtin_bit_cast(float, q.rflat[0]); b_.y = __builtin_bit_cast(float, q.rlin[0]); b_.z = q.jp[0]; b_.w = q.m[0];
+            *(v4f_t *) (myRec + pr_ * 512) = a_; *(v4f_t *) (myRec + pr_ * 512 + 256) = b_;
+        };
+        auto unstash = [&](const int pr_) {
+            const v4f_t a_ = *(const v4f_t *) (myRec + pr_ * 512), b_ = *(const v4f_t *) (myRec + pr_ * 512 + 256);
+            PtIn<NSG> q = {};
+            q.rgeo = a_.x; q.rrec = a_.y; q.color = a_.z; q.wgt = a_.w;
+            // (scalars first: __builtin_bit_cast on an ELEMENT of an ext-vector returns element 0 whatever the index - the trap of round 4, met again in round 6 the other
+            // way round: every residual's is-linearised flag read back as its index, every residual skipped, energies 0)
+            const float bx_ = b_.x, by_ = b_.y;
+            q.rflat[0] = __builtin_bit_cast(int, bx_); q.rlin[0] = __builtin_bit_cast(int, by_); q.jp[0] = b_.z; q.m[0] = b_.w;
+            return q;
+        };
         PtStep sa = {0, 0}, sb = {0, 0};
         TapsG ta = {}, tb = {};
 #if LD_STAMP_ON
@@ -1067,8 +1161,8 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
                 back_end(p, qa);
             } else {
             if constexpr (PIPE) load_point<NSG, HAS_L, FIX, DESC>(qb, B, cur, FS, (unsigned) (p0 + ((pi + LD_WAVES < np) ? pi + LD_WAVES : pi)), s, k, lane);
-#pragma clang loop unroll(disable)
-            do {
+            if constexpr (STASH) stash(0, qa);
+            auto one_point = [&]() {
                 const unsigned p = (unsigned) (p0 + pi);
                 const bool n1 = pi + LD_WAVES < np, n2 = pi + 2 * LD_WAVES < np;
                 const unsigned p1 = n1 ? p + LD_WAVES : p, p2 = n2 ? p + 2 * LD_WAVES : p1;
@@ -1084,20 +1178,39 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
                     back_end(p, qa);
                 } else if constexpr (NSG == 1) {
                     LCYC(0);
+                    Hit ha = interp(ta);          // the taps of this point are consumed here: the next point's go into the same registers
+                    // (pinned: the sample is plain arithmetic, which the compiler sinks to its first use - behind the next point's tap loads, with the old taps alive across
+                    // them in a second register set and 14 moves per point)
+                    asm volatile("" : "+v"(ha.h0), "+v"(ha.h1), "+v"(ha.h2), "+v"(ha.Ku), "+v"(ha.Kv));
+                    if constexpr (STASH) stash(par ^ 1, qb);
                     if (n1) sb = pstep(p1, qb);          // (the fused point step stores: only for a real next point)
-                    front_g(G0{}, qb, sb, tb);
+                    front_g(G0{}, qb, sb, ta);
                     LCYC(1);          // point step + projection + tap issue of the next point
                     load_point<NSG, HAS_L, FIX, DESC>(qc, B, cur, FS, p2, s, k, lane);
                     LCYC(2);          // record loads issued
+#if LD_STASH_RD
+                    if constexpr (STASH) qa = unstash(par);
+#endif
+#ifdef LD_STASH_DBG
+                    if constexpr (STASH) {
+                        const PtIn<NSG> t_ = unstash(par);
+                        auto ne = [](float a, float b) { return __builtin_bit_cast(int, a) != __builtin_bit_cast(int, b); };
+                        const bool mm[8] = {ne(t_.rgeo, qa.rgeo), ne(t_.rrec, qa.rrec), ne(t_.color, qa.color), ne(t_.wgt, qa.wgt), t_.rflat[0] != qa.rflat[0], t_.rlin[0] != qa.rlin[0], ne(t_.jp[0], qa.jp[0]), ne(t_.m[0], qa.m[0])};
+                        for (int u = 0; u < 8; u++) if (mm[u]) B.energyLog[40 + u] = (double) (p + 1) + 1e-3 * (double) lane + 1e-6 * (double) (pi - waveU);
+                        if (lane == 0 && wave == 0) B.energyLog[48] += 1.0;
+                        if (mm[5]) { B.energyLog[49] = (double) t_.rlin[0]; B.energyLog[50] = (double) qa.rlin[0]; B.energyLog[51] = (double) t_.rflat[0]; B.energyLog[52] = (double) (s * 8 + k); atomicAdd(&B.energyLog[53], 1.0); }
+                        if (lane == 0) atomicAdd(&B.energyLog[54], 1.0);
+                    }
+#endif
                     back_begin(p, qa, sa);
-                    back_g(G0{}, p, qa, ta);
+                    back_x(G0{}, M0{}, p, qa, ha);
                     back_end(p, qa);
                     LCYC(3);          // everything behind the taps of this point
 #if LD_STAMP_ON
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
                     LCYC(4);          // what is still in flight at the end of the iteration (stamps build only: waits for the stores too)
-                    ta = tb;
+                    par ^= 1;
                 } else {
                     LCYC(0);
                     front_g(G1{}, qa, sa, tb);
@@ -1116,9 +1229,23 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
 #endif
                     LCYC(4);
                 }
-                if constexpr (PIPE) { qa = qb; qb = qc; sa = sb; }
+                if constexpr (PIPE) {
+                    if constexpr (STASH && LD_STASH_RD) { qb = qc; sa = sb; }          // (qc is loaded behind the last use of qb: the same registers, no copy)
+                    else { qa = qb; qb = qc; sa = sb; }
+                }
                 pi += LD_WAVES;
-            } while (pi < np);
+            };
+            if constexpr (STASH && LD_PEEL) {
+                // The first point peeled off the loop: the wait for the next point's records (the top of the body) counts the stores issued behind their loads, and at
+                // the loop header the compiler takes the minimum over the ways into it - entered straight from the prologue (no store yet) that is vmcnt(0) for every
+                // iteration, i.e. a wait for the stores of the point just finished; entered from a copy of the body it is vmcnt(<stores per point>)
+                one_point();
+#pragma clang loop unroll(disable)
+                while (pi < np) one_point();
+            } else {
+#pragma clang loop unroll(disable)
+                do one_point(); while (pi < np);
+            }
             }
         }
 #if LD_STAMP_ON
@@ -1247,7 +1374,7 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize_one(OneArgs a) {
 // ---------------------------------------------------------------------------------------------------------
 size_t ba_linearize_lds_bytes(int FS, bool hasL) {
     size_t fl = (size_t) FS * (sizeof(DevPair) / 4) + 2 * (size_t) FS * 64 + (size_t) LD_WAVES * FS * LD_TOPN + (hasL ? (size_t) LD_WAVES * FS * LD_TOPN : 0) + (size_t) FS * 8 + LD_TAIL_FLOATS + 2 * (size_t) FS;
-    return fl * sizeof(float) + 256;
+    return fl * sizeof(float) + 256 + (FS == 8 ? (size_t) LD_WAVES * 4096 : 0);          // + the record stash of the one-slot-group kernels
 }
 
 template <int NSG, bool HAS_L, bool FIX, bool MARG = false>
