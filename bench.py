@@ -481,6 +481,23 @@ def batch_parity_check(win, ba):
     return {"energy_gpu": e_gpu, "energy_oracle_at_that_state": e_orc, "rel": rel, "residual_states_differing": mism, "ok": bool(np.isfinite(e_gpu) and rel <= 1e-4)}
 
 
+def batch_trajectory_check(win, ba):
+    """OUTSIDE the timed region (oracle = checker only): the window was taken through exactly 10 forced GN iterations BY THE BATCHED LAUNCHES from its initial state;
+    the oracle runs its own FullSystem::optimize loop for 10 forced iterations from the same initial state, and re-evaluates the state the batch reached - the two
+    energies must agree (1e-4 relative, north_star).  batch_parity_check alone accepts ANY finite state (it asks whether the GPU's energy for a state is the oracle's
+    energy for that state): a batched kernel that skipped every residual passed it in round 6 until the test suite caught it."""
+    from oracle import pyoracle as po
+    res = ba.get_residuals()
+    w2 = transplant(win, ba.get_frames(), ba.get_points(), res)
+    o = po.OracleWindow(w2); o.collect_active(reset_oob=False)
+    e_state = o.linearize_all(False); o.close()
+    o2 = po.OracleWindow(win); o2.set_force_all_iterations(True); o2.optimize(10)
+    eo = o2.energy_log(); o2.close()
+    rel = abs(e_state - eo[-1]) / abs(eo[-1])
+    return {"energy_of_the_batch_state_after_10_iterations_by_the_oracle": e_state, "energy_after_the_oracle_s_own_10_iterations": float(eo[-1]), "energy_before": float(eo[0]),
+            "rel": rel, "ok": bool(np.isfinite(e_state) and rel <= 1e-4)}
+
+
 def batched_line(args, local_rank, Bs=(8, 32), min_timed_s=0.2):
     """Batched windows: B independent C3 windows per launch (ldso_ba_batch_*), three launches per iteration for the
     whole batch.  Aggregate GN iterations/s over the batch, the roofline of the batched k_linearize (B x the algorithmic bytes of
@@ -491,7 +508,7 @@ def batched_line(args, local_rank, Bs=(8, 32), min_timed_s=0.2):
     tstream = torch.cuda.Stream()
     torch.cuda.set_stream(tstream)
     out = {"workload": f"B independent, DIFFERENT C3 windows (seeds 20260925 + i: own scene, images, poses, points; {win.F} KF x {win.P} pt, R = {win.R}) per launch, forced GN iterations"}
-    handles, wins = [], []
+    handles, wins, iterated = [], [], set()
     for B in Bs:
         while len(handles) < B:
             wi = win if not handles else synth.add_synthetic_prior(synth.make_config("C3", seed=20260925 + len(handles)))
@@ -500,6 +517,15 @@ def batched_line(args, local_rank, Bs=(8, 32), min_timed_s=0.2):
             handles.append(g); wins.append(wi)
         bt = binding.BABatch(handles[:B])
         bt.enqueue_gn(0, 10); torch.cuda.synchronize()
+        # the trajectory of the batched launches against the oracle's own 10 iterations, on the windows of this batch that start from their initial state (the first and
+        # the last of them); the batch is taken apart for it (handles back on their own chunking and residual sets) and formed again
+        fresh = [i for i in range(B) if i not in iterated]
+        traj = {}
+        if fresh:
+            bt.close()
+            traj = {f"window_{i}": batch_trajectory_check(wins[i], handles[i]) for i in sorted({fresh[0], fresh[-1]})}
+            bt = binding.BABatch(handles[:B])
+        iterated.update(range(B))
         blocks, total, steps = [], 0.0, 50
         while total < min_timed_s or len(blocks) < 3:
             t0 = time.perf_counter()
@@ -516,7 +542,8 @@ def batched_line(args, local_rank, Bs=(8, 32), min_timed_s=0.2):
         # the oracle on what the timed batch left behind: the first and the last window of the batch (handles back on their own chunking)
         par = {f"window_{i}": batch_parity_check(wins[i], handles[i]) for i in sorted({0, B - 1})}
         par["tolerance"] = 1e-4
-        par["ok"] = bool(all(v["ok"] for k, v in par.items() if k.startswith("window_")))
+        par["first_10_iterations"] = traj
+        par["ok"] = bool(all(v["ok"] for k, v in par.items() if k.startswith("window_")) and all(v["ok"] for v in traj.values()))
         prof = _batch_profile_figures(B)
         us = max(lin_us, prof.get("rocprofv3_us", 0.0))          # as for the headline: the longer of the live and the committed duration
         roof = {"bound": "hbm", "kernel": "k_linearize_batch (all B windows in one launch)", "achieved": round(alg / (us * 1e-6) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",

@@ -36,9 +36,6 @@
 #ifndef LD_STASH
 #define LD_STASH 1          // the records of the point in work wait in LDS (see STASH in linearize_body)
 #endif
-#ifndef LD_STASH_RD
-#define LD_STASH_RD 1
-#endif
 #ifndef LD_PEEL
 #define LD_PEEL 1
 #endif
@@ -1188,20 +1185,7 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
                     LCYC(1);          // point step + projection + tap issue of the next point
                     load_point<NSG, HAS_L, FIX, DESC>(qc, B, cur, FS, p2, s, k, lane);
                     LCYC(2);          // record loads issued
-#if LD_STASH_RD
                     if constexpr (STASH) qa = unstash(par);
-#endif
-#ifdef LD_STASH_DBG
-                    if constexpr (STASH) {
-                        const PtIn<NSG> t_ = unstash(par);
-                        auto ne = [](float a, float b) { return __builtin_bit_cast(int, a) != __builtin_bit_cast(int, b); };
-                        const bool mm[8] = {ne(t_.rgeo, qa.rgeo), ne(t_.rrec, qa.rrec), ne(t_.color, qa.color), ne(t_.wgt, qa.wgt), t_.rflat[0] != qa.rflat[0], t_.rlin[0] != qa.rlin[0], ne(t_.jp[0], qa.jp[0]), ne(t_.m[0], qa.m[0])};
-                        for (int u = 0; u < 8; u++) if (mm[u]) B.energyLog[40 + u] = (double) (p + 1) + 1e-3 * (double) lane + 1e-6 * (double) (pi - waveU);
-                        if (lane == 0 && wave == 0) B.energyLog[48] += 1.0;
-                        if (mm[5]) { B.energyLog[49] = (double) t_.rlin[0]; B.energyLog[50] = (double) qa.rlin[0]; B.energyLog[51] = (double) t_.rflat[0]; B.energyLog[52] = (double) (s * 8 + k); atomicAdd(&B.energyLog[53], 1.0); }
-                        if (lane == 0) atomicAdd(&B.energyLog[54], 1.0);
-                    }
-#endif
                     back_begin(p, qa, sa);
                     back_x(G0{}, M0{}, p, qa, ha);
                     back_end(p, qa);
@@ -1230,7 +1214,7 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
                     LCYC(4);
                 }
                 if constexpr (PIPE) {
-                    if constexpr (STASH && LD_STASH_RD) { qb = qc; sa = sb; }          // (qc is loaded behind the last use of qb: the same registers, no copy)
+                    if constexpr (STASH) { qb = qc; sa = sb; }          // (qc is loaded behind the last use of qb: the same registers, no copy)
                     else { qa = qb; qb = qc; sa = sb; }
                 }
                 pi += LD_WAVES;

@@ -26,4 +26,4 @@ if pt is not None and len(bad):
 eo, eg = ro["out"]["state_NewEnergy"], rg["out"]["state_NewEnergy"]
 d = np.abs(eo - eg) > 1e-3 * np.maximum(1, np.abs(eo))
 print("energy differs", d.sum())
-g.get_energy_log(); print("stash debug", g._dbg)
+
