@@ -326,6 +326,30 @@ def test_window_shape_boundaries(F, P):
     assert rel(g2.get_energy_log(), o2.energy_log()) < tol
 
 
+@pytest.mark.parametrize("F,P,per_wave", [(5, 2600, "2 points in four wavefronts, 1 in the others"), (7, 5700, "3 points per wavefront, ragged last chunk"), (8, 9000, "4-5 points per wavefront")])
+def test_pipelined_point_loop_of_the_single_window_kernel(F, P, per_wave):
+    """k_linearize_one<1> above 8 points per chunk: the software pipeline with the point's records parked in LDS and the first point peeled off the loop (round 6) - chunk
+    sizes that leave the wavefronts of a workgroup with DIFFERENT numbers of points (a wavefront with one point runs the peeled iteration only).  One stage-wise pass and
+    three fast-path iterations against the oracle: energies 1e-4, residual states bit for bit.  (Round 6: a bit-cast on a vector element made this loop read every residual's
+    is-linearised flag as its index - energies 0; the full-size C4 test was the only one with more than 8 points per chunk.)"""
+    win = synth.make_window(F=F, P=P, w=320, h=240, fx=200.0, seed=600 + F)
+    o = po.OracleWindow(win); g = binding.BA.from_window(win)
+    cuts = np.asarray(g.get_chunk_cuts())
+    sizes = np.diff(np.concatenate([[0], cuts]))
+    assert sizes.max() > 8, (per_wave, sizes.max())
+    o.collect_active(); g.collect_active()
+    Eo, Eg = o.linearize_all(False), g.linearize_all(False)
+    assert abs(Eo - Eg) <= TOL * Eo
+    assert np.array_equal(o.get_residuals(False)["out"]["state_NewState"], g.get_residuals()["out"]["state_NewState"])
+    o.close(); g.close()
+    o2 = po.OracleWindow(win); o2.set_force_all_iterations(True)
+    g2 = binding.BA.from_window(win)
+    rmo = o2.optimize(3); rmg, its = g2.optimize(3, force_all=True)
+    assert its == 3 and abs(rmo - rmg) <= 5 * TOL * rmo
+    assert rel(g2.get_energy_log(), o2.energy_log()) < 5 * TOL
+    o2.close(); g2.close()
+
+
 @pytest.mark.parametrize("name", ["C3", "C4"])
 def test_full_size_parity_and_properties(name):
     """BASELINE configs at full size: one stage-wise pass against the oracle plus size-independent properties."""
