@@ -36,6 +36,9 @@
 #ifndef LD_STASH
 #define LD_STASH 1          // the records of the point in work wait in LDS (see STASH in linearize_body)
 #endif
+#ifndef LD_STASH_LM
+#define LD_STASH_LM 1          // ... and its uniform fields are read from there (ds_read_b32) instead of by v_readlane / DPP broadcasts
+#endif
 #ifndef LD_PEEL
 #define LD_PEEL 1
 #endif
@@ -203,6 +206,7 @@ struct PtIn {
     float color, wgt;
     int rflat[NSG], rlin[NSG], rnew[NSG], rlidx[NSG];     // SlotTab of this lane's slot(s)
     float jp[NSG], m[NSG];        // this lane's pair of the slot record: JpJdF[k] and scalar k (LD_SM_*; integers as raw bits)
+    const float *ls;              // where the point's records are parked in the wavefront's LDS (STASH, linearize_body): [64 lanes][rgeo, rrec, colour, weight] | [64 lanes][rflat, rlin, jp, m]
 };
 // dword i of a record held one-dword-per-lane (wave-uniform result: a scalar register)
 #define RLF(v, i) __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, (v)), (i)))
@@ -458,30 +462,43 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
     int nidCnt = 0;
 
     // ================= FRONT half, per point: the fused point step ===============================================================
-    auto pstep = [&](const unsigned p, const PtIn<NSG> &q) -> PtStep {
-        float idp = RLF(q.rgeo, GEO_IDP), idz = RLF(q.rgeo, GEO_IDZ);
+    // Dword i of the point's PtGeo / PtRec and the uniform scalars of a slot record (the m of lane j of its 8-lane group).  From registers: v_readlane (PtGeo / PtRec
+    // arrive one dword per lane) and a DPP broadcast + select.  LM = true (the pipelined loop of the one-slot-group descriptor kernels, whose records are parked in LDS
+    // anyway): ONE ds_read_b32 each, every lane the same address (or its slot's) - the loop is bound by vector-instruction issue and the LDS port is idle
+    // (37 v_readlane + ~25 DPP moves / selects per point, round 6)
+    using LM0 = std::false_type;
+    auto qgeo = [&](auto lc, const PtIn<NSG> &q, const int i) -> float { if constexpr (decltype(lc)::value) return q.ls[i * 4]; else return RLF(q.rgeo, i); };
+    auto qrec = [&](auto lc, const PtIn<NSG> &q, const int i) -> float { if constexpr (decltype(lc)::value) return q.ls[i * 4 + 1]; else return RLF(q.rrec, i); };
+    auto qreci = [&](auto lc, const PtIn<NSG> &q, const int i) -> int { const float f_ = qrec(lc, q, i); return __builtin_bit_cast(int, f_); };
+    auto qmlane = [&](auto lc, auto jc, const PtIn<NSG> &q, const int g) -> float {          // m of lane j (3: energy, 5: state, 6: activity) of this lane's slot
+        constexpr int j = decltype(jc)::value;
+        if constexpr (decltype(lc)::value) return q.ls[256 + (s * 8 + j) * 4 + 3];
+        else { float lo, hi; group_bcast_pair<(j & 3)>(q.m[g], k, lo, hi); return (j < 4) ? lo : hi; }
+    };
+    using J3 = std::integral_constant<int, 3>; using J5 = std::integral_constant<int, 5>; using J6 = std::integral_constant<int, 6>;
+    auto pstepT = [&](auto lc, const unsigned p, const PtIn<NSG> &q) -> PtStep {
+        float idp = qgeo(lc, q, GEO_IDP), idz = qgeo(lc, q, GEO_IDZ);
         if (stepMode & 1) {
             // ---- resubstituteFPt for this point, then backupState + doStepFromBackup (stepfacD = 1) ------------
-            const float rHdi = RLF(q.rrec, REC_HDI), rBd = RLF(q.rrec, REC_BDSUM), rIdH = RLF(q.rrec, REC_IDH);
+            const float rHdi = qrec(lc, q, REC_HDI), rBd = qrec(lc, q, REC_BDSUM), rIdH = qrec(lc, q, REC_IDH);
             float step = 0.0f;
-            if (RLI(q.rrec, REC_NACT) > 0) {
+            if (__builtin_amdgcn_readfirstlane(qreci(lc, q, REC_NACT)) > 0) {
                 float b = rBd;
                 float dot = 0;
-                dot += xc0 * (RLF(q.rrec, REC_HCDA + 0) + RLF(q.rrec, REC_HCDL + 0)); dot += xc1 * (RLF(q.rrec, REC_HCDA + 1) + RLF(q.rrec, REC_HCDL + 1));
-                dot += xc2 * (RLF(q.rrec, REC_HCDA + 2) + RLF(q.rrec, REC_HCDL + 2)); dot += xc3 * (RLF(q.rrec, REC_HCDA + 3) + RLF(q.rrec, REC_HCDL + 3));
+                dot += xc0 * (qrec(lc, q, REC_HCDA + 0) + qrec(lc, q, REC_HCDL + 0)); dot += xc1 * (qrec(lc, q, REC_HCDA + 1) + qrec(lc, q, REC_HCDL + 1));
+                dot += xc2 * (qrec(lc, q, REC_HCDA + 2) + qrec(lc, q, REC_HCDL + 2)); dot += xc3 * (qrec(lc, q, REC_HCDA + 3) + qrec(lc, q, REC_HCDL + 3));
                 b -= dot;
 #pragma unroll
                 for (int g = 0; g < NSG; g++) {
                     const int t = g * 8 + s;
                     // the activity flag of the slot record sits in the m of lane 6 of its 8-lane group
-                    float l2, h2;
-                    group_bcast_pair<2>(q.m[g], k, l2, h2); (void) l2;
+                    const float h2 = qmlane(lc, J6{}, q, g);
                     const bool act = (t < F) && (q.rflat[g] >= 0) && (__builtin_bit_cast(int, h2) != 0);
                     float sres = seq8(sXa[t * 8 + k] * q.jp[g], k, lane);
                     sres = act ? sres : 0.0f;
                     b -= sum_slots(sres, a16, a32);
                 }
-                if (isfinite(b)) step = -b * rHdi; else { step = RLF(q.rgeo, GEO_STEP); if (lane == 0) *(gptr_t<double>) (unsigned long long) (B.scalars + 4) = 1.0; }
+                if (isfinite(b)) step = -b * rHdi; else { step = qgeo(lc, q, GEO_STEP); if (lane == 0) *(gptr_t<double>) (unsigned long long) (B.scalars + 4) = 1.0; }
             }
             const float ni = idp + 1.0f * step;
             {
@@ -502,16 +519,16 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
         PtStep r; r.idp = idp; r.idz = idz;
         return r;
     };
+    auto pstep = [&](const unsigned p, const PtIn<NSG> &q) -> PtStep { return pstepT(LM0{}, p, q); };
     // ================= FRONT half, per slot group: pattern projection, tap loads ====================================================
     // MODE 0: the lanes' slots are the targets g * 8 + s of ONE point.  MODE 3 (PAIR, second slot group of windows of 9..12 key frames): lanes 0..31 hold the targets
     // 8..11 of point A, lanes 32..63 the targets 8..11 of point B - pu / pv / idp are per-lane values then
-    auto front_x = [&](auto gc, auto mc, const PtIn<NSG> &q, const float pu, const float pv, const float idp, TapsG &T) {
+    auto front_xT = [&](auto lc, auto gc, auto mc, const PtIn<NSG> &q, const float pu, const float pv, const float idp, TapsG &T) {
         constexpr int g = decltype(gc)::value, MODE = decltype(mc)::value;
 #if LD_OPAQUE_K
         int k = k_; asm volatile("" : "+v"(k));
 #endif
-        float l1, h1;
-        group_bcast_pair<1>(q.m[g], k, l1, h1); (void) l1;          // the state of the slot record: m of lane 5 of the group
+        const float h1 = qmlane(lc, J5{}, q, g);          // the state of the slot record: m of lane 5 of the group
         const int qState = __builtin_bit_cast(int, h1);
         const int t = (MODE == 3) ? 8 + (s & 3) : g * 8 + s;
         const bool exists = (t < F) && (q.rflat[g] >= 0);           // MARG: the flag of the point is read by the back half; unflagged points load taps nobody uses
@@ -541,7 +558,9 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
         T.t[6] = r1a.x; T.t[7] = r1a.y; T.t[8] = r1a.z; T.t[9] = r1a.w; T.t[10] = r1b.x; T.t[11] = r1b.y;
     };
     using M0 = std::integral_constant<int, 0>;
-    auto front_g = [&](auto gc, const PtIn<NSG> &q, const PtStep &ps, TapsG &T) { front_x(gc, M0{}, q, RLF(q.rgeo, GEO_U), RLF(q.rgeo, GEO_V), ps.idp, T); };
+    auto front_x = [&](auto gc, auto mc, const PtIn<NSG> &q, const float pu, const float pv, const float idp, TapsG &T) { front_xT(LM0{}, gc, mc, q, pu, pv, idp, T); };
+    auto front_gT = [&](auto lc, auto gc, const PtIn<NSG> &q, const PtStep &ps, TapsG &T) { front_xT(lc, gc, M0{}, q, qgeo(lc, q, GEO_U), qgeo(lc, q, GEO_V), ps.idp, T); };
+    auto front_g = [&](auto gc, const PtIn<NSG> &q, const PtStep &ps, TapsG &T) { front_gT(LM0{}, gc, q, ps, T); };
 
     // ================= the bilinear Vec3f sample of the target image (GlobalFuncs.h:89-103) from the taps the front half loaded ====================================
     // (its own step since round 6: in the pipelined loop of one slot group per point it runs BEFORE the next point's front half, which then loads into the same
@@ -572,13 +591,13 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
     float maxRelBS = 0.0f;
     int numGood = 0, nActive = 0;
     float gT[NSG];
-    auto back_begin = [&](const unsigned p, const PtIn<NSG> &q, const PtStep &ps) {
-        pu = RLF(q.rgeo, GEO_U); pv = RLF(q.rgeo, GEO_V);
-        priorF = MARG ? RLF(q.rgeo, GEO_PRIOR) * S.idepthFixPriorMargFac : RLF(q.rgeo, GEO_PRIOR);
+    auto back_beginT = [&](auto lc, const unsigned p, const PtIn<NSG> &q, const PtStep &ps) {
+        pu = qgeo(lc, q, GEO_U); pv = qgeo(lc, q, GEO_V);
+        priorF = MARG ? qgeo(lc, q, GEO_PRIOR) * S.idepthFixPriorMargFac : qgeo(lc, q, GEO_PRIOR);
         flagged = MARG ? (margFlags[p] != 0) : true;
         color = q.color; wgt = q.wgt;
         idp = ps.idp; idz = ps.idz;
-        recNActive = RLI(q.rrec, REC_NACT);
+        recNActive = qreci(lc, q, REC_NACT);
         deltaF = idp - idz;
         HddA = 0; bdA = 0; HcdA0 = 0; HcdA1 = 0; HcdA2 = 0; HcdA3 = 0;
         HddL = 0; bdL = 0; HcdL0 = 0; HcdL1 = 0; HcdL2 = 0; HcdL3 = 0;
@@ -586,10 +605,11 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
         // AccumulatedSCHessian.cc:14-21: the SOLVE that finds a point without an active residual zeroes its maxRelBaseline - i.e. the solve whose
         // point step is fused in front of this pass (PtRec.nActive = active residuals of the linearisation that solve used).  A pass that is followed
         // by no solve (the last linearizeAll(false) of optimize(), the fixing pass) zeroes nothing.
-        maxRelBS = ((stepMode & 1) && recNActive <= 0) ? 0.0f : RLF(q.rrec, REC_MAXRELBS);
-        numGood = RLI(q.rrec, REC_NUMGOOD);
+        maxRelBS = ((stepMode & 1) && recNActive <= 0) ? 0.0f : qrec(lc, q, REC_MAXRELBS);
+        numGood = qreci(lc, q, REC_NUMGOOD);
         nActive = 0;
     };
+    auto back_begin = [&](const unsigned p, const PtIn<NSG> &q, const PtStep &ps) { back_beginT(LM0{}, p, q, ps); };
 
     // pair mode (PAIR): the per-point sums below live as "one point per half-wave" - lanes 0..31 hold point A's value, lanes 32..63 point B's.  MODE 1 / 2: a full pass
     // (8 slots) of point A / B, its slot sums go to that half only; MODE 3: the shared pass of the second slot group, sums per half-wave
@@ -597,7 +617,7 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
     float gT0B = 0.0f;            // (pair mode) the first group's G entries of point B (gT[0]: point A's; gT[1]: the shared second group's)
     bool hasB = true;             // (pair mode) point B exists
     const int half = lane >> 5;
-    auto back_x = [&](auto gc, auto mc, const unsigned p, const PtIn<NSG> &q, const Hit &T) {
+    auto back_xT = [&](auto lc, auto gc, auto mc, const unsigned p, const PtIn<NSG> &q, const Hit &T) {
         constexpr int g = decltype(gc)::value, MODE = decltype(mc)::value;
         auto ACC = [&](float &X, const float v) {
             if constexpr (MODE == 0) X += sum_slots(v, a16, a32);
@@ -611,10 +631,8 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
         int qState[NSG], qActive[NSG];
         float qEnergy[NSG];
         {
-            float l1, h1, l2, h2, l3, h3;
-            group_bcast_pair<1>(q.m[g], k, l1, h1); group_bcast_pair<2>(q.m[g], k, l2, h2); group_bcast_pair<3>(q.m[g], k, l3, h3);
+            const float h1 = qmlane(lc, J5{}, q, g), h2 = qmlane(lc, J6{}, q, g), l3 = qmlane(lc, J3{}, q, g);
             qState[g] = __builtin_bit_cast(int, h1); qActive[g] = __builtin_bit_cast(int, h2); qEnergy[g] = l3;
-            (void) l1; (void) l2; (void) h3;
         }
         {
             const int t = (MODE == 3) ? 8 + (s & 3) : g * 8 + s;
@@ -927,6 +945,7 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
             }
         }   // slot group
     };   // back_x
+    auto back_x = [&](auto gc, auto mc, const unsigned p, const PtIn<NSG> &q, const Hit &T) { back_xT(LM0{}, gc, mc, p, q, T); };
     auto back_g = [&](auto gc, const unsigned p, const PtIn<NSG> &q, const TapsG &T) { back_x(gc, M0{}, p, q, interp(T)); };
 
     auto back_end = [&](const unsigned p, const PtIn<NSG> &q) {
@@ -1114,7 +1133,8 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
         // (qa = qb, qb = qc: 16 vector moves per point of an issue-bound loop; LDS instructions have their own issue port)
         constexpr bool STASH = DESC && NSG == 1 && !HAS_L && !FIX && LD_STASH;
         int par = 0;
-        float *const myRec = sRec + wave * 1024 + lane * 4;          // [parity][half][lane][4 dwords]
+        float *const wRec = sRec + wave * 1024;                      // [parity][half][lane][4 dwords]
+        float *const myRec = wRec + lane * 4;
         auto stash = [&](const int pr_, const PtIn<NSG> &q) {
             v4f_t a_, b_;
             a_.x = q.rgeo; a_.y = q.rrec; a_.z = q.color; a_.w = q.wgt;
@@ -1124,6 +1144,7 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
         auto unstash = [&](const int pr_) {
             const v4f_t a_ = *(const v4f_t *) (myRec + pr_ * 512), b_ = *(const v4f_t *) (myRec + pr_ * 512 + 256);
             PtIn<NSG> q = {};
+            q.ls = wRec + pr_ * 512;
             q.rgeo = a_.x; q.rrec = a_.y; q.color = a_.z; q.wgt = a_.w;
             // (scalars first: __builtin_bit_cast on an ELEMENT of an ext-vector returns element 0 whatever the index - the trap of round 4, met again in round 6 the other
             // way round: every residual's is-linearised flag read back as its index, every residual skipped, energies 0)
@@ -1179,15 +1200,16 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
                     // (pinned: the sample is plain arithmetic, which the compiler sinks to its first use - behind the next point's tap loads, with the old taps alive across
                     // them in a second register set and 14 moves per point)
                     asm volatile("" : "+v"(ha.h0), "+v"(ha.h1), "+v"(ha.h2), "+v"(ha.Ku), "+v"(ha.Kv));
-                    if constexpr (STASH) stash(par ^ 1, qb);
-                    if (n1) sb = pstep(p1, qb);          // (the fused point step stores: only for a real next point)
-                    front_g(G0{}, qb, sb, ta);
+                    using LMS = std::bool_constant<STASH && LD_STASH_LM>;
+                    if constexpr (STASH) { stash(par ^ 1, qb); qb.ls = wRec + (par ^ 1) * 512; }
+                    if (n1) sb = pstepT(LMS{}, p1, qb);          // (the fused point step stores: only for a real next point)
+                    front_gT(LMS{}, G0{}, qb, sb, ta);
                     LCYC(1);          // point step + projection + tap issue of the next point
                     load_point<NSG, HAS_L, FIX, DESC>(qc, B, cur, FS, p2, s, k, lane);
                     LCYC(2);          // record loads issued
                     if constexpr (STASH) qa = unstash(par);
-                    back_begin(p, qa, sa);
-                    back_x(G0{}, M0{}, p, qa, ha);
+                    back_beginT(LMS{}, p, qa, sa);
+                    back_xT(LMS{}, G0{}, M0{}, p, qa, ha);
                     back_end(p, qa);
                     LCYC(3);          // everything behind the taps of this point
 #if LD_STAMP_ON
