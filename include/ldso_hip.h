@@ -358,6 +358,13 @@ int ldso_tr_track_batch(ldso_tracker_t *t, int nhyp, double *T_ref2new_inout, fl
  * best_out = index of the winning try or -1; tries_consumed_out = how many tries the sequential loop would have run. */
 /* calcRes evaluations per pyramid level of the last track (hypothesis 0 of a batch) and the reference point counts pc_n[lvl] */
 int ldso_tr_last_track_evals(ldso_tracker_t *t, int evals[5], int pc_n[5]);
+/* LM solves of the last track call (all hypotheses) whose 8 x 8 system was rank-deficient to float precision (a pivot below 1e-6 of the diagonal entry it started from: fewer than
+ * eight reference points on a level) and were solved by the reference's diagonally pivoted LDL^T (Eigen's `Hl.ldlt().solve(-b)`, CoarseTracker.cc:120-128) instead of the unpivoted register
+ * factorisation; 0 on any normal track. */
+int ldso_tr_last_track_pivoted_solves(ldso_tracker_t *t, int *n);
+/* Debug / test entry: the 8 x 8 LM solve of the tracking kernel on its own - H with diag_scale (= 1 + lambda) on the diagonal, x = -b (`Hl.ldlt().solve(-b)`,
+ * CoarseTracker.cc:120-128); *pivoted = 1 when the system went through the pivoted factorisation.  Runs on the current device, synchronous. */
+int ldso_tr_debug_solve8(const double H[64], const double b[8], double diag_scale, double x[8], int *pivoted);
 int ldso_tr_select_hypothesis(int nhyp, int coarsestLvl, const double *lastResiduals /*nhyp*5*/, const int *ok /*nhyp*/, double lastCoarseRMSE0,
                               double reTrackThreshold, int *best_out, int *tries_consumed_out, double achievedRes_out[5]);
 /* The motion-hypothesis list of FullSystem::trackNewCoarse (FullSystem.cc:189-309): worldToCam poses [R|t] (Frame::getPose()) of

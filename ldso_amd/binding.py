@@ -601,6 +601,12 @@ class Tracker:
         r = self.track_batch([T], [(a, b)], coarsest, min_res)
         return {k: (v[0] if isinstance(v, (list, np.ndarray)) else v) for k, v in r.items()}
 
+    def last_track_pivoted_solves(self):
+        """LM solves of the last track call that fell back to the pivoted LDL^T (ill-conditioned 8 x 8 system)"""
+        n = C.c_int(0)
+        _chk(self.L.ldso_tr_last_track_pivoted_solves(self.h, C.byref(n)))
+        return int(n.value)
+
     def last_track_evals(self):
         """(evals[5], pc_n[5]) of the last track: calcRes evaluations and reference points per pyramid level"""
         ev = np.zeros(5, np.int32); pc = np.zeros(5, np.int32)

@@ -56,7 +56,7 @@ struct TrHyp {                 // one motion hypothesis in / result out
     double lastResiduals[5];
     double flow[3];
     int ok, iterations;
-    int evals[5], pad_;         // calcRes evaluations per pyramid level (algorithmic bytes of a track = sum evals[l] * pc_n[l] * 64 B)
+    int evals[5], pivotedSolves;          // calcRes evaluations per pyramid level (algorithmic bytes of a track = sum evals[l] * pc_n[l] * 64 B); LM solves that fell back to the pivoted factorisation
     double dbg[12];             // LDSO_STAMPS builds: time in tr_eval / serial LM sections / evals count
 };
 
@@ -468,8 +468,13 @@ __device__ __forceinline__ double tr_rcp(double d) {
     r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
     return r;
 }
-__device__ __forceinline__ void ldlt8_lane(const double *H /*LDS 64, row major*/, const double *rhs /*LDS 8*/, double rhsSign, double diagScale, double *x /*8 registers*/) {
+// Returns false when a pivot has lost six digits against the diagonal entry it started from (|d_k| < 1e-6 |H_kk|: column k is, to float precision, a combination of the
+// columns in front of it - a rank-deficient system: fewer than eight reference points on a level; the entries of H are float sums, so "zero" pivots come out at ~1e-7):
+// Eigen's diagonal pivoting defers such a pivot to the end, where the unpivoted elimination inverts it early - the caller then runs the pivoted factorisation
+// (tr_solve_pivoted8, the reference's algorithm) instead.
+__device__ __forceinline__ bool ldlt8_lane(const double *H /*LDS 64, row major*/, const double *rhs /*LDS 8*/, double rhsSign, double diagScale, double *x /*8 registers*/) {
     double A[8][8], y[8], inv[8];
+    bool wellConditioned = true;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
 #pragma unroll
@@ -481,6 +486,7 @@ __device__ __forceinline__ void ldlt8_lane(const double *H /*LDS 64, row major*/
 #pragma unroll
     for (int k = 0; k < 8; k++) {
         const double d = A[k][k];
+        wellConditioned = wellConditioned && (fabs(d) >= 1e-6 * fabs(H[k * 8 + k] * diagScale));          // (the entry it started from: re-read, not kept in a register)
         const bool valid = fabs(d) > 2.2250738585072014e-308;
         inv[k] = valid ? tr_rcp(d) : 0.0;
         const double sc = valid ? inv[k] : 1.0;
@@ -501,6 +507,7 @@ __device__ __forceinline__ void ldlt8_lane(const double *H /*LDS 64, row major*/
     for (int c = 7; c >= 1; c--)
 #pragma unroll
         for (int r = 0; r < c; r++) x[r] = __builtin_fma(-A[c][r], x[c], x[r]);
+    return wellConditioned;
 }
 
 __device__ __forceinline__ void tr_vec6(const double *acc, double *rs) {
@@ -511,6 +518,16 @@ __device__ __forceinline__ void tr_vec6(const double *acc, double *rs) {
     rs[3] = 0;
     rs[4] = (double) ((float) a3 / ((float) a4 + 0.1f));
     rs[5] = (double) ((float) (int) a5 / (float) (int) a1);
+}
+
+// The 8 x 8 LM system by the reference's own algorithm (Eigen's diagonally pivoted LDL^T, CoarseTracker.cc:120-128): the fallback of ldlt8_lane for ill-conditioned
+// systems.  Rare, single thread, out of line (its arrays live in scratch memory).
+__device__ __attribute__((noinline)) void tr_solve_pivoted8(const double *sH, const double *sB, double rhsSign, double diagScale, double *sInc) {
+    double Hl[64], nb[8], xs[8];
+    for (int i = 0; i < 64; i++) Hl[i] = sH[i];
+    for (int i = 0; i < 8; i++) { Hl[i * 8 + i] *= diagScale; nb[i] = rhsSign * sB[i]; }
+    small_ldlt_solve(Hl, nb, xs, 8);
+    for (int i = 0; i < 8; i++) sInc[i] = xs[i];
 }
 
 // The step when an affine parameter is fixed (setting_affineOptModeA/B < 0; CoarseTracker.cc:129-166): rare, single thread, kept out
@@ -718,7 +735,12 @@ __global__ __launch_bounds__(TR_NT) void k_tr_track(const TrParams *__restrict__
             tQ = wall_clock64();
 #endif
             // lane 0 alone: the solve (right-hand side -b, ldlt8_lane), then the step from the increment it has just stored
-            if (tid == 0) { double xs[8]; ldlt8_lane(sH, sB, -1.0, (double) (1 + sLambda), xs); for (int i = 0; i < 8; i++) sInc[i] = xs[i]; }
+            if (tid == 0) {
+                double xs[8];
+                const bool wellConditioned = ldlt8_lane(sH, sB, -1.0, (double) (1 + sLambda), xs);
+                for (int i = 0; i < 8; i++) sInc[i] = xs[i];
+                if (!wellConditioned) { tr_solve_pivoted8(sH, sB, -1.0, (double) (1 + sLambda), sInc); hy.pivotedSolves++; }
+            }
 #if LD_STAMP_ON_TR
             tS1 += wall_clock64() - tQ; tQ = wall_clock64();
 #endif
@@ -866,6 +888,7 @@ struct ldso_tracker {
     double lastAcc[TR_NACC];
     bool haveAcc = false;
     int lastEvals[5] = {0, 0, 0, 0, 0};      // of hypothesis 0 of the last track call
+    int lastPivotedSolves = 0;               // LM solves of the last track call (all hypotheses) that fell back to the pivoted factorisation (ldlt8_lane)
 };
 
 template <class T> static int tr_alloc(ldso_tracker *H, T **p, size_t n) {
@@ -1203,7 +1226,8 @@ int ldso_tr_track_batch(ldso_tracker_t *H, int nhyp, double *T_inout /*nhyp*12*/
         if (flow) memcpy(flow + i * 3, hy[i].flow, 24);
         if (ok) ok[i] = hy[i].ok;
         if (iterations) iterations[i] = hy[i].iterations;
-        if (i == 0) memcpy(H->lastEvals, hy[i].evals, sizeof(H->lastEvals));
+        if (i == 0) { memcpy(H->lastEvals, hy[i].evals, sizeof(H->lastEvals)); H->lastPivotedSolves = 0; }
+        H->lastPivotedSolves += hy[i].pivotedSolves;
 #if LD_STAMP_ON_TR
         if (i == 0) { long long ph[5][8]; hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_trPh), sizeof(ph)); long long z[5][8] = {}; hipMemcpyToSymbol(HIP_SYMBOL(g_trPh), z, sizeof(z));
             for (int l = 0; l < 5; l++) if (ph[l][7]) fprintf(stderr, "[tr phases] lvl %d: setup %.2f pass %.2f dpp %.2f barrier %.2f sum %.2f us per eval (%d evals)\n", l, ph[l][0] / 100.0 / ph[l][7], ph[l][1] / 100.0 / ph[l][7], ph[l][2] / 100.0 / ph[l][7], ph[l][3] / 100.0 / ph[l][7], ph[l][4] / 100.0 / ph[l][7], (int) ph[l][7]); }
@@ -1334,6 +1358,44 @@ int ldso_tr_track_new_coarse(ldso_tracker_t *H, const double sprelast[12], const
 int ldso_tr_last_track_evals(ldso_tracker_t *H, int evals[5], int pc_n[5]) {
     REQ(H && evals && pc_n, "null argument");
     for (int l = 0; l < 5; l++) { evals[l] = H->lastEvals[l]; pc_n[l] = (l < H->levels) ? H->P.lv[l].n : 0; }
+    return LDSO_OK;
+}
+
+// LM solves of the last ldso_tr_track / ldso_tr_track_batch call whose 8 x 8 system was rank-deficient to float precision (a pivot below 1e-6 of the diagonal entry it started from) and went
+// through the reference's pivoted LDL^T instead of the unpivoted register version (0 on any normal track)
+int ldso_tr_last_track_pivoted_solves(ldso_tracker_t *H, int *n) {
+    REQ(H && n, "null argument");
+    *n = H->lastPivotedSolves;
+    return LDSO_OK;
+}
+
+// The LM solve of k_tr_track on its own (debug / test entry): H (1 + lambda on the diagonal = diag_scale) x = -b by one lane, exactly the code path of the kernel -
+// the unpivoted register factorisation and, when it reports a rank-deficient system, the pivoted one.
+__global__ void k_tr_solve8(const double *H, const double *b, double diagScale, double *x, int *pivoted) {
+    __shared__ double sH[64], sB[8], sInc[8];
+    if (threadIdx.x < 64) sH[threadIdx.x] = H[threadIdx.x];
+    if (threadIdx.x < 8) sB[threadIdx.x] = b[threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double xs[8];
+        const bool wellConditioned = ldlt8_lane(sH, sB, -1.0, diagScale, xs);
+        for (int i = 0; i < 8; i++) sInc[i] = xs[i];
+        if (!wellConditioned) tr_solve_pivoted8(sH, sB, -1.0, diagScale, sInc);
+        *pivoted = wellConditioned ? 0 : 1;
+        for (int i = 0; i < 8; i++) x[i] = sInc[i];
+    }
+}
+int ldso_tr_debug_solve8(const double H[64], const double b[8], double diag_scale, double x[8], int *pivoted) {
+    REQ(H && b && x && pivoted, "ldso_tr_debug_solve8: null argument");
+    double *d = nullptr;
+    CHK(hipMalloc((void **) &d, (64 + 8 + 8 + 1) * sizeof(double)));
+    CHK(hipMemcpy(d, H, 64 * sizeof(double), hipMemcpyHostToDevice));
+    CHK(hipMemcpy(d + 64, b, 8 * sizeof(double), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_tr_solve8, dim3(1), dim3(64), 0, 0, d, d + 64, diag_scale, d + 72, (int *) (d + 80));
+    CHK(hipGetLastError());
+    CHK(hipMemcpy(x, d + 72, 8 * sizeof(double), hipMemcpyDeviceToHost));
+    CHK(hipMemcpy(pivoted, d + 80, sizeof(int), hipMemcpyDeviceToHost));
+    CHK(hipFree(d));
     return LDSO_OK;
 }
 

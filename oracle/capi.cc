@@ -395,6 +395,15 @@ double orc_time_optimize(void *h, int niters) {
     return std::chrono::duration<double>(t1 - t0).count();
 }
 
+// Eigen::LDLT<Mat88>::solve as the tracker uses it (`Hl.ldlt().solve(-b)`, CoarseTracker.cc:120-128): the checker of the device tracker's 8 x 8 solve
+// (tests/test_tracker_gpu.py: ldso_tr_debug_solve8).  A row-major 8 x 8, b, x: 8.
+void orc_ldlt_solve8(const double *A, const double *b, double *x) {
+    Mat<double, 8, 8> M; Mat<double, 8, 1> v;
+    for (int i = 0; i < 8; i++) { v[i] = b[i]; for (int j = 0; j < 8; j++) M(i, j) = A[i * 8 + j]; }
+    const Mat<double, 8, 1> r = ldlt_solve<8>(M, v);
+    for (int i = 0; i < 8; i++) x[i] = r[i];
+}
+
 }  // extern "C"
 
 #include "tracker_capi.inc"

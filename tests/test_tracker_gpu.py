@@ -98,6 +98,63 @@ def test_track_matches_oracle(name, levels):
     assert err < 0.25 * np.linalg.norm(synth.se3_log(sc["T_true"]))
 
 
+def _solve8_device(H, b, diag_scale):
+    import ctypes as C
+    L = binding.lib()
+    H = np.ascontiguousarray(H, np.float64); b = np.ascontiguousarray(b, np.float64); x = np.zeros(8); piv = C.c_int(-1)
+    rc = L.ldso_tr_debug_solve8(H.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), C.c_double(diag_scale), x.ctypes.data_as(C.c_void_p), C.byref(piv))
+    assert rc == 0, L.ldso_last_error()
+    return x, piv.value
+
+
+def _solve8_oracle(H, b, diag_scale):
+    import ctypes as C
+    L = po.lib()
+    A = np.ascontiguousarray(H, np.float64).copy(); A[np.diag_indices(8)] *= diag_scale
+    nb = np.ascontiguousarray(-np.asarray(b, np.float64)); x = np.zeros(8)
+    L.orc_ldlt_solve8(A.ctypes.data_as(C.c_void_p), nb.ctypes.data_as(C.c_void_p), x.ctypes.data_as(C.c_void_p))
+    return x
+
+
+def test_lm_solve_unpivoted_in_registers_and_pivoted_when_rank_deficient():
+    """the 8 x 8 LM solve of the tracking kernel is an unpivoted LDL^T in one lane's registers, the reference runs Eigen's diagonally pivoted one
+    (`Hl.ldlt().solve(-b)`, CoarseTracker.cc:120-128).  The device solve watches its pivots: one that lost six digits against the diagonal entry it started from sends
+    the system through the pivoted factorisation (the reference's algorithm).  Against the oracle's restatement of Eigen's LDLT: (i) well-conditioned SPD systems of the
+    tracker's scaling (columns scaled 1 / 0.5 / 10 / 1000): the register path, solution 1e-10; (ii) rank 5 with a damping that no longer regularises it
+    (lambda = 1e-9): the pivoted path, the oracle's solution.  In a track the multiplicative damping (lambda >= 1e-3 after a rejected step) keeps even a one-point
+    reference (five entries per level) on the register path - (iii): such a track follows the oracle's, iteration by iteration."""
+    rng = np.random.default_rng(11)
+    sc = np.array([1.0, 1.0, 1.0, 0.5, 0.5, 0.5, 10.0, 1000.0])
+    for rep in range(20):
+        J = rng.normal(size=(200, 8)) * sc
+        H, b = J.T @ J / 200, J.T @ rng.normal(size=200) / 200
+        lam = float(10.0 ** rng.uniform(-4, 0))
+        x, piv = _solve8_device(H, b, 1 + lam)
+        xo = _solve8_oracle(H, b, 1 + lam)
+        assert piv == 0 and np.abs(x - xo).max() <= 1e-10 * np.abs(xo).max(), (rep, piv)
+    for rep in range(10):
+        J = rng.normal(size=(5, 8)) * sc                      # five residuals: rank 5
+        H, b = J.T @ J / 5, J.T @ rng.normal(size=5) / 5
+        x, piv = _solve8_device(H, b, 1 + 1e-9)
+        xo = _solve8_oracle(H, b, 1 + 1e-9)
+        assert piv == 1, rep
+        # the same factorisation in the same precision; the directions the data do not determine are divided by pivots of ~1e-9: compare what the system determines
+        r, ro_ = (H * (1 + 1e-9 * np.eye(8))) @ x + b, (H * (1 + 1e-9 * np.eye(8))) @ xo + b
+        assert np.abs(r).max() <= 1e-6 * np.abs(b).max() and np.abs(ro_).max() <= 1e-6 * np.abs(b).max(), (rep, np.abs(r).max(), np.abs(ro_).max())
+        assert np.abs(x - xo).max() <= 1e-3 * np.abs(xo).max(), rep
+    scn = tracker_scenario("small")
+    a, b_ = scn["new_aff"]
+    pts = np.array(scn["pts"], np.float32)
+    for n in (2, 1):
+        o, g = make_pair(dict(scn, pts=pts[np.linspace(0, len(pts) - 1, n).astype(int)]))
+        ro = o.track(np.eye(4), a, b_, scn["levels"] - 1); rg = g.track(np.eye(4), a, b_, scn["levels"] - 1)
+        assert g.last_track_pivoted_solves() == 0
+        assert bool(rg["ok"]) == bool(ro["ok"]) and rg["iterations"] == ro["iterations"], n
+        To, Tg = np.eye(4), np.eye(4)
+        To[:3, :4] = ro["T"]; Tg[:3, :4] = rg["T"]
+        assert np.linalg.norm(synth.se3_log(Tg @ np.linalg.inv(To))) < 1e-3 * np.linalg.norm(synth.se3_log(To)) + 1e-5, n
+
+
 def test_track_batch_equals_single():
     sc = tracker_scenario("small")
     o, g = make_pair(sc)
