@@ -1128,10 +1128,12 @@ static __device__ __forceinline__ void linearize_body(const BaPtrs &B, const BaD
         using G0 = std::integral_constant<int, 0>;
         using G1 = std::integral_constant<int, NSG - 1>;
         constexpr bool PIPE = DESC || (NSG == 1 && LD_PIPE_ARGS);
-        // One slot group per point, descriptor-based kernels (round 6, second half): the records of the point in work are parked in the wavefront's own LDS by the
+        // One slot group per point, the batched kernel (round 6, second half): the records of the point in work are parked in the wavefront's own LDS by the
         // iteration in front (two ds_write_b128) and read back where the back half starts (two ds_read_b128) instead of being rotated through a third register set
         // (qa = qb, qb = qc: 16 vector moves per point of an issue-bound loop; LDS instructions have their own issue port)
-        constexpr bool STASH = DESC && NSG == 1 && !HAS_L && !FIX && LD_STASH;
+        // (the batched kernel only: in k_linearize_one a wavefront has one to three points - nothing to amortise the LDS round trips and the peeled copy of the loop
+        // body against; measured at C4, 12 points per chunk: 16.36 us with the stash, 15.85 without, profiles/r06_linearize_peel_stash_ab.log)
+        constexpr bool STASH = DESC && !ONE && NSG == 1 && !HAS_L && !FIX && LD_STASH;
         int par = 0;
         float *const wRec = sRec + wave * 1024;                      // [parity][half][lane][4 dwords]
         float *const myRec = wRec + lane * 4;
