@@ -1380,9 +1380,9 @@ __global__ __launch_bounds__(64 * LD_WAVES) void k_linearize_one(OneArgs a) {
 // ---------------------------------------------------------------------------------------------------------
 // launcher
 // ---------------------------------------------------------------------------------------------------------
-size_t ba_linearize_lds_bytes(int FS, bool hasL) {
+size_t ba_linearize_lds_bytes(int FS, bool hasL, bool stash = false) {
     size_t fl = (size_t) FS * (sizeof(DevPair) / 4) + 2 * (size_t) FS * 64 + (size_t) LD_WAVES * FS * LD_TOPN + (hasL ? (size_t) LD_WAVES * FS * LD_TOPN : 0) + (size_t) FS * 8 + LD_TAIL_FLOATS + 2 * (size_t) FS;
-    return fl * sizeof(float) + 256 + (FS == 8 ? (size_t) LD_WAVES * 4096 : 0);          // + the record stash of the one-slot-group kernels
+    return fl * sizeof(float) + 256 + ((stash && FS == 8) ? (size_t) LD_WAVES * 4096 : 0);          // + the record stash of the batched one-slot-group kernel
 }
 
 template <int NSG, bool HAS_L, bool FIX, bool MARG = false>
@@ -1439,7 +1439,7 @@ hipError_t ba_launch_linearize_marg(const BaPtrs &B, const BaDims &D, const ResS
 hipError_t ba_launch_linearize_batch(const BatchItem *d_items, const BatchBlock *d_blocks, int totalChunks, const int32_t *d_wgStart, int nWG, int FS, int cur, const ldso_settings_t &S, int stepMode,
                                      float calibPrior, hipStream_t st, int itCheck) {
     if (totalChunks == 0) return hipSuccess;
-    const size_t lds = ba_linearize_lds_bytes(FS, false);
+    const size_t lds = ba_linearize_lds_bytes(FS, false, true);
     const int grid = d_wgStart != nullptr ? nWG : totalChunks;
     if (grid <= 0) return hipSuccess;
     if (FS == 8) {
