@@ -92,6 +92,10 @@ int ldso_ba_set_image_raw(ldso_ba_t *h, int slot, const float *irradiance);
 int ldso_ba_set_image_pyramid(ldso_ba_t *h, int slot, ldso_pyramid_t *pyr);
 int ldso_ba_get_image(ldso_ba_t *h, int slot, float *out_w_h_3);
 
+/* K-splits (workgroups) per 16 x 16 tile of the Schur complement in the GN fast path (the device counterpart of AccumulatedSCHessianSSE's per-thread accumulators,
+ * AccumulatedSCHessian.cc:53-119: each split owns a range of points and adds its fp32 partial tile into the fp64 system).  8 for a lone window (latency), 4 for the
+ * windows of a batch of four or more (throughput; LDSO_BATCH_KS overrides).  Two runs agree bit for bit only under the same number. */
+int ldso_ba_set_reduce_splits(ldso_ba_t *h, int splits);
 /* Describe the window: EnergyFunctional::frames / allPoints / p->residuals after makeIDX
  * (EnergyFunctional.cc:380-401).  image_slot[f] = slot holding frame f's image.  linJ / lin_res_toZeroF
  * (R entries, may be NULL) are read where residuals[i].is_linearized != 0. */
@@ -236,6 +240,7 @@ int ldso_ba_gn_solve_reduced(ldso_ba_t *h, const void *reduce_buf_dev, int itera
  * fetched per handle as usual. */
 typedef struct ldso_ba_batch ldso_ba_batch_t;
 int ldso_ba_batch_create(ldso_ba_t *const *handles, int n, ldso_ba_batch_t **out);
+int ldso_ba_batch_reduce_splits(ldso_ba_batch_t *b, int *splits);          /* K-splits per Schur tile the batch reduces its windows with (ldso_ba_set_reduce_splits) */
 /* The chunking ldso_ba_batch_create applies, as host logic without a device (tests/test_batch_balance_cpu.py): n_seg runs of points that may share a chunk (one window's
  * points of one host frame each, in launch order), n_wg workgroups, a chunk costing chunk_cost points on top of its own -> chunk_end[] (cumulative point counts, ascending,
  * a chunk never spans two segments) and wg_first_chunk[n_wg + 1] (workgroup w works through the chunks [wg_first_chunk[w], wg_first_chunk[w + 1])), chosen so that the

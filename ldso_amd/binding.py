@@ -267,6 +267,10 @@ class BA:
     def set_chunk_points(self, n):
         _chk(self.L.ldso_ba_set_chunk_points(self.h, C.c_int(n)))
 
+    def set_reduce_splits(self, splits):
+        """K-splits per Schur tile of this handle's GN fast path (8; a batch of >= 4 windows uses 4: BABatch.reduce_splits())"""
+        _chk(self.L.ldso_ba_set_reduce_splits(self.h, C.c_int(int(splits))))
+
     def get_chunk_cuts(self):
         """ends of the chunks in force (one past the last point of every chunk)"""
         n = C.c_int()
@@ -478,6 +482,12 @@ class BABatch:
         us = C.c_double()
         _chk(self.L.ldso_ba_batch_time_linearize(self.h, C.c_int(reps), C.byref(us)))
         return us.value
+
+    def reduce_splits(self):
+        """K-splits per Schur tile the batch reduces its windows with (BA.set_reduce_splits gives a lone handle the same arithmetic)"""
+        n = C.c_int(0)
+        _chk(self.L.ldso_ba_batch_reduce_splits(self.h, C.byref(n)))
+        return int(n.value)
 
     def chunk_points(self):
         n = C.c_int()

@@ -91,6 +91,7 @@ struct ldso_ba {
     std::vector<BatchBlock> h_blocks;
     bool appliedValid = false;         // the applied residual set holds a linearisation of the resident window (its per-chunk partials feed the next reduce)
     LinHead linHead;                   // chunk geometry of the current window by value (k_linearize_one)
+    int reduceSplits = LD_SCT_KS;      // K-splits per 16 x 16 Schur tile (BaDims::ks; ldso_ba_set_reduce_splits)
     bool linHeadOk = false;            // the chunks are regular (every host cut into CH-point pieces): true for everything build_chunks produces
     const void *inBatch = nullptr;     // the ldso_ba_batch this handle belongs to (at most one; it must outlive the batch: ldso_ba_destroy refuses while set)
     int chunkPoints = 0;               // points per workgroup of k_linearize: 0 = as few as keep the grid within one wave of workgroups (one window alone on the chip)
@@ -611,7 +612,7 @@ int ldso_ba_set_window(ldso_ba_t *H, int F, const int32_t *image_slot, int P, co
     // a call that fails half way (bad indices, allocation) must not leave the dimensions of the NEW window over the data of the old one:
     // the handle then holds no window (every entry point that needs one says so)
     struct WinGuard { ldso_ba *H; bool ok; ~WinGuard() { if (!ok) { H->D.P = 0; H->D.R = 0; H->R = 0; H->appliedValid = false; H->itemValid = false; } } } guard{H, false};
-    D.F = F; D.FS = (F + 7) / 8 * 8; D.P = P; D.R = R; D.n = 8 * F + 4; D.GS = 8 * D.FS + LD_GEXTRA; D.w = H->w; D.h = H->h; D.nsg = D.FS / 8;
+    D.F = F; D.FS = (F + 7) / 8 * 8; D.P = P; D.R = R; D.n = 8 * F + 4; D.GS = 8 * D.FS + LD_GEXTRA; D.w = H->w; D.h = H->h; D.nsg = D.FS / 8; D.ks = H->reduceSplits;
     D.pBegin = 0; D.pEnd = P; D.wM3G = (float) (H->w - 3); D.hM3G = (float) (H->h - 3);
     H->GSP = (D.GS + 15) / 16 * 16;
     H->R = R;
@@ -856,7 +857,7 @@ int ldso_ba_update_window(ldso_ba_t *H, int F, const int32_t *image_slot, const 
     // from here on the handle describes the new window (a failure leaves it without one, as in ldso_ba_set_window)
     struct WinGuard { ldso_ba *H; bool ok; ~WinGuard() { if (!ok) { H->D.P = 0; H->D.R = 0; H->R = 0; H->appliedValid = false; H->itemValid = false; } } } guard{H, false};
     BaDims &D = H->D;
-    D.F = F; D.FS = FS; D.P = P; D.R = R; D.n = 8 * F + 4; D.GS = 8 * D.FS + LD_GEXTRA; D.w = H->w; D.h = H->h; D.nsg = D.FS / 8;
+    D.F = F; D.FS = FS; D.P = P; D.R = R; D.n = 8 * F + 4; D.GS = 8 * D.FS + LD_GEXTRA; D.w = H->w; D.h = H->h; D.nsg = D.FS / 8; D.ks = H->reduceSplits;
     D.pBegin = 0; D.pEnd = P; D.wM3G = (float) (H->w - 3); D.hM3G = (float) (H->h - 3); D.nL = 0;
     H->GSP = (D.GS + 15) / 16 * 16;
     H->R = R;
@@ -1029,6 +1030,15 @@ int ldso_ba_set_chunk_points(ldso_ba_t *H, int points_per_workgroup) {
     if (H->D.P > 0) { CHK(hipSetDevice(H->device)); return rechunk(H); }
     return LDSO_OK;
 }
+// K-splits (workgroups) per 16 x 16 tile of the Schur complement in the GN fast path of THIS handle: the fp32 partial sums of a tile are formed per split, so two runs
+// agree bit for bit only under the same number (a batch uses ldso_ba_batch_reduce_splits; default LD_SCT_KS = 8).  Takes effect with the next reduction.
+int ldso_ba_set_reduce_splits(ldso_ba_t *H, int splits) {
+    REQ(H && splits >= 1 && splits <= 16, "ldso_ba_set_reduce_splits: bad arguments");
+    REQ(!H->inBatch, "ldso_ba_set_reduce_splits: the handle is part of a batch");
+    H->reduceSplits = splits; H->D.ks = splits;
+    return LDSO_OK;
+}
+
 int ldso_ba_get_dims(ldso_ba_t *H, int *F, int *P, int *R) {
     REQ(H, "ldso_ba_get_dims: null handle");
     if (F) *F = H->D.F;
@@ -1332,7 +1342,7 @@ static int enqueue_iteration(ldso_ba *H, int iteration, double lambda, int logId
     A.flags = 0; A.iteration = iteration; A.lambda = lambda; A.hasL = H->hasL ? 1 : 0; A.hasPrior = H->hasPrior ? 1 : 0; A.GSP = H->GSP; A.logIdx = logIdx;
     A.reduceOut = nullptr; A.reduceIn = nullptr; A.itCheck = itCheck; A.waitCtr = nullptr; A.waitTarget = 0; A.hostStop = (itCheck >= 0) ? H->d_stop : nullptr; A.lastIt = lastIt;
     const int nT = H->GSP / 16;
-    const int nReduce = H->D.F * H->D.F * (H->hasL ? 2 : 1) + LD_SCT_KS * nT * (nT + 1) / 2 + 1;      // grid of ba_launch_reduce in atomic mode
+    const int nReduce = H->D.F * H->D.F * (H->hasL ? 2 : 1) + H->D.ks * nT * (nT + 1) / 2 + 1;      // grid of ba_launch_reduce in atomic mode
     if (nReduce + 2 <= H->numCU && !H->noFusedLaunch) {
         // k_reduce (fp64 atomics straight into B.acc, no k_gather on this path) and the control step in ONE launch: the control
         // workgroup waits on a device counter for the reduce workgroups (k_reduce_solve, ba_solve.hip).  Only while every workgroup
@@ -1650,6 +1660,7 @@ struct ldso_ba_batch {
     int chunkPoints = 0;               // the chunking ldso_ba_batch_create gave its windows
     int totalChunks = 0, totalReduce = 0, FS = 0, cur = 0;
     int n0 = 0;                        // windows in the first half (= all of them for batches under 4 windows)
+    int ks = LD_SCT_KS;                // K-splits per Schur tile of the batched reduction (ldso_ba_batch_create: 4 from 4 windows on, LDSO_BATCH_KS)
     int halfChunks[2] = {0, 0}, halfReduce[2] = {0, 0};
     // Balanced launches (round 6): workgroup w of a batched k_linearize works through the blocks [wgStart[w], wgStart[w + 1]) of its launch's table, cut by
     // ldso_ba_batch_create so that every workgroup carries the same load.  wg[0] = the whole batch, wg[1] / wg[2] = the halves; empty: one block per workgroup
@@ -1673,11 +1684,11 @@ static int batch_refresh(ldso_ba_batch *Bt) {
             BatchItem &it = Bt->items[pass * n + i];
             if (pass == 1 && (int) i == Bt->n0) { Bt->halfChunks[0] = lin; Bt->halfReduce[0] = red; lin = 0; red = 0; }
             if (H->B.acc != H->ownAcc) H->B.acc = H->ownAcc;
-            it.B = H->B; it.D = H->D; it.set[0] = H->sets[0]; it.set[1] = H->sets[1]; it.cs = H->chunkStarts;
+            it.B = H->B; it.D = H->D; it.D.ks = Bt->ks; it.set[0] = H->sets[0]; it.set[1] = H->sets[1]; it.cs = H->chunkStarts;
             it.hasPrior = H->hasPrior ? 1 : 0; it.GSP = H->GSP; it.linBlock0 = lin; it.redBlock0 = red;
             const int nT = H->GSP / 16;
             lin += H->D.nChunks;
-            red += H->D.F * H->D.F + LD_SCT_KS * nT * (nT + 1) / 2 + 1;
+            red += H->D.F * H->D.F + Bt->ks * nT * (nT + 1) / 2 + 1;
         }
         if (pass == 0) { Bt->totalChunks = lin; Bt->totalReduce = red; }
         else if (Bt->n0 == (int) n) { Bt->halfChunks[0] = lin; Bt->halfReduce[0] = red; Bt->halfChunks[1] = 0; Bt->halfReduce[1] = 0; }
@@ -1867,6 +1878,10 @@ int ldso_ba_batch_create(ldso_ba_t *const *handles, int n, ldso_ba_batch_t **out
     Bt->h.assign(handles, handles + n);
     Bt->items.resize(2 * (size_t) n);
     Bt->n0 = (n >= 4) ? n / 2 : n;
+    // K-splits per Schur tile of the batched reduction: a lone window spreads every 16 x 16 tile of its Schur complement over LD_SCT_KS = 8 workgroups (latency); the
+    // windows of a batch fill the chip anyway and halve the workgroups and the fp64 atomics (round 6, A/B on one box: 4 -> +3.3 % window-iterations/s at B = 32, 2 -> -11 %)
+    Bt->ks = (n >= 4) ? 4 : LD_SCT_KS;
+    if (const char *e = getenv("LDSO_BATCH_KS")) { const int v = atoi(e); if (v >= 1 && v <= 16) Bt->ks = v; }
     Bt->FS = H0->D.FS;
     Bt->Dmax = H0->D;
     for (int i = 0; i < n; i++) if (handles[i]->D.F > Bt->Dmax.F) Bt->Dmax = handles[i]->D;
@@ -1886,6 +1901,13 @@ int ldso_ba_batch_create(ldso_ba_t *const *handles, int n, ldso_ba_batch_t **out
 }
 
 // points per workgroup ldso_ba_batch_create chose for the windows of this batch (0: it left their single-window chunking alone)
+// K-splits per Schur tile the batch reduces its windows with (see ldso_ba_set_reduce_splits)
+int ldso_ba_batch_reduce_splits(ldso_ba_batch_t *Bt, int *splits) {
+    REQ(Bt && splits, "ldso_ba_batch_reduce_splits: bad arguments");
+    *splits = Bt->ks;
+    return LDSO_OK;
+}
+
 int ldso_ba_batch_chunk_points(ldso_ba_batch_t *Bt, int *points_per_workgroup) {
     REQ(Bt && points_per_workgroup, "ldso_ba_batch_chunk_points: null argument");
     *points_per_workgroup = Bt->chunkPoints;

@@ -119,6 +119,7 @@ struct BaDims {
     int32_t F, FS, P, R, n, GS, w, h, nChunks, nL, nsg;
     int32_t pBegin, pEnd;      // shard of points owned by this rank
     float wM3G, hM3G;
+    int32_t ks;                // K-splits (workgroups) per 16 x 16 Schur tile of the reduction (LD_SCT_KS for a lone window: latency; fewer for the windows of a batch: throughput)
 };
 
 struct BaPtrs {

@@ -156,7 +156,7 @@ hipError_t ba_launch_gather(const BaPtrs &B, const BaDims &D, const ResSet &S, b
 hipError_t ba_launch_reduce(const BaPtrs &B, const BaDims &D, const ResSet &S, const ChunkStarts &chunkStart, bool hasL, int GSP, int atomicMode, bool hasPrior,
                             float calibPrior, double l1, double il, int itCheck, hipStream_t st) {
     const int nT = GSP / 16;
-    int nb = D.F * D.F * (hasL ? 2 : 1) + (atomicMode ? SCT_KS * nT * (nT + 1) / 2 + 1 : LD_SC_SPLITS);
+    int nb = D.F * D.F * (hasL ? 2 : 1) + (atomicMode ? D.ks * nT * (nT + 1) / 2 + 1 : LD_SC_SPLITS);
     size_t lds = atomicMode ? (size_t) (2 * SCT_SLAB * 16 + SCT_SLAB) * sizeof(float) : (size_t) (SC_SLAB * GSP) * sizeof(float);
     if (lds > 48 * 1024) hipFuncSetAttribute((const void *) k_reduce, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
     hipLaunchKernelGGL(k_reduce, dim3(nb), dim3(256), lds, st, B, D, S, chunkStart, hasL ? 1 : 0, GSP, atomicMode, hasPrior ? 1 : 0, calibPrior, l1, il, itCheck);

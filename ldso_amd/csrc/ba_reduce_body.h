@@ -129,19 +129,20 @@ static __device__ __forceinline__ void reduce_body(const BaPtrs &B, const BaDims
     }
 
     const int nSplitBase = nPairBlocks;
-    if (atomicMode && bid < nSplitBase + SCT_KS * (GSP / 16) * (GSP / 16 + 1) / 2) {
+    const int KS = D.ks;          // K-splits per Schur tile: a field of the window's dimensions since round 6 (a batch runs its windows with fewer)
+    if (atomicMode && bid < nSplitBase + KS * (GSP / 16) * (GSP / 16 + 1) / 2) {
         // ------------------------------- Part B, atomic mode: one block per (16x16 tile, K-split) ---------------------
         // The block stages the two 16-column blocks of its G rows (and the weights HdiF) in LDS with 16-byte loads, its four
         // waves interleave the k-steps of v_mfma_f32_16x16x4_f32, the four partial tiles are summed through LDS and each
-        // thread adds ONE element (scaled by -1/(1+lambda)) into HFinal / bFinal: SCT_KS-way contention per address.
+        // thread adds ONE element (scaled by -1/(1+lambda)) into HFinal / bFinal: KS-way contention per address.
         extern __shared__ __attribute__((aligned(16))) float sT_[];
         float *sAc = sT_, *sBc = sAc + SCT_SLAB * 16, *sWc = sBc + SCT_SLAB * 16;      // [SLAB][16], [SLAB][16], [SLAB]
-        const int bb = bid - nSplitBase, tile = bb / SCT_KS, ks = bb % SCT_KS;
+        const int bb = bid - nSplitBase, tile = bb / KS, ks = bb % KS;
         const int nT = GSP / 16, GS = D.GS, n = D.n;
         int ti = 0, rem = tile;
         while (rem >= nT - ti) { rem -= nT - ti; ti++; }
         const int tj = ti + rem;
-        const int P0 = D.pBegin, Pn = D.pEnd - D.pBegin, per = ((Pn + SCT_KS - 1) / SCT_KS + 3) & ~3;
+        const int P0 = D.pBegin, Pn = D.pEnd - D.pBegin, per = ((Pn + KS - 1) / KS + 3) & ~3;
         const int pa = P0 + ks * per, pb = min(P0 + Pn, pa + per);
         const int wave = tid >> 6, lane = tid & 63, li = lane & 15, lk = lane >> 4;
         const int wcol = 8 * FS + 5;

@@ -1347,7 +1347,7 @@ __global__ __launch_bounds__(NT) void k_reduce_solve(BaPtrs B, BaDims D, ResSet 
         if (LD_ITER_SKIPPED(B, A.itCheck)) return;
         // dispatch order = index order: the Schur tile workgroups (the longest) get the lowest indices, then the pair workgroups,
         // the extras workgroup last; reduce_body numbers them pairs | tiles | extras
-        const int nT_ = A.GSP / 16, nTiles = SCT_KS * nT_ * (nT_ + 1) / 2, nPair = D.F * D.F * (A.hasL ? 2 : 1);
+        const int nT_ = A.GSP / 16, nTiles = D.ks * nT_ * (nT_ + 1) / 2, nPair = D.F * D.F * (A.hasL ? 2 : 1);
         const int q = (int) blockIdx.x - 2;
         const int bid = (q < nTiles) ? nPair + q : (q < nTiles + nPair) ? q - nTiles : q;
         reduce_body(B, D, S, chunkStart, A.hasL, A.GSP, atomicMode, A.hasPrior, calibPrior, l1, il, -1, bid);
@@ -1587,7 +1587,7 @@ hipError_t ba_launch_gn_solve(const BaPtrs &B, const BaDims &D, const ResSet &S,
 hipError_t ba_launch_reduce_solve(const BaPtrs &B, const BaDims &D, const ResSet &S, const ldso_settings_t &St, const SolveArgs &A, const ChunkStarts &chunkStart,
                                   int atomicMode, float calibPrior, double l1, double il, hipStream_t st) {
     const int nT = A.GSP / 16;
-    const int nReduce = D.F * D.F * (A.hasL ? 2 : 1) + SCT_KS * nT * (nT + 1) / 2 + 1;
+    const int nReduce = D.F * D.F * (A.hasL ? 2 : 1) + D.ks * nT * (nT + 1) / 2 + 1;
     size_t mirror = (size_t) D.F * sizeof(DevFrame) + sizeof(DevCalib) + (D.F <= 8 ? (size_t) D.F * D.F * 2 * LD_AD_LDS_PITCH * sizeof(float) : 0), stats = 64 * sizeof(double) + (256 + 8) * sizeof(int) + TH_CAP * sizeof(float);
     size_t lds0 = solve_lds_common(D) + 64 * sizeof(double) + mirror + 64;
     size_t lds = lds0 > stats + 64 ? lds0 : stats + 64;

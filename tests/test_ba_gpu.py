@@ -526,7 +526,7 @@ def test_large_batch_is_rechunked_and_equals_solo_runs_under_the_same_chunking()
     assert len(set(len(c) for c in cuts)) > 1 or len(set(tuple(c) for c in cuts)) > 1, "windows at different places of the launch are cut differently"
     b.enqueue_gn(0, 4); b.sync(); torch.cuda.synchronize()
     for i in (0, 5, 11):
-        g = binding.BA.from_window(wins[i], stream=st); g.set_chunk_cuts(cuts[i])
+        g = binding.BA.from_window(wins[i], stream=st); g.set_chunk_cuts(cuts[i]); g.set_reduce_splits(b.reduce_splits())
         assert np.array_equal(g.get_chunk_cuts(), cuts[i])
         g.collect_active(); g.linearize_all(False); g.apply_res()
         g.set_debug_split_launch(True); g.enqueue_gn(0, 4); g.sync(); torch.cuda.synchronize()
@@ -565,10 +565,11 @@ def test_batched_windows_equal_individual_runs():
             g = binding.BA.from_window(w, stream=st)
             g.collect_active(); g.linearize_all(False); g.apply_res()
             lst.append(g)
+    b = binding.BABatch(batch)
     for g in solo:
         g.set_debug_split_launch(True)
+        g.set_reduce_splits(b.reduce_splits())          # the fp32 partial tiles of the Schur complement are formed per K-split: a batch of >= 4 windows uses 4, a lone window 8
         g.enqueue_gn(0, 5)
-    b = binding.BABatch(batch)
     b.enqueue_gn(0, 3); b.enqueue_gn(3, 2)
     b.sync(); torch.cuda.synchronize()
     for w, gs, gb in zip(wins, solo, batch):
