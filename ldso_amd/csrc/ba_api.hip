@@ -403,6 +403,7 @@ static int create_body(ldso_ba *H, int device, int w, int h, int max_frames, int
     CHK(hipHostGetDevicePointer((void **) &H->d_stop, H->h_stop, 0));
     memset(&H->B, 0, sizeof(H->B));
     memset(&H->D, 0, sizeof(H->D));
+    if (const char *e = getenv("LDSO_REDUCE_KS")) { const int v = atoi(e); if (v >= 1 && v <= 16) H->reduceSplits = v; }          // tuning knob: ldso_ba_set_reduce_splits for every handle of the process
     BaPtrs &B = H->B;
     const size_t F = max_frames, P = max_points, FS = H->FSmax, nmax = 8 * F + 4;
     DA(B.frames, F); DA(B.calib, 1); DA(B.pairs, F * F); DA(B.pairRt, F * F * 12);
